@@ -1,0 +1,115 @@
+"""Synthetic DTU-shaped inputs for the MVSNet cost-volume path.
+
+There is no DTU data (and no network) in either container, so every parity
+test, golden fixture and bench line is driven by the deterministic recipe in
+SURVEY.md section 8(d): DTU-like intrinsics, cameras on an arc looking at a
+point 680 mm in front of the reference view, and the DTU depth sweep
+425 mm + k * 2.5 mm * 1.06.
+
+The projection matrices follow the reference loader's contract
+(MVSNet/datasets/dtu_yao_eval.py:93-95): a 4x4 matrix whose top 3x4 block is
+K_feat @ [R | t] (intrinsics already at feature resolution) and whose last row
+is (0, 0, 0, 1).
+
+Only numpy is needed here; torch tensors are made by the callers.
+"""
+import math
+
+import numpy as np
+
+# DTU full-resolution intrinsics (1600x1200 images), SURVEY.md 8(d).
+DTU_FX, DTU_FY, DTU_CX, DTU_CY = 2892.33, 2883.18, 823.205, 619.071
+DTU_DEPTH_MIN = 425.0
+DTU_INTERVAL = 2.5 * 1.06  # interval_scale 1.06, MVSNet/eval.sh
+DTU_TARGET_Z = 680.0
+
+_THETA_DEG = (0.0, -8.0, 8.0, -4.0, 4.0, -12.0, 12.0)
+_PHI_DEG = (0.0, 3.0, -3.0, -6.0, 6.0, 2.0, -2.0)
+
+
+def _rot_y(a):
+    c, s = math.cos(a), math.sin(a)
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], dtype=np.float64)
+
+
+def _rot_x(a):
+    c, s = math.cos(a), math.sin(a)
+    return np.array([[1, 0, 0], [0, c, -s], [0, s, c]], dtype=np.float64)
+
+
+def feature_intrinsics(feat_h, feat_w):
+    """DTU intrinsics divided by 4 (dtu_yao_eval.py:54), rescaled so the same
+    field of view covers a feat_h x feat_w feature map (296x400 is native)."""
+    sx, sy = feat_w / 400.0, feat_h / 296.0
+    K = np.array([[DTU_FX / 4 * sx, 0, DTU_CX / 4 * sx],
+                  [0, DTU_FY / 4 * sy, DTU_CY / 4 * sy],
+                  [0, 0, 1]], dtype=np.float64)
+    return K
+
+
+def arc_extrinsics(nviews):
+    """World->camera [R|t] 4x4 for `nviews` cameras on an arc around the
+    target point (0, 0, 680); view 0 is the reference (identity)."""
+    assert 1 <= nviews <= len(_THETA_DEG)
+    target = np.array([0.0, 0.0, DTU_TARGET_Z])
+    out = []
+    for i in range(nviews):
+        R = _rot_y(math.radians(_THETA_DEG[i])) @ _rot_x(math.radians(_PHI_DEG[i]))
+        C = target - R.T @ np.array([0.0, 0.0, DTU_TARGET_Z])
+        t = -R @ C
+        E = np.eye(4)
+        E[:3, :3] = R
+        E[:3, 3] = t
+        out.append(E)
+    return np.stack(out)
+
+
+def proj_matrices(nviews, feat_h, feat_w, batch=1):
+    """[B, V, 4, 4] float32 projection matrices in the reference loader's
+    convention (top 3x4 = K @ E[:3,:4])."""
+    K = feature_intrinsics(feat_h, feat_w)
+    E = arc_extrinsics(nviews)
+    P = E.copy()
+    for i in range(nviews):
+        P[i, :3, :4] = K @ E[i, :3, :4]
+    P = P.astype(np.float32)
+    return np.broadcast_to(P, (batch,) + P.shape).copy()
+
+
+def cas_proj_matrices(nviews, feat_h, feat_w, batch=1):
+    """[B, V, 2, 4, 4] CasMVSNet convention: [.,.,0] extrinsic, [.,.,1,:3,:3]
+    intrinsic (CasMVSNet/datasets/general_eval.py:158-180)."""
+    K = feature_intrinsics(feat_h, feat_w)
+    E = arc_extrinsics(nviews)
+    P = np.zeros((nviews, 2, 4, 4), dtype=np.float32)
+    for i in range(nviews):
+        P[i, 0] = E[i]
+        P[i, 1, :3, :3] = K
+    return np.broadcast_to(P, (batch,) + P.shape).copy()
+
+
+def depth_values(ndepth, batch=1, interval=DTU_INTERVAL, depth_min=DTU_DEPTH_MIN):
+    """[B, D] float32 plane-sweep hypotheses (dtu_yao_eval.py:99-100).
+    To keep the full DTU depth range at small D, callers widen `interval`."""
+    dv = (depth_min + interval * np.arange(ndepth, dtype=np.float64)).astype(np.float32)
+    return np.broadcast_to(dv, (batch, ndepth)).copy()
+
+
+def sweep_interval(ndepth):
+    """Interval that spans the DTU range (192 planes of 2.65 mm) with `ndepth`
+    planes, as the reference's eval script does when numdepth is reduced."""
+    return DTU_INTERVAL * 192.0 / ndepth
+
+
+def smooth_features(rng, shape, scale=1.0):
+    """Band-limited random feature maps [..., H, W]: white noise blurred by a
+    small separable box filter so bilinear sampling sees realistic gradients."""
+    x = rng.standard_normal(shape).astype(np.float32)
+    for ax in (-1, -2):
+        x = (np.roll(x, 1, ax) + x + np.roll(x, -1, ax)) / 3.0
+    return (x * scale).astype(np.float32)
+
+
+def images(rng, batch, nviews, h, w):
+    """[B, V, 3, H, W] uniform[0,1) float32 (the loader divides by 255)."""
+    return rng.random((batch, nviews, 3, h, w), dtype=np.float32)

@@ -1,0 +1,192 @@
+"""PyTorch (ATen, CPU) restatement of the reference MVSNet forward.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  This is the `cpu_baseline`
+that bench.py times on the GPU box's host cores (kind "port": the reference's
+Python cannot travel there) and a second, ATen-level checker beside the plain-C
+oracle.  It is a functional re-expression -- weights come in as a state_dict
+with the reference's key names -- of:
+
+  FeatureNet            MVSNet/models/mvsnet.py:8-45
+  homo_warping          MVSNet/models/module.py:46-87
+  variance aggregation  MVSNet/models/mvsnet.py:152-170
+  CostRegNet            MVSNet/models/mvsnet.py:48-93
+  softmax/regression    MVSNet/models/mvsnet.py:183-185, module.py:91-103
+  photometric conf.     MVSNet/models/mvsnet.py:187-191
+
+Parity status: PINNED -- tests/test_oracle_golden.py checks every stage against
+golden vectors captured from the imported reference.
+"""
+import torch
+import torch.nn.functional as F
+
+EPS = 1e-5
+
+
+def _bn_eval(x, sd, p):
+    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"],
+                        sd[p + ".bias"], False, 0.0, EPS)
+
+
+def _bn_train(x, sd, p):
+    return F.batch_norm(x, None, None, sd[p + ".weight"], sd[p + ".bias"], True, 0.0, EPS)
+
+
+def feature_net(img, sd, prefix="feature.", train=False):
+    """[B,3,H,W] -> [B,32,H/4,W/4]  (mvsnet.py:8-45)"""
+    bn = _bn_train if train else _bn_eval
+    spec = (("conv0", 1, 1), ("conv1", 1, 1), ("conv2", 2, 2), ("conv3", 1, 1), ("conv4", 1, 1),
+            ("conv5", 2, 2), ("conv6", 1, 1))
+    x = img
+    for name, stride, pad in spec:
+        x = F.conv2d(x, sd[f"{prefix}{name}.conv.weight"], None, stride, pad)
+        x = F.relu(bn(x, sd, f"{prefix}{name}.bn"))
+    return F.conv2d(x, sd[prefix + "feature.weight"], sd[prefix + "feature.bias"], 1, 1)
+
+
+def sweep_grid(src_proj, ref_proj, depth, H, W):
+    """Normalised sampling grid [B, D, H*W, 2] (module.py:62-81).
+    depth: [B,D] or [B,D,H,W]."""
+    B, D = depth.shape[0], depth.shape[1]
+    dev = depth.device
+    M = src_proj @ torch.inverse(ref_proj)
+    R, t = M[:, :3, :3], M[:, :3, 3:4]
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32, device=dev),
+                            torch.arange(W, dtype=torch.float32, device=dev), indexing="ij")
+    pix = torch.stack((xs.reshape(-1), ys.reshape(-1), torch.ones(H * W, device=dev)))
+    ray = R @ pix.unsqueeze(0).expand(B, 3, H * W)
+    pts = ray.unsqueeze(2) * depth.reshape(B, 1, D, -1) + t.reshape(B, 3, 1, 1)
+    uv = pts[:, :2] / pts[:, 2:3]
+    gx = uv[:, 0] / ((W - 1) / 2) - 1
+    gy = uv[:, 1] / ((H - 1) / 2) - 1
+    return torch.stack((gx, gy), dim=3)
+
+
+def warp(src_fea, src_proj, ref_proj, depth, align_corners=False):
+    """[B,C,H,W] -> [B,C,D,H,W]  (module.py:46-87)"""
+    B, C, H, W = src_fea.shape
+    D = depth.shape[1]
+    with torch.no_grad():
+        grid = sweep_grid(src_proj, ref_proj, depth, H, W)
+    out = F.grid_sample(src_fea, grid.reshape(B, D * H, W, 2), mode="bilinear",
+                        padding_mode="zeros", align_corners=align_corners)
+    return out.reshape(B, C, D, H, W)
+
+
+def variance_volume(features, projs, depth, align_corners=False, alias_quirk=False):
+    """features: list of V [B,C,H,W]; projs: list of V [B,4,4] -> [B,C,D,H,W]
+    (mvsnet.py:152-170; alias_quirk: CVP modules.py:228-229)."""
+    V = len(features)
+    D = depth.shape[1]
+    ref = features[0].unsqueeze(2).expand(-1, -1, D, -1, -1)
+    q = ref * ref
+    s = q.clone() if alias_quirk else ref.clone()
+    for fea, proj in zip(features[1:], projs[1:]):
+        w = warp(fea, proj, projs[0], depth, align_corners)
+        s = s + w
+        q = q + w * w
+    return q / V - (s / V) ** 2
+
+
+def cost_reg_net(x, sd, prefix="cost_regularization.", train=False):
+    """[B,32,D,H,W] -> [B,1,D,H,W]  (mvsnet.py:48-93)"""
+    bn = _bn_train if train else _bn_eval
+
+    def conv(name, t, stride):
+        t = F.conv3d(t, sd[f"{prefix}{name}.conv.weight"], None, stride, 1)
+        return F.relu(bn(t, sd, f"{prefix}{name}.bn"))
+
+    def up(name, t):
+        t = F.conv_transpose3d(t, sd[f"{prefix}{name}.0.weight"], None, 2, 1, 1)
+        return F.relu(bn(t, sd, f"{prefix}{name}.1"))
+
+    c0 = conv("conv0", x, 1)
+    c2 = conv("conv2", conv("conv1", c0, 2), 1)
+    c4 = conv("conv4", conv("conv3", c2, 2), 1)
+    t = conv("conv6", conv("conv5", c4, 2), 1)
+    t = c4 + up("conv7", t)
+    t = c2 + up("conv9", t)
+    t = c0 + up("conv11", t)
+    return F.conv3d(t, sd[prefix + "prob.weight"], sd[prefix + "prob.bias"], 1, 1)
+
+
+def regress(cost, depth, clamp_idx=False):
+    """cost [B,D,H,W] -> (depth [B,H,W], confidence [B,H,W], prob [B,D,H,W])
+    (mvsnet.py:183-191)."""
+    B, D = cost.shape[:2]
+    prob = F.softmax(cost, dim=1)
+    dv = depth.reshape(B, D, 1, 1) if depth.dim() == 2 else depth
+    est = (prob * dv).sum(1)
+    with torch.no_grad():
+        padded = F.pad(prob.unsqueeze(1), (0, 0, 0, 0, 1, 2))
+        s4 = 4 * F.avg_pool3d(padded, (4, 1, 1), stride=1, padding=0).squeeze(1)
+        ramp = torch.arange(D, dtype=torch.float32, device=cost.device).reshape(1, D, 1, 1)
+        idx = (prob * ramp).sum(1).long()
+        if clamp_idx:
+            idx = idx.clamp(0, D - 1)
+        conf = torch.gather(s4, 1, idx.unsqueeze(1)).squeeze(1)
+    return est, conf, prob
+
+
+def mvsnet_forward(imgs, projs, depth, sd, train=False, stages=None):
+    """imgs [B,V,3,H,W], projs [B,V,4,4], depth [B,D] -> dict like
+    MVSNet.forward(refine=False) (mvsnet.py:136-195).  `stages`, if a dict,
+    receives per-stage wall-clock seconds."""
+    import time
+    t0 = time.perf_counter()
+    V = imgs.shape[1]
+    feats = [feature_net(imgs[:, v], sd, train=train) for v in range(V)]
+    t1 = time.perf_counter()
+    var = variance_volume(feats, [projs[:, v] for v in range(V)], depth)
+    t2 = time.perf_counter()
+    cost = cost_reg_net(var, sd, train=train).squeeze(1)
+    t3 = time.perf_counter()
+    est, conf, _ = regress(cost, depth)
+    t4 = time.perf_counter()
+    if stages is not None:
+        stages.update(feature=t1 - t0, costvol=t2 - t1, costreg=t3 - t2, regress=t4 - t3)
+    return {"depth": est, "photometric_confidence": conf}
+
+
+def masked_smooth_l1(est, gt, mask):
+    """mvsnet.py:201-203"""
+    m = mask > 0.5
+    return F.smooth_l1_loss(est[m], gt[m], reduction="mean")
+
+
+def random_state_dict(seed=0, peaked=30.0):
+    """Seeded MVSNet(refine=False) weights with the reference's key names and
+    PyTorch's default initialisers; BatchNorm running statistics and affine
+    parameters are randomised and the `prob` layer scaled by `peaked` so the
+    softmax over depth is not flat ("No real data")."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def conv_w(key, shape, fan_in, bias=False, nb=0):
+        bound = (1.0 / fan_in) ** 0.5  # kaiming_uniform(a=sqrt(5)) bound
+        sd[key + ".weight"] = (torch.rand(shape, generator=g) * 2 - 1) * bound
+        if bias:
+            sd[key + ".bias"] = (torch.rand(nb, generator=g) * 2 - 1) * bound
+
+    def bn(key, c):
+        sd[key + ".weight"] = 0.5 + torch.rand(c, generator=g)
+        sd[key + ".bias"] = 0.2 * torch.randn(c, generator=g)
+        sd[key + ".running_mean"] = 0.1 * torch.randn(c, generator=g)
+        sd[key + ".running_var"] = 0.5 + torch.rand(c, generator=g)
+        sd[key + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+
+    for name, ci, co, k in (("conv0", 3, 8, 3), ("conv1", 8, 8, 3), ("conv2", 8, 16, 5),
+                            ("conv3", 16, 16, 3), ("conv4", 16, 16, 3), ("conv5", 16, 32, 5),
+                            ("conv6", 32, 32, 3)):
+        conv_w(f"feature.{name}.conv", (co, ci, k, k), ci * k * k)
+        bn(f"feature.{name}.bn", co)
+    conv_w("feature.feature", (32, 32, 3, 3), 32 * 9, True, 32)
+    for name, ci, co in (("conv0", 32, 8), ("conv1", 8, 16), ("conv2", 16, 16), ("conv3", 16, 32),
+                         ("conv4", 32, 32), ("conv5", 32, 64), ("conv6", 64, 64)):
+        conv_w(f"cost_regularization.{name}.conv", (co, ci, 3, 3, 3), ci * 27)
+        bn(f"cost_regularization.{name}.bn", co)
+    for name, ci, co in (("conv7", 64, 32), ("conv9", 32, 16), ("conv11", 16, 8)):
+        conv_w(f"cost_regularization.{name}.0", (ci, co, 3, 3, 3), co * 27)
+        bn(f"cost_regularization.{name}.1", co)
+    conv_w("cost_regularization.prob", (1, 8, 3, 3, 3), 8 * 27, True, 1)
+    sd["cost_regularization.prob.weight"] *= peaked
+    return sd

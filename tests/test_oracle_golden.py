@@ -1,0 +1,156 @@
+"""Pins the CPU oracles (oracle/mvs_oracle.c and oracle/torch_ref.py) against
+golden vectors captured from the imported reference (tests/golden/make_golden.py).
+CPU only.  The warp / variance restatements are bit-exact; convolution and
+softmax sums differ from ATen/MKL-DNN only in summation order."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rot_trans_torch
+from oracle import c_oracle as co
+from oracle import torch_ref as tr
+
+
+def _rts(proj):
+    return np.stack([rot_trans_torch(proj, v) for v in range(1, proj.shape[1])])
+
+
+@pytest.mark.parametrize("v", [1, 2])
+def test_warp_bit_exact(v):
+    g = load_golden("g1_warp")
+    out = co.warp(g["src"], rot_trans_torch(g["proj"], v), g["depth"])
+    ref = g[f"warped_v{v}"]
+    assert (ref == 0).mean() > 0.05, "fixture must exercise zero padding"
+    np.testing.assert_array_equal(out, ref)
+
+
+def test_warp_identity_known_answer():
+    g = load_golden("g2_identity")
+    out = co.warp(g["src"], rot_trans_torch(g["proj"], 0), g["depth"])
+    np.testing.assert_allclose(out, g["warped"], atol=1e-6, rtol=0)
+    # independent closed form: identical projections => ix = x*W/(W-1) - 0.5
+    src = g["src"].astype(np.float64)
+    B, C, H, W = src.shape
+    x = np.arange(W) * W / (W - 1) - 0.5
+    y = np.arange(H) * H / (H - 1) - 0.5
+    x0, y0 = np.floor(x).astype(int), np.floor(y).astype(int)
+
+    def tap(yy, xx):
+        ok = ((yy >= 0) & (yy < H))[:, None] & ((xx >= 0) & (xx < W))[None, :]
+        return np.where(ok, src[:, :, np.clip(yy, 0, H - 1)][:, :, :, np.clip(xx, 0, W - 1)], 0)
+
+    fx, fy = (x - x0)[None, :], (y - y0)[:, None]
+    want = (tap(y0, x0) * (1 - fx) * (1 - fy) + tap(y0, x0 + 1) * fx * (1 - fy) +
+            tap(y0 + 1, x0) * (1 - fx) * fy + tap(y0 + 1, x0 + 1) * fx * fy)
+    np.testing.assert_allclose(out[:, :, 0], want, atol=2e-5)
+
+
+def test_warp_per_pixel_depth_cas():
+    g = load_golden("g8_cas_perpixel")
+    out = co.warp(g["src"], rot_trans_torch(g["proj"], 1), g["depth"])
+    np.testing.assert_array_equal(out, g["warped"])
+    prob = torch.softmax(torch.from_numpy(g["cost"]), 1).numpy()
+    dep, _ = co.softmax_regress_conf(g["cost"], g["depth"], clamp_idx=True)
+    np.testing.assert_allclose(dep, g["regressed"], atol=2e-4)
+    assert prob.shape == g["cost"].shape
+
+
+@pytest.mark.parametrize("name", ["g6_e2e_64x96_v3_d8", "g3_e2e_64x64_v2_d8",
+                                  "g3_e2e_64x64_v5_d8_b2"])
+def test_variance_bit_exact(name):
+    g = load_golden(name)
+    f = g["features"]
+    V = f.shape[1]
+    var = co.costvol_variance(f[:, 0], np.stack([f[:, v] for v in range(1, V)]),
+                              _rts(g["proj"]), g["depth_values"])
+    np.testing.assert_array_equal(var, g["variance"])
+
+
+def test_variance_cvp_alias_quirk():
+    g = load_golden("g8_cvp_alias")
+    f = g["feats"]
+    var = co.costvol_variance(f[0], f[1:], _rts(g["proj"]), g["depth"], alias_quirk=True)
+    np.testing.assert_array_equal(var, g["variance"])
+    plain = co.costvol_variance(f[0], f[1:], _rts(g["proj"]), g["depth"], alias_quirk=False)
+    assert np.abs(plain - var).max() > 1e-3
+
+
+def test_variance_backward():
+    g = load_golden("g7_variance_grad")
+    f = g["feats"]
+    gr, gs = co.costvol_variance_bwd(g["grad_out"], f[0], f[1:], _rts(g["proj"]), g["depth"])
+    np.testing.assert_allclose(gr, g["grad_feats"][0], atol=2e-6)
+    np.testing.assert_allclose(gs, g["grad_feats"][1:], atol=2e-6)
+
+
+def test_costregnet_layers_and_whole(weights):
+    g = load_golden("g6_e2e_64x96_v3_d8")
+    pre = "cost_regularization."
+    s, b = co.bn_fold(*(weights[f"{pre}conv0.bn.{k}"] for k in
+                        ("weight", "bias", "running_mean", "running_var")))
+    c0 = co.conv3d(g["variance"], weights[pre + "conv0.conv.weight"], s, b, None, True, 1)
+    np.testing.assert_allclose(c0, g["act_conv0"], atol=1e-5)
+    s, b = co.bn_fold(*(weights[f"{pre}conv1.bn.{k}"] for k in
+                        ("weight", "bias", "running_mean", "running_var")))
+    c1 = co.conv3d(g["act_conv0"], weights[pre + "conv1.conv.weight"], s, b, None, True, 2)
+    np.testing.assert_allclose(c1, g["act_conv1"], atol=1e-5)
+    s, b = co.bn_fold(*(weights[f"{pre}conv7.1.{k}"] for k in
+                        ("weight", "bias", "running_mean", "running_var")))
+    c7 = co.deconv3d(g["act_conv6"], weights[pre + "conv7.0.weight"], s, b, None, True, 2)
+    np.testing.assert_allclose(c7, g["act_conv7"], atol=1e-5)
+    cost = co.costregnet(g["variance"], weights)
+    np.testing.assert_allclose(cost, g["cost"], atol=3e-5)
+
+
+@pytest.mark.parametrize("name", ["g5_regress_d8", "g5_regress_d192"])
+def test_regress_confidence_edges(name):
+    g = load_golden(name)
+    dep, conf = co.softmax_regress_conf(g["cost"], g["depth_values"])
+    np.testing.assert_allclose(dep, g["depth"], atol=5e-4)
+    np.testing.assert_allclose(conf, g["confidence"], atol=1e-6)
+    d2, c2, _ = tr.regress(torch.from_numpy(g["cost"]), torch.from_numpy(g["depth_values"]))
+    np.testing.assert_array_equal(d2.numpy(), g["depth"])
+    np.testing.assert_array_equal(c2.numpy(), g["confidence"])
+
+
+@pytest.mark.parametrize("name", ["g6_e2e_64x96_v3_d8", "g6_e2e_128x160_v3_d16",
+                                  "g3_e2e_64x64_v5_d8_b2"])
+def test_torch_restatement_end_to_end(name, weights):
+    g = load_golden(name)
+    sd = {k: torch.from_numpy(v) for k, v in weights.items()}
+    out = tr.mvsnet_forward(torch.from_numpy(g["imgs"]), torch.from_numpy(g["proj"]),
+                            torch.from_numpy(g["depth_values"]), sd)
+    np.testing.assert_allclose(out["depth"].numpy(), g["depth"], atol=1e-4)
+    np.testing.assert_allclose(out["photometric_confidence"].numpy(), g["confidence"], atol=1e-6)
+    spread = g["depth"].max() - g["depth"].min()
+    assert spread > 50, "weights must give a non-trivial depth map"
+
+
+def test_c_oracle_end_to_end(weights):
+    g = load_golden("g6_e2e_64x96_v3_d8")
+    f = g["features"]
+    var = co.costvol_variance(f[:, 0], np.stack([f[:, v] for v in (1, 2)]), _rts(g["proj"]),
+                              g["depth_values"])
+    cost = co.costregnet(var, weights)
+    dep, conf = co.softmax_regress_conf(cost[:, 0], g["depth_values"])
+    np.testing.assert_allclose(dep, g["depth"], atol=1e-3)
+    np.testing.assert_allclose(conf, g["confidence"], atol=1e-4)
+
+
+def test_train_step_restatement(weights):
+    g = load_golden("g7_train_step")
+    sd = {k: torch.from_numpy(v).clone().requires_grad_(v.dtype == np.float32 and
+                                                        "running" not in k)
+          for k, v in weights.items()}
+    out = tr.mvsnet_forward(torch.from_numpy(g["imgs"]), torch.from_numpy(g["proj"]),
+                            torch.from_numpy(g["depth_values"]), sd, train=True)
+    loss = tr.masked_smooth_l1(out["depth"], torch.from_numpy(g["gt"]), torch.from_numpy(g["mask"]))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-5)
+    assert co.masked_smooth_l1(g["depth"], g["gt"], g["mask"]) == pytest.approx(float(g["loss"]),
+                                                                                rel=1e-5)
+    for k in g:
+        if k.startswith("grad__"):
+            ref = g[k]
+            got = sd[k[6:]].grad.numpy()
+            np.testing.assert_allclose(got, ref, atol=1e-4 * max(1.0, np.abs(ref).max()))
