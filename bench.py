@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""MVSNet depth-map throughput on MI355X (BASELINE.json's metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full MVSNet.forward (FeatureNet -> fused warp+variance ->
+CostRegNet -> softmax/expectation/confidence) for one reference view of
+BASELINE.json configs[1]: DTU 1600x1184, N=5 views, D=192, fp32, inputs already
+resident in HBM.  With N ranks each GPU processes its own reference views
+(weak scaling, no data-path collective: reference views are independent,
+SURVEY.md 8e).  Rank 0 prints ONE JSON line.
+
+Besides the contract fields the line carries
+  roofline     -- the dominant kernel of the step, timed with HIP events on the
+                  launch stream inside the timed region, against its roofline;
+  cpu_baseline -- the ATen CPU restatement of the reference forward
+                  (oracle/torch_ref.py, kind "port") timed on this box's host
+                  cores on ONE reference view of the same workload;
+  stages_ms / rooflines -- per-kernel breakdown from a separate instrumented
+                  pass (not part of the timed region).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+from mvs_amd import ops, synth  # noqa: E402
+from mvs_amd.models import MVSNet  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
+FP32_MFMA_PEAK_TF = 157.3    # v_mfma_f32_16x16x4_f32 / 32x32x2, dense fp32
+
+
+def algorithmic_work(V, C, D, h, w):
+    """SURVEY.md 8(d) / BASELINE.md 3: algorithmic bytes (HBM-bound kernels) and
+    flops (MFMA-bound kernels) per reference view at feature resolution h x w."""
+    n0 = D * h * w
+    work = {
+        "costvol_variance": ("hbm", (V * C * h * w + D + C * n0) * 4.0),
+        "softmax_regress_conf": ("hbm", (n0 + 2 * h * w) * 4.0),
+    }
+    chans = {"conv0": (32, 8, 1, 0), "conv1": (8, 16, 2, 0), "conv2": (16, 16, 1, 1),
+             "conv3": (16, 32, 2, 1), "conv4": (32, 32, 1, 2), "conv5": (32, 64, 2, 2),
+             "conv6": (64, 64, 1, 3)}
+    for name, (ci, co, s, lvl) in chans.items():
+        n_in = n0 / (8 ** lvl)
+        n_out = n_in / (8 if s == 2 else 1)
+        work["costreg." + name] = ("mfma", 2.0 * 27 * ci * co * n_out)
+    for name, (ci, co, lvl_in) in {"conv7": (64, 32, 3), "conv9": (32, 16, 2),
+                                   "conv11": (16, 8, 1)}.items():
+        work["costreg." + name] = ("mfma", 2.0 * 27 * ci * co * n0 / (8 ** lvl_in))
+    work["costreg.prob"] = ("mfma", 2.0 * 27 * 8 * 1 * n0)
+    return work
+
+
+def roofline_entry(name, kind, amount, ms):
+    if kind == "hbm":
+        ach = amount / (ms * 1e-3) / 1e9
+        return {"kernel": name, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes": amount, "ms": round(ms, 4)}
+    ach = amount / (ms * 1e-3) / 1e12
+    return {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TF,
+            "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": None,
+            "algorithmic_flops": amount, "ms": round(ms, 4)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--height", type=int, default=1184)
+    ap.add_argument("--width", type=int, default=1600)
+    ap.add_argument("--views", type=int, default=5)
+    ap.add_argument("--ndepth", type=int, default=192)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--conv-impl", choices=["auto", "direct", "mfma"], default="auto")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with "
+                  "torch.distributed.run --nproc-per-node N", file=sys.stderr)
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)   # RCCL over xGMI
+
+    H, W, V, D = args.height, args.width, args.views, args.ndepth
+    h, w = H // 4, W // 4
+    # --- synthetic DTU-shaped workload; each rank = its own ref views
+    rng = np.random.default_rng(rank)
+    imgs = torch.from_numpy(synth.images(rng, 1, V, H, W)).to(dev)
+    proj = torch.from_numpy(synth.proj_matrices(V, h, w)).to(dev)
+    dvals = torch.from_numpy(synth.depth_values(D)).to(dev)
+    sd = synth.random_state_dict(seed=0)
+    model = MVSNet(refine=False)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    model.cost_regularization.conv_impl = {"auto": ops.IMPL_AUTO, "direct": ops.IMPL_DIRECT,
+                                           "mfma": ops.IMPL_MFMA}[args.conv_impl]
+
+    def step():
+        with torch.no_grad():
+            return model(imgs, proj, dvals)
+
+    # --- warmup (also: one fully instrumented pass to find the dominant kernel)
+    for _ in range(max(args.warmup - 1, 0)):
+        step()
+    torch.cuda.synchronize()
+    full = ops.StageTimer()
+    ops.set_timer(full)
+    for _ in range(3 if args.warmup > 0 else 1):
+        step()
+    torch.cuda.synchronize()
+    ops.set_timer(None)
+    stages = {k: v[1] for k, v in full.summary_ms().items()}
+    work = algorithmic_work(V, 32, D, h, w)
+    dominant = max((k for k in stages if k in work), key=lambda k: stages[k])
+
+    # --- timed region: EXACTLY K steps, barrier + synchronize on both sides;
+    # only the dominant kernel carries HIP events (2 per step)
+    live = ops.StageTimer(only={dominant})
+    ops.set_timer(live)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ops.set_timer(None)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out["depth"]).all()
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.steps / elapsed
+    kind, amount = work[dominant]
+    roof = roofline_entry(dominant, kind, amount, live.summary_ms()[dominant][1])
+    rooflines = [roofline_entry(k, work[k][0], work[k][1], stages[k]) for k in stages if k in work]
+    line = {
+        "metric": "depth-maps/sec", "value": round(value, 4), "unit": "depth-maps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "ms_per_ref_view": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"MVSNet DTU {W}x{H}, N={V} views, D={D} inference (BASELINE "
+                               "configs[1]); 1 reference view per step per GPU",
+                   "feature_res": [h, w], "sharding": f"ref-views x{world}, no collective",
+                   "conv_impl": args.conv_impl, "proj_inverse": model.proj_where},
+        "roofline": roof,
+        "stages_ms": {k: round(v, 4) for k, v in sorted(stages.items())},
+        "rooflines": rooflines,
+    }
+
+    # --- CPU baseline beside it: rank 0, N=1 only, ONE ref view of the same workload
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import torch_ref   # the checker, timed here as the reported CPU baseline
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        sd_cpu = {k: v.clone() for k, v in sd.items()}
+        st = {}
+        with torch.no_grad():
+            c0 = time.perf_counter()
+            ref_out = torch_ref.mvsnet_forward(imgs.cpu(), proj.cpu(), dvals.cpu(), sd_cpu, stages=st)
+            cpu_s = time.perf_counter() - c0
+        err = float((out["depth"].cpu() - ref_out["depth"]).abs().max())
+        line["cpu_baseline"] = {
+            "value": round(1.0 / cpu_s, 5), "unit": "depth-maps/s", "cores": torch.get_num_threads(),
+            "kind": "port", "seconds": round(cpu_s, 2),
+            "sample": "1 reference view of the same workload (one full forward, no warm-up), "
+                      "ATen CPU restatement of the reference forward (oracle/torch_ref.py)",
+            "stages_s": {k: round(v, 3) for k, v in st.items()},
+            "max_abs_depth_diff_vs_gpu_mm": err,
+        }
+    print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,130 @@
+/*
+ * mvs_hip.h -- C ABI of libmvs_hip.so: the MI355X (gfx950) implementation of
+ * the MVSNet cost-volume hot path.
+ *
+ * The reference (doubleZ0108/MVS) has no FFI layer: its boundary for this path
+ * is the Python model API (MVSNet/models/__init__.py:1, module.py, mvsnet.py).
+ * mvs_amd/models mirrors that API and calls the entry points below through
+ * ctypes on tensor.data_ptr(); INTEGRATION.md shows the binding.  Each entry
+ * point cites the reference lines whose arithmetic it replaces.
+ *
+ * Conventions (all entry points)
+ *   - extern "C", plain pointers and ints; no torch types.
+ *   - every pointer is a DEVICE pointer on the current HIP device, float32,
+ *     contiguous in the stated layout; the library never allocates.
+ *   - asynchronous on `stream` (a hipStream_t passed as void*; NULL = default).
+ *   - returns MVS_OK (0) or a negative MVS_E* code and never throws;
+ *     mvs_last_error_string() describes the last failure on this thread.
+ *   - re-entrant: no global mutable state besides the thread-local error text.
+ *
+ * Layout codes
+ *   MVS_LAYOUT_NCHW (0): [B,C,H,W] / [B,C,D,H,W]   (the reference's layout)
+ *   MVS_LAYOUT_NHWC (1): [B,H,W,C] / [B,D,H,W,C]   (channels-last; what the
+ *                        MFMA convolution kernels consume)
+ * depth_mode
+ *   0: depth_values [B,D]        (MVSNet, module.py:74)
+ *   1: depth_values [B,D,H,W]    (CasMVSNet/models/module.py:249,267;
+ *                                 CVP-MVSNet/models/modules.py:253)
+ */
+#ifndef MVS_HIP_H
+#define MVS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVS_OK 0
+#define MVS_EINVAL (-1)      /* bad argument (null pointer, non-positive size, unsupported shape) */
+#define MVS_EUNSUPPORTED (-2) /* combination not implemented by this build */
+#define MVS_ELAUNCH (-3)     /* HIP launch / runtime error (see error string) */
+#define MVS_EWORKSPACE (-4)  /* workspace too small */
+
+#define MVS_LAYOUT_NCHW 0
+#define MVS_LAYOUT_NHWC 1
+
+/* Library version: major*10000 + minor*100 + patch. */
+int mvs_version(void);
+/* Text of the last error on the calling thread ("" if none). */
+const char *mvs_last_error_string(void);
+/* Name of the compiled GPU architecture ("gfx950"). */
+const char *mvs_arch(void);
+
+/* ---- layout helpers ------------------------------------------------- */
+/* [B,C,S] -> [B,S,C] and back (S = H*W or D*H*W). */
+int mvs_nchw_to_nhwc_f32(const float *in, float *out, int B, int C, int64_t S, void *stream);
+int mvs_nhwc_to_nchw_f32(const float *in, float *out, int B, int C, int64_t S, void *stream);
+
+/* ---- K1: plane-sweep warp -- MVSNet/models/module.py:46-87 ---------- */
+/* src_fea [B,C,H,W]; rot_trans [B,12] = rows of (src_proj @ inverse(ref_proj))[:3,:4]
+ * (module.py:63-65, evaluated by the caller with torch); out [B,C,D,H,W].
+ * align_corners: 0 = what the reference's grid_sample call runs with on
+ * torch >= 1.3 (the parity target), 1 = torch 1.2 / MVSNet_pl behaviour. */
+int mvs_warp_fwd_f32(const float *src_fea, const float *rot_trans, const float *depth_values,
+                     int depth_mode, int B, int C, int D, int H, int W, int align_corners,
+                     float *out, void *stream);
+/* grad_src [B,C,H,W] (overwritten) = d/d src_fea of <grad_out, warp(src)>;
+ * the grid carries no gradient (module.py:62). */
+int mvs_warp_bwd_f32(const float *grad_out, const float *rot_trans, const float *depth_values,
+                     int depth_mode, int B, int C, int D, int H, int W, int align_corners,
+                     float *grad_src, void *stream);
+
+/* ---- K1+K2: fused warp + variance -- mvsnet.py:152-170 -------------- */
+/* ref_fea [B,C,H,W]|[B,H,W,C]; src_feas [V-1,B,...] same layout; rot_trans
+ * [V-1,B,12]; out_var [B,C,D,H,W] | [B,D,H,W,C].  Per-view warped volumes are
+ * never materialised.  alias_quirk=1 reproduces CVP-MVSNet/models/modules.py:
+ * 228-229 (S0 = Q0 = ref^2).  C must be a multiple of 4 and <= 64. */
+int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *src_feas,
+                                 const float *rot_trans, const float *depth_values,
+                                 int depth_mode, int B, int V, int C, int D, int H, int W,
+                                 int align_corners, int alias_quirk, int fea_layout,
+                                 int out_layout, float *out_var, void *stream);
+/* grad_var in out_layout; grad_ref / grad_srcs in fea_layout, overwritten. */
+int mvs_costvol_variance_bwd_f32(const float *grad_var, const float *ref_fea,
+                                 const float *src_feas, const float *rot_trans,
+                                 const float *depth_values, int depth_mode, int B, int V, int C,
+                                 int D, int H, int W, int align_corners, int fea_layout,
+                                 int out_layout, float *grad_ref, float *grad_srcs, void *stream);
+
+/* ---- K3: CostRegNet layers -- mvsnet.py:48-93, module.py:26-33 ------ */
+/* One 3x3x3 convolution (pad 1, stride 1|2, no bias) or transposed
+ * convolution (stride 2, pad 1, output_padding 1 -> exactly 2x; stride 1 for
+ * CVP net.py:66-69), followed by y = acc*scale[co] + shift[co] (eval-mode
+ * BatchNorm3d folded to an affine; NULL = identity / conv bias in `shift`),
+ * optional ReLU, optional residual add AFTER the ReLU (mvsnet.py:89-91).
+ * weight: PyTorch layout -- conv (Cout,Cin,3,3,3), transposed (Cin,Cout,3,3,3).
+ * in [B,Cin,D,H,W]|[B,D,H,W,Cin]; out/residual in the same layout family with
+ * Cout channels at the output resolution.
+ * impl: 0 = auto, 1 = direct (VALU) kernel, 2 = MFMA implicit-GEMM kernel
+ * (channels-last only).  `packed_weight` (from mvs_conv3d_pack_weights_f32) is
+ * required by impl 2 and ignored by impl 1; with impl 0 it is used if given. */
+int mvs_conv3d_f32(const float *in, const float *weight, const float *packed_weight,
+                   const float *scale, const float *shift, const float *residual, int relu,
+                   int transposed, int B, int Cin, int Cout, int D, int H, int W, int stride,
+                   int layout, int impl, float *out, void *stream);
+/* Number of floats mvs_conv3d_pack_weights_f32 writes for this layer. */
+int64_t mvs_conv3d_packed_weight_floats(int transposed, int Cin, int Cout, int stride);
+/* Re-order a PyTorch-layout weight tensor into MFMA A-fragment order. */
+int mvs_conv3d_pack_weights_f32(const float *weight, int transposed, int Cin, int Cout,
+                                int stride, float *packed, void *stream);
+/* 1 if impl 2 (MFMA) supports this layer shape, else 0. */
+int mvs_conv3d_mfma_supported(int transposed, int Cin, int Cout, int stride);
+
+/* ---- K4+K5: softmax + expectation + confidence -- mvsnet.py:183-191 -- */
+/* cost [B,D,H,W]; out_depth, out_conf [B,H,W]; out_prob [B,D,H,W] or NULL.
+ * clamp_idx=1 is CasMVSNet's index clamp (cas_mvsnet.py:63). */
+int mvs_softmax_regress_conf_f32(const float *cost, const float *depth_values, int depth_mode,
+                                 int clamp_idx, int B, int D, int H, int W, float *out_depth,
+                                 float *out_conf, float *out_prob, void *stream);
+/* grad_cost [B,D,H,W] (overwritten) from grad_depth [B,H,W]; confidence
+ * carries no gradient (mvsnet.py:187 no_grad). */
+int mvs_softmax_regress_bwd_f32(const float *cost, const float *depth_values, int depth_mode,
+                                const float *grad_depth, int B, int D, int H, int W,
+                                float *grad_cost, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVS_HIP_H */

@@ -1,0 +1,88 @@
+"""ctypes binding of libmvs_hip.so (the C ABI declared in include/mvs_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or fails to
+load, every op raises.  torch must be imported first so that the HIP runtime
+already in the process (torch's bundled libamdhip64, SONAME libamdhip64.so.7)
+is the one the library binds to -- device pointers and streams are then shared.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads the HIP runtime the library must share)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmvs_hip.so")
+
+MVS_LAYOUT_NCHW = 0
+MVS_LAYOUT_NHWC = 1
+
+_c_f = ctypes.c_void_p   # device pointers travel as integers
+_c_i = ctypes.c_int
+_c_l = ctypes.c_int64
+
+_SIGS = {
+    "mvs_version": (ctypes.c_int, []),
+    "mvs_last_error_string": (ctypes.c_char_p, []),
+    "mvs_arch": (ctypes.c_char_p, []),
+    "mvs_nchw_to_nhwc_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_l, _c_f]),
+    "mvs_nhwc_to_nchw_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_l, _c_f]),
+    "mvs_warp_fwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i] + [_c_i] * 6 + [_c_f, _c_f]),
+    "mvs_warp_bwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i] + [_c_i] * 6 + [_c_f, _c_f]),
+    "mvs_costvol_variance_fwd_f32": (_c_i, [_c_f] * 4 + [_c_i] * 11 + [_c_f, _c_f]),
+    "mvs_costvol_variance_bwd_f32": (_c_i, [_c_f] * 5 + [_c_i] * 10 + [_c_f, _c_f, _c_f]),
+    "mvs_conv3d_f32": (_c_i, [_c_f] * 6 + [_c_i] * 11 + [_c_f, _c_f]),
+    "mvs_conv3d_packed_weight_floats": (_c_l, [_c_i] * 4),
+    "mvs_conv3d_pack_weights_f32": (_c_i, [_c_f] + [_c_i] * 4 + [_c_f, _c_f]),
+    "mvs_conv3d_mfma_supported": (_c_i, [_c_i] * 4),
+    "mvs_softmax_regress_conf_f32": (_c_i, [_c_f, _c_f] + [_c_i] * 6 + [_c_f] * 4),
+    "mvs_softmax_regress_bwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_f] + [_c_i] * 4 + [_c_f, _c_f]),
+}
+
+_lib = None
+
+
+class MvsHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libmvs_hip.so (once).  Raises MvsHipError when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MvsHipError(
+            f"{LIB_PATH} not found: build it with `python -m mvs_amd.build` (hipcc, gfx950). "
+            "mvs_amd has no CPU or PyTorch fallback for the cost-volume path.")
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_LOCAL)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError here = ABI drift, fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().mvs_last_error_string().decode(errors="replace")
+        raise MvsHipError(f"{what} failed (rc={rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous float32 CUDA(HIP) tensor, or None."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MvsHipError("mvs_amd ops need device (HIP) tensors; got a CPU tensor")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise MvsHipError(f"expected contiguous float32, got {t.dtype} contiguous={t.is_contiguous()}")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,71 @@
+"""Build recipe for libmvs_hip.so (hipcc, gfx950 only, in-tree).
+
+    python -m mvs_amd.build            # incremental
+    python -m mvs_amd.build --force
+
+The library is built next to the sources (mvs_amd/csrc/libmvs_hip.so) so it
+travels with the repo snapshot to the GPU box; it is git-ignored.
+"""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "obj")
+LIB = os.path.join(CSRC, "libmvs_hip.so")
+SOURCES = ("capi", "sweep", "regress", "conv3d_direct", "conv3d_mfma")
+HEADERS = (os.path.join(CSRC, "mvs_common.h"),
+           os.path.join(os.path.dirname(HERE), "include", "mvs_hip.h"))
+# -ffp-contract=off: the plane-sweep coordinate arithmetic places its FMAs by
+# hand to match the reference bit for bit; everything else uses fmaf/MFMA.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: libmvs_hip.so cannot be built on this machine")
+    return exe
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    cc = hipcc()
+    jobs = []
+    for name in SOURCES:
+        src = os.path.join(CSRC, name + ".hip")
+        obj = os.path.join(OBJ, name + ".o")
+        if force or _stale(obj, (src,) + HEADERS):
+            jobs.append([cc] + FLAGS + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+        for warn in ex.map(run, jobs):
+            if verbose and warn.strip():
+                print(warn)
+    objs = [os.path.join(OBJ, n + ".o") for n in SOURCES]
+    if force or jobs or _stale(LIB, objs):
+        run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

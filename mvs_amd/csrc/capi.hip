@@ -1,0 +1,140 @@
+// C-ABI glue of libmvs_hip.so: error text, version, layout helpers and the
+// mvs_conv3d_f32 dispatcher (include/mvs_hip.h).
+#include "mvs_common.h"
+
+#include <cstring>
+
+namespace mvs {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int conv3d_direct_launch(const float *, const float *, const float *, const float *, const float *,
+                         int, int, int, int, int, int, int, int, int, int, float *, hipStream_t);
+int conv3d_mfma_launch(const float *, const float *, const float *, const float *, const float *,
+                       int, int, int, int, int, int, int, int, int, float *, hipStream_t);
+int conv3d_pack_launch(const float *, int, int, int, int, float *, hipStream_t);
+int64_t conv3d_packed_floats(int, int, int, int);
+int conv3d_mfma_supported(int, int, int, int);
+
+// [B,C,S] <-> [B,S,C] through a 32x33 LDS tile (both sides coalesced).
+__global__ __launch_bounds__(256) void transpose_cs_kernel(const float *__restrict__ in,
+                                                           float *__restrict__ out, int R,
+                                                           int64_t S) {
+    // in: [B][R][S] -> out: [B][S][R]
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int64_t s0 = (int64_t)blockIdx.x * 32;
+    const int r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const float *ip = in + (int64_t)b * R * S;
+    float *op = out + (int64_t)b * R * S;
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        int r = r0 + ty + k;
+        int64_t s = s0 + tx;
+        tile[ty + k][tx] = (r < R && s < S) ? ip[(int64_t)r * S + s] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        int64_t s = s0 + ty + k;
+        int r = r0 + tx;
+        if (r < R && s < S) op[s * R + r] = tile[tx][ty + k];
+    }
+}
+
+static int launch_transpose(const float *in, float *out, int B, int R, int64_t S, hipStream_t st,
+                            const char *what) {
+    if (!in || !out || B <= 0 || R <= 0 || S <= 0) {
+        set_error("%s: invalid argument", what);
+        return MVS_EINVAL;
+    }
+    // generic: in [B][R][S] -> out [B][S][R]
+    int64_t gx = (S + 31) / 32;
+    int gy = (R + 31) / 32;
+    if (gx > 0x7fffffffLL || gy > 65535 || B > 65535) {
+        set_error("%s: problem too large", what);
+        return MVS_EINVAL;
+    }
+    hipLaunchKernelGGL(transpose_cs_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)B),
+                       dim3(256), 0, st, in, out, R, S);
+    return check_launch(what);
+}
+
+}  // namespace mvs
+
+using namespace mvs;
+
+extern "C" int mvs_version(void) { return 100; /* 0.1.0 */ }
+extern "C" const char *mvs_last_error_string(void) { return g_err; }
+extern "C" const char *mvs_arch(void) { return "gfx950"; }
+
+extern "C" int mvs_nchw_to_nhwc_f32(const float *in, float *out, int B, int C, int64_t S,
+                                    void *stream) {
+    return launch_transpose(in, out, B, C, S, as_stream(stream), "mvs_nchw_to_nhwc_f32");
+}
+
+extern "C" int mvs_nhwc_to_nchw_f32(const float *in, float *out, int B, int C, int64_t S,
+                                    void *stream) {
+    // in [B][S][C] -> out [B][C][S]: same kernel with the roles of R and S swapped
+    if (S > 0x7fffffffLL) {
+        set_error("mvs_nhwc_to_nchw_f32: S too large");
+        return MVS_EINVAL;
+    }
+    return launch_transpose(in, out, B, (int)S, (int64_t)C, as_stream(stream),
+                            "mvs_nhwc_to_nchw_f32");
+}
+
+extern "C" int mvs_conv3d_mfma_supported(int transposed, int Cin, int Cout, int stride) {
+    return conv3d_mfma_supported(transposed, Cin, Cout, stride);
+}
+
+extern "C" int64_t mvs_conv3d_packed_weight_floats(int transposed, int Cin, int Cout, int stride) {
+    return conv3d_packed_floats(transposed, Cin, Cout, stride);
+}
+
+extern "C" int mvs_conv3d_pack_weights_f32(const float *weight, int transposed, int Cin, int Cout,
+                                           int stride, float *packed, void *stream) {
+    if (!weight || !packed) {
+        set_error("mvs_conv3d_pack_weights_f32: null pointer");
+        return MVS_EINVAL;
+    }
+    return conv3d_pack_launch(weight, transposed, Cin, Cout, stride, packed, as_stream(stream));
+}
+
+extern "C" int mvs_conv3d_f32(const float *in, const float *weight, const float *packed_weight,
+                              const float *scale, const float *shift, const float *residual,
+                              int relu, int transposed, int B, int Cin, int Cout, int D, int H,
+                              int W, int stride, int layout, int impl, float *out, void *stream) {
+    if (!in || !out || B <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0 ||
+        (stride != 1 && stride != 2) || (layout != MVS_LAYOUT_NCHW && layout != MVS_LAYOUT_NHWC) ||
+        impl < 0 || impl > 2) {
+        set_error("mvs_conv3d_f32: invalid argument");
+        return MVS_EINVAL;
+    }
+    hipStream_t st = as_stream(stream);
+    const bool mfma_ok = layout == MVS_LAYOUT_NHWC && packed_weight &&
+                         conv3d_mfma_supported(transposed, Cin, Cout, stride);
+    if (impl == 2 && !mfma_ok) {
+        set_error("mvs_conv3d_f32: MFMA path needs channels-last, packed weights and a supported "
+                  "shape (%s Cin=%d Cout=%d stride=%d)",
+                  transposed ? "deconv" : "conv", Cin, Cout, stride);
+        return MVS_EUNSUPPORTED;
+    }
+    if (impl == 2 || (impl == 0 && mfma_ok))
+        return conv3d_mfma_launch(in, packed_weight, scale, shift, residual, relu, transposed, B,
+                                  Cin, Cout, D, H, W, stride, out, st);
+    if (!weight) {
+        set_error("mvs_conv3d_f32: direct path needs the PyTorch-layout weight");
+        return MVS_EINVAL;
+    }
+    return conv3d_direct_launch(in, weight, scale, shift, residual, relu, transposed, B, Cin, Cout,
+                                D, H, W, stride, layout, out, st);
+}

@@ -1,0 +1,99 @@
+// Shared host/device helpers for libmvs_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/mvs_hip.h"
+
+namespace mvs {
+
+void set_error(const char *fmt, ...);
+
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return MVS_ELAUNCH;
+    }
+    return MVS_OK;
+}
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+// ---------------------------------------------------------------------
+// Plane-sweep sampling coordinate, op-for-op as the reference evaluates it
+// (MVSNet/models/module.py:73-79 followed by ATen's grid_sampler
+// un-normalisation).  The FMA placement below reproduces ATen's CPU kernels
+// bit for bit (oracle/mvs_oracle.c, pinned by tests/test_oracle_golden.py);
+// this file is compiled with -ffp-contract=off so nothing else is fused.
+struct SweepCam {
+    float r[12];  // rows of (src_proj @ inverse(ref_proj))[:3,:4]
+};
+
+__device__ __forceinline__ void sweep_ray(const float *__restrict__ r, float x, float y,
+                                          float &rx, float &ry, float &rz) {
+    rx = __fmaf_rn(r[1], y, r[0] * x) + r[2];
+    ry = __fmaf_rn(r[5], y, r[4] * x) + r[6];
+    rz = __fmaf_rn(r[9], y, r[8] * x) + r[10];
+}
+
+// half_w = (W-1)/2, half_h = (H-1)/2 (module.py:78-79); unn_* is W/2,H/2 for
+// align_corners=0 or (W-1)/2,(H-1)/2 for align_corners=1.
+__device__ __forceinline__ void sweep_coord(const float *__restrict__ r, float rx, float ry,
+                                            float rz, float d, float half_w, float half_h,
+                                            float unn_w, float unn_h, int align_corners,
+                                            float &ix, float &iy) {
+    float X = rx * d + r[3];
+    float Y = ry * d + r[7];
+    float Z = rz * d + r[11];
+    float px = X / Z;
+    float py = Y / Z;
+    float gx = px / half_w - 1.0f;
+    float gy = py / half_h - 1.0f;
+    if (align_corners) {
+        ix = (gx + 1.0f) * unn_w;
+        iy = (gy + 1.0f) * unn_h;
+    } else {
+        ix = __fmaf_rn(gx + 1.0f, unn_w, -0.5f);
+        iy = __fmaf_rn(gy + 1.0f, unn_h, -0.5f);
+    }
+}
+
+// Bilinear taps with zeros padding (ATen grid_sampler_2d bilinear/zeros).
+struct Taps {
+    float nw, ne, sw, se;  // weights of (y0,x0) (y0,x1) (y1,x0) (y1,x1)
+    int x0, x1, y0, y1;    // clamped to valid indices
+    bool x0ok, x1ok, y0ok, y1ok;
+};
+
+__device__ __forceinline__ Taps make_taps(float ix, float iy, int H, int W) {
+    Taps t;
+    float x0f = floorf(ix), y0f = floorf(iy);
+    float w = ix - x0f, e = 1.0f - w;
+    float n = iy - y0f, s = 1.0f - n;
+    t.nw = s * e;
+    t.ne = s * w;
+    t.sw = n * e;
+    t.se = n * w;
+    t.x0ok = (x0f >= 0.0f) && (x0f <= (float)(W - 1));
+    t.x1ok = (x0f >= -1.0f) && (x0f <= (float)(W - 2));
+    t.y0ok = (y0f >= 0.0f) && (y0f <= (float)(H - 1));
+    t.y1ok = (y0f >= -1.0f) && (y0f <= (float)(H - 2));
+    t.x0 = t.x0ok ? (int)x0f : 0;
+    t.x1 = t.x1ok ? (int)x0f + 1 : 0;
+    t.y0 = t.y0ok ? (int)y0f : 0;
+    t.y1 = t.y1ok ? (int)y0f + 1 : 0;
+    return t;
+}
+
+__device__ __forceinline__ float blend(const Taps &t, float v00, float v01, float v10,
+                                       float v11) {
+    return __fmaf_rn(v11, t.se, __fmaf_rn(v10, t.sw, __fmaf_rn(v01, t.ne, v00 * t.nw)));
+}
+
+}  // namespace mvs

@@ -1,0 +1,112 @@
+// K4+K5: softmax over the depth axis, depth expectation and photometric
+// confidence in one kernel (replaces mvsnet.py:183-191 and module.py:91-103:
+// the reference makes ~7 passes over the probability volume; this makes three
+// reads of the cost volume -- max, normaliser, expectation -- that stay in
+// L2 / Infinity Cache, and never writes the probability volume unless asked).
+//
+// One thread per pixel, x fastest: every read of cost[b,d,y,:] is a coalesced
+// 256-B wavefront row.  Arithmetic follows ATen's softmax: p = exp(c-max)/sum.
+#include "mvs_common.h"
+
+namespace mvs {
+
+__global__ __launch_bounds__(256) void softmax_regress_conf_kernel(
+    const float *__restrict__ cost, const float *__restrict__ depth, int depth_mode,
+    int clamp_idx, int B, int D, int64_t plane, float *__restrict__ out_depth,
+    float *__restrict__ out_conf, float *__restrict__ out_prob) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * plane) return;
+    const int b = (int)(i / plane);
+    const int64_t pix = i % plane;
+    const float *c = cost + (int64_t)b * D * plane + pix;
+    float m = c[0];
+    for (int d = 1; d < D; ++d) m = fmaxf(m, c[(int64_t)d * plane]);
+    float sum = 0.0f;
+    for (int d = 0; d < D; ++d) sum += expf(c[(int64_t)d * plane] - m);
+    float dep = 0.0f, fidx = 0.0f;
+    const float *dv = depth_mode == 0 ? depth + (int64_t)b * D : depth + (int64_t)b * D * plane + pix;
+    const int64_t dstride = depth_mode == 0 ? 1 : plane;
+    float *pp = out_prob ? out_prob + (int64_t)b * D * plane + pix : nullptr;
+    for (int d = 0; d < D; ++d) {
+        float pr = expf(c[(int64_t)d * plane] - m) / sum;
+        dep += pr * dv[(int64_t)d * dstride];   // module.py:102
+        fidx += pr * (float)d;                  // mvsnet.py:189
+        if (pp) pp[(int64_t)d * plane] = pr;
+    }
+    // .long() truncates toward zero (mvsnet.py:189); Cas clamps (cas_mvsnet.py:63)
+    int idx = (int)fidx;
+    if (clamp_idx) idx = min(max(idx, 0), D - 1);
+    // 4 * avg_pool3d over the (1,2)-padded window == p[idx-1] + ... + p[idx+2]
+    float s4 = 0.0f;
+#pragma unroll
+    for (int k = -1; k <= 2; ++k) {
+        int dd = idx + k;
+        if (dd >= 0 && dd < D) s4 += expf(c[(int64_t)dd * plane] - m) / sum;
+    }
+    out_depth[i] = dep;
+    out_conf[i] = s4;
+}
+
+// d depth / d cost_k = p_k (dv_k - depth); grad_cost = grad_depth * that.
+__global__ __launch_bounds__(256) void softmax_regress_bwd_kernel(
+    const float *__restrict__ cost, const float *__restrict__ depth, int depth_mode,
+    const float *__restrict__ gdepth, int B, int D, int64_t plane,
+    float *__restrict__ gcost) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * plane) return;
+    const int b = (int)(i / plane);
+    const int64_t pix = i % plane;
+    const float *c = cost + (int64_t)b * D * plane + pix;
+    float m = c[0];
+    for (int d = 1; d < D; ++d) m = fmaxf(m, c[(int64_t)d * plane]);
+    float sum = 0.0f;
+    for (int d = 0; d < D; ++d) sum += expf(c[(int64_t)d * plane] - m);
+    const float *dv = depth_mode == 0 ? depth + (int64_t)b * D : depth + (int64_t)b * D * plane + pix;
+    const int64_t dstride = depth_mode == 0 ? 1 : plane;
+    float dep = 0.0f;
+    for (int d = 0; d < D; ++d) dep += expf(c[(int64_t)d * plane] - m) / sum * dv[(int64_t)d * dstride];
+    const float g = gdepth[i];
+    float *gc = gcost + (int64_t)b * D * plane + pix;
+    for (int d = 0; d < D; ++d) {
+        float pr = expf(c[(int64_t)d * plane] - m) / sum;
+        gc[(int64_t)d * plane] = g * pr * (dv[(int64_t)d * dstride] - dep);
+    }
+}
+
+}  // namespace mvs
+
+using namespace mvs;
+
+extern "C" int mvs_softmax_regress_conf_f32(const float *cost, const float *depth_values,
+                                            int depth_mode, int clamp_idx, int B, int D, int H,
+                                            int W, float *out_depth, float *out_conf,
+                                            float *out_prob, void *stream) {
+    if (!cost || !depth_values || !out_depth || !out_conf || B <= 0 || D <= 0 || H <= 0 ||
+        W <= 0 || depth_mode < 0 || depth_mode > 1) {
+        set_error("mvs_softmax_regress_conf_f32: invalid argument");
+        return MVS_EINVAL;
+    }
+    const int64_t plane = (int64_t)H * W;
+    const int64_t n = (int64_t)B * plane;
+    unsigned grid = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(softmax_regress_conf_kernel, dim3(grid), dim3(256), 0, as_stream(stream),
+                       cost, depth_values, depth_mode, clamp_idx, B, D, plane, out_depth, out_conf,
+                       out_prob);
+    return check_launch("mvs_softmax_regress_conf_f32");
+}
+
+extern "C" int mvs_softmax_regress_bwd_f32(const float *cost, const float *depth_values,
+                                           int depth_mode, const float *grad_depth, int B, int D,
+                                           int H, int W, float *grad_cost, void *stream) {
+    if (!cost || !depth_values || !grad_depth || !grad_cost || B <= 0 || D <= 0 || H <= 0 ||
+        W <= 0 || depth_mode < 0 || depth_mode > 1) {
+        set_error("mvs_softmax_regress_bwd_f32: invalid argument");
+        return MVS_EINVAL;
+    }
+    const int64_t plane = (int64_t)H * W;
+    const int64_t n = (int64_t)B * plane;
+    unsigned grid = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(softmax_regress_bwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream),
+                       cost, depth_values, depth_mode, grad_depth, B, D, plane, grad_cost);
+    return check_launch("mvs_softmax_regress_bwd_f32");
+}

@@ -1,0 +1,220 @@
+"""MVSNet with the reference's Python surface (MVSNet/models/mvsnet.py) and the
+cost-volume path on MI355X HIP kernels.
+
+    model = MVSNet(refine=False)
+    out = model(imgs[B,V,3,H,W], proj_matrices[B,V,4,4], depth_values[B,D])
+    out["depth"], out["photometric_confidence"]            # [B,H/4,W/4]
+
+Module / parameter names equal the reference's, so `load_state_dict` accepts
+its checkpoints (including `module.`-prefixed DataParallel ones via
+`load_reference_checkpoint`).
+
+eval():  FeatureNet (PyTorch-ROCm) -> fused warp+variance (HIP, channels-last,
+         per-view volumes never materialised) -> CostRegNet as MFMA implicit-GEMM
+         3D convolutions with folded BatchNorm (HIP) -> fused softmax /
+         expectation / confidence (HIP).
+train(): same kernels for warp+variance and softmax-regression with their
+         hand-written backward kernels; CostRegNet runs through PyTorch-ROCm
+         autograd (batch-statistics BatchNorm), as does FeatureNet.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from .module import ConvBnReLU, ConvBnReLU3D
+
+
+class FeatureNet(nn.Module):
+    """[B,3,H,W] -> [B,32,H/4,W/4]  (mvsnet.py:8-45)"""
+
+    def __init__(self):
+        super().__init__()
+        self.inplanes = 32
+        self.conv0 = ConvBnReLU(3, 8, 3, 1, 1)
+        self.conv1 = ConvBnReLU(8, 8, 3, 1, 1)
+        self.conv2 = ConvBnReLU(8, 16, 5, 2, 2)
+        self.conv3 = ConvBnReLU(16, 16, 3, 1, 1)
+        self.conv4 = ConvBnReLU(16, 16, 3, 1, 1)
+        self.conv5 = ConvBnReLU(16, 32, 5, 2, 2)
+        self.conv6 = ConvBnReLU(32, 32, 3, 1, 1)
+        self.feature = nn.Conv2d(32, 32, 3, 1, 1)
+
+    def forward(self, x):
+        for blk in (self.conv0, self.conv1, self.conv2, self.conv3, self.conv4, self.conv5,
+                    self.conv6):
+            x = blk(x)
+        return self.feature(x)
+
+
+def _deconv_block(cin, cout):
+    return nn.Sequential(
+        nn.ConvTranspose3d(cin, cout, kernel_size=3, padding=1, output_padding=1, stride=2,
+                           bias=False),
+        nn.BatchNorm3d(cout),
+        nn.ReLU(inplace=True))
+
+
+class CostRegNet(nn.Module):
+    """3D U-Net regulariser [B,32,D,H,W] -> [B,1,D,H,W]  (mvsnet.py:48-93)"""
+
+    # (name, kind, stride, skip-from)
+    _PLAN = (("conv0", "conv", 1), ("conv1", "conv", 2), ("conv2", "conv", 1),
+             ("conv3", "conv", 2), ("conv4", "conv", 1), ("conv5", "conv", 2),
+             ("conv6", "conv", 1), ("conv7", "deconv", 2), ("conv9", "deconv", 2),
+             ("conv11", "deconv", 2))
+
+    def __init__(self):
+        super().__init__()
+        self.conv0 = ConvBnReLU3D(32, 8)
+        self.conv1 = ConvBnReLU3D(8, 16, stride=2)
+        self.conv2 = ConvBnReLU3D(16, 16)
+        self.conv3 = ConvBnReLU3D(16, 32, stride=2)
+        self.conv4 = ConvBnReLU3D(32, 32)
+        self.conv5 = ConvBnReLU3D(32, 64, stride=2)
+        self.conv6 = ConvBnReLU3D(64, 64)
+        self.conv7 = _deconv_block(64, 32)
+        self.conv9 = _deconv_block(32, 16)
+        self.conv11 = _deconv_block(16, 8)
+        self.prob = nn.Conv3d(8, 1, 3, stride=1, padding=1)
+        self._hip_cache = None
+        self.conv_impl = ops.IMPL_AUTO
+
+    # -- autograd path (training): PyTorch-ROCm ops, batch-statistics BN
+    def forward(self, x):
+        c0 = self.conv0(x)
+        c2 = self.conv2(self.conv1(c0))
+        c4 = self.conv4(self.conv3(c2))
+        x = self.conv6(self.conv5(c4))
+        x = c4 + self.conv7(x)
+        x = c2 + self.conv9(x)
+        x = c0 + self.conv11(x)
+        return self.prob(x)
+
+    # -- inference path: HIP kernels, BN folded to a per-channel affine
+    def _layers(self):
+        out = []
+        for name, kind, stride in self._PLAN:
+            m = getattr(self, name)
+            conv, bn = (m.conv, m.bn) if kind == "conv" else (m[0], m[1])
+            out.append((name, kind, stride, conv, bn))
+        return out
+
+    def _hip_params(self):
+        layers = self._layers()
+        key = tuple((p._version, p.data_ptr()) for _, _, _, conv, bn in layers
+                    for p in (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var))
+        key += ((self.prob.weight._version, self.prob.weight.data_ptr()),
+                (self.prob.bias._version, self.prob.bias.data_ptr()))
+        if self._hip_cache is not None and self._hip_cache[0] == key:
+            return self._hip_cache[1]
+        params = {}
+        with torch.no_grad():
+            for name, kind, stride, conv, bn in layers:
+                scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).float().contiguous()
+                shift = (bn.bias - bn.running_mean * scale).float().contiguous()
+                w = conv.weight.detach().float().contiguous()
+                params[name] = dict(weight=w, scale=scale, shift=shift, stride=stride,
+                                    transposed=(kind == "deconv"),
+                                    packed=ops.pack_conv3d_weight(w, kind == "deconv", stride))
+            w = self.prob.weight.detach().float().contiguous()
+            params["prob"] = dict(weight=w, scale=None,
+                                  shift=self.prob.bias.detach().float().contiguous(), stride=1,
+                                  transposed=False, packed=ops.pack_conv3d_weight(w, False, 1))
+        self._hip_cache = (key, params)
+        return params
+
+    def forward_hip(self, x_cl):
+        """x_cl: variance volume, channels-last [B,D,H,W,32] -> cost [B,D,H,W]."""
+        P = self._hip_params()
+
+        def run(name, t, skip=None, relu=True):
+            p = P[name]
+            with ops.stage("costreg." + name):
+                return _conv(p, t, skip, relu)
+
+        def _conv(p, t, skip, relu):
+            return ops.conv3d(t, p["weight"], p["scale"], p["shift"], skip, relu, p["transposed"],
+                              p["stride"], channels_last=True, packed=p["packed"],
+                              impl=self.conv_impl)
+
+        c0 = run("conv0", x_cl)
+        c2 = run("conv2", run("conv1", c0))
+        c4 = run("conv4", run("conv3", c2))
+        t = run("conv6", run("conv5", c4))
+        t = run("conv7", t, c4)
+        t = run("conv9", t, c2)
+        t = run("conv11", t, c0)
+        cost = run("prob", t, None, relu=False)     # [B,D,H,W,1]
+        return cost.squeeze(-1)
+
+
+class RefineNet(nn.Module):
+    """mvsnet.py:96-114.  Never enabled by the reference drivers
+    (train.py:93, eval.py:103 pass refine=False); kept for state_dict parity."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = ConvBnReLU(4, 32)
+        self.conv2 = ConvBnReLU(32, 32)
+        self.conv3 = ConvBnReLU(32, 32)
+        self.res = ConvBnReLU(32, 1)
+
+    def forward(self, img, depth_init):
+        x = torch.cat((F.interpolate(img, size=[128, 160]), depth_init.unsqueeze(1)), 1)
+        return depth_init + self.res(self.conv3(self.conv2(self.conv1(x))))
+
+
+class MVSNet(nn.Module):
+    def __init__(self, refine=True, align_corners=False, proj_where="host"):
+        super().__init__()
+        self.refine = refine
+        self.align_corners = align_corners
+        self.proj_where = proj_where
+        self.feature = FeatureNet()
+        self.cost_regularization = CostRegNet()
+        if self.refine:
+            self.refine_network = RefineNet()
+
+    def forward(self, imgs, proj_matrices, depth_values):
+        if imgs.shape[1] != proj_matrices.shape[1]:
+            raise AssertionError("Different number of images and projection matrices")
+        V = imgs.shape[1]
+        with ops.stage("feature"):
+            feats = [self.feature(imgs[:, v]) for v in range(V)]
+        ref_proj = proj_matrices[:, 0]
+        with ops.stage("rot_trans"):
+            rts = torch.stack([ops.rot_trans(proj_matrices[:, v], ref_proj, self.proj_where)
+                               for v in range(1, V)])                   # [V-1,B,12]
+        if self.training or torch.is_grad_enabled() and any(f.requires_grad for f in feats):
+            var = ops.costvol_variance(feats[0], torch.stack(feats[1:]), rts, depth_values,
+                                       self.align_corners)              # [B,32,D,h,w]
+            cost = self.cost_regularization(var).squeeze(1)
+        else:
+            with ops.stage("to_channels_last"):
+                ref_cl = ops.nchw_to_nhwc(feats[0])
+                src_cl = torch.stack([ops.nchw_to_nhwc(f) for f in feats[1:]])
+            with ops.stage("costvol_variance"):
+                var = ops.costvol_variance_cl(ref_cl, src_cl, rts, depth_values,
+                                              self.align_corners)       # [B,D,h,w,32]
+            cost = self.cost_regularization.forward_hip(var)            # [B,D,h,w]
+        with ops.stage("softmax_regress_conf"):
+            depth, conf, _ = ops.softmax_regress_conf(cost, depth_values)
+        out = {"depth": depth, "photometric_confidence": conf}
+        if self.refine:
+            out["refined_depth"] = self.refine_network(imgs[:, 0], depth)
+        return out
+
+
+def mvsnet_loss(depth_est, depth_gt, mask):
+    """mvsnet.py:201-203: smooth-L1 (beta 1), mean over mask > 0.5."""
+    m = mask > 0.5
+    return F.smooth_l1_loss(depth_est[m], depth_gt[m], reduction="mean")
+
+
+def load_reference_checkpoint(model, ckpt):
+    """Accepts the reference's checkpoint dicts (train.py:159-164): {'model':
+    state_dict, ...} with or without the DataParallel `module.` prefix."""
+    sd = ckpt["model"] if isinstance(ckpt, dict) and "model" in ckpt else ckpt
+    sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+    return model.load_state_dict(sd, strict=True)

@@ -1,0 +1,301 @@
+"""Torch-facing wrappers of the libmvs_hip.so C ABI (include/mvs_hip.h).
+
+Tensors in, tensors out; device memory and streams come from PyTorch-ROCm,
+every FLOP of the cost-volume path runs in the hand-written HIP kernels.
+There is no fallback: CPU tensors or a missing library raise MvsHipError.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import MVS_LAYOUT_NCHW, MVS_LAYOUT_NHWC, MvsHipError, check, ptr, stream
+
+_I = ctypes.c_int
+
+
+# ------------------------------------------------------------ stage timing
+class StageTimer:
+    """HIP-event timing of named stages on torch's current stream (the stream
+    every kernel of this package is launched on).  bench.py installs one with
+    set_timer(); when none is installed the hooks cost nothing."""
+
+    def __init__(self, only=None):
+        self.only = only          # None = every stage, else a set of names
+        self.pairs = {}
+
+    def begin(self, name):
+        if self.only is not None and name not in self.only:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def end(self, name, start):
+        if start is None:
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.pairs.setdefault(name, []).append((start, ev))
+
+    def summary_ms(self):
+        """name -> (count, mean ms); call after torch.cuda.synchronize()."""
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v))
+                for k, v in self.pairs.items()}
+
+
+_timer = None
+
+
+def set_timer(t):
+    global _timer
+    _timer = t
+
+
+class stage:
+    """with ops.stage("name"): ...  -- no-op unless a StageTimer is installed."""
+
+    def __init__(self, name):
+        self.name = name
+        self.ev = None
+
+    def __enter__(self):
+        if _timer is not None:
+            self.ev = _timer.begin(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        if _timer is not None:
+            _timer.end(self.name, self.ev)
+        return False
+
+
+def _f32c(t):
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+def rot_trans(src_proj, ref_proj, where="host"):
+    """rows of (src_proj @ inverse(ref_proj))[:3,:4] -> [B,12] on src_proj's device.
+
+    This is MVSNet/models/module.py:63-65.  The depth map is sensitive to the
+    rounding of this 4x4 fp32 inverse (~2e-4 mm), so by default it is evaluated
+    with the same ATen CPU (LAPACK) ops the reference's CPU forward uses
+    (`where="host"`: bit-identical, costs one small D2H/H2D round trip);
+    `where="device"` keeps it on the GPU (no sync, rounding differs in the
+    last bits)."""
+    dev = src_proj.device
+    with torch.no_grad():
+        if where == "host":
+            s, r = src_proj.detach().float().cpu(), ref_proj.detach().float().cpu()
+        else:
+            s, r = src_proj.detach().float(), ref_proj.detach().float()
+        m = torch.matmul(s, torch.inverse(r))
+        return m[:, :3, :4].reshape(-1, 12).contiguous().to(dev, non_blocking=True)
+
+
+def _depth_mode(depth_values):
+    if depth_values.dim() == 2:
+        return 0
+    if depth_values.dim() == 4:
+        return 1
+    raise MvsHipError(f"depth_values must be [B,D] or [B,D,H,W], got {tuple(depth_values.shape)}")
+
+
+def nchw_to_nhwc(x):
+    """[B,C,*spatial] -> [B,*spatial,C] (contiguous) on the HIP transpose kernel."""
+    x = _f32c(x)
+    B, C = x.shape[0], x.shape[1]
+    S = x[0, 0].numel()
+    out = torch.empty((B,) + tuple(x.shape[2:]) + (C,), device=x.device, dtype=torch.float32)
+    check(_lib.load().mvs_nchw_to_nhwc_f32(ptr(x), ptr(out), B, C, S, stream()), "mvs_nchw_to_nhwc_f32")
+    return out
+
+
+def nhwc_to_nchw(x):
+    x = _f32c(x)
+    B, C = x.shape[0], x.shape[-1]
+    S = x[0, ..., 0].numel()
+    out = torch.empty((B, C) + tuple(x.shape[1:-1]), device=x.device, dtype=torch.float32)
+    check(_lib.load().mvs_nhwc_to_nchw_f32(ptr(x), ptr(out), B, C, S, stream()), "mvs_nhwc_to_nchw_f32")
+    return out
+
+
+# ---------------------------------------------------------------- K1 warp
+class _HomoWarp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src_fea, rt, depth_values, align_corners):
+        src_fea, depth_values = _f32c(src_fea), _f32c(depth_values)
+        B, C, H, W = src_fea.shape
+        D = depth_values.shape[1]
+        mode = _depth_mode(depth_values)
+        out = torch.empty((B, C, D, H, W), device=src_fea.device, dtype=torch.float32)
+        check(_lib.load().mvs_warp_fwd_f32(ptr(src_fea), ptr(rt), ptr(depth_values), mode, B, C, D,
+                                           H, W, int(align_corners), ptr(out), stream()),
+              "mvs_warp_fwd_f32")
+        ctx.save_for_backward(rt, depth_values)
+        ctx.meta = (B, C, D, H, W, mode, int(align_corners))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        rt, depth_values = ctx.saved_tensors
+        B, C, D, H, W, mode, ac = ctx.meta
+        grad_out = _f32c(grad_out)
+        g = torch.empty((B, C, H, W), device=grad_out.device, dtype=torch.float32)
+        check(_lib.load().mvs_warp_bwd_f32(ptr(grad_out), ptr(rt), ptr(depth_values), mode, B, C, D,
+                                           H, W, ac, ptr(g), stream()), "mvs_warp_bwd_f32")
+        return g, None, None, None
+
+
+def homo_warp(src_fea, rt, depth_values, align_corners=False):
+    return _HomoWarp.apply(src_fea, rt, depth_values, align_corners)
+
+
+# ------------------------------------------------------ K1+K2 fused variance
+class _CostVolVariance(torch.autograd.Function):
+    """Planar ([B,C,H,W] -> [B,C,D,H,W]) fused warp+variance with backward."""
+
+    @staticmethod
+    def forward(ctx, ref_fea, src_feas, rts, depth_values, align_corners, alias_quirk):
+        ref_fea, src_feas, depth_values = _f32c(ref_fea), _f32c(src_feas), _f32c(depth_values)
+        B, C, H, W = ref_fea.shape
+        V = src_feas.shape[0] + 1
+        D = depth_values.shape[1]
+        mode = _depth_mode(depth_values)
+        out = torch.empty((B, C, D, H, W), device=ref_fea.device, dtype=torch.float32)
+        check(_lib.load().mvs_costvol_variance_fwd_f32(
+            ptr(ref_fea), ptr(src_feas), ptr(rts), ptr(depth_values), mode, B, V, C, D, H, W,
+            int(align_corners), int(alias_quirk), MVS_LAYOUT_NCHW, MVS_LAYOUT_NCHW, ptr(out),
+            stream()), "mvs_costvol_variance_fwd_f32")
+        ctx.save_for_backward(ref_fea, src_feas, rts, depth_values)
+        ctx.meta = (B, V, C, D, H, W, mode, int(align_corners), int(alias_quirk))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_var):
+        ref_fea, src_feas, rts, depth_values = ctx.saved_tensors
+        B, V, C, D, H, W, mode, ac, quirk = ctx.meta
+        if quirk:
+            raise MvsHipError("alias_quirk (CVP inference form) is not differentiable here")
+        grad_var = _f32c(grad_var)
+        g_ref = torch.empty_like(ref_fea)
+        g_src = torch.empty_like(src_feas)
+        check(_lib.load().mvs_costvol_variance_bwd_f32(
+            ptr(grad_var), ptr(ref_fea), ptr(src_feas), ptr(rts), ptr(depth_values), mode, B, V, C,
+            D, H, W, ac, MVS_LAYOUT_NCHW, MVS_LAYOUT_NCHW, ptr(g_ref), ptr(g_src), stream()),
+            "mvs_costvol_variance_bwd_f32")
+        return g_ref, g_src, None, None, None, None
+
+
+def costvol_variance(ref_fea, src_feas, rts, depth_values, align_corners=False, alias_quirk=False):
+    """ref_fea [B,C,H,W]; src_feas [V-1,B,C,H,W]; rts [V-1,B,12] -> [B,C,D,H,W]
+    (differentiable w.r.t. the feature maps)."""
+    return _CostVolVariance.apply(ref_fea, src_feas, rts, depth_values, align_corners, alias_quirk)
+
+
+def costvol_variance_cl(ref_fea_cl, src_feas_cl, rts, depth_values, align_corners=False,
+                        alias_quirk=False):
+    """Channels-last inference form: ref [B,H,W,C]; srcs [V-1,B,H,W,C] -> [B,D,H,W,C]."""
+    ref_fea_cl, src_feas_cl, depth_values = _f32c(ref_fea_cl), _f32c(src_feas_cl), _f32c(depth_values)
+    B, H, W, C = ref_fea_cl.shape
+    V = src_feas_cl.shape[0] + 1
+    D = depth_values.shape[1]
+    out = torch.empty((B, D, H, W, C), device=ref_fea_cl.device, dtype=torch.float32)
+    check(_lib.load().mvs_costvol_variance_fwd_f32(
+        ptr(ref_fea_cl), ptr(src_feas_cl), ptr(rts), ptr(depth_values), _depth_mode(depth_values),
+        B, V, C, D, H, W, int(align_corners), int(alias_quirk), MVS_LAYOUT_NHWC, MVS_LAYOUT_NHWC,
+        ptr(out), stream()), "mvs_costvol_variance_fwd_f32")
+    return out
+
+
+# ---------------------------------------------------------------- K3 conv
+IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA = 0, 1, 2
+
+
+def conv3d_mfma_supported(transposed, cin, cout, stride):
+    return bool(_lib.load().mvs_conv3d_mfma_supported(int(transposed), cin, cout, stride))
+
+
+def pack_conv3d_weight(weight, transposed, stride):
+    """PyTorch-layout weight -> MFMA A-fragment order (None if the shape has no
+    MFMA configuration)."""
+    weight = _f32c(weight)
+    cin, cout = (weight.shape[0], weight.shape[1]) if transposed else (weight.shape[1], weight.shape[0])
+    n = _lib.load().mvs_conv3d_packed_weight_floats(int(transposed), cin, cout, stride)
+    if n <= 0:
+        return None
+    packed = torch.empty(n, device=weight.device, dtype=torch.float32)
+    check(_lib.load().mvs_conv3d_pack_weights_f32(ptr(weight), int(transposed), cin, cout, stride,
+                                                  ptr(packed), stream()),
+          "mvs_conv3d_pack_weights_f32")
+    return packed
+
+
+def conv3d(x, weight, scale=None, shift=None, residual=None, relu=False, transposed=False,
+           stride=1, channels_last=False, packed=None, impl=IMPL_AUTO):
+    """3x3x3 (transposed) convolution + per-channel affine + ReLU + skip add.
+    x: [B,Cin,D,H,W] or, with channels_last, [B,D,H,W,Cin]."""
+    x = _f32c(x)
+    weight = _f32c(weight) if weight is not None else None
+    if channels_last:
+        B, D, H, W, cin = x.shape
+    else:
+        B, cin, D, H, W = x.shape
+    if weight is not None:
+        cout = weight.shape[1] if transposed else weight.shape[0]
+    else:
+        raise MvsHipError("conv3d needs the PyTorch-layout weight (used for shape and the direct path)")
+    if transposed:
+        Do, Ho, Wo = D * stride, H * stride, W * stride
+    else:
+        Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
+    shape = (B, Do, Ho, Wo, cout) if channels_last else (B, cout, Do, Ho, Wo)
+    out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    if residual is not None:
+        residual = _f32c(residual)
+        if tuple(residual.shape) != shape:
+            raise MvsHipError(f"residual shape {tuple(residual.shape)} != output shape {shape}")
+    check(_lib.load().mvs_conv3d_f32(
+        ptr(x), ptr(weight), ptr(packed), ptr(_f32c(scale)) if scale is not None else None,
+        ptr(_f32c(shift)) if shift is not None else None, ptr(residual), int(relu), int(transposed),
+        B, cin, cout, D, H, W, stride, MVS_LAYOUT_NHWC if channels_last else MVS_LAYOUT_NCHW,
+        impl, ptr(out), stream()), "mvs_conv3d_f32")
+    return out
+
+
+# ------------------------------------------------------------- K4+K5 regress
+class _SoftmaxRegress(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cost, depth_values, clamp_idx, want_prob):
+        cost, depth_values = _f32c(cost), _f32c(depth_values)
+        B, D, H, W = cost.shape
+        mode = _depth_mode(depth_values)
+        depth = torch.empty((B, H, W), device=cost.device, dtype=torch.float32)
+        conf = torch.empty((B, H, W), device=cost.device, dtype=torch.float32)
+        prob = torch.empty_like(cost) if want_prob else None
+        check(_lib.load().mvs_softmax_regress_conf_f32(
+            ptr(cost), ptr(depth_values), mode, int(clamp_idx), B, D, H, W, ptr(depth), ptr(conf),
+            ptr(prob), stream()), "mvs_softmax_regress_conf_f32")
+        ctx.save_for_backward(cost, depth_values)
+        ctx.meta = (B, D, H, W, mode)
+        ctx.mark_non_differentiable(conf)
+        if want_prob:
+            ctx.mark_non_differentiable(prob)
+            return depth, conf, prob
+        return depth, conf, None
+
+    @staticmethod
+    def backward(ctx, g_depth, g_conf, g_prob):
+        cost, depth_values = ctx.saved_tensors
+        B, D, H, W, mode = ctx.meta
+        g_depth = _f32c(g_depth)
+        g_cost = torch.empty_like(cost)
+        check(_lib.load().mvs_softmax_regress_bwd_f32(
+            ptr(cost), ptr(depth_values), mode, ptr(g_depth), B, D, H, W, ptr(g_cost), stream()),
+            "mvs_softmax_regress_bwd_f32")
+        return g_cost, None, None, None
+
+
+def softmax_regress_conf(cost, depth_values, clamp_idx=False, want_prob=False):
+    """cost [B,D,H,W] -> (depth [B,H,W], photometric confidence [B,H,W], prob or None)."""
+    return _SoftmaxRegress.apply(cost, depth_values, clamp_idx, want_prob)

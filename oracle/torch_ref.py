@@ -153,40 +153,4 @@ def masked_smooth_l1(est, gt, mask):
     return F.smooth_l1_loss(est[m], gt[m], reduction="mean")
 
 
-def random_state_dict(seed=0, peaked=30.0):
-    """Seeded MVSNet(refine=False) weights with the reference's key names and
-    PyTorch's default initialisers; BatchNorm running statistics and affine
-    parameters are randomised and the `prob` layer scaled by `peaked` so the
-    softmax over depth is not flat ("No real data")."""
-    g = torch.Generator().manual_seed(seed)
-    sd = {}
-
-    def conv_w(key, shape, fan_in, bias=False, nb=0):
-        bound = (1.0 / fan_in) ** 0.5  # kaiming_uniform(a=sqrt(5)) bound
-        sd[key + ".weight"] = (torch.rand(shape, generator=g) * 2 - 1) * bound
-        if bias:
-            sd[key + ".bias"] = (torch.rand(nb, generator=g) * 2 - 1) * bound
-
-    def bn(key, c):
-        sd[key + ".weight"] = 0.5 + torch.rand(c, generator=g)
-        sd[key + ".bias"] = 0.2 * torch.randn(c, generator=g)
-        sd[key + ".running_mean"] = 0.1 * torch.randn(c, generator=g)
-        sd[key + ".running_var"] = 0.5 + torch.rand(c, generator=g)
-        sd[key + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
-
-    for name, ci, co, k in (("conv0", 3, 8, 3), ("conv1", 8, 8, 3), ("conv2", 8, 16, 5),
-                            ("conv3", 16, 16, 3), ("conv4", 16, 16, 3), ("conv5", 16, 32, 5),
-                            ("conv6", 32, 32, 3)):
-        conv_w(f"feature.{name}.conv", (co, ci, k, k), ci * k * k)
-        bn(f"feature.{name}.bn", co)
-    conv_w("feature.feature", (32, 32, 3, 3), 32 * 9, True, 32)
-    for name, ci, co in (("conv0", 32, 8), ("conv1", 8, 16), ("conv2", 16, 16), ("conv3", 16, 32),
-                         ("conv4", 32, 32), ("conv5", 32, 64), ("conv6", 64, 64)):
-        conv_w(f"cost_regularization.{name}.conv", (co, ci, 3, 3, 3), ci * 27)
-        bn(f"cost_regularization.{name}.bn", co)
-    for name, ci, co in (("conv7", 64, 32), ("conv9", 32, 16), ("conv11", 16, 8)):
-        conv_w(f"cost_regularization.{name}.0", (ci, co, 3, 3, 3), co * 27)
-        bn(f"cost_regularization.{name}.1", co)
-    conv_w("cost_regularization.prob", (1, 8, 3, 3, 3), 8 * 27, True, 1)
-    sd["cost_regularization.prob.weight"] *= peaked
-    return sd
+from mvs_amd.synth import random_state_dict  # noqa: E402,F401  (seeded synthetic weights)

@@ -1,0 +1,388 @@
+"""Parity of the HIP path (through the C ABI of libmvs_hip.so) against
+  (1) golden vectors captured from the reference's CPU forward, and
+  (2) the CPU oracle on seeded inputs at sizes it finishes in seconds.
+Run on the GPU box: python -m pytest tests -m gpu
+Tolerances: the plane-sweep coordinate / bilinear / variance arithmetic is
+op-for-op the reference's (bit-exact expected, 1e-6 allowed); convolutions
+differ in summation order only (1e-4 on O(10) activations); the end-to-end gate
+is the north star's 1e-3 mm on depth."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rot_trans_torch
+
+pytestmark = pytest.mark.gpu
+
+DEPTH_TOL_MM = 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from mvs_amd import _lib
+    _lib.load()  # must exist: no fallback
+    return torch.device("cuda:0")
+
+
+def G(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _rts(proj):
+    return np.stack([rot_trans_torch(proj, v) for v in range(1, proj.shape[1])])
+
+
+def test_runtime_and_layout_roundtrip(dev):
+    from mvs_amd import _lib, ops
+    assert _lib.load().mvs_version() >= 100
+    assert _lib.load().mvs_arch() == b"gfx950"
+    x = torch.randn(2, 7, 5, 9, 11, device=dev)
+    y = ops.nchw_to_nhwc(x)
+    assert torch.equal(y, x.permute(0, 2, 3, 4, 1).contiguous())
+    assert torch.equal(ops.nhwc_to_nchw(y), x)
+
+
+def test_rot_trans_host_matches_reference_eval(dev):
+    from mvs_amd import ops
+    g = load_golden("g1_warp")
+    P = G(g["proj"], dev)
+    got = ops.rot_trans(P[:, 1], P[:, 0], where="host").cpu().numpy()
+    np.testing.assert_array_equal(got, rot_trans_torch(g["proj"], 1))
+    dv = ops.rot_trans(P[:, 1], P[:, 0], where="device").cpu().numpy()
+    np.testing.assert_allclose(dv, got, rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------ K1
+@pytest.mark.parametrize("v", [1, 2])
+def test_warp_golden(dev, v):
+    from mvs_amd.models import homo_warping
+    g = load_golden("g1_warp")
+    out = homo_warping(G(g["src"], dev), G(g["proj"][:, v], dev), G(g["proj"][:, 0], dev),
+                       G(g["depth"], dev)).cpu().numpy()
+    ref = g[f"warped_v{v}"]
+    np.testing.assert_allclose(out, ref, atol=1e-6, rtol=0)
+    assert (out == ref).mean() > 0.999, f"expected bit-exact warp, exact fraction {(out == ref).mean()}"
+
+
+def test_warp_per_pixel_depth_golden(dev):
+    from mvs_amd.models import homo_warping
+    g = load_golden("g8_cas_perpixel")
+    out = homo_warping(G(g["src"], dev), G(g["proj"][:, 1], dev), G(g["proj"][:, 0], dev),
+                       G(g["depth"], dev)).cpu().numpy()
+    np.testing.assert_allclose(out, g["warped"], atol=1e-6, rtol=0)
+
+
+def test_warp_align_corners_true_identity(dev):
+    """torch-1.2 semantics (MVSNet_pl): identical projections sample pixel centres."""
+    from mvs_amd.models import homo_warping
+    g = load_golden("g2_identity")
+    src = G(g["src"], dev)
+    P0 = G(g["proj"][:, 0], dev)
+    out = homo_warping(src, P0, P0, G(g["depth"], dev), align_corners=True)
+    np.testing.assert_allclose(out.cpu().numpy(),
+                               np.repeat(g["src"][:, :, None], g["depth"].shape[1], 2), atol=2e-5)
+    out_f = homo_warping(src, P0, P0, G(g["depth"], dev)).cpu().numpy()
+    np.testing.assert_allclose(out_f, g["warped"], atol=1e-6)
+
+
+def test_warp_backward_golden(dev):
+    from mvs_amd.models import homo_warping
+    g = load_golden("g7_warp_grad")
+    src = G(g["src"], dev).requires_grad_(True)
+    out = homo_warping(src, G(g["proj"][:, 1], dev), G(g["proj"][:, 0], dev), G(g["depth"], dev))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["warped"], atol=1e-6)
+    out.backward(G(g["grad_out"], dev))
+    np.testing.assert_allclose(src.grad.cpu().numpy(), g["grad_src"], atol=1e-5)
+
+
+# --------------------------------------------------------------- K1+K2
+@pytest.mark.parametrize("name", ["g6_e2e_64x96_v3_d8", "g3_e2e_64x64_v2_d8",
+                                  "g3_e2e_64x64_v5_d8_b2"])
+@pytest.mark.parametrize("layout", ["planar", "channels_last"])
+def test_variance_golden(dev, name, layout):
+    from mvs_amd import ops
+    g = load_golden(name)
+    f = g["features"]
+    V = f.shape[1]
+    rts = G(_rts(g["proj"]), dev)
+    ref = G(f[:, 0], dev)
+    srcs = G(np.stack([f[:, v] for v in range(1, V)]), dev)
+    dv = G(g["depth_values"], dev)
+    if layout == "planar":
+        var = ops.costvol_variance(ref, srcs, rts, dv).cpu().numpy()
+    else:
+        cl = ops.costvol_variance_cl(ops.nchw_to_nhwc(ref),
+                                     torch.stack([ops.nchw_to_nhwc(s) for s in srcs]), rts, dv)
+        var = cl.permute(0, 4, 1, 2, 3).contiguous().cpu().numpy()
+    np.testing.assert_allclose(var, g["variance"], atol=1e-7, rtol=0)
+    assert (var == g["variance"]).mean() > 0.999
+
+
+@pytest.mark.parametrize("layout", ["planar", "channels_last"])
+def test_variance_cvp_alias_quirk_golden(dev, layout):
+    from mvs_amd import ops
+    g = load_golden("g8_cvp_alias")
+    f = g["feats"]
+    rts, dv = G(_rts(g["proj"]), dev), G(g["depth"], dev)
+    if layout == "planar":
+        var = ops.costvol_variance(G(f[0], dev), G(f[1:], dev), rts, dv, False, True).cpu().numpy()
+    else:
+        cl = ops.costvol_variance_cl(ops.nchw_to_nhwc(G(f[0], dev)),
+                                     torch.stack([ops.nchw_to_nhwc(G(s, dev)) for s in f[1:]]),
+                                     rts, dv, False, True)
+        var = cl.permute(0, 4, 1, 2, 3).contiguous().cpu().numpy()
+    np.testing.assert_allclose(var, g["variance"], atol=1e-7, rtol=0)
+
+
+def test_variance_backward_golden(dev):
+    from mvs_amd import ops
+    g = load_golden("g7_variance_grad")
+    f = g["feats"]
+    ref = G(f[0], dev).requires_grad_(True)
+    srcs = G(f[1:], dev).requires_grad_(True)
+    var = ops.costvol_variance(ref, srcs, G(_rts(g["proj"]), dev), G(g["depth"], dev))
+    np.testing.assert_allclose(var.detach().cpu().numpy(), g["variance"], atol=1e-6)
+    var.backward(G(g["grad_out"], dev))
+    np.testing.assert_allclose(ref.grad.cpu().numpy(), g["grad_feats"][0], atol=2e-5)
+    np.testing.assert_allclose(srcs.grad.cpu().numpy(), g["grad_feats"][1:], atol=2e-5)
+
+
+def test_variance_vs_oracle_seeded_midsize(dev):
+    """C oracle vs HIP on a seeded mid-size case incl. ragged sizes (W not a
+    multiple of the wave) and per-pixel hypotheses."""
+    from mvs_amd import ops, synth
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(7)
+    B, C, D, H, W, V = 1, 32, 12, 37, 53, 4
+    proj = synth.proj_matrices(V, H, W, batch=B)
+    feats = synth.smooth_features(rng, (V, B, C, H, W))
+    base = synth.depth_values(D, batch=B, interval=synth.sweep_interval(D))
+    pp = (base[:, :, None, None] + 5 * rng.standard_normal((B, D, H, W))).astype(np.float32)
+    rts = _rts(proj)
+    for depth in (base, pp):
+        want = co.costvol_variance(feats[0], feats[1:], rts, depth)
+        got = ops.costvol_variance(G(feats[0], dev), G(feats[1:], dev), G(rts, dev),
+                                   G(depth, dev)).cpu().numpy()
+        np.testing.assert_allclose(got, want, atol=1e-7, rtol=0)
+        cl = ops.costvol_variance_cl(ops.nchw_to_nhwc(G(feats[0], dev)),
+                                     torch.stack([ops.nchw_to_nhwc(G(s, dev)) for s in feats[1:]]),
+                                     G(rts, dev), G(depth, dev))
+        np.testing.assert_allclose(cl.permute(0, 4, 1, 2, 3).cpu().numpy(), want, atol=1e-7, rtol=0)
+
+
+# ------------------------------------------------------------------ K3
+def _fold(weights, prefix):
+    from oracle.c_oracle import bn_fold
+    return bn_fold(*(weights[f"{prefix}.{k}"] for k in ("weight", "bias", "running_mean",
+                                                        "running_var")))
+
+
+_LAYERS = (  # name, input act, conv-weight key, bn prefix, transposed, stride, skip act
+    ("conv0", "variance", "conv0.conv.weight", "conv0.bn", False, 1, None),
+    ("conv1", "act_conv0", "conv1.conv.weight", "conv1.bn", False, 2, None),
+    ("conv2", "act_conv1", "conv2.conv.weight", "conv2.bn", False, 1, None),
+    ("conv3", "act_conv2", "conv3.conv.weight", "conv3.bn", False, 2, None),
+    ("conv4", "act_conv3", "conv4.conv.weight", "conv4.bn", False, 1, None),
+    ("conv5", "act_conv4", "conv5.conv.weight", "conv5.bn", False, 2, None),
+    ("conv6", "act_conv5", "conv6.conv.weight", "conv6.bn", False, 1, None),
+    ("conv7", "act_conv6", "conv7.0.weight", "conv7.1", True, 2, None),
+    ("conv9", "SKIP_conv7", "conv9.0.weight", "conv9.1", True, 2, None),
+    ("conv11", "SKIP_conv9", "conv11.0.weight", "conv11.1", True, 2, None),
+)
+
+
+def _layer_io(g, name_in):
+    if name_in == "SKIP_conv7":
+        return g["act_conv4"] + g["act_conv7"]
+    if name_in == "SKIP_conv9":
+        return g["act_conv2"] + g["act_conv9"]
+    return g[name_in]
+
+
+@pytest.mark.parametrize("layer", _LAYERS, ids=[l[0] for l in _LAYERS])
+@pytest.mark.parametrize("impl", ["direct_planar", "direct_cl", "mfma"])
+def test_conv3d_layer_golden(dev, weights, layer, impl):
+    from mvs_amd import ops
+    name, name_in, wkey, bnp, transposed, stride, _ = layer
+    g = load_golden("g6_e2e_64x96_v3_d8")
+    pre = "cost_regularization."
+    x = _layer_io(g, name_in)
+    w = weights[pre + wkey]
+    scale, shift = _fold(weights, pre + bnp)
+    want = g["act_" + name]
+    cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+    xt, wt = G(x, dev), G(w, dev)
+    if impl == "direct_planar":
+        got = ops.conv3d(xt, wt, G(scale, dev), G(shift, dev), None, True, transposed, stride,
+                         channels_last=False, impl=ops.IMPL_DIRECT)
+    else:
+        if impl == "mfma" and not ops.conv3d_mfma_supported(transposed, cin, cout, stride):
+            pytest.skip("no MFMA configuration for this layer yet (direct path covers it)")
+        packed = ops.pack_conv3d_weight(wt, transposed, stride) if impl == "mfma" else None
+        cl = ops.conv3d(ops.nchw_to_nhwc(xt), wt, G(scale, dev), G(shift, dev), None, True,
+                        transposed, stride, channels_last=True, packed=packed,
+                        impl=ops.IMPL_MFMA if impl == "mfma" else ops.IMPL_DIRECT)
+        got = ops.nhwc_to_nchw(cl)
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=2e-5, rtol=1e-5)
+
+
+def test_conv3d_residual_and_bias_epilogue(dev, weights):
+    """skip add after ReLU (mvsnet.py:89-91) and the biased `prob` conv."""
+    from mvs_amd import ops
+    g = load_golden("g6_e2e_64x96_v3_d8")
+    pre = "cost_regularization."
+    scale, shift = _fold(weights, pre + "conv7.1")
+    x = ops.nchw_to_nhwc(G(g["act_conv6"], dev))
+    skip = ops.nchw_to_nhwc(G(g["act_conv4"], dev))
+    got = ops.conv3d(x, G(weights[pre + "conv7.0.weight"], dev), G(scale, dev), G(shift, dev), skip,
+                     True, True, 2, channels_last=True)
+    np.testing.assert_allclose(ops.nhwc_to_nchw(got).cpu().numpy(), g["act_conv4"] + g["act_conv7"],
+                               atol=2e-5, rtol=1e-5)
+    x = ops.nchw_to_nhwc(G(g["act_conv0"] + g["act_conv11"], dev))
+    got = ops.conv3d(x, G(weights[pre + "prob.weight"], dev), None,
+                     G(weights[pre + "prob.bias"], dev), None, False, False, 1, channels_last=True)
+    np.testing.assert_allclose(ops.nhwc_to_nchw(got).cpu().numpy(), g["cost"], atol=5e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(1, 5, 9, 21), (2, 8, 16, 48), (1, 3, 7, 33)])
+@pytest.mark.parametrize("cfg", [(32, 8, 1), (8, 16, 2), (16, 16, 1), (16, 32, 2), (32, 32, 1),
+                                 (32, 64, 2), (64, 64, 1)])
+def test_conv3d_mfma_vs_oracle_ragged(dev, shape, cfg):
+    """MFMA kernel vs C oracle on ragged volumes (partial tiles on every axis)."""
+    from mvs_amd import ops
+    from oracle import c_oracle as co
+    B, D, H, W = shape
+    cin, cout, stride = cfg
+    rng = np.random.default_rng(cin * 1000 + cout * 10 + stride + D)
+    x = rng.standard_normal((B, cin, D, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 3, 3, 3)) / np.sqrt(27 * cin)).astype(np.float32)
+    scale = (0.5 + rng.random(cout)).astype(np.float32)
+    shift = rng.standard_normal(cout).astype(np.float32) * 0.1
+    want = co.conv3d(x, w, scale, shift, None, True, stride)
+    res = rng.standard_normal(want.shape).astype(np.float32)
+    want = want + res
+    wt = G(w, dev)
+    got = ops.conv3d(ops.nchw_to_nhwc(G(x, dev)), wt, G(scale, dev), G(shift, dev),
+                     ops.nchw_to_nhwc(G(res, dev)), True, False, stride, channels_last=True,
+                     packed=ops.pack_conv3d_weight(wt, False, stride), impl=ops.IMPL_MFMA)
+    np.testing.assert_allclose(ops.nhwc_to_nchw(got).cpu().numpy(), want, atol=2e-5, rtol=1e-5)
+
+
+def test_costregnet_hip_golden(dev, weights):
+    from mvs_amd import ops
+    from mvs_amd.models import MVSNet
+    g = load_golden("g6_e2e_64x96_v3_d8")
+    model = MVSNet(refine=False)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    model = model.to(dev).eval()
+    with torch.no_grad():
+        for impl in (ops.IMPL_DIRECT, ops.IMPL_AUTO):
+            model.cost_regularization.conv_impl = impl
+            cost = model.cost_regularization.forward_hip(ops.nchw_to_nhwc(G(g["variance"], dev)))
+            np.testing.assert_allclose(cost.cpu().numpy(), g["cost"][:, 0], atol=5e-4, rtol=1e-5)
+
+
+# --------------------------------------------------------------- K4+K5
+@pytest.mark.parametrize("name", ["g5_regress_d8", "g5_regress_d192"])
+def test_regress_confidence_golden(dev, name):
+    from mvs_amd import ops
+    g = load_golden(name)
+    depth, conf, prob = ops.softmax_regress_conf(G(g["cost"], dev), G(g["depth_values"], dev),
+                                                 want_prob=True)
+    np.testing.assert_allclose(depth.cpu().numpy(), g["depth"], atol=5e-4)
+    np.testing.assert_allclose(conf.cpu().numpy(), g["confidence"], atol=2e-6)
+    want_p = torch.softmax(torch.from_numpy(g["cost"]), 1).numpy()
+    np.testing.assert_allclose(prob.cpu().numpy(), want_p, atol=1e-6)
+
+
+def test_regress_per_pixel_and_clamp_golden(dev):
+    from mvs_amd import ops
+    g = load_golden("g8_cas_perpixel")
+    depth, _, _ = ops.softmax_regress_conf(G(g["cost"], dev), G(g["depth"], dev), clamp_idx=True)
+    np.testing.assert_allclose(depth.cpu().numpy(), g["regressed"], atol=2e-4)
+
+
+def test_regress_backward_vs_torch(dev):
+    from mvs_amd import ops
+    rng = np.random.default_rng(3)
+    cost = rng.standard_normal((2, 16, 6, 10)).astype(np.float32) * 2
+    from mvs_amd import synth
+    dv = synth.depth_values(16, batch=2, interval=synth.sweep_interval(16))
+    c = G(cost, dev).requires_grad_(True)
+    depth, _, _ = ops.softmax_regress_conf(c, G(dv, dev))
+    gd = rng.standard_normal((2, 6, 10)).astype(np.float32)
+    depth.backward(G(gd, dev))
+    ct = torch.from_numpy(cost).requires_grad_(True)
+    want = (torch.softmax(ct, 1) * torch.from_numpy(dv).view(2, 16, 1, 1)).sum(1)
+    want.backward(torch.from_numpy(gd))
+    np.testing.assert_allclose(c.grad.cpu().numpy(), ct.grad.numpy(), atol=2e-4, rtol=1e-4)
+
+
+# ----------------------------------------------------------- end to end
+@pytest.mark.parametrize("name", ["g6_e2e_64x96_v3_d8", "g6_e2e_128x160_v3_d16",
+                                  "g3_e2e_64x64_v2_d8", "g3_e2e_64x64_v5_d8_b2"])
+def test_mvsnet_eval_matches_reference_cpu_forward(dev, weights, name):
+    """The north-star gate: depth within 1e-3 mm of the reference CPU forward."""
+    from mvs_amd.models import MVSNet
+    g = load_golden(name)
+    model = MVSNet(refine=False)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    model = model.to(dev).eval()
+    with torch.no_grad():
+        out = model(G(g["imgs"], dev), G(g["proj"], dev), G(g["depth_values"], dev))
+    depth = out["depth"].cpu().numpy()
+    conf = out["photometric_confidence"].cpu().numpy()
+    assert depth.shape == g["depth"].shape
+    err = np.abs(depth - g["depth"]).max()
+    assert err < DEPTH_TOL_MM, f"max |depth - reference| = {err} mm"
+    np.testing.assert_allclose(conf, g["confidence"], atol=1e-4)
+
+
+def test_mvsnet_eval_from_reference_features(dev, weights):
+    """Same gate with FeatureNet taken out of the loop (features from the
+    reference): isolates the HIP cost-volume path proper."""
+    from mvs_amd import ops
+    from mvs_amd.models import MVSNet
+    g = load_golden("g6_e2e_128x160_v3_d16")
+    model = MVSNet(refine=False)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    model = model.to(dev).eval()
+    f = g["features"]
+    with torch.no_grad():
+        cl = [ops.nchw_to_nhwc(G(f[:, v], dev)) for v in range(f.shape[1])]
+        var = ops.costvol_variance_cl(cl[0], torch.stack(cl[1:]), G(_rts(g["proj"]), dev),
+                                      G(g["depth_values"], dev))
+        cost = model.cost_regularization.forward_hip(var)
+        np.testing.assert_allclose(cost.cpu().numpy(), g["cost"][:, 0], atol=5e-4, rtol=1e-5)
+        depth, conf, _ = ops.softmax_regress_conf(cost, G(g["depth_values"], dev))
+    assert np.abs(depth.cpu().numpy() - g["depth"]).max() < DEPTH_TOL_MM
+    np.testing.assert_allclose(conf.cpu().numpy(), g["confidence"], atol=1e-4)
+
+
+def test_mvsnet_train_step_golden(dev, weights):
+    """train(): loss and gradients against the reference's backward."""
+    from mvs_amd.models import MVSNet, mvsnet_loss
+    g = load_golden("g7_train_step")
+    model = MVSNet(refine=False)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    model = model.to(dev).train()
+    out = model(G(g["imgs"], dev), G(g["proj"], dev), G(g["depth_values"], dev))
+    loss = mvsnet_loss(out["depth"], G(g["gt"], dev), G(g["mask"], dev))
+    loss.backward()
+    np.testing.assert_allclose(out["depth"].detach().cpu().numpy(), g["depth"], atol=5e-3)
+    np.testing.assert_allclose(loss.item(), float(g["loss"]), rtol=1e-4)
+    params = dict(model.named_parameters())
+    for k in g:
+        if k.startswith("grad__"):
+            ref = g[k]
+            got = params[k[6:]].grad.cpu().numpy()
+            np.testing.assert_allclose(got, ref, atol=2e-3 * max(1.0, np.abs(ref).max()),
+                                       err_msg=k)
+
+
+def test_cpu_tensors_rejected():
+    from mvs_amd import ops
+    from mvs_amd._lib import MvsHipError
+    with pytest.raises(MvsHipError):
+        ops.softmax_regress_conf(torch.zeros(1, 4, 2, 2), torch.zeros(1, 4))
