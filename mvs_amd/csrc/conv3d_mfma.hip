@@ -118,15 +118,20 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
             const int gx = ix0 + lx, gy = iy0 + ly, gz = iz0 + lz;
             const bool ok = lx < XT && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H && gz >= 0 &&
                             gz < a.D;
+            // branch-free: load from the clamped voxel, zero it afterwards if outside
+            const int cx = min(max(gx, 0), a.W - 1), cy = min(max(gy, 0), a.H - 1);
+            const int cz = min(max(gz, 0), a.D - 1);
             const float *src =
-                in_b + (((int64_t)gz * a.H + gy) * a.W + gx) * CIN + ch * CK + ekq * KS;
+                in_b + (((int64_t)cz * a.H + cy) * a.W + cx) * CIN + ch * CK + ekq * KS;
             float *dst = lds + (ekq * PLANE + v) * KS;
             if constexpr (KS == 4) {
-                float4 val = ok ? *reinterpret_cast<const float4 *>(src)
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 val = *reinterpret_cast<const float4 *>(src);
+                val.x = ok ? val.x : 0.f; val.y = ok ? val.y : 0.f;
+                val.z = ok ? val.z : 0.f; val.w = ok ? val.w : 0.f;
                 *reinterpret_cast<float4 *>(dst) = val;
             } else {
-                float2 val = ok ? *reinterpret_cast<const float2 *>(src) : make_float2(0.f, 0.f);
+                float2 val = *reinterpret_cast<const float2 *>(src);
+                val.x = ok ? val.x : 0.f; val.y = ok ? val.y : 0.f;
                 *reinterpret_cast<float2 *>(dst) = val;
             }
         }
@@ -218,38 +223,331 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------
-// Weight packing: PyTorch (Cout,Cin,3,3,3) -> A-fragment order
+// Transposed convolution k=3, stride 2, pad 1, output_padding 1 (mvsnet.py:66-79)
+// on the same MFMA machinery.  out[o] += in[i]*w[k] with o = 2i-1+k, so per
+// dimension an even output (o=2j) sees one tap (k=1, i=j) and an odd output
+// (o=2j+1) two (k=2, i=j) and (k=0, i=j+1).  The 8 output parity classes are 8
+// small convolutions on the INPUT grid with 1..8 taps (27 in total): a wave's
+// N-tile is 16 consecutive input positions jx, and each class keeps its own
+// accumulators, so no MFMA work is wasted on structural zeros.
+// PXM (Cout = 8): the two x parities share one MFMA -- rows = (px, 8 channels),
+// k = (dx in {0,1}, ci) -- 18 instead of 27 half-empty class-taps, and the
+// epilogue becomes one fully contiguous 1-KiB store per wave.
+template <int CIN_, int COUT_, int CK_, int TZ_, int TY_, bool PXM_>
+struct DeconvCfg {
+    static constexpr int CIN = CIN_, COUT = COUT_, CK = CK_, TZ = TZ_, TY = TY_;
+    static constexpr bool PXM = PXM_;
+    static constexpr int KS = CK / 4;
+    static constexpr int MT = PXM ? 1 : (COUT + 15) / 16;
+    static constexpr int XT = 17, YT = TY + 1, ZT = TZ + 1;
+    static constexpr int NVOX = ZT * YT * XT;
+    static constexpr int PLANE = (CK == 16) ? round_up_c(NVOX, 16) : round_up_c(NVOX, 32) + 16;
+    static constexpr int NCHUNK = CIN / CK;
+    static constexpr int ROWS = TZ * TY;
+    static constexpr int RPW = ROWS / 4;
+    static constexpr int NCLS = PXM ? 4 : 8;
+    static constexpr int NCT = PXM ? 18 : 27;
+    static constexpr int LDS_FLOATS = 4 * PLANE * KS;
+    static_assert(CIN % CK == 0 && ROWS % 4 == 0, "bad deconv tile");
+    static_assert(!PXM || COUT == 8, "x-parity merge is the Cout=8 form");
+};
+
+// per-dimension tap t of parity p -> (kernel index k, input offset d)
+__host__ __device__ constexpr int dc_k(int p, int t) { return p == 0 ? 1 : (t == 0 ? 2 : 0); }
+__host__ __device__ constexpr int dc_d(int p, int t) { return (p == 1 && t == 1) ? 1 : 0; }
+
+template <class Cfg>
+__global__ __launch_bounds__(256) void deconv3d_mfma_kernel(ConvArgs a) {
+    constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, CK = Cfg::CK, KS = Cfg::KS, MT = Cfg::MT;
+    constexpr int RPW = Cfg::RPW, TY = Cfg::TY, TZ = Cfg::TZ, XT = Cfg::XT, YT = Cfg::YT;
+    constexpr int NVOX = Cfg::NVOX, PLANE = Cfg::PLANE, NCT = Cfg::NCT, NCLS = Cfg::NCLS;
+    constexpr bool PXM = Cfg::PXM;
+    __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = lane & 15, kq = lane >> 4;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y; bid /= a.tiles_y;
+    const int tz = bid % a.tiles_z;
+    const int b = bid / a.tiles_z;
+    const int jx0 = tx * 16, jy0 = ty * TY, jz0 = tz * TZ;
+
+    f32x4 acc[NCLS][RPW][MT];
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[c][r][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float *in_b = a.in + (int64_t)b * a.D * a.H * a.W * CIN;
+    const int rd_base = (kq * PLANE + n) * KS;
+
+#pragma unroll 1
+    for (int ch = 0; ch < Cfg::NCHUNK; ++ch) {
+        if (ch) __syncthreads();
+        for (int e = tid; e < 4 * NVOX; e += 256) {
+            const int ekq = e / NVOX, v = e - ekq * NVOX;
+            const int lx = v % XT, t2 = v / XT;
+            const int ly = t2 % YT, lz = t2 / YT;
+            const int gx = jx0 + lx, gy = jy0 + ly, gz = jz0 + lz;
+            const bool ok = gx < a.W && gy < a.H && gz < a.D;
+            const int cx = min(gx, a.W - 1), cy = min(gy, a.H - 1), cz = min(gz, a.D - 1);
+            const float *src =
+                in_b + (((int64_t)cz * a.H + cy) * a.W + cx) * CIN + ch * CK + ekq * KS;
+            float *dst = lds + (ekq * PLANE + v) * KS;
+            if constexpr (KS == 4) {
+                float4 val = *reinterpret_cast<const float4 *>(src);
+                val.x = ok ? val.x : 0.f; val.y = ok ? val.y : 0.f;
+                val.z = ok ? val.z : 0.f; val.w = ok ? val.w : 0.f;
+                *reinterpret_cast<float4 *>(dst) = val;
+            } else {
+                float2 val = *reinterpret_cast<const float2 *>(src);
+                val.x = ok ? val.x : 0.f; val.y = ok ? val.y : 0.f;
+                *reinterpret_cast<float2 *>(dst) = val;
+            }
+        }
+        __syncthreads();
+
+        const float *wch = a.wpk + (int64_t)ch * NCT * MT * 64 * KS + lane * KS;
+        int ct = 0;  // compile-time after unrolling
+#pragma unroll
+        for (int pz = 0; pz < 2; ++pz)
+#pragma unroll
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int px = 0; px < (PXM ? 1 : 2); ++px) {
+                    const int cls = (pz * 2 + py) * (PXM ? 1 : 2) + px;
+#pragma unroll
+                    for (int tzz = 0; tzz <= pz; ++tzz)
+#pragma unroll
+                        for (int tyy = 0; tyy <= py; ++tyy)
+#pragma unroll
+                            for (int txx = 0; txx <= (PXM ? 1 : px); ++txx) {
+                                const int dz = dc_d(pz, tzz), dy = dc_d(py, tyy);
+                                const int dx = PXM ? txx : dc_d(px, txx);
+                                float af[MT][KS];
+#pragma unroll
+                                for (int m = 0; m < MT; ++m) {
+                                    const float *wp = wch + (ct * MT + m) * 64 * KS;
+                                    if constexpr (KS == 4) {
+                                        float4 t = *reinterpret_cast<const float4 *>(wp);
+                                        af[m][0] = t.x; af[m][1] = t.y; af[m][2] = t.z; af[m][3] = t.w;
+                                    } else {
+                                        float2 t = *reinterpret_cast<const float2 *>(wp);
+                                        af[m][0] = t.x; af[m][1] = t.y;
+                                    }
+                                }
+#pragma unroll
+                                for (int r = 0; r < RPW; ++r) {
+                                    const int row = wv * RPW + r;
+                                    const int zr = row / TY, yr = row % TY;
+                                    const float *rp =
+                                        lds + rd_base + (((zr + dz) * YT + (yr + dy)) * XT + dx) * KS;
+                                    float bf[KS];
+                                    if constexpr (KS == 4) {
+                                        float4 t = *reinterpret_cast<const float4 *>(rp);
+                                        bf[0] = t.x; bf[1] = t.y; bf[2] = t.z; bf[3] = t.w;
+                                    } else {
+                                        float2 t = *reinterpret_cast<const float2 *>(rp);
+                                        bf[0] = t.x; bf[1] = t.y;
+                                    }
+#pragma unroll
+                                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                                        for (int s = 0; s < KS; ++s)
+                                            acc[cls][r][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                                af[m][s], bf[s], acc[cls][r][m], 0, 0, 0);
+                                }
+                                ++ct;
+                            }
+                }
+    }
+
+#pragma unroll
+    for (int pz = 0; pz < 2; ++pz)
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < (PXM ? 1 : 2); ++px) {
+                const int cls = (pz * 2 + py) * (PXM ? 1 : 2) + px;
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) {
+                    const int row = wv * RPW + r;
+                    const int jz = jz0 + row / TY, jy = jy0 + row % TY, jx = jx0 + n;
+                    if (jz >= a.D || jy >= a.H || jx >= a.W) continue;
+                    const int oz = 2 * jz + pz, oy = 2 * jy + py;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const int ox = 2 * jx + (PXM ? (kq >> 1) : px);
+                        const int c0 = PXM ? (kq & 1) * 4 : m * 16 + kq * 4;
+                        if (c0 >= COUT) continue;
+                        f32x4 v = acc[cls][r][m];
+                        if (a.scale) {
+                            const float4 sc = *reinterpret_cast<const float4 *>(a.scale + c0);
+                            v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
+                        }
+                        if (a.shift) {
+                            const float4 sh = *reinterpret_cast<const float4 *>(a.shift + c0);
+                            v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w;
+                        }
+                        if (a.relu) {
+                            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+                            v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                        }
+                        const int64_t o =
+                            ((((int64_t)b * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * COUT + c0;
+                        if (a.residual) {
+                            const float4 rs = *reinterpret_cast<const float4 *>(a.residual + o);
+                            v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
+                        }
+                        *reinterpret_cast<float4 *>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+            }
+}
+
+// ---------------------------------------------------------------------
+// Cout = 1 convolution (the `prob` layer, mvsnet.py:81,92: 8 -> 1 with bias).
+// One output channel cannot fill an MFMA tile, and the layer is HBM-bound
+// anyway (727 MB in, 91 MB out at config 2), so it runs on the VALU from an LDS
+// halo tile: thread (x,y) of a 32x8 tile produces 4 outputs along z and reads
+// every staged voxel once for all of them; weights are wave-uniform (SGPRs).
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3d_cout1_kernel(ConvArgs a, const float *__restrict__ w) {
+    constexpr int CQ = CIN / 4, TX = 32, TY = 8, TZ = 4;
+    constexpr int XT = TX + 2, YT = TY + 2, ZT = TZ + 2, NVOX = ZT * YT * XT;
+    constexpr int PLANE = round_up_c(NVOX, 16);
+    __shared__ __attribute__((aligned(16))) float lds[CQ * PLANE * 4];
+    const int tid = threadIdx.x, lx = tid & 31, ly = tid >> 5;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y; bid /= a.tiles_y;
+    const int tz = bid % a.tiles_z;
+    const int b = bid / a.tiles_z;
+    const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
+    const float *in_b = a.in + (int64_t)b * a.D * a.H * a.W * CIN;
+    for (int e = tid; e < CQ * NVOX; e += 256) {
+        const int q = e / NVOX, v = e - q * NVOX;
+        const int vx = v % XT, t2 = v / XT, vy = t2 % YT, vz = t2 / YT;
+        const int gx = x0 + vx - 1, gy = y0 + vy - 1, gz = z0 + vz - 1;
+        const bool ok = gx >= 0 && gx < a.W && gy >= 0 && gy < a.H && gz >= 0 && gz < a.D;
+        const int cx = min(max(gx, 0), a.W - 1), cy = min(max(gy, 0), a.H - 1);
+        const int cz = min(max(gz, 0), a.D - 1);
+        float4 val = *reinterpret_cast<const float4 *>(
+            in_b + (((int64_t)cz * a.H + cy) * a.W + cx) * CIN + q * 4);
+        val.x = ok ? val.x : 0.f; val.y = ok ? val.y : 0.f;
+        val.z = ok ? val.z : 0.f; val.w = ok ? val.w : 0.f;
+        *reinterpret_cast<float4 *>(lds + (q * PLANE + v) * 4) = val;
+    }
+    __syncthreads();
+    float acc[TZ];
+#pragma unroll
+    for (int z = 0; z < TZ; ++z) acc[z] = 0.f;
+    // runtime loop over the 9 (ky,kx) taps keeps only 3*CIN wave-uniform weights
+    // live (SGPRs) at a time; dz, q, z are unrolled with immediate LDS offsets
+#pragma unroll 1
+    for (int kyx = 0; kyx < 9; ++kyx) {
+        const int ky = kyx / 3, kx = kyx - ky * 3;
+        float wk[3][CIN];
+#pragma unroll
+        for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) wk[kz][ci] = w[ci * 27 + kz * 9 + kyx];  // (1,CIN,3,3,3)
+        const float *lp = lds + ((ly + ky) * XT + lx + kx) * 4;
+#pragma unroll
+        for (int dz = 0; dz < ZT; ++dz)
+#pragma unroll
+            for (int q = 0; q < CQ; ++q) {
+                const float4 t = *reinterpret_cast<const float4 *>(lp + (q * PLANE + dz * YT * XT) * 4);
+#pragma unroll
+                for (int z = 0; z < TZ; ++z) {
+                    const int kz = dz - z;
+                    if (kz < 0 || kz > 2) continue;
+                    acc[z] = fmaf(t.x, wk[kz][q * 4 + 0], acc[z]);
+                    acc[z] = fmaf(t.y, wk[kz][q * 4 + 1], acc[z]);
+                    acc[z] = fmaf(t.z, wk[kz][q * 4 + 2], acc[z]);
+                    acc[z] = fmaf(t.w, wk[kz][q * 4 + 3], acc[z]);
+                }
+            }
+    }
+    const int ox = x0 + lx, oy = y0 + ly;
+    if (ox >= a.Wo || oy >= a.Ho) return;
+#pragma unroll
+    for (int z = 0; z < TZ; ++z) {
+        const int oz = z0 + z;
+        if (oz >= a.Do) continue;
+        float v = acc[z];
+        if (a.scale) v *= a.scale[0];
+        if (a.shift) v += a.shift[0];
+        if (a.relu) v = fmaxf(v, 0.f);
+        const int64_t o = (((int64_t)b * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
+        if (a.residual) v += a.residual[o];
+        a.out[o] = v;
+    }
+}
+
+// ---------------------------------------------------------------------
+// Weight packing: PyTorch layout -> A-fragment order
 // packed[ch][tap][mt][lane][s], lane = (m = lane&15, kq = lane>>4),
 // input channel = ch*CK + kq*KS + s.
 struct PackArgs {
     const float *w;
     float *packed;
-    int Cin, Cout, mode, ck, mt;
+    int Cin, Cout, mode, ck, mt, ntaps;   // mode 0/1/2 conv, 3 deconv, 4 deconv x-parity-merged
 };
 
 __global__ __launch_bounds__(256) void conv3d_pack_kernel(PackArgs p, int64_t total) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int KS = p.ck / 4;
-    const int NKX = p.mode == 2 ? 4 : 3;
-    const int NTAPS = 9 * NKX;
     int64_t t = i;
     const int s = (int)(t % KS); t /= KS;
     const int lane = (int)(t % 64); t /= 64;
     const int mt = (int)(t % p.mt); t /= p.mt;
-    const int tap = (int)(t % NTAPS); t /= NTAPS;
+    const int tap = (int)(t % p.ntaps); t /= p.ntaps;
     const int ch = (int)t;
     const int m = lane & 15, kq = lane >> 4;
     const int cin = ch * p.ck + kq * KS + s;
-    const int kz = tap / (3 * NKX), ky = (tap / NKX) % 3, kxp = tap % NKX;
     float val = 0.0f;
-    if (p.mode == 2) {
-        const int sft = m >> 3, co = m & 7, kx = kxp - sft;
-        if (kx >= 0 && kx <= 2)
-            val = p.w[((int64_t)co * p.Cin + cin) * 27 + kz * 9 + ky * 3 + kx];
+    if (p.mode <= 2) {
+        const int NKX = p.mode == 2 ? 4 : 3;
+        const int kz = tap / (3 * NKX), ky = (tap / NKX) % 3, kxp = tap % NKX;
+        if (p.mode == 2) {
+            const int sft = m >> 3, co = m & 7, kx = kxp - sft;
+            if (kx >= 0 && kx <= 2)
+                val = p.w[((int64_t)co * p.Cin + cin) * 27 + kz * 9 + ky * 3 + kx];
+        } else {
+            const int co = mt * 16 + m;
+            if (co < p.Cout) val = p.w[((int64_t)co * p.Cin + cin) * 27 + kz * 9 + ky * 3 + kxp];
+        }
     } else {
-        const int co = mt * 16 + m;
-        if (co < p.Cout) val = p.w[((int64_t)co * p.Cin + cin) * 27 + kz * 9 + ky * 3 + kxp];
+        const bool pxm = p.mode == 4;
+        int ct = 0, kz = -1, ky = -1, kx = -1;
+        bool found = false;
+        for (int pz = 0; pz < 2 && !found; ++pz)
+            for (int py = 0; py < 2 && !found; ++py)
+                for (int px = 0; px < (pxm ? 1 : 2) && !found; ++px)
+                    for (int tz = 0; tz <= pz && !found; ++tz)
+                        for (int ty = 0; ty <= py && !found; ++ty)
+                            for (int tx = 0; tx <= (pxm ? 1 : px) && !found; ++tx) {
+                                if (ct == tap) {
+                                    kz = dc_k(pz, tz);
+                                    ky = dc_k(py, ty);
+                                    if (pxm) {
+                                        const int prow = m >> 3;   // x parity of this MFMA row
+                                        kx = prow == 0 ? (tx == 0 ? 1 : -1) : (tx == 0 ? 2 : 0);
+                                    } else {
+                                        kx = dc_k(px, tx);
+                                    }
+                                    found = true;
+                                }
+                                ++ct;
+                            }
+        const int co = pxm ? (m & 7) : mt * 16 + m;
+        if (found && kx >= 0 && co < p.Cout)   // weight (Cin,Cout,3,3,3)
+            val = p.w[((int64_t)cin * p.Cout + co) * 27 + kz * 9 + ky * 3 + kx];
     }
     p.packed[i] = val;
 }
@@ -267,15 +565,32 @@ static CfgInfo info_of() {
                    conv3d_mfma_kernel<Cfg>};
 }
 
+template <class Cfg>
+static CfgInfo dinfo_of() {
+    return CfgInfo{Cfg::PXM ? 4 : 3, Cfg::CK, Cfg::MT, Cfg::TZ, Cfg::TY, 16, Cfg::NCT,
+                   deconv3d_mfma_kernel<Cfg>};
+}
+
 static bool lookup(int transposed, int Cin, int Cout, int stride, CfgInfo &ci) {
-    if (transposed) return false;
 #define MVS_CFG(cin, cout, mode, ck, tz, ty)                       \
     if (Cin == cin && Cout == cout) {                              \
         ci = info_of<ConvCfg<cin, cout, mode, ck, tz, ty>>();      \
         return true;                                               \
     }
+#define MVS_DCFG(cin, cout, ck, tz, ty, pxm)                       \
+    if (Cin == cin && Cout == cout) {                              \
+        ci = dinfo_of<DeconvCfg<cin, cout, ck, tz, ty, pxm>>();    \
+        return true;                                               \
+    }
+    if (transposed) {
+        if (stride != 2) return false;
+        MVS_DCFG(64, 32, 16, 2, 4, false)
+        MVS_DCFG(32, 16, 16, 2, 8, false)
+        MVS_DCFG(16, 8, 16, 4, 8, true)
+        return false;
+    }
     if (stride == 1) {
-        // Cout = 8: shifted form (conv0 of MVSNet / CasMVSNet stages / CVP-free)
+        // Cout = 8: shifted form (conv0 of MVSNet / of the CasMVSNet stages)
         MVS_CFG(32, 8, 2, 8, 4, 8)
         MVS_CFG(16, 8, 2, 8, 4, 8)
         MVS_CFG(8, 8, 2, 8, 4, 8)
@@ -291,16 +606,22 @@ static bool lookup(int transposed, int Cin, int Cout, int stride, CfgInfo &ci) {
         MVS_CFG(32, 64, 1, 8, 2, 4)
     }
 #undef MVS_CFG
+#undef MVS_DCFG
     return false;
+}
+
+static bool is_cout1(int transposed, int Cin, int Cout, int stride) {
+    return !transposed && stride == 1 && Cout == 1 && (Cin == 8 || Cin == 16);
 }
 
 int conv3d_mfma_supported(int transposed, int Cin, int Cout, int stride) {
     CfgInfo ci;
-    return lookup(transposed, Cin, Cout, stride, ci) ? 1 : 0;
+    return (lookup(transposed, Cin, Cout, stride, ci) || is_cout1(transposed, Cin, Cout, stride)) ? 1 : 0;
 }
 
 int64_t conv3d_packed_floats(int transposed, int Cin, int Cout, int stride) {
     CfgInfo ci;
+    if (is_cout1(transposed, Cin, Cout, stride)) return (int64_t)Cin * 27;  // used as is
     if (!lookup(transposed, Cin, Cout, stride, ci)) return 0;
     return (int64_t)(Cin / ci.ck) * ci.ntaps * ci.mt * 64 * (ci.ck / 4);
 }
@@ -308,12 +629,18 @@ int64_t conv3d_packed_floats(int transposed, int Cin, int Cout, int stride) {
 int conv3d_pack_launch(const float *weight, int transposed, int Cin, int Cout, int stride,
                        float *packed, hipStream_t st) {
     CfgInfo ci;
+    if (is_cout1(transposed, Cin, Cout, stride)) {
+        if (hipMemcpyAsync(packed, weight, sizeof(float) * (size_t)Cin * 27,
+                           hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return check_launch("mvs_conv3d_pack_weights_f32(copy)");
+        return MVS_OK;
+    }
     if (!lookup(transposed, Cin, Cout, stride, ci)) {
-        set_error("mvs_conv3d_pack_weights_f32: no MFMA configuration for %s Cin=%d Cout=%d stride=%d",
+        set_error("mvs_conv3d_pack_weights_f32: no fast-path configuration for %s Cin=%d Cout=%d stride=%d",
                   transposed ? "deconv" : "conv", Cin, Cout, stride);
         return MVS_EUNSUPPORTED;
     }
-    PackArgs p{weight, packed, Cin, Cout, ci.mode, ci.ck, ci.mt};
+    PackArgs p{weight, packed, Cin, Cout, ci.mode, ci.ck, ci.mt, ci.ntaps};
     const int64_t total = conv3d_packed_floats(transposed, Cin, Cout, stride);
     hipLaunchKernelGGL(conv3d_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                        p, total);
@@ -324,21 +651,39 @@ int conv3d_mfma_launch(const float *in, const float *packed, const float *scale,
                        const float *shift, const float *residual, int relu, int transposed, int B,
                        int Cin, int Cout, int D, int H, int W, int stride, float *out,
                        hipStream_t st) {
+    ConvArgs a;
+    a.in = in; a.wpk = packed; a.scale = scale; a.shift = shift; a.residual = residual;
+    a.out = out;
+    a.B = B; a.D = D; a.H = H; a.W = W;
+    a.relu = relu;
+    if (is_cout1(transposed, Cin, Cout, stride)) {
+        a.Do = D; a.Ho = H; a.Wo = W;
+        a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 7) / 8; a.tiles_z = (D + 3) / 4;
+        const int64_t nblk = (int64_t)B * a.tiles_x * a.tiles_y * a.tiles_z;
+        if (nblk <= 0 || nblk > 0x7fffffffLL) return MVS_EINVAL;
+        if (Cin == 8)
+            hipLaunchKernelGGL(conv3d_cout1_kernel<8>, dim3((unsigned)nblk), dim3(256), 0, st, a, packed);
+        else
+            hipLaunchKernelGGL(conv3d_cout1_kernel<16>, dim3((unsigned)nblk), dim3(256), 0, st, a, packed);
+        return check_launch("mvs_conv3d_f32(cout1)");
+    }
     CfgInfo ci;
     if (!lookup(transposed, Cin, Cout, stride, ci)) {
         set_error("mvs_conv3d_f32(mfma): no configuration for %s Cin=%d Cout=%d stride=%d",
                   transposed ? "deconv" : "conv", Cin, Cout, stride);
         return MVS_EUNSUPPORTED;
     }
-    ConvArgs a;
-    a.in = in; a.wpk = packed; a.scale = scale; a.shift = shift; a.residual = residual;
-    a.out = out;
-    a.B = B; a.D = D; a.H = H; a.W = W;
-    a.Do = (D - 1) / stride + 1; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;
-    a.tiles_x = (a.Wo + ci.xout - 1) / ci.xout;
-    a.tiles_y = (a.Ho + ci.ty - 1) / ci.ty;
-    a.tiles_z = (a.Do + ci.tz - 1) / ci.tz;
-    a.relu = relu;
+    if (transposed) {
+        a.Do = D * 2; a.Ho = H * 2; a.Wo = W * 2;
+        a.tiles_x = (W + 15) / 16;          // tiles on the INPUT grid
+        a.tiles_y = (H + ci.ty - 1) / ci.ty;
+        a.tiles_z = (D + ci.tz - 1) / ci.tz;
+    } else {
+        a.Do = (D - 1) / stride + 1; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;
+        a.tiles_x = (a.Wo + ci.xout - 1) / ci.xout;
+        a.tiles_y = (a.Ho + ci.ty - 1) / ci.ty;
+        a.tiles_z = (a.Do + ci.tz - 1) / ci.tz;
+    }
     const int64_t nblk = (int64_t)B * a.tiles_x * a.tiles_y * a.tiles_z;
     if (nblk <= 0 || nblk > 0x7fffffffLL) {
         set_error("mvs_conv3d_f32(mfma): bad grid");

@@ -14,6 +14,15 @@ namespace mvs {
 
 constexpr int kMaxSrcViews = 8;
 
+__device__ __forceinline__ float4 sel4(bool keep, float4 v) {
+    return make_float4(keep ? v.x : 0.f, keep ? v.y : 0.f, keep ? v.z : 0.f, keep ? v.w : 0.f);
+}
+// value at idx if idx >= 0 else 0, without a branch around the load
+__device__ __forceinline__ float ldz(const float *__restrict__ p, int idx) {
+    float v = p[max(idx, 0)];
+    return idx >= 0 ? v : 0.0f;
+}
+
 struct SweepParams {
     int B, C, D, H, W, V;     // V = total views (ref + sources)
     int depth_mode;           // 0: [B,D]   1: [B,D,H,W]
@@ -57,10 +66,10 @@ __global__ __launch_bounds__(256) void warp_fwd_planar_kernel(
     float *op = out + (((int64_t)b * p.C) * p.D + d) * plane + pix;
     for (int c = 0; c < p.C; ++c) {
         const float *pl = sp + (int64_t)c * plane;
-        float v00 = m00 ? pl[o00] : 0.0f;
-        float v01 = m01 ? pl[o01] : 0.0f;
-        float v10 = m10 ? pl[o10] : 0.0f;
-        float v11 = m11 ? pl[o11] : 0.0f;
+        float v00 = pl[o00]; v00 = m00 ? v00 : 0.0f;
+        float v01 = pl[o01]; v01 = m01 ? v01 : 0.0f;
+        float v10 = pl[o10]; v10 = m10 ? v10 : 0.0f;
+        float v11 = pl[o11]; v11 = m11 ? v11 : 0.0f;
         op[(int64_t)c * p.D * plane] = blend(t, v00, v01, v10, v11);
     }
 }
@@ -146,10 +155,10 @@ __global__ __launch_bounds__(256) void variance_fwd_planar_kernel(
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const float *pl = sp + (int64_t)v * view_stride + (int64_t)c * plane;
-            float v00 = o00[v] >= 0 ? pl[o00[v]] : 0.0f;
-            float v01 = o01[v] >= 0 ? pl[o01[v]] : 0.0f;
-            float v10 = o10[v] >= 0 ? pl[o10[v]] : 0.0f;
-            float v11 = o11[v] >= 0 ? pl[o11[v]] : 0.0f;
+            float v00 = ldz(pl, o00[v]);
+            float v01 = ldz(pl, o01[v]);
+            float v10 = ldz(pl, o10[v]);
+            float v11 = ldz(pl, o11[v]);
             float w = __fmaf_rn(v11, wse[v],
                                 __fmaf_rn(v10, wsw[v], __fmaf_rn(v01, wne[v], v00 * wnw[v])));
             s = s + w;
@@ -214,7 +223,6 @@ __global__ __launch_bounds__(256) void variance_fwd_cl_kernel(
     const int q4 = (lane % CQ) * 4;  // first channel of this lane's quad
     const int vsub = lane / CQ;
     const int64_t view_stride = (int64_t)p.B * plane * C;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 1
     for (int step = 0; step < CQ; ++step) {
         const int j = step * VPS + vsub;  // voxel slot within the wave
@@ -231,10 +239,13 @@ __global__ __launch_bounds__(256) void variance_fwd_cl_kernel(
             const float4 w = s_w[wv][v][j];
             const int4 o = s_o[wv][v][j];
             const float *sv = sb + (int64_t)v * view_stride;
-            float4 a = o.x >= 0 ? *reinterpret_cast<const float4 *>(sv + (int64_t)o.x * C) : zero4;
-            float4 bq = o.y >= 0 ? *reinterpret_cast<const float4 *>(sv + (int64_t)o.y * C) : zero4;
-            float4 c = o.z >= 0 ? *reinterpret_cast<const float4 *>(sv + (int64_t)o.z * C) : zero4;
-            float4 e = o.w >= 0 ? *reinterpret_cast<const float4 *>(sv + (int64_t)o.w * C) : zero4;
+            // branch-free gathers: always load from a clamped texel, then mask
+            float4 a = *reinterpret_cast<const float4 *>(sv + (int64_t)max(o.x, 0) * C);
+            float4 bq = *reinterpret_cast<const float4 *>(sv + (int64_t)max(o.y, 0) * C);
+            float4 c = *reinterpret_cast<const float4 *>(sv + (int64_t)max(o.z, 0) * C);
+            float4 e = *reinterpret_cast<const float4 *>(sv + (int64_t)max(o.w, 0) * C);
+            a = sel4(o.x >= 0, a); bq = sel4(o.y >= 0, bq);
+            c = sel4(o.z >= 0, c); e = sel4(o.w >= 0, e);
             float t0 = __fmaf_rn(e.x, w.w, __fmaf_rn(c.x, w.z, __fmaf_rn(bq.x, w.y, a.x * w.x)));
             float t1 = __fmaf_rn(e.y, w.w, __fmaf_rn(c.y, w.z, __fmaf_rn(bq.y, w.y, a.y * w.x)));
             float t2 = __fmaf_rn(e.z, w.w, __fmaf_rn(c.z, w.z, __fmaf_rn(bq.z, w.y, a.z * w.x)));
@@ -297,10 +308,10 @@ __global__ __launch_bounds__(256) void variance_bwd_planar_kernel(
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const float *pl = srcs + (int64_t)v * view_stride + fo;
-            float v00 = o00[v] >= 0 ? pl[o00[v]] : 0.0f;
-            float v01 = o01[v] >= 0 ? pl[o01[v]] : 0.0f;
-            float v10 = o10[v] >= 0 ? pl[o10[v]] : 0.0f;
-            float v11 = o11[v] >= 0 ? pl[o11[v]] : 0.0f;
+            float v00 = ldz(pl, o00[v]);
+            float v01 = ldz(pl, o01[v]);
+            float v10 = ldz(pl, o10[v]);
+            float v11 = ldz(pl, o11[v]);
             w[v] = __fmaf_rn(v11, wse[v],
                              __fmaf_rn(v10, wsw[v], __fmaf_rn(v01, wne[v], v00 * wnw[v])));
             s += w[v];

@@ -1,0 +1,190 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol
+include/mvs_hip.h declares, the Python mirror keeps the reference's surface and
+state_dict layout, host logic (sharding, flat gradient all-reduce over gloo with
+world_size 2), and bench.py's algorithmic work equals BASELINE.md section 3.
+No compute kernel is launched here."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, load_golden
+
+
+def test_library_exports_every_declared_symbol():
+    from mvs_amd import _lib
+    hdr = open(os.path.join(REPO, "include", "mvs_hip.h")).read()
+    declared = set(re.findall(r"\b(mvs_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 15
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in mvs_hip.h but not exported"
+    assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
+    assert lib.mvs_version() >= 100
+    assert lib.mvs_arch() == b"gfx950"
+
+
+def test_only_hip_runtime_of_the_process_is_torchs():
+    from mvs_amd import _lib
+    _lib.load()
+    maps = open("/proc/self/maps").read()
+    hips = {ln.split()[-1] for ln in maps.splitlines() if "libamdhip64" in ln}
+    assert len(hips) == 1, hips   # one HIP runtime: pointers/streams are shared with torch
+
+
+def test_ops_fail_loudly_without_device_tensors():
+    from mvs_amd import ops
+    from mvs_amd._lib import MvsHipError
+    with pytest.raises(MvsHipError):
+        ops.softmax_regress_conf(torch.zeros(1, 4, 2, 2), torch.zeros(1, 4))
+    with pytest.raises(MvsHipError):
+        ops.costvol_variance_cl(torch.zeros(1, 4, 4, 8), torch.zeros(1, 1, 4, 4, 8),
+                                torch.zeros(1, 1, 12), torch.zeros(1, 2))
+
+
+def test_missing_library_is_an_error(monkeypatch, tmp_path):
+    from mvs_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.MvsHipError):
+        _lib.load()
+
+
+def test_mfma_config_table():
+    from mvs_amd import _lib
+    lib = _lib.load()
+    for cin, cout, s in ((32, 8, 1), (8, 16, 2), (16, 16, 1), (16, 32, 2), (32, 32, 1),
+                         (32, 64, 2), (64, 64, 1)):
+        assert lib.mvs_conv3d_mfma_supported(0, cin, cout, s) == 1
+        assert lib.mvs_conv3d_packed_weight_floats(0, cin, cout, s) >= 27 * cin * cout
+    assert lib.mvs_conv3d_mfma_supported(0, 5, 7, 1) == 0
+    assert lib.mvs_conv3d_packed_weight_floats(0, 5, 7, 1) == 0
+
+
+def test_state_dict_layout_matches_reference(weights):
+    from mvs_amd.models import MVSNet, load_reference_checkpoint
+    model = MVSNet(refine=False)
+    assert set(model.state_dict().keys()) == set(weights.keys())
+    for k, v in model.state_dict().items():
+        assert tuple(v.shape) == tuple(weights[k].shape), k
+    assert sum(p.numel() for p in model.parameters()) == 338129
+    assert sum(p.numel() for p in model.cost_regularization.parameters()) == 298009
+    ckpt = {"epoch": 3, "model": {"module." + k: torch.from_numpy(v) for k, v in weights.items()}}
+    load_reference_checkpoint(model, ckpt)          # DataParallel-prefixed (train.py:159-164)
+    np.testing.assert_array_equal(model.feature.feature.bias.detach().numpy(),
+                                  weights["feature.feature.bias"])
+    assert set(MVSNet(refine=True).state_dict()) > set(weights)
+
+
+def test_python_surface():
+    import inspect
+    from mvs_amd import models
+    for name in ("MVSNet", "mvsnet_loss", "homo_warping", "depth_regression"):
+        assert hasattr(models, name)
+    sig = inspect.signature(models.homo_warping)
+    assert list(sig.parameters)[:4] == ["src_fea", "src_proj", "ref_proj", "depth_values"]
+    p = torch.softmax(torch.randn(2, 5, 3, 4), 1)
+    dv = torch.linspace(400, 900, 5).repeat(2, 1)
+    np.testing.assert_allclose(models.depth_regression(p, dv).numpy(),
+                               (p * dv.view(2, 5, 1, 1)).sum(1).numpy())
+    est, gt = torch.tensor([1.0, 5.0, 2.0]), torch.tensor([1.5, 2.0, 2.0])
+    loss = models.mvsnet_loss(est, gt, torch.tensor([1.0, 1.0, 0.0]))
+    assert loss.item() == pytest.approx((0.5 * 0.25 + 2.5) / 2)
+
+
+def test_synthetic_geometry():
+    from mvs_amd import synth
+    P = synth.proj_matrices(5, 296, 400)[0].astype(np.float64)
+    tgt = np.array([0, 0, synth.DTU_TARGET_Z, 1.0])
+    for v in range(5):                       # every camera looks at the target point
+        uvw = P[v] @ tgt
+        u, vv = uvw[0] / uvw[2], uvw[1] / uvw[2]
+        assert abs(u - synth.DTU_CX / 4) < 1e-3 and abs(vv - synth.DTU_CY / 4) < 1e-3
+    dv = synth.depth_values(192)
+    assert dv.shape == (1, 192) and dv[0, 0] == 425.0
+    assert abs(dv[0, -1] - (425 + 2.65 * 191)) < 1e-3
+
+
+def test_bench_algorithmic_work_matches_baseline_md():
+    sys.path.insert(0, REPO)
+    import bench
+    work = bench.algorithmic_work(5, 32, 192, 296, 400)
+    assert abs(work["costvol_variance"][1] / 1e9 - 2.986) < 2e-3
+    assert abs(work["softmax_regress_conf"][1] / 1e6 - 91.9) < 0.1
+    flops = sum(v for k, (kind, v) in work.items() if kind == "mfma")
+    assert abs(flops / 1e9 - 461.6) < 0.5
+    assert abs(work["costreg.conv0"][1] / 1e9 - 314.3) < 0.1
+
+
+def test_ref_view_sharding():
+    from mvs_amd.parallel import shard_ref_views
+    for world in (1, 2, 4, 8):
+        got = sorted(i for r in range(world) for i in shard_ref_views(49, r, world))
+        assert got == list(range(49))
+    assert shard_ref_views(49, 3, 8) == [3, 11, 19, 27, 35, 43]
+
+
+def _gloo_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from mvs_amd.parallel import (FlatGradAllReduce, broadcast_parameters, init_distributed,
+                                  reduce_scalars, shard_ref_views)
+    from mvs_amd.models import FeatureNet
+    init_distributed("gloo")
+    torch.manual_seed(100 + rank)            # different init per rank ...
+    net = FeatureNet()
+    broadcast_parameters(net, 0)             # ... made identical here
+    torch.manual_seed(0)
+    data = torch.rand(4, 3, 16, 16)          # the global batch, same on every rank
+    mine = shard_ref_views(4, rank, world)
+    net.train()
+    loss = net(data[mine]).square().mean()
+    loss.backward()
+    FlatGradAllReduce(net.parameters())()
+    flat = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    sc = reduce_scalars({"loss": loss.item()})
+    q.put((rank, flat.numpy(), torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy(),
+           sc))
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_gloo_world2():
+    """world_size-2 data-parallel step over gloo: averaged gradients are
+    identical on both ranks and equal the mean of the per-shard gradients."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29000 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, g0, w0, s0), (_, g1, w1, s1) = res
+    np.testing.assert_array_equal(w0, w1)
+    np.testing.assert_array_equal(g0, g1)
+    assert np.abs(g0).max() > 0
+    assert "loss" in s0
+    # single-process check of the same average
+    from mvs_amd.models import FeatureNet
+    net = FeatureNet()
+    off = 0
+    with torch.no_grad():
+        for p in net.parameters():
+            p.copy_(torch.from_numpy(w0[off:off + p.numel()]).reshape(p.shape))
+            off += p.numel()
+    torch.manual_seed(0)
+    data = torch.rand(4, 3, 16, 16)
+    net.train()
+    grads = []
+    for shard in ([0, 2], [1, 3]):
+        net.zero_grad()
+        net(data[shard]).square().mean().backward()
+        grads.append(torch.cat([p.grad.reshape(-1) for p in net.parameters()]).numpy())
+    np.testing.assert_allclose(g0, (grads[0] + grads[1]) / 2, atol=1e-6)
