@@ -109,30 +109,51 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
 #pragma unroll 1
     for (int ch = 0; ch < Cfg::NCHUNK; ++ch) {
         if (ch) __syncthreads();
-        // ---- stage the halo tile of CK channels: global (channels-last) -> LDS planes
-        for (int e = tid; e < 4 * NVOX; e += 256) {
-            const int ekq = e / NVOX, v = e - ekq * NVOX;
-            const int lxp = v % XTP, t2 = v / XTP;
-            const int ly = t2 % YT, lz = t2 / YT;
-            const int lx = (SX == 2) ? (lxp < XH ? 2 * lxp : 2 * (lxp - XH) + 1) : lxp;
-            const int gx = ix0 + lx, gy = iy0 + ly, gz = iz0 + lz;
-            const bool ok = lx < XT && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H && gz >= 0 &&
-                            gz < a.D;
-            // branch-free: load from the clamped voxel, zero it afterwards if outside
-            const int cx = min(max(gx, 0), a.W - 1), cy = min(max(gy, 0), a.H - 1);
-            const int cz = min(max(gz, 0), a.D - 1);
-            const float *src =
-                in_b + (((int64_t)cz * a.H + cy) * a.W + cx) * CIN + ch * CK + ekq * KS;
-            float *dst = lds + (ekq * PLANE + v) * KS;
-            if constexpr (KS == 4) {
-                float4 val = *reinterpret_cast<const float4 *>(src);
-                val.x = ok ? val.x : 0.f; val.y = ok ? val.y : 0.f;
-                val.z = ok ? val.z : 0.f; val.w = ok ? val.w : 0.f;
-                *reinterpret_cast<float4 *>(dst) = val;
-            } else {
-                float2 val = *reinterpret_cast<const float2 *>(src);
-                val.x = ok ? val.x : 0.f; val.y = ok ? val.y : 0.f;
-                *reinterpret_cast<float2 *>(dst) = val;
+        // ---- stage the halo tile of CK channels: global (channels-last) -> LDS planes.
+        // Compile-time trip count, SB loads in flight per thread per batch (the
+        // volume streams from HBM: one load at a time is pure latency).
+        {
+            constexpr int NIT = (4 * NVOX + 255) / 256;
+            constexpr int SB = 8;
+#pragma unroll 1
+            for (int it0 = 0; it0 < NIT; it0 += SB) {
+                float stg[SB][KS];
+                int dsto[SB];
+#pragma unroll
+                for (int j = 0; j < SB; ++j) {
+                    const int e = tid + (it0 + j) * 256;
+                    const int ec = min(e, 4 * NVOX - 1);
+                    const int ekq = ec / NVOX, v = ec - ekq * NVOX;
+                    const int lxp = v % XTP, t2 = v / XTP;
+                    const int ly = t2 % YT, lz = t2 / YT;
+                    const int lx = (SX == 2) ? (lxp < XH ? 2 * lxp : 2 * (lxp - XH) + 1) : lxp;
+                    const int gx = ix0 + lx, gy = iy0 + ly, gz = iz0 + lz;
+                    const bool ok = lx < XT && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H &&
+                                    gz >= 0 && gz < a.D;
+                    const int cx = min(max(gx, 0), a.W - 1), cy = min(max(gy, 0), a.H - 1);
+                    const int cz = min(max(gz, 0), a.D - 1);
+                    const float *src =
+                        in_b + (((int64_t)cz * a.H + cy) * a.W + cx) * CIN + ch * CK + ekq * KS;
+                    dsto[j] = (e < 4 * NVOX && it0 + j < NIT) ? (ekq * PLANE + v) * KS : -1;
+                    if constexpr (KS == 4) {
+                        float4 val = *reinterpret_cast<const float4 *>(src);
+                        stg[j][0] = ok ? val.x : 0.f; stg[j][1] = ok ? val.y : 0.f;
+                        stg[j][2] = ok ? val.z : 0.f; stg[j][3] = ok ? val.w : 0.f;
+                    } else {
+                        float2 val = *reinterpret_cast<const float2 *>(src);
+                        stg[j][0] = ok ? val.x : 0.f; stg[j][1] = ok ? val.y : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < SB; ++j) {
+                    if (dsto[j] < 0) continue;
+                    float *dst = lds + dsto[j];
+                    if constexpr (KS == 4)
+                        *reinterpret_cast<float4 *>(dst) =
+                            make_float4(stg[j][0], stg[j][1], stg[j][2], stg[j][3]);
+                    else
+                        *reinterpret_cast<float2 *>(dst) = make_float2(stg[j][0], stg[j][1]);
+                }
             }
         }
         __syncthreads();
@@ -287,25 +308,45 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_kernel(ConvArgs a) {
 #pragma unroll 1
     for (int ch = 0; ch < Cfg::NCHUNK; ++ch) {
         if (ch) __syncthreads();
-        for (int e = tid; e < 4 * NVOX; e += 256) {
-            const int ekq = e / NVOX, v = e - ekq * NVOX;
-            const int lx = v % XT, t2 = v / XT;
-            const int ly = t2 % YT, lz = t2 / YT;
-            const int gx = jx0 + lx, gy = jy0 + ly, gz = jz0 + lz;
-            const bool ok = gx < a.W && gy < a.H && gz < a.D;
-            const int cx = min(gx, a.W - 1), cy = min(gy, a.H - 1), cz = min(gz, a.D - 1);
-            const float *src =
-                in_b + (((int64_t)cz * a.H + cy) * a.W + cx) * CIN + ch * CK + ekq * KS;
-            float *dst = lds + (ekq * PLANE + v) * KS;
-            if constexpr (KS == 4) {
-                float4 val = *reinterpret_cast<const float4 *>(src);
-                val.x = ok ? val.x : 0.f; val.y = ok ? val.y : 0.f;
-                val.z = ok ? val.z : 0.f; val.w = ok ? val.w : 0.f;
-                *reinterpret_cast<float4 *>(dst) = val;
-            } else {
-                float2 val = *reinterpret_cast<const float2 *>(src);
-                val.x = ok ? val.x : 0.f; val.y = ok ? val.y : 0.f;
-                *reinterpret_cast<float2 *>(dst) = val;
+        {
+            constexpr int NIT = (4 * NVOX + 255) / 256;
+            constexpr int SB = 8;
+#pragma unroll 1
+            for (int it0 = 0; it0 < NIT; it0 += SB) {
+                float stg[SB][KS];
+                int dsto[SB];
+#pragma unroll
+                for (int j = 0; j < SB; ++j) {
+                    const int e = tid + (it0 + j) * 256;
+                    const int ec = min(e, 4 * NVOX - 1);
+                    const int ekq = ec / NVOX, v = ec - ekq * NVOX;
+                    const int lx = v % XT, t2 = v / XT;
+                    const int ly = t2 % YT, lz = t2 / YT;
+                    const int gx = jx0 + lx, gy = jy0 + ly, gz = jz0 + lz;
+                    const bool ok = gx < a.W && gy < a.H && gz < a.D;
+                    const int cx = min(gx, a.W - 1), cy = min(gy, a.H - 1), cz = min(gz, a.D - 1);
+                    const float *src =
+                        in_b + (((int64_t)cz * a.H + cy) * a.W + cx) * CIN + ch * CK + ekq * KS;
+                    dsto[j] = (e < 4 * NVOX && it0 + j < NIT) ? (ekq * PLANE + v) * KS : -1;
+                    if constexpr (KS == 4) {
+                        float4 val = *reinterpret_cast<const float4 *>(src);
+                        stg[j][0] = ok ? val.x : 0.f; stg[j][1] = ok ? val.y : 0.f;
+                        stg[j][2] = ok ? val.z : 0.f; stg[j][3] = ok ? val.w : 0.f;
+                    } else {
+                        float2 val = *reinterpret_cast<const float2 *>(src);
+                        stg[j][0] = ok ? val.x : 0.f; stg[j][1] = ok ? val.y : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < SB; ++j) {
+                    if (dsto[j] < 0) continue;
+                    float *dst = lds + dsto[j];
+                    if constexpr (KS == 4)
+                        *reinterpret_cast<float4 *>(dst) =
+                            make_float4(stg[j][0], stg[j][1], stg[j][2], stg[j][3]);
+                    else
+                        *reinterpret_cast<float2 *>(dst) = make_float2(stg[j][0], stg[j][1]);
+                }
             }
         }
         __syncthreads();
@@ -428,18 +469,34 @@ __global__ __launch_bounds__(256) void conv3d_cout1_kernel(ConvArgs a, const flo
     const int b = bid / a.tiles_z;
     const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
     const float *in_b = a.in + (int64_t)b * a.D * a.H * a.W * CIN;
-    for (int e = tid; e < CQ * NVOX; e += 256) {
-        const int q = e / NVOX, v = e - q * NVOX;
-        const int vx = v % XT, t2 = v / XT, vy = t2 % YT, vz = t2 / YT;
-        const int gx = x0 + vx - 1, gy = y0 + vy - 1, gz = z0 + vz - 1;
-        const bool ok = gx >= 0 && gx < a.W && gy >= 0 && gy < a.H && gz >= 0 && gz < a.D;
-        const int cx = min(max(gx, 0), a.W - 1), cy = min(max(gy, 0), a.H - 1);
-        const int cz = min(max(gz, 0), a.D - 1);
-        float4 val = *reinterpret_cast<const float4 *>(
-            in_b + (((int64_t)cz * a.H + cy) * a.W + cx) * CIN + q * 4);
-        val.x = ok ? val.x : 0.f; val.y = ok ? val.y : 0.f;
-        val.z = ok ? val.z : 0.f; val.w = ok ? val.w : 0.f;
-        *reinterpret_cast<float4 *>(lds + (q * PLANE + v) * 4) = val;
+    {
+        constexpr int NIT = (CQ * NVOX + 255) / 256;
+        constexpr int SB = 8;
+#pragma unroll 1
+        for (int it0 = 0; it0 < NIT; it0 += SB) {
+            float4 stg[SB];
+            int dsto[SB];
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {
+                const int e = tid + (it0 + j) * 256;
+                const int ec = min(e, CQ * NVOX - 1);
+                const int q = ec / NVOX, v = ec - q * NVOX;
+                const int vx = v % XT, t2 = v / XT, vy = t2 % YT, vz = t2 / YT;
+                const int gx = x0 + vx - 1, gy = y0 + vy - 1, gz = z0 + vz - 1;
+                const bool ok = gx >= 0 && gx < a.W && gy >= 0 && gy < a.H && gz >= 0 && gz < a.D;
+                const int cx = min(max(gx, 0), a.W - 1), cy = min(max(gy, 0), a.H - 1);
+                const int cz = min(max(gz, 0), a.D - 1);
+                float4 val = *reinterpret_cast<const float4 *>(
+                    in_b + (((int64_t)cz * a.H + cy) * a.W + cx) * CIN + q * 4);
+                val.x = ok ? val.x : 0.f; val.y = ok ? val.y : 0.f;
+                val.z = ok ? val.z : 0.f; val.w = ok ? val.w : 0.f;
+                stg[j] = val;
+                dsto[j] = (e < CQ * NVOX && it0 + j < NIT) ? (q * PLANE + v) * 4 : -1;
+            }
+#pragma unroll
+            for (int j = 0; j < SB; ++j)
+                if (dsto[j] >= 0) *reinterpret_cast<float4 *>(lds + dsto[j]) = stg[j];
+        }
     }
     __syncthreads();
     float acc[TZ];

@@ -23,18 +23,21 @@ __global__ __launch_bounds__(256) void softmax_regress_conf_kernel(
     for (int d = 1; d < D; ++d) m = fmaxf(m, c[(int64_t)d * plane]);
     float sum = 0.0f;
     for (int d = 0; d < D; ++d) sum += expf(c[(int64_t)d * plane] - m);
-    float dep = 0.0f, fidx = 0.0f;
+    // The fp32 products p_d * dv_d are the reference's (module.py:102); their SUM is
+    // carried in fp64: at D=192 and depths ~900 mm a naive fp32 running sum alone
+    // costs up to 5e-4 mm against ATen's cascade summation, half the parity budget.
+    double dep = 0.0, fidx = 0.0;
     const float *dv = depth_mode == 0 ? depth + (int64_t)b * D : depth + (int64_t)b * D * plane + pix;
     const int64_t dstride = depth_mode == 0 ? 1 : plane;
     float *pp = out_prob ? out_prob + (int64_t)b * D * plane + pix : nullptr;
     for (int d = 0; d < D; ++d) {
         float pr = expf(c[(int64_t)d * plane] - m) / sum;
-        dep += pr * dv[(int64_t)d * dstride];   // module.py:102
-        fidx += pr * (float)d;                  // mvsnet.py:189
+        dep += (double)(pr * dv[(int64_t)d * dstride]);   // module.py:102
+        fidx += (double)(pr * (float)d);                  // mvsnet.py:189
         if (pp) pp[(int64_t)d * plane] = pr;
     }
     // .long() truncates toward zero (mvsnet.py:189); Cas clamps (cas_mvsnet.py:63)
-    int idx = (int)fidx;
+    int idx = (int)(float)fidx;
     if (clamp_idx) idx = min(max(idx, 0), D - 1);
     // 4 * avg_pool3d over the (1,2)-padded window == p[idx-1] + ... + p[idx+2]
     float s4 = 0.0f;
@@ -43,7 +46,7 @@ __global__ __launch_bounds__(256) void softmax_regress_conf_kernel(
         int dd = idx + k;
         if (dd >= 0 && dd < D) s4 += expf(c[(int64_t)dd * plane] - m) / sum;
     }
-    out_depth[i] = dep;
+    out_depth[i] = (float)dep;
     out_conf[i] = s4;
 }
 

@@ -181,7 +181,17 @@ class MVSNet(nn.Module):
             raise AssertionError("Different number of images and projection matrices")
         V = imgs.shape[1]
         with ops.stage("feature"):
-            feats = [self.feature(imgs[:, v]) for v in range(V)]
+            if self.training:
+                # per-view calls: BatchNorm batch statistics are per call in the
+                # reference (mvsnet.py:146)
+                feats = [self.feature(imgs[:, v]) for v in range(V)]
+            else:
+                # eval: running-stat BN is per-sample, so all B*V views go through
+                # FeatureNet as one batch (same values, 1/V the launches)
+                B = imgs.shape[0]
+                f = self.feature(imgs.reshape(B * V, *imgs.shape[2:]))
+                f = f.reshape(B, V, *f.shape[1:])
+                feats = [f[:, v] for v in range(V)]
         ref_proj = proj_matrices[:, 0]
         with ops.stage("rot_trans"):
             rts = torch.stack([ops.rot_trans(proj_matrices[:, v], ref_proj, self.proj_where)

@@ -67,6 +67,11 @@ def main():
         dd, cd, _ = ops.softmax_regress_conf(cost_cpu.to(dev), gd)
         res["depth_from_cpu_cost_maxabs_mm"] = mx(dd, d_cpu)
         res["conf_from_cpu_cost_maxabs"] = mx(cd, c_cpu)
+        # fp64 ground truth of the regression stage: whose rounding is it?
+        p64 = torch.softmax(cost_cpu.double(), 1)
+        d64 = (p64 * dv.double().reshape(1, D, 1, 1)).sum(1)
+        res["regress_hip_vs_fp64_mm"] = float((dd.cpu().double() - d64).abs().max())
+        res["regress_cpuref_vs_fp64_mm"] = float((d_cpu.double() - d64).abs().max())
         # (e) end to end
         out = model(gi, gp, gd)
         res["e2e_depth_maxabs_mm"] = mx(out["depth"], d_cpu)
