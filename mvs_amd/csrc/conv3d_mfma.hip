@@ -26,6 +26,8 @@
 // this is conv0, 68 % of CostRegNet's FLOPs.
 #include "mvs_common.h"
 
+#include <cstdlib>
+
 namespace mvs {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -75,7 +77,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-template <class Cfg>
+// ABL (tuning builds only, selected by env MVS_CONV_ABLATE for the conv0 shape):
+// 1 = no staging loads, 2 = no A (weight) loads, 4 = no B (LDS) reads, 8 = no MFMA.
+template <class Cfg, int ABL = 0>
 __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
     constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, MODE = Cfg::MODE, CK = Cfg::CK;
     constexpr int KS = Cfg::KS, MT = Cfg::MT, RPW = Cfg::RPW, TY = Cfg::TY, TZ = Cfg::TZ;
@@ -135,7 +139,10 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
                     const float *src =
                         in_b + (((int64_t)cz * a.H + cy) * a.W + cx) * CIN + ch * CK + ekq * KS;
                     dsto[j] = (e < 4 * NVOX && it0 + j < NIT) ? (ekq * PLANE + v) * KS : -1;
-                    if constexpr (KS == 4) {
+                    if constexpr (ABL & 1) {
+#pragma unroll
+                        for (int k = 0; k < KS; ++k) stg[j][k] = ok ? (float)(cx + k) : 0.f;
+                    } else if constexpr (KS == 4) {
                         float4 val = *reinterpret_cast<const float4 *>(src);
                         stg[j][0] = ok ? val.x : 0.f; stg[j][1] = ok ? val.y : 0.f;
                         stg[j][2] = ok ? val.z : 0.f; stg[j][3] = ok ? val.w : 0.f;
@@ -171,7 +178,10 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     const float *wp = wkz + (kyx * MT + m) * 64 * KS;
-                    if constexpr (KS == 4) {
+                    if constexpr (ABL & 2) {
+#pragma unroll
+                        for (int k = 0; k < KS; ++k) af[m][k] = (float)(lane + kyx + k);
+                    } else if constexpr (KS == 4) {
                         float4 t = *reinterpret_cast<const float4 *>(wp);
                         af[m][0] = t.x; af[m][1] = t.y; af[m][2] = t.z; af[m][3] = t.w;
                     } else {
@@ -185,7 +195,10 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
                     const int zr = row / TY, yr = row % TY;
                     const float *rp = rdz + (((zr * SZY) * YT + (yr * SZY + ky)) * XTP + xoff) * KS;
                     float bf[KS];
-                    if constexpr (KS == 4) {
+                    if constexpr (ABL & 4) {
+#pragma unroll
+                        for (int k = 0; k < KS; ++k) bf[k] = (float)(lane + r + k);
+                    } else if constexpr (KS == 4) {
                         float4 t = *reinterpret_cast<const float4 *>(rp);
                         bf[0] = t.x; bf[1] = t.y; bf[2] = t.z; bf[3] = t.w;
                     } else {
@@ -195,9 +208,14 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
-                        for (int s = 0; s < KS; ++s)
-                            acc[r][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][s], bf[s],
-                                                                             acc[r][m], 0, 0, 0);
+                        for (int s = 0; s < KS; ++s) {
+                            if constexpr (ABL & 8) {
+                                asm volatile("" ::"v"(af[m][s]), "v"(bf[s]));   // keep the loads live
+                            } else {
+                                acc[r][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                    af[m][s], bf[s], acc[r][m], 0, 0, 0);
+                            }
+                        }
                 }
             }
         }
@@ -619,7 +637,7 @@ struct CfgInfo {
 template <class Cfg>
 static CfgInfo info_of() {
     return CfgInfo{Cfg::MODE, Cfg::CK, Cfg::MT, Cfg::TZ, Cfg::TY, Cfg::XOUT, Cfg::NTAPS,
-                   conv3d_mfma_kernel<Cfg>};
+                   conv3d_mfma_kernel<Cfg, 0>};
 }
 
 template <class Cfg>
@@ -746,7 +764,21 @@ int conv3d_mfma_launch(const float *in, const float *packed, const float *scale,
         set_error("mvs_conv3d_f32(mfma): bad grid");
         return MVS_EINVAL;
     }
-    hipLaunchKernelGGL(ci.kernel, dim3((unsigned)nblk), dim3(256), 0, st, a);
+    void (*kern)(ConvArgs) = ci.kernel;
+    if (!transposed && Cin == 32 && Cout == 8 && stride == 1) {   // tuning hook, conv0 only
+        const char *abl = getenv("MVS_CONV_ABLATE");
+        using C0 = ConvCfg<32, 8, 2, 8, 4, 8>;
+        switch (abl ? atoi(abl) : 0) {
+            case 1: kern = conv3d_mfma_kernel<C0, 1>; break;
+            case 2: kern = conv3d_mfma_kernel<C0, 2>; break;
+            case 4: kern = conv3d_mfma_kernel<C0, 4>; break;
+            case 8: kern = conv3d_mfma_kernel<C0, 8>; break;
+            case 3: kern = conv3d_mfma_kernel<C0, 3>; break;
+            case 7: kern = conv3d_mfma_kernel<C0, 7>; break;
+            default: break;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), 0, st, a);
     return check_launch("mvs_conv3d_f32(mfma)");
 }
 
