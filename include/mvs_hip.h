@@ -20,7 +20,13 @@
  * Layout codes
  *   MVS_LAYOUT_NCHW (0): [B,C,H,W] / [B,C,D,H,W]   (the reference's layout)
  *   MVS_LAYOUT_NHWC (1): [B,H,W,C] / [B,D,H,W,C]   (channels-last; what the
- *                        MFMA convolution kernels consume)
+ *                        MFMA convolution kernels consume and produce)
+ *   MVS_LAYOUT_C8   (2): [B,D,H,C/8,W,8]  8-channel blocked volume.  Only as the
+ *                        out_layout of mvs_costvol_variance_fwd_f32 (with NHWC
+ *                        features) and the input layout of an MFMA
+ *                        mvs_conv3d_f32 (whose output is then NHWC): the 32-channel
+ *                        variance volume is consumed 8 channels at a time, and this
+ *                        keeps every pass on whole, distinct cache lines.
  * depth_mode
  *   0: depth_values [B,D]        (MVSNet, module.py:74)
  *   1: depth_values [B,D,H,W]    (CasMVSNet/models/module.py:249,267;
@@ -44,6 +50,7 @@ extern "C" {
 
 #define MVS_LAYOUT_NCHW 0
 #define MVS_LAYOUT_NHWC 1
+#define MVS_LAYOUT_C8 2
 
 /* Library version: major*10000 + minor*100 + patch. */
 int mvs_version(void);

@@ -18,7 +18,7 @@ void set_error(const char *fmt, ...) {
 int conv3d_direct_launch(const float *, const float *, const float *, const float *, const float *,
                          int, int, int, int, int, int, int, int, int, int, float *, hipStream_t);
 int conv3d_mfma_launch(const float *, const float *, const float *, const float *, const float *,
-                       int, int, int, int, int, int, int, int, int, float *, hipStream_t);
+                       int, int, int, int, int, int, int, int, int, int, float *, hipStream_t);
 int conv3d_pack_launch(const float *, int, int, int, int, float *, hipStream_t);
 int64_t conv3d_packed_floats(int, int, int, int);
 int conv3d_mfma_supported(int, int, int, int);
@@ -114,13 +114,14 @@ extern "C" int mvs_conv3d_f32(const float *in, const float *weight, const float 
                               int relu, int transposed, int B, int Cin, int Cout, int D, int H,
                               int W, int stride, int layout, int impl, float *out, void *stream) {
     if (!in || !out || B <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0 ||
-        (stride != 1 && stride != 2) || (layout != MVS_LAYOUT_NCHW && layout != MVS_LAYOUT_NHWC) ||
+        (stride != 1 && stride != 2) ||
+        (layout != MVS_LAYOUT_NCHW && layout != MVS_LAYOUT_NHWC && layout != MVS_LAYOUT_C8) ||
         impl < 0 || impl > 2) {
         set_error("mvs_conv3d_f32: invalid argument");
         return MVS_EINVAL;
     }
     hipStream_t st = as_stream(stream);
-    const bool mfma_ok = layout == MVS_LAYOUT_NHWC && packed_weight &&
+    const bool mfma_ok = layout != MVS_LAYOUT_NCHW && packed_weight &&
                          conv3d_mfma_supported(transposed, Cin, Cout, stride);
     if (impl == 2 && !mfma_ok) {
         set_error("mvs_conv3d_f32: MFMA path needs channels-last, packed weights and a supported "
@@ -130,7 +131,11 @@ extern "C" int mvs_conv3d_f32(const float *in, const float *weight, const float 
     }
     if (impl == 2 || (impl == 0 && mfma_ok))
         return conv3d_mfma_launch(in, packed_weight, scale, shift, residual, relu, transposed, B,
-                                  Cin, Cout, D, H, W, stride, out, st);
+                                  Cin, Cout, D, H, W, stride, layout == MVS_LAYOUT_C8, out, st);
+    if (layout == MVS_LAYOUT_C8) {
+        set_error("mvs_conv3d_f32: the 8-channel-blocked layout is input-only for the MFMA path");
+        return MVS_EUNSUPPORTED;
+    }
     if (!weight) {
         set_error("mvs_conv3d_f32: direct path needs the PyTorch-layout weight");
         return MVS_EINVAL;

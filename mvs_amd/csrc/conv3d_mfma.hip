@@ -68,6 +68,7 @@ struct ConvArgs {
     int Do, Ho, Wo;        // output dims
     int tiles_x, tiles_y, tiles_z;
     int relu;
+    int in_c8;   // input is [B,D,H,C/8,W,8] (8-channel blocked) instead of [B,D,H,W,C]
 };
 
 // XCD-aware bijective remap: consecutive tiles land on the same XCD (same L2)
@@ -125,9 +126,12 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
                 int dsto[SB];
 #pragma unroll
                 for (int j = 0; j < SB; ++j) {
+                    // lane -> (voxel, 16/8-byte piece) with the piece fastest: a wave's
+                    // load covers whole contiguous runs of the input instead of one
+                    // piece from each of 64 lines
                     const int e = tid + (it0 + j) * 256;
                     const int ec = min(e, 4 * NVOX - 1);
-                    const int ekq = ec / NVOX, v = ec - ekq * NVOX;
+                    const int ekq = ec & 3, v = ec >> 2;
                     const int lxp = v % XTP, t2 = v / XTP;
                     const int ly = t2 % YT, lz = t2 / YT;
                     const int lx = (SX == 2) ? (lxp < XH ? 2 * lxp : 2 * (lxp - XH) + 1) : lxp;
@@ -136,8 +140,10 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
                                     gz >= 0 && gz < a.D;
                     const int cx = min(max(gx, 0), a.W - 1), cy = min(max(gy, 0), a.H - 1);
                     const int cz = min(max(gz, 0), a.D - 1);
+                    const int c0 = ch * CK + ekq * KS;   // first channel of this piece
                     const float *src =
-                        in_b + (((int64_t)cz * a.H + cy) * a.W + cx) * CIN + ch * CK + ekq * KS;
+                        a.in_c8 ? in_b + ((((int64_t)cz * a.H + cy) * (CIN / 8) + (c0 >> 3)) * a.W + cx) * 8 + (c0 & 7)
+                                : in_b + (((int64_t)cz * a.H + cy) * a.W + cx) * CIN + c0;
                     dsto[j] = (e < 4 * NVOX && it0 + j < NIT) ? (ekq * PLANE + v) * KS : -1;
                     if constexpr (ABL & 1) {
 #pragma unroll
@@ -337,7 +343,7 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_kernel(ConvArgs a) {
                 for (int j = 0; j < SB; ++j) {
                     const int e = tid + (it0 + j) * 256;
                     const int ec = min(e, 4 * NVOX - 1);
-                    const int ekq = ec / NVOX, v = ec - ekq * NVOX;
+                    const int ekq = ec & 3, v = ec >> 2;
                     const int lx = v % XT, t2 = v / XT;
                     const int ly = t2 % YT, lz = t2 / YT;
                     const int gx = jx0 + lx, gy = jy0 + ly, gz = jz0 + lz;
@@ -498,7 +504,7 @@ __global__ __launch_bounds__(256) void conv3d_cout1_kernel(ConvArgs a, const flo
             for (int j = 0; j < SB; ++j) {
                 const int e = tid + (it0 + j) * 256;
                 const int ec = min(e, CQ * NVOX - 1);
-                const int q = ec / NVOX, v = ec - q * NVOX;
+                const int q = ec % CQ, v = ec / CQ;
                 const int vx = v % XT, t2 = v / XT, vy = t2 % YT, vz = t2 / YT;
                 const int gx = x0 + vx - 1, gy = y0 + vy - 1, gz = z0 + vz - 1;
                 const bool ok = gx >= 0 && gx < a.W && gy >= 0 && gy < a.H && gz >= 0 && gz < a.D;
@@ -724,13 +730,18 @@ int conv3d_pack_launch(const float *weight, int transposed, int Cin, int Cout, i
 
 int conv3d_mfma_launch(const float *in, const float *packed, const float *scale,
                        const float *shift, const float *residual, int relu, int transposed, int B,
-                       int Cin, int Cout, int D, int H, int W, int stride, float *out,
+                       int Cin, int Cout, int D, int H, int W, int stride, int in_c8, float *out,
                        hipStream_t st) {
     ConvArgs a;
     a.in = in; a.wpk = packed; a.scale = scale; a.shift = shift; a.residual = residual;
     a.out = out;
     a.B = B; a.D = D; a.H = H; a.W = W;
     a.relu = relu;
+    a.in_c8 = in_c8;
+    if (in_c8 && (transposed || is_cout1(transposed, Cin, Cout, stride) || Cin % 8)) {
+        set_error("mvs_conv3d_f32: the 8-channel-blocked input layout is only taken by the conv kernels");
+        return MVS_EUNSUPPORTED;
+    }
     if (is_cout1(transposed, Cin, Cout, stride)) {
         a.Do = D; a.Ho = H; a.Wo = W;
         a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 7) / 8; a.tiles_z = (D + 3) / 4;

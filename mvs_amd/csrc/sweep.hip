@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void variance_fwd_planar_kernel(
 template <int CQ, int NV>
 __global__ __launch_bounds__(256) void variance_fwd_cl_kernel(
     const float *__restrict__ ref, const float *__restrict__ srcs, const float *__restrict__ rt,
-    const float *__restrict__ depth, SweepParams p, float *__restrict__ out) {
+    const float *__restrict__ depth, SweepParams p, float *__restrict__ out, int out_c8) {
     constexpr int C = CQ * 4;
     constexpr int VPS = 64 / CQ;  // voxels per step
     __shared__ float4 s_w[4][NV][64];  // tap weights nw, ne, sw, se
@@ -258,7 +258,13 @@ __global__ __launch_bounds__(256) void variance_fwd_cl_kernel(
         { float m = s.y / p.fV; o4.y = q.y / p.fV - m * m; }
         { float m = s.z / p.fV; o4.z = q.z / p.fV - m * m; }
         { float m = s.w / p.fV; o4.w = q.w / p.fV - m * m; }
-        *reinterpret_cast<float4 *>(out + idx * C + q4) = o4;
+        if (out_c8) {   // [B,D,H,C/8,W,8]: row (b,d,y), 8-channel block q4/8, then x
+            const int64_t row = idx / p.W;
+            const int x = (int)(idx - row * p.W);
+            *reinterpret_cast<float4 *>(out + ((row * (C / 8) + (q4 >> 3)) * p.W + x) * 8 + (q4 & 7)) = o4;
+        } else {
+            *reinterpret_cast<float4 *>(out + idx * C + q4) = o4;
+        }
     }
 }
 
@@ -355,12 +361,12 @@ static bool grid_for(int64_t total, int per_block, unsigned &grid) {
 
 template <int CQ>
 static int launch_variance_cl(int NV, const float *ref, const float *srcs, const float *rt,
-                              const float *depth, const SweepParams &p, float *out, unsigned grid,
-                              hipStream_t st) {
+                              const float *depth, const SweepParams &p, float *out, int out_c8,
+                              unsigned grid, hipStream_t st) {
 #define MVS_CL_CASE(n)                                                                         \
     case n:                                                                                    \
         hipLaunchKernelGGL((variance_fwd_cl_kernel<CQ, n>), dim3(grid), dim3(256), 0, st, ref, \
-                           srcs, rt, depth, p, out);                                           \
+                           srcs, rt, depth, p, out, out_c8);                                   \
         return MVS_OK;
     switch (NV) {
         MVS_CL_CASE(1) MVS_CL_CASE(2) MVS_CL_CASE(3) MVS_CL_CASE(4) MVS_CL_CASE(5) MVS_CL_CASE(6)
@@ -429,8 +435,9 @@ extern "C" int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *s
                   kMaxSrcViews + 1);
         return MVS_EUNSUPPORTED;
     }
-    if (fea_layout != out_layout) {
-        set_error("mvs_costvol_variance_fwd_f32: fea_layout and out_layout must match");
+    const int out_c8 = out_layout == MVS_LAYOUT_C8;
+    if (fea_layout != out_layout && !(fea_layout == MVS_LAYOUT_NHWC && out_c8)) {
+        set_error("mvs_costvol_variance_fwd_f32: out_layout must equal fea_layout (or be C8 with NHWC features)");
         return MVS_EUNSUPPORTED;
     }
     SweepParams p = make_params(B, V, C, D, H, W, depth_mode, align_corners, alias_quirk);
@@ -457,10 +464,10 @@ extern "C" int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *s
     if (fea_layout != MVS_LAYOUT_NHWC) return MVS_EINVAL;
     int rc;
     switch (C) {
-        case 8: rc = launch_variance_cl<2>(NV, ref_fea, src_feas, rot_trans, depth_values, p, out_var, grid, st); break;
-        case 16: rc = launch_variance_cl<4>(NV, ref_fea, src_feas, rot_trans, depth_values, p, out_var, grid, st); break;
-        case 32: rc = launch_variance_cl<8>(NV, ref_fea, src_feas, rot_trans, depth_values, p, out_var, grid, st); break;
-        case 64: rc = launch_variance_cl<16>(NV, ref_fea, src_feas, rot_trans, depth_values, p, out_var, grid, st); break;
+        case 8: rc = launch_variance_cl<2>(NV, ref_fea, src_feas, rot_trans, depth_values, p, out_var, out_c8, grid, st); break;
+        case 16: rc = launch_variance_cl<4>(NV, ref_fea, src_feas, rot_trans, depth_values, p, out_var, out_c8, grid, st); break;
+        case 32: rc = launch_variance_cl<8>(NV, ref_fea, src_feas, rot_trans, depth_values, p, out_var, out_c8, grid, st); break;
+        case 64: rc = launch_variance_cl<16>(NV, ref_fea, src_feas, rot_trans, depth_values, p, out_var, out_c8, grid, st); break;
         default:
             set_error("mvs_costvol_variance_fwd_f32: channels-last needs C in {8,16,32,64}, got %d", C);
             return MVS_EUNSUPPORTED;

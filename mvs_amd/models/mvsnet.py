@@ -124,8 +124,14 @@ class CostRegNet(nn.Module):
         self._hip_cache = (key, params)
         return params
 
-    def forward_hip(self, x_cl):
-        """x_cl: variance volume, channels-last [B,D,H,W,32] -> cost [B,D,H,W]."""
+    def wants_c8_input(self):
+        """True when conv0 runs on the MFMA kernel, which streams the variance
+        volume as [B,D,H,C/8,W,8] (see include/mvs_hip.h, MVS_LAYOUT_C8)."""
+        return self.conv_impl != ops.IMPL_DIRECT and self._hip_params()["conv0"]["packed"] is not None
+
+    def forward_hip(self, x_cl, in_c8=False):
+        """x_cl: variance volume, channels-last [B,D,H,W,32] (or 8-channel blocked
+        [B,D,H,4,W,8] with in_c8) -> cost [B,D,H,W]."""
         P = self._hip_params()
 
         def run(name, t, skip=None, relu=True):
@@ -133,12 +139,13 @@ class CostRegNet(nn.Module):
             with ops.stage("costreg." + name):
                 return _conv(p, t, skip, relu)
 
-        def _conv(p, t, skip, relu):
+        def _conv(p, t, skip, relu, c8=False):
             return ops.conv3d(t, p["weight"], p["scale"], p["shift"], skip, relu, p["transposed"],
                               p["stride"], channels_last=True, packed=p["packed"],
-                              impl=self.conv_impl)
+                              impl=self.conv_impl, in_c8=c8)
 
-        c0 = run("conv0", x_cl)
+        with ops.stage("costreg.conv0"):
+            c0 = _conv(P["conv0"], x_cl, None, True, in_c8)
         c2 = run("conv2", run("conv1", c0))
         c4 = run("conv4", run("conv3", c2))
         t = run("conv6", run("conv5", c4))
@@ -204,10 +211,11 @@ class MVSNet(nn.Module):
             with ops.stage("to_channels_last"):
                 ref_cl = ops.nchw_to_nhwc(feats[0])
                 src_cl = torch.stack([ops.nchw_to_nhwc(f) for f in feats[1:]])
+            c8 = self.cost_regularization.wants_c8_input()
             with ops.stage("costvol_variance"):
                 var = ops.costvol_variance_cl(ref_cl, src_cl, rts, depth_values,
-                                              self.align_corners)       # [B,D,h,w,32]
-            cost = self.cost_regularization.forward_hip(var)            # [B,D,h,w]
+                                              self.align_corners, out_c8=c8)
+            cost = self.cost_regularization.forward_hip(var, in_c8=c8)  # [B,D,h,w]
         with ops.stage("softmax_regress_conf"):
             depth, conf, _ = ops.softmax_regress_conf(cost, depth_values)
         out = {"depth": depth, "photometric_confidence": conf}

@@ -9,7 +9,8 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import MVS_LAYOUT_NCHW, MVS_LAYOUT_NHWC, MvsHipError, check, ptr, stream
+from ._lib import (MVS_LAYOUT_C8, MVS_LAYOUT_NCHW, MVS_LAYOUT_NHWC, MvsHipError, check, ptr,
+                   stream)
 
 _I = ctypes.c_int
 
@@ -194,18 +195,36 @@ def costvol_variance(ref_fea, src_feas, rts, depth_values, align_corners=False, 
 
 
 def costvol_variance_cl(ref_fea_cl, src_feas_cl, rts, depth_values, align_corners=False,
-                        alias_quirk=False):
-    """Channels-last inference form: ref [B,H,W,C]; srcs [V-1,B,H,W,C] -> [B,D,H,W,C]."""
+                        alias_quirk=False, out_c8=False):
+    """Channels-last inference form: ref [B,H,W,C]; srcs [V-1,B,H,W,C] -> [B,D,H,W,C],
+    or with out_c8 the 8-channel-blocked volume [B,D,H,C/8,W,8] the conv0 kernel
+    streams chunk by chunk."""
     ref_fea_cl, src_feas_cl, depth_values = _f32c(ref_fea_cl), _f32c(src_feas_cl), _f32c(depth_values)
     B, H, W, C = ref_fea_cl.shape
     V = src_feas_cl.shape[0] + 1
     D = depth_values.shape[1]
-    out = torch.empty((B, D, H, W, C), device=ref_fea_cl.device, dtype=torch.float32)
+    if out_c8 and C % 8:
+        raise MvsHipError("out_c8 needs C to be a multiple of 8")
+    shape = (B, D, H, C // 8, W, 8) if out_c8 else (B, D, H, W, C)
+    out = torch.empty(shape, device=ref_fea_cl.device, dtype=torch.float32)
     check(_lib.load().mvs_costvol_variance_fwd_f32(
         ptr(ref_fea_cl), ptr(src_feas_cl), ptr(rts), ptr(depth_values), _depth_mode(depth_values),
-        B, V, C, D, H, W, int(align_corners), int(alias_quirk), MVS_LAYOUT_NHWC, MVS_LAYOUT_NHWC,
-        ptr(out), stream()), "mvs_costvol_variance_fwd_f32")
+        B, V, C, D, H, W, int(align_corners), int(alias_quirk), MVS_LAYOUT_NHWC,
+        MVS_LAYOUT_C8 if out_c8 else MVS_LAYOUT_NHWC, ptr(out), stream()),
+        "mvs_costvol_variance_fwd_f32")
     return out
+
+
+def c8_to_nchw(x):
+    """[B,D,H,C/8,W,8] -> [B,C,D,H,W] (torch ops; tests / debugging only)."""
+    B, D, H, G, W, _ = x.shape
+    return x.permute(0, 3, 5, 1, 2, 4).reshape(B, G * 8, D, H, W).contiguous()
+
+
+def nchw_to_c8(x):
+    """[B,C,D,H,W] -> [B,D,H,C/8,W,8] (torch ops; tests / debugging only)."""
+    B, C, D, H, W = x.shape
+    return x.reshape(B, C // 8, 8, D, H, W).permute(0, 3, 4, 1, 5, 2).contiguous()
 
 
 # ---------------------------------------------------------------- K3 conv
@@ -232,12 +251,18 @@ def pack_conv3d_weight(weight, transposed, stride):
 
 
 def conv3d(x, weight, scale=None, shift=None, residual=None, relu=False, transposed=False,
-           stride=1, channels_last=False, packed=None, impl=IMPL_AUTO):
+           stride=1, channels_last=False, packed=None, impl=IMPL_AUTO, in_c8=False):
     """3x3x3 (transposed) convolution + per-channel affine + ReLU + skip add.
-    x: [B,Cin,D,H,W] or, with channels_last, [B,D,H,W,Cin]."""
+    x: [B,Cin,D,H,W] or, with channels_last, [B,D,H,W,Cin]; with in_c8 the input
+    is the 8-channel-blocked [B,D,H,Cin/8,W,8] (MFMA conv path only; the output
+    is channels-last)."""
     x = _f32c(x)
     weight = _f32c(weight) if weight is not None else None
-    if channels_last:
+    if in_c8:
+        B, D, H, G, W, _ = x.shape
+        cin = G * 8
+        channels_last = True
+    elif channels_last:
         B, D, H, W, cin = x.shape
     else:
         B, cin, D, H, W = x.shape
@@ -258,7 +283,8 @@ def conv3d(x, weight, scale=None, shift=None, residual=None, relu=False, transpo
     check(_lib.load().mvs_conv3d_f32(
         ptr(x), ptr(weight), ptr(packed), ptr(_f32c(scale)) if scale is not None else None,
         ptr(_f32c(shift)) if shift is not None else None, ptr(residual), int(relu), int(transposed),
-        B, cin, cout, D, H, W, stride, MVS_LAYOUT_NHWC if channels_last else MVS_LAYOUT_NCHW,
+        B, cin, cout, D, H, W, stride,
+        MVS_LAYOUT_C8 if in_c8 else (MVS_LAYOUT_NHWC if channels_last else MVS_LAYOUT_NCHW),
         impl, ptr(out), stream()), "mvs_conv3d_f32")
     return out
 

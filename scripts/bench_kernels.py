@@ -52,10 +52,13 @@ def main():
         sc = torch.rand(co, device=dev, generator=g) + 0.5
         sh = torch.randn(co, device=dev, generator=g) * 0.1
         pk = ops.pack_conv3d_weight(wt, tr, s)
+        c8 = name == "conv0" and os.environ.get("MVS_BENCH_C8", "1") == "1"
+        if c8:
+            x = x.reshape(1, D // f, h // f, ci // 8, w // f, 8)   # same bytes, blocked meaning
         med, best = timeit(lambda: ops.conv3d(x, wt, sc, sh, None, True, tr, s, channels_last=True,
-                                              packed=pk, impl=ops.IMPL_MFMA), reps)
-        nout = x[0, ..., 0].numel() * (8 if tr else (1 / 8 if s == 2 else 1))
-        flops = 2 * 27 * ci * co * (x[0, ..., 0].numel() if tr else nout)
+                                              packed=pk, impl=ops.IMPL_MFMA, in_c8=c8), reps)
+        nin = (D // f) * (h // f) * (w // f)
+        flops = 2 * 27 * ci * co * (nin if tr else nin / (8 if s == 2 else 1))
         res[name] = {"ms": round(med, 4), "best_ms": round(best, 4),
                      "TFLOPs": round(flops / med / 1e9, 2), "frac_fp32_mfma": round(flops / med / 1e9 / 157.3, 4)}
         del x
@@ -66,7 +69,7 @@ def main():
         dv = torch.from_numpy(synth.depth_values(D)).to(dev)
         feats = torch.randn(V, 1, h, w, 32, device=dev, generator=g)
         rts = torch.stack([ops.rot_trans(proj[:, v], proj[:, 0]) for v in range(1, V)])
-        med, best = timeit(lambda: ops.costvol_variance_cl(feats[0], feats[1:], rts, dv), reps)
+        med, best = timeit(lambda: ops.costvol_variance_cl(feats[0], feats[1:], rts, dv, out_c8=True), reps)
         byt = (V * 32 * h * w + D + 32 * D * h * w) * 4
         res["variance"] = {"ms": round(med, 4), "best_ms": round(best, 4), "GBs": round(byt / med / 1e6, 1),
                            "frac_hbm": round(byt / med / 1e6 / 8000, 4)}

@@ -119,6 +119,25 @@ def test_variance_golden(dev, name, layout):
     assert (var == g["variance"]).mean() > 0.999
 
 
+def test_variance_c8_blocked_layout_and_conv0(dev, weights):
+    """[B,D,H,C/8,W,8] variance output and the conv0 kernel reading it."""
+    from mvs_amd import ops
+    g = load_golden("g6_e2e_64x96_v3_d8")
+    f = g["features"]
+    cl = [ops.nchw_to_nhwc(G(f[:, v], dev)) for v in range(f.shape[1])]
+    var8 = ops.costvol_variance_cl(cl[0], torch.stack(cl[1:]), G(_rts(g["proj"]), dev),
+                                   G(g["depth_values"], dev), out_c8=True)
+    assert var8.shape == (1, 8, 16, 4, 24, 8)
+    np.testing.assert_allclose(ops.c8_to_nchw(var8).cpu().numpy(), g["variance"], atol=1e-7, rtol=0)
+    assert torch.equal(ops.nchw_to_c8(ops.c8_to_nchw(var8)), var8)
+    pre = "cost_regularization."
+    scale, shift = _fold(weights, pre + "conv0.bn")
+    wt = G(weights[pre + "conv0.conv.weight"], dev)
+    got = ops.conv3d(var8, wt, G(scale, dev), G(shift, dev), None, True, False, 1,
+                     packed=ops.pack_conv3d_weight(wt, False, 1), impl=ops.IMPL_MFMA, in_c8=True)
+    np.testing.assert_allclose(ops.nhwc_to_nchw(got).cpu().numpy(), g["act_conv0"], atol=2e-5, rtol=1e-5)
+
+
 @pytest.mark.parametrize("layout", ["planar", "channels_last"])
 def test_variance_cvp_alias_quirk_golden(dev, layout):
     from mvs_amd import ops
