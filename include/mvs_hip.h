@@ -88,6 +88,11 @@ int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *src_feas,
                                  int depth_mode, int B, int V, int C, int D, int H, int W,
                                  int align_corners, int alias_quirk, int fea_layout,
                                  int out_layout, float *out_var, void *stream);
+/* Self-test: the variance kernel divides by the view count V with a 3-op
+ * multiply/FMA sequence instead of an IEEE division; this checks it against
+ * x / V for EVERY float bit pattern on the device and writes the number of
+ * mismatching patterns (expected 0) to *mismatch_count (device pointer). */
+int mvs_selftest_div_by_views_f32(int V, unsigned long long *mismatch_count, void *stream);
 /* grad_var in out_layout; grad_ref / grad_srcs in fea_layout, overwritten. */
 int mvs_costvol_variance_bwd_f32(const float *grad_var, const float *ref_fea,
                                  const float *src_feas, const float *rot_trans,

@@ -30,6 +30,7 @@ _SIGS = {
     "mvs_warp_fwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i] + [_c_i] * 6 + [_c_f, _c_f]),
     "mvs_warp_bwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i] + [_c_i] * 6 + [_c_f, _c_f]),
     "mvs_costvol_variance_fwd_f32": (_c_i, [_c_f] * 4 + [_c_i] * 11 + [_c_f, _c_f]),
+    "mvs_selftest_div_by_views_f32": (_c_i, [_c_i, _c_f, _c_f]),
     "mvs_costvol_variance_bwd_f32": (_c_i, [_c_f] * 5 + [_c_i] * 10 + [_c_f, _c_f, _c_f]),
     "mvs_conv3d_f32": (_c_i, [_c_f] * 6 + [_c_i] * 11 + [_c_f, _c_f]),
     "mvs_conv3d_packed_weight_floats": (_c_l, [_c_i] * 4),

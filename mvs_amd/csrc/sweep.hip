@@ -170,39 +170,79 @@ __global__ __launch_bounds__(256) void variance_fwd_planar_kernel(
 }
 
 // ---------------------------------------------------------------------
-// K1+K2 fused, channels-last: features [B,H,W,C] -> variance [B,D,H,W,C].
+// K1+K2 fused, channels-last: features [B,H,W,C] -> variance [B,D,H,W,C]
+// (or the 8-channel-blocked [B,D,H,C/8,W,8] the conv0 kernel streams).
 //
-// A wave owns 64 consecutive voxels of the flattened (b,d,y,x) space.  Phase 1:
-// lane l evaluates the homography + bilinear tap set of voxel l for every
+// A wave owns 64 consecutive voxels of one batch item's flattened (d,y,x) space.
+// Phase 1: lane l evaluates the homography + bilinear tap set of voxel l for every
 // source view (exact arithmetic, once per voxel) and parks it in a wave-private
-// LDS record.  Phase 2: the wave walks its voxels 64/CQ at a time with lane =
-// (voxel, channel-quad): the CQ lanes of a voxel read one whole 16*CQ-byte
-// texel per tap (a full 128-B line at C=32) and the wave stores 1 KiB of
-// contiguous variance per step.
+// LDS record: 4 tap weights (already zero for taps outside the image, NaN if
+// the coordinate is not finite -- the reference's 0*NaN) and 4 clamped byte
+// offsets.  Phase 2: the wave walks its voxels 64/CQ at a time with lane =
+// (voxel, channel-quad): the CQ lanes of a voxel read one whole 16*CQ-byte texel
+// per tap (a full 128-B line at C=32) through an SGPR base + 32-bit offset, and
+// the wave stores 1 KiB of contiguous variance per step.  No masks, no 64-bit
+// integer arithmetic and no IEEE division in the inner loop.
+
+// n / d for n < 2^32 by multiply-high (Granlund-Montgomery); host-built.
+struct FastDiv {
+    uint32_t m, s1, s2, d;
+};
+static FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    f.m = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.s1 = l < 1 ? l : 1;
+    f.s2 = l == 0 ? 0 : l - 1;
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv &f) {
+    const uint32_t t = __umulhi(f.m, n);
+    return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+
+// x / V, correctly rounded, for the small integer V = number of views:
+// q = RN(x*(1/V)); r = x - q*V exactly (one FMA); q' = RN(q + r*(1/V)).
+// Equal to IEEE x / V for every finite x outside the subnormal-result range
+// (checked exhaustively on the GPU: mvs_selftest_div_by_views_f32); tiny |x| take
+// the true division so the result is the reference's in every case.
+__device__ __forceinline__ float div_views_fast(float x, float fV, float rV) {
+    const float q = x * rV;
+    const float r = __fmaf_rn(-q, fV, x);
+    return __fmaf_rn(r, rV, q);
+}
+__device__ __forceinline__ bool div_views_tiny(float x) { return fabsf(x) < 1e-30f; }
+__device__ __forceinline__ float div_views(float x, float fV, float rV) {
+    return div_views_tiny(x) ? x / fV : div_views_fast(x, fV, rV);
+}
+
 template <int CQ, int NV>
 __global__ __launch_bounds__(256) void variance_fwd_cl_kernel(
     const float *__restrict__ ref, const float *__restrict__ srcs, const float *__restrict__ rt,
-    const float *__restrict__ depth, SweepParams p, float *__restrict__ out, int out_c8) {
+    const float *__restrict__ depth, SweepParams p, FastDiv fd_plane, FastDiv fd_w,
+    float *__restrict__ out, int out_c8) {
     constexpr int C = CQ * 4;
     constexpr int VPS = 64 / CQ;  // voxels per step
-    __shared__ float4 s_w[4][NV][64];  // tap weights nw, ne, sw, se
-    __shared__ int4 s_o[4][NV][64];    // texel index of each tap, <0 = outside
+    __shared__ float4 s_w[4][NV][64];  // tap weights nw, ne, sw, se (pre-masked)
+    __shared__ uint4 s_o[4][NV][64];   // byte offset of each tap's texel (clamped)
 
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    const int64_t plane = (int64_t)p.H * p.W;
-    const int64_t total = (int64_t)p.B * p.D * plane;
-    const int64_t wave_base = ((int64_t)blockIdx.x * 4 + wv) * 64;
+    const int b = blockIdx.y;
+    const uint32_t plane = (uint32_t)(p.H * p.W);
+    const uint32_t total = (uint32_t)p.D * plane;          // voxels of one batch item
+    const uint32_t wave_base = (blockIdx.x * 4u + wv) * 64u;
 
-    {   // phase 1
-        int64_t idx = wave_base + lane;
-        bool live = idx < total;
-        int64_t cidx = live ? idx : total - 1;
-        int64_t pix = cidx % plane;
-        int d = (int)((cidx / plane) % p.D);
-        int b = (int)(cidx / (plane * p.D));
-        int x = (int)(pix % p.W), y = (int)(pix / p.W);
-        const float dv = depth_at(depth, p, b, d, pix);
+    {   // phase 1: lane = voxel
+        const uint32_t idx = min(wave_base + lane, total - 1);
+        const uint32_t d = fdiv(idx, fd_plane);
+        const uint32_t pix = idx - d * plane;
+        const uint32_t y = fdiv(pix, fd_w);
+        const uint32_t x = pix - y * (uint32_t)p.W;
+        const float dv = p.depth_mode == 0 ? depth[(int64_t)b * p.D + d]
+                                           : depth[(int64_t)b * total + idx];
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const float *r = rt + ((int64_t)v * p.B + b) * 12;
@@ -211,61 +251,94 @@ __global__ __launch_bounds__(256) void variance_fwd_cl_kernel(
             sweep_coord(r, rx, ry, rz, dv, p.half_w, p.half_h, p.unn_w, p.unn_h,
                         p.align_corners, ix, iy);
             Taps t = make_taps(ix, iy, p.H, p.W);
-            s_w[wv][v][lane] = make_float4(t.nw, t.ne, t.sw, t.se);
-            s_o[wv][v][lane] = make_int4((t.x0ok && t.y0ok) ? t.y0 * p.W + t.x0 : -1,
-                                         (t.x1ok && t.y0ok) ? t.y0 * p.W + t.x1 : -1,
-                                         (t.x0ok && t.y1ok) ? t.y1 * p.W + t.x0 : -1,
-                                         (t.x1ok && t.y1ok) ? t.y1 * p.W + t.x1 : -1);
+            // a tap outside the image contributes value 0 in the reference; with
+            // finite features that equals weight 0.  Non-finite coordinates give
+            // NaN weights there (0 * NaN) -- keep them.
+            const bool fin = (fabsf(ix) <= 3.0e38f) && (fabsf(iy) <= 3.0e38f);
+            const float dead = fin ? 0.0f : __int_as_float(0x7fc00000);
+            const bool m00 = t.x0ok && t.y0ok, m01 = t.x1ok && t.y0ok;
+            const bool m10 = t.x0ok && t.y1ok, m11 = t.x1ok && t.y1ok;
+            s_w[wv][v][lane] = make_float4(m00 ? t.nw : dead, m01 ? t.ne : dead,
+                                           m10 ? t.sw : dead, m11 ? t.se : dead);
+            s_o[wv][v][lane] = make_uint4((uint32_t)(t.y0 * p.W + t.x0) * (C * 4u),
+                                          (uint32_t)(t.y0 * p.W + t.x1) * (C * 4u),
+                                          (uint32_t)(t.y1 * p.W + t.x0) * (C * 4u),
+                                          (uint32_t)(t.y1 * p.W + t.x1) * (C * 4u));
         }
     }
     __syncthreads();
 
-    const int q4 = (lane % CQ) * 4;  // first channel of this lane's quad
+    const uint32_t qoff = (uint32_t)(lane % CQ) * 16u;   // byte offset of this lane's quad
     const int vsub = lane / CQ;
-    const int64_t view_stride = (int64_t)p.B * plane * C;
+    const size_t fea_bytes = (size_t)plane * C * 4;       // one feature map of one batch item
+    const char *ref_b = reinterpret_cast<const char *>(ref) + (size_t)b * fea_bytes;
+    const float rV = 1.0f / p.fV;
 #pragma unroll 1
     for (int step = 0; step < CQ; ++step) {
         const int j = step * VPS + vsub;  // voxel slot within the wave
-        const int64_t idx = wave_base + j;
+        const uint32_t idx = wave_base + j;
         if (idx >= total) continue;
-        const int64_t pix = idx % plane;
-        const int b = (int)(idx / (plane * p.D));
-        const float4 r = *reinterpret_cast<const float4 *>(ref + ((int64_t)b * plane + pix) * C + q4);
+        const uint32_t d = fdiv(idx, fd_plane);
+        const uint32_t pix = idx - d * plane;
+        const float4 r = *reinterpret_cast<const float4 *>(ref_b + (pix * (C * 4u) + qoff));
         float4 q = make_float4(r.x * r.x, r.y * r.y, r.z * r.z, r.w * r.w);
         float4 s = p.alias_quirk ? q : r;
-        const float *sb = srcs + (int64_t)b * plane * C + q4;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const float4 w = s_w[wv][v][j];
-            const int4 o = s_o[wv][v][j];
-            const float *sv = sb + (int64_t)v * view_stride;
-            // branch-free gathers: always load from a clamped texel, then mask
-            float4 a = *reinterpret_cast<const float4 *>(sv + (int64_t)max(o.x, 0) * C);
-            float4 bq = *reinterpret_cast<const float4 *>(sv + (int64_t)max(o.y, 0) * C);
-            float4 c = *reinterpret_cast<const float4 *>(sv + (int64_t)max(o.z, 0) * C);
-            float4 e = *reinterpret_cast<const float4 *>(sv + (int64_t)max(o.w, 0) * C);
-            a = sel4(o.x >= 0, a); bq = sel4(o.y >= 0, bq);
-            c = sel4(o.z >= 0, c); e = sel4(o.w >= 0, e);
-            float t0 = __fmaf_rn(e.x, w.w, __fmaf_rn(c.x, w.z, __fmaf_rn(bq.x, w.y, a.x * w.x)));
-            float t1 = __fmaf_rn(e.y, w.w, __fmaf_rn(c.y, w.z, __fmaf_rn(bq.y, w.y, a.y * w.x)));
-            float t2 = __fmaf_rn(e.z, w.w, __fmaf_rn(c.z, w.z, __fmaf_rn(bq.z, w.y, a.z * w.x)));
-            float t3 = __fmaf_rn(e.w, w.w, __fmaf_rn(c.w, w.z, __fmaf_rn(bq.w, w.y, a.w * w.x)));
+            const uint4 o = s_o[wv][v][j];
+            // wave-uniform base (SGPRs) + 32-bit per-lane offset
+            const char *sv = reinterpret_cast<const char *>(srcs) +
+                             ((size_t)v * p.B + b) * fea_bytes;
+            const float4 a = *reinterpret_cast<const float4 *>(sv + (o.x + qoff));
+            const float4 bq = *reinterpret_cast<const float4 *>(sv + (o.y + qoff));
+            const float4 c = *reinterpret_cast<const float4 *>(sv + (o.z + qoff));
+            const float4 e = *reinterpret_cast<const float4 *>(sv + (o.w + qoff));
+            const float t0 = __fmaf_rn(e.x, w.w, __fmaf_rn(c.x, w.z, __fmaf_rn(bq.x, w.y, a.x * w.x)));
+            const float t1 = __fmaf_rn(e.y, w.w, __fmaf_rn(c.y, w.z, __fmaf_rn(bq.y, w.y, a.y * w.x)));
+            const float t2 = __fmaf_rn(e.z, w.w, __fmaf_rn(c.z, w.z, __fmaf_rn(bq.z, w.y, a.z * w.x)));
+            const float t3 = __fmaf_rn(e.w, w.w, __fmaf_rn(c.w, w.z, __fmaf_rn(bq.w, w.y, a.w * w.x)));
             s.x = s.x + t0; s.y = s.y + t1; s.z = s.z + t2; s.w = s.w + t3;
             q.x = q.x + t0 * t0; q.y = q.y + t1 * t1; q.z = q.z + t2 * t2; q.w = q.w + t3 * t3;
         }
         float4 o4;
-        { float m = s.x / p.fV; o4.x = q.x / p.fV - m * m; }
-        { float m = s.y / p.fV; o4.y = q.y / p.fV - m * m; }
-        { float m = s.z / p.fV; o4.z = q.z / p.fV - m * m; }
-        { float m = s.w / p.fV; o4.w = q.w / p.fV - m * m; }
-        if (out_c8) {   // [B,D,H,C/8,W,8]: row (b,d,y), 8-channel block q4/8, then x
-            const int64_t row = idx / p.W;
-            const int x = (int)(idx - row * p.W);
-            *reinterpret_cast<float4 *>(out + ((row * (C / 8) + (q4 >> 3)) * p.W + x) * 8 + (q4 & 7)) = o4;
+        { const float m = div_views_fast(s.x, p.fV, rV); o4.x = div_views_fast(q.x, p.fV, rV) - m * m; }
+        { const float m = div_views_fast(s.y, p.fV, rV); o4.y = div_views_fast(q.y, p.fV, rV) - m * m; }
+        { const float m = div_views_fast(s.z, p.fV, rV); o4.z = div_views_fast(q.z, p.fV, rV) - m * m; }
+        { const float m = div_views_fast(s.w, p.fV, rV); o4.w = div_views_fast(q.w, p.fV, rV) - m * m; }
+        const bool tiny = div_views_tiny(s.x) || div_views_tiny(s.y) || div_views_tiny(s.z) ||
+                          div_views_tiny(s.w) || div_views_tiny(q.x) || div_views_tiny(q.y) ||
+                          div_views_tiny(q.z) || div_views_tiny(q.w);
+        if (__any(tiny)) {   // wave-uniform, practically never taken: true IEEE division
+            { const float m = s.x / p.fV; o4.x = q.x / p.fV - m * m; }
+            { const float m = s.y / p.fV; o4.y = q.y / p.fV - m * m; }
+            { const float m = s.z / p.fV; o4.z = q.z / p.fV - m * m; }
+            { const float m = s.w / p.fV; o4.w = q.w / p.fV - m * m; }
+        }
+        float *ob = out + (size_t)b * total * C;
+        if (out_c8) {   // [B,D,H,C/8,W,8]: row (d,y), 8-channel block, then x
+            const uint32_t y = fdiv(pix, fd_w);
+            const uint32_t x = pix - y * (uint32_t)p.W;
+            const uint32_t row = d * (uint32_t)p.H + y;
+            *reinterpret_cast<float4 *>(
+                ob + ((size_t)(row * (C / 8) + (qoff >> 5)) * p.W + x) * 8 + ((qoff >> 2) & 7)) = o4;
         } else {
-            *reinterpret_cast<float4 *>(out + idx * C + q4) = o4;
+            *reinterpret_cast<float4 *>(ob + (size_t)idx * C + (qoff >> 2)) = o4;
         }
     }
+}
+
+// Exhaustive check of div_views against IEEE division: every float bit pattern.
+__global__ __launch_bounds__(256) void div_selftest_kernel(float fV, unsigned long long *mismatch) {
+    const float rV = 1.0f / fV;
+    unsigned long long bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32);
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float((uint32_t)i);
+        const float a = div_views(x, fV, rV), c = x / fV;
+        if (__float_as_uint(a) != __float_as_uint(c) && !(a != a && c != c)) ++bad;
+    }
+    if (bad) atomicAdd(mismatch, bad);
 }
 
 // ---------------------------------------------------------------------
@@ -362,11 +435,18 @@ static bool grid_for(int64_t total, int per_block, unsigned &grid) {
 template <int CQ>
 static int launch_variance_cl(int NV, const float *ref, const float *srcs, const float *rt,
                               const float *depth, const SweepParams &p, float *out, int out_c8,
-                              unsigned grid, hipStream_t st) {
+                              hipStream_t st) {
+    const int64_t per_item = (int64_t)p.D * p.H * p.W;
+    if (per_item >= (1ll << 31) || (int64_t)p.H * p.W * CQ * 16 >= (1ll << 32) || p.B > 65535) {
+        set_error("mvs_costvol_variance_fwd_f32: volume too large for 32-bit indexing");
+        return MVS_EINVAL;
+    }
+    const dim3 grid((unsigned)((per_item + 255) / 256), (unsigned)p.B);
+    const FastDiv fdp = make_fastdiv((uint32_t)(p.H * p.W)), fdw = make_fastdiv((uint32_t)p.W);
 #define MVS_CL_CASE(n)                                                                         \
     case n:                                                                                    \
-        hipLaunchKernelGGL((variance_fwd_cl_kernel<CQ, n>), dim3(grid), dim3(256), 0, st, ref, \
-                           srcs, rt, depth, p, out, out_c8);                                   \
+        hipLaunchKernelGGL((variance_fwd_cl_kernel<CQ, n>), grid, dim3(256), 0, st, ref, srcs, \
+                           rt, depth, p, fdp, fdw, out, out_c8);                               \
         return MVS_OK;
     switch (NV) {
         MVS_CL_CASE(1) MVS_CL_CASE(2) MVS_CL_CASE(3) MVS_CL_CASE(4) MVS_CL_CASE(5) MVS_CL_CASE(6)
@@ -464,16 +544,29 @@ extern "C" int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *s
     if (fea_layout != MVS_LAYOUT_NHWC) return MVS_EINVAL;
     int rc;
     switch (C) {
-        case 8: rc = launch_variance_cl<2>(NV, ref_fea, src_feas, rot_trans, depth_values, p, out_var, out_c8, grid, st); break;
-        case 16: rc = launch_variance_cl<4>(NV, ref_fea, src_feas, rot_trans, depth_values, p, out_var, out_c8, grid, st); break;
-        case 32: rc = launch_variance_cl<8>(NV, ref_fea, src_feas, rot_trans, depth_values, p, out_var, out_c8, grid, st); break;
-        case 64: rc = launch_variance_cl<16>(NV, ref_fea, src_feas, rot_trans, depth_values, p, out_var, out_c8, grid, st); break;
+        case 8: rc = launch_variance_cl<2>(NV, ref_fea, src_feas, rot_trans, depth_values, p, out_var, out_c8, st); break;
+        case 16: rc = launch_variance_cl<4>(NV, ref_fea, src_feas, rot_trans, depth_values, p, out_var, out_c8, st); break;
+        case 32: rc = launch_variance_cl<8>(NV, ref_fea, src_feas, rot_trans, depth_values, p, out_var, out_c8, st); break;
+        case 64: rc = launch_variance_cl<16>(NV, ref_fea, src_feas, rot_trans, depth_values, p, out_var, out_c8, st); break;
         default:
             set_error("mvs_costvol_variance_fwd_f32: channels-last needs C in {8,16,32,64}, got %d", C);
             return MVS_EUNSUPPORTED;
     }
     if (rc != MVS_OK) return rc;
     return check_launch("mvs_costvol_variance_fwd_f32(channels-last)");
+}
+
+extern "C" int mvs_selftest_div_by_views_f32(int V, unsigned long long *mismatch_count,
+                                             void *stream) {
+    if (V < 1 || !mismatch_count) {
+        set_error("mvs_selftest_div_by_views_f32: invalid argument");
+        return MVS_EINVAL;
+    }
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(mismatch_count, 0, sizeof(unsigned long long), st) != hipSuccess)
+        return check_launch("mvs_selftest_div_by_views_f32 memset");
+    hipLaunchKernelGGL(div_selftest_kernel, dim3(4096), dim3(256), 0, st, (float)V, mismatch_count);
+    return check_launch("mvs_selftest_div_by_views_f32");
 }
 
 extern "C" int mvs_costvol_variance_bwd_f32(const float *grad_var, const float *ref_fea,

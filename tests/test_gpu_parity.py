@@ -119,6 +119,17 @@ def test_variance_golden(dev, name, layout):
     assert (var == g["variance"]).mean() > 0.999
 
 
+@pytest.mark.parametrize("V", [2, 3, 5, 7])
+def test_division_by_view_count_is_ieee_exact(dev, V):
+    """The variance kernel's 3-op division by V equals IEEE x / V for all 2^32
+    float bit patterns (brute force on the device)."""
+    from mvs_amd import _lib
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    _lib.check(_lib.load().mvs_selftest_div_by_views_f32(V, cnt.data_ptr(), _lib.stream()),
+               "mvs_selftest_div_by_views_f32")
+    assert int(cnt.item()) == 0
+
+
 def test_variance_c8_blocked_layout_and_conv0(dev, weights):
     """[B,D,H,C/8,W,8] variance output and the conv0 kernel reading it."""
     from mvs_amd import ops
