@@ -27,6 +27,10 @@
  *                        mvs_conv3d_f32 (whose output is then NHWC): the 32-channel
  *                        variance volume is consumed 8 channels at a time, and this
  *                        keeps every pass on whole, distinct cache lines.
+ *   MVS_LAYOUT_C16  (3): [B,C/16,H,W,16]  16-channel blocked FEATURE maps, the
+ *                        fea_layout of the LDS-staged variance kernel (a source
+ *                        footprint row is one contiguous run); build it with
+ *                        mvs_nchw_to_nhwc_f32(in, out, B*C/16, 16, H*W).
  * depth_mode
  *   0: depth_values [B,D]        (MVSNet, module.py:74)
  *   1: depth_values [B,D,H,W]    (CasMVSNet/models/module.py:249,267;
@@ -51,6 +55,7 @@ extern "C" {
 #define MVS_LAYOUT_NCHW 0
 #define MVS_LAYOUT_NHWC 1
 #define MVS_LAYOUT_C8 2
+#define MVS_LAYOUT_C16 3
 
 /* Library version: major*10000 + minor*100 + patch. */
 int mvs_version(void);
@@ -81,7 +86,9 @@ int mvs_warp_bwd_f32(const float *grad_out, const float *rot_trans, const float 
 /* ---- K1+K2: fused warp + variance -- mvsnet.py:152-170 -------------- */
 /* ref_fea [B,C,H,W]|[B,H,W,C]; src_feas [V-1,B,...] same layout; rot_trans
  * [V-1,B,12]; out_var [B,C,D,H,W] | [B,D,H,W,C].  Per-view warped volumes are
- * never materialised.  alias_quirk=1 reproduces CVP-MVSNet/models/modules.py:
+ * never materialised.  fea_layout C16 (with out_layout NHWC or C8) selects the
+ * LDS-staged kernel: per-view source footprints of a 4x16x4-voxel block are
+ * staged in LDS and sampled from there.  alias_quirk=1 reproduces CVP-MVSNet/models/modules.py:
  * 228-229 (S0 = Q0 = ref^2).  C must be a multiple of 4 and <= 64. */
 int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *src_feas,
                                  const float *rot_trans, const float *depth_values,

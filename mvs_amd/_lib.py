@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmvs_hip.so")
 MVS_LAYOUT_NCHW = 0
 MVS_LAYOUT_NHWC = 1
 MVS_LAYOUT_C8 = 2
+MVS_LAYOUT_C16 = 3
 
 _c_f = ctypes.c_void_p   # device pointers travel as integers
 _c_i = ctypes.c_int

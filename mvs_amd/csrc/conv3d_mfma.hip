@@ -786,6 +786,11 @@ int conv3d_mfma_launch(const float *in, const float *packed, const float *scale,
             case 8: kern = conv3d_mfma_kernel<C0, 8>; break;
             case 3: kern = conv3d_mfma_kernel<C0, 3>; break;
             case 7: kern = conv3d_mfma_kernel<C0, 7>; break;
+            case 9: kern = conv3d_mfma_kernel<C0, 9>; break;
+            case 10: kern = conv3d_mfma_kernel<C0, 10>; break;
+            case 12: kern = conv3d_mfma_kernel<C0, 12>; break;
+            case 14: kern = conv3d_mfma_kernel<C0, 14>; break;
+            case 15: kern = conv3d_mfma_kernel<C0, 15>; break;
             default: break;
         }
     }

@@ -10,6 +10,8 @@
 // reference op for op (see mvs_common.h) and is bit-exact with it.
 #include "mvs_common.h"
 
+#include <cstdlib>
+
 namespace mvs {
 
 constexpr int kMaxSrcViews = 8;
@@ -213,7 +215,11 @@ __device__ __forceinline__ float div_views_fast(float x, float fV, float rV) {
     const float r = __fmaf_rn(-q, fV, x);
     return __fmaf_rn(r, rV, q);
 }
-__device__ __forceinline__ bool div_views_tiny(float x) { return fabsf(x) < 1e-30f; }
+// tiny (subnormal-range quotient) or non-finite (inf*rV would poison the FMA)
+__device__ __forceinline__ bool div_views_tiny(float x) {
+    const float ax = fabsf(x);
+    return !(ax >= 1e-30f && ax <= 3.0e38f);
+}
 __device__ __forceinline__ float div_views(float x, float fV, float rV) {
     return div_views_tiny(x) ? x / fV : div_views_fast(x, fV, rV);
 }
@@ -222,7 +228,7 @@ template <int CQ, int NV>
 __global__ __launch_bounds__(256) void variance_fwd_cl_kernel(
     const float *__restrict__ ref, const float *__restrict__ srcs, const float *__restrict__ rt,
     const float *__restrict__ depth, SweepParams p, FastDiv fd_plane, FastDiv fd_w,
-    float *__restrict__ out, int out_c8) {
+    float *__restrict__ out, int out_c8, int ablate) {
     constexpr int C = CQ * 4;
     constexpr int VPS = 64 / CQ;  // voxels per step
     __shared__ float4 s_w[4][NV][64];  // tap weights nw, ne, sw, se (pre-masked)
@@ -286,7 +292,8 @@ __global__ __launch_bounds__(256) void variance_fwd_cl_kernel(
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const float4 w = s_w[wv][v][j];
-            const uint4 o = s_o[wv][v][j];
+            uint4 o = s_o[wv][v][j];
+            if (ablate & 1) o = make_uint4(0u, 0u, 0u, 0u);   // tuning: every gather hits one line
             // wave-uniform base (SGPRs) + 32-bit per-lane offset
             const char *sv = reinterpret_cast<const char *>(srcs) +
                              ((size_t)v * p.B + b) * fea_bytes;
@@ -324,6 +331,244 @@ __global__ __launch_bounds__(256) void variance_fwd_cl_kernel(
                 ob + ((size_t)(row * (C / 8) + (qoff >> 5)) * p.W + x) * 8 + ((qoff >> 2) & 7)) = o4;
         } else {
             *reinterpret_cast<float4 *>(ob + (size_t)idx * C + (qoff >> 2)) = o4;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------
+// K1+K2 fused with LDS-staged source tiles (the north-star form).
+//
+// The gather kernel above tops out on the vector-L1 path (64 B/clk/CU: 2 KiB of
+// taps per voxel).  Here a block owns an 8x8-pixel tile of the reference view
+// over 4 consecutive depth planes (256 voxels, lane = voxel).  For every source
+// view the block computes, at run time, the bounding box of all texels its
+// voxels' bilinear taps touch (an arbitrary homography: no geometry is assumed),
+// copies that footprint into LDS 16 channels at a time, and samples from LDS
+// (256 B/clk/CU, conflict-free: a 16-channel texel half is padded from 64 to
+// 80 bytes so 16 neighbouring texels cover all 64 banks).  A footprint that does
+// not fit its LDS share (extreme baselines) falls back to global gathers for that
+// view -- same arithmetic, slower.  Features come 16-channel blocked:
+// [B,C/16,H,W,16], so a footprint row is one contiguous run in memory.
+// Arithmetic is identical to the other kernels (pre-masked weights, FMA order):
+// results are bit-identical to them.
+constexpr int kTileW = 8, kTileH = 8, kTileD = 4;   // square tile: compact footprints under rotation
+constexpr int kTexelPad = 20;   // floats per staged 16-channel texel half (16 + 4 pad)
+
+// 16 channels of one view: bilinear blend of the four taps, then S += w, Q += w*w
+// (mvsnet.py:164-165).  Four channels at a time so at most 4 float4 loads are live.
+__device__ __forceinline__ void accumulate_taps(const float *__restrict__ t00,
+                                                const float *__restrict__ t01,
+                                                const float *__restrict__ t10,
+                                                const float *__restrict__ t11, float wnw, float wne,
+                                                float wsw, float wse, float (&S)[16],
+                                                float (&Q)[16]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float4 a = reinterpret_cast<const float4 *>(t00)[k];
+        const float4 bq = reinterpret_cast<const float4 *>(t01)[k];
+        const float4 c = reinterpret_cast<const float4 *>(t10)[k];
+        const float4 e = reinterpret_cast<const float4 *>(t11)[k];
+        const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {bq.x, bq.y, bq.z, bq.w};
+        const float cv[4] = {c.x, c.y, c.z, c.w}, ev[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const float w = __fmaf_rn(ev[cc], wse, __fmaf_rn(cv[cc], wsw,
+                                      __fmaf_rn(bv[cc], wne, av[cc] * wnw)));
+            S[k * 4 + cc] = S[k * 4 + cc] + w;
+            Q[k * 4 + cc] = Q[k * 4 + cc] + w * w;
+        }
+        __builtin_amdgcn_sched_barrier(0);   // bound register pressure: no hoisting across k
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256, 2) void variance_fwd_lds_kernel(
+    const float *__restrict__ ref16, const float *__restrict__ srcs16,
+    const float *__restrict__ rt, const float *__restrict__ depth, SweepParams p, int cap,
+    int tiles_x, int tiles_y, float *__restrict__ out, int out_c8) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // NV * cap * kTexelPad
+    __shared__ int s_box[NV][4];                                   // xmin, ymin, xmax, ymax
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int dc = bid / tiles_y;
+    const int b = blockIdx.y;
+    const int px = tx * kTileW + (lane & (kTileW - 1)), py = ty * kTileH + lane / kTileW;
+    const int d = dc * kTileD + wv;
+    const bool live = px < p.W && py < p.H && d < p.D;
+    const int cx = min(px, p.W - 1), cy = min(py, p.H - 1), cd = min(d, p.D - 1);
+    const int plane = p.H * p.W;
+    const int pix = cy * p.W + cx;
+    const float dv = p.depth_mode == 0 ? depth[(int64_t)b * p.D + cd]
+                                       : depth[((int64_t)b * p.D + cd) * plane + pix];
+    if (tid < NV) {
+        s_box[tid][0] = 0x7fffffff; s_box[tid][1] = 0x7fffffff;
+        s_box[tid][2] = -1; s_box[tid][3] = -1;
+    }
+    __syncthreads();
+
+    // ---- phase A: homography + tap set per source view (registers), footprint boxes
+    float wnw[NV], wne[NV], wsw[NV], wse[NV];
+    int tx0[NV], ty0[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const float *r = rt + ((int64_t)v * p.B + b) * 12;
+        float rx, ry, rz, ix, iy;
+        sweep_ray(r, (float)cx, (float)cy, rx, ry, rz);
+        sweep_coord(r, rx, ry, rz, dv, p.half_w, p.half_h, p.unn_w, p.unn_h, p.align_corners, ix,
+                    iy);
+        Taps t = make_taps(ix, iy, p.H, p.W);
+        const bool fin = (fabsf(ix) <= 3.0e38f) && (fabsf(iy) <= 3.0e38f);
+        const float dead = fin ? 0.0f : __int_as_float(0x7fc00000);
+        const bool m00 = t.x0ok && t.y0ok, m01 = t.x1ok && t.y0ok;
+        const bool m10 = t.x0ok && t.y1ok, m11 = t.x1ok && t.y1ok;
+        wnw[v] = m00 ? t.nw : dead; wne[v] = m01 ? t.ne : dead;
+        wsw[v] = m10 ? t.sw : dead; wse[v] = m11 ? t.se : dead;
+        // integer position of the (x0,y0) tap; x1 = x0+1, y1 = y0+1.  Saturate far-away
+        // coordinates so the int conversion is defined; their weights are dead anyway.
+        const float x0f = fminf(fmaxf(floorf(ix), -4.0f), (float)p.W + 4.0f);
+        const float y0f = fminf(fmaxf(floorf(iy), -4.0f), (float)p.H + 4.0f);
+        tx0[v] = fin ? (int)x0f : -4;
+        ty0[v] = fin ? (int)y0f : -4;
+        // box over the texels that carry a live weight
+        const bool anyx = t.x0ok || t.x1ok, anyy = t.y0ok || t.y1ok;
+        int lo_x = 0x7fffffff, hi_x = -1, lo_y = 0x7fffffff, hi_y = -1;
+        if (anyx && anyy) {
+            lo_x = t.x0ok ? tx0[v] : tx0[v] + 1;
+            hi_x = t.x1ok ? tx0[v] + 1 : tx0[v];
+            lo_y = t.y0ok ? ty0[v] : ty0[v] + 1;
+            hi_y = t.y1ok ? ty0[v] + 1 : ty0[v];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo_x = min(lo_x, __shfl_xor(lo_x, off)); hi_x = max(hi_x, __shfl_xor(hi_x, off));
+            lo_y = min(lo_y, __shfl_xor(lo_y, off)); hi_y = max(hi_y, __shfl_xor(hi_y, off));
+        }
+        if (lane == 0) {
+            atomicMin(&s_box[v][0], lo_x); atomicMin(&s_box[v][1], lo_y);
+            atomicMax(&s_box[v][2], hi_x); atomicMax(&s_box[v][3], hi_y);
+        }
+    }
+    __syncthreads();
+
+    int bx0[NV], by0[NV], bw[NV], bh[NV];
+    bool staged[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        // block-uniform: keep the boxes in SGPRs
+        int x0 = __builtin_amdgcn_readfirstlane(s_box[v][0]);
+        int y0 = __builtin_amdgcn_readfirstlane(s_box[v][1]);
+        int x1 = __builtin_amdgcn_readfirstlane(s_box[v][2]);
+        int y1 = __builtin_amdgcn_readfirstlane(s_box[v][3]);
+        if (x1 < x0 || y1 < y0) { x0 = y0 = x1 = y1 = 0; }   // no live tap in this block
+        bx0[v] = x0; by0[v] = y0; bw[v] = x1 - x0 + 1; bh[v] = y1 - y0 + 1;
+        staged[v] = bw[v] * bh[v] <= cap;
+    }
+
+    const int ngroups = p.C >> 4;
+    const float rV = 1.0f / p.fV;
+    const size_t grp_floats = (size_t)plane * 16;   // one 16-channel group of one map
+#pragma unroll 1
+    for (int g = 0; g < ngroups; ++g) {
+        if (g) __syncthreads();
+        // make the tap positions opaque per iteration: otherwise LICM hoists every
+        // view's 4 LDS offsets + 4 64-bit fallback pointers out of this loop and spills
+#pragma unroll
+        for (int v = 0; v < NV; ++v) asm volatile("" : "+v"(tx0[v]), "+v"(ty0[v]));
+        // ---- stage the footprints of this channel group
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if (!staged[v]) continue;   // block-uniform
+            const float *src = srcs16 + (((size_t)v * p.B + b) * ngroups + g) * grp_floats;
+            float *dst = lds + (size_t)v * cap * kTexelPad;
+            const int n4 = bw[v] * bh[v] * 4;
+            for (int e = tid; e < n4; e += 256) {
+                const int t = e >> 2, piece = e & 3;
+                const int ly = t / bw[v], lx = t - ly * bw[v];
+                const float4 val = *reinterpret_cast<const float4 *>(
+                    src + ((size_t)(by0[v] + ly) * p.W + (bx0[v] + lx)) * 16 + piece * 4);
+                *reinterpret_cast<float4 *>(dst + t * kTexelPad + piece * 4) = val;
+            }
+        }
+        __syncthreads();
+
+        // ---- accumulate S, Q over the views for this voxel's 16 channels
+        float S[16], Q[16];
+        {
+            const float4 *rp = reinterpret_cast<const float4 *>(
+                ref16 + ((size_t)b * ngroups + g) * grp_floats + (size_t)pix * 16);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 r4 = rp[k];
+                const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    Q[k * 4 + c] = rr[c] * rr[c];
+                    S[k * 4 + c] = p.alias_quirk ? Q[k * 4 + c] : rr[c];
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            // staged: clamp the tap into the staged box (typed LDS pointer -> ds_read);
+            // else: clamp into the image and gather from global.  Taps that fall outside
+            // carry a zero (or NaN) weight, so any in-range finite texel will do.
+            if (staged[v]) {
+                const int x0c = min(max(tx0[v], bx0[v]), bx0[v] + bw[v] - 1) - bx0[v];
+                const int x1c = min(max(tx0[v] + 1, bx0[v]), bx0[v] + bw[v] - 1) - bx0[v];
+                const int y0c = min(max(ty0[v], by0[v]), by0[v] + bh[v] - 1) - by0[v];
+                const int y1c = min(max(ty0[v] + 1, by0[v]), by0[v] + bh[v] - 1) - by0[v];
+                const float *base = lds + v * cap * kTexelPad;
+                accumulate_taps(base + (y0c * bw[v] + x0c) * kTexelPad,
+                                base + (y0c * bw[v] + x1c) * kTexelPad,
+                                base + (y1c * bw[v] + x0c) * kTexelPad,
+                                base + (y1c * bw[v] + x1c) * kTexelPad, wnw[v], wne[v], wsw[v],
+                                wse[v], S, Q);
+            } else {
+                const float *base = srcs16 + (((size_t)v * p.B + b) * ngroups + g) * grp_floats;
+                const int x0c = min(max(tx0[v], 0), p.W - 1), x1c = min(max(tx0[v] + 1, 0), p.W - 1);
+                const int y0c = min(max(ty0[v], 0), p.H - 1), y1c = min(max(ty0[v] + 1, 0), p.H - 1);
+                accumulate_taps(base + ((size_t)y0c * p.W + x0c) * 16,
+                                base + ((size_t)y0c * p.W + x1c) * 16,
+                                base + ((size_t)y1c * p.W + x0c) * 16,
+                                base + ((size_t)y1c * p.W + x1c) * 16, wnw[v], wne[v], wsw[v],
+                                wse[v], S, Q);
+            }
+        }
+        // ---- variance, store
+        float var[16];
+        bool tiny = false;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const float m = div_views_fast(S[c], p.fV, rV);
+            var[c] = div_views_fast(Q[c], p.fV, rV) - m * m;
+            tiny = tiny || div_views_tiny(S[c]) || div_views_tiny(Q[c]);
+        }
+        if (__any(tiny)) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const float m = S[c] / p.fV;
+                var[c] = Q[c] / p.fV - m * m;
+            }
+        }
+        if (live) {
+            const size_t vox = ((size_t)b * p.D + d) * plane + pix;
+            if (out_c8) {
+                const size_t row = ((size_t)b * p.D + d) * p.H + py;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float *o = out + ((row * (p.C >> 3) + (g * 2 + h)) * p.W + px) * 8;
+                    reinterpret_cast<float4 *>(o)[0] = make_float4(var[h * 8 + 0], var[h * 8 + 1], var[h * 8 + 2], var[h * 8 + 3]);
+                    reinterpret_cast<float4 *>(o)[1] = make_float4(var[h * 8 + 4], var[h * 8 + 5], var[h * 8 + 6], var[h * 8 + 7]);
+                }
+            } else {
+                float4 *o = reinterpret_cast<float4 *>(out + vox * p.C + g * 16);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    o[k] = make_float4(var[k * 4], var[k * 4 + 1], var[k * 4 + 2], var[k * 4 + 3]);
+            }
         }
     }
 }
@@ -443,10 +688,12 @@ static int launch_variance_cl(int NV, const float *ref, const float *srcs, const
     }
     const dim3 grid((unsigned)((per_item + 255) / 256), (unsigned)p.B);
     const FastDiv fdp = make_fastdiv((uint32_t)(p.H * p.W)), fdw = make_fastdiv((uint32_t)p.W);
+    const char *abl_env = getenv("MVS_SWEEP_ABLATE");   // tuning only
+    const int ablate = abl_env ? atoi(abl_env) : 0;
 #define MVS_CL_CASE(n)                                                                         \
     case n:                                                                                    \
         hipLaunchKernelGGL((variance_fwd_cl_kernel<CQ, n>), grid, dim3(256), 0, st, ref, srcs, \
-                           rt, depth, p, fdp, fdw, out, out_c8);                               \
+                           rt, depth, p, fdp, fdw, out, out_c8, ablate);                       \
         return MVS_OK;
     switch (NV) {
         MVS_CL_CASE(1) MVS_CL_CASE(2) MVS_CL_CASE(3) MVS_CL_CASE(4) MVS_CL_CASE(5) MVS_CL_CASE(6)
@@ -516,8 +763,10 @@ extern "C" int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *s
         return MVS_EUNSUPPORTED;
     }
     const int out_c8 = out_layout == MVS_LAYOUT_C8;
-    if (fea_layout != out_layout && !(fea_layout == MVS_LAYOUT_NHWC && out_c8)) {
-        set_error("mvs_costvol_variance_fwd_f32: out_layout must equal fea_layout (or be C8 with NHWC features)");
+    const bool fea_cl = fea_layout == MVS_LAYOUT_NHWC || fea_layout == MVS_LAYOUT_C16;
+    if (fea_layout != out_layout && !(fea_cl && (out_c8 || out_layout == MVS_LAYOUT_NHWC))) {
+        set_error("mvs_costvol_variance_fwd_f32: unsupported layout pair fea=%d out=%d", fea_layout,
+                  out_layout);
         return MVS_EUNSUPPORTED;
     }
     SweepParams p = make_params(B, V, C, D, H, W, depth_mode, align_corners, alias_quirk);
@@ -540,6 +789,34 @@ extern "C" int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *s
         }
 #undef MVS_PL_CASE
         return check_launch("mvs_costvol_variance_fwd_f32(planar)");
+    }
+    if (fea_layout == MVS_LAYOUT_C16) {
+        // LDS-staged kernel: features [B,C/16,H,W,16]
+        if (C % 16 || C > 64) {
+            set_error("mvs_costvol_variance_fwd_f32: C16 features need C in {16,32,48,64}, got %d", C);
+            return MVS_EUNSUPPORTED;
+        }
+        if ((int64_t)H * W >= (1 << 26) || B > 65535) return MVS_EINVAL;
+        const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (H + kTileH - 1) / kTileH;
+        const int dchunks = (D + kTileD - 1) / kTileD;
+        const int64_t nblk = (int64_t)tiles_x * tiles_y * dchunks;
+        if (nblk > 0x7fffffffLL) return MVS_EINVAL;
+        // LDS share per view: 48 KiB in total keeps 3 blocks (12 waves) per CU
+        const int cap = (48 * 1024) / (NV * kTexelPad * 4);
+        const size_t shmem = (size_t)NV * cap * kTexelPad * sizeof(float);
+        const dim3 g((unsigned)nblk, (unsigned)B);
+#define MVS_LDS_CASE(n)                                                                        \
+    case n:                                                                                    \
+        hipLaunchKernelGGL((variance_fwd_lds_kernel<n>), g, dim3(256), shmem, st, ref_fea,     \
+                           src_feas, rot_trans, depth_values, p, cap, tiles_x, tiles_y,        \
+                           out_var, out_c8);                                                   \
+        break;
+        switch (NV) {
+            MVS_LDS_CASE(1) MVS_LDS_CASE(2) MVS_LDS_CASE(3) MVS_LDS_CASE(4) MVS_LDS_CASE(5)
+            MVS_LDS_CASE(6) MVS_LDS_CASE(7) MVS_LDS_CASE(8)
+        }
+#undef MVS_LDS_CASE
+        return check_launch("mvs_costvol_variance_fwd_f32(lds)");
     }
     if (fea_layout != MVS_LAYOUT_NHWC) return MVS_EINVAL;
     int rc;

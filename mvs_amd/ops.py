@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import (MVS_LAYOUT_C8, MVS_LAYOUT_NCHW, MVS_LAYOUT_NHWC, MvsHipError, check, ptr,
+from ._lib import (MVS_LAYOUT_C8, MVS_LAYOUT_C16, MVS_LAYOUT_NCHW, MVS_LAYOUT_NHWC, MvsHipError, check, ptr,
                    stream)
 
 _I = ctypes.c_int
@@ -210,6 +210,41 @@ def costvol_variance_cl(ref_fea_cl, src_feas_cl, rts, depth_values, align_corner
     check(_lib.load().mvs_costvol_variance_fwd_f32(
         ptr(ref_fea_cl), ptr(src_feas_cl), ptr(rts), ptr(depth_values), _depth_mode(depth_values),
         B, V, C, D, H, W, int(align_corners), int(alias_quirk), MVS_LAYOUT_NHWC,
+        MVS_LAYOUT_C8 if out_c8 else MVS_LAYOUT_NHWC, ptr(out), stream()),
+        "mvs_costvol_variance_fwd_f32")
+    return out
+
+
+def nchw_to_c16(x):
+    """[...,C,H,W] -> [...,C/16,H,W,16]: 16-channel blocked feature maps for the
+    LDS-staged variance kernel (one HIP transpose launch)."""
+    x = _f32c(x)
+    *lead, C, H, W = x.shape
+    if C % 16:
+        raise MvsHipError(f"nchw_to_c16 needs C % 16 == 0, got {C}")
+    n = 1
+    for v in lead:
+        n *= v
+    out = torch.empty(tuple(lead) + (C // 16, H, W, 16), device=x.device, dtype=torch.float32)
+    check(_lib.load().mvs_nchw_to_nhwc_f32(ptr(x), ptr(out), n * (C // 16), 16, H * W, stream()),
+          "mvs_nchw_to_nhwc_f32")
+    return out
+
+
+def costvol_variance_c16(ref16, srcs16, rts, depth_values, align_corners=False, alias_quirk=False,
+                         out_c8=False):
+    """LDS-staged fused warp+variance.  ref16 [B,C/16,H,W,16]; srcs16 [V-1,B,C/16,H,W,16]
+    -> [B,D,H,W,C] or (out_c8) [B,D,H,C/8,W,8]."""
+    ref16, srcs16, depth_values = _f32c(ref16), _f32c(srcs16), _f32c(depth_values)
+    B, G, H, W, _ = ref16.shape
+    C = G * 16
+    V = srcs16.shape[0] + 1
+    D = depth_values.shape[1]
+    shape = (B, D, H, C // 8, W, 8) if out_c8 else (B, D, H, W, C)
+    out = torch.empty(shape, device=ref16.device, dtype=torch.float32)
+    check(_lib.load().mvs_costvol_variance_fwd_f32(
+        ptr(ref16), ptr(srcs16), ptr(rts), ptr(depth_values), _depth_mode(depth_values), B, V, C,
+        D, H, W, int(align_corners), int(alias_quirk), MVS_LAYOUT_C16,
         MVS_LAYOUT_C8 if out_c8 else MVS_LAYOUT_NHWC, ptr(out), stream()),
         "mvs_costvol_variance_fwd_f32")
     return out

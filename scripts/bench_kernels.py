@@ -73,6 +73,15 @@ def main():
         byt = (V * 32 * h * w + D + 32 * D * h * w) * 4
         res["variance"] = {"ms": round(med, 4), "best_ms": round(best, 4), "GBs": round(byt / med / 1e6, 1),
                            "frac_hbm": round(byt / med / 1e6 / 8000, 4)}
+    if want("variance_lds"):
+        proj = torch.from_numpy(synth.proj_matrices(V, h, w)).to(dev)
+        dv = torch.from_numpy(synth.depth_values(D)).to(dev)
+        f16 = torch.randn(V, 1, 2, h, w, 16, device=dev, generator=g)
+        rts = torch.stack([ops.rot_trans(proj[:, v], proj[:, 0]) for v in range(1, V)])
+        med, best = timeit(lambda: ops.costvol_variance_c16(f16[0], f16[1:], rts, dv, out_c8=True), reps)
+        byt = (V * 32 * h * w + D + 32 * D * h * w) * 4
+        res["variance_lds"] = {"ms": round(med, 4), "best_ms": round(best, 4), "GBs": round(byt / med / 1e6, 1),
+                               "frac_hbm": round(byt / med / 1e6 / 8000, 4)}
     if want("regress"):
         cost = torch.randn(1, D, h, w, device=dev, generator=g) * 4
         dv = torch.from_numpy(synth.depth_values(D)).to(dev)

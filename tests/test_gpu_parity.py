@@ -119,6 +119,54 @@ def test_variance_golden(dev, name, layout):
     assert (var == g["variance"]).mean() > 0.999
 
 
+@pytest.mark.parametrize("name", ["g6_e2e_64x96_v3_d8", "g3_e2e_64x64_v2_d8",
+                                  "g3_e2e_64x64_v5_d8_b2"])
+@pytest.mark.parametrize("out_c8", [False, True])
+def test_variance_lds_staged_golden(dev, name, out_c8):
+    """LDS-staged kernel (16-channel blocked features) against the reference."""
+    from mvs_amd import ops
+    g = load_golden(name)
+    f = g["features"]
+    V = f.shape[1]
+    ref16 = ops.nchw_to_c16(G(f[:, 0], dev))
+    srcs16 = ops.nchw_to_c16(G(np.stack([f[:, v] for v in range(1, V)]), dev))
+    assert ref16.shape == (f.shape[0], 2, f.shape[3], f.shape[4], 16)
+    out = ops.costvol_variance_c16(ref16, srcs16, G(_rts(g["proj"]), dev), G(g["depth_values"], dev),
+                                   out_c8=out_c8)
+    var = ops.c8_to_nchw(out) if out_c8 else out.permute(0, 4, 1, 2, 3).contiguous()
+    np.testing.assert_allclose(var.cpu().numpy(), g["variance"], atol=1e-7, rtol=0)
+    assert (var.cpu().numpy() == g["variance"]).mean() > 0.999
+
+
+def test_variance_lds_staged_vs_oracle_ragged_and_fallback(dev):
+    """Ragged sizes, per-pixel hypotheses, the CVP alias quirk, 7 source views
+    (small LDS share per view) and a wide-baseline camera whose footprint does
+    not fit in LDS (global-gather fallback inside the same kernel)."""
+    from mvs_amd import ops, synth
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(11)
+    for (B, C, D, H, W, V, quirk, wide) in [(1, 32, 6, 37, 53, 4, False, False),
+                                            (2, 16, 5, 21, 30, 3, True, False),
+                                            (1, 32, 4, 40, 48, 7, False, False),
+                                            (1, 32, 8, 64, 80, 3, False, True)]:
+        proj = synth.proj_matrices(V, H, W, batch=B)
+        if wide:   # scale + strong rotation: the source footprint of a tile is huge
+            proj[:, 1, :2, :3] *= 3.0
+            proj[:, 2, :3, :3] = proj[:, 2, :3, :3] @ np.array(
+                [[0, -1, 0], [1, 0, 0], [0, 0, 1]], np.float32)
+        feats = synth.smooth_features(rng, (V, B, C, H, W))
+        base = synth.depth_values(D, batch=B, interval=synth.sweep_interval(D))
+        pp = (base[:, :, None, None] + 5 * rng.standard_normal((B, D, H, W))).astype(np.float32)
+        rts = _rts(proj)
+        for depth in (base, pp):
+            want = co.costvol_variance(feats[0], feats[1:], rts, depth, alias_quirk=quirk)
+            out = ops.costvol_variance_c16(ops.nchw_to_c16(G(feats[0], dev)),
+                                           ops.nchw_to_c16(G(feats[1:], dev)), G(rts, dev),
+                                           G(depth, dev), alias_quirk=quirk)
+            got = out.permute(0, 4, 1, 2, 3).cpu().numpy()
+            np.testing.assert_allclose(got, want, atol=1e-7, rtol=0)
+
+
 @pytest.mark.parametrize("V", [2, 3, 5, 7])
 def test_division_by_view_count_is_ieee_exact(dev, V):
     """The variance kernel's 3-op division by V equals IEEE x / V for all 2^32
