@@ -55,6 +55,10 @@ struct ConvCfg {
     static constexpr int RPW = ROWS / 4;              // N-tiles (rows) per wave
     static constexpr int XOUT = (MODE == 2) ? 32 : 16;
     static constexpr int LDS_FLOATS = 4 * PLANE * KS;
+    // Preload a whole chunk's weight fragments into registers ahead of the staging
+    // phase when they fit (conv0: 36 taps x 2 floats = 72 VGPRs): the MFMA loop then
+    // never waits on a global load.
+    static constexpr bool PREA = (NTAPS * MT * KS <= 80);
     static_assert(CIN % CK == 0, "CIN must be a multiple of the chunk");
     static_assert(CK == 8 || CK == 16, "chunk is 8 or 16 channels");
     static_assert(ROWS % 4 == 0, "rows split over 4 waves");
@@ -113,6 +117,23 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
 
 #pragma unroll 1
     for (int ch = 0; ch < Cfg::NCHUNK; ++ch) {
+        const float *wch = a.wpk + (int64_t)ch * NTAPS * MT * 64 * KS + lane * KS;
+        float apre[Cfg::PREA ? NTAPS : 1][MT][KS];
+        if constexpr (Cfg::PREA && !(ABL & 2)) {
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const float *wp = wch + (t * MT + m) * 64 * KS;
+                    if constexpr (KS == 4) {
+                        float4 w4 = *reinterpret_cast<const float4 *>(wp);
+                        apre[t][m][0] = w4.x; apre[t][m][1] = w4.y; apre[t][m][2] = w4.z; apre[t][m][3] = w4.w;
+                    } else {
+                        float2 w2 = *reinterpret_cast<const float2 *>(wp);
+                        apre[t][m][0] = w2.x; apre[t][m][1] = w2.y;
+                    }
+                }
+        }
         if (ch) __syncthreads();
         // ---- stage the halo tile of CK channels: global (channels-last) -> LDS planes.
         // Compile-time trip count, SB loads in flight per thread per batch (the
@@ -171,8 +192,8 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
         }
         __syncthreads();
 
-        const float *wch = a.wpk + (int64_t)ch * NTAPS * MT * 64 * KS + lane * KS;
-#pragma unroll 1
+        constexpr int KZ_UNROLL = Cfg::PREA ? 3 : 1;
+#pragma unroll KZ_UNROLL
         for (int kz = 0; kz < 3; ++kz) {
             const float *rdz = lds + rd_base + kz * (YT * XTP) * KS;
             const float *wkz = wch + kz * (3 * NKX) * MT * 64 * KS;
@@ -187,6 +208,9 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
                     if constexpr (ABL & 2) {
 #pragma unroll
                         for (int k = 0; k < KS; ++k) af[m][k] = (float)(lane + kyx + k);
+                    } else if constexpr (Cfg::PREA) {
+#pragma unroll
+                        for (int k = 0; k < KS; ++k) af[m][k] = apre[kz * 3 * NKX + kyx][m][k];
                     } else if constexpr (KS == 4) {
                         float4 t = *reinterpret_cast<const float4 *>(wp);
                         af[m][0] = t.x; af[m][1] = t.y; af[m][2] = t.z; af[m][3] = t.w;
