@@ -34,8 +34,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int round_up_c(int v, int m) { return (v + m - 1) / m * m; }
 
-template <int CIN_, int COUT_, int MODE_, int CK_, int TZ_, int TY_>
+template <int CIN_, int COUT_, int MODE_, int CK_, int TZ_, int TY_, int SB_ = 8, int PREA_ = -1>
 struct ConvCfg {
+    static constexpr int SB = SB_;   // staging loads in flight per thread
     static constexpr int CIN = CIN_, COUT = COUT_, MODE = MODE_, CK = CK_, TZ = TZ_, TY = TY_;
     static constexpr int SX = (MODE == 0) ? 1 : 2;    // x step of a wave's B reads
     static constexpr int SZY = (MODE == 1) ? 2 : 1;   // conv stride in y, z
@@ -58,7 +59,7 @@ struct ConvCfg {
     // Preload a whole chunk's weight fragments into registers ahead of the staging
     // phase when they fit (conv0: 36 taps x 2 floats = 72 VGPRs): the MFMA loop then
     // never waits on a global load.
-    static constexpr bool PREA = (NTAPS * MT * KS <= 80);
+    static constexpr bool PREA = PREA_ < 0 ? (NTAPS * MT * KS <= 80) : (PREA_ != 0);
     static_assert(CIN % CK == 0, "CIN must be a multiple of the chunk");
     static_assert(CK == 8 || CK == 16, "chunk is 8 or 16 channels");
     static_assert(ROWS % 4 == 0, "rows split over 4 waves");
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
         // volume streams from HBM: one load at a time is pure latency).
         {
             constexpr int NIT = (4 * NVOX + 255) / 256;
-            constexpr int SB = 8;
+            constexpr int SB = Cfg::SB;
 #pragma unroll 1
             for (int it0 = 0; it0 < NIT; it0 += SB) {
                 float stg[SB][KS];
@@ -696,7 +697,10 @@ static bool lookup(int transposed, int Cin, int Cout, int stride, CfgInfo &ci) {
     }
     if (stride == 1) {
         // Cout = 8: shifted form (conv0 of MVSNet / of the CasMVSNet stages)
-        MVS_CFG(32, 8, 2, 8, 4, 8)
+        if (Cin == 32 && Cout == 8) {   // conv0: 16 staging loads in flight, no A preload (measured best)
+            ci = info_of<ConvCfg<32, 8, 2, 8, 4, 8, 16, 0>>();
+            return true;
+        }
         MVS_CFG(16, 8, 2, 8, 4, 8)
         MVS_CFG(8, 8, 2, 8, 4, 8)
         MVS_CFG(8, 16, 0, 8, 4, 8)
@@ -815,6 +819,15 @@ int conv3d_mfma_launch(const float *in, const float *packed, const float *scale,
             case 12: kern = conv3d_mfma_kernel<C0, 12>; break;
             case 14: kern = conv3d_mfma_kernel<C0, 14>; break;
             case 15: kern = conv3d_mfma_kernel<C0, 15>; break;
+            default: break;
+        }
+        const char *var = getenv("MVS_CONV0_VARIANT");   // tuning: staging depth / A preload
+        switch (var ? atoi(var) : 0) {
+            case 1: kern = conv3d_mfma_kernel<ConvCfg<32, 8, 2, 8, 4, 8, 8, 0>, 0>; break;
+            case 2: kern = conv3d_mfma_kernel<ConvCfg<32, 8, 2, 8, 4, 8, 16, 0>, 0>; break;
+            case 3: kern = conv3d_mfma_kernel<ConvCfg<32, 8, 2, 8, 4, 8, 32, 0>, 0>; break;
+            case 4: kern = conv3d_mfma_kernel<ConvCfg<32, 8, 2, 8, 4, 8, 16, 1>, 0>; break;
+            case 5: kern = conv3d_mfma_kernel<ConvCfg<32, 8, 2, 8, 4, 8, 32, 1>, 0>; break;
             default: break;
         }
     }

@@ -381,11 +381,18 @@ __device__ __forceinline__ void accumulate_taps(const float *__restrict__ t00,
     }
 }
 
+// LDS share per view (texels): 48 KiB in total keeps 2-3 blocks per CU
+__host__ __device__ constexpr int lds_cap(int nv) {
+    return (48 * 1024) / (nv * kTexelPad * 4) > 256 ? 256 : (48 * 1024) / (nv * kTexelPad * 4);
+}
+
 template <int NV>
 __global__ __launch_bounds__(256, 2) void variance_fwd_lds_kernel(
     const float *__restrict__ ref16, const float *__restrict__ srcs16,
-    const float *__restrict__ rt, const float *__restrict__ depth, SweepParams p, int cap,
+    const float *__restrict__ rt, const float *__restrict__ depth, SweepParams p,
     int tiles_x, int tiles_y, float *__restrict__ out, int out_c8) {
+    constexpr int cap = lds_cap(NV);
+    constexpr int MAXIT = (cap * 4 + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float lds[];   // NV * cap * kTexelPad
     __shared__ int s_box[NV][4];                                   // xmin, ymin, xmax, ymax
 
@@ -477,19 +484,37 @@ __global__ __launch_bounds__(256, 2) void variance_fwd_lds_kernel(
         // view's 4 LDS offsets + 4 64-bit fallback pointers out of this loop and spills
 #pragma unroll
         for (int v = 0; v < NV; ++v) asm volatile("" : "+v"(tx0[v]), "+v"(ty0[v]));
-        // ---- stage the footprints of this channel group
+        // ---- stage the footprints of this channel group.  All loads of all views
+        // are issued before the first LDS write (MAXIT*NV float4 in flight per thread):
+        // a one-load-at-a-time copy loop is pure L2 latency.
+        {
+            float4 sv4[NV][MAXIT];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            if (!staged[v]) continue;   // block-uniform
-            const float *src = srcs16 + (((size_t)v * p.B + b) * ngroups + g) * grp_floats;
-            float *dst = lds + (size_t)v * cap * kTexelPad;
-            const int n4 = bw[v] * bh[v] * 4;
-            for (int e = tid; e < n4; e += 256) {
-                const int t = e >> 2, piece = e & 3;
-                const int ly = t / bw[v], lx = t - ly * bw[v];
-                const float4 val = *reinterpret_cast<const float4 *>(
-                    src + ((size_t)(by0[v] + ly) * p.W + (bx0[v] + lx)) * 16 + piece * 4);
-                *reinterpret_cast<float4 *>(dst + t * kTexelPad + piece * 4) = val;
+            for (int v = 0; v < NV; ++v) {
+                const float *src = srcs16 + (((size_t)v * p.B + b) * ngroups + g) * grp_floats;
+                const int n4 = staged[v] ? bw[v] * bh[v] * 4 : 0;
+                const unsigned inv = (65536u + bw[v] - 1) / bw[v];   // t / bw for t < cap
+#pragma unroll
+                for (int it = 0; it < MAXIT; ++it) {
+                    const int e = tid + it * 256;
+                    const int ec = min(e, max(n4 - 1, 0));
+                    const int t = ec >> 2, piece = ec & 3;
+                    const int ly = (int)(((unsigned)t * inv) >> 16), lx = t - ly * bw[v];
+                    sv4[v][it] = *reinterpret_cast<const float4 *>(
+                        src + ((size_t)(by0[v] + ly) * p.W + (bx0[v] + lx)) * 16 + piece * 4);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int n4 = staged[v] ? bw[v] * bh[v] * 4 : 0;
+                float *dst = lds + v * cap * kTexelPad;
+#pragma unroll
+                for (int it = 0; it < MAXIT; ++it) {
+                    const int e = tid + it * 256;
+                    if (e < n4)
+                        *reinterpret_cast<float4 *>(dst + (e >> 2) * kTexelPad + (e & 3) * 4) =
+                            sv4[v][it];
+                }
             }
         }
         __syncthreads();
@@ -801,15 +826,13 @@ extern "C" int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *s
         const int dchunks = (D + kTileD - 1) / kTileD;
         const int64_t nblk = (int64_t)tiles_x * tiles_y * dchunks;
         if (nblk > 0x7fffffffLL) return MVS_EINVAL;
-        // LDS share per view: 48 KiB in total keeps 3 blocks (12 waves) per CU
-        const int cap = (48 * 1024) / (NV * kTexelPad * 4);
-        const size_t shmem = (size_t)NV * cap * kTexelPad * sizeof(float);
+        const size_t shmem = (size_t)NV * lds_cap(NV) * kTexelPad * sizeof(float);
         const dim3 g((unsigned)nblk, (unsigned)B);
 #define MVS_LDS_CASE(n)                                                                        \
     case n:                                                                                    \
         hipLaunchKernelGGL((variance_fwd_lds_kernel<n>), g, dim3(256), shmem, st, ref_fea,     \
-                           src_feas, rot_trans, depth_values, p, cap, tiles_x, tiles_y,        \
-                           out_var, out_c8);                                                   \
+                           src_feas, rot_trans, depth_values, p, tiles_x, tiles_y, out_var,    \
+                           out_c8);                                                            \
         break;
         switch (NV) {
             MVS_LDS_CASE(1) MVS_LDS_CASE(2) MVS_LDS_CASE(3) MVS_LDS_CASE(4) MVS_LDS_CASE(5)

@@ -178,6 +178,8 @@ class MVSNet(nn.Module):
         self.refine = refine
         self.align_corners = align_corners
         self.proj_where = proj_where
+        self.variance_impl = "lds"      # "lds" (LDS-staged source tiles) | "gather"
+        self._feature_cl = False
         self.feature = FeatureNet()
         self.cost_regularization = CostRegNet()
         if self.refine:
@@ -187,34 +189,47 @@ class MVSNet(nn.Module):
         if imgs.shape[1] != proj_matrices.shape[1]:
             raise AssertionError("Different number of images and projection matrices")
         V = imgs.shape[1]
-        with ops.stage("feature"):
-            if self.training:
-                # per-view calls: BatchNorm batch statistics are per call in the
-                # reference (mvsnet.py:146)
-                feats = [self.feature(imgs[:, v]) for v in range(V)]
-            else:
-                # eval: running-stat BN is per-sample, so all B*V views go through
-                # FeatureNet as one batch (same values, 1/V the launches)
-                B = imgs.shape[0]
-                f = self.feature(imgs.reshape(B * V, *imgs.shape[2:]))
-                f = f.reshape(B, V, *f.shape[1:])
-                feats = [f[:, v] for v in range(V)]
         ref_proj = proj_matrices[:, 0]
         with ops.stage("rot_trans"):
             rts = torch.stack([ops.rot_trans(proj_matrices[:, v], ref_proj, self.proj_where)
                                for v in range(1, V)])                   # [V-1,B,12]
-        if self.training or torch.is_grad_enabled() and any(f.requires_grad for f in feats):
+        autograd_path = self.training or (torch.is_grad_enabled() and
+                                          any(p.requires_grad for p in self.parameters()))
+        if autograd_path:
+            with ops.stage("feature"):
+                # per-view calls: BatchNorm batch statistics are per call in the
+                # reference (mvsnet.py:146)
+                feats = [self.feature(imgs[:, v]) for v in range(V)]
             var = ops.costvol_variance(feats[0], torch.stack(feats[1:]), rts, depth_values,
                                        self.align_corners)              # [B,32,D,h,w]
             cost = self.cost_regularization(var).squeeze(1)
         else:
-            with ops.stage("to_channels_last"):
-                ref_cl = ops.nchw_to_nhwc(feats[0])
-                src_cl = torch.stack([ops.nchw_to_nhwc(f) for f in feats[1:]])
+            B = imgs.shape[0]
+            with ops.stage("feature"):
+                # eval: running-stat BN is per-sample, so all B*V views go through
+                # FeatureNet as one batch, in channels_last (MIOpen's NHWC kernels are
+                # faster here and hand over the layout the sweep kernel wants)
+                if not self._feature_cl:
+                    self.feature.to(memory_format=torch.channels_last)
+                    self._feature_cl = True
+                x = imgs.reshape(B * V, *imgs.shape[2:]).contiguous(memory_format=torch.channels_last)
+                f = self.feature(x)                                      # [B*V,32,h,w], NHWC strides
+                f = f.permute(0, 2, 3, 1)                                # [B*V,h,w,32] view
+                h, w, C = f.shape[1], f.shape[2], f.shape[3]
             c8 = self.cost_regularization.wants_c8_input()
+            use_lds = self.variance_impl == "lds" and C % 16 == 0
+            with ops.stage("to_channels_last"):
+                if use_lds:   # [B*V,h,w,C] -> [V,B,C/16,h,w,16]
+                    f16 = f.reshape(B, V, h, w, C // 16, 16).permute(1, 0, 4, 2, 3, 5).contiguous()
+                else:
+                    fcl = f.reshape(B, V, h, w, C).transpose(0, 1).contiguous()   # [V,B,h,w,C]
             with ops.stage("costvol_variance"):
-                var = ops.costvol_variance_cl(ref_cl, src_cl, rts, depth_values,
-                                              self.align_corners, out_c8=c8)
+                if use_lds:
+                    var = ops.costvol_variance_c16(f16[0], f16[1:], rts, depth_values,
+                                                   self.align_corners, out_c8=c8)
+                else:
+                    var = ops.costvol_variance_cl(fcl[0], fcl[1:], rts, depth_values,
+                                                  self.align_corners, out_c8=c8)
             cost = self.cost_regularization.forward_hip(var, in_c8=c8)  # [B,D,h,w]
         with ops.stage("softmax_regress_conf"):
             depth, conf, _ = ops.softmax_regress_conf(cost, depth_values)
