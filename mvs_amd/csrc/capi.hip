@@ -50,11 +50,39 @@ __global__ __launch_bounds__(256) void transpose_cs_kernel(const float *__restri
     }
 }
 
+// [B][R][S] -> [B][S][R] for tiny R (RGB images): one thread per position, R
+// coalesced plane reads, one R*4-byte contiguous write.
+template <int R>
+__global__ __launch_bounds__(256) void transpose_small_r_kernel(const float *__restrict__ in,
+                                                                float *__restrict__ out,
+                                                                int64_t S) {
+    const int b = blockIdx.y;
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= S) return;
+    const float *ip = in + (int64_t)b * R * S + s;
+    float v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = ip[(int64_t)r * S];
+    float *op = out + ((int64_t)b * S + s) * R;
+#pragma unroll
+    for (int r = 0; r < R; ++r) op[r] = v[r];
+}
+
 static int launch_transpose(const float *in, float *out, int B, int R, int64_t S, hipStream_t st,
                             const char *what) {
     if (!in || !out || B <= 0 || R <= 0 || S <= 0) {
         set_error("%s: invalid argument", what);
         return MVS_EINVAL;
+    }
+    if (R <= 4 && B <= 65535 && (S + 255) / 256 <= 0x7fffffffLL) {
+        const dim3 g((unsigned)((S + 255) / 256), (unsigned)B);
+        switch (R) {
+            case 1: hipLaunchKernelGGL(transpose_small_r_kernel<1>, g, dim3(256), 0, st, in, out, S); break;
+            case 2: hipLaunchKernelGGL(transpose_small_r_kernel<2>, g, dim3(256), 0, st, in, out, S); break;
+            case 3: hipLaunchKernelGGL(transpose_small_r_kernel<3>, g, dim3(256), 0, st, in, out, S); break;
+            default: hipLaunchKernelGGL(transpose_small_r_kernel<4>, g, dim3(256), 0, st, in, out, S); break;
+        }
+        return check_launch(what);
     }
     // generic: in [B][R][S] -> out [B][S][R]
     int64_t gx = (S + 31) / 32;

@@ -377,7 +377,7 @@ __device__ __forceinline__ void accumulate_taps(const float *__restrict__ t00,
             S[k * 4 + cc] = S[k * 4 + cc] + w;
             Q[k * 4 + cc] = Q[k * 4 + cc] + w * w;
         }
-        __builtin_amdgcn_sched_barrier(0);   // bound register pressure: no hoisting across k
+        if (k == 1) __builtin_amdgcn_sched_barrier(0);   // 8 tap loads in flight, not 16
     }
 }
 
@@ -390,7 +390,7 @@ template <int NV>
 __global__ __launch_bounds__(256, 2) void variance_fwd_lds_kernel(
     const float *__restrict__ ref16, const float *__restrict__ srcs16,
     const float *__restrict__ rt, const float *__restrict__ depth, SweepParams p,
-    int tiles_x, int tiles_y, float *__restrict__ out, int out_c8) {
+    int tiles_x, int tiles_y, float *__restrict__ out, int out_c8, int ablate) {
     constexpr int cap = lds_cap(NV);
     constexpr int MAXIT = (cap * 4 + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float lds[];   // NV * cap * kTexelPad
@@ -423,9 +423,13 @@ __global__ __launch_bounds__(256, 2) void variance_fwd_lds_kernel(
     for (int v = 0; v < NV; ++v) {
         const float *r = rt + ((int64_t)v * p.B + b) * 12;
         float rx, ry, rz, ix, iy;
-        sweep_ray(r, (float)cx, (float)cy, rx, ry, rz);
-        sweep_coord(r, rx, ry, rz, dv, p.half_w, p.half_h, p.unn_w, p.unn_h, p.align_corners, ix,
-                    iy);
+        if (ablate & 4) {   // tuning: no homography arithmetic
+            ix = (float)cx + 0.25f + r[3] * 1e-30f; iy = (float)cy + 0.25f;
+        } else {
+            sweep_ray(r, (float)cx, (float)cy, rx, ry, rz);
+            sweep_coord(r, rx, ry, rz, dv, p.half_w, p.half_h, p.unn_w, p.unn_h, p.align_corners,
+                        ix, iy);
+        }
         Taps t = make_taps(ix, iy, p.H, p.W);
         const bool fin = (fabsf(ix) <= 3.0e38f) && (fabsf(iy) <= 3.0e38f);
         const float dead = fin ? 0.0f : __int_as_float(0x7fc00000);
@@ -492,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void variance_fwd_lds_kernel(
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const float *src = srcs16 + (((size_t)v * p.B + b) * ngroups + g) * grp_floats;
-                const int n4 = staged[v] ? bw[v] * bh[v] * 4 : 0;
+                const int n4 = (staged[v] && !(ablate & 1)) ? bw[v] * bh[v] * 4 : 0;
                 const unsigned inv = (65536u + bw[v] - 1) / bw[v];   // t / bw for t < cap
 #pragma unroll
                 for (int it = 0; it < MAXIT; ++it) {
@@ -537,6 +541,7 @@ __global__ __launch_bounds__(256, 2) void variance_fwd_lds_kernel(
         }
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
+            if (ablate & 2) continue;   // tuning: no tap accumulation
             // staged: clamp the tap into the staged box (typed LDS pointer -> ds_read);
             // else: clamp into the image and gather from global.  Taps that fall outside
             // carry a zero (or NaN) weight, so any in-range finite texel will do.
@@ -827,12 +832,14 @@ extern "C" int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *s
         const int64_t nblk = (int64_t)tiles_x * tiles_y * dchunks;
         if (nblk > 0x7fffffffLL) return MVS_EINVAL;
         const size_t shmem = (size_t)NV * lds_cap(NV) * kTexelPad * sizeof(float);
+        const char *abl_env = getenv("MVS_SWEEP_ABLATE");   // tuning only
+        const int lds_ablate = abl_env ? atoi(abl_env) : 0;
         const dim3 g((unsigned)nblk, (unsigned)B);
 #define MVS_LDS_CASE(n)                                                                        \
     case n:                                                                                    \
         hipLaunchKernelGGL((variance_fwd_lds_kernel<n>), g, dim3(256), shmem, st, ref_fea,     \
                            src_feas, rot_trans, depth_values, p, tiles_x, tiles_y, out_var,    \
-                           out_c8);                                                            \
+                           out_c8, lds_ablate);                                                \
         break;
         switch (NV) {
             MVS_LDS_CASE(1) MVS_LDS_CASE(2) MVS_LDS_CASE(3) MVS_LDS_CASE(4) MVS_LDS_CASE(5)
