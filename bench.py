@@ -63,7 +63,23 @@ def algorithmic_work(V, C, D, h, w):
     return work
 
 
-def roofline_entry(name, kind, amount, ms):
+def pmc_traffic():
+    """HBM-side bytes per launch measured with rocprofv3 PMC passes of this same
+    command (profiles/pmc_traffic.json, written from scripts/profile_round.sh)."""
+    try:
+        with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
+            return {k: v.get("traffic_bytes") for k, v in json.load(f)["kernels"].items()}
+    except (OSError, ValueError, KeyError):
+        return {}
+
+
+def roofline_entry(name, kind, amount, ms, traffic=None):
+    e = _roofline_entry(name, kind, amount, ms)
+    e["traffic"] = traffic
+    return e
+
+
+def _roofline_entry(name, kind, amount, ms):
     if kind == "hbm":
         ach = amount / (ms * 1e-3) / 1e9
         return {"kernel": name, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
@@ -98,6 +114,9 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
+    # the reference's drivers set this (MVSNet/eval.py:23, train.py:25); on ROCm it lets
+    # MIOpen pick its fastest FeatureNet convolution kernels during warm-up
+    torch.backends.cudnn.benchmark = True
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -167,8 +186,11 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.steps / elapsed
     kind, amount = work[dominant]
-    roof = roofline_entry(dominant, kind, amount, live.summary_ms()[dominant][1])
-    rooflines = [roofline_entry(k, work[k][0], work[k][1], stages[k]) for k in stages if k in work]
+    traffic = pmc_traffic() if (H, W, V, D) == (1184, 1600, 5, 192) else {}
+    roof = roofline_entry(dominant, kind, amount, live.summary_ms()[dominant][1],
+                          traffic.get(dominant))
+    rooflines = [roofline_entry(k, work[k][0], work[k][1], stages[k], traffic.get(k))
+                 for k in stages if k in work]
     line = {
         "metric": "depth-maps/sec", "value": round(value, 4), "unit": "depth-maps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -690,9 +690,11 @@ static bool lookup(int transposed, int Cin, int Cout, int stride, CfgInfo &ci) {
     }
     if (transposed) {
         if (stride != 2) return false;
-        MVS_DCFG(64, 32, 16, 2, 4, false)
-        MVS_DCFG(32, 16, 16, 2, 8, false)
-        MVS_DCFG(16, 8, 16, 4, 8, true)
+        // tiles sized so accumulators (classes x rows x m-tiles x 4) stay at 64 VGPRs:
+        // two waves per SIMD hide the epilogue's residual loads and the staging latency
+        MVS_DCFG(64, 32, 16, 2, 2, false)
+        MVS_DCFG(32, 16, 16, 2, 4, false)
+        MVS_DCFG(16, 8, 16, 2, 8, true)
         return false;
     }
     if (stride == 1) {

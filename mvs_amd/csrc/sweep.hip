@@ -387,7 +387,7 @@ __host__ __device__ constexpr int lds_cap(int nv) {
 }
 
 template <int NV>
-__global__ __launch_bounds__(256, 2) void variance_fwd_lds_kernel(
+__global__ __launch_bounds__(256, 3) void variance_fwd_lds_kernel(
     const float *__restrict__ ref16, const float *__restrict__ srcs16,
     const float *__restrict__ rt, const float *__restrict__ depth, SweepParams p,
     int tiles_x, int tiles_y, float *__restrict__ out, int out_c8, int ablate) {
@@ -488,6 +488,14 @@ __global__ __launch_bounds__(256, 2) void variance_fwd_lds_kernel(
         // view's 4 LDS offsets + 4 64-bit fallback pointers out of this loop and spills
 #pragma unroll
         for (int v = 0; v < NV; ++v) asm volatile("" : "+v"(tx0[v]), "+v"(ty0[v]));
+        // reference-view channels of this voxel: issued first, consumed after the barrier
+        float4 ref4[4];
+        {
+            const float4 *rp = reinterpret_cast<const float4 *>(
+                ref16 + ((size_t)b * ngroups + g) * grp_floats + (size_t)pix * 16);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ref4[k] = rp[k];
+        }
         // ---- stage the footprints of this channel group.  All loads of all views
         // are issued before the first LDS write (MAXIT*NV float4 in flight per thread):
         // a one-load-at-a-time copy loop is pure L2 latency.
@@ -526,11 +534,9 @@ __global__ __launch_bounds__(256, 2) void variance_fwd_lds_kernel(
         // ---- accumulate S, Q over the views for this voxel's 16 channels
         float S[16], Q[16];
         {
-            const float4 *rp = reinterpret_cast<const float4 *>(
-                ref16 + ((size_t)b * ngroups + g) * grp_floats + (size_t)pix * 16);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float4 r4 = rp[k];
+                const float4 r4 = ref4[k];
                 const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
