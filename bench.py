@@ -143,13 +143,15 @@ def main():
         with torch.no_grad():
             return model(imgs, proj, dvals)
 
-    # --- warmup (also: one fully instrumented pass to find the dominant kernel)
-    for _ in range(max(args.warmup - 1, 0)):
+    # --- W untimed warm-up steps; the last (up to) 3 of them carry HIP events on every
+    # stage (per-kernel breakdown + which kernel dominates).  W=0 still takes one.
+    n_instr = max(1, min(3, args.warmup))
+    for _ in range(max(args.warmup - n_instr, 0)):
         step()
     torch.cuda.synchronize()
     full = ops.StageTimer()
     ops.set_timer(full)
-    for _ in range(3 if args.warmup > 0 else 1):
+    for _ in range(n_instr):
         step()
     torch.cuda.synchronize()
     ops.set_timer(None)
