@@ -8,34 +8,59 @@
 // 256-B wavefront row.  Arithmetic follows ATen's softmax: p = exp(c-max)/sum.
 #include "mvs_common.h"
 
+#include <cmath>
+
 namespace mvs {
 
+// Block = 64 pixels x 4 depth quarters (wave w owns depths [w*D/4, (w+1)*D/4)):
+// 4x the memory-level parallelism of one thread per pixel at the 118k-pixel sizes of
+// this path; the three partial reductions go through a few hundred bytes of LDS.
 __global__ __launch_bounds__(256) void softmax_regress_conf_kernel(
     const float *__restrict__ cost, const float *__restrict__ depth, int depth_mode,
     int clamp_idx, int B, int D, int64_t plane, float *__restrict__ out_depth,
     float *__restrict__ out_conf, float *__restrict__ out_prob) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)B * plane) return;
-    const int b = (int)(i / plane);
-    const int64_t pix = i % plane;
+    __shared__ float s_f[4][64];
+    __shared__ double s_d[2][4][64];
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = i < (int64_t)B * plane;
+    const int64_t ic = live ? i : (int64_t)B * plane - 1;
+    const int b = (int)(ic / plane);
+    const int64_t pix = ic % plane;
     const float *c = cost + (int64_t)b * D * plane + pix;
-    float m = c[0];
-    for (int d = 1; d < D; ++d) m = fmaxf(m, c[(int64_t)d * plane]);
-    float sum = 0.0f;
-    for (int d = 0; d < D; ++d) sum += expf(c[(int64_t)d * plane] - m);
+    const int d0 = (int)((int64_t)D * part / 4), d1 = (int)((int64_t)D * (part + 1) / 4);
+    // max
+    float m = -INFINITY;
+    for (int d = d0; d < d1; ++d) m = fmaxf(m, c[(int64_t)d * plane]);
+    s_f[part][lane] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(s_f[0][lane], s_f[1][lane]), fmaxf(s_f[2][lane], s_f[3][lane]));
+    __syncthreads();
+    // normaliser: quarter sums combined in quarter order (fp32, as ATen's softmax)
+    float psum = 0.0f;
+    for (int d = d0; d < d1; ++d) psum += expf(c[(int64_t)d * plane] - m);
+    s_f[part][lane] = psum;
+    __syncthreads();
+    const float sum = ((s_f[0][lane] + s_f[1][lane]) + s_f[2][lane]) + s_f[3][lane];
     // The fp32 products p_d * dv_d are the reference's (module.py:102); their SUM is
     // carried in fp64: at D=192 and depths ~900 mm a naive fp32 running sum alone
     // costs up to 5e-4 mm against ATen's cascade summation, half the parity budget.
     double dep = 0.0, fidx = 0.0;
     const float *dv = depth_mode == 0 ? depth + (int64_t)b * D : depth + (int64_t)b * D * plane + pix;
     const int64_t dstride = depth_mode == 0 ? 1 : plane;
-    float *pp = out_prob ? out_prob + (int64_t)b * D * plane + pix : nullptr;
-    for (int d = 0; d < D; ++d) {
-        float pr = expf(c[(int64_t)d * plane] - m) / sum;
+    float *pp = (out_prob && live) ? out_prob + (int64_t)b * D * plane + pix : nullptr;
+    for (int d = d0; d < d1; ++d) {
+        const float pr = expf(c[(int64_t)d * plane] - m) / sum;
         dep += (double)(pr * dv[(int64_t)d * dstride]);   // module.py:102
         fidx += (double)(pr * (float)d);                  // mvsnet.py:189
         if (pp) pp[(int64_t)d * plane] = pr;
     }
+    s_d[0][part][lane] = dep;
+    s_d[1][part][lane] = fidx;
+    __syncthreads();
+    if (part != 0 || !live) return;
+    dep = ((s_d[0][0][lane] + s_d[0][1][lane]) + s_d[0][2][lane]) + s_d[0][3][lane];
+    fidx = ((s_d[1][0][lane] + s_d[1][1][lane]) + s_d[1][2][lane]) + s_d[1][3][lane];
     // .long() truncates toward zero (mvsnet.py:189); Cas clamps (cas_mvsnet.py:63)
     int idx = (int)(float)fidx;
     if (clamp_idx) idx = min(max(idx, 0), D - 1);
@@ -91,7 +116,7 @@ extern "C" int mvs_softmax_regress_conf_f32(const float *cost, const float *dept
     }
     const int64_t plane = (int64_t)H * W;
     const int64_t n = (int64_t)B * plane;
-    unsigned grid = (unsigned)((n + 255) / 256);
+    unsigned grid = (unsigned)((n + 63) / 64);
     hipLaunchKernelGGL(softmax_regress_conf_kernel, dim3(grid), dim3(256), 0, as_stream(stream),
                        cost, depth_values, depth_mode, clamp_idx, B, D, plane, out_depth, out_conf,
                        out_prob);

@@ -189,10 +189,8 @@ class MVSNet(nn.Module):
         if imgs.shape[1] != proj_matrices.shape[1]:
             raise AssertionError("Different number of images and projection matrices")
         V = imgs.shape[1]
-        ref_proj = proj_matrices[:, 0]
         with ops.stage("rot_trans"):
-            rts = torch.stack([ops.rot_trans(proj_matrices[:, v], ref_proj, self.proj_where)
-                               for v in range(1, V)])                   # [V-1,B,12]
+            rts = ops.rot_trans_all(proj_matrices, self.proj_where)      # [V-1,B,12]
         autograd_path = self.training or (torch.is_grad_enabled() and
                                           any(p.requires_grad for p in self.parameters()))
         if autograd_path:
