@@ -768,6 +768,7 @@ int conv3d_mfma_launch(const float *in, const float *packed, const float *scale,
     a.B = B; a.D = D; a.H = H; a.W = W;
     a.relu = relu;
     a.in_c8 = in_c8;
+
     if (in_c8 && (transposed || is_cout1(transposed, Cin, Cout, stride) || Cin % 8)) {
         set_error("mvs_conv3d_f32: the 8-channel-blocked input layout is only taken by the conv kernels");
         return MVS_EUNSUPPORTED;

@@ -386,7 +386,16 @@ __host__ __device__ constexpr int lds_cap(int nv) {
     return (48 * 1024) / (nv * kTexelPad * 4) > 256 ? 256 : (48 * 1024) / (nv * kTexelPad * 4);
 }
 
-template <int NV>
+// CORNER (shared depth planes only): the footprint box of a source view is taken from
+// the projections of the block's 8 corner voxels instead of a reduction over all 256
+// voxels.  Per depth plane the map pixel -> source is a homography, so (all Z > 0) the
+// tile's image is the convex hull of its 4 corner images; along depth each coordinate
+// is a Moebius function of d, hence monotone between the two extreme planes.  Every
+// wave computes the same boxes from 8*NV lanes with shuffles only: no LDS atomics, two
+// barriers fewer, and the staging loads go out before the per-voxel arithmetic.  A wave
+// whose taps are not all inside the (1-texel padded) box -- never observed -- samples
+// that view from global memory instead, so the result cannot depend on the argument.
+template <int NV, bool CORNER>
 __global__ __launch_bounds__(256, 3) void variance_fwd_lds_kernel(
     const float *__restrict__ ref16, const float *__restrict__ srcs16,
     const float *__restrict__ rt, const float *__restrict__ depth, SweepParams p,
@@ -410,15 +419,57 @@ __global__ __launch_bounds__(256, 3) void variance_fwd_lds_kernel(
     const int pix = cy * p.W + cx;
     const float dv = p.depth_mode == 0 ? depth[(int64_t)b * p.D + cd]
                                        : depth[((int64_t)b * p.D + cd) * plane + pix];
-    if (tid < NV) {
-        s_box[tid][0] = 0x7fffffff; s_box[tid][1] = 0x7fffffff;
-        s_box[tid][2] = -1; s_box[tid][3] = -1;
+    int bx0[NV], by0[NV], bw[NV], bh[NV];
+    bool staged[NV];
+    if constexpr (CORNER) {
+        // ---- phase 0: boxes from the 8 corner voxels, lane = (view, corner)
+        const int v0 = lane >> 3, k = lane & 7;
+        const int xlo = tx * kTileW, xhi = min(tx * kTileW + kTileW - 1, p.W - 1);
+        const int ylo = ty * kTileH, yhi = min(ty * kTileH + kTileH - 1, p.H - 1);
+        const int dlo = dc * kTileD, dhi = min(dc * kTileD + kTileD - 1, p.D - 1);
+        const float *r = rt + ((int64_t)min(v0, NV - 1) * p.B + b) * 12;
+        const float cxk = (float)((k & 1) ? xhi : xlo), cyk = (float)((k & 2) ? yhi : ylo);
+        const float dk = depth[(int64_t)b * p.D + ((k & 4) ? dhi : dlo)];
+        float rx, ry, rz, ix, iy;
+        sweep_ray(r, cxk, cyk, rx, ry, rz);
+        sweep_coord(r, rx, ry, rz, dk, p.half_w, p.half_h, p.unn_w, p.unn_h, p.align_corners, ix,
+                    iy);
+        const bool zok = (rz * dk + r[11]) > 1e-6f && fabsf(ix) < 1.0e9f && fabsf(iy) < 1.0e9f;
+        int lo_x = (int)floorf(ix) - 1, hi_x = (int)floorf(ix) + 2;
+        int lo_y = (int)floorf(iy) - 1, hi_y = (int)floorf(iy) + 2;
+        int bad = zok ? 0 : 1;
+#pragma unroll
+        for (int off = 1; off <= 4; off <<= 1) {
+            lo_x = min(lo_x, __shfl_xor(lo_x, off)); hi_x = max(hi_x, __shfl_xor(hi_x, off));
+            lo_y = min(lo_y, __shfl_xor(lo_y, off)); hi_y = max(hi_y, __shfl_xor(hi_y, off));
+            bad |= __shfl_xor(bad, off);
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            int x0 = max(__builtin_amdgcn_readlane(lo_x, v * 8), 0);
+            int x1 = min(__builtin_amdgcn_readlane(hi_x, v * 8), p.W - 1);
+            int y0 = max(__builtin_amdgcn_readlane(lo_y, v * 8), 0);
+            int y1 = min(__builtin_amdgcn_readlane(hi_y, v * 8), p.H - 1);
+            const int vbad = __builtin_amdgcn_readlane(bad, v * 8);
+            const bool empty = x1 < x0 || y1 < y0;       // footprint entirely off the image
+            if (empty) { x0 = y0 = x1 = y1 = 0; }
+            bx0[v] = x0; by0[v] = y0; bw[v] = x1 - x0 + 1; bh[v] = y1 - y0 + 1;
+            staged[v] = !vbad && bw[v] * bh[v] <= cap;
+        }
+    } else {
+        if (tid < NV) {
+            s_box[tid][0] = 0x7fffffff; s_box[tid][1] = 0x7fffffff;
+            s_box[tid][2] = -1; s_box[tid][3] = -1;
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     // ---- phase A: homography + tap set per source view (registers), footprint boxes
     float wnw[NV], wne[NV], wsw[NV], wse[NV];
     int tx0[NV], ty0[NV];
+    bool wave_in[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) wave_in[v] = true;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const float *r = rt + ((int64_t)v * p.B + b) * 12;
@@ -452,22 +503,28 @@ __global__ __launch_bounds__(256, 3) void variance_fwd_lds_kernel(
             lo_y = t.y0ok ? ty0[v] : ty0[v] + 1;
             hi_y = t.y1ok ? ty0[v] + 1 : ty0[v];
         }
+        if constexpr (CORNER) {
+            // safety net: is every live tap of this wave inside the staged box?
+            const bool inbox = !(anyx && anyy) ||
+                               (lo_x >= bx0[v] && hi_x < bx0[v] + bw[v] && lo_y >= by0[v] &&
+                                hi_y < by0[v] + bh[v]);
+            wave_in[v] = __all(inbox);
+        } else {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            lo_x = min(lo_x, __shfl_xor(lo_x, off)); hi_x = max(hi_x, __shfl_xor(hi_x, off));
-            lo_y = min(lo_y, __shfl_xor(lo_y, off)); hi_y = max(hi_y, __shfl_xor(hi_y, off));
-        }
-        if (lane == 0) {
-            atomicMin(&s_box[v][0], lo_x); atomicMin(&s_box[v][1], lo_y);
-            atomicMax(&s_box[v][2], hi_x); atomicMax(&s_box[v][3], hi_y);
+            for (int off = 32; off > 0; off >>= 1) {
+                lo_x = min(lo_x, __shfl_xor(lo_x, off)); hi_x = max(hi_x, __shfl_xor(hi_x, off));
+                lo_y = min(lo_y, __shfl_xor(lo_y, off)); hi_y = max(hi_y, __shfl_xor(hi_y, off));
+            }
+            if (lane == 0) {
+                atomicMin(&s_box[v][0], lo_x); atomicMin(&s_box[v][1], lo_y);
+                atomicMax(&s_box[v][2], hi_x); atomicMax(&s_box[v][3], hi_y);
+            }
         }
     }
-    __syncthreads();
+    if constexpr (!CORNER) __syncthreads();
 
-    int bx0[NV], by0[NV], bw[NV], bh[NV];
-    bool staged[NV];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
+    for (int v = 0; v < NV && !CORNER; ++v) {
         // block-uniform: keep the boxes in SGPRs
         int x0 = __builtin_amdgcn_readfirstlane(s_box[v][0]);
         int y0 = __builtin_amdgcn_readfirstlane(s_box[v][1]);
@@ -494,7 +551,8 @@ __global__ __launch_bounds__(256, 3) void variance_fwd_lds_kernel(
             const float4 *rp = reinterpret_cast<const float4 *>(
                 ref16 + ((size_t)b * ngroups + g) * grp_floats + (size_t)pix * 16);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) ref4[k] = rp[k];
+            for (int k = 0; k < 4; ++k)
+                ref4[k] = (ablate & 16) ? make_float4(1.f, 2.f, 3.f, 4.f) : rp[k];
         }
         // ---- stage the footprints of this channel group.  All loads of all views
         // are issued before the first LDS write (MAXIT*NV float4 in flight per thread):
@@ -551,7 +609,7 @@ __global__ __launch_bounds__(256, 3) void variance_fwd_lds_kernel(
             // staged: clamp the tap into the staged box (typed LDS pointer -> ds_read);
             // else: clamp into the image and gather from global.  Taps that fall outside
             // carry a zero (or NaN) weight, so any in-range finite texel will do.
-            if (staged[v]) {
+            if (staged[v] && wave_in[v]) {
                 const int x0c = min(max(tx0[v], bx0[v]), bx0[v] + bw[v] - 1) - bx0[v];
                 const int x1c = min(max(tx0[v] + 1, bx0[v]), bx0[v] + bw[v] - 1) - bx0[v];
                 const int y0c = min(max(ty0[v], by0[v]), by0[v] + bh[v] - 1) - by0[v];
@@ -589,7 +647,11 @@ __global__ __launch_bounds__(256, 3) void variance_fwd_lds_kernel(
                 var[c] = Q[c] / p.fV - m * m;
             }
         }
-        if (live) {
+        if (ablate & 8) {   // tuning: keep the results live without the stores
+#pragma unroll
+            for (int c = 0; c < 16; ++c) asm volatile("" ::"v"(var[c]));
+        }
+        if (live && !(ablate & 8)) {
             const size_t vox = ((size_t)b * p.D + d) * plane + pix;
             if (out_c8) {
                 const size_t row = ((size_t)b * p.D + d) * p.H + py;
@@ -843,9 +905,14 @@ extern "C" int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *s
         const dim3 g((unsigned)nblk, (unsigned)B);
 #define MVS_LDS_CASE(n)                                                                        \
     case n:                                                                                    \
-        hipLaunchKernelGGL((variance_fwd_lds_kernel<n>), g, dim3(256), shmem, st, ref_fea,     \
-                           src_feas, rot_trans, depth_values, p, tiles_x, tiles_y, out_var,    \
-                           out_c8, lds_ablate);                                                \
+        if (depth_mode == 0 && !(lds_ablate & 32))                                             \
+            hipLaunchKernelGGL((variance_fwd_lds_kernel<n, true>), g, dim3(256), shmem, st,    \
+                               ref_fea, src_feas, rot_trans, depth_values, p, tiles_x,         \
+                               tiles_y, out_var, out_c8, lds_ablate);                          \
+        else                                                                                   \
+            hipLaunchKernelGGL((variance_fwd_lds_kernel<n, false>), g, dim3(256), shmem, st,   \
+                               ref_fea, src_feas, rot_trans, depth_values, p, tiles_x,         \
+                               tiles_y, out_var, out_c8, lds_ablate);                          \
         break;
         switch (NV) {
             MVS_LDS_CASE(1) MVS_LDS_CASE(2) MVS_LDS_CASE(3) MVS_LDS_CASE(4) MVS_LDS_CASE(5)
