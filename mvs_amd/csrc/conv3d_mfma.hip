@@ -293,6 +293,198 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------
+// Double-buffered form of the same convolution (one 512-thread block per CU, two LDS
+// halo tiles).  While the 8 waves run the MFMA loop on chunk c out of buffer c&1, the
+// halo of chunk c+1 is already in flight from HBM into registers (issued before the
+// loop, written to the other buffer after it): HBM latency sits entirely under the
+// matrix phase, and there is ONE barrier per chunk.  The chunk's weight fragments are
+// loaded into registers first, so every wait inside the MFMA loop is on loads older
+// than the prefetch (vmcnt retires in order) or on LDS.
+template <class Cfg>
+__global__ __launch_bounds__(512) void conv3d_mfma_db_kernel(ConvArgs a) {
+    constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, MODE = Cfg::MODE, CK = Cfg::CK;
+    constexpr int KS = Cfg::KS, MT = Cfg::MT, TY = Cfg::TY, TZ = Cfg::TZ;
+    constexpr int SX = Cfg::SX, SZY = Cfg::SZY, NKX = Cfg::NKX, NTAPS = Cfg::NTAPS;
+    constexpr int XT = Cfg::XT, YT = Cfg::YT, XH = Cfg::XH, XTP = Cfg::XTP;
+    constexpr int NVOX = Cfg::NVOX, PLANE = Cfg::PLANE, NCHUNK = Cfg::NCHUNK;
+    constexpr int RPW = Cfg::ROWS / 8;                       // rows per wave, 8 waves
+    constexpr int NIT = (4 * NVOX + 511) / 512;              // staging items per thread
+    constexpr int BUF = Cfg::LDS_FLOATS;
+    static_assert(Cfg::ROWS % 8 == 0, "rows split over 8 waves");
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = lane & 15, kq = lane >> 4;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y; bid /= a.tiles_y;
+    const int tz = bid % a.tiles_z;
+    const int b = bid / a.tiles_z;
+    const int ox0 = tx * Cfg::XOUT, oy0 = ty * TY, oz0 = tz * TZ;
+    const int ix0 = (MODE == 1 ? 2 * ox0 : ox0) - 1;
+    const int iy0 = oy0 * SZY - 1, iz0 = oz0 * SZY - 1;
+    const float *in_b = a.in + (int64_t)b * a.D * a.H * a.W * CIN;
+
+    // ---- staging geometry of this thread's items (the same for every chunk)
+    int g_off[NIT];        // element offset of the item's voxel inside the batch item
+    int l_off[NIT];        // LDS float offset inside a buffer, -1 = no item
+    unsigned okmask = 0;   // bit it: the item lies inside the volume (else zero padding)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int e = tid + it * 512;
+        const int ec = min(e, 4 * NVOX - 1);
+        const int ekq = ec & 3, v = ec >> 2;
+        const int lxp = v % XTP, t2 = v / XTP;
+        const int ly = t2 % YT, lz = t2 / YT;
+        const int lx = (SX == 2) ? (lxp < XH ? 2 * lxp : 2 * (lxp - XH) + 1) : lxp;
+        const int gx = ix0 + lx, gy = iy0 + ly, gz = iz0 + lz;
+        const bool ok = lx < XT && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H && gz >= 0 &&
+                        gz < a.D;
+        const int cx = min(max(gx, 0), a.W - 1), cy = min(max(gy, 0), a.H - 1);
+        const int cz = min(max(gz, 0), a.D - 1);
+        // chunk-independent part; the chunk adds ch*CK (NHWC) or ch*W*8 (C8, CK == 8)
+        g_off[it] = a.in_c8 ? (((cz * a.H + cy) * (CIN / 8)) * a.W + cx) * 8 + ekq * KS
+                            : ((cz * a.H + cy) * a.W + cx) * CIN + ekq * KS;
+        l_off[it] = e < 4 * NVOX ? (ekq * PLANE + v) * KS : -1;
+        okmask |= ok ? (1u << it) : 0u;
+    }
+    const int ch_step = a.in_c8 ? a.W * 8 * (CK / 8) : CK;
+    static_assert(NIT <= 32, "okmask is 32 bits");
+
+    float pre[NIT][KS];
+    auto issue = [&](int ch) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const float *src = in_b + g_off[it] + ch * ch_step;
+            if constexpr (KS == 4) {
+                const float4 t = *reinterpret_cast<const float4 *>(src);
+                pre[it][0] = t.x; pre[it][1] = t.y; pre[it][2] = t.z; pre[it][3] = t.w;
+            } else {
+                const float2 t = *reinterpret_cast<const float2 *>(src);
+                pre[it][0] = t.x; pre[it][1] = t.y;
+            }
+        }
+    };
+    auto commit = [&](float *buf) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (l_off[it] < 0) continue;
+            const bool ok = (okmask >> it) & 1u;
+            if constexpr (KS == 4)
+                *reinterpret_cast<float4 *>(buf + l_off[it]) =
+                    make_float4(ok ? pre[it][0] : 0.f, ok ? pre[it][1] : 0.f,
+                                ok ? pre[it][2] : 0.f, ok ? pre[it][3] : 0.f);
+            else
+                *reinterpret_cast<float2 *>(buf + l_off[it]) =
+                    make_float2(ok ? pre[it][0] : 0.f, ok ? pre[it][1] : 0.f);
+        }
+    };
+
+    f32x4 acc[RPW][MT];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[r][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int rd_base = (kq * PLANE + n) * KS;
+
+    issue(0);
+    commit(lds);
+    __syncthreads();
+
+#pragma unroll 1
+    for (int ch = 0; ch < NCHUNK; ++ch) {
+        const float *buf = lds + (ch & 1) * BUF;
+        // weight fragments of this chunk first (older than the prefetch below)
+        const float *wch = a.wpk + (int64_t)ch * NTAPS * MT * 64 * KS + lane * KS;
+        float apre[NTAPS][MT][KS];
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const float *wp = wch + (t * MT + m) * 64 * KS;
+                if constexpr (KS == 4) {
+                    const float4 w4 = *reinterpret_cast<const float4 *>(wp);
+                    apre[t][m][0] = w4.x; apre[t][m][1] = w4.y; apre[t][m][2] = w4.z; apre[t][m][3] = w4.w;
+                } else {
+                    const float2 w2 = *reinterpret_cast<const float2 *>(wp);
+                    apre[t][m][0] = w2.x; apre[t][m][1] = w2.y;
+                }
+            }
+        if (ch + 1 < NCHUNK) issue(ch + 1);   // next halo: in flight during the MFMA loop
+
+#pragma unroll
+        for (int kz = 0; kz < 3; ++kz) {
+            const float *rdz = buf + rd_base + kz * (YT * XTP) * KS;
+#pragma unroll
+            for (int kyx = 0; kyx < 3 * NKX; ++kyx) {
+                const int ky = kyx / NKX, kx = kyx % NKX;
+                const int xoff = (SX == 2) ? ((kx & 1) * XH + (kx >> 1)) : kx;
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) {
+                    const int row = wv * RPW + r;
+                    const int zr = row / TY, yr = row % TY;
+                    const float *rp = rdz + (((zr * SZY) * YT + (yr * SZY + ky)) * XTP + xoff) * KS;
+                    float bf[KS];
+                    if constexpr (KS == 4) {
+                        const float4 t = *reinterpret_cast<const float4 *>(rp);
+                        bf[0] = t.x; bf[1] = t.y; bf[2] = t.z; bf[3] = t.w;
+                    } else {
+                        const float2 t = *reinterpret_cast<const float2 *>(rp);
+                        bf[0] = t.x; bf[1] = t.y;
+                    }
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int s2 = 0; s2 < KS; ++s2)
+                            acc[r][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                apre[kz * 3 * NKX + kyx][m][s2], bf[s2], acc[r][m], 0, 0, 0);
+                }
+            }
+        }
+        if (ch + 1 < NCHUNK) commit(lds + ((ch + 1) & 1) * BUF);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int row = wv * RPW + r;
+        const int oz = oz0 + row / TY, oy = oy0 + row % TY;
+        if (oz >= a.Do || oy >= a.Ho) continue;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            int ox, c0;
+            if (MODE == 2) {
+                ox = ox0 + 2 * n + (kq >> 1);
+                c0 = (kq & 1) * 4;
+            } else {
+                ox = ox0 + n;
+                c0 = m * 16 + kq * 4;
+            }
+            if (ox >= a.Wo || c0 >= COUT) continue;
+            f32x4 v = acc[r][m];
+            if (a.scale) {
+                const float4 sc = *reinterpret_cast<const float4 *>(a.scale + c0);
+                v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
+            }
+            if (a.shift) {
+                const float4 sh = *reinterpret_cast<const float4 *>(a.shift + c0);
+                v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w;
+            }
+            if (a.relu) {
+                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+                v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+            }
+            const int64_t o = ((((int64_t)b * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * COUT + c0;
+            if (a.residual) {
+                const float4 rs = *reinterpret_cast<const float4 *>(a.residual + o);
+                v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
+            }
+            *reinterpret_cast<float4 *>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------
 // Transposed convolution k=3, stride 2, pad 1, output_padding 1 (mvsnet.py:66-79)
 // on the same MFMA machinery.  out[o] += in[i]*w[k] with o = 2i-1+k, so per
 // dimension an even output (o=2j) sees one tap (k=1, i=j) and an odd output
@@ -807,6 +999,7 @@ int conv3d_mfma_launch(const float *in, const float *packed, const float *scale,
         return MVS_EINVAL;
     }
     void (*kern)(ConvArgs) = ci.kernel;
+    int threads = 256;
     if (!transposed && Cin == 32 && Cout == 8 && stride == 1) {   // tuning hook, conv0 only
         const char *abl = getenv("MVS_CONV_ABLATE");
         using C0 = ConvCfg<32, 8, 2, 8, 4, 8>;
@@ -831,10 +1024,11 @@ int conv3d_mfma_launch(const float *in, const float *packed, const float *scale,
             case 3: kern = conv3d_mfma_kernel<ConvCfg<32, 8, 2, 8, 4, 8, 32, 0>, 0>; break;
             case 4: kern = conv3d_mfma_kernel<ConvCfg<32, 8, 2, 8, 4, 8, 16, 1>, 0>; break;
             case 5: kern = conv3d_mfma_kernel<ConvCfg<32, 8, 2, 8, 4, 8, 32, 1>, 0>; break;
+            case 9: kern = conv3d_mfma_db_kernel<ConvCfg<32, 8, 2, 8, 4, 8>>; threads = 512; break;
             default: break;
         }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(threads), 0, st, a);
     return check_launch("mvs_conv3d_f32(mfma)");
 }
 
