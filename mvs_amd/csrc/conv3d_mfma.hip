@@ -116,6 +116,35 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
     // per-lane LDS read base (floats): plane kq, slot n
     const int rd_base = (kq * PLANE + n) * KS;
 
+    // ---- staging geometry of this thread's halo items: identical for every chunk, so
+    // the div/mod-by-constant address arithmetic (quarter-rate integer multiplies) is
+    // paid once per block instead of once per chunk.  Within each group of 64 items the
+    // lanes are ordered (piece, voxel): a wave's loads still cover one contiguous run,
+    // and its ds_writes land on 16 consecutive slots of one plane (conflict-free).
+    constexpr int NIT = (4 * NVOX + 255) / 256;
+    static_assert(NIT <= 32, "okmask is 32 bits");
+    int g_off[NIT];
+    unsigned okmask = 0;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int e = tid + it * 256;
+        const int ec = min(e, 4 * NVOX - 1);
+        const int ekq = (ec >> 4) & 3, v = ((ec >> 6) << 4) | (ec & 15);
+        const int vc = min(v, NVOX - 1);
+        const int lxp = vc % XTP, t2 = vc / XTP;
+        const int ly = t2 % YT, lz = t2 / YT;
+        const int lx = (SX == 2) ? (lxp < XH ? 2 * lxp : 2 * (lxp - XH) + 1) : lxp;
+        const int gx = ix0 + lx, gy = iy0 + ly, gz = iz0 + lz;
+        const bool ok = v < NVOX && lx < XT && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H &&
+                        gz >= 0 && gz < a.D;
+        const int cx = min(max(gx, 0), a.W - 1), cy = min(max(gy, 0), a.H - 1);
+        const int cz = min(max(gz, 0), a.D - 1);
+        g_off[it] = a.in_c8 ? (((cz * a.H + cy) * (CIN / 8)) * a.W + cx) * 8 + ekq * KS
+                            : ((cz * a.H + cy) * a.W + cx) * CIN + ekq * KS;
+        okmask |= ok ? (1u << it) : 0u;
+    }
+    const int ch_step = a.in_c8 ? a.W * 8 * (CK / 8) : CK;
+
 #pragma unroll 1
     for (int ch = 0; ch < Cfg::NCHUNK; ++ch) {
         const float *wch = a.wpk + (int64_t)ch * NTAPS * MT * 64 * KS + lane * KS;
@@ -136,58 +165,43 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
                 }
         }
         if (ch) __syncthreads();
-        // ---- stage the halo tile of CK channels: global (channels-last) -> LDS planes.
-        // Compile-time trip count, SB loads in flight per thread per batch (the
-        // volume streams from HBM: one load at a time is pure latency).
+        // ---- stage the halo tile of CK channels: global -> LDS planes, SB loads in
+        // flight per thread per batch (the volume streams from HBM)
         {
-            constexpr int NIT = (4 * NVOX + 255) / 256;
             constexpr int SB = Cfg::SB;
-#pragma unroll 1
+#pragma unroll
             for (int it0 = 0; it0 < NIT; it0 += SB) {
                 float stg[SB][KS];
-                int dsto[SB];
 #pragma unroll
                 for (int j = 0; j < SB; ++j) {
-                    // lane -> (voxel, 16/8-byte piece) with the piece fastest: a wave's
-                    // load covers whole contiguous runs of the input instead of one
-                    // piece from each of 64 lines
-                    const int e = tid + (it0 + j) * 256;
-                    const int ec = min(e, 4 * NVOX - 1);
-                    const int ekq = ec & 3, v = ec >> 2;
-                    const int lxp = v % XTP, t2 = v / XTP;
-                    const int ly = t2 % YT, lz = t2 / YT;
-                    const int lx = (SX == 2) ? (lxp < XH ? 2 * lxp : 2 * (lxp - XH) + 1) : lxp;
-                    const int gx = ix0 + lx, gy = iy0 + ly, gz = iz0 + lz;
-                    const bool ok = lx < XT && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H &&
-                                    gz >= 0 && gz < a.D;
-                    const int cx = min(max(gx, 0), a.W - 1), cy = min(max(gy, 0), a.H - 1);
-                    const int cz = min(max(gz, 0), a.D - 1);
-                    const int c0 = ch * CK + ekq * KS;   // first channel of this piece
-                    const float *src =
-                        a.in_c8 ? in_b + ((((int64_t)cz * a.H + cy) * (CIN / 8) + (c0 >> 3)) * a.W + cx) * 8 + (c0 & 7)
-                                : in_b + (((int64_t)cz * a.H + cy) * a.W + cx) * CIN + c0;
-                    dsto[j] = (e < 4 * NVOX && it0 + j < NIT) ? (ekq * PLANE + v) * KS : -1;
+                    if (it0 + j >= NIT) continue;
+                    const float *src = in_b + g_off[it0 + j] + ch * ch_step;
                     if constexpr (ABL & 1) {
 #pragma unroll
-                        for (int k = 0; k < KS; ++k) stg[j][k] = ok ? (float)(cx + k) : 0.f;
+                        for (int k = 0; k < KS; ++k) stg[j][k] = (float)(g_off[it0 + j] + k);
                     } else if constexpr (KS == 4) {
-                        float4 val = *reinterpret_cast<const float4 *>(src);
-                        stg[j][0] = ok ? val.x : 0.f; stg[j][1] = ok ? val.y : 0.f;
-                        stg[j][2] = ok ? val.z : 0.f; stg[j][3] = ok ? val.w : 0.f;
+                        const float4 val = *reinterpret_cast<const float4 *>(src);
+                        stg[j][0] = val.x; stg[j][1] = val.y; stg[j][2] = val.z; stg[j][3] = val.w;
                     } else {
-                        float2 val = *reinterpret_cast<const float2 *>(src);
-                        stg[j][0] = ok ? val.x : 0.f; stg[j][1] = ok ? val.y : 0.f;
+                        const float2 val = *reinterpret_cast<const float2 *>(src);
+                        stg[j][0] = val.x; stg[j][1] = val.y;
                     }
                 }
 #pragma unroll
                 for (int j = 0; j < SB; ++j) {
-                    if (dsto[j] < 0) continue;
-                    float *dst = lds + dsto[j];
+                    if (it0 + j >= NIT) continue;
+                    const int e = tid + (it0 + j) * 256;
+                    const int ekq = (e >> 4) & 3, v = ((e >> 6) << 4) | (e & 15);
+                    if (v >= NVOX) continue;
+                    const bool ok = (okmask >> (it0 + j)) & 1u;
+                    float *dst = lds + (ekq * PLANE + v) * KS;
                     if constexpr (KS == 4)
                         *reinterpret_cast<float4 *>(dst) =
-                            make_float4(stg[j][0], stg[j][1], stg[j][2], stg[j][3]);
+                            make_float4(ok ? stg[j][0] : 0.f, ok ? stg[j][1] : 0.f,
+                                        ok ? stg[j][2] : 0.f, ok ? stg[j][3] : 0.f);
                     else
-                        *reinterpret_cast<float2 *>(dst) = make_float2(stg[j][0], stg[j][1]);
+                        *reinterpret_cast<float2 *>(dst) =
+                            make_float2(ok ? stg[j][0] : 0.f, ok ? stg[j][1] : 0.f);
                 }
             }
         }
