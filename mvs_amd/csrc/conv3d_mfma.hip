@@ -121,14 +121,15 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
     // paid once per block instead of once per chunk.  Within each group of 64 items the
     // lanes are ordered (piece, voxel): a wave's loads still cover one contiguous run,
     // and its ds_writes land on 16 consecutive slots of one plane (conflict-free).
-    constexpr int NIT = (4 * NVOX + 255) / 256;
+    constexpr int NITEMS = round_up_c(NVOX, 16) * 4;   // whole 64-item groups (16 voxels x 4 pieces)
+    constexpr int NIT = (NITEMS + 255) / 256;
     static_assert(NIT <= 32, "okmask is 32 bits");
     int g_off[NIT];
     unsigned okmask = 0;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int e = tid + it * 256;
-        const int ec = min(e, 4 * NVOX - 1);
+        const int ec = min(e, NITEMS - 1);
         const int ekq = (ec >> 4) & 3, v = ((ec >> 6) << 4) | (ec & 15);
         const int vc = min(v, NVOX - 1);
         const int lxp = vc % XTP, t2 = vc / XTP;
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
                     if (it0 + j >= NIT) continue;
                     const int e = tid + (it0 + j) * 256;
                     const int ekq = (e >> 4) & 3, v = ((e >> 6) << 4) | (e & 15);
-                    if (v >= NVOX) continue;
+                    if (e >= NITEMS || v >= NVOX) continue;
                     const bool ok = (okmask >> (it0 + j)) & 1u;
                     float *dst = lds + (ekq * PLANE + v) * KS;
                     if constexpr (KS == 4)
