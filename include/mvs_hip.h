@@ -131,6 +131,22 @@ int mvs_conv3d_pack_weights_f32(const float *weight, int transposed, int Cin, in
 /* 1 if impl 2 (MFMA) supports this layer shape, else 0. */
 int mvs_conv3d_mfma_supported(int transposed, int Cin, int Cout, int stride);
 
+/* ---- FeatureNet layers -- mvsnet.py:8-45 ("next" row 1) ---- */
+/* One 2D convolution of FeatureNet on the fp32 matrix cores: k x k (3 stride 1, or 5
+ * stride 2), pad k/2, no conv bias, then y = acc*scale[co] + shift[co] (BatchNorm(eval)
+ * folded; for the last layer scale = NULL and shift = the conv bias) and optional ReLU.
+ * in: [B,H,W,Cin] channels-last, or with in_planar the reference's [B,3,H,W] image
+ * (3-channel layer only).  out: [B,Ho,Wo,Cout] channels-last.  Supported (Cin,Cout,k,
+ * stride): (3,8,3,1) (8,8,3,1) (8,16,5,2) (16,16,3,1) (16,32,5,2) (32,32,3,1). */
+int mvs_conv2d_f32(const float *in, const float *packed_weight, const float *scale,
+                   const float *shift, int relu, int B, int Cin, int Cout, int H, int W,
+                   int ksize, int stride, int in_planar, float *out, void *stream);
+int64_t mvs_conv2d_packed_weight_floats(int Cin, int Cout, int ksize, int stride);
+/* weight: PyTorch layout (Cout,Cin,k,k) -> MFMA A-fragment order. */
+int mvs_conv2d_pack_weights_f32(const float *weight, int Cin, int Cout, int ksize, int stride,
+                                float *packed, void *stream);
+int mvs_conv2d_supported(int Cin, int Cout, int ksize, int stride);
+
 /* ---- K4+K5: softmax + expectation + confidence -- mvsnet.py:183-191 -- */
 /* cost [B,D,H,W]; out_depth, out_conf [B,H,W]; out_prob [B,D,H,W] or NULL.
  * clamp_idx=1 is CasMVSNet's index clamp (cas_mvsnet.py:63). */

@@ -1,0 +1,354 @@
+// FeatureNet (MVSNet/models/mvsnet.py:8-45) convolutions on the fp32 matrix cores:
+// SURVEY.md section 8(f), "next" row 1.  Same machinery as conv3d_mfma.hip in two
+// dimensions: implicit GEMM on v_mfma_f32_16x16x4_f32 with A = weights (16 output
+// channels x 4 input channels), B = inputs (4 input channels x 16 pixels along x),
+// channels-last activations, an LDS halo tile per block staged as 4 planes
+// [kq][pixel][CK/4], BatchNorm(eval) affine + ReLU (+ bias) in the epilogue.
+// Layers: 3x3 stride 1 and 5x5 stride 2 (x de-interleaved in LDS for stride 2), input
+// channels 3 (read straight from the planar [B,3,H,W] image, padded to 4), 8, 16, 32.
+// The two full-resolution 8-channel layers are HBM-bound (303 MB each way for 5 views);
+// the kernel's job there is to stream whole lines and keep the MFMA work off the
+// critical path, which MIOpen's generic fp32 igemm does not (1.2 ms per layer).
+#include "mvs_common.h"
+
+namespace mvs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int round_up2(int v, int m) { return (v + m - 1) / m * m; }
+
+template <int CIN_, int COUT_, int KH_, int STRIDE_, int CK_, int TY_>
+struct Conv2Cfg {
+    static constexpr int CIN = CIN_;     // padded input channels (multiple of 4)
+    static constexpr int COUT = COUT_, KH = KH_, STRIDE = STRIDE_, CK = CK_, TY = TY_;
+    static constexpr int KS = CK / 4;    // floats per lane read: 1, 2 or 4
+    static constexpr int MT = (COUT + 15) / 16;
+    static constexpr int NTAPS = KH * KH;
+    static constexpr int XT = 15 * STRIDE + KH;
+    static constexpr int YT = (TY - 1) * STRIDE + KH;
+    static constexpr int XH = (XT + 1) / 2;
+    static constexpr int XTP = STRIDE == 2 ? 2 * XH : XT;
+    static constexpr int NPIX = YT * XTP;
+    // plane stride (pixel slots): conflict-free operand reads (see conv3d_mfma.hip)
+    static constexpr int PLANE = KS == 4 ? round_up2(NPIX, 16) : round_up2(NPIX, 32) + 16;
+    static constexpr int NCHUNK = CIN / CK;
+    static constexpr int RPW = TY / 4;
+    static constexpr int NITEMS = round_up2(NPIX, 16) * 4;
+    static constexpr int NIT = (NITEMS + 255) / 256;
+    static constexpr int LDS_FLOATS = 4 * PLANE * KS;
+    static_assert(CIN % CK == 0 && (CK == 4 || CK == 8 || CK == 16), "bad chunk");
+    static_assert(TY % 4 == 0 && NIT <= 32, "bad tile");
+};
+
+struct Conv2Args {
+    const float *in, *wpk, *scale, *shift;
+    float *out;
+    int B, H, W;        // input size
+    int Ho, Wo;         // output size
+    int cin_real;       // channels present in memory (3 for the RGB layer)
+    int in_planar;      // input is [B,cin_real,H,W] instead of [B,H,W,CIN]
+    int tiles_x, tiles_y;
+    int relu;
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(256) void conv2d_mfma_kernel(Conv2Args a) {
+    constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, KH = Cfg::KH, S = Cfg::STRIDE, CK = Cfg::CK;
+    constexpr int KS = Cfg::KS, MT = Cfg::MT, RPW = Cfg::RPW, TY = Cfg::TY, NTAPS = Cfg::NTAPS;
+    constexpr int XT = Cfg::XT, YT = Cfg::YT, XH = Cfg::XH, XTP = Cfg::XTP;
+    constexpr int NPIX = Cfg::NPIX, PLANE = Cfg::PLANE, NIT = Cfg::NIT, NITEMS = Cfg::NITEMS;
+    constexpr int PAD = KH / 2;
+    __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = lane & 15, kq = lane >> 4;
+    int bid = blockIdx.x;
+    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int b = bid / a.tiles_y;
+    const int ox0 = tx * 16, oy0 = ty * TY;
+    const int ix0 = ox0 * S - PAD, iy0 = oy0 * S - PAD;
+
+    // staging geometry, once per block (piece-major lane order inside 64-item groups)
+    int g_off[NIT];
+    unsigned okmask = 0;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int e = min(tid + it * 256, NITEMS - 1);
+        const int ekq = (e >> 4) & 3, v = ((e >> 6) << 4) | (e & 15);
+        const int vc = min(v, NPIX - 1);
+        const int lxp = vc % XTP, ly = vc / XTP;
+        const int lx = (S == 2) ? (lxp < XH ? 2 * lxp : 2 * (lxp - XH) + 1) : lxp;
+        const int gx = ix0 + lx, gy = iy0 + ly;
+        bool ok = v < NPIX && lx < XT && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H;
+        const int cx = min(max(gx, 0), a.W - 1), cy = min(max(gy, 0), a.H - 1);
+        if (a.in_planar) {   // [B,cin_real,H,W], KS == 1: piece kq is channel kq
+            ok = ok && ekq < a.cin_real;
+            g_off[it] = (min(ekq, a.cin_real - 1) * a.H + cy) * a.W + cx;
+        } else {
+            g_off[it] = (cy * a.W + cx) * CIN + ekq * KS;
+        }
+        okmask |= ok ? (1u << it) : 0u;
+    }
+    const float *in_b = a.in + (int64_t)b * a.H * a.W * (a.in_planar ? a.cin_real : CIN);
+
+    f32x4 acc[RPW][MT];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[r][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int rd_base = (kq * PLANE + n) * KS;
+
+#pragma unroll 1
+    for (int ch = 0; ch < Cfg::NCHUNK; ++ch) {
+        if (ch) __syncthreads();
+        {
+            float stg[NIT][KS];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const float *src = in_b + g_off[it] + ch * CK;
+                if constexpr (KS == 4) {
+                    const float4 t = *reinterpret_cast<const float4 *>(src);
+                    stg[it][0] = t.x; stg[it][1] = t.y; stg[it][2] = t.z; stg[it][3] = t.w;
+                } else if constexpr (KS == 2) {
+                    const float2 t = *reinterpret_cast<const float2 *>(src);
+                    stg[it][0] = t.x; stg[it][1] = t.y;
+                } else {
+                    stg[it][0] = *src;
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int e = tid + it * 256;
+                const int ekq = (e >> 4) & 3, v = ((e >> 6) << 4) | (e & 15);
+                if (e >= NITEMS || v >= NPIX) continue;
+                const bool ok = (okmask >> it) & 1u;
+                float *dst = lds + (ekq * PLANE + v) * KS;
+                if constexpr (KS == 4)
+                    *reinterpret_cast<float4 *>(dst) =
+                        make_float4(ok ? stg[it][0] : 0.f, ok ? stg[it][1] : 0.f,
+                                    ok ? stg[it][2] : 0.f, ok ? stg[it][3] : 0.f);
+                else if constexpr (KS == 2)
+                    *reinterpret_cast<float2 *>(dst) =
+                        make_float2(ok ? stg[it][0] : 0.f, ok ? stg[it][1] : 0.f);
+                else
+                    *dst = ok ? stg[it][0] : 0.f;
+            }
+        }
+        __syncthreads();
+
+        const float *wch = a.wpk + (int64_t)ch * NTAPS * MT * 64 * KS + lane * KS;
+#pragma unroll
+        for (int tap = 0; tap < NTAPS; ++tap) {
+            const int ky = tap / KH, kx = tap % KH;
+            const int xoff = (S == 2) ? ((kx & 1) * XH + (kx >> 1)) : kx;
+            float af[MT][KS];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const float *wp = wch + (tap * MT + m) * 64 * KS;
+                if constexpr (KS == 4) {
+                    const float4 t = *reinterpret_cast<const float4 *>(wp);
+                    af[m][0] = t.x; af[m][1] = t.y; af[m][2] = t.z; af[m][3] = t.w;
+                } else if constexpr (KS == 2) {
+                    const float2 t = *reinterpret_cast<const float2 *>(wp);
+                    af[m][0] = t.x; af[m][1] = t.y;
+                } else {
+                    af[m][0] = *wp;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int yr = wv * RPW + r;   // wave-uniform row of the tile
+                const float *rp = lds + rd_base + ((yr * S + ky) * XTP + xoff) * KS;
+                float bf[KS];
+                if constexpr (KS == 4) {
+                    const float4 t = *reinterpret_cast<const float4 *>(rp);
+                    bf[0] = t.x; bf[1] = t.y; bf[2] = t.z; bf[3] = t.w;
+                } else if constexpr (KS == 2) {
+                    const float2 t = *reinterpret_cast<const float2 *>(rp);
+                    bf[0] = t.x; bf[1] = t.y;
+                } else {
+                    bf[0] = *rp;
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int s2 = 0; s2 < KS; ++s2)
+                        acc[r][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][s2], bf[s2],
+                                                                         acc[r][m], 0, 0, 0);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int oy = oy0 + wv * RPW + r, ox = ox0 + n;
+        if (oy >= a.Ho || ox >= a.Wo) continue;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int c0 = m * 16 + kq * 4;
+            if (c0 >= COUT) continue;
+            f32x4 v = acc[r][m];
+            if (a.scale) {
+                const float4 sc = *reinterpret_cast<const float4 *>(a.scale + c0);
+                v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
+            }
+            if (a.shift) {
+                const float4 sh = *reinterpret_cast<const float4 *>(a.shift + c0);
+                v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w;
+            }
+            if (a.relu) {
+                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+                v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+            }
+            *reinterpret_cast<float4 *>(a.out + (((int64_t)b * a.Ho + oy) * a.Wo + ox) * COUT + c0) =
+                make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// PyTorch (Cout,Cin,KH,KW) -> packed[ch][tap][mt][lane][s]; input channel =
+// ch*CK + kq*KS + s (channels >= cin_real are zero: the padded RGB layer).
+struct Pack2Args {
+    const float *w;
+    float *packed;
+    int cin_real, Cout, KH, ck, mt;
+};
+
+__global__ __launch_bounds__(256) void conv2d_pack_kernel(Pack2Args p, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int KS = p.ck / 4, NT = p.KH * p.KH;
+    int64_t t = i;
+    const int s = (int)(t % KS); t /= KS;
+    const int lane = (int)(t % 64); t /= 64;
+    const int mt = (int)(t % p.mt); t /= p.mt;
+    const int tap = (int)(t % NT); t /= NT;
+    const int ch = (int)t;
+    const int m = lane & 15, kq = lane >> 4;
+    const int cin = ch * p.ck + kq * KS + s, co = mt * 16 + m;
+    float val = 0.0f;
+    if (cin < p.cin_real && co < p.Cout) val = p.w[((int64_t)co * p.cin_real + cin) * NT + tap];
+    p.packed[i] = val;
+}
+
+struct Cfg2Info {
+    int cin_pad, ck, mt, ty, ntaps;
+    void (*kernel)(Conv2Args);
+};
+
+template <class Cfg>
+static Cfg2Info info2() {
+    return Cfg2Info{Cfg::CIN, Cfg::CK, Cfg::MT, Cfg::TY, Cfg::NTAPS, conv2d_mfma_kernel<Cfg>};
+}
+
+static bool lookup2(int Cin, int Cout, int ksize, int stride, Cfg2Info &ci) {
+#define MVS_C2(cin_real, cin_pad, cout, kh, st, ck, ty)                        \
+    if (Cin == cin_real && Cout == cout && ksize == kh && stride == st) {      \
+        ci = info2<Conv2Cfg<cin_pad, cout, kh, st, ck, ty>>();                 \
+        return true;                                                           \
+    }
+    MVS_C2(3, 4, 8, 3, 1, 4, 32)      // feature.conv0 (RGB, planar input)
+    MVS_C2(8, 8, 8, 3, 1, 8, 32)      // feature.conv1
+    MVS_C2(8, 8, 16, 5, 2, 8, 16)     // feature.conv2
+    MVS_C2(16, 16, 16, 3, 1, 16, 32)  // feature.conv3, conv4
+    MVS_C2(16, 16, 32, 5, 2, 16, 8)   // feature.conv5
+    MVS_C2(32, 32, 32, 3, 1, 16, 32)  // feature.conv6, feature.feature
+#undef MVS_C2
+    return false;
+}
+
+int conv2d_supported(int Cin, int Cout, int ksize, int stride) {
+    Cfg2Info ci;
+    return lookup2(Cin, Cout, ksize, stride, ci) ? 1 : 0;
+}
+
+int64_t conv2d_packed_floats(int Cin, int Cout, int ksize, int stride) {
+    Cfg2Info ci;
+    if (!lookup2(Cin, Cout, ksize, stride, ci)) return 0;
+    return (int64_t)(ci.cin_pad / ci.ck) * ci.ntaps * ci.mt * 64 * (ci.ck / 4);
+}
+
+int conv2d_pack_launch(const float *weight, int Cin, int Cout, int ksize, int stride,
+                       float *packed, hipStream_t st) {
+    Cfg2Info ci;
+    if (!lookup2(Cin, Cout, ksize, stride, ci)) {
+        set_error("mvs_conv2d_pack_weights_f32: no configuration for Cin=%d Cout=%d k=%d stride=%d",
+                  Cin, Cout, ksize, stride);
+        return MVS_EUNSUPPORTED;
+    }
+    Pack2Args p{weight, packed, Cin, Cout, ksize, ci.ck, ci.mt};
+    const int64_t total = conv2d_packed_floats(Cin, Cout, ksize, stride);
+    hipLaunchKernelGGL(conv2d_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       p, total);
+    return check_launch("mvs_conv2d_pack_weights_f32");
+}
+
+int conv2d_launch(const float *in, const float *packed, const float *scale, const float *shift,
+                  int relu, int B, int Cin, int Cout, int H, int W, int ksize, int stride,
+                  int in_planar, float *out, hipStream_t st) {
+    Cfg2Info ci;
+    if (!lookup2(Cin, Cout, ksize, stride, ci)) {
+        set_error("mvs_conv2d_f32: no configuration for Cin=%d Cout=%d k=%d stride=%d", Cin, Cout,
+                  ksize, stride);
+        return MVS_EUNSUPPORTED;
+    }
+    if (in_planar && ci.ck != 4) {
+        set_error("mvs_conv2d_f32: planar input is only taken by the 3-channel layer");
+        return MVS_EUNSUPPORTED;
+    }
+    if (!in_planar && Cin != ci.cin_pad) {
+        set_error("mvs_conv2d_f32: channels-last input needs Cin %% 4 == 0");
+        return MVS_EUNSUPPORTED;
+    }
+    if ((int64_t)H * W * ci.cin_pad >= (1ll << 31)) {
+        set_error("mvs_conv2d_f32: image too large for 32-bit offsets");
+        return MVS_EINVAL;
+    }
+    Conv2Args a;
+    a.in = in; a.wpk = packed; a.scale = scale; a.shift = shift; a.out = out;
+    a.B = B; a.H = H; a.W = W;
+    const int pad = ksize / 2;
+    a.Ho = (H + 2 * pad - ksize) / stride + 1;
+    a.Wo = (W + 2 * pad - ksize) / stride + 1;
+    a.cin_real = Cin; a.in_planar = in_planar;
+    a.tiles_x = (a.Wo + 15) / 16;
+    a.tiles_y = (a.Ho + ci.ty - 1) / ci.ty;
+    a.relu = relu;
+    const int64_t nblk = (int64_t)B * a.tiles_x * a.tiles_y;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return MVS_EINVAL;
+    hipLaunchKernelGGL(ci.kernel, dim3((unsigned)nblk), dim3(256), 0, st, a);
+    return check_launch("mvs_conv2d_f32");
+}
+
+}  // namespace mvs
+
+using namespace mvs;
+
+extern "C" int mvs_conv2d_supported(int Cin, int Cout, int ksize, int stride) {
+    return conv2d_supported(Cin, Cout, ksize, stride);
+}
+
+extern "C" int64_t mvs_conv2d_packed_weight_floats(int Cin, int Cout, int ksize, int stride) {
+    return conv2d_packed_floats(Cin, Cout, ksize, stride);
+}
+
+extern "C" int mvs_conv2d_pack_weights_f32(const float *weight, int Cin, int Cout, int ksize,
+                                           int stride, float *packed, void *stream) {
+    if (!weight || !packed) {
+        set_error("mvs_conv2d_pack_weights_f32: null pointer");
+        return MVS_EINVAL;
+    }
+    return conv2d_pack_launch(weight, Cin, Cout, ksize, stride, packed, as_stream(stream));
+}
+
+extern "C" int mvs_conv2d_f32(const float *in, const float *packed_weight, const float *scale,
+                              const float *shift, int relu, int B, int Cin, int Cout, int H, int W,
+                              int ksize, int stride, int in_planar, float *out, void *stream) {
+    if (!in || !packed_weight || !out || B <= 0 || H <= 0 || W <= 0) {
+        set_error("mvs_conv2d_f32: invalid argument");
+        return MVS_EINVAL;
+    }
+    return conv2d_launch(in, packed_weight, scale, shift, relu, B, Cin, Cout, H, W, ksize, stride,
+                         in_planar, out, as_stream(stream));
+}

@@ -46,6 +46,48 @@ class FeatureNet(nn.Module):
             x = blk(x)
         return self.feature(x)
 
+    # -- inference path on the HIP 2D MFMA kernels (BN folded), channels-last output
+    _PLAN = (("conv0", 1), ("conv1", 1), ("conv2", 2), ("conv3", 1), ("conv4", 1), ("conv5", 2),
+             ("conv6", 1))
+
+    def _hip_params(self):
+        mods = [(n, getattr(self, n), s) for n, s in self._PLAN]
+        key = tuple((p._version, p.data_ptr()) for _, m, _ in mods
+                    for p in (m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean,
+                              m.bn.running_var))
+        key += ((self.feature.weight._version, self.feature.weight.data_ptr()),
+                (self.feature.bias._version, self.feature.bias.data_ptr()))
+        cache = getattr(self, "_hip_cache", None)
+        if cache is not None and cache[0] == key:
+            return cache[1]
+        P = []
+        with torch.no_grad():
+            for name, m, stride in mods:
+                w = m.conv.weight.detach().float().contiguous()
+                scale = (m.bn.weight / torch.sqrt(m.bn.running_var + m.bn.eps)).float().contiguous()
+                shift = (m.bn.bias - m.bn.running_mean * scale).float().contiguous()
+                P.append(dict(name=name, cin=w.shape[1], cout=w.shape[0], k=w.shape[2],
+                              stride=stride, packed=ops.pack_conv2d_weight(w, stride), scale=scale,
+                              shift=shift, relu=True))
+            w = self.feature.weight.detach().float().contiguous()
+            P.append(dict(name="feature", cin=w.shape[1], cout=w.shape[0], k=w.shape[2], stride=1,
+                          packed=ops.pack_conv2d_weight(w, 1), scale=None,
+                          shift=self.feature.bias.detach().float().contiguous(), relu=False))
+        self._hip_cache = (key, P)
+        return P
+
+    def hip_supported(self):
+        return all(p["packed"] is not None for p in self._hip_params())
+
+    def forward_hip(self, imgs_nchw):
+        """[N,3,H,W] image batch (the reference's layout) -> [N,H/4,W/4,32] channels-last."""
+        x = imgs_nchw
+        for i, p in enumerate(self._hip_params()):
+            with ops.stage("feature." + p["name"]):
+                x = ops.conv2d(x, p["packed"], p["cin"], p["cout"], p["k"], p["stride"], p["scale"],
+                               p["shift"], p["relu"], planar=(i == 0))
+        return x
+
 
 def _deconv_block(cin, cout):
     return nn.Sequential(
@@ -179,6 +221,7 @@ class MVSNet(nn.Module):
         self.align_corners = align_corners
         self.proj_where = proj_where
         self.variance_impl = "lds"      # "lds" (LDS-staged source tiles) | "gather"
+        self.feature_impl = "hip"       # "hip" (2D MFMA kernels) | "torch" (PyTorch-ROCm / MIOpen)
         self._feature_cl = False
         self.feature = FeatureNet()
         self.cost_regularization = CostRegNet()
@@ -203,19 +246,23 @@ class MVSNet(nn.Module):
             cost = self.cost_regularization(var).squeeze(1)
         else:
             B = imgs.shape[0]
-            with ops.stage("feature"):
-                # eval: running-stat BN is per-sample, so all B*V views go through
-                # FeatureNet as one batch, in channels_last (MIOpen's NHWC kernels are
-                # faster here and hand over the layout the sweep kernel wants)
-                if not self._feature_cl:
-                    self.feature.to(memory_format=torch.channels_last)
-                    self._feature_cl = True
-                # NCHW -> NHWC through the HIP transpose (torch's strided copy of a
-                # 3-channel image costs ~2 ms here), viewed back as a channels_last tensor
-                x = ops.nchw_to_nhwc(imgs.reshape(B * V, *imgs.shape[2:])).permute(0, 3, 1, 2)
-                f = self.feature(x)                                      # [B*V,32,h,w], NHWC strides
-                f = f.permute(0, 2, 3, 1)                                # [B*V,h,w,32] view
-                h, w, C = f.shape[1], f.shape[2], f.shape[3]
+            flat = imgs.reshape(B * V, *imgs.shape[2:])
+            # eval: running-stat BN is per-sample, so all B*V views go through FeatureNet
+            # as one batch (same values as the reference's per-view loop, mvsnet.py:146)
+            if self.feature_impl == "hip" and self.feature.hip_supported():
+                f = self.feature.forward_hip(flat)           # [B*V,h,w,32]: HIP 2D MFMA kernels
+            else:
+                with ops.stage("feature"):
+                    # PyTorch-ROCm in channels_last: MIOpen's NHWC kernels are the faster
+                    # ones here and hand over the layout the sweep kernel wants.  The
+                    # NCHW->NHWC image conversion goes through the HIP transpose (torch's
+                    # strided copy of a 3-channel image costs ~2 ms).
+                    if not self._feature_cl:
+                        self.feature.to(memory_format=torch.channels_last)
+                        self._feature_cl = True
+                    f = self.feature(ops.nchw_to_nhwc(flat).permute(0, 3, 1, 2))
+                    f = f.permute(0, 2, 3, 1)                # [B*V,h,w,32] view of NHWC storage
+            h, w, C = f.shape[1], f.shape[2], f.shape[3]
             c8 = self.cost_regularization.wants_c8_input()
             use_lds = self.variance_impl == "lds" and C % 16 == 0
             with ops.stage("to_channels_last"):

@@ -340,6 +340,41 @@ def conv3d(x, weight, scale=None, shift=None, residual=None, relu=False, transpo
     return out
 
 
+# ------------------------------------------------------------ FeatureNet convs
+def conv2d_supported(cin, cout, ksize, stride):
+    return bool(_lib.load().mvs_conv2d_supported(cin, cout, ksize, stride))
+
+
+def pack_conv2d_weight(weight, stride):
+    """(Cout,Cin,k,k) -> MFMA A-fragment order, or None if the layer shape has no kernel."""
+    weight = _f32c(weight)
+    cout, cin, k, _ = weight.shape
+    n = _lib.load().mvs_conv2d_packed_weight_floats(cin, cout, k, stride)
+    if n <= 0:
+        return None
+    packed = torch.empty(n, device=weight.device, dtype=torch.float32)
+    check(_lib.load().mvs_conv2d_pack_weights_f32(ptr(weight), cin, cout, k, stride, ptr(packed),
+                                                  stream()), "mvs_conv2d_pack_weights_f32")
+    return packed
+
+
+def conv2d(x, packed, cin, cout, ksize, stride, scale=None, shift=None, relu=False, planar=False):
+    """FeatureNet convolution.  x: [B,H,W,cin] channels-last, or (planar) the [B,3,H,W]
+    image.  Returns [B,Ho,Wo,cout] channels-last."""
+    x = _f32c(x)
+    if planar:
+        B, _, H, W = x.shape
+    else:
+        B, H, W, _ = x.shape
+    pad = ksize // 2
+    Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
+    out = torch.empty((B, Ho, Wo, cout), device=x.device, dtype=torch.float32)
+    check(_lib.load().mvs_conv2d_f32(ptr(x), ptr(packed), ptr(scale), ptr(shift), int(relu), B, cin,
+                                     cout, H, W, ksize, stride, int(planar), ptr(out), stream()),
+          "mvs_conv2d_f32")
+    return out
+
+
 # ------------------------------------------------------------- K4+K5 regress
 class _SoftmaxRegress(torch.autograd.Function):
     @staticmethod

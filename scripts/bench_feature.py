@@ -17,6 +17,11 @@ dev = torch.device("cuda:0")
 m = MVSNet(refine=False); m.load_state_dict(synth.random_state_dict(0)); m = m.to(dev).eval()
 x = torch.rand(5, 3, 1184, 1600, device=dev)
 with torch.no_grad():
+    from mvs_amd import ops
+    tm = ops.StageTimer(); ops.set_timer(tm)
+    print("HIP 2D MFMA kernels    ms", round(t(lambda: m.feature.forward_hip(x)), 3))
+    torch.cuda.synchronize(); ops.set_timer(None)
+    print({k: round(v[1], 4) for k, v in tm.summary_ms().items()})
     print("default nchw           ms", round(t(lambda: m.feature(x)), 3))
     torch.backends.cudnn.benchmark = True
     t0 = time.time(); m.feature(x); torch.cuda.synchronize(); print("benchmark first call s", round(time.time() - t0, 2))

@@ -407,6 +407,49 @@ def test_costregnet_hip_golden(dev, weights):
             np.testing.assert_allclose(cost.cpu().numpy(), g["cost"][:, 0], atol=5e-4, rtol=1e-5)
 
 
+# ------------------------------------------------------------ FeatureNet
+@pytest.mark.parametrize("cfg", [(3, 8, 3, 1), (8, 8, 3, 1), (8, 16, 5, 2), (16, 16, 3, 1),
+                                 (16, 32, 5, 2), (32, 32, 3, 1)])
+@pytest.mark.parametrize("shape", [(2, 37, 53), (1, 64, 96), (1, 17, 130)])
+def test_conv2d_mfma_vs_aten(dev, cfg, shape):
+    """2D MFMA kernels of FeatureNet vs ATen's CPU conv2d on ragged images."""
+    import torch.nn.functional as F
+    from mvs_amd import ops
+    cin, cout, k, stride = cfg
+    B, H, W = shape
+    g = torch.Generator().manual_seed(cin * 100 + cout + H)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    want = F.relu(F.conv2d(x, w, None, stride, k // 2) * scale.view(1, -1, 1, 1) +
+                  shift.view(1, -1, 1, 1))
+    packed = ops.pack_conv2d_weight(w.to(dev), stride)
+    assert packed is not None
+    xin = x.to(dev) if cin == 3 else ops.nchw_to_nhwc(x.to(dev))
+    got = ops.conv2d(xin, packed, cin, cout, k, stride, scale.to(dev), shift.to(dev), True,
+                     planar=(cin == 3))
+    np.testing.assert_allclose(got.permute(0, 3, 1, 2).cpu().numpy(), want.numpy(), atol=3e-5,
+                               rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["g6_e2e_64x96_v3_d8", "g6_e2e_128x160_v3_d16"])
+def test_featurenet_hip_golden(dev, weights, name):
+    """FeatureNet on the HIP kernels vs the features the reference computed."""
+    from mvs_amd.models import MVSNet
+    g = load_golden(name)
+    model = MVSNet(refine=False)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    model = model.to(dev).eval()
+    assert model.feature.hip_supported()
+    imgs = G(g["imgs"], dev)
+    B, V = imgs.shape[:2]
+    with torch.no_grad():
+        f = model.feature.forward_hip(imgs.reshape(B * V, *imgs.shape[2:]))
+    got = f.permute(0, 3, 1, 2).reshape(B, V, 32, f.shape[1], f.shape[2]).cpu().numpy()
+    np.testing.assert_allclose(got, g["features"], atol=2e-6, rtol=1e-5)
+
+
 # --------------------------------------------------------------- K4+K5
 @pytest.mark.parametrize("name", ["g5_regress_d8", "g5_regress_d192"])
 def test_regress_confidence_golden(dev, name):
