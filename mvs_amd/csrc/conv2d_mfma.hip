@@ -55,7 +55,7 @@ template <class Cfg>
 __global__ __launch_bounds__(256) void conv2d_mfma_kernel(Conv2Args a) {
     constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, KH = Cfg::KH, S = Cfg::STRIDE, CK = Cfg::CK;
     constexpr int KS = Cfg::KS, MT = Cfg::MT, RPW = Cfg::RPW, TY = Cfg::TY, NTAPS = Cfg::NTAPS;
-    constexpr int XT = Cfg::XT, YT = Cfg::YT, XH = Cfg::XH, XTP = Cfg::XTP;
+    constexpr int XT = Cfg::XT, XH = Cfg::XH, XTP = Cfg::XTP;
     constexpr int NPIX = Cfg::NPIX, PLANE = Cfg::PLANE, NIT = Cfg::NIT, NITEMS = Cfg::NITEMS;
     constexpr int PAD = KH / 2;
     __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];

@@ -36,12 +36,16 @@ __global__ __launch_bounds__(256) void softmax_regress_conf_kernel(
     __syncthreads();
     m = fmaxf(fmaxf(s_f[0][lane], s_f[1][lane]), fmaxf(s_f[2][lane], s_f[3][lane]));
     __syncthreads();
-    // normaliser: quarter sums combined in quarter order (fp32, as ATen's softmax)
-    float psum = 0.0f;
-    for (int d = d0; d < d1; ++d) psum += expf(c[(int64_t)d * plane] - m);
-    s_f[part][lane] = psum;
+    // normaliser: the fp32 exponentials are summed in fp64 and rounded once, i.e. the
+    // correctly rounded sum -- whatever order ATen's vectorised fp32 reduction uses, this
+    // is within its rounding error, and it does not depend on the quarter split
+    double psum = 0.0;
+    for (int d = d0; d < d1; ++d) psum += (double)expf(c[(int64_t)d * plane] - m);
+    s_d[0][part][lane] = psum;
     __syncthreads();
-    const float sum = ((s_f[0][lane] + s_f[1][lane]) + s_f[2][lane]) + s_f[3][lane];
+    const float sum =
+        (float)(((s_d[0][0][lane] + s_d[0][1][lane]) + s_d[0][2][lane]) + s_d[0][3][lane]);
+    __syncthreads();
     // The fp32 products p_d * dv_d are the reference's (module.py:102); their SUM is
     // carried in fp64: at D=192 and depths ~900 mm a naive fp32 running sum alone
     // costs up to 5e-4 mm against ATen's cascade summation, half the parity budget.
