@@ -60,6 +60,12 @@ def algorithmic_work(V, C, D, h, w):
                                    "conv11": (16, 8, 1)}.items():
         work["costreg." + name] = ("mfma", 2.0 * 27 * ci * co * n0 / (8 ** lvl_in))
     work["costreg.prob"] = ("mfma", 2.0 * 27 * 8 * 1 * n0)
+    # FeatureNet: V views, image 4h x 4w; (cin, cout, k, out-scale)
+    for name, (ci, co, k, sc) in {"conv0": (3, 8, 3, 1), "conv1": (8, 8, 3, 1),
+                                  "conv2": (8, 16, 5, 2), "conv3": (16, 16, 3, 2),
+                                  "conv4": (16, 16, 3, 2), "conv5": (16, 32, 5, 4),
+                                  "conv6": (32, 32, 3, 4), "feature": (32, 32, 3, 4)}.items():
+        work["feature." + name] = ("mfma", 2.0 * k * k * ci * co * V * (4 * h // sc) * (4 * w // sc))
     return work
 
 

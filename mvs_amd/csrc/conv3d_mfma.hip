@@ -561,6 +561,33 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_kernel(ConvArgs a) {
     const float *in_b = a.in + (int64_t)b * a.D * a.H * a.W * CIN;
     const int rd_base = (kq * PLANE + n) * KS;
 
+    // skip-connection values (mvsnet.py:89-91) for every output this lane will write:
+    // issued now, consumed in the epilogue, so their HBM latency hides under the staging
+    // and MFMA phases instead of stalling the store tail
+    float4 res[NCLS][RPW][MT];
+    if (a.residual) {
+#pragma unroll
+        for (int pz = 0; pz < 2; ++pz)
+#pragma unroll
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int px = 0; px < (PXM ? 1 : 2); ++px)
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            const int cls = (pz * 2 + py) * (PXM ? 1 : 2) + px;
+                            const int row = wv * RPW + r;
+                            const int jz = min(jz0 + row / TY, a.D - 1), jy = min(jy0 + row % TY, a.H - 1);
+                            const int jx = min(jx0 + n, a.W - 1);
+                            const int oz = 2 * jz + pz, oy = 2 * jy + py;
+                            const int ox = 2 * jx + (PXM ? (kq >> 1) : px);
+                            const int c0 = min(PXM ? (kq & 1) * 4 : m * 16 + kq * 4, COUT - 4);
+                            res[cls][r][m] = *reinterpret_cast<const float4 *>(
+                                a.residual + ((((int64_t)b * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * COUT + c0);
+                        }
+    }
+
 #pragma unroll 1
     for (int ch = 0; ch < Cfg::NCHUNK; ++ch) {
         if (ch) __syncthreads();
@@ -696,7 +723,7 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_kernel(ConvArgs a) {
                         const int64_t o =
                             ((((int64_t)b * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * COUT + c0;
                         if (a.residual) {
-                            const float4 rs = *reinterpret_cast<const float4 *>(a.residual + o);
+                            const float4 rs = res[cls][r][m];
                             v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
                         }
                         *reinterpret_cast<float4 *>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
@@ -713,7 +740,7 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_kernel(ConvArgs a) {
 // every staged voxel once for all of them; weights are wave-uniform (SGPRs).
 template <int CIN>
 __global__ __launch_bounds__(256) void conv3d_cout1_kernel(ConvArgs a, const float *__restrict__ w) {
-    constexpr int CQ = CIN / 4, TX = 32, TY = 8, TZ = 4;
+    constexpr int CQ = CIN / 4, TX = 32, TY = 8, TZ = 2;   // 43 KB of LDS: 3 blocks per CU
     constexpr int XT = TX + 2, YT = TY + 2, ZT = TZ + 2, NVOX = ZT * YT * XT;
     constexpr int PLANE = round_up_c(NVOX, 16);
     __shared__ __attribute__((aligned(16))) float lds[CQ * PLANE * 4];
@@ -982,7 +1009,7 @@ int conv3d_mfma_launch(const float *in, const float *packed, const float *scale,
     }
     if (is_cout1(transposed, Cin, Cout, stride)) {
         a.Do = D; a.Ho = H; a.Wo = W;
-        a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 7) / 8; a.tiles_z = (D + 3) / 4;
+        a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 7) / 8; a.tiles_z = (D + 1) / 2;
         const int64_t nblk = (int64_t)B * a.tiles_x * a.tiles_y * a.tiles_z;
         if (nblk <= 0 || nblk > 0x7fffffffLL) return MVS_EINVAL;
         if (Cin == 8)

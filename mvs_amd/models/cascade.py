@@ -1,0 +1,78 @@
+"""CasMVSNet stage (DepthNet) on the HIP kernels: SURVEY.md 8(a) row a9.
+
+One cascade stage of CasMVSNet/models/cas_mvsnet.py:12-66 -- projection matrices
+composed from (extrinsic, intrinsic) pairs (:30-33), per-pixel depth hypotheses
+[B,D,H,W] (module.py:249,267), variance cost volume, the parametrised CostRegNet
+(module.py:407-438: same topology as MVSNet's with `base_channels`, `prob` without
+bias), softmax regression and the index-clamped confidence (:63).  The cascade glue
+around it (hypothesis ranges, resizes, FPN features) is a "next" row.
+"""
+import torch
+
+from .. import ops
+
+_CONVS = (("conv0", 1), ("conv1", 2), ("conv2", 1), ("conv3", 2), ("conv4", 1), ("conv5", 2),
+          ("conv6", 1))
+_DECONVS = ("conv7", "conv9", "conv11")
+
+
+def compose_cas_proj(cas_proj):
+    """[B,V,2,4,4] (extrinsic, intrinsic) -> [B,V,4,4] with top 3x4 = K @ E[:3,:4]
+    (cas_mvsnet.py:30-33), evaluated with torch on the tensor's device."""
+    E, K = cas_proj[:, :, 0], cas_proj[:, :, 1]
+    P = E.clone()
+    P[:, :, :3, :4] = torch.matmul(K[:, :, :3, :3], E[:, :, :3, :4])
+    return P
+
+
+def pack_costreg(sd, prefix=""):
+    """Fold BatchNorm(eval) and pack the weights of a Cas-style CostRegNet state_dict
+    (keys `convN.conv.weight`, `convN.bn.*`, `prob.weight`)."""
+    P = {}
+    eps = 1e-5
+    with torch.no_grad():
+        for name, stride, tr in [(n, s, False) for n, s in _CONVS] + [(n, 2, True) for n in _DECONVS]:
+            w = sd[f"{prefix}{name}.conv.weight"].float().contiguous()
+            g, b = sd[f"{prefix}{name}.bn.weight"], sd[f"{prefix}{name}.bn.bias"]
+            mu, var = sd[f"{prefix}{name}.bn.running_mean"], sd[f"{prefix}{name}.bn.running_var"]
+            scale = (g / torch.sqrt(var + eps)).float().contiguous()
+            P[name] = dict(weight=w, scale=scale, shift=(b - mu * scale).float().contiguous(),
+                           stride=stride, transposed=tr, packed=ops.pack_conv3d_weight(w, tr, stride))
+        w = sd[f"{prefix}prob.weight"].float().contiguous()
+        bias = sd.get(f"{prefix}prob.bias")
+        P["prob"] = dict(weight=w, scale=None, shift=None if bias is None else bias.float().contiguous(),
+                         stride=1, transposed=False, packed=ops.pack_conv3d_weight(w, False, 1))
+    return P
+
+
+def costreg_forward(x_cl, P, impl=ops.IMPL_AUTO):
+    """x_cl [B,D,H,W,Cin] channels-last -> cost [B,D,H,W] (module.py:429-438)."""
+    def run(name, t, skip=None, relu=True):
+        p = P[name]
+        return ops.conv3d(t, p["weight"], p["scale"], p["shift"], skip, relu, p["transposed"],
+                          p["stride"], channels_last=True, packed=p["packed"], impl=impl)
+
+    c0 = run("conv0", x_cl)
+    c2 = run("conv2", run("conv1", c0))
+    c4 = run("conv4", run("conv3", c2))
+    t = run("conv6", run("conv5", c4))
+    t = run("conv7", t, c4)
+    t = run("conv9", t, c2)
+    t = run("conv11", t, c0)
+    return run("prob", t, None, relu=False).squeeze(-1)
+
+
+def depthnet_forward(features, cas_proj, depth_values, costreg_params, prob_volume_init=None,
+                     proj_where="host"):
+    """features: list of V tensors [B,C,H,W]; cas_proj [B,V,2,4,4]; depth_values [B,D,H,W]
+    -> {"depth", "photometric_confidence"} as DepthNet.forward (cas_mvsnet.py:12-66)."""
+    proj = compose_cas_proj(cas_proj)
+    rts = ops.rot_trans_all(proj, proj_where)
+    ref = ops.nchw_to_nhwc(features[0])
+    srcs = torch.stack([ops.nchw_to_nhwc(f) for f in features[1:]])
+    var = ops.costvol_variance_cl(ref, srcs, rts, depth_values)
+    cost = costreg_forward(var, costreg_params)
+    if prob_volume_init is not None:
+        cost = cost + prob_volume_init
+    depth, conf, _ = ops.softmax_regress_conf(cost, depth_values, clamp_idx=True)
+    return {"depth": depth, "photometric_confidence": conf}

@@ -26,7 +26,29 @@ for name in ("fetch", "write"):
             agg[k][0] += 1
             agg[k][1] += float(row["Counter_Value"])
     out[name.upper() + "_SIZE_per_launch_KB"] = {k: round(v[1] / v[0], 1) for k, v in
-                                                 sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]}
+                                                 sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]}
 json.dump(out, open(f"{root}/summary.json", "w"), indent=1)
+# per-stage HBM-side traffic for bench.py's roofline.traffic (2*FETCH + WRITE, bytes)
+names = {"costvol_variance": "variance_fwd_lds_kernel", "costreg.conv0": "ConvCfg<32, 8, 2",
+         "costreg.conv1": "ConvCfg<8, 16, 1", "costreg.conv2": "ConvCfg<16, 16, 0",
+         "costreg.conv4": "ConvCfg<32, 32, 0", "costreg.conv11": "DeconvCfg<16, 8",
+         "costreg.prob": "conv3d_cout1_kernel<8>", "softmax_regress_conf": "softmax_regress_conf_kernel",
+         "feature.conv0": "Conv2Cfg<4, 8, 3, 1", "feature.conv1": "Conv2Cfg<8, 8, 3, 1",
+         "feature.conv2": "Conv2Cfg<8, 16, 5, 2"}
+F, W = out["FETCH_SIZE_per_launch_KB"], out["WRITE_SIZE_per_launch_KB"]
+def find(d, sub):
+    return next((v for k, v in d.items() if sub in k), None)
+traffic = {"_note": "HBM-side bytes per launch from rocprofv3 PMC passes (scripts/profile_round.sh): "
+           "traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.  FETCH_SIZE is doubled per "
+           "MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced streaming reads; "
+           "Infinity-Cache hits are included; other access widths are uncalibrated); WRITE_SIZE is "
+           "used as reported (it equals the algorithmic write bytes of these kernels).",
+           "round": tag, "kernels": {}}
+for st, sub in names.items():
+    f, w = find(F, sub), find(W, sub)
+    traffic["kernels"][st] = {"fetch_size_kb": f, "write_size_kb": w,
+                              "traffic_bytes": None if f is None and w is None
+                              else int((2 * (f or 0) + (w or 0)) * 1024)}
+json.dump(traffic, open(f"{root}/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:6000])
 PY

@@ -245,7 +245,8 @@ def main():
     hk.remove()
     save("g8_cas_depthnet", feats=torch.stack(feats), cas_proj=cproj, depth=ppc,
          variance=capc["variance"], cost=capc["cost"], out_depth=oc["depth"],
-         out_conf=oc["photometric_confidence"])
+         out_conf=oc["photometric_confidence"],
+         **{"creg__" + k: v for k, v in creg.state_dict().items()})
 
     # CVP alias quirk (CVP-MVSNet/models/modules.py:228-229): restated from the
     # reference lines with the reference's own homo_warping (the CVP module

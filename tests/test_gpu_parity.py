@@ -527,6 +527,31 @@ def test_mvsnet_eval_from_reference_features(dev, weights):
     np.testing.assert_allclose(conf.cpu().numpy(), g["confidence"], atol=1e-4)
 
 
+def test_cas_depthnet_stage_golden(dev):
+    """One CasMVSNet cascade stage (per-pixel hypotheses, (E,K) projection pairs,
+    base-8 CostRegNet without prob bias, clamped confidence index) on the HIP kernels
+    vs the reference's DepthNet.forward (cas_mvsnet.py:12-66)."""
+    from mvs_amd.models import cascade
+    g = load_golden("g8_cas_depthnet")
+    sd = {k[6:]: G(v, dev) for k, v in g.items() if k.startswith("creg__") and v.ndim > 0}
+    P = cascade.pack_costreg(sd)
+    feats = [G(g["feats"][v], dev) for v in range(g["feats"].shape[0])]
+    with torch.no_grad():
+        from mvs_amd import ops
+        proj = cascade.compose_cas_proj(G(g["cas_proj"], dev))
+        rts = ops.rot_trans_all(proj)
+        var = ops.costvol_variance_cl(ops.nchw_to_nhwc(feats[0]),
+                                      torch.stack([ops.nchw_to_nhwc(f) for f in feats[1:]]), rts,
+                                      G(g["depth"], dev))
+        np.testing.assert_allclose(var.permute(0, 4, 1, 2, 3).cpu().numpy(), g["variance"],
+                                   atol=1e-7, rtol=0)
+        cost = cascade.costreg_forward(var, P)
+        np.testing.assert_allclose(cost.cpu().numpy(), g["cost"][:, 0], atol=2e-5, rtol=1e-5)
+        out = cascade.depthnet_forward(feats, G(g["cas_proj"], dev), G(g["depth"], dev), P)
+    assert np.abs(out["depth"].cpu().numpy() - g["out_depth"]).max() < DEPTH_TOL_MM
+    np.testing.assert_allclose(out["photometric_confidence"].cpu().numpy(), g["out_conf"], atol=1e-5)
+
+
 def test_mvsnet_train_step_golden(dev, weights):
     """train(): loss and gradients against the reference's backward."""
     from mvs_amd.models import MVSNet, mvsnet_loss

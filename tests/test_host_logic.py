@@ -114,8 +114,10 @@ def test_bench_algorithmic_work_matches_baseline_md():
     work = bench.algorithmic_work(5, 32, 192, 296, 400)
     assert abs(work["costvol_variance"][1] / 1e9 - 2.986) < 2e-3
     assert abs(work["softmax_regress_conf"][1] / 1e6 - 91.9) < 0.1
-    flops = sum(v for k, (kind, v) in work.items() if kind == "mfma")
+    flops = sum(v for k, (kind, v) in work.items() if kind == "mfma" and k.startswith("costreg."))
     assert abs(flops / 1e9 - 461.6) < 0.5
+    fnet = sum(v for k, (kind, v) in work.items() if k.startswith("feature."))
+    assert abs(fnet / 1e9 - 89.0) < 1.0          # ~17.8 GFLOP per view
     assert abs(work["costreg.conv0"][1] / 1e9 - 314.3) < 0.1
 
 
