@@ -66,8 +66,11 @@ def depthnet_forward(features, cas_proj, depth_values, costreg_params, prob_volu
                      proj_where="host"):
     """features: list of V tensors [B,C,H,W]; cas_proj [B,V,2,4,4]; depth_values [B,D,H,W]
     -> {"depth", "photometric_confidence"} as DepthNet.forward (cas_mvsnet.py:12-66)."""
-    proj = compose_cas_proj(cas_proj)
-    rts = ops.rot_trans_all(proj, proj_where)
+    # like rot_trans, the K @ E composition is evaluated where the reference's CPU forward
+    # evaluates it (host) unless told otherwise: the depth is sensitive to its rounding
+    dev = cas_proj.device
+    proj = compose_cas_proj(cas_proj.cpu() if proj_where == "host" else cas_proj)
+    rts = ops.rot_trans_all(proj, proj_where, device=dev)
     ref = ops.nchw_to_nhwc(features[0])
     srcs = torch.stack([ops.nchw_to_nhwc(f) for f in features[1:]])
     var = ops.costvol_variance_cl(ref, srcs, rts, depth_values)

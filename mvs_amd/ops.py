@@ -94,12 +94,12 @@ def rot_trans(src_proj, ref_proj, where="host"):
         return m[:, :3, :4].reshape(-1, 12).contiguous().to(dev, non_blocking=True)
 
 
-def rot_trans_all(proj_matrices, where="host"):
+def rot_trans_all(proj_matrices, where="host", device=None):
     """[B,V,4,4] -> [V-1,B,12]: rot_trans of every source view against view 0 with ONE
     device->host hop and one upload.  Each view's product keeps the reference's exact
     shapes ([B,4,4] @ inverse([B,4,4]), module.py:63), so the values are bit-identical
     to calling rot_trans per view."""
-    dev = proj_matrices.device
+    dev = device if device is not None else proj_matrices.device
     with torch.no_grad():
         P = proj_matrices.detach().float()
         if where == "host":

@@ -538,8 +538,8 @@ def test_cas_depthnet_stage_golden(dev):
     feats = [G(g["feats"][v], dev) for v in range(g["feats"].shape[0])]
     with torch.no_grad():
         from mvs_amd import ops
-        proj = cascade.compose_cas_proj(G(g["cas_proj"], dev))
-        rts = ops.rot_trans_all(proj)
+        proj = cascade.compose_cas_proj(torch.from_numpy(g["cas_proj"]))   # host, as the reference
+        rts = ops.rot_trans_all(proj, device=dev)
         var = ops.costvol_variance_cl(ops.nchw_to_nhwc(feats[0]),
                                       torch.stack([ops.nchw_to_nhwc(f) for f in feats[1:]]), rts,
                                       G(g["depth"], dev))
