@@ -232,11 +232,11 @@ class MVSNet(nn.Module):
         if imgs.shape[1] != proj_matrices.shape[1]:
             raise AssertionError("Different number of images and projection matrices")
         V = imgs.shape[1]
-        with ops.stage("rot_trans"):
-            rts = ops.rot_trans_all(proj_matrices, self.proj_where)      # [V-1,B,12]
         autograd_path = self.training or (torch.is_grad_enabled() and
                                           any(p.requires_grad for p in self.parameters()))
         if autograd_path:
+            with ops.stage("rot_trans"):
+                rts = ops.rot_trans_all(proj_matrices, self.proj_where)  # [V-1,B,12]
             with ops.stage("feature"):
                 # per-view calls: BatchNorm batch statistics are per call in the
                 # reference (mvsnet.py:146)
@@ -246,6 +246,8 @@ class MVSNet(nn.Module):
             cost = self.cost_regularization(var).squeeze(1)
         else:
             B = imgs.shape[0]
+            # the host hop of rot_trans runs while FeatureNet occupies the GPU
+            rt_job = ops.HostRotTrans(proj_matrices) if self.proj_where == "host" else None
             flat = imgs.reshape(B * V, *imgs.shape[2:])
             # eval: running-stat BN is per-sample, so all B*V views go through FeatureNet
             # as one batch (same values as the reference's per-view loop, mvsnet.py:146)
@@ -263,6 +265,9 @@ class MVSNet(nn.Module):
                     f = self.feature(ops.nchw_to_nhwc(flat).permute(0, 3, 1, 2))
                     f = f.permute(0, 2, 3, 1)                # [B*V,h,w,32] view of NHWC storage
             h, w, C = f.shape[1], f.shape[2], f.shape[3]
+            with ops.stage("rot_trans"):
+                rts = rt_job.result() if rt_job is not None else \
+                    ops.rot_trans_all(proj_matrices, self.proj_where)   # [V-1,B,12]
             c8 = self.cost_regularization.wants_c8_input()
             use_lds = self.variance_impl == "lds" and C % 16 == 0
             with ops.stage("to_channels_last"):

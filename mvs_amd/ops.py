@@ -110,6 +110,42 @@ def rot_trans_all(proj_matrices, where="host", device=None):
         return out.contiguous().to(dev, non_blocking=True)
 
 
+_side_streams = {}
+
+
+class HostRotTrans:
+    """rot_trans_all(where="host") split in two so the host hop overlaps GPU work:
+
+        job = HostRotTrans(proj_matrices)      # marks "inputs ready" on the current stream
+        ... launch kernels that do not need the result (FeatureNet) ...
+        rts = job.result()                     # D2H on a side stream, CPU 4x4 algebra, H2D
+
+    The side stream waits only for the event recorded at construction, so the copy does
+    not queue behind the kernels launched in between and the GPU never idles on the hop.
+    Values are bit-identical to rot_trans_all."""
+
+    def __init__(self, proj_matrices):
+        self.P = proj_matrices.detach()
+        self.dev = proj_matrices.device
+        self.ev = torch.cuda.Event()
+        self.ev.record()
+
+    def result(self):
+        key = (self.dev.type, self.dev.index)
+        side = _side_streams.get(key)
+        if side is None:
+            side = _side_streams[key] = torch.cuda.Stream(device=self.dev)
+        with torch.no_grad():
+            side.wait_event(self.ev)
+            with torch.cuda.stream(side):
+                host = self.P.float().to("cpu", non_blocking=True)
+            side.synchronize()
+            inv_ref = torch.inverse(host[:, 0])
+            out = torch.stack([torch.matmul(host[:, v], inv_ref)[:, :3, :4].reshape(-1, 12)
+                               for v in range(1, host.shape[1])])
+            return out.contiguous().to(self.dev, non_blocking=True)
+
+
 def _depth_mode(depth_values):
     if depth_values.dim() == 2:
         return 0

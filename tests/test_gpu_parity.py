@@ -51,6 +51,9 @@ def test_rot_trans_host_matches_reference_eval(dev):
     np.testing.assert_array_equal(got, rot_trans_torch(g["proj"], 1))
     dv = ops.rot_trans(P[:, 1], P[:, 0], where="device").cpu().numpy()
     np.testing.assert_allclose(dv, got, rtol=1e-4, atol=1e-4)
+    job = ops.HostRotTrans(P)
+    torch.randn(512, 512, device=dev) @ torch.randn(512, 512, device=dev)   # work queued in between
+    np.testing.assert_array_equal(job.result().cpu().numpy(), ops.rot_trans_all(P).cpu().numpy())
     allv = ops.rot_trans_all(P).cpu().numpy()
     for v in (1, 2):
         np.testing.assert_array_equal(allv[v - 1], rot_trans_torch(g["proj"], v))
