@@ -940,6 +940,7 @@ static bool lookup(int transposed, int Cin, int Cout, int stride, CfgInfo &ci) {
         MVS_CFG(16, 8, 2, 8, 4, 8)
         MVS_CFG(8, 8, 2, 8, 4, 8)
         MVS_CFG(8, 16, 0, 8, 4, 8)
+        MVS_CFG(8, 32, 0, 8, 4, 8)      // input gradient of conv0
         MVS_CFG(16, 16, 0, 16, 4, 8)
         MVS_CFG(32, 32, 0, 16, 4, 8)
         MVS_CFG(64, 64, 0, 16, 4, 8)

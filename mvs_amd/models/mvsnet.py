@@ -133,6 +133,28 @@ class CostRegNet(nn.Module):
         x = c0 + self.conv11(x)
         return self.prob(x)
 
+    # -- autograd path on the HIP conv kernels (forward + input gradients), channels-last
+    def forward_train_hip(self, x_cl):
+        """x_cl [B,D,H,W,32] -> cost [B,D,H,W]; same graph as forward() (mvsnet.py:83-93)."""
+        from ..train_ops import conv3d_cl, conv_bn_relu_cl
+
+        def blk(name, t, stride=1):
+            m = getattr(self, name)
+            return conv_bn_relu_cl(t, m.conv, m.bn, False, stride)
+
+        def up(name, t):
+            m = getattr(self, name)
+            return conv_bn_relu_cl(t, m[0], m[1], True, 2)
+
+        c0 = blk("conv0", x_cl)
+        c2 = blk("conv2", blk("conv1", c0, 2))
+        c4 = blk("conv4", blk("conv3", c2, 2))
+        t = blk("conv6", blk("conv5", c4, 2))
+        t = c4 + up("conv7", t)
+        t = c2 + up("conv9", t)
+        t = c0 + up("conv11", t)
+        return (conv3d_cl(t, self.prob.weight) + self.prob.bias).squeeze(-1)
+
     # -- inference path: HIP kernels, BN folded to a per-channel affine
     def _layers(self):
         out = []
@@ -222,6 +244,7 @@ class MVSNet(nn.Module):
         self.proj_where = proj_where
         self.variance_impl = "lds"      # "lds" (LDS-staged source tiles) | "gather"
         self.feature_impl = "hip"       # "hip" (2D MFMA kernels) | "torch" (PyTorch-ROCm / MIOpen)
+        self.train_impl = "hip"         # CostRegNet autograd convs: "hip" (MFMA fwd+dgrad) | "torch"
         self._feature_cl = False
         self.feature = FeatureNet()
         self.cost_regularization = CostRegNet()
@@ -243,7 +266,10 @@ class MVSNet(nn.Module):
                 feats = [self.feature(imgs[:, v]) for v in range(V)]
             var = ops.costvol_variance(feats[0], torch.stack(feats[1:]), rts, depth_values,
                                        self.align_corners)              # [B,32,D,h,w]
-            cost = self.cost_regularization(var).squeeze(1)
+            if self.train_impl == "hip":
+                cost = self.cost_regularization.forward_train_hip(var.permute(0, 2, 3, 4, 1))
+            else:
+                cost = self.cost_regularization(var).squeeze(1)
         else:
             B = imgs.shape[0]
             # the host hop of rot_trans runs while FeatureNet occupies the GPU

@@ -1,0 +1,100 @@
+"""Training-path (autograd) 3D convolution on the HIP kernels, channels-last.
+
+MIOpen's fp32 3D convolutions dominate a training step of the reference model on this
+stack (1.45 s per 640x512x192 sample: `naive_conv_*_ncdhw` and im2col GEMMs).  Here the
+forward AND the input gradient of every CostRegNet layer run on the MFMA kernels of
+libmvs_hip.so -- the input gradient of a convolution is again one of the supported
+layer shapes:
+
+    conv   k3 s1 (Ci->Co)   dgrad = conv   k3 s1 (Co->Ci), weights flipped + transposed
+    conv   k3 s2 (Ci->Co)   dgrad = deconv k3 s2 (Co->Ci), same weight tensor
+    deconv k3 s2 (Ci->Co)   dgrad = conv   k3 s2 (Co->Ci), same weight tensor
+
+The weight gradient (a reduction over all voxels) is 27 strided-view GEMMs in torch for
+now; BatchNorm (batch statistics), ReLU and the skip adds stay torch autograd ops.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+class _Conv3dCL(torch.autograd.Function):
+    """x [B,D,H,W,Ci] -> raw convolution output [B,Do,Ho,Wo,Co] (no bias, no affine)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, transposed, stride):
+        x = x.contiguous()
+        w = weight.detach().contiguous()
+        packed = ops.pack_conv3d_weight(w, transposed, stride)
+        out = ops.conv3d(x, w, None, None, None, False, transposed, stride, channels_last=True,
+                         packed=packed)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (transposed, stride)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        transposed, stride = ctx.cfg
+        g = g.contiguous()
+        w = weight.detach()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            if not transposed and stride == 1:
+                wt = w.flip(2, 3, 4).permute(1, 0, 2, 3, 4).contiguous()      # (Ci,Co,k) as a conv weight
+                gx = ops.conv3d(g, wt, channels_last=True, packed=ops.pack_conv3d_weight(wt, False, 1))
+            elif not transposed:
+                if any(s % 2 for s in x.shape[1:4]):
+                    raise ops.MvsHipError("stride-2 conv backward needs even D, H, W")
+                wc = w.contiguous()                                            # (Co,Ci,k) as a deconv weight
+                gx = ops.conv3d(g, wc, transposed=True, stride=2, channels_last=True,
+                                packed=ops.pack_conv3d_weight(wc, True, 2))
+            else:
+                wc = w.contiguous()                                            # (Ci,Co,k) as a conv weight
+                gx = ops.conv3d(g, wc, stride=stride, channels_last=True,
+                                packed=ops.pack_conv3d_weight(wc, False, stride))
+        if ctx.needs_input_grad[1]:
+            gw = _wgrad(x, g, transposed, stride, weight.shape)
+        return gx, gw, None, None
+
+
+def _wgrad(x, g, transposed, stride, wshape):
+    """dW by 27 GEMMs over strided views (fp32; torch / hipBLASLt)."""
+    gw = torch.empty(wshape, device=x.device, dtype=torch.float32)
+    if not transposed:
+        _, Do, Ho, Wo, Co = g.shape
+        xp = F.pad(x, (0, 0, 1, 1, 1, 1, 1, 1))
+        g2 = g.reshape(-1, Co)
+        for kz in range(3):
+            for ky in range(3):
+                for kx in range(3):
+                    xv = xp[:, kz:kz + stride * Do:stride, ky:ky + stride * Ho:stride,
+                            kx:kx + stride * Wo:stride, :]
+                    gw[:, :, kz, ky, kx] = g2.t() @ xv.reshape(g2.shape[0], -1)
+    else:   # out[o] += in[i] w[ci,co,k], o = 2i - 1 + k
+        _, D, H, W, Ci = x.shape
+        gp = F.pad(g, (0, 0, 1, 1, 1, 1, 1, 1))
+        x2 = x.reshape(-1, Ci)
+        for kz in range(3):
+            for ky in range(3):
+                for kx in range(3):
+                    gv = gp[:, kz:kz + 2 * D:2, ky:ky + 2 * H:2, kx:kx + 2 * W:2, :]
+                    gw[:, :, kz, ky, kx] = x2.t() @ gv.reshape(x2.shape[0], -1)
+    return gw
+
+
+def conv3d_cl(x, weight, transposed=False, stride=1):
+    return _Conv3dCL.apply(x, weight, transposed, stride)
+
+
+def conv_bn_relu_cl(x, conv, bn, transposed=False, stride=1):
+    """ConvBnReLU3D / deconv block of the reference (module.py:26-33, mvsnet.py:66-79) in
+    channels-last with batch statistics when bn.training (running stats are updated)."""
+    y = conv3d_cl(x, conv.weight, transposed, stride)
+    C = y.shape[-1]
+    y2 = F.batch_norm(y.reshape(-1, C), bn.running_mean, bn.running_var, bn.weight, bn.bias,
+                      bn.training, bn.momentum, bn.eps)
+    if bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return F.relu(y2).reshape(y.shape)

@@ -555,6 +555,32 @@ def test_cas_depthnet_stage_golden(dev):
     np.testing.assert_allclose(out["photometric_confidence"].cpu().numpy(), g["out_conf"], atol=1e-5)
 
 
+@pytest.mark.parametrize("cfg", [(32, 8, False, 1), (8, 16, False, 2), (16, 16, False, 1),
+                                 (64, 32, True, 2), (16, 8, True, 2), (8, 1, False, 1)])
+def test_conv3d_autograd_vs_torch(dev, cfg):
+    """Forward, input gradient (HIP kernels) and weight gradient of the training-path
+    convolution against torch's own conv3d / conv_transpose3d autograd."""
+    import torch.nn.functional as F
+    from mvs_amd.train_ops import conv3d_cl
+    cin, cout, transposed, stride = cfg
+    g = torch.Generator(device=dev).manual_seed(cin + cout)
+    x = torch.randn(1, 8, 8, 16, cin, device=dev, generator=g, requires_grad=True)
+    wshape = (cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3)
+    w = (torch.randn(wshape, device=dev, generator=g) / (27 * cin) ** 0.5).requires_grad_(True)
+    y = conv3d_cl(x, w, transposed, stride)
+    go = torch.randn(y.shape, device=dev, generator=g)
+    y.backward(go)
+    xr = x.detach().permute(0, 4, 1, 2, 3).contiguous().requires_grad_(True)
+    wr = w.detach().clone().requires_grad_(True)
+    yr = F.conv_transpose3d(xr, wr, None, 2, 1, 1) if transposed else F.conv3d(xr, wr, None, stride, 1)
+    yr.backward(go.permute(0, 4, 1, 2, 3).contiguous())
+    np.testing.assert_allclose(y.detach().permute(0, 4, 1, 2, 3).cpu().numpy(), yr.detach().cpu().numpy(),
+                               atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(x.grad.permute(0, 4, 1, 2, 3).cpu().numpy(), xr.grad.cpu().numpy(),
+                               atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(w.grad.cpu().numpy(), wr.grad.cpu().numpy(), atol=2e-4, rtol=1e-3)
+
+
 def test_mvsnet_train_step_golden(dev, weights):
     """train(): loss and gradients against the reference's backward."""
     from mvs_amd.models import MVSNet, mvsnet_loss
