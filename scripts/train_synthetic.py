@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--ndepth", type=int, default=192)
     ap.add_argument("--lr", type=float, default=1e-3)     # train.py:98
     args = ap.parse_args()
+    # (train.py:25 sets cudnn.benchmark; on this stack it costs a 280 s MIOpen search in the
+    # first step and changes nothing afterwards: 186 ms either way -- left off)
     rank, world, dev = parallel.init_distributed()
     torch.manual_seed(1)                                  # train.py:53,65-66
     model = MVSNet(refine=False).to(dev)
