@@ -509,6 +509,26 @@ def test_mvsnet_eval_matches_reference_cpu_forward(dev, weights, name):
     np.testing.assert_allclose(conf, g["confidence"], atol=1e-4)
 
 
+@pytest.mark.parametrize("feature_impl,variance_impl,conv_impl",
+                         [("torch", "gather", "auto"), ("hip", "gather", "direct"),
+                          ("torch", "lds", "auto")])
+def test_mvsnet_eval_alternate_paths(dev, weights, feature_impl, variance_impl, conv_impl):
+    """Every selectable implementation (PyTorch-ROCm FeatureNet, gather sweep kernel, direct
+    VALU convolutions) passes the same 1e-3 mm gate as the default path."""
+    from mvs_amd import ops
+    from mvs_amd.models import MVSNet
+    g = load_golden("g6_e2e_128x160_v3_d16")
+    model = MVSNet(refine=False)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    model = model.to(dev).eval()
+    model.feature_impl, model.variance_impl = feature_impl, variance_impl
+    model.cost_regularization.conv_impl = {"auto": ops.IMPL_AUTO, "direct": ops.IMPL_DIRECT}[conv_impl]
+    with torch.no_grad():
+        out = model(G(g["imgs"], dev), G(g["proj"], dev), G(g["depth_values"], dev))
+    assert np.abs(out["depth"].cpu().numpy() - g["depth"]).max() < DEPTH_TOL_MM
+    np.testing.assert_allclose(out["photometric_confidence"].cpu().numpy(), g["confidence"], atol=1e-4)
+
+
 def test_mvsnet_eval_from_reference_features(dev, weights):
     """Same gate with FeatureNet taken out of the loop (features from the
     reference): isolates the HIP cost-volume path proper."""
