@@ -79,6 +79,17 @@ class FeatureNet(nn.Module):
     def hip_supported(self):
         return all(p["packed"] is not None for p in self._hip_params())
 
+    def forward_train_hip(self, img_nchw):
+        """Autograd path on the HIP 2D kernels: [N,3,H,W] -> [N,32,H/4,W/4] (the planar layout
+        the autograd variance op takes), batch-statistics BatchNorm as in forward()."""
+        from ..train_ops import conv2d_bn_relu_cl, conv2d_cl
+        x = conv2d_bn_relu_cl(img_nchw, self.conv0.conv, self.conv0.bn, 1, planar=True)
+        for name, stride in self._PLAN[1:]:
+            m = getattr(self, name)
+            x = conv2d_bn_relu_cl(x, m.conv, m.bn, stride)
+        x = conv2d_cl(x, self.feature.weight, 1) + self.feature.bias
+        return x.permute(0, 3, 1, 2).contiguous()
+
     def forward_hip(self, imgs_nchw):
         """[N,3,H,W] image batch (the reference's layout) -> [N,H/4,W/4,32] channels-last."""
         x = imgs_nchw
@@ -263,7 +274,10 @@ class MVSNet(nn.Module):
             with ops.stage("feature"):
                 # per-view calls: BatchNorm batch statistics are per call in the
                 # reference (mvsnet.py:146)
-                feats = [self.feature(imgs[:, v]) for v in range(V)]
+                if self.train_impl == "hip" and self.feature.hip_supported():
+                    feats = [self.feature.forward_train_hip(imgs[:, v]) for v in range(V)]
+                else:
+                    feats = [self.feature(imgs[:, v]) for v in range(V)]
             var = ops.costvol_variance(feats[0], torch.stack(feats[1:]), rts, depth_values,
                                        self.align_corners)              # [B,32,D,h,w]
             if self.train_impl == "hip":

@@ -98,3 +98,64 @@ def conv_bn_relu_cl(x, conv, bn, transposed=False, stride=1):
     if bn.training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
     return F.relu(y2).reshape(y.shape)
+
+
+# ------------------------------------------------------------------ FeatureNet (2D)
+class _Conv2dCL(torch.autograd.Function):
+    """x [N,H,W,Ci] (or the planar [N,3,H,W] image for the RGB layer) -> raw convolution
+    output [N,Ho,Wo,Co] on the 2D MFMA kernels.  k in {3 (stride 1), 5 (stride 2)}."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, planar):
+        x = x.contiguous()
+        w = weight.detach().contiguous()
+        cout, cin, k, _ = w.shape
+        out = ops.conv2d(x, ops.pack_conv2d_weight(w, stride), cin, cout, k, stride, None, None,
+                         False, planar=planar)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, planar)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        stride, planar = ctx.cfg
+        g = g.contiguous()
+        w = weight.detach()
+        cout, cin, k, _ = w.shape
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            if stride == 1 and ops.conv2d_supported(cout, cin, k, 1) and not planar:
+                wt = w.flip(2, 3).permute(1, 0, 2, 3).contiguous()
+                gx = ops.conv2d(g, ops.pack_conv2d_weight(wt, 1), cout, cin, k, 1)
+            else:   # 5x5 stride-2 layers: transposed convolution through torch (NHWC views)
+                gx = F.conv_transpose2d(g.permute(0, 3, 1, 2), w, None, stride, k // 2, stride - 1)
+                gx = gx if planar else gx.permute(0, 2, 3, 1).contiguous()
+        if ctx.needs_input_grad[1]:
+            xcl = x.permute(0, 2, 3, 1) if planar else x
+            pad = k // 2
+            xp = F.pad(xcl, (0, 0, pad, pad, pad, pad))
+            _, Ho, Wo, Co = g.shape
+            g2 = g.reshape(-1, Co)
+            gw = torch.empty(w.shape, device=x.device, dtype=torch.float32)
+            for ky in range(k):
+                for kx in range(k):
+                    xv = xp[:, ky:ky + stride * Ho:stride, kx:kx + stride * Wo:stride, :]
+                    gw[:, :, ky, kx] = g2.t() @ xv.reshape(g2.shape[0], -1)
+        return gx, gw, None, None
+
+
+def conv2d_cl(x, weight, stride=1, planar=False):
+    return _Conv2dCL.apply(x, weight, stride, planar)
+
+
+def conv2d_bn_relu_cl(x, conv, bn, stride=1, planar=False):
+    """ConvBnReLU of the reference (module.py:6-13) in channels-last, batch statistics when
+    bn.training."""
+    y = conv2d_cl(x, conv.weight, stride, planar)
+    C = y.shape[-1]
+    y2 = F.batch_norm(y.reshape(-1, C), bn.running_mean, bn.running_var, bn.weight, bn.bias,
+                      bn.training, bn.momentum, bn.eps)
+    if bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return F.relu(y2).reshape(y.shape)

@@ -601,6 +601,32 @@ def test_conv3d_autograd_vs_torch(dev, cfg):
     np.testing.assert_allclose(w.grad.cpu().numpy(), wr.grad.cpu().numpy(), atol=2e-4, rtol=1e-3)
 
 
+@pytest.mark.parametrize("cfg", [(3, 8, 3, 1), (8, 8, 3, 1), (8, 16, 5, 2), (16, 32, 5, 2),
+                                 (32, 32, 3, 1)])
+def test_conv2d_autograd_vs_torch(dev, cfg):
+    import torch.nn.functional as F
+    from mvs_amd.train_ops import conv2d_cl
+    cin, cout, k, stride = cfg
+    g = torch.Generator(device=dev).manual_seed(cin * 7 + cout)
+    planar = cin == 3
+    xn = torch.randn(2, cin, 24, 32, device=dev, generator=g)
+    x = (xn if planar else xn.permute(0, 2, 3, 1).contiguous()).requires_grad_(not planar)
+    w = (torch.randn(cout, cin, k, k, device=dev, generator=g) / (cin * k * k) ** 0.5).requires_grad_(True)
+    y = conv2d_cl(x, w, stride, planar)
+    go = torch.randn(y.shape, device=dev, generator=g)
+    y.backward(go)
+    xr = xn.clone().requires_grad_(True)
+    wr = w.detach().clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, stride, k // 2)
+    yr.backward(go.permute(0, 3, 1, 2).contiguous())
+    np.testing.assert_allclose(y.detach().permute(0, 3, 1, 2).cpu().numpy(), yr.detach().cpu().numpy(),
+                               atol=3e-5, rtol=1e-4)
+    if not planar:
+        np.testing.assert_allclose(x.grad.permute(0, 3, 1, 2).cpu().numpy(), xr.grad.cpu().numpy(),
+                                   atol=3e-5, rtol=1e-4)
+    np.testing.assert_allclose(w.grad.cpu().numpy(), wr.grad.cpu().numpy(), atol=3e-4, rtol=1e-3)
+
+
 def test_mvsnet_train_step_golden(dev, weights):
     """train(): loss and gradients against the reference's backward."""
     from mvs_amd.models import MVSNet, mvsnet_loss
