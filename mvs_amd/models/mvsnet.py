@@ -256,6 +256,8 @@ class MVSNet(nn.Module):
         self.variance_impl = "lds"      # "lds" (LDS-staged source tiles) | "gather"
         self.feature_impl = "hip"       # "hip" (2D MFMA kernels) | "torch" (PyTorch-ROCm / MIOpen)
         self.train_impl = "hip"         # CostRegNet autograd convs: "hip" (MFMA fwd+dgrad) | "torch"
+        self.train_feature_impl = "torch"   # FeatureNet autograd: MIOpen's 2D fp32 path is fast
+                                            # (1.6 ms backward); "hip" = mvs_amd.train_ops.conv2d_cl
         self._feature_cl = False
         self.feature = FeatureNet()
         self.cost_regularization = CostRegNet()
@@ -274,7 +276,7 @@ class MVSNet(nn.Module):
             with ops.stage("feature"):
                 # per-view calls: BatchNorm batch statistics are per call in the
                 # reference (mvsnet.py:146)
-                if self.train_impl == "hip" and self.feature.hip_supported():
+                if self.train_feature_impl == "hip" and self.feature.hip_supported():
                     feats = [self.feature.forward_train_hip(imgs[:, v]) for v in range(V)]
                 else:
                     feats = [self.feature(imgs[:, v]) for v in range(V)]

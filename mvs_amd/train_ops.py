@@ -59,8 +59,24 @@ class _Conv3dCL(torch.autograd.Function):
         return gx, gw, None, None
 
 
+_SPLIT = 16384   # voxels per split-K slice
+
+
+def _tall_gemm_t(a, b):
+    """a^T @ b for a [N,Ma], b [N,Mb] with N in the millions and Ma, Mb <= 64: as one
+    batched GEMM over N/_SPLIT slices + a sum (a single skinny GEMM with K = N runs on a
+    handful of CUs: 2.9 ms per tap for conv0, 154 ms per training step in total)."""
+    n = a.shape[0]
+    pad = (-n) % _SPLIT
+    if pad:
+        a = F.pad(a, (0, 0, 0, pad))
+        b = F.pad(b, (0, 0, 0, pad))
+    nb = a.shape[0] // _SPLIT
+    return torch.bmm(a.view(nb, _SPLIT, -1).transpose(1, 2), b.view(nb, _SPLIT, -1)).sum(0)
+
+
 def _wgrad(x, g, transposed, stride, wshape):
-    """dW by 27 GEMMs over strided views (fp32; torch / hipBLASLt)."""
+    """dW by 27 split-K batched GEMMs over strided views (fp32; torch / hipBLASLt)."""
     gw = torch.empty(wshape, device=x.device, dtype=torch.float32)
     if not transposed:
         _, Do, Ho, Wo, Co = g.shape
@@ -71,7 +87,7 @@ def _wgrad(x, g, transposed, stride, wshape):
                 for kx in range(3):
                     xv = xp[:, kz:kz + stride * Do:stride, ky:ky + stride * Ho:stride,
                             kx:kx + stride * Wo:stride, :]
-                    gw[:, :, kz, ky, kx] = g2.t() @ xv.reshape(g2.shape[0], -1)
+                    gw[:, :, kz, ky, kx] = _tall_gemm_t(g2, xv.reshape(g2.shape[0], -1))
     else:   # out[o] += in[i] w[ci,co,k], o = 2i - 1 + k
         _, D, H, W, Ci = x.shape
         gp = F.pad(g, (0, 0, 1, 1, 1, 1, 1, 1))
@@ -80,7 +96,7 @@ def _wgrad(x, g, transposed, stride, wshape):
             for ky in range(3):
                 for kx in range(3):
                     gv = gp[:, kz:kz + 2 * D:2, ky:ky + 2 * H:2, kx:kx + 2 * W:2, :]
-                    gw[:, :, kz, ky, kx] = x2.t() @ gv.reshape(x2.shape[0], -1)
+                    gw[:, :, kz, ky, kx] = _tall_gemm_t(x2, gv.reshape(x2.shape[0], -1))
     return gw
 
 
@@ -141,7 +157,7 @@ class _Conv2dCL(torch.autograd.Function):
             for ky in range(k):
                 for kx in range(k):
                     xv = xp[:, ky:ky + stride * Ho:stride, kx:kx + stride * Wo:stride, :]
-                    gw[:, :, ky, kx] = g2.t() @ xv.reshape(g2.shape[0], -1)
+                    gw[:, :, ky, kx] = _tall_gemm_t(g2, xv.reshape(g2.shape[0], -1))
         return gx, gw, None, None
 
 
