@@ -1,0 +1,180 @@
+"""CascadeMVSNet (BASELINE config 3) with every stage's cost-volume path on the HIP kernels.
+
+Mirrors the reference's Python surface (CasMVSNet/models/cas_mvsnet.py:69-164):
+
+    model = CascadeMVSNet(ndepths=[48, 32, 8], depth_interals_ratio=[4, 2, 1])
+    out = model(imgs[B,V,3,H,W], {"stage1": P1, "stage2": P2, "stage3": P3}, depth_values[B,D])
+    out["stage1"]["depth"], ..., out["depth"], out["photometric_confidence"]
+
+with P_s [B,V,2,4,4] = (extrinsic, stage intrinsic) pairs (general_eval.py:158-180).  Module
+and parameter names equal the reference's, so its checkpoints load unchanged.
+
+What runs where (eval): the FPN FeatureNet (module.py:304-405) and the glue between stages
+-- hypothesis ranges (module.py:485-524), the bilinear / trilinear resizes
+(cas_mvsnet.py:134-151) -- are PyTorch-ROCm ops ("next" rows); each stage's
+DepthNet (cas_mvsnet.py:12-66: warp + variance with per-pixel hypotheses, CostRegNet,
+softmax regression, clamped confidence) runs on the kernels via models/cascade.py.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import cascade
+from .. import ops
+
+
+class _CBR2d(nn.Module):
+    """conv + BatchNorm + ReLU with the reference's child names `conv` / `bn`."""
+
+    def __init__(self, cin, cout, k, stride=1, pad=1):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, stride=stride, padding=pad, bias=False)
+        self.bn = nn.BatchNorm2d(cout)
+
+    def forward(self, x):
+        return F.relu(self.bn(self.conv(x)), inplace=True)
+
+
+class _CBR3d(nn.Module):
+    def __init__(self, cin, cout, stride=1, transposed=False):
+        super().__init__()
+        if transposed:
+            self.conv = nn.ConvTranspose3d(cin, cout, 3, stride=stride, padding=1, output_padding=1,
+                                           bias=False)
+        else:
+            self.conv = nn.Conv3d(cin, cout, 3, stride=stride, padding=1, bias=False)
+        self.bn = nn.BatchNorm3d(cout)
+
+    def forward(self, x):
+        return F.relu(self.bn(self.conv(x)), inplace=True)
+
+
+class FeatureNet(nn.Module):
+    """FPN feature pyramid: stage1 [B,32,H/4,W/4], stage2 [B,16,H/2,W/2], stage3 [B,8,H,W]
+    (module.py:304-405, arch_mode "fpn", 3 stages)."""
+
+    def __init__(self, base_channels=8):
+        super().__init__()
+        b = base_channels
+        self.conv0 = nn.Sequential(_CBR2d(3, b, 3), _CBR2d(b, b, 3))
+        self.conv1 = nn.Sequential(_CBR2d(b, 2 * b, 5, 2, 2), _CBR2d(2 * b, 2 * b, 3), _CBR2d(2 * b, 2 * b, 3))
+        self.conv2 = nn.Sequential(_CBR2d(2 * b, 4 * b, 5, 2, 2), _CBR2d(4 * b, 4 * b, 3), _CBR2d(4 * b, 4 * b, 3))
+        self.out1 = nn.Conv2d(4 * b, 4 * b, 1, bias=False)
+        self.inner1 = nn.Conv2d(2 * b, 4 * b, 1, bias=True)
+        self.inner2 = nn.Conv2d(b, 4 * b, 1, bias=True)
+        self.out2 = nn.Conv2d(4 * b, 2 * b, 3, padding=1, bias=False)
+        self.out3 = nn.Conv2d(4 * b, b, 3, padding=1, bias=False)
+        self.out_channels = [4 * b, 2 * b, b]
+
+    def forward(self, x):
+        c0 = self.conv0(x)
+        c1 = self.conv1(c0)
+        top = self.conv2(c1)
+        out = {"stage1": self.out1(top)}
+        top = F.interpolate(top, scale_factor=2, mode="nearest") + self.inner1(c1)
+        out["stage2"] = self.out2(top)
+        top = F.interpolate(top, scale_factor=2, mode="nearest") + self.inner2(c0)
+        out["stage3"] = self.out3(top)
+        return out
+
+
+class CostRegNet(nn.Module):
+    """module.py:407-438; holds the parameters (state_dict contract) -- the arithmetic runs in
+    cascade.costreg_forward on the kernels."""
+
+    def __init__(self, in_channels, base_channels):
+        super().__init__()
+        b = base_channels
+        self.conv0 = _CBR3d(in_channels, b)
+        self.conv1 = _CBR3d(b, 2 * b, 2)
+        self.conv2 = _CBR3d(2 * b, 2 * b)
+        self.conv3 = _CBR3d(2 * b, 4 * b, 2)
+        self.conv4 = _CBR3d(4 * b, 4 * b)
+        self.conv5 = _CBR3d(4 * b, 8 * b, 2)
+        self.conv6 = _CBR3d(8 * b, 8 * b)
+        self.conv7 = _CBR3d(8 * b, 4 * b, 2, transposed=True)
+        self.conv9 = _CBR3d(4 * b, 2 * b, 2, transposed=True)
+        self.conv11 = _CBR3d(2 * b, b, 2, transposed=True)
+        self.prob = nn.Conv3d(b, 1, 3, stride=1, padding=1, bias=False)
+        self._packed = None
+
+    def forward(self, x):   # planar autograd form (training)
+        c0 = self.conv0(x)
+        c2 = self.conv2(self.conv1(c0))
+        c4 = self.conv4(self.conv3(c2))
+        t = self.conv6(self.conv5(c4))
+        t = c4 + self.conv7(t)
+        t = c2 + self.conv9(t)
+        t = c0 + self.conv11(t)
+        return self.prob(t)
+
+    def hip_params(self):
+        key = tuple((p._version, p.data_ptr()) for p in list(self.parameters()) + list(self.buffers()))
+        if self._packed is None or self._packed[0] != key:
+            self._packed = (key, cascade.pack_costreg(self.state_dict()))
+        return self._packed[1]
+
+
+def depth_hypotheses(cur_depth, ndepth, interval, shape):
+    """Per-pixel hypothesis volume [B,D,H,W] (module.py:485-524).  cur_depth [B,D0] (first
+    stage: the full sweep's end points) or [B,H,W] (later stages: +-ndepth/2 intervals around
+    the previous estimate)."""
+    B, H, W = shape
+    ramp = torch.arange(ndepth, device=cur_depth.device, dtype=cur_depth.dtype)
+    if cur_depth.dim() == 2:
+        lo, hi = cur_depth[:, 0], cur_depth[:, -1]
+        step = (hi - lo) / (ndepth - 1)
+        d = lo.unsqueeze(1) + ramp.reshape(1, -1) * step.unsqueeze(1)
+        return d.unsqueeze(-1).unsqueeze(-1).repeat(1, 1, H, W)
+    lo = cur_depth - ndepth / 2 * interval
+    hi = cur_depth + ndepth / 2 * interval
+    step = (hi - lo) / (ndepth - 1)
+    return lo.unsqueeze(1) + ramp.reshape(1, -1, 1, 1) * step.unsqueeze(1)
+
+
+class CascadeMVSNet(nn.Module):
+    def __init__(self, refine=False, ndepths=(48, 32, 8), depth_interals_ratio=(4, 2, 1),
+                 cr_base_chs=(8, 8, 8), proj_where="host"):
+        super().__init__()
+        if refine:
+            raise NotImplementedError("the reference never enables refine (test.py:168)")
+        assert len(ndepths) == len(depth_interals_ratio) == 3
+        self.ndepths = list(ndepths)
+        self.depth_interals_ratio = list(depth_interals_ratio)
+        self.num_stage = 3
+        self.proj_where = proj_where
+        self.stage_scale = {"stage1": 4, "stage2": 2, "stage3": 1}
+        self.feature = FeatureNet(base_channels=8)
+        self.cost_regularization = nn.ModuleList(
+            [CostRegNet(self.feature.out_channels[i], cr_base_chs[i]) for i in range(3)])
+
+    def forward(self, imgs, proj_matrices, depth_values):
+        B, V, _, H, W = imgs.shape
+        depth_min, depth_max = float(depth_values[0, 0]), float(depth_values[0, -1])
+        depth_interval = (depth_max - depth_min) / depth_values.size(1)
+        with ops.stage("feature"):
+            feats = [self.feature(imgs[:, v]) for v in range(V)]
+        outputs, depth = {}, None
+        for s in range(3):
+            key = f"stage{s + 1}"
+            scale = self.stage_scale[key]
+            with ops.stage(key + ".hypotheses"):
+                if depth is None:
+                    cur = depth_values
+                else:
+                    cur = F.interpolate(depth.detach().unsqueeze(1), [H, W], mode="bilinear",
+                                        align_corners=False).squeeze(1)
+                hyp = depth_hypotheses(cur, self.ndepths[s], self.depth_interals_ratio[s] * depth_interval,
+                                       (B, H, W))
+                hyp = F.interpolate(hyp.unsqueeze(1), [self.ndepths[s], H // scale, W // scale],
+                                    mode="trilinear", align_corners=False).squeeze(1).contiguous()
+            stage_feats = [f[key] for f in feats]
+            if self.training:
+                raise NotImplementedError("CascadeMVSNet here is the inference path (config 3)")
+            out = cascade.depthnet_forward(stage_feats, proj_matrices[key], hyp,
+                                           self.cost_regularization[s].hip_params(),
+                                           proj_where=self.proj_where, tag=key + ".")
+            depth = out["depth"]
+            outputs[key] = out
+            outputs.update(out)
+        return outputs

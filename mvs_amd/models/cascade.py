@@ -63,19 +63,24 @@ def costreg_forward(x_cl, P, impl=ops.IMPL_AUTO):
 
 
 def depthnet_forward(features, cas_proj, depth_values, costreg_params, prob_volume_init=None,
-                     proj_where="host"):
+                     proj_where="host", tag=""):
     """features: list of V tensors [B,C,H,W]; cas_proj [B,V,2,4,4]; depth_values [B,D,H,W]
     -> {"depth", "photometric_confidence"} as DepthNet.forward (cas_mvsnet.py:12-66)."""
     # like rot_trans, the K @ E composition is evaluated where the reference's CPU forward
     # evaluates it (host) unless told otherwise: the depth is sensitive to its rounding
     dev = cas_proj.device
-    proj = compose_cas_proj(cas_proj.cpu() if proj_where == "host" else cas_proj)
-    rts = ops.rot_trans_all(proj, proj_where, device=dev)
-    ref = ops.nchw_to_nhwc(features[0])
-    srcs = torch.stack([ops.nchw_to_nhwc(f) for f in features[1:]])
-    var = ops.costvol_variance_cl(ref, srcs, rts, depth_values)
-    cost = costreg_forward(var, costreg_params)
-    if prob_volume_init is not None:
-        cost = cost + prob_volume_init
-    depth, conf, _ = ops.softmax_regress_conf(cost, depth_values, clamp_idx=True)
+    with ops.stage(tag + "rot_trans"):
+        proj = compose_cas_proj(cas_proj.cpu() if proj_where == "host" else cas_proj)
+        rts = ops.rot_trans_all(proj, proj_where, device=dev)
+    with ops.stage(tag + "to_channels_last"):
+        ref = ops.nchw_to_nhwc(features[0])
+        srcs = torch.stack([ops.nchw_to_nhwc(f) for f in features[1:]])
+    with ops.stage(tag + "costvol_variance"):
+        var = ops.costvol_variance_cl(ref, srcs, rts, depth_values)
+    with ops.stage(tag + "costreg"):
+        cost = costreg_forward(var, costreg_params)
+        if prob_volume_init is not None:
+            cost = cost + prob_volume_init
+    with ops.stage(tag + "softmax_regress_conf"):
+        depth, conf, _ = ops.softmax_regress_conf(cost, depth_values, clamp_idx=True)
     return {"depth": depth, "photometric_confidence": conf}

@@ -153,3 +153,25 @@ def random_state_dict(seed=0, peaked=30.0):
     conv_w("cost_regularization.prob", (1, 8, 3, 3, 3), 8 * 27, True, 1)
     sd["cost_regularization.prob.weight"] *= peaked
     return sd
+
+
+def cas_random_state_dict(seed=0, peaked=100.0):
+    """Seeded CascadeMVSNet state_dict (reference key names, 934,304 parameters): PyTorch's
+    default conv init, BatchNorm affine/statistics perturbed away from identity, `prob`
+    scaled so the softmax over depth is peaked like a trained network's.  Deterministic for
+    a given torch build (CPU generator), so goldens store the seed, not 3.7 MB of weights."""
+    import torch
+    from .models.cas_mvsnet import CascadeMVSNet
+    torch.manual_seed(seed)
+    net = CascadeMVSNet()
+    g = torch.Generator().manual_seed(seed + 1)
+    sd = net.state_dict()
+    with torch.no_grad():
+        for k, v in sd.items():
+            if k.endswith("bn.weight") or k.endswith("running_var"):
+                v.copy_(0.5 + torch.rand(v.shape, generator=g))
+            elif k.endswith("bn.bias") or k.endswith("running_mean"):
+                v.copy_(0.1 * torch.randn(v.shape, generator=g))
+            elif k.endswith("prob.weight"):
+                v.mul_(peaked)
+    return {k: v.clone() for k, v in sd.items()}

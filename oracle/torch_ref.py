@@ -12,6 +12,7 @@ with the reference's key names -- of:
   CostRegNet            MVSNet/models/mvsnet.py:48-93
   softmax/regression    MVSNet/models/mvsnet.py:183-185, module.py:91-103
   photometric conf.     MVSNet/models/mvsnet.py:187-191
+  CasMVSNet cascade     CasMVSNet/models/cas_mvsnet.py:12-66,108-164; module.py:304-438,485-524
 
 Parity status: PINNED -- tests/test_oracle_golden.py checks every stage against
 golden vectors captured from the imported reference.
@@ -145,6 +146,90 @@ def mvsnet_forward(imgs, projs, depth, sd, train=False, stages=None):
     if stages is not None:
         stages.update(feature=t1 - t0, costvol=t2 - t1, costreg=t3 - t2, regress=t4 - t3)
     return {"depth": est, "photometric_confidence": conf}
+
+
+# ---- CasMVSNet (BASELINE config 3) -----------------------------------------------------
+
+def cas_feature_net(img, sd, prefix="feature."):
+    """FPN pyramid {"stage1": [B,32,H/4,W/4], "stage2": [B,16,H/2,W/2], "stage3": [B,8,H,W]}
+    (CasMVSNet/models/module.py:304-405, arch "fpn")."""
+    def cbr(name, t, stride, pad):
+        t = F.conv2d(t, sd[f"{prefix}{name}.conv.weight"], None, stride, pad)
+        return F.relu(_bn_eval(t, sd, f"{prefix}{name}.bn"))
+
+    c0 = cbr("conv0.1", cbr("conv0.0", img, 1, 1), 1, 1)
+    c1 = cbr("conv1.2", cbr("conv1.1", cbr("conv1.0", c0, 2, 2), 1, 1), 1, 1)
+    top = cbr("conv2.2", cbr("conv2.1", cbr("conv2.0", c1, 2, 2), 1, 1), 1, 1)
+    out = {"stage1": F.conv2d(top, sd[prefix + "out1.weight"])}
+    top = F.interpolate(top, scale_factor=2, mode="nearest") + \
+        F.conv2d(c1, sd[prefix + "inner1.weight"], sd[prefix + "inner1.bias"])
+    out["stage2"] = F.conv2d(top, sd[prefix + "out2.weight"], None, 1, 1)
+    top = F.interpolate(top, scale_factor=2, mode="nearest") + \
+        F.conv2d(c0, sd[prefix + "inner2.weight"], sd[prefix + "inner2.bias"])
+    out["stage3"] = F.conv2d(top, sd[prefix + "out3.weight"], None, 1, 1)
+    return out
+
+
+def cas_cost_reg_net(x, sd, prefix):
+    """[B,Cin,D,H,W] -> [B,1,D,H,W]  (CasMVSNet/models/module.py:407-438; prob has no bias)."""
+    def layer(name, t, stride, up=False):
+        w = sd[f"{prefix}{name}.conv.weight"]
+        t = F.conv_transpose3d(t, w, None, 2, 1, 1) if up else F.conv3d(t, w, None, stride, 1)
+        return F.relu(_bn_eval(t, sd, f"{prefix}{name}.bn"))
+
+    c0 = layer("conv0", x, 1)
+    c2 = layer("conv2", layer("conv1", c0, 2), 1)
+    c4 = layer("conv4", layer("conv3", c2, 2), 1)
+    t = layer("conv6", layer("conv5", c4, 2), 1)
+    t = c4 + layer("conv7", t, 2, True)
+    t = c2 + layer("conv9", t, 2, True)
+    t = c0 + layer("conv11", t, 2, True)
+    return F.conv3d(t, sd[prefix + "prob.weight"], None, 1, 1)
+
+
+def cas_hypotheses(cur, ndepth, interval, H, W):
+    """module.py:485-524: [B,D0] sweep end points or [B,H,W] previous depth -> [B,ndepth,H,W]."""
+    ramp = torch.arange(ndepth, dtype=cur.dtype, device=cur.device)
+    if cur.dim() == 2:
+        lo, hi = cur[:, 0], cur[:, -1]
+        step = (hi - lo) / (ndepth - 1)
+        d = lo[:, None] + ramp[None] * step[:, None]
+        return d[:, :, None, None].repeat(1, 1, H, W)
+    lo, hi = cur - ndepth / 2 * interval, cur + ndepth / 2 * interval
+    step = (hi - lo) / (ndepth - 1)
+    return lo[:, None] + ramp.reshape(1, -1, 1, 1) * step[:, None]
+
+
+def cascade_forward(imgs, projs, depth_values, sd, ndepths=(48, 32, 8), ratios=(4, 2, 1), stages=None):
+    """imgs [B,V,3,H,W]; projs {"stageK": [B,V,2,4,4]}; depth_values [B,D] -> dict like
+    CascadeMVSNet.forward (cas_mvsnet.py:108-164)."""
+    import time
+    B, V, _, H, W = imgs.shape
+    interval = (float(depth_values[0, -1]) - float(depth_values[0, 0])) / depth_values.size(1)
+    t0 = time.perf_counter()
+    feats = [cas_feature_net(imgs[:, v], sd) for v in range(V)]
+    if stages is not None:
+        stages["feature"] = time.perf_counter() - t0
+    out, depth = {}, None
+    for s, scale in enumerate((4, 2, 1)):
+        t0 = time.perf_counter()
+        key = f"stage{s + 1}"
+        cur = depth_values if depth is None else F.interpolate(
+            depth.unsqueeze(1), [H, W], mode="bilinear", align_corners=False).squeeze(1)
+        hyp = cas_hypotheses(cur, ndepths[s], ratios[s] * interval, H, W)
+        hyp = F.interpolate(hyp.unsqueeze(1), [ndepths[s], H // scale, W // scale], mode="trilinear",
+                            align_corners=False).squeeze(1)
+        P = projs[key]
+        full = P[:, :, 0].clone()
+        full[:, :, :3, :4] = torch.matmul(P[:, :, 1, :3, :3], P[:, :, 0, :3, :4])
+        var = variance_volume([f[key] for f in feats], [full[:, v] for v in range(V)], hyp)
+        cost = cas_cost_reg_net(var, sd, f"cost_regularization.{s}.").squeeze(1)
+        depth, conf, _ = regress(cost, hyp, clamp_idx=True)
+        out[key] = {"depth": depth, "photometric_confidence": conf}
+        out.update(out[key])
+        if stages is not None:
+            stages[key] = time.perf_counter() - t0
+    return out
 
 
 def masked_smooth_l1(est, gt, mask):

@@ -575,6 +575,62 @@ def test_cas_depthnet_stage_golden(dev):
     np.testing.assert_allclose(out["photometric_confidence"].cpu().numpy(), g["out_conf"], atol=1e-5)
 
 
+def _cascade_case(dev):
+    from mvs_amd import synth
+    from mvs_amd.models.cas_mvsnet import CascadeMVSNet
+    g = load_golden("g9_cas_cascade")
+    net = CascadeMVSNet()
+    net.load_state_dict(synth.cas_random_state_dict(int(g["seed"])))
+    net.eval().to(dev)
+    proj = {k: G(g["proj_" + k], dev) for k in ("stage1", "stage2", "stage3")}
+    return g, net, proj
+
+
+def test_cascade_stages_golden(dev):
+    """Each stage of the 3-stage CasMVSNet forward in isolation: hypotheses built around the
+    GOLDEN previous-stage depth (so a stage's error is not the previous stage's), FPN
+    features from PyTorch-ROCm, DepthNet on the HIP kernels; vs the reference's
+    CascadeMVSNet CPU forward (cas_mvsnet.py:108-164)."""
+    import torch.nn.functional as F
+    from mvs_amd.models import cascade
+    from mvs_amd.models.cas_mvsnet import depth_hypotheses
+    g, net, proj = _cascade_case(dev)
+    imgs, dv = G(g["imgs"], dev), G(g["depth_values"], dev)
+    B, V, _, H, W = imgs.shape
+    interval = (float(dv[0, -1]) - float(dv[0, 0])) / dv.size(1)
+    with torch.no_grad():
+        feats = [net.feature(imgs[:, v]) for v in range(V)]
+        for s, scale in enumerate((4, 2, 1)):
+            key = f"stage{s + 1}"
+            np.testing.assert_allclose(feats[0][key].cpu().numpy(), g[key + "_feat_ref"], atol=2e-5, rtol=1e-4)
+            if s == 0:
+                cur = dv
+            else:
+                prev = G(g[f"stage{s}_depth"], dev)
+                cur = F.interpolate(prev.unsqueeze(1), [H, W], mode="bilinear", align_corners=False).squeeze(1)
+            hyp = depth_hypotheses(cur, net.ndepths[s], net.depth_interals_ratio[s] * interval, (B, H, W))
+            hyp = F.interpolate(hyp.unsqueeze(1), [net.ndepths[s], H // scale, W // scale], mode="trilinear",
+                                align_corners=False).squeeze(1).contiguous()
+            out = cascade.depthnet_forward([f[key] for f in feats], proj[key], hyp,
+                                           net.cost_regularization[s].hip_params())
+            err = np.abs(out["depth"].cpu().numpy() - g[key + "_depth"])
+            print(key, "max depth err", err.max(), "median", np.median(err))
+            assert err.max() < DEPTH_TOL_MM, (key, err.max())
+            np.testing.assert_allclose(out["photometric_confidence"].cpu().numpy(), g[key + "_conf"], atol=2e-4)
+
+
+def test_cascade_end_to_end_golden(dev):
+    """The whole cascade through the reference's model API: final and per-stage depth maps."""
+    g, net, proj = _cascade_case(dev)
+    with torch.no_grad():
+        out = net(G(g["imgs"], dev), proj, G(g["depth_values"], dev))
+    assert out["depth"] is out["stage3"]["depth"]
+    for key in ("stage1", "stage2", "stage3"):
+        err = np.abs(out[key]["depth"].cpu().numpy() - g[key + "_depth"])
+        print(key, "max depth err", err.max(), "median", np.median(err))
+        assert err.max() < DEPTH_TOL_MM, (key, err.max())
+
+
 @pytest.mark.parametrize("cfg", [(32, 8, False, 1), (8, 16, False, 2), (16, 16, False, 1),
                                  (64, 32, True, 2), (16, 8, True, 2), (8, 1, False, 1)])
 def test_conv3d_autograd_vs_torch(dev, cfg):

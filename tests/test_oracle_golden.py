@@ -154,3 +154,22 @@ def test_train_step_restatement(weights):
             ref = g[k]
             got = sd[k[6:]].grad.numpy()
             np.testing.assert_allclose(got, ref, atol=1e-4 * max(1.0, np.abs(ref).max()))
+
+
+def test_torch_ref_cascade_matches_reference():
+    """oracle/torch_ref.cascade_forward (3-stage CasMVSNet) vs the imported reference's
+    CascadeMVSNet forward (golden g9, made by tests/golden/make_golden_cas.py)."""
+    from mvs_amd import synth
+    from oracle import torch_ref
+    g = load_golden("g9_cas_cascade")
+    sd = synth.cas_random_state_dict(int(g["seed"]))
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    with torch.no_grad():
+        feat = torch_ref.cas_feature_net(T(g["imgs"][:, 0]), sd)
+        for k in ("stage1", "stage2", "stage3"):
+            np.testing.assert_allclose(feat[k].numpy(), g[k + "_feat_ref"], atol=1e-5, rtol=1e-5)
+        out = torch_ref.cascade_forward(T(g["imgs"]), {k: T(g["proj_" + k]) for k in ("stage1", "stage2", "stage3")},
+                                        T(g["depth_values"]), sd)
+    for k in ("stage1", "stage2", "stage3"):
+        assert np.abs(out[k]["depth"].numpy() - g[k + "_depth"]).max() < 1e-3, k
+        np.testing.assert_allclose(out[k]["photometric_confidence"].numpy(), g[k + "_conf"], atol=1e-4)
