@@ -172,10 +172,22 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    dbg = os.environ.get("MVS_BENCH_DEBUG") == "1"   # host-side issue time per step, allocator activity
+    if dbg:
+        ms0, issue = torch.cuda.memory_stats(), []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+        if dbg:
+            issue.append(time.perf_counter())
     torch.cuda.synchronize()
+    if dbg:
+        ms1 = torch.cuda.memory_stats()
+        print("[debug] issue ms/step:", [round((b - a) * 1e3, 2) for a, b in zip([t0] + issue, issue)],
+              "device_alloc", ms1["num_device_alloc"] - ms0["num_device_alloc"],
+              "device_free", ms1["num_device_free"] - ms0["num_device_free"],
+              "reserved GB", round(ms0["reserved_bytes.all.current"] / 2**30, 2),
+              round(ms1["reserved_bytes.all.current"] / 2**30, 2), file=sys.stderr)
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0

@@ -24,6 +24,7 @@
 // the 16 MFMA rows carry (8 channels) x (2 x-shifts) against a 4-tap x window,
 // i.e. 75 % useful MFMA work instead of the 50 % a zero-padded M tile gives --
 // this is conv0, 68 % of CostRegNet's FLOPs.
+#include <type_traits>
 #include "mvs_common.h"
 
 #include <cstdlib>
@@ -74,6 +75,7 @@ struct ConvArgs {
     int tiles_x, tiles_y, tiles_z;
     int relu;
     int in_c8;   // input is [B,D,H,C/8,W,8] (8-channel blocked) instead of [B,D,H,W,C]
+    int ystrip;  // tile order: 0 = x, y, z; n > 0 = y within strips of n tile rows, then z, then x
 };
 
 // XCD-aware bijective remap: consecutive tiles land on the same XCD (same L2)
@@ -81,6 +83,36 @@ struct ConvArgs {
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// Tile owned by a workgroup.  Tiles that share halo planes should run close together in
+// time on the same XCD so the re-read hits that XCD's 4-MiB L2: with `ystrip` the order is
+// y inside a strip of tile rows (fastest), then z, then x -- the y and z neighbours of a
+// tile are then at most one strip column (a few MiB of input) away instead of a whole
+// z-slab (tens of MiB).
+struct TileIdx { int tx, ty, tz, b; };
+__device__ __forceinline__ TileIdx decode_ordered_tile(const ConvArgs &a, int bid) {
+    TileIdx t;
+    if (a.ystrip <= 0) {
+        t.tx = bid % a.tiles_x; bid /= a.tiles_x;
+        t.ty = bid % a.tiles_y; bid /= a.tiles_y;
+        t.tz = bid % a.tiles_z;
+        t.b = bid / a.tiles_z;
+    } else {
+        const int per_b = a.tiles_x * a.tiles_y * a.tiles_z;
+        t.b = bid / per_b; bid -= t.b * per_b;
+        const int full = a.ystrip * a.tiles_z * a.tiles_x;
+        const int s = bid / full; bid -= s * full;
+        const int y0 = s * a.ystrip;
+        const int hs = min(a.ystrip, a.tiles_y - y0);   // the last strip may be short
+        t.ty = y0 + bid % hs; bid /= hs;
+        t.tz = bid % a.tiles_z;
+        t.tx = bid / a.tiles_z;
+    }
+    return t;
+}
+__device__ __forceinline__ TileIdx decode_tile(const ConvArgs &a, int blk, int nblk) {
+    return decode_ordered_tile(a, xcd_remap(blk, nblk));
 }
 
 // ABL (tuning builds only, selected by env MVS_CONV_ABLATE for the conv0 shape):
@@ -97,14 +129,19 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = lane & 15, kq = lane >> 4;
 
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
-    const int ty = bid % a.tiles_y; bid /= a.tiles_y;
-    const int tz = bid % a.tiles_z;
-    const int b = bid / a.tiles_z;
+    const TileIdx tile = decode_tile(a, blockIdx.x, gridDim.x);
+    const int tx = tile.tx, ty = tile.ty, tz = tile.tz, b = tile.b;
     const int ox0 = tx * Cfg::XOUT, oy0 = ty * TY, oz0 = tz * TZ;
     const int ix0 = (MODE == 1 ? 2 * ox0 : ox0) - 1;
     const int iy0 = oy0 * SZY - 1, iz0 = oz0 * SZY - 1;
+
+    // ABL & 16 (tuning): phase timestamps of wave 0 into the buffer passed as `residual`
+    long long *dbg = nullptr;
+    if constexpr (ABL & 16) {
+        dbg = reinterpret_cast<long long *>(const_cast<float *>(a.residual)) + (int64_t)blockIdx.x * 32;
+        if (tid == 0) dbg[0] = clock64();
+    }
+#define MVS_STAMP(k) do { if constexpr (ABL & 16) { if (tid == 0) dbg[k] = clock64(); } } while (0)
 
     f32x4 acc[RPW][MT];
 #pragma unroll
@@ -145,6 +182,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
         okmask |= ok ? (1u << it) : 0u;
     }
     const int ch_step = a.in_c8 ? a.W * 8 * (CK / 8) : CK;
+    MVS_STAMP(1);
 
 #pragma unroll 1
     for (int ch = 0; ch < Cfg::NCHUNK; ++ch) {
@@ -166,6 +204,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
                 }
         }
         if (ch) __syncthreads();
+        MVS_STAMP(2 + ch * 4);
         // ---- stage the halo tile of CK channels: global -> LDS planes, SB loads in
         // flight per thread per batch (the volume streams from HBM)
         {
@@ -206,7 +245,9 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
                 }
             }
         }
+        MVS_STAMP(3 + ch * 4);
         __syncthreads();
+        MVS_STAMP(4 + ch * 4);
 
         constexpr int KZ_UNROLL = Cfg::PREA ? 3 : 1;
 #pragma unroll KZ_UNROLL
@@ -265,8 +306,9 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
                 }
             }
         }
+        MVS_STAMP(5 + ch * 4);
     }
-
+    {
     // ---- epilogue: BN affine, ReLU, skip add, one 16-byte store per lane
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
@@ -298,13 +340,312 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
                 v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
             }
             const int64_t o = ((((int64_t)b * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * COUT + c0;
-            if (a.residual) {
+            if (a.residual && !(ABL & 16)) {
                 const float4 rs = *reinterpret_cast<const float4 *>(a.residual + o);
                 v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
             }
             *reinterpret_cast<float4 *>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
+    }
+    if constexpr (ABL & 16) {
+        if (tid == 0) {
+            dbg[18] = clock64();
+            unsigned xcc, hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            dbg[19] = ((long long)xcc << 32) | hwid;
+        }
+    }
+#undef MVS_STAMP
+}
+
+// ---------------------------------------------------------------------
+// conv0-class layers (Cout = 8, stride 1, 8-channel-blocked input) as a PERSISTENT,
+// DMA-fed kernel: one 512-thread workgroup per CU walks a list of (4,4,32)-voxel output
+// tiles.  Phase timestamps of the kernel above showed a third of every workgroup's life
+// in its VALU-heavy prologue / staging / epilogue, crawling beside the partner
+// workgroup's MFMA stream (VALU issue on a SIMD is arbitrated by age), so the matrix
+// pipe idled ~30 %.  Here
+//   * the whole layer's A fragments (Cin/8 x 18 KiB) live in LDS for the kernel's
+//     lifetime: no global load is ever waited on inside the MFMA loop;
+//   * the input halo of an 8-channel chunk goes HBM -> LDS with global_load_lds_dwordx4
+//     (no staging VGPRs, no ds_write pass, 5 DMA instructions per thread per chunk) into
+//     the buffer the MFMAs are NOT reading; chunk k+1 (of this tile or the next) is in
+//     flight during the MFMAs of chunk k, and there is one barrier per chunk;
+//   * all 8 waves do both jobs, so the two waves of a SIMD are always in the same phase.
+// LDS image of a chunk: [h = channel half][voxel][4 channels], voxel order (z,y,x') with
+// x de-interleaved as in MODE 2; lane (n,kq) reads channels 2kq, 2kq+1 of voxel n with
+// one ds_read_b64 -- the same channel <-> (k-step, kq) assignment as the kernel above,
+// so the packed weights are shared.
+__device__ const float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};   // source of out-of-volume halo voxels
+
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_byte_addr)
+                 : "memory");
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// One ds_read_b64 at a compile-time offset from a per-lane LDS byte address.  Written
+// as asm so that it STAYS a ds_read_b64 (64-bank rules, two 32-lane groups: conflict-free
+// for the 16-byte voxel stride used below): hipcc merges neighbouring b64 loads into
+// ds_read2_b64, which is serviced under 32-bank rules in 16-lane groups -- a 2-way
+// conflict on this layout that makes the reads, not the MFMAs, set the pace.  The
+// compiler does not see these loads complete: lds_wait<N>() is the matching s_waitcnt.
+template <int OFF>
+__device__ __forceinline__ f32x2 lds_read_b64(unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536 && OFF % 8 == 0, "ds_read_b64 offset field");
+    f32x2 v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+// wait until at most N LDS reads issued after the three tied ones are outstanding
+template <int N>
+__device__ __forceinline__ void lds_wait(f32x2 &a, f32x2 &b, f32x2 &c) {
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N));
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int CIN>
+struct PersistCfg {
+    static constexpr int NCHUNK = CIN / 8, NTAPS = 36;
+    static constexpr int TZ = 4, TY = 4, XOUT = 32;
+    static constexpr int XT = 34, XH = 17, YT = TY + 2, ZT = TZ + 2;
+    static constexpr int NVOX = ZT * YT * XT;                 // 1224
+    static constexpr int PLANE = round_up_c(NVOX, 64);        // 1280 voxels per channel half
+    static constexpr int NDMA = 2 * PLANE / 64;               // wave-instructions per chunk (40)
+    static constexpr int IPW = NDMA / 8;                      // per wave (5)
+    static constexpr int W_FLOATS = NCHUNK * NTAPS * 64 * 2;
+    static constexpr int BUF_FLOATS = 2 * PLANE * 4;
+    static constexpr int LDS_FLOATS = W_FLOATS + 2 * BUF_FLOATS;
+    static_assert(NDMA % 8 == 0, "DMA instructions split evenly over 8 waves");
+    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+};
+
+template <int CIN, int ABL = 0>
+__global__ __launch_bounds__(512) void conv3d_c8_persistent_kernel(ConvArgs a, int ntiles) {
+    using P = PersistCfg<CIN>;
+    constexpr int NTAPS = P::NTAPS, XT = P::XT, XH = P::XH, YT = P::YT, PLANE = P::PLANE;
+    constexpr int IPW = P::IPW;
+    __shared__ __attribute__((aligned(16))) float lds[P::LDS_FLOATS];
+    float *wl = lds;
+    float *buf0 = lds + P::W_FLOATS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kq = lane >> 4;
+    const unsigned lds_base = (unsigned)(uintptr_t)lds;
+
+    // ---- tiles of this workgroup: XCD x (= blockIdx & 7) owns a contiguous range of the
+    // ordered tile list, its workgroups take that range round-robin, so the tiles in
+    // flight on one XCD are neighbours and share halo lines in that XCD's L2
+    int t_cur, t_end, t_step;
+    {
+        const int nb = gridDim.x;
+        if ((nb & 7) == 0) {
+            const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per = nb >> 3;
+            const int lo = (int)((int64_t)ntiles * xcd / 8), hi = (int)((int64_t)ntiles * (xcd + 1) / 8);
+            t_cur = lo + j; t_end = hi; t_step = per;
+        } else {
+            t_cur = blockIdx.x; t_end = ntiles; t_step = nb;
+        }
+    }
+
+    // ---- once: all A fragments -> LDS; tile-independent halo coordinates of this
+    // thread's DMA items (item i of wave w is DMA instruction g = i*8 + w of the chunk:
+    // channel half h = g / (PLANE/64), voxels (g % (PLANE/64))*64 + lane)
+    {
+        constexpr int NWI = P::W_FLOATS / 4 / 64;   // 16-byte granules / 64 lanes
+        for (int i = wv; i < NWI; i += 8)
+            glds16(a.wpk + ((size_t)i * 64 + lane) * 4, lds_base + (unsigned)i * 1024u);
+    }
+    int loc[IPW];        // lx | ly << 8 | lz << 16 | h << 24 | valid << 31 (as sign)
+    unsigned dst[IPW];   // LDS byte offset of the instruction inside a chunk buffer
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+        const int g = i * 8 + wv;
+        const int h = g / (PLANE / 64), vb = g % (PLANE / 64);
+        const int v = vb * 64 + lane;
+        const int vc = min(v, P::NVOX - 1);
+        const int lxp = vc % XT, t2 = vc / XT;
+        const int ly = t2 % YT, lz = t2 / YT;
+        const int lx = lxp < XH ? 2 * lxp : 2 * (lxp - XH) + 1;
+        loc[i] = lx | (ly << 8) | (lz << 16) | (h << 24) | (v < P::NVOX ? 0 : (int)0x80000000);
+        dst[i] = (unsigned)((h * PLANE + vb * 64) * 16);
+    }
+
+    const int64_t plane_in = (int64_t)a.H * a.W * CIN;   // floats per z-plane ([D,H,C/8,W,8])
+    const int row_in = a.W * CIN;                        // floats per (z,y) row
+    const int ch_step = a.W * 8;                         // floats between 8-channel blocks of a row
+
+    // geometry of one tile: source pointer of every DMA item for chunk 0, and its
+    // per-chunk step (0 for halo voxels outside the volume: they read the zero page)
+    const float *src[IPW];
+    int step[IPW];
+    TileIdx tile;
+    auto geometry = [&](int t) {
+        tile = decode_ordered_tile(a, t);
+        const int ix0 = tile.tx * P::XOUT - 1, iy0 = tile.ty * P::TY - 1, iz0 = tile.tz * P::TZ - 1;
+        const float *in_b = a.in + (int64_t)tile.b * a.D * plane_in;
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const int gx = ix0 + (loc[i] & 255), gy = iy0 + ((loc[i] >> 8) & 255);
+            const int gz = iz0 + ((loc[i] >> 16) & 255), h = (loc[i] >> 24) & 1;
+            const bool ok = loc[i] >= 0 && (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H &&
+                            (unsigned)gz < (unsigned)a.D;
+            const float *p = in_b + (int64_t)gz * plane_in + (int64_t)gy * row_in + gx * 8 + h * 4;
+            src[i] = ok ? p : g_zero_page;
+            step[i] = ok ? ch_step : 0;
+        }
+    };
+    auto issue = [&](int ch, int parity) {
+        const unsigned base = lds_base + (unsigned)(P::W_FLOATS + parity * P::BUF_FLOATS) * 4u;
+#pragma unroll
+        for (int i = 0; i < IPW; ++i)
+            glds16(src[i] + (int64_t)ch * step[i], base + dst[i]);
+    };
+
+    // BatchNorm(eval) affine of this lane's 4 output channels
+    const int c0 = (kq & 1) * 4;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.scale) sc = *reinterpret_cast<const float4 *>(a.scale + c0);
+    if (a.shift) sh = *reinterpret_cast<const float4 *>(a.shift + c0);
+
+    // per-lane LDS read bases (floats): B = plane kq>>1, voxel n, channel pair kq&1; rows 2w, 2w+1
+    const int rdB = ((kq >> 1) * PLANE + n) * 4 + (kq & 1) * 2;
+    int rowoff[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int row = wv * 2 + r;
+        rowoff[r] = ((row / P::TY) * YT + (row % P::TY)) * XT * 4;
+    }
+    const int rdA = lane * 2;
+
+    f32x4 acc[2];
+    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ABL & 16 (tuning): cycles of wave 0 per phase, summed over the tiles of this
+    // workgroup, into the buffer passed as `residual`: [wait, barrier, issue, mfma, epilogue]
+    long long tsum[6] = {0, 0, 0, 0, 0, 0};
+    long long tprev = 0;
+    if constexpr (ABL & 16) tprev = clock64();
+#define MVS_LAP(k) do { if constexpr (ABL & 16) { const long long tn = clock64(); tsum[k] += tn - tprev; tprev = tn; } } while (0)
+
+    int parity = 0;
+    if (t_cur < t_end) {
+        geometry(t_cur);
+        issue(0, 0);
+    }
+    while (t_cur < t_end) {
+        const TileIdx cur = tile;
+        const int t_next = t_cur + t_step;
+#pragma unroll 1
+        for (int ch = 0; ch < P::NCHUNK; ++ch) {
+            // this chunk's DMA (issued one phase ago) has landed for every wave, and
+            // every wave is done reading the other buffer
+            MVS_LAP(4);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            MVS_LAP(0);
+            __syncthreads();
+            MVS_LAP(1);
+            // next chunk (of this tile, or the first of the next one) -> the other buffer.
+            // (Issuing it a few taps into the MFMA stream, deferring the stores of a tile
+            // into the next tile's stream, or hoisting the geometry were each measured:
+            // no gain -- a wave's VALU/DMA issue crawls beside its partner's MFMAs.)
+            if (ch + 1 < P::NCHUNK) {
+                issue(ch + 1, parity ^ 1);
+            } else if (t_next < t_end) {
+                geometry(t_next);
+                issue(0, parity ^ 1);
+            }
+            MVS_LAP(2);
+            // ---- MFMA stream of the chunk: per tap one A read (feeds 4 MFMAs) and one B read
+            // per row (2 MFMAs each), software-pipelined PD taps ahead through PD+1
+            // register slots; LDS returns in order, so "tap t has landed" is lgkmcnt <=
+            // 3 x (taps issued after it)
+            const unsigned aA = lds_base + (unsigned)(ch * (NTAPS * 64 * 2) + rdA) * 4u;
+            const unsigned aB0 = lds_base + (unsigned)(P::W_FLOATS + parity * P::BUF_FLOATS + rdB + rowoff[0]) * 4u;
+            const unsigned aB1 = lds_base + (unsigned)(P::W_FLOATS + parity * P::BUF_FLOATS + rdB + rowoff[1]) * 4u;
+            constexpr int PD = 3;
+            f32x2 fa[PD + 1], fb0[PD + 1], fb1[PD + 1];
+            auto fetch = [&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr int kz = t / 12, ky = (t / 4) % 3, kx = t % 4;
+                constexpr int boff = ((kz * YT + ky) * XT + (kx & 1) * XH + (kx >> 1)) * 16;
+                fa[t % (PD + 1)] = lds_read_b64<t * 512>(aA);
+                fb0[t % (PD + 1)] = lds_read_b64<boff>(aB0);
+                fb1[t % (PD + 1)] = lds_read_b64<boff>(aB1);
+            };
+            static_for<0, PD>(fetch);
+            static_for<0, NTAPS>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr int sl = t % (PD + 1);
+                if constexpr (t + PD < NTAPS) fetch(std::integral_constant<int, t + PD>{});
+                constexpr int newer = (t + PD < NTAPS ? PD : NTAPS - 1 - t);
+                lds_wait<3 * newer>(fa[sl], fb0[sl], fb1[sl]);
+                if constexpr (ABL & 8) {
+                    asm volatile("" ::"v"(fa[sl]), "v"(fb0[sl]), "v"(fb1[sl]));
+                } else {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl].x, fb0[sl].x, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl].x, fb1[sl].x, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl].y, fb0[sl].y, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl].y, fb1[sl].y, acc[1], 0, 0, 0);
+                }
+            });
+            parity ^= 1;
+            MVS_LAP(3);
+        }
+        // ---- epilogue of `cur`: BN affine, ReLU, one 16-byte store per lane and row
+        if constexpr (ABL & 16) {
+            asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));
+            asm volatile("s_nop 0" ::: "memory");
+            MVS_LAP(5);
+        }
+        {
+            const int ox = cur.tx * P::XOUT + 2 * n + (kq >> 1);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int row = wv * 2 + r;
+                const int oz = cur.tz * P::TZ + row / P::TY, oy = cur.ty * P::TY + row % P::TY;
+                f32x4 v = acc[r];
+                acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo) continue;
+                v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
+                v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+                if (a.relu) {
+                    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+                    v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                }
+                const int64_t o = ((((int64_t)cur.b * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * 8 + c0;
+                if (a.residual && !(ABL & 16)) {
+                    const float4 rs = *reinterpret_cast<const float4 *>(a.residual + o);
+                    v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
+                }
+                *reinterpret_cast<float4 *>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        t_cur = t_next;
+    }
+    if constexpr (ABL & 16) {
+        MVS_LAP(4);
+        if (tid == 0) {
+            long long *dbg = reinterpret_cast<long long *>(const_cast<float *>(a.residual)) + (int64_t)blockIdx.x * 8;
+            for (int k = 0; k < 6; ++k) dbg[k] = tsum[k];
+        }
+    }
+#undef MVS_LAP
 }
 
 // ---------------------------------------------------------------------
@@ -330,11 +671,8 @@ __global__ __launch_bounds__(512) void conv3d_mfma_db_kernel(ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = lane & 15, kq = lane >> 4;
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
-    const int ty = bid % a.tiles_y; bid /= a.tiles_y;
-    const int tz = bid % a.tiles_z;
-    const int b = bid / a.tiles_z;
+    const TileIdx tile = decode_tile(a, blockIdx.x, gridDim.x);
+    const int tx = tile.tx, ty = tile.ty, tz = tile.tz, b = tile.b;
     const int ox0 = tx * Cfg::XOUT, oy0 = ty * TY, oz0 = tz * TZ;
     const int ix0 = (MODE == 1 ? 2 * ox0 : ox0) - 1;
     const int iy0 = oy0 * SZY - 1, iz0 = oz0 * SZY - 1;
@@ -543,11 +881,8 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_kernel(ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = lane & 15, kq = lane >> 4;
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
-    const int ty = bid % a.tiles_y; bid /= a.tiles_y;
-    const int tz = bid % a.tiles_z;
-    const int b = bid / a.tiles_z;
+    const TileIdx tile = decode_tile(a, blockIdx.x, gridDim.x);
+    const int tx = tile.tx, ty = tile.ty, tz = tile.tz, b = tile.b;
     const int jx0 = tx * 16, jy0 = ty * TY, jz0 = tz * TZ;
 
     f32x4 acc[NCLS][RPW][MT];
@@ -745,11 +1080,8 @@ __global__ __launch_bounds__(256) void conv3d_cout1_kernel(ConvArgs a, const flo
     constexpr int PLANE = round_up_c(NVOX, 16);
     __shared__ __attribute__((aligned(16))) float lds[CQ * PLANE * 4];
     const int tid = threadIdx.x, lx = tid & 31, ly = tid >> 5;
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
-    const int ty = bid % a.tiles_y; bid /= a.tiles_y;
-    const int tz = bid % a.tiles_z;
-    const int b = bid / a.tiles_z;
+    const TileIdx tile = decode_tile(a, blockIdx.x, gridDim.x);
+    const int tx = tile.tx, ty = tile.ty, tz = tile.tz, b = tile.b;
     const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
     const float *in_b = a.in + (int64_t)b * a.D * a.H * a.W * CIN;
     {
@@ -1003,6 +1335,10 @@ int conv3d_mfma_launch(const float *in, const float *packed, const float *scale,
     a.B = B; a.D = D; a.H = H; a.W = W;
     a.relu = relu;
     a.in_c8 = in_c8;
+    {
+        const char *ys = getenv("MVS_CONV_YSTRIP");   // tuning; default: strips of 4 tile rows
+        a.ystrip = ys ? atoi(ys) : 4;
+    }
 
     if (in_c8 && (transposed || is_cout1(transposed, Cin, Cout, stride) || Cin % 8)) {
         set_error("mvs_conv3d_f32: the 8-channel-blocked input layout is only taken by the conv kernels");
@@ -1041,6 +1377,41 @@ int conv3d_mfma_launch(const float *in, const float *packed, const float *scale,
         set_error("mvs_conv3d_f32(mfma): bad grid");
         return MVS_EINVAL;
     }
+    // conv0-class layers on the 8-channel-blocked volume: persistent DMA-fed kernel
+    // (MVS_CONV0_VARIANT=10 selects the per-tile kernel instead: tuning / A-B testing)
+    if (!transposed && Cout == 8 && stride == 1 && in_c8 && (Cin == 32 || Cin == 16 || Cin == 8)) {
+        const char *var = getenv("MVS_CONV0_VARIANT");
+        if (!var || atoi(var) == 0 || atoi(var) >= 20) {
+            static int n_cu = 0;
+            if (n_cu == 0) {
+                int dev = 0, cu = 0;
+                if (hipGetDevice(&dev) != hipSuccess ||
+                    hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0)
+                    cu = 256;
+                n_cu = cu;
+            }
+            a.tiles_x = (a.Wo + 31) / 32; a.tiles_y = (a.Ho + 3) / 4; a.tiles_z = (a.Do + 3) / 4;
+            const int64_t nt = (int64_t)B * a.tiles_x * a.tiles_y * a.tiles_z;
+            if (nt <= 0 || nt > 0x7fffffffLL) return MVS_EINVAL;
+            if (!getenv("MVS_CONV_YSTRIP")) a.ystrip = 8;
+            const int grid = (int)(nt < n_cu ? nt : n_cu);
+            const int v = var ? atoi(var) : 0;
+            if (Cin == 32) {
+                if (v == 28)
+                    hipLaunchKernelGGL((conv3d_c8_persistent_kernel<32, 8>), dim3(grid), dim3(512), 0, st, a, (int)nt);
+                else if (v == 36)
+                    hipLaunchKernelGGL((conv3d_c8_persistent_kernel<32, 16>), dim3(grid), dim3(512), 0, st, a, (int)nt);
+
+                else
+                    hipLaunchKernelGGL((conv3d_c8_persistent_kernel<32>), dim3(grid), dim3(512), 0, st, a, (int)nt);
+            } else if (Cin == 16) {
+                hipLaunchKernelGGL((conv3d_c8_persistent_kernel<16>), dim3(grid), dim3(512), 0, st, a, (int)nt);
+            } else {
+                hipLaunchKernelGGL((conv3d_c8_persistent_kernel<8>), dim3(grid), dim3(512), 0, st, a, (int)nt);
+            }
+            return check_launch("mvs_conv3d_f32(mfma, persistent)");
+        }
+    }
     void (*kern)(ConvArgs) = ci.kernel;
     int threads = 256;
     if (!transposed && Cin == 32 && Cout == 8 && stride == 1) {   // tuning hook, conv0 only
@@ -1058,6 +1429,8 @@ int conv3d_mfma_launch(const float *in, const float *packed, const float *scale,
             case 12: kern = conv3d_mfma_kernel<C0, 12>; break;
             case 14: kern = conv3d_mfma_kernel<C0, 14>; break;
             case 15: kern = conv3d_mfma_kernel<C0, 15>; break;
+            case 16: kern = conv3d_mfma_kernel<ConvCfg<32, 8, 2, 8, 4, 8, 16, 0>, 16>; break;
+            case 23: kern = conv3d_mfma_kernel<ConvCfg<32, 8, 2, 8, 4, 8, 16, 0>, 23>; break;
             default: break;
         }
         const char *var = getenv("MVS_CONV0_VARIANT");   // tuning: staging depth / A preload

@@ -406,10 +406,26 @@ __global__ __launch_bounds__(256, 3) void variance_fwd_lds_kernel(
     __shared__ int s_box[NV][4];                                   // xmin, ymin, xmax, ymax
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int bid = blockIdx.x;
-    const int tx = bid % tiles_x; bid /= tiles_x;
-    const int ty = bid % tiles_y;
-    const int dc = bid / tiles_y;
+    // Block order: depth chunk fastest, and consecutive blocks on the same XCD (blockIdx
+    // round-robins the 8 XCDs).  The footprints of one pixel tile move by a fraction of a
+    // texel per depth plane, so the depth chunks of a tile re-read the same source lines out
+    // of that XCD's L2; ordered by tile first, every depth chunk swept all source maps
+    // (61 MB at config 2, > L2) again.  (ablate & 64: the plain x, y, depth order.)
+    int tx, ty, dc;
+    if (!(ablate & 64)) {
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + ((int)blockIdx.x >> 3);
+        const int ndc = nwg / (tiles_x * tiles_y);
+        dc = bid % ndc; bid /= ndc;
+        tx = bid % tiles_x;
+        ty = bid / tiles_x;
+    } else {
+        int bid = blockIdx.x;
+        tx = bid % tiles_x; bid /= tiles_x;
+        ty = bid % tiles_y;
+        dc = bid / tiles_y;
+    }
     const int b = blockIdx.y;
     const int px = tx * kTileW + (lane & (kTileW - 1)), py = ty * kTileH + lane / kTileW;
     const int d = dc * kTileD + wv;

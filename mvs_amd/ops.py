@@ -113,37 +113,128 @@ def rot_trans_all(proj_matrices, where="host", device=None):
 _side_streams = {}
 
 
+def _side_stream(dev):
+    key = (dev.type, dev.index)
+    side = _side_streams.get(key)
+    if side is None:
+        side = _side_streams[key] = torch.cuda.Stream(device=dev)
+    return side
+
+
+def _rot_trans_host_math(host):
+    """[B,V,4,4] CPU fp32 -> [V-1,B,12]: the reference's own CPU ops (module.py:63-65)."""
+    inv_ref = torch.inverse(host[:, 0])
+    return torch.stack([torch.matmul(host[:, v], inv_ref)[:, :3, :4].reshape(-1, 12)
+                        for v in range(1, host.shape[1])]).contiguous()
+
+
+class _HostHop:
+    """Stream-ordered host hop: D2H -> CPU function -> H2D enqueued on a side stream with
+    hipLaunchHostFunc, so the launching thread never blocks on the GPU (it may run many
+    reference views ahead; a blocking hop ties it to one, and every host hiccup then
+    shows up as GPU idle time).  One instance per (device, shape); the side stream
+    serialises the uses of its pinned buffers."""
+    _hip = None
+    _instances = {}
+
+    @classmethod
+    def hip(cls):
+        if cls._hip is None:
+            import ctypes
+            path = None
+            with open("/proc/self/maps") as f:
+                for line in f:
+                    if "libamdhip64" in line:
+                        path = line.split()[-1]
+                        break
+            lib = ctypes.CDLL(path) if path else None   # the runtime torch already mapped
+            if lib is None or not hasattr(lib, "hipLaunchHostFunc"):
+                cls._hip = False
+            else:
+                lib.hipLaunchHostFunc.restype = ctypes.c_int
+                lib.hipLaunchHostFunc.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+                cls._hip = lib
+        return cls._hip
+
+    def __init__(self, shape_in, shape_out, fn):
+        import ctypes
+        self.pin_in = torch.empty(shape_in, dtype=torch.float32).pin_memory()
+        self.pin_out = torch.empty(shape_out, dtype=torch.float32).pin_memory()
+        self.error = None
+
+        def _cb(_):
+            try:
+                with torch.no_grad():
+                    self.pin_out.copy_(fn(self.pin_in))
+            except BaseException as e:   # cannot propagate out of a runtime thread
+                self.error = e
+        self._cb = ctypes.CFUNCTYPE(None, ctypes.c_void_p)(_cb)   # keep alive
+
+    @classmethod
+    def get(cls, dev, shape_in, shape_out, fn):
+        key = (dev.type, dev.index, tuple(shape_in), fn)
+        inst = cls._instances.get(key)
+        if inst is None:
+            inst = cls._instances[key] = cls(shape_in, shape_out, fn)
+        return inst
+
+    def enqueue(self, src, side):
+        """On `side` (current stream = side): src (device) -> fn on the host -> new device tensor."""
+        import ctypes
+        if self.error is not None:
+            e, self.error = self.error, None
+            raise MvsHipError(f"host hop failed: {e!r}")
+        self.pin_in.copy_(src, non_blocking=True)
+        rc = self.hip().hipLaunchHostFunc(ctypes.c_void_p(side.cuda_stream),
+                                          ctypes.cast(self._cb, ctypes.c_void_p), None)
+        if rc != 0:
+            raise MvsHipError(f"hipLaunchHostFunc failed (rc={rc})")
+        out = torch.empty(self.pin_out.shape, dtype=torch.float32, device=src.device)
+        out.copy_(self.pin_out, non_blocking=True)
+        return out
+
+
 class HostRotTrans:
-    """rot_trans_all(where="host") split in two so the host hop overlaps GPU work:
+    """rot_trans_all(where="host") as a stream-ordered job that overlaps GPU work:
 
         job = HostRotTrans(proj_matrices)      # marks "inputs ready" on the current stream
         ... launch kernels that do not need the result (FeatureNet) ...
-        rts = job.result()                     # D2H on a side stream, CPU 4x4 algebra, H2D
+        rts = job.result()                     # current stream waits for the hop's upload
 
-    The side stream waits only for the event recorded at construction, so the copy does
-    not queue behind the kernels launched in between and the GPU never idles on the hop.
-    Values are bit-identical to rot_trans_all."""
+    The hop (D2H, the reference's CPU 4x4 algebra, H2D) is enqueued on a side stream that
+    waits only for the event recorded at construction, so it does not queue behind the
+    kernels launched in between, and -- with hipLaunchHostFunc -- the launching thread
+    never waits for the GPU.  blocking=True (or a runtime without hipLaunchHostFunc) does
+    the hop synchronously in result().  Values are bit-identical to rot_trans_all."""
 
-    def __init__(self, proj_matrices):
+    def __init__(self, proj_matrices, blocking=False):
         self.P = proj_matrices.detach()
         self.dev = proj_matrices.device
-        self.ev = torch.cuda.Event()
-        self.ev.record()
+        ev = torch.cuda.Event()
+        ev.record()
+        side = _side_stream(self.dev)
+        side.wait_event(ev)
+        self.out = self.done = None
+        if not blocking and _HostHop.hip():
+            B, V = self.P.shape[0], self.P.shape[1]
+            hop = _HostHop.get(self.dev, (B, V, 4, 4), (V - 1, B, 12), _rot_trans_host_math)
+            with torch.no_grad(), torch.cuda.stream(side):
+                self.out = hop.enqueue(self.P.float(), side)
+                self.done = torch.cuda.Event()
+                self.done.record(side)
 
     def result(self):
-        key = (self.dev.type, self.dev.index)
-        side = _side_streams.get(key)
-        if side is None:
-            side = _side_streams[key] = torch.cuda.Stream(device=self.dev)
+        if self.out is not None:
+            cur = torch.cuda.current_stream(self.dev)
+            cur.wait_event(self.done)
+            self.out.record_stream(cur)   # allocated on the side stream, consumed here
+            return self.out
+        side = _side_stream(self.dev)
         with torch.no_grad():
-            side.wait_event(self.ev)
             with torch.cuda.stream(side):
                 host = self.P.float().to("cpu", non_blocking=True)
             side.synchronize()
-            inv_ref = torch.inverse(host[:, 0])
-            out = torch.stack([torch.matmul(host[:, v], inv_ref)[:, :3, :4].reshape(-1, 12)
-                               for v in range(1, host.shape[1])])
-            return out.contiguous().to(self.dev, non_blocking=True)
+            return _rot_trans_host_math(host).to(self.dev, non_blocking=True)
 
 
 def _depth_mode(depth_values):
