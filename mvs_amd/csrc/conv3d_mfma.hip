@@ -380,15 +380,6 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
 // so the packed weights are shared.
 __device__ const float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};   // source of out-of-volume halo voxels
 
-__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_byte_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_byte_addr)
-                 : "memory");
-}
-
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // One ds_read_b64 at a compile-time offset from a per-lane LDS byte address.  Written
@@ -1077,48 +1068,49 @@ template <int CIN>
 __global__ __launch_bounds__(256) void conv3d_cout1_kernel(ConvArgs a, const float *__restrict__ w) {
     constexpr int CQ = CIN / 4, TX = 32, TY = 8, TZ = 4;   // (TZ = 2 measured slower: 0.57 vs 0.46 ms)
     constexpr int XT = TX + 2, YT = TY + 2, ZT = TZ + 2, NVOX = ZT * YT * XT;
-    constexpr int PLANE = round_up_c(NVOX, 16);
+    constexpr int PLANE = round_up_c(NVOX, 64);            // whole 64-lane DMA instructions
     __shared__ __attribute__((aligned(16))) float lds[CQ * PLANE * 4];
+    __shared__ __attribute__((aligned(16))) float wl[27 * CIN];
     const int tid = threadIdx.x, lx = tid & 31, ly = tid >> 5;
     const TileIdx tile = decode_tile(a, blockIdx.x, gridDim.x);
     const int tx = tile.tx, ty = tile.ty, tz = tile.tz, b = tile.b;
     const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
     const float *in_b = a.in + (int64_t)b * a.D * a.H * a.W * CIN;
     {
-        constexpr int NIT = (CQ * NVOX + 255) / 256;
-        constexpr int SB = 8;
-#pragma unroll 1
-        for (int it0 = 0; it0 < NIT; it0 += SB) {
-            float4 stg[SB];
-            int dsto[SB];
+        // halo tile HBM -> LDS by DMA, planes [q][voxel][4 channels]: instruction i of wave
+        // w covers voxels (i*4 + w)*64 + lane of every channel quad q; out-of-volume
+        // voxels (and the plane's tail) read the zero page
+        const int lane = tid & 63;
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const unsigned lds_base = (unsigned)(uintptr_t)lds;
+        constexpr int NI = PLANE / 64 / 4;
 #pragma unroll
-            for (int j = 0; j < SB; ++j) {
-                const int e = tid + (it0 + j) * 256;
-                const int ec = min(e, CQ * NVOX - 1);
-                const int q = ec % CQ, v = ec / CQ;
-                const int vx = v % XT, t2 = v / XT, vy = t2 % YT, vz = t2 / YT;
-                const int gx = x0 + vx - 1, gy = y0 + vy - 1, gz = z0 + vz - 1;
-                const bool ok = gx >= 0 && gx < a.W && gy >= 0 && gy < a.H && gz >= 0 && gz < a.D;
-                const int cx = min(max(gx, 0), a.W - 1), cy = min(max(gy, 0), a.H - 1);
-                const int cz = min(max(gz, 0), a.D - 1);
-                float4 val = *reinterpret_cast<const float4 *>(
-                    in_b + (((int64_t)cz * a.H + cy) * a.W + cx) * CIN + q * 4);
-                val.x = ok ? val.x : 0.f; val.y = ok ? val.y : 0.f;
-                val.z = ok ? val.z : 0.f; val.w = ok ? val.w : 0.f;
-                stg[j] = val;
-                dsto[j] = (e < CQ * NVOX && it0 + j < NIT) ? (q * PLANE + v) * 4 : -1;
-            }
+        for (int i = 0; i < NI; ++i) {
+            const int vb = i * 4 + wv;
+            const int v = vb * 64 + lane;
+            const int vc = min(v, NVOX - 1);
+            const int vx = vc % XT, t2 = vc / XT, vy = t2 % YT, vz = t2 / YT;
+            const int gx = x0 + vx - 1, gy = y0 + vy - 1, gz = z0 + vz - 1;
+            const bool ok = v < NVOX && (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H &&
+                            (unsigned)gz < (unsigned)a.D;
+            const float *p = in_b + (((int64_t)gz * a.H + gy) * a.W + gx) * CIN;
 #pragma unroll
-            for (int j = 0; j < SB; ++j)
-                if (dsto[j] >= 0) *reinterpret_cast<float4 *>(lds + dsto[j]) = stg[j];
+            for (int q = 0; q < CQ; ++q)
+                glds16(ok ? p + q * 4 : g_zero_page, lds_base + (unsigned)((q * PLANE + vb * 64) * 16));
         }
+        for (int i = tid; i < 27 * CIN; i += 256) {
+            const int kyx = i / (3 * CIN), r = i - kyx * (3 * CIN), kz = r / CIN, ci = r - kz * CIN;
+            wl[i] = w[ci * 27 + kz * 9 + kyx];   // PyTorch layout (1,CIN,3,3,3)
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
     float acc[TZ];
 #pragma unroll
     for (int z = 0; z < TZ; ++z) acc[z] = 0.f;
-    // runtime loop over the 9 (ky,kx) taps keeps only 3*CIN wave-uniform weights
-    // live (SGPRs) at a time; dz, q, z are unrolled with immediate LDS offsets
+    // runtime loop over the 9 (ky,kx) taps; its 3*CIN weights come from LDS as broadcast
+    // reads ([kyx][kz][ci], staged once per block).  Scalar loads per tap stalled the loop:
+    // SMEM returns out of order, so every LDS wait behind them became lgkmcnt(0).
 #pragma unroll 1
     for (int kyx = 0; kyx < 9; ++kyx) {
         const int ky = kyx / 3, kx = kyx - ky * 3;
@@ -1126,7 +1118,11 @@ __global__ __launch_bounds__(256) void conv3d_cout1_kernel(ConvArgs a, const flo
 #pragma unroll
         for (int kz = 0; kz < 3; ++kz)
 #pragma unroll
-            for (int ci = 0; ci < CIN; ++ci) wk[kz][ci] = w[ci * 27 + kz * 9 + kyx];  // (1,CIN,3,3,3)
+            for (int c4 = 0; c4 < CIN / 4; ++c4) {
+                const float4 t = *reinterpret_cast<const float4 *>(wl + (kyx * 3 + kz) * CIN + c4 * 4);
+                wk[kz][c4 * 4 + 0] = t.x; wk[kz][c4 * 4 + 1] = t.y;
+                wk[kz][c4 * 4 + 2] = t.z; wk[kz][c4 * 4 + 3] = t.w;
+            }
         const float *lp = lds + ((ly + ky) * XT + lx + kx) * 4;
 #pragma unroll
         for (int dz = 0; dz < ZT; ++dz)

@@ -96,4 +96,19 @@ __device__ __forceinline__ float blend(const Taps &t, float v00, float v01, floa
     return __fmaf_rn(v11, t.se, __fmaf_rn(v10, t.sw, __fmaf_rn(v01, t.ne, v00 * t.nw)));
 }
 
+#ifdef __HIPCC__
+// LDS-DMA: each lane's 16 bytes at `gsrc` -> LDS byte address `lds_byte_addr` + 16*lane
+// (global_load_lds_dwordx4; the destination base is wave-uniform and travels in M0, which
+// the compiler reserves -- saved and restored inside the one statement).  Honours EXEC.
+// The compiler does not count these: pair with an explicit s_waitcnt vmcnt.
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_byte_addr)
+                 : "memory");
+}
+#endif
+
 }  // namespace mvs

@@ -687,6 +687,315 @@ __global__ __launch_bounds__(256, 3) void variance_fwd_lds_kernel(
     }
 }
 
+// ---------------------------------------------------------------------
+// The same kernel with the footprints moved HBM -> LDS by DMA (global_load_lds_dwordx4):
+// no staging registers (the register-staged form above keeps NV x 3 float4 per thread in
+// flight), no ds_write pass, and the copy for channel group g+1 is issued before group
+// g's variances are formed and stored, so it lands under that work; the first group's
+// copy lands under the per-voxel homography arithmetic.  LDS image of a view: 4 planes
+// [channel quad k][texel][4 floats] -- a DMA instruction fills 64 consecutive texels of a
+// plane, 16 neighbouring texels cover all 64 banks without padding, and the four
+// quads of a tap sit at immediate offsets k * plane.  Arithmetic and results identical
+// to the kernels above.
+// texels per view: 48 KiB in total (3 workgroups per CU; the register budget allows no
+// more), whole 64-lane DMA instructions where that costs little
+__host__ __device__ constexpr int dma_cap(int nv) {
+    const int raw = (48 * 1024) / (nv * 64);
+    return raw >= 256 ? 256 : (raw >= 192 ? 192 : raw);
+}
+
+// taps from the planar LDS image: o?? = texel index of the tap, PL = plane stride (texels)
+template <int PL>
+__device__ __forceinline__ void accumulate_taps_planar(const float *__restrict__ base, int o00,
+                                                       int o01, int o10, int o11, float wnw,
+                                                       float wne, float wsw, float wse,
+                                                       float (&S)[16], float (&Q)[16]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float4 a = *reinterpret_cast<const float4 *>(base + (k * PL + o00) * 4);
+        const float4 bq = *reinterpret_cast<const float4 *>(base + (k * PL + o01) * 4);
+        const float4 c = *reinterpret_cast<const float4 *>(base + (k * PL + o10) * 4);
+        const float4 e = *reinterpret_cast<const float4 *>(base + (k * PL + o11) * 4);
+        const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {bq.x, bq.y, bq.z, bq.w};
+        const float cv[4] = {c.x, c.y, c.z, c.w}, ev[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const float w = __fmaf_rn(ev[cc], wse, __fmaf_rn(cv[cc], wsw,
+                                      __fmaf_rn(bv[cc], wne, av[cc] * wnw)));
+            S[k * 4 + cc] = S[k * 4 + cc] + w;
+            Q[k * 4 + cc] = Q[k * 4 + cc] + w * w;
+        }
+        if (k == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int NV, bool CORNER>
+__global__ __launch_bounds__(256, 3) void variance_fwd_dma_kernel(
+    const float *__restrict__ ref16, const float *__restrict__ srcs16,
+    const float *__restrict__ rt, const float *__restrict__ depth, SweepParams p,
+    int tiles_x, int tiles_y, float *__restrict__ out, int out_c8, int ablate) {
+    constexpr int cap = dma_cap(NV);
+    constexpr int NJ = (cap + 63) / 64;          // DMA instructions per plane
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // NV * 4 * cap * 4 floats
+    __shared__ int s_box[NV][4];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tx, ty, dc;
+    {   // depth chunk fastest, consecutive blocks on one XCD (see the kernel above)
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + ((int)blockIdx.x >> 3);
+        const int ndc = nwg / (tiles_x * tiles_y);
+        dc = bid % ndc; bid /= ndc;
+        tx = bid % tiles_x;
+        ty = bid / tiles_x;
+    }
+    const int b = blockIdx.y;
+    const int px = tx * kTileW + (lane & (kTileW - 1)), py = ty * kTileH + lane / kTileW;
+    const int d = dc * kTileD + wv;
+    const bool live = px < p.W && py < p.H && d < p.D;
+    const int cx = min(px, p.W - 1), cy = min(py, p.H - 1), cd = min(d, p.D - 1);
+    const int plane = p.H * p.W;
+    const int pix = cy * p.W + cx;
+    const float dv = p.depth_mode == 0 ? depth[(int64_t)b * p.D + cd]
+                                       : depth[((int64_t)b * p.D + cd) * plane + pix];
+    const int ngroups = p.C >> 4;
+    const size_t grp_floats = (size_t)plane * 16;
+    const unsigned lds_base = (unsigned)(uintptr_t)lds;
+
+    int bx0[NV], by0[NV], bw[NV], bh[NV];
+    bool staged[NV];
+    // per-view source offsets (floats, inside one 16-channel group) of this lane's texels
+    int soff[NV][NJ];
+    auto plan_dma = [&]() {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int n = bw[v] * bh[v];
+            const unsigned inv = (65536u + bw[v] - 1) / bw[v];   // t / bw for t < 65536 / bw
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int t = min(j * 64 + lane, max(n - 1, 0));
+                const int ly = (int)(((unsigned)t * inv) >> 16), lx = t - ly * bw[v];
+                soff[v][j] = ((by0[v] + ly) * p.W + (bx0[v] + lx)) * 16;
+            }
+        }
+    };
+    // wave w copies channel quad w of every view (4 waves, 4 quads)
+    auto issue_dma = [&](int g) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if (!staged[v] || (ablate & 1)) continue;
+            const float *src = srcs16 + (((size_t)v * p.B + b) * ngroups + g) * grp_floats + wv * 4;
+            const int n = bw[v] * bh[v];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if (j * 64 >= n) continue;                       // wave-uniform
+                if (j * 64 + lane < cap)                         // the last instruction may be partial
+                    glds16(src + soff[v][j],
+                           lds_base + (unsigned)(((v * 4 + wv) * cap + j * 64) * 16));
+            }
+        }
+    };
+
+    if constexpr (CORNER) {
+        const int v0 = lane >> 3, k = lane & 7;
+        const int xlo = tx * kTileW, xhi = min(tx * kTileW + kTileW - 1, p.W - 1);
+        const int ylo = ty * kTileH, yhi = min(ty * kTileH + kTileH - 1, p.H - 1);
+        const int dlo = dc * kTileD, dhi = min(dc * kTileD + kTileD - 1, p.D - 1);
+        const float *r = rt + ((int64_t)min(v0, NV - 1) * p.B + b) * 12;
+        const float cxk = (float)((k & 1) ? xhi : xlo), cyk = (float)((k & 2) ? yhi : ylo);
+        const float dk = depth[(int64_t)b * p.D + ((k & 4) ? dhi : dlo)];
+        float rx, ry, rz, ix, iy;
+        sweep_ray(r, cxk, cyk, rx, ry, rz);
+        sweep_coord(r, rx, ry, rz, dk, p.half_w, p.half_h, p.unn_w, p.unn_h, p.align_corners, ix,
+                    iy);
+        const bool zok = (rz * dk + r[11]) > 1e-6f && fabsf(ix) < 1.0e9f && fabsf(iy) < 1.0e9f;
+        int lo_x = (int)floorf(ix) - 1, hi_x = (int)floorf(ix) + 2;
+        int lo_y = (int)floorf(iy) - 1, hi_y = (int)floorf(iy) + 2;
+        int bad = zok ? 0 : 1;
+#pragma unroll
+        for (int off = 1; off <= 4; off <<= 1) {
+            lo_x = min(lo_x, __shfl_xor(lo_x, off)); hi_x = max(hi_x, __shfl_xor(hi_x, off));
+            lo_y = min(lo_y, __shfl_xor(lo_y, off)); hi_y = max(hi_y, __shfl_xor(hi_y, off));
+            bad |= __shfl_xor(bad, off);
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            int x0 = max(__builtin_amdgcn_readlane(lo_x, v * 8), 0);
+            int x1 = min(__builtin_amdgcn_readlane(hi_x, v * 8), p.W - 1);
+            int y0 = max(__builtin_amdgcn_readlane(lo_y, v * 8), 0);
+            int y1 = min(__builtin_amdgcn_readlane(hi_y, v * 8), p.H - 1);
+            const int vbad = __builtin_amdgcn_readlane(bad, v * 8);
+            if (x1 < x0 || y1 < y0) { x0 = y0 = x1 = y1 = 0; }
+            bx0[v] = x0; by0[v] = y0; bw[v] = x1 - x0 + 1; bh[v] = y1 - y0 + 1;
+            staged[v] = !vbad && bw[v] * bh[v] <= cap;
+        }
+        plan_dma();
+        issue_dma(0);      // lands under phase A
+    } else {
+        if (tid < NV) {
+            s_box[tid][0] = 0x7fffffff; s_box[tid][1] = 0x7fffffff;
+            s_box[tid][2] = -1; s_box[tid][3] = -1;
+        }
+        __syncthreads();
+    }
+
+    // ---- phase A: homography + tap set per source view (registers)
+    float wnw[NV], wne[NV], wsw[NV], wse[NV];
+    int tx0[NV], ty0[NV];
+    bool wave_in[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) wave_in[v] = true;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const float *r = rt + ((int64_t)v * p.B + b) * 12;
+        float rx, ry, rz, ix, iy;
+        sweep_ray(r, (float)cx, (float)cy, rx, ry, rz);
+        sweep_coord(r, rx, ry, rz, dv, p.half_w, p.half_h, p.unn_w, p.unn_h, p.align_corners, ix, iy);
+        Taps t = make_taps(ix, iy, p.H, p.W);
+        const bool fin = (fabsf(ix) <= 3.0e38f) && (fabsf(iy) <= 3.0e38f);
+        const float dead = fin ? 0.0f : __int_as_float(0x7fc00000);
+        const bool m00 = t.x0ok && t.y0ok, m01 = t.x1ok && t.y0ok;
+        const bool m10 = t.x0ok && t.y1ok, m11 = t.x1ok && t.y1ok;
+        wnw[v] = m00 ? t.nw : dead; wne[v] = m01 ? t.ne : dead;
+        wsw[v] = m10 ? t.sw : dead; wse[v] = m11 ? t.se : dead;
+        const float x0f = fminf(fmaxf(floorf(ix), -4.0f), (float)p.W + 4.0f);
+        const float y0f = fminf(fmaxf(floorf(iy), -4.0f), (float)p.H + 4.0f);
+        tx0[v] = fin ? (int)x0f : -4;
+        ty0[v] = fin ? (int)y0f : -4;
+        const bool anyx = t.x0ok || t.x1ok, anyy = t.y0ok || t.y1ok;
+        int lo_x = 0x7fffffff, hi_x = -1, lo_y = 0x7fffffff, hi_y = -1;
+        if (anyx && anyy) {
+            lo_x = t.x0ok ? tx0[v] : tx0[v] + 1;
+            hi_x = t.x1ok ? tx0[v] + 1 : tx0[v];
+            lo_y = t.y0ok ? ty0[v] : ty0[v] + 1;
+            hi_y = t.y1ok ? ty0[v] + 1 : ty0[v];
+        }
+        if constexpr (CORNER) {
+            const bool inbox = !(anyx && anyy) ||
+                               (lo_x >= bx0[v] && hi_x < bx0[v] + bw[v] && lo_y >= by0[v] &&
+                                hi_y < by0[v] + bh[v]);
+            wave_in[v] = __all(inbox);
+        } else {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                lo_x = min(lo_x, __shfl_xor(lo_x, off)); hi_x = max(hi_x, __shfl_xor(hi_x, off));
+                lo_y = min(lo_y, __shfl_xor(lo_y, off)); hi_y = max(hi_y, __shfl_xor(hi_y, off));
+            }
+            if (lane == 0) {
+                atomicMin(&s_box[v][0], lo_x); atomicMin(&s_box[v][1], lo_y);
+                atomicMax(&s_box[v][2], hi_x); atomicMax(&s_box[v][3], hi_y);
+            }
+        }
+    }
+    if constexpr (!CORNER) {
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            int x0 = __builtin_amdgcn_readfirstlane(s_box[v][0]);
+            int y0 = __builtin_amdgcn_readfirstlane(s_box[v][1]);
+            int x1 = __builtin_amdgcn_readfirstlane(s_box[v][2]);
+            int y1 = __builtin_amdgcn_readfirstlane(s_box[v][3]);
+            if (x1 < x0 || y1 < y0) { x0 = y0 = x1 = y1 = 0; }
+            bx0[v] = x0; by0[v] = y0; bw[v] = x1 - x0 + 1; bh[v] = y1 - y0 + 1;
+            staged[v] = bw[v] * bh[v] <= cap;
+        }
+        plan_dma();
+        issue_dma(0);
+    }
+
+    const float rV = 1.0f / p.fV;
+#pragma unroll 1
+    for (int g = 0; g < ngroups; ++g) {
+        // make the tap positions opaque per iteration (see the kernel above)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) asm volatile("" : "+v"(tx0[v]), "+v"(ty0[v]));
+        float4 ref4[4];
+        {
+            const float4 *rp = reinterpret_cast<const float4 *>(
+                ref16 + ((size_t)b * ngroups + g) * grp_floats + (size_t)pix * 16);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ref4[k] = rp[k];
+        }
+        // this group's footprints have landed for every wave
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        float S[16], Q[16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 r4 = ref4[k];
+            const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                Q[k * 4 + c] = rr[c] * rr[c];
+                S[k * 4 + c] = p.alias_quirk ? Q[k * 4 + c] : rr[c];
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if (ablate & 2) continue;
+            if (staged[v] && wave_in[v]) {
+                const int x0c = min(max(tx0[v], bx0[v]), bx0[v] + bw[v] - 1) - bx0[v];
+                const int x1c = min(max(tx0[v] + 1, bx0[v]), bx0[v] + bw[v] - 1) - bx0[v];
+                const int y0c = min(max(ty0[v], by0[v]), by0[v] + bh[v] - 1) - by0[v];
+                const int y1c = min(max(ty0[v] + 1, by0[v]), by0[v] + bh[v] - 1) - by0[v];
+                accumulate_taps_planar<cap>(lds + v * 4 * cap * 4, y0c * bw[v] + x0c,
+                                            y0c * bw[v] + x1c, y1c * bw[v] + x0c,
+                                            y1c * bw[v] + x1c, wnw[v], wne[v], wsw[v], wse[v], S, Q);
+            } else {
+                const float *base = srcs16 + (((size_t)v * p.B + b) * ngroups + g) * grp_floats;
+                const int x0c = min(max(tx0[v], 0), p.W - 1), x1c = min(max(tx0[v] + 1, 0), p.W - 1);
+                const int y0c = min(max(ty0[v], 0), p.H - 1), y1c = min(max(ty0[v] + 1, 0), p.H - 1);
+                accumulate_taps(base + ((size_t)y0c * p.W + x0c) * 16,
+                                base + ((size_t)y0c * p.W + x1c) * 16,
+                                base + ((size_t)y1c * p.W + x0c) * 16,
+                                base + ((size_t)y1c * p.W + x1c) * 16, wnw[v], wne[v], wsw[v],
+                                wse[v], S, Q);
+            }
+        }
+        // every wave is done with this group's LDS image: start the next group's copy; it
+        // lands while the variances below are formed and stored
+        if (g + 1 < ngroups) {
+            __syncthreads();
+            issue_dma(g + 1);
+        }
+        float var[16];
+        bool tiny = false;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const float m = div_views_fast(S[c], p.fV, rV);
+            var[c] = div_views_fast(Q[c], p.fV, rV) - m * m;
+            tiny = tiny || div_views_tiny(S[c]) || div_views_tiny(Q[c]);
+        }
+        if (__any(tiny)) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const float m = S[c] / p.fV;
+                var[c] = Q[c] / p.fV - m * m;
+            }
+        }
+        if (live && !(ablate & 8)) {
+            const size_t vox = ((size_t)b * p.D + d) * plane + pix;
+            if (out_c8) {
+                const size_t row = ((size_t)b * p.D + d) * p.H + py;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float *o = out + ((row * (p.C >> 3) + (g * 2 + h)) * p.W + px) * 8;
+                    reinterpret_cast<float4 *>(o)[0] = make_float4(var[h * 8 + 0], var[h * 8 + 1], var[h * 8 + 2], var[h * 8 + 3]);
+                    reinterpret_cast<float4 *>(o)[1] = make_float4(var[h * 8 + 4], var[h * 8 + 5], var[h * 8 + 6], var[h * 8 + 7]);
+                }
+            } else {
+                float4 *o = reinterpret_cast<float4 *>(out + vox * p.C + g * 16);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    o[k] = make_float4(var[k * 4], var[k * 4 + 1], var[k * 4 + 2], var[k * 4 + 3]);
+            }
+        }
+    }
+}
+
 // Exhaustive check of div_views against IEEE division: every float bit pattern.
 __global__ __launch_bounds__(256) void div_selftest_kernel(float fV, unsigned long long *mismatch) {
     const float rV = 1.0f / fV;
@@ -921,7 +1230,17 @@ extern "C" int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *s
         const dim3 g((unsigned)nblk, (unsigned)B);
 #define MVS_LDS_CASE(n)                                                                        \
     case n:                                                                                    \
-        if (depth_mode == 0 && !(lds_ablate & 32))                                             \
+        if (!(lds_ablate & 128)) {   /* DMA-staged form (default) */                           \
+            const size_t sh2 = (size_t)n * 4 * dma_cap(n) * 16;                                \
+            if (depth_mode == 0 && !(lds_ablate & 32))                                         \
+                hipLaunchKernelGGL((variance_fwd_dma_kernel<n, true>), g, dim3(256), sh2, st,  \
+                                   ref_fea, src_feas, rot_trans, depth_values, p, tiles_x,     \
+                                   tiles_y, out_var, out_c8, lds_ablate);                      \
+            else                                                                               \
+                hipLaunchKernelGGL((variance_fwd_dma_kernel<n, false>), g, dim3(256), sh2, st, \
+                                   ref_fea, src_feas, rot_trans, depth_values, p, tiles_x,     \
+                                   tiles_y, out_var, out_c8, lds_ablate);                      \
+        } else if (depth_mode == 0 && !(lds_ablate & 32))                                      \
             hipLaunchKernelGGL((variance_fwd_lds_kernel<n, true>), g, dim3(256), shmem, st,    \
                                ref_fea, src_feas, rot_trans, depth_values, p, tiles_x,         \
                                tiles_y, out_var, out_c8, lds_ablate);                          \

@@ -356,6 +356,36 @@ def test_conv3d_mfma_vs_oracle_ragged(dev, shape, cfg):
     np.testing.assert_allclose(ops.nhwc_to_nchw(got).cpu().numpy(), want, atol=2e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [(1, 5, 9, 21), (2, 8, 16, 48), (1, 3, 7, 33), (1, 37, 30, 70)])
+@pytest.mark.parametrize("cin", [32, 16, 8])
+def test_conv3d_c8_persistent_vs_oracle_ragged(dev, shape, cin):
+    """The persistent DMA-fed kernel (Cout = 8, 8-channel-blocked input) vs the C oracle:
+    partial tiles on every axis, batch > 1, more tiles than workgroups-per-XCD on the last
+    shape (so a workgroup walks several tiles), residual add, and bit-identity with the
+    per-tile MFMA kernel on the same input (same accumulation order)."""
+    from mvs_amd import ops
+    from oracle import c_oracle as co
+    B, D, H, W = shape
+    rng = np.random.default_rng(cin * 100 + D)
+    x = rng.standard_normal((B, cin, D, H, W)).astype(np.float32)
+    w = (rng.standard_normal((8, cin, 3, 3, 3)) / np.sqrt(27 * cin)).astype(np.float32)
+    scale = (0.5 + rng.random(8)).astype(np.float32)
+    shift = rng.standard_normal(8).astype(np.float32) * 0.1
+    want = co.conv3d(x, w, scale, shift, None, True, 1)
+    res = rng.standard_normal(want.shape).astype(np.float32)
+    want = want + res
+    wt = G(w, dev)
+    pk = ops.pack_conv3d_weight(wt, False, 1)
+    xg = G(x, dev)
+    rcl = ops.nchw_to_nhwc(G(res, dev))
+    got = ops.conv3d(ops.nchw_to_c8(xg), wt, G(scale, dev), G(shift, dev), rcl, True, False, 1,
+                     channels_last=True, packed=pk, impl=ops.IMPL_MFMA, in_c8=True)
+    np.testing.assert_allclose(ops.nhwc_to_nchw(got).cpu().numpy(), want, atol=2e-5, rtol=1e-5)
+    ref = ops.conv3d(ops.nchw_to_nhwc(xg), wt, G(scale, dev), G(shift, dev), rcl, True, False, 1,
+                     channels_last=True, packed=pk, impl=ops.IMPL_MFMA)
+    assert torch.equal(got, ref)
+
+
 @pytest.mark.parametrize("shape", [(1, 3, 5, 21), (2, 4, 8, 16), (1, 5, 9, 33)])
 @pytest.mark.parametrize("cfg", [(64, 32), (32, 16), (16, 8)])
 def test_deconv3d_mfma_vs_oracle_ragged(dev, shape, cfg):
