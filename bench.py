@@ -175,15 +175,19 @@ def main():
     torch.cuda.synchronize()
     dbg = os.environ.get("MVS_BENCH_DEBUG") == "1"   # host-side issue time per step, allocator activity
     if dbg:
-        ms0, issue = torch.cuda.memory_stats(), []
+        ms0, issue, evs = torch.cuda.memory_stats(), [], [torch.cuda.Event(enable_timing=True)]
+        evs[0].record()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
         if dbg:
             issue.append(time.perf_counter())
+            evs.append(torch.cuda.Event(enable_timing=True))
+            evs[-1].record()
     torch.cuda.synchronize()
     if dbg:
         ms1 = torch.cuda.memory_stats()
+        print("[debug] gpu ms/step:", [round(a.elapsed_time(b), 2) for a, b in zip(evs, evs[1:])], file=sys.stderr)
         print("[debug] issue ms/step:", [round((b - a) * 1e3, 2) for a, b in zip([t0] + issue, issue)],
               "device_alloc", ms1["num_device_alloc"] - ms0["num_device_alloc"],
               "device_free", ms1["num_device_free"] - ms0["num_device_free"],

@@ -1,0 +1,13 @@
+"""Host-side readers/writers of the on-disk contract around the hot path (SURVEY.md
+Appendix A): PFM, camera files, pair.txt, the DTU evaluation sample."""
+from .data_io import read_pfm, save_pfm
+from .dtu_eval import MVSDataset, read_cam_file, read_pair_file
+
+__all__ = ["read_pfm", "save_pfm", "MVSDataset", "read_cam_file", "read_pair_file"]
+
+
+def find_dataset_def(name):
+    """Reference surface (MVSNet/datasets/__init__.py): dataset class by module name."""
+    if name in ("dtu_yao_eval", "dtu_eval"):
+        return MVSDataset
+    raise KeyError(f"dataset {name!r} is not part of this build (evaluation loader only)")

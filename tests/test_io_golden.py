@@ -1,0 +1,102 @@
+"""On-disk contract vs golden vectors captured from the reference's
+own loader and PFM code (tests/golden/make_golden_io.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+from io_fixture import build_scan  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def scan(tmp_path_factory):
+    root = str(tmp_path_factory.mktemp("dtu"))
+    return root, build_scan(root)
+
+
+def test_pfm_bytes_and_roundtrip(tmp_path):
+    from mvs_amd.datasets import read_pfm, save_pfm
+    g = load_golden("g10_io")
+    for name in ("grey", "color"):
+        arr = g[f"pfm_{name}_array"]
+        path = str(tmp_path / (name + ".pfm"))
+        save_pfm(path, arr)
+        assert open(path, "rb").read() == g[f"pfm_{name}_bytes"].tobytes()   # byte-identical file
+        back, scale = read_pfm(path)
+        assert scale == 1.0 and back.dtype.kind == "f" and np.array_equal(back, arr)
+    with pytest.raises(Exception):
+        save_pfm(str(tmp_path / "x.pfm"), np.zeros((2, 2), dtype=np.float64))
+    bad = tmp_path / "bad.pfm"
+    bad.write_bytes(b"P6\n1 1\n255\n\0\0\0")
+    with pytest.raises(Exception):
+        read_pfm(str(bad))
+
+
+def test_cam_file_and_pairs(scan):
+    from mvs_amd.datasets import read_cam_file, read_pair_file
+    root, _ = scan
+    g = load_golden("g10_io")
+    K, E, dmin, dint = read_cam_file(os.path.join(root, "scan1/cams/00000002_cam.txt"), interval_scale=1.06)
+    assert np.array_equal(K, g["cam_K"]) and np.array_equal(E, g["cam_E"])
+    assert dmin == float(g["cam_dmin"]) and dint == float(g["cam_dint"])
+    pairs = read_pair_file(os.path.join(root, "scan1/pair.txt"))
+    assert [[r] + s for r, s in pairs] == g["metas"].tolist()
+
+
+def test_eval_samples_match_reference_loader(scan):
+    from mvs_amd.datasets import MVSDataset, find_dataset_def
+    from mvs_amd.datasets.dtu_eval import read_image
+    root, listfile = scan
+    g = load_golden("g10_io")
+    ds = find_dataset_def("dtu_yao_eval")(root, listfile, "test", 3, 192, 1.06)
+    assert isinstance(ds, MVSDataset) and len(ds) == int(g["n_samples"])
+    for i in (0, len(ds) - 1):
+        s = ds[i]
+        assert np.array_equal(s["proj_matrices"], g[f"s{i}_proj"])           # bit-identical fp32
+        assert np.array_equal(s["depth_values"], g[f"s{i}_depth_values"])
+        assert s["filename"] == str(g[f"s{i}_filename"])
+        assert list(s["imgs"].shape) == g[f"s{i}_imgs_shape"].tolist() and s["imgs"].dtype == np.float32
+        assert np.array_equal(s["imgs"][:, :, ::97, ::131], g[f"s{i}_imgs_probe"])
+    with pytest.raises(AssertionError):
+        read_image(os.path.join(root, "scan1/images/00000000.jpg"), expect_hw=(100, 100))
+
+
+def test_eval_tool_argument_surface():
+    from mvs_amd.tools import eval_depth
+    with pytest.raises(SystemExit):
+        eval_depth.main(["--help"])
+
+
+@pytest.mark.gpu
+def test_eval_tool_writes_reference_output_tree(scan, tmp_path):
+    """mvs_amd.tools.eval_depth (eval.py save_depth): checkpoint in the reference's format
+    (DataParallel 'module.' keys) -> {outdir}/{scan}/depth_est|confidence/{ref:08d}.pfm whose
+    contents are the model's outputs for that sample."""
+    import torch
+    from mvs_amd import synth
+    from mvs_amd.datasets import MVSDataset, read_pfm
+    from mvs_amd.models import MVSNet
+    from mvs_amd.tools import eval_depth
+    root, listfile = scan
+    sd = synth.random_state_dict(0)
+    ckpt = str(tmp_path / "model_000000.ckpt")
+    torch.save({"epoch": 0, "model": {"module." + k: v for k, v in sd.items()}}, ckpt)
+    outdir = str(tmp_path / "out")
+    eval_depth.main(["--testpath", root, "--testlist", listfile, "--loadckpt", ckpt, "--outdir", outdir,
+                     "--nviews", "3", "--numdepth", "48", "--num_workers", "0"])
+    ds = MVSDataset(root, listfile, "test", 3, 48, 1.06)
+    model = MVSNet(refine=False)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    for i in range(len(ds)):
+        s = ds[i]
+        with torch.no_grad():
+            out = model(*(torch.from_numpy(s[k])[None].cuda() for k in ("imgs", "proj_matrices", "depth_values")))
+        for kind, key in (("depth_est", "depth"), ("confidence", "photometric_confidence")):
+            arr, scale = read_pfm(os.path.join(outdir, s["filename"].format(kind, ".pfm")))
+            assert scale == 1.0 and arr.shape == (296, 400)
+            assert np.array_equal(arr, out[key][0].cpu().numpy())
