@@ -161,10 +161,11 @@ def main():
         step()
     torch.cuda.synchronize()
     ops.set_timer(None)
-    stages = {k: v[1] for k, v in full.summary_ms().items()}
+    # per stage: the fastest of the instrumented occurrences -- the kernels' own durations,
+    # without whatever a profiler or a busy host adds between the two events of one occurrence
+    stages = full.min_ms()
     work = algorithmic_work(V, 32, D, h, w)
-    fastest = full.min_ms()   # robust against profiler / host noise inside one occurrence
-    dominant = max((k for k in stages if k in work), key=lambda k: fastest[k])
+    dominant = max((k for k in stages if k in work), key=lambda k: stages[k])
 
     # --- timed region: EXACTLY K steps, barrier + synchronize on both sides;
     # only the dominant kernel carries HIP events (2 per step)

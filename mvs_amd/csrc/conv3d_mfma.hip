@@ -400,6 +400,12 @@ template <int N>
 __device__ __forceinline__ void lds_wait(f32x2 &a, f32x2 &b, f32x2 &c) {
     asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N));
 }
+// wait until at most N LDS operations are outstanding (pair with an empty asm "+v" on the
+// registers the landed reads wrote, so their consumers stay behind the wait)
+template <int N>
+__device__ __forceinline__ void lds_wait_n() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (I < N) {
@@ -408,30 +414,40 @@ __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 
-template <int CIN>
+template <int CIN_, int COUT_ = 8, int MODE_ = 2, int TZ_ = 4, int TY_ = 4>
 struct PersistCfg {
-    static constexpr int NCHUNK = CIN / 8, NTAPS = 36;
-    static constexpr int TZ = 4, TY = 4, XOUT = 32;
-    static constexpr int XT = 34, XH = 17, YT = TY + 2, ZT = TZ + 2;
-    static constexpr int NVOX = ZT * YT * XT;                 // 1224
-    static constexpr int PLANE = round_up_c(NVOX, 64);        // 1280 voxels per channel half
-    static constexpr int NDMA = 2 * PLANE / 64;               // wave-instructions per chunk (40)
-    static constexpr int IPW = NDMA / 8;                      // per wave (5)
-    static constexpr int W_FLOATS = NCHUNK * NTAPS * 64 * 2;
+    static constexpr int CIN = CIN_, COUT = COUT_, MODE = MODE_, TZ = TZ_, TY = TY_;
+    static constexpr int NCHUNK = CIN / 8;
+    static constexpr int NKX = (MODE == 2) ? 4 : 3, NTAPS = 9 * NKX;
+    static constexpr int MT = (MODE == 2) ? 1 : COUT / 16;
+    static constexpr int SZY = (MODE == 1) ? 2 : 1;          // conv stride in y, z
+    static constexpr int XOUT = (MODE == 2) ? 32 : 16;
+    static constexpr int SX = (MODE == 0) ? 1 : 2;           // x step of a wave's B reads
+    static constexpr int XT = 15 * SX + NKX, XH = (XT + 1) / 2, XTP = (SX == 2) ? 2 * XH : XT;
+    static constexpr int YT = (TY - 1) * SZY + 3, ZT = (TZ - 1) * SZY + 3;
+    static constexpr int NVOX = ZT * YT * XTP;
+    static constexpr int PLANE = round_up_c(NVOX, 64);        // voxels per channel half
+    static constexpr int NDMA = 2 * PLANE / 64;               // wave-instructions per chunk
+    static constexpr int IPW = (NDMA + 7) / 8;                // per wave
+    static constexpr int ROWS = TZ * TY, RPW = ROWS / 8;      // (z,y) output rows per wave
+    static constexpr int W_FLOATS = NCHUNK * NTAPS * MT * 64 * 2;
     static constexpr int BUF_FLOATS = 2 * PLANE * 4;
     static constexpr int LDS_FLOATS = W_FLOATS + 2 * BUF_FLOATS;
-    static_assert(NDMA % 8 == 0, "DMA instructions split evenly over 8 waves");
+    // (MODE 0, stride 1 with Cout >= 16, is expressible but not instantiated: conv2 gained 9 %
+    // and its weights would need the 8-channel-chunk packing)
+    static_assert(MODE >= 0 && MODE <= 2, "MODE 0: stride 1; MODE 1: stride 2; MODE 2: Cout = 8 shifted form");
+    static_assert(MODE != 2 || COUT == 8, "MODE 2 is the Cout = 8 form");
+    static_assert(MODE == 2 || COUT % 16 == 0, "MODE 0/1 need whole 16-channel M tiles");
+    static_assert(ROWS % 8 == 0, "rows split over 8 waves");
     static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 };
 
-template <int CIN, int ABL = 0>
+template <class P, int ABL = 0>
 __global__ __launch_bounds__(512) void conv3d_c8_persistent_kernel(ConvArgs a, int ntiles) {
-    using P = PersistCfg<CIN>;
-    constexpr int NTAPS = P::NTAPS, XT = P::XT, XH = P::XH, YT = P::YT, PLANE = P::PLANE;
-    constexpr int IPW = P::IPW;
+    constexpr int CIN = P::CIN, COUT = P::COUT, MODE = P::MODE, MT = P::MT, RPW = P::RPW;
+    constexpr int NTAPS = P::NTAPS, NKX = P::NKX, XT = P::XT, XH = P::XH, XTP = P::XTP, YT = P::YT;
+    constexpr int PLANE = P::PLANE, IPW = P::IPW, SZY = P::SZY;
     __shared__ __attribute__((aligned(16))) float lds[P::LDS_FLOATS];
-    float *wl = lds;
-    float *buf0 = lds + P::W_FLOATS;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -457,28 +473,31 @@ __global__ __launch_bounds__(512) void conv3d_c8_persistent_kernel(ConvArgs a, i
     // thread's DMA items (item i of wave w is DMA instruction g = i*8 + w of the chunk:
     // channel half h = g / (PLANE/64), voxels (g % (PLANE/64))*64 + lane)
     {
-        constexpr int NWI = P::W_FLOATS / 4 / 64;   // 16-byte granules / 64 lanes
+        constexpr int NGR = P::W_FLOATS / 4;        // 16-byte granules
+        constexpr int NWI = (NGR + 63) / 64;        // wave-instructions (the last may be partial)
         for (int i = wv; i < NWI; i += 8)
-            glds16(a.wpk + ((size_t)i * 64 + lane) * 4, lds_base + (unsigned)i * 1024u);
+            if (i * 64 + lane < NGR)
+                glds16(a.wpk + ((size_t)i * 64 + lane) * 4, lds_base + (unsigned)i * 1024u);
     }
-    int loc[IPW];        // lx | ly << 8 | lz << 16 | h << 24 | valid << 31 (as sign)
-    unsigned dst[IPW];   // LDS byte offset of the instruction inside a chunk buffer
+    int loc[IPW];        // lx | ly << 8 | lz << 16 | h << 24 | invalid << 31 (as sign)
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
-        const int g = i * 8 + wv;
+        const int g = min(i * 8 + wv, P::NDMA - 1);
         const int h = g / (PLANE / 64), vb = g % (PLANE / 64);
         const int v = vb * 64 + lane;
         const int vc = min(v, P::NVOX - 1);
-        const int lxp = vc % XT, t2 = vc / XT;
+        const int lxp = vc % XTP, t2 = vc / XTP;
         const int ly = t2 % YT, lz = t2 / YT;
-        const int lx = lxp < XH ? 2 * lxp : 2 * (lxp - XH) + 1;
-        loc[i] = lx | (ly << 8) | (lz << 16) | (h << 24) | (v < P::NVOX ? 0 : (int)0x80000000);
-        dst[i] = (unsigned)((h * PLANE + vb * 64) * 16);
+        // x de-interleaved (evens, then odds) where a wave's B reads step by 2
+        const int lx = (P::SX == 1) ? lxp : (lxp < XH ? 2 * lxp : 2 * (lxp - XH) + 1);
+        loc[i] = lx | (ly << 8) | (lz << 16) | (h << 24) | ((v < P::NVOX && lx < XT) ? 0 : (int)0x80000000);
     }
 
-    const int64_t plane_in = (int64_t)a.H * a.W * CIN;   // floats per z-plane ([D,H,C/8,W,8])
+    // input addressing: 8-channel-blocked [D,H,C/8,W,8] or channels-last [D,H,W,C]
+    const int64_t plane_in = (int64_t)a.H * a.W * CIN;   // floats per z-plane
     const int row_in = a.W * CIN;                        // floats per (z,y) row
-    const int ch_step = a.W * 8;                         // floats between 8-channel blocks of a row
+    const int vox_in = a.in_c8 ? 8 : CIN;                // floats between x neighbours
+    const int ch_step = a.in_c8 ? a.W * 8 : 8;           // floats between 8-channel chunks
 
     // geometry of one tile: source pointer of every DMA item for chunk 0, and its
     // per-chunk step (0 for halo voxels outside the volume: they read the zero page)
@@ -487,7 +506,8 @@ __global__ __launch_bounds__(512) void conv3d_c8_persistent_kernel(ConvArgs a, i
     TileIdx tile;
     auto geometry = [&](int t) {
         tile = decode_ordered_tile(a, t);
-        const int ix0 = tile.tx * P::XOUT - 1, iy0 = tile.ty * P::TY - 1, iz0 = tile.tz * P::TZ - 1;
+        const int ix0 = tile.tx * P::XOUT * (MODE == 1 ? 2 : 1) - 1;
+        const int iy0 = tile.ty * P::TY * SZY - 1, iz0 = tile.tz * P::TZ * SZY - 1;
         const float *in_b = a.in + (int64_t)tile.b * a.D * plane_in;
 #pragma unroll
         for (int i = 0; i < IPW; ++i) {
@@ -495,7 +515,7 @@ __global__ __launch_bounds__(512) void conv3d_c8_persistent_kernel(ConvArgs a, i
             const int gz = iz0 + ((loc[i] >> 16) & 255), h = (loc[i] >> 24) & 1;
             const bool ok = loc[i] >= 0 && (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H &&
                             (unsigned)gz < (unsigned)a.D;
-            const float *p = in_b + (int64_t)gz * plane_in + (int64_t)gy * row_in + gx * 8 + h * 4;
+            const float *p = in_b + (int64_t)gz * plane_in + (int64_t)gy * row_in + gx * vox_in + h * 4;
             src[i] = ok ? p : g_zero_page;
             step[i] = ok ? ch_step : 0;
         }
@@ -503,32 +523,39 @@ __global__ __launch_bounds__(512) void conv3d_c8_persistent_kernel(ConvArgs a, i
     auto issue = [&](int ch, int parity) {
         const unsigned base = lds_base + (unsigned)(P::W_FLOATS + parity * P::BUF_FLOATS) * 4u;
 #pragma unroll
-        for (int i = 0; i < IPW; ++i)
-            glds16(src[i] + (int64_t)ch * step[i], base + dst[i]);
+        for (int i = 0; i < IPW; ++i) {
+            if (P::NDMA % 8 != 0 && i * 8 + wv >= P::NDMA) continue;   // wave-uniform
+            glds16(src[i] + (int64_t)ch * step[i], base + (unsigned)(i * 8 + wv) * 1024u);
+        }
     };
 
-    // BatchNorm(eval) affine of this lane's 4 output channels
-    const int c0 = (kq & 1) * 4;
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.scale) sc = *reinterpret_cast<const float4 *>(a.scale + c0);
-    if (a.shift) sh = *reinterpret_cast<const float4 *>(a.shift + c0);
-
-    // per-lane LDS read bases (floats): B = plane kq>>1, voxel n, channel pair kq&1; rows 2w, 2w+1
-    const int rdB = ((kq >> 1) * PLANE + n) * 4 + (kq & 1) * 2;
-    int rowoff[2];
+    // BatchNorm(eval) affine of this lane's output channels (4 per M tile)
+    float4 sc[MT], sh[MT];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int row = wv * 2 + r;
-        rowoff[r] = ((row / P::TY) * YT + (row % P::TY)) * XT * 4;
+    for (int m = 0; m < MT; ++m) {
+        const int c0 = (MODE == 2) ? (kq & 1) * 4 : m * 16 + kq * 4;
+        sc[m] = a.scale ? *reinterpret_cast<const float4 *>(a.scale + c0) : make_float4(1.f, 1.f, 1.f, 1.f);
+        sh[m] = a.shift ? *reinterpret_cast<const float4 *>(a.shift + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    // per-lane LDS read bases (floats): B = plane kq>>1, voxel n, channel pair kq&1
+    const int rdB = ((kq >> 1) * PLANE + n) * 4 + (kq & 1) * 2;
+    int rowoff[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int row = wv * RPW + r;
+        rowoff[r] = (((row / P::TY) * SZY) * YT + (row % P::TY) * SZY) * XTP * 4;
     }
     const int rdA = lane * 2;
 
-    f32x4 acc[2];
-    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[RPW][MT];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[r][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // ABL & 16 (tuning): cycles of wave 0 per phase, summed over the tiles of this
-    // workgroup, into the buffer passed as `residual`: [wait, barrier, issue, mfma, epilogue]
+    // workgroup, into the buffer passed as `residual`: [wait, barrier, issue, mfma, stores, drain]
     long long tsum[6] = {0, 0, 0, 0, 0, 0};
     long long tprev = 0;
     if constexpr (ABL & 16) tprev = clock64();
@@ -552,9 +579,9 @@ __global__ __launch_bounds__(512) void conv3d_c8_persistent_kernel(ConvArgs a, i
             __syncthreads();
             MVS_LAP(1);
             // next chunk (of this tile, or the first of the next one) -> the other buffer.
-            // (Issuing it a few taps into the MFMA stream, deferring the stores of a tile
-            // into the next tile's stream, or hoisting the geometry were each measured:
-            // no gain -- a wave's VALU/DMA issue crawls beside its partner's MFMAs.)
+            // (Issuing it a few taps into the MFMA stream, staggering it between the two
+            // waves of a SIMD, deferring a tile's stores into the next tile's stream, or
+            // hoisting the geometry were each measured: no gain.)
             if (ch + 1 < P::NCHUNK) {
                 issue(ch + 1, parity ^ 1);
             } else if (t_next < t_end) {
@@ -562,22 +589,27 @@ __global__ __launch_bounds__(512) void conv3d_c8_persistent_kernel(ConvArgs a, i
                 issue(0, parity ^ 1);
             }
             MVS_LAP(2);
-            // ---- MFMA stream of the chunk: per tap one A read (feeds 4 MFMAs) and one B read
-            // per row (2 MFMAs each), software-pipelined PD taps ahead through PD+1
-            // register slots; LDS returns in order, so "tap t has landed" is lgkmcnt <=
-            // 3 x (taps issued after it)
-            const unsigned aA = lds_base + (unsigned)(ch * (NTAPS * 64 * 2) + rdA) * 4u;
-            const unsigned aB0 = lds_base + (unsigned)(P::W_FLOATS + parity * P::BUF_FLOATS + rdB + rowoff[0]) * 4u;
-            const unsigned aB1 = lds_base + (unsigned)(P::W_FLOATS + parity * P::BUF_FLOATS + rdB + rowoff[1]) * 4u;
-            constexpr int PD = 3;
-            f32x2 fa[PD + 1], fb0[PD + 1], fb1[PD + 1];
+            // ---- MFMA stream of the chunk: per tap MT A reads and one B read per row,
+            // software-pipelined PD taps ahead through PD+1 register slots; LDS returns in
+            // order, so "tap t has landed" is lgkmcnt <= (MT+RPW) x (taps issued after it)
+            const unsigned aA = lds_base + (unsigned)(ch * (NTAPS * MT * 64 * 2) + rdA) * 4u;
+            unsigned aB[RPW];
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+                aB[r] = lds_base + (unsigned)(P::W_FLOATS + parity * P::BUF_FLOATS + rdB + rowoff[r]) * 4u;
+            constexpr int PD = 3, NRD = MT + RPW;
+            f32x2 fa[PD + 1][MT], fb[PD + 1][RPW];
             auto fetch = [&](auto tc) {
                 constexpr int t = decltype(tc)::value;
-                constexpr int kz = t / 12, ky = (t / 4) % 3, kx = t % 4;
-                constexpr int boff = ((kz * YT + ky) * XT + (kx & 1) * XH + (kx >> 1)) * 16;
-                fa[t % (PD + 1)] = lds_read_b64<t * 512>(aA);
-                fb0[t % (PD + 1)] = lds_read_b64<boff>(aB0);
-                fb1[t % (PD + 1)] = lds_read_b64<boff>(aB1);
+                constexpr int kz = t / (3 * NKX), ky = (t / NKX) % 3, kx = t % NKX;
+                constexpr int xoff = (P::SX == 1) ? kx : (kx & 1) * XH + (kx >> 1);
+                constexpr int boff = ((kz * YT + ky) * XTP + xoff) * 16;
+                static_for<0, MT>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    fa[t % (PD + 1)][m] = lds_read_b64<(t * MT + m) * 512>(aA);
+                });
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) fb[t % (PD + 1)][r] = lds_read_b64<boff>(aB[r]);
             };
             static_for<0, PD>(fetch);
             static_for<0, NTAPS>([&](auto tc) {
@@ -585,46 +617,59 @@ __global__ __launch_bounds__(512) void conv3d_c8_persistent_kernel(ConvArgs a, i
                 constexpr int sl = t % (PD + 1);
                 if constexpr (t + PD < NTAPS) fetch(std::integral_constant<int, t + PD>{});
                 constexpr int newer = (t + PD < NTAPS ? PD : NTAPS - 1 - t);
-                lds_wait<3 * newer>(fa[sl], fb0[sl], fb1[sl]);
+                lds_wait_n<NRD * newer>();
+#pragma unroll
+                for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(fa[sl][m]));
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) asm volatile("" : "+v"(fb[sl][r]));
                 if constexpr (ABL & 8) {
-                    asm volatile("" ::"v"(fa[sl]), "v"(fb0[sl]), "v"(fb1[sl]));
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r) asm volatile("" ::"v"(fa[sl][0]), "v"(fb[sl][r]));
                 } else {
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl].x, fb0[sl].x, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl].x, fb1[sl].x, acc[1], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl].y, fb0[sl].y, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl].y, fb1[sl].y, acc[1], 0, 0, 0);
+                    // same accumulation order as conv3d_mfma_kernel: per (tap, row, M tile) k-step 0, 1
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            acc[r][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl][m].x, fb[sl][r].x, acc[r][m], 0, 0, 0);
+                            acc[r][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl][m].y, fb[sl][r].y, acc[r][m], 0, 0, 0);
+                        }
                 }
             });
             parity ^= 1;
             MVS_LAP(3);
         }
-        // ---- epilogue of `cur`: BN affine, ReLU, one 16-byte store per lane and row
+        // ---- epilogue of `cur`: BN affine, ReLU, skip add, one 16-byte store per lane, row, M tile
         if constexpr (ABL & 16) {
-            asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));
+            asm volatile("" : "+v"(acc[0][0]));
             asm volatile("s_nop 0" ::: "memory");
             MVS_LAP(5);
         }
         {
-            const int ox = cur.tx * P::XOUT + 2 * n + (kq >> 1);
+            const int ox = (MODE == 2) ? cur.tx * P::XOUT + 2 * n + (kq >> 1) : cur.tx * P::XOUT + n;
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int row = wv * 2 + r;
+            for (int r = 0; r < RPW; ++r) {
+                const int row = wv * RPW + r;
                 const int oz = cur.tz * P::TZ + row / P::TY, oy = cur.ty * P::TY + row % P::TY;
-                f32x4 v = acc[r];
-                acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo) continue;
-                v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
-                v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
-                if (a.relu) {
-                    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
-                    v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    f32x4 v = acc[r][m];
+                    acc[r][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo) continue;
+                    const int c0 = (MODE == 2) ? (kq & 1) * 4 : m * 16 + kq * 4;
+                    v[0] = v[0] * sc[m].x + sh[m].x; v[1] = v[1] * sc[m].y + sh[m].y;
+                    v[2] = v[2] * sc[m].z + sh[m].z; v[3] = v[3] * sc[m].w + sh[m].w;
+                    if (a.relu) {
+                        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+                        v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                    }
+                    const int64_t o = ((((int64_t)cur.b * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * COUT + c0;
+                    if (a.residual && !(ABL & 16)) {
+                        const float4 rs = *reinterpret_cast<const float4 *>(a.residual + o);
+                        v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
+                    }
+                    *reinterpret_cast<float4 *>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
                 }
-                const int64_t o = ((((int64_t)cur.b * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * 8 + c0;
-                if (a.residual && !(ABL & 16)) {
-                    const float4 rs = *reinterpret_cast<const float4 *>(a.residual + o);
-                    v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
-                }
-                *reinterpret_cast<float4 *>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
         t_cur = t_next;
@@ -1373,11 +1418,18 @@ int conv3d_mfma_launch(const float *in, const float *packed, const float *scale,
         set_error("mvs_conv3d_f32(mfma): bad grid");
         return MVS_EINVAL;
     }
-    // conv0-class layers on the 8-channel-blocked volume: persistent DMA-fed kernel
+    // Persistent DMA-fed kernel: the Cout = 8 stride-1 layers on the 8-channel-blocked
+    // volume (conv0 and the cascade's first layers) and the stride-2 layers whose weights
+    // fit in LDS beside two halo buffers (conv1 8->16, conv3 16->32).
     // (MVS_CONV0_VARIANT=10 selects the per-tile kernel instead: tuning / A-B testing)
-    if (!transposed && Cout == 8 && stride == 1 && in_c8 && (Cin == 32 || Cin == 16 || Cin == 8)) {
+    {
+        const bool c8_class = !transposed && Cout == 8 && stride == 1 && in_c8 &&
+                              (Cin == 32 || Cin == 16 || Cin == 8);
+        const bool s2_class = !transposed && stride == 2 && !in_c8 &&
+                              ((Cin == 8 && Cout == 16) || (Cin == 16 && Cout == 32));
         const char *var = getenv("MVS_CONV0_VARIANT");
-        if (!var || atoi(var) == 0 || atoi(var) >= 20) {
+        const int v = var ? atoi(var) : 0;
+        if ((c8_class || s2_class) && (v == 0 || v >= 20)) {
             static int n_cu = 0;
             if (n_cu == 0) {
                 int dev = 0, cu = 0;
@@ -1386,25 +1438,30 @@ int conv3d_mfma_launch(const float *in, const float *packed, const float *scale,
                     cu = 256;
                 n_cu = cu;
             }
-            a.tiles_x = (a.Wo + 31) / 32; a.tiles_y = (a.Ho + 3) / 4; a.tiles_z = (a.Do + 3) / 4;
+            if (c8_class) {
+                a.tiles_x = (a.Wo + 31) / 32; a.tiles_y = (a.Ho + 3) / 4; a.tiles_z = (a.Do + 3) / 4;
+            } else {
+                a.tiles_x = (a.Wo + 15) / 16; a.tiles_y = (a.Ho + 3) / 4; a.tiles_z = (a.Do + 1) / 2;
+            }
             const int64_t nt = (int64_t)B * a.tiles_x * a.tiles_y * a.tiles_z;
             if (nt <= 0 || nt > 0x7fffffffLL) return MVS_EINVAL;
             if (!getenv("MVS_CONV_YSTRIP")) a.ystrip = 8;
-            const int grid = (int)(nt < n_cu ? nt : n_cu);
-            const int v = var ? atoi(var) : 0;
-            if (Cin == 32) {
-                if (v == 28)
-                    hipLaunchKernelGGL((conv3d_c8_persistent_kernel<32, 8>), dim3(grid), dim3(512), 0, st, a, (int)nt);
-                else if (v == 36)
-                    hipLaunchKernelGGL((conv3d_c8_persistent_kernel<32, 16>), dim3(grid), dim3(512), 0, st, a, (int)nt);
-
-                else
-                    hipLaunchKernelGGL((conv3d_c8_persistent_kernel<32>), dim3(grid), dim3(512), 0, st, a, (int)nt);
-            } else if (Cin == 16) {
-                hipLaunchKernelGGL((conv3d_c8_persistent_kernel<16>), dim3(grid), dim3(512), 0, st, a, (int)nt);
-            } else {
-                hipLaunchKernelGGL((conv3d_c8_persistent_kernel<8>), dim3(grid), dim3(512), 0, st, a, (int)nt);
-            }
+            const dim3 grid((unsigned)(nt < n_cu ? nt : n_cu)), blk(512);
+            const int ntl = (int)nt;
+            if (s2_class && Cin == 8)
+                hipLaunchKernelGGL((conv3d_c8_persistent_kernel<PersistCfg<8, 16, 1, 2, 4>>), grid, blk, 0, st, a, ntl);
+            else if (s2_class)
+                hipLaunchKernelGGL((conv3d_c8_persistent_kernel<PersistCfg<16, 32, 1, 2, 4>>), grid, blk, 0, st, a, ntl);
+            else if (Cin == 32 && v == 28)
+                hipLaunchKernelGGL((conv3d_c8_persistent_kernel<PersistCfg<32>, 8>), grid, blk, 0, st, a, ntl);
+            else if (Cin == 32 && v == 36)
+                hipLaunchKernelGGL((conv3d_c8_persistent_kernel<PersistCfg<32>, 16>), grid, blk, 0, st, a, ntl);
+            else if (Cin == 32)
+                hipLaunchKernelGGL((conv3d_c8_persistent_kernel<PersistCfg<32>>), grid, blk, 0, st, a, ntl);
+            else if (Cin == 16)
+                hipLaunchKernelGGL((conv3d_c8_persistent_kernel<PersistCfg<16>>), grid, blk, 0, st, a, ntl);
+            else
+                hipLaunchKernelGGL((conv3d_c8_persistent_kernel<PersistCfg<8>>), grid, blk, 0, st, a, ntl);
             return check_launch("mvs_conv3d_f32(mfma, persistent)");
         }
     }
