@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(CSRC, "libmvs_hip.so")
 SOURCES = ("capi", "sweep", "regress", "conv3d_direct", "conv3d_mfma", "conv2d_mfma")
-HEADERS = (os.path.join(CSRC, "mvs_common.h"),
+HEADERS = (os.path.join(CSRC, "mvs_common.h"), os.path.join(CSRC, "conv_persistent.h"),
            os.path.join(os.path.dirname(HERE), "include", "mvs_hip.h"))
 # -ffp-contract=off: the plane-sweep coordinate arithmetic places its FMAs by
 # hand to match the reference bit for bit; everything else uses fmaf/MFMA.

@@ -9,7 +9,9 @@
 // The two full-resolution 8-channel layers are HBM-bound (303 MB each way for 5 views);
 // the kernel's job there is to stream whole lines and keep the MFMA work off the
 // critical path, which MIOpen's generic fp32 igemm does not (1.2 ms per layer).
+#include <cstdlib>
 #include "mvs_common.h"
+#include "conv_persistent.h"
 
 namespace mvs {
 
@@ -232,6 +234,64 @@ __global__ __launch_bounds__(256) void conv2d_pack_kernel(Pack2Args p, int64_t t
     p.packed[i] = val;
 }
 
+// Layout of the persistent kernel (conv_persistent.h), 8-channel chunks:
+// packed[ch][ky][kx'][mt][lane][s], input channel = ch*8 + 2*kq + s.  shifted (Cout = 8): 4
+// x-taps, row m = (shift m>>3, channel m&7) holds w[kx' - shift] (zero outside 0..2).
+struct PackP2Args {
+    const float *w;
+    float *packed;
+    int Cin, Cout, KH, nkx, mt, shifted;
+};
+
+__global__ __launch_bounds__(256) void conv2d_pack_persistent_kernel(PackP2Args p, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int64_t t = i;
+    const int s = (int)(t % 2); t /= 2;
+    const int lane = (int)(t % 64); t /= 64;
+    const int mt = (int)(t % p.mt); t /= p.mt;
+    const int kx = (int)(t % p.nkx); t /= p.nkx;
+    const int ky = (int)(t % p.KH); t /= p.KH;
+    const int ch = (int)t;
+    const int m = lane & 15, kq = lane >> 4;
+    const int cin = ch * 8 + kq * 2 + s;
+    const int co = p.shifted ? (m & 7) : mt * 16 + m;
+    const int kxr = p.shifted ? kx - (m >> 3) : kx;
+    float val = 0.0f;
+    if (cin < p.Cin && co < p.Cout && kxr >= 0 && kxr < p.KH)
+        val = p.w[(((int64_t)co * p.Cin + cin) * p.KH + ky) * p.KH + kxr];
+    p.packed[i] = val;
+}
+
+// FeatureNet layers that run on the persistent DMA-fed kernel: the batch of images is a
+// volume whose planes are the images, the kernel is one plane deep.
+struct Persist2Info {
+    int mode, ty, xout, nkx, mt, nchunk;
+    void (*kernel)(ConvArgs, int);
+};
+
+static bool lookup_persist2(int Cin, int Cout, int ksize, int stride, Persist2Info &pi) {
+#define MVS_P2(cin, cout, kh, st, mode, ty)                                                      \
+    if (Cin == cin && Cout == cout && ksize == kh && stride == st) {                             \
+        using P = PersistCfg<cin, cout, mode, 1, ty, 1, kh>;                                     \
+        pi = Persist2Info{mode, ty, P::XOUT, P::NKX, P::MT, P::NCHUNK,                            \
+                          conv3d_c8_persistent_kernel<P>};                                       \
+        return true;                                                                             \
+    }
+    MVS_P2(8, 8, 3, 1, 2, 32)     // feature.conv1
+    MVS_P2(8, 16, 5, 2, 1, 16)    // feature.conv2
+    MVS_P2(16, 16, 3, 1, 0, 32)   // feature.conv3, conv4
+    MVS_P2(16, 32, 5, 2, 1, 16)   // feature.conv5
+    MVS_P2(32, 32, 3, 1, 0, 32)   // feature.conv6, feature.feature
+#undef MVS_P2
+    return false;
+}
+
+static bool persist2_enabled() {
+    const char *e = getenv("MVS_CONV2D_PERSISTENT");   // tuning / A-B: 0 = per-tile kernels
+    return !e || atoi(e) != 0;
+}
+
 struct Cfg2Info {
     int cin_pad, ck, mt, ty, ntaps;
     void (*kernel)(Conv2Args);
@@ -264,6 +324,9 @@ int conv2d_supported(int Cin, int Cout, int ksize, int stride) {
 }
 
 int64_t conv2d_packed_floats(int Cin, int Cout, int ksize, int stride) {
+    Persist2Info pi;
+    if (persist2_enabled() && lookup_persist2(Cin, Cout, ksize, stride, pi))
+        return (int64_t)pi.nchunk * ksize * pi.nkx * pi.mt * 128;
     Cfg2Info ci;
     if (!lookup2(Cin, Cout, ksize, stride, ci)) return 0;
     return (int64_t)(ci.cin_pad / ci.ck) * ci.ntaps * ci.mt * 64 * (ci.ck / 4);
@@ -271,6 +334,14 @@ int64_t conv2d_packed_floats(int Cin, int Cout, int ksize, int stride) {
 
 int conv2d_pack_launch(const float *weight, int Cin, int Cout, int ksize, int stride,
                        float *packed, hipStream_t st) {
+    Persist2Info pi;
+    if (persist2_enabled() && lookup_persist2(Cin, Cout, ksize, stride, pi)) {
+        PackP2Args pp{weight, packed, Cin, Cout, ksize, pi.nkx, pi.mt, pi.mode == 2};
+        const int64_t total = conv2d_packed_floats(Cin, Cout, ksize, stride);
+        hipLaunchKernelGGL(conv2d_pack_persistent_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
+                           0, st, pp, total);
+        return check_launch("mvs_conv2d_pack_weights_f32");
+    }
     Cfg2Info ci;
     if (!lookup2(Cin, Cout, ksize, stride, ci)) {
         set_error("mvs_conv2d_pack_weights_f32: no configuration for Cin=%d Cout=%d k=%d stride=%d",
@@ -287,6 +358,33 @@ int conv2d_pack_launch(const float *weight, int Cin, int Cout, int ksize, int st
 int conv2d_launch(const float *in, const float *packed, const float *scale, const float *shift,
                   int relu, int B, int Cin, int Cout, int H, int W, int ksize, int stride,
                   int in_planar, float *out, hipStream_t st) {
+    Persist2Info pi;
+    if (!in_planar && persist2_enabled() && lookup_persist2(Cin, Cout, ksize, stride, pi)) {
+        if ((int64_t)B * H * W * Cin >= (1ll << 40)) return MVS_EINVAL;
+        ConvArgs a;
+        a.in = in; a.wpk = packed; a.scale = scale; a.shift = shift; a.residual = nullptr; a.out = out;
+        a.B = 1; a.D = B; a.H = H; a.W = W;
+        const int pad = ksize / 2;
+        a.Do = B;
+        a.Ho = (H + 2 * pad - ksize) / stride + 1;
+        a.Wo = (W + 2 * pad - ksize) / stride + 1;
+        a.tiles_x = (a.Wo + pi.xout - 1) / pi.xout;
+        a.tiles_y = (a.Ho + pi.ty - 1) / pi.ty;
+        a.tiles_z = B;
+        a.relu = relu; a.in_c8 = 0; a.ystrip = 4;
+        const int64_t nt = (int64_t)a.tiles_x * a.tiles_y * a.tiles_z;
+        if (nt <= 0 || nt > 0x7fffffffLL) return MVS_EINVAL;
+        static int n_cu = 0;
+        if (n_cu == 0) {
+            int dev = 0, cu = 0;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0)
+                cu = 256;
+            n_cu = cu;
+        }
+        hipLaunchKernelGGL(pi.kernel, dim3((unsigned)(nt < n_cu ? nt : n_cu)), dim3(512), 0, st, a, (int)nt);
+        return check_launch("mvs_conv2d_f32(persistent)");
+    }
     Cfg2Info ci;
     if (!lookup2(Cin, Cout, ksize, stride, ci)) {
         set_error("mvs_conv2d_f32: no configuration for Cin=%d Cout=%d k=%d stride=%d", Cin, Cout,

@@ -26,14 +26,13 @@
 // this is conv0, 68 % of CostRegNet's FLOPs.
 #include <type_traits>
 #include "mvs_common.h"
+#include "conv_persistent.h"
 
 #include <cstdlib>
 
 namespace mvs {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int round_up_c(int v, int m) { return (v + m - 1) / m * m; }
 
 template <int CIN_, int COUT_, int MODE_, int CK_, int TZ_, int TY_, int SB_ = 8, int PREA_ = -1>
 struct ConvCfg {
@@ -67,53 +66,7 @@ struct ConvCfg {
     static_assert(MODE != 2 || COUT == 8, "MODE 2 is the Cout=8 shifted form");
 };
 
-struct ConvArgs {
-    const float *in, *wpk, *scale, *shift, *residual;
-    float *out;
-    int B, D, H, W;        // input dims
-    int Do, Ho, Wo;        // output dims
-    int tiles_x, tiles_y, tiles_z;
-    int relu;
-    int in_c8;   // input is [B,D,H,C/8,W,8] (8-channel blocked) instead of [B,D,H,W,C]
-    int ystrip;  // tile order: 0 = x, y, z; n > 0 = y within strips of n tile rows, then z, then x
-};
 
-// XCD-aware bijective remap: consecutive tiles land on the same XCD (same L2)
-// so halo re-reads of neighbouring tiles hit that L2 (guide T1).
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-}
-
-// Tile owned by a workgroup.  Tiles that share halo planes should run close together in
-// time on the same XCD so the re-read hits that XCD's 4-MiB L2: with `ystrip` the order is
-// y inside a strip of tile rows (fastest), then z, then x -- the y and z neighbours of a
-// tile are then at most one strip column (a few MiB of input) away instead of a whole
-// z-slab (tens of MiB).
-struct TileIdx { int tx, ty, tz, b; };
-__device__ __forceinline__ TileIdx decode_ordered_tile(const ConvArgs &a, int bid) {
-    TileIdx t;
-    if (a.ystrip <= 0) {
-        t.tx = bid % a.tiles_x; bid /= a.tiles_x;
-        t.ty = bid % a.tiles_y; bid /= a.tiles_y;
-        t.tz = bid % a.tiles_z;
-        t.b = bid / a.tiles_z;
-    } else {
-        const int per_b = a.tiles_x * a.tiles_y * a.tiles_z;
-        t.b = bid / per_b; bid -= t.b * per_b;
-        const int full = a.ystrip * a.tiles_z * a.tiles_x;
-        const int s = bid / full; bid -= s * full;
-        const int y0 = s * a.ystrip;
-        const int hs = min(a.ystrip, a.tiles_y - y0);   // the last strip may be short
-        t.ty = y0 + bid % hs; bid /= hs;
-        t.tz = bid % a.tiles_z;
-        t.tx = bid / a.tiles_z;
-    }
-    return t;
-}
-__device__ __forceinline__ TileIdx decode_tile(const ConvArgs &a, int blk, int nblk) {
-    return decode_ordered_tile(a, xcd_remap(blk, nblk));
-}
 
 // ABL (tuning builds only, selected by env MVS_CONV_ABLATE for the conv0 shape):
 // 1 = no staging loads, 2 = no A (weight) loads, 4 = no B (LDS) reads, 8 = no MFMA.
@@ -360,329 +313,6 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
 #undef MVS_STAMP
 }
 
-// ---------------------------------------------------------------------
-// conv0-class layers (Cout = 8, stride 1, 8-channel-blocked input) as a PERSISTENT,
-// DMA-fed kernel: one 512-thread workgroup per CU walks a list of (4,4,32)-voxel output
-// tiles.  Phase timestamps of the kernel above showed a third of every workgroup's life
-// in its VALU-heavy prologue / staging / epilogue, crawling beside the partner
-// workgroup's MFMA stream (VALU issue on a SIMD is arbitrated by age), so the matrix
-// pipe idled ~30 %.  Here
-//   * the whole layer's A fragments (Cin/8 x 18 KiB) live in LDS for the kernel's
-//     lifetime: no global load is ever waited on inside the MFMA loop;
-//   * the input halo of an 8-channel chunk goes HBM -> LDS with global_load_lds_dwordx4
-//     (no staging VGPRs, no ds_write pass, 5 DMA instructions per thread per chunk) into
-//     the buffer the MFMAs are NOT reading; chunk k+1 (of this tile or the next) is in
-//     flight during the MFMAs of chunk k, and there is one barrier per chunk;
-//   * all 8 waves do both jobs, so the two waves of a SIMD are always in the same phase.
-// LDS image of a chunk: [h = channel half][voxel][4 channels], voxel order (z,y,x') with
-// x de-interleaved as in MODE 2; lane (n,kq) reads channels 2kq, 2kq+1 of voxel n with
-// one ds_read_b64 -- the same channel <-> (k-step, kq) assignment as the kernel above,
-// so the packed weights are shared.
-__device__ const float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};   // source of out-of-volume halo voxels
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// One ds_read_b64 at a compile-time offset from a per-lane LDS byte address.  Written
-// as asm so that it STAYS a ds_read_b64 (64-bank rules, two 32-lane groups: conflict-free
-// for the 16-byte voxel stride used below): hipcc merges neighbouring b64 loads into
-// ds_read2_b64, which is serviced under 32-bank rules in 16-lane groups -- a 2-way
-// conflict on this layout that makes the reads, not the MFMAs, set the pace.  The
-// compiler does not see these loads complete: lds_wait<N>() is the matching s_waitcnt.
-template <int OFF>
-__device__ __forceinline__ f32x2 lds_read_b64(unsigned addr) {
-    static_assert(OFF >= 0 && OFF < 65536 && OFF % 8 == 0, "ds_read_b64 offset field");
-    f32x2 v;
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-    return v;
-}
-// wait until at most N LDS reads issued after the three tied ones are outstanding
-template <int N>
-__device__ __forceinline__ void lds_wait(f32x2 &a, f32x2 &b, f32x2 &c) {
-    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N));
-}
-// wait until at most N LDS operations are outstanding (pair with an empty asm "+v" on the
-// registers the landed reads wrote, so their consumers stay behind the wait)
-template <int N>
-__device__ __forceinline__ void lds_wait_n() {
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
-}
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-template <int CIN_, int COUT_ = 8, int MODE_ = 2, int TZ_ = 4, int TY_ = 4>
-struct PersistCfg {
-    static constexpr int CIN = CIN_, COUT = COUT_, MODE = MODE_, TZ = TZ_, TY = TY_;
-    static constexpr int NCHUNK = CIN / 8;
-    static constexpr int NKX = (MODE == 2) ? 4 : 3, NTAPS = 9 * NKX;
-    static constexpr int MT = (MODE == 2) ? 1 : COUT / 16;
-    static constexpr int SZY = (MODE == 1) ? 2 : 1;          // conv stride in y, z
-    static constexpr int XOUT = (MODE == 2) ? 32 : 16;
-    static constexpr int SX = (MODE == 0) ? 1 : 2;           // x step of a wave's B reads
-    static constexpr int XT = 15 * SX + NKX, XH = (XT + 1) / 2, XTP = (SX == 2) ? 2 * XH : XT;
-    static constexpr int YT = (TY - 1) * SZY + 3, ZT = (TZ - 1) * SZY + 3;
-    static constexpr int NVOX = ZT * YT * XTP;
-    static constexpr int PLANE = round_up_c(NVOX, 64);        // voxels per channel half
-    static constexpr int NDMA = 2 * PLANE / 64;               // wave-instructions per chunk
-    static constexpr int IPW = (NDMA + 7) / 8;                // per wave
-    static constexpr int ROWS = TZ * TY, RPW = ROWS / 8;      // (z,y) output rows per wave
-    static constexpr int W_FLOATS = NCHUNK * NTAPS * MT * 64 * 2;
-    static constexpr int BUF_FLOATS = 2 * PLANE * 4;
-    static constexpr int LDS_FLOATS = W_FLOATS + 2 * BUF_FLOATS;
-    // (MODE 0, stride 1 with Cout >= 16, is expressible but not instantiated: conv2 gained 9 %
-    // and its weights would need the 8-channel-chunk packing)
-    static_assert(MODE >= 0 && MODE <= 2, "MODE 0: stride 1; MODE 1: stride 2; MODE 2: Cout = 8 shifted form");
-    static_assert(MODE != 2 || COUT == 8, "MODE 2 is the Cout = 8 form");
-    static_assert(MODE == 2 || COUT % 16 == 0, "MODE 0/1 need whole 16-channel M tiles");
-    static_assert(ROWS % 8 == 0, "rows split over 8 waves");
-    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
-};
-
-template <class P, int ABL = 0>
-__global__ __launch_bounds__(512) void conv3d_c8_persistent_kernel(ConvArgs a, int ntiles) {
-    constexpr int CIN = P::CIN, COUT = P::COUT, MODE = P::MODE, MT = P::MT, RPW = P::RPW;
-    constexpr int NTAPS = P::NTAPS, NKX = P::NKX, XT = P::XT, XH = P::XH, XTP = P::XTP, YT = P::YT;
-    constexpr int PLANE = P::PLANE, IPW = P::IPW, SZY = P::SZY;
-    __shared__ __attribute__((aligned(16))) float lds[P::LDS_FLOATS];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = lane & 15, kq = lane >> 4;
-    const unsigned lds_base = (unsigned)(uintptr_t)lds;
-
-    // ---- tiles of this workgroup: XCD x (= blockIdx & 7) owns a contiguous range of the
-    // ordered tile list, its workgroups take that range round-robin, so the tiles in
-    // flight on one XCD are neighbours and share halo lines in that XCD's L2
-    int t_cur, t_end, t_step;
-    {
-        const int nb = gridDim.x;
-        if ((nb & 7) == 0) {
-            const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per = nb >> 3;
-            const int lo = (int)((int64_t)ntiles * xcd / 8), hi = (int)((int64_t)ntiles * (xcd + 1) / 8);
-            t_cur = lo + j; t_end = hi; t_step = per;
-        } else {
-            t_cur = blockIdx.x; t_end = ntiles; t_step = nb;
-        }
-    }
-
-    // ---- once: all A fragments -> LDS; tile-independent halo coordinates of this
-    // thread's DMA items (item i of wave w is DMA instruction g = i*8 + w of the chunk:
-    // channel half h = g / (PLANE/64), voxels (g % (PLANE/64))*64 + lane)
-    {
-        constexpr int NGR = P::W_FLOATS / 4;        // 16-byte granules
-        constexpr int NWI = (NGR + 63) / 64;        // wave-instructions (the last may be partial)
-        for (int i = wv; i < NWI; i += 8)
-            if (i * 64 + lane < NGR)
-                glds16(a.wpk + ((size_t)i * 64 + lane) * 4, lds_base + (unsigned)i * 1024u);
-    }
-    int loc[IPW];        // lx | ly << 8 | lz << 16 | h << 24 | invalid << 31 (as sign)
-#pragma unroll
-    for (int i = 0; i < IPW; ++i) {
-        const int g = min(i * 8 + wv, P::NDMA - 1);
-        const int h = g / (PLANE / 64), vb = g % (PLANE / 64);
-        const int v = vb * 64 + lane;
-        const int vc = min(v, P::NVOX - 1);
-        const int lxp = vc % XTP, t2 = vc / XTP;
-        const int ly = t2 % YT, lz = t2 / YT;
-        // x de-interleaved (evens, then odds) where a wave's B reads step by 2
-        const int lx = (P::SX == 1) ? lxp : (lxp < XH ? 2 * lxp : 2 * (lxp - XH) + 1);
-        loc[i] = lx | (ly << 8) | (lz << 16) | (h << 24) | ((v < P::NVOX && lx < XT) ? 0 : (int)0x80000000);
-    }
-
-    // input addressing: 8-channel-blocked [D,H,C/8,W,8] or channels-last [D,H,W,C]
-    const int64_t plane_in = (int64_t)a.H * a.W * CIN;   // floats per z-plane
-    const int row_in = a.W * CIN;                        // floats per (z,y) row
-    const int vox_in = a.in_c8 ? 8 : CIN;                // floats between x neighbours
-    const int ch_step = a.in_c8 ? a.W * 8 : 8;           // floats between 8-channel chunks
-
-    // geometry of one tile: source pointer of every DMA item for chunk 0, and its
-    // per-chunk step (0 for halo voxels outside the volume: they read the zero page)
-    const float *src[IPW];
-    int step[IPW];
-    TileIdx tile;
-    auto geometry = [&](int t) {
-        tile = decode_ordered_tile(a, t);
-        const int ix0 = tile.tx * P::XOUT * (MODE == 1 ? 2 : 1) - 1;
-        const int iy0 = tile.ty * P::TY * SZY - 1, iz0 = tile.tz * P::TZ * SZY - 1;
-        const float *in_b = a.in + (int64_t)tile.b * a.D * plane_in;
-#pragma unroll
-        for (int i = 0; i < IPW; ++i) {
-            const int gx = ix0 + (loc[i] & 255), gy = iy0 + ((loc[i] >> 8) & 255);
-            const int gz = iz0 + ((loc[i] >> 16) & 255), h = (loc[i] >> 24) & 1;
-            const bool ok = loc[i] >= 0 && (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H &&
-                            (unsigned)gz < (unsigned)a.D;
-            const float *p = in_b + (int64_t)gz * plane_in + (int64_t)gy * row_in + gx * vox_in + h * 4;
-            src[i] = ok ? p : g_zero_page;
-            step[i] = ok ? ch_step : 0;
-        }
-    };
-    auto issue = [&](int ch, int parity) {
-        const unsigned base = lds_base + (unsigned)(P::W_FLOATS + parity * P::BUF_FLOATS) * 4u;
-#pragma unroll
-        for (int i = 0; i < IPW; ++i) {
-            if (P::NDMA % 8 != 0 && i * 8 + wv >= P::NDMA) continue;   // wave-uniform
-            glds16(src[i] + (int64_t)ch * step[i], base + (unsigned)(i * 8 + wv) * 1024u);
-        }
-    };
-
-    // BatchNorm(eval) affine of this lane's output channels (4 per M tile)
-    float4 sc[MT], sh[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int c0 = (MODE == 2) ? (kq & 1) * 4 : m * 16 + kq * 4;
-        sc[m] = a.scale ? *reinterpret_cast<const float4 *>(a.scale + c0) : make_float4(1.f, 1.f, 1.f, 1.f);
-        sh[m] = a.shift ? *reinterpret_cast<const float4 *>(a.shift + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-
-    // per-lane LDS read bases (floats): B = plane kq>>1, voxel n, channel pair kq&1
-    const int rdB = ((kq >> 1) * PLANE + n) * 4 + (kq & 1) * 2;
-    int rowoff[RPW];
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-        const int row = wv * RPW + r;
-        rowoff[r] = (((row / P::TY) * SZY) * YT + (row % P::TY) * SZY) * XTP * 4;
-    }
-    const int rdA = lane * 2;
-
-    f32x4 acc[RPW][MT];
-#pragma unroll
-    for (int r = 0; r < RPW; ++r)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[r][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // ABL & 16 (tuning): cycles of wave 0 per phase, summed over the tiles of this
-    // workgroup, into the buffer passed as `residual`: [wait, barrier, issue, mfma, stores, drain]
-    long long tsum[6] = {0, 0, 0, 0, 0, 0};
-    long long tprev = 0;
-    if constexpr (ABL & 16) tprev = clock64();
-#define MVS_LAP(k) do { if constexpr (ABL & 16) { const long long tn = clock64(); tsum[k] += tn - tprev; tprev = tn; } } while (0)
-
-    int parity = 0;
-    if (t_cur < t_end) {
-        geometry(t_cur);
-        issue(0, 0);
-    }
-    while (t_cur < t_end) {
-        const TileIdx cur = tile;
-        const int t_next = t_cur + t_step;
-#pragma unroll 1
-        for (int ch = 0; ch < P::NCHUNK; ++ch) {
-            // this chunk's DMA (issued one phase ago) has landed for every wave, and
-            // every wave is done reading the other buffer
-            MVS_LAP(4);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            MVS_LAP(0);
-            __syncthreads();
-            MVS_LAP(1);
-            // next chunk (of this tile, or the first of the next one) -> the other buffer.
-            // (Issuing it a few taps into the MFMA stream, staggering it between the two
-            // waves of a SIMD, deferring a tile's stores into the next tile's stream, or
-            // hoisting the geometry were each measured: no gain.)
-            if (ch + 1 < P::NCHUNK) {
-                issue(ch + 1, parity ^ 1);
-            } else if (t_next < t_end) {
-                geometry(t_next);
-                issue(0, parity ^ 1);
-            }
-            MVS_LAP(2);
-            // ---- MFMA stream of the chunk: per tap MT A reads and one B read per row,
-            // software-pipelined PD taps ahead through PD+1 register slots; LDS returns in
-            // order, so "tap t has landed" is lgkmcnt <= (MT+RPW) x (taps issued after it)
-            const unsigned aA = lds_base + (unsigned)(ch * (NTAPS * MT * 64 * 2) + rdA) * 4u;
-            unsigned aB[RPW];
-#pragma unroll
-            for (int r = 0; r < RPW; ++r)
-                aB[r] = lds_base + (unsigned)(P::W_FLOATS + parity * P::BUF_FLOATS + rdB + rowoff[r]) * 4u;
-            constexpr int PD = 3, NRD = MT + RPW;
-            f32x2 fa[PD + 1][MT], fb[PD + 1][RPW];
-            auto fetch = [&](auto tc) {
-                constexpr int t = decltype(tc)::value;
-                constexpr int kz = t / (3 * NKX), ky = (t / NKX) % 3, kx = t % NKX;
-                constexpr int xoff = (P::SX == 1) ? kx : (kx & 1) * XH + (kx >> 1);
-                constexpr int boff = ((kz * YT + ky) * XTP + xoff) * 16;
-                static_for<0, MT>([&](auto mc) {
-                    constexpr int m = decltype(mc)::value;
-                    fa[t % (PD + 1)][m] = lds_read_b64<(t * MT + m) * 512>(aA);
-                });
-#pragma unroll
-                for (int r = 0; r < RPW; ++r) fb[t % (PD + 1)][r] = lds_read_b64<boff>(aB[r]);
-            };
-            static_for<0, PD>(fetch);
-            static_for<0, NTAPS>([&](auto tc) {
-                constexpr int t = decltype(tc)::value;
-                constexpr int sl = t % (PD + 1);
-                if constexpr (t + PD < NTAPS) fetch(std::integral_constant<int, t + PD>{});
-                constexpr int newer = (t + PD < NTAPS ? PD : NTAPS - 1 - t);
-                lds_wait_n<NRD * newer>();
-#pragma unroll
-                for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(fa[sl][m]));
-#pragma unroll
-                for (int r = 0; r < RPW; ++r) asm volatile("" : "+v"(fb[sl][r]));
-                if constexpr (ABL & 8) {
-#pragma unroll
-                    for (int r = 0; r < RPW; ++r) asm volatile("" ::"v"(fa[sl][0]), "v"(fb[sl][r]));
-                } else {
-                    // same accumulation order as conv3d_mfma_kernel: per (tap, row, M tile) k-step 0, 1
-#pragma unroll
-                    for (int r = 0; r < RPW; ++r)
-#pragma unroll
-                        for (int m = 0; m < MT; ++m) {
-                            acc[r][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl][m].x, fb[sl][r].x, acc[r][m], 0, 0, 0);
-                            acc[r][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl][m].y, fb[sl][r].y, acc[r][m], 0, 0, 0);
-                        }
-                }
-            });
-            parity ^= 1;
-            MVS_LAP(3);
-        }
-        // ---- epilogue of `cur`: BN affine, ReLU, skip add, one 16-byte store per lane, row, M tile
-        if constexpr (ABL & 16) {
-            asm volatile("" : "+v"(acc[0][0]));
-            asm volatile("s_nop 0" ::: "memory");
-            MVS_LAP(5);
-        }
-        {
-            const int ox = (MODE == 2) ? cur.tx * P::XOUT + 2 * n + (kq >> 1) : cur.tx * P::XOUT + n;
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                const int row = wv * RPW + r;
-                const int oz = cur.tz * P::TZ + row / P::TY, oy = cur.ty * P::TY + row % P::TY;
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    f32x4 v = acc[r][m];
-                    acc[r][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo) continue;
-                    const int c0 = (MODE == 2) ? (kq & 1) * 4 : m * 16 + kq * 4;
-                    v[0] = v[0] * sc[m].x + sh[m].x; v[1] = v[1] * sc[m].y + sh[m].y;
-                    v[2] = v[2] * sc[m].z + sh[m].z; v[3] = v[3] * sc[m].w + sh[m].w;
-                    if (a.relu) {
-                        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
-                        v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-                    }
-                    const int64_t o = ((((int64_t)cur.b * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * COUT + c0;
-                    if (a.residual && !(ABL & 16)) {
-                        const float4 rs = *reinterpret_cast<const float4 *>(a.residual + o);
-                        v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
-                    }
-                    *reinterpret_cast<float4 *>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
-                }
-            }
-        }
-        t_cur = t_next;
-    }
-    if constexpr (ABL & 16) {
-        MVS_LAP(4);
-        if (tid == 0) {
-            long long *dbg = reinterpret_cast<long long *>(const_cast<float *>(a.residual)) + (int64_t)blockIdx.x * 8;
-            for (int k = 0; k < 6; ++k) dbg[k] = tsum[k];
-        }
-    }
-#undef MVS_LAP
-}
 
 // ---------------------------------------------------------------------
 // Double-buffered form of the same convolution (one 512-thread block per CU, two LDS
