@@ -22,19 +22,19 @@ for name in ("fetch", "write"):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for f in glob.glob(f"{root}/pmc_{name}/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            k = row["Kernel_Name"].split("(")[0][:90]
+            k = row["Kernel_Name"].split("(")[0][:110]
             agg[k][0] += 1
             agg[k][1] += float(row["Counter_Value"])
     out[name.upper() + "_SIZE_per_launch_KB"] = {k: round(v[1] / v[0], 1) for k, v in
                                                  sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]}
 json.dump(out, open(f"{root}/summary.json", "w"), indent=1)
 # per-stage HBM-side traffic for bench.py's roofline.traffic (2*FETCH + WRITE, bytes)
-names = {"costvol_variance": "variance_fwd_lds_kernel", "costreg.conv0": "conv3d_c8_persistent_kernel<32",
-         "costreg.conv1": "ConvCfg<8, 16, 1", "costreg.conv2": "ConvCfg<16, 16, 0",
+names = {"costvol_variance": "variance_fwd_dma_kernel", "costreg.conv0": "PersistCfg<32, 8, 2, 4, 4, 3",
+         "costreg.conv1": "PersistCfg<8, 16, 1, 2, 4, 3", "costreg.conv2": "ConvCfg<16, 16, 0",
          "costreg.conv4": "ConvCfg<32, 32, 0", "costreg.conv11": "DeconvCfg<16, 8",
          "costreg.prob": "conv3d_cout1_kernel<8>", "softmax_regress_conf": "softmax_regress_conf_kernel",
-         "feature.conv0": "Conv2Cfg<4, 8, 3, 1", "feature.conv1": "Conv2Cfg<8, 8, 3, 1",
-         "feature.conv2": "Conv2Cfg<8, 16, 5, 2"}
+         "feature.conv0": "Conv2Cfg<4, 8, 3, 1", "feature.conv1": "PersistCfg<8, 8, 2, 1, 32, 1",
+         "feature.conv2": "PersistCfg<8, 16, 1, 1, 16, 1"}
 F, W = out["FETCH_SIZE_per_launch_KB"], out["WRITE_SIZE_per_launch_KB"]
 def find(d, sub):
     return next((v for k, v in d.items() if sub in k), None)
