@@ -283,6 +283,12 @@ static bool lookup_persist2(int Cin, int Cout, int ksize, int stride, Persist2In
     MVS_P2(16, 16, 3, 1, 0, 32)   // feature.conv3, conv4
     MVS_P2(16, 32, 5, 2, 1, 16)   // feature.conv5
     MVS_P2(32, 32, 3, 1, 0, 32)   // feature.conv6, feature.feature
+    // CasMVSNet FPN heads (CasMVSNet/models/module.py:330-341)
+    MVS_P2(32, 32, 1, 1, 0, 32)   // out1
+    MVS_P2(16, 32, 1, 1, 0, 32)   // inner1
+    MVS_P2(8, 32, 1, 1, 0, 32)    // inner2
+    MVS_P2(32, 16, 3, 1, 0, 32)   // out2
+    MVS_P2(32, 8, 3, 1, 2, 32)    // out3
 #undef MVS_P2
     return false;
 }
@@ -319,6 +325,8 @@ static bool lookup2(int Cin, int Cout, int ksize, int stride, Cfg2Info &ci) {
 }
 
 int conv2d_supported(int Cin, int Cout, int ksize, int stride) {
+    Persist2Info pi;
+    if (persist2_enabled() && lookup_persist2(Cin, Cout, ksize, stride, pi)) return 1;
     Cfg2Info ci;
     return lookup2(Cin, Cout, ksize, stride, ci) ? 1 : 0;
 }

@@ -77,6 +77,67 @@ class FeatureNet(nn.Module):
         out["stage3"] = self.out3(top)
         return out
 
+    # -- inference path on the HIP 2D kernels (BatchNorm folded), channels-last features
+    def _hip_params(self):
+        params = list(self.parameters()) + list(self.buffers())
+        key = tuple((p._version, p.data_ptr()) for p in params)
+        cache = getattr(self, "_hip_cache", None)
+        if cache is not None and cache[0] == key:
+            return cache[1]
+
+        def cbr(m, stride):
+            w = m.conv.weight.detach().float().contiguous()
+            scale = (m.bn.weight / torch.sqrt(m.bn.running_var + m.bn.eps)).float().contiguous()
+            shift = (m.bn.bias - m.bn.running_mean * scale).float().contiguous()
+            return dict(cin=w.shape[1], cout=w.shape[0], k=w.shape[2], stride=stride,
+                        packed=ops.pack_conv2d_weight(w, stride), scale=scale, shift=shift, relu=True)
+
+        def plain(m):
+            w = m.weight.detach().float().contiguous()
+            return dict(cin=w.shape[1], cout=w.shape[0], k=w.shape[2], stride=1,
+                        packed=ops.pack_conv2d_weight(w, 1), scale=None,
+                        shift=None if m.bias is None else m.bias.detach().float().contiguous(), relu=False)
+
+        with torch.no_grad():
+            P = {"conv0": [cbr(self.conv0[0], 1), cbr(self.conv0[1], 1)],
+                 "conv1": [cbr(self.conv1[0], 2), cbr(self.conv1[1], 1), cbr(self.conv1[2], 1)],
+                 "conv2": [cbr(self.conv2[0], 2), cbr(self.conv2[1], 1), cbr(self.conv2[2], 1)],
+                 "out1": plain(self.out1), "inner1": plain(self.inner1), "inner2": plain(self.inner2),
+                 "out2": plain(self.out2), "out3": plain(self.out3)}
+        self._hip_cache = (key, P)
+        return P
+
+    def hip_supported(self):
+        P = self._hip_params()
+        flat = [q for v in P.values() for q in (v if isinstance(v, list) else [v])]
+        return all(q["packed"] is not None for q in flat)
+
+    def forward_hip(self, imgs_nchw):
+        """[N,3,H,W] -> {"stage1": [N,H/4,W/4,32], "stage2": [N,H/2,W/2,16], "stage3": [N,H,W,8]}
+        channels-last (module.py:343-405; the nearest x2 upsample + lateral add stay torch ops)."""
+        P = self._hip_params()
+
+        def run(x, p, planar=False):
+            return ops.conv2d(x, p["packed"], p["cin"], p["cout"], p["k"], p["stride"], p["scale"], p["shift"],
+                              p["relu"], planar=planar)
+
+        def up2(t):   # nearest-neighbour x2 on [N,H,W,C]
+            return t.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+
+        c0 = run(run(imgs_nchw, P["conv0"][0], planar=True), P["conv0"][1])
+        c1 = c0
+        for p in P["conv1"]:
+            c1 = run(c1, p)
+        top = c1
+        for p in P["conv2"]:
+            top = run(top, p)
+        out = {"stage1": run(top, P["out1"])}
+        top = up2(top) + run(c1, P["inner1"])
+        out["stage2"] = run(top, P["out2"])
+        top = up2(top) + run(c0, P["inner2"])
+        out["stage3"] = run(top, P["out3"])
+        return out
+
 
 class CostRegNet(nn.Module):
     """module.py:407-438; holds the parameters (state_dict contract) -- the arithmetic runs in
@@ -134,7 +195,7 @@ def depth_hypotheses(cur_depth, ndepth, interval, shape):
 
 class CascadeMVSNet(nn.Module):
     def __init__(self, refine=False, ndepths=(48, 32, 8), depth_interals_ratio=(4, 2, 1),
-                 cr_base_chs=(8, 8, 8), proj_where="host"):
+                 cr_base_chs=(8, 8, 8), proj_where="host", feature_impl="hip"):
         super().__init__()
         if refine:
             raise NotImplementedError("the reference never enables refine (test.py:168)")
@@ -143,6 +204,7 @@ class CascadeMVSNet(nn.Module):
         self.depth_interals_ratio = list(depth_interals_ratio)
         self.num_stage = 3
         self.proj_where = proj_where
+        self.feature_impl = feature_impl   # "hip": 2D MFMA kernels; "torch": PyTorch-ROCm / MIOpen
         self.stage_scale = {"stage1": 4, "stage2": 2, "stage3": 1}
         self.feature = FeatureNet(base_channels=8)
         self.cost_regularization = nn.ModuleList(
@@ -152,8 +214,13 @@ class CascadeMVSNet(nn.Module):
         B, V, _, H, W = imgs.shape
         depth_min, depth_max = float(depth_values[0, 0]), float(depth_values[0, -1])
         depth_interval = (depth_max - depth_min) / depth_values.size(1)
+        use_hip = self.feature_impl == "hip" and not self.training and self.feature.hip_supported()
         with ops.stage("feature"):
-            feats = [self.feature(imgs[:, v]) for v in range(V)]
+            if use_hip:   # all views in one batch; channels-last pyramids, split per view
+                pyr = self.feature.forward_hip(imgs.reshape(B * V, 3, H, W))
+                feats = [{k: t.reshape(B, V, *t.shape[1:])[:, v] for k, t in pyr.items()} for v in range(V)]
+            else:
+                feats = [self.feature(imgs[:, v]) for v in range(V)]
         outputs, depth = {}, None
         for s in range(3):
             key = f"stage{s + 1}"
@@ -173,7 +240,8 @@ class CascadeMVSNet(nn.Module):
                 raise NotImplementedError("CascadeMVSNet here is the inference path (config 3)")
             out = cascade.depthnet_forward(stage_feats, proj_matrices[key], hyp,
                                            self.cost_regularization[s].hip_params(),
-                                           proj_where=self.proj_where, tag=key + ".")
+                                           proj_where=self.proj_where, tag=key + ".",
+                                           features_cl=use_hip)
             depth = out["depth"]
             outputs[key] = out
             outputs.update(out)

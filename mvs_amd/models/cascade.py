@@ -63,8 +63,8 @@ def costreg_forward(x_cl, P, impl=ops.IMPL_AUTO):
 
 
 def depthnet_forward(features, cas_proj, depth_values, costreg_params, prob_volume_init=None,
-                     proj_where="host", tag=""):
-    """features: list of V tensors [B,C,H,W]; cas_proj [B,V,2,4,4]; depth_values [B,D,H,W]
+                     proj_where="host", tag="", features_cl=False):
+    """features: list of V tensors [B,C,H,W] ([B,H,W,C] with features_cl); cas_proj [B,V,2,4,4]; depth_values [B,D,H,W]
     -> {"depth", "photometric_confidence"} as DepthNet.forward (cas_mvsnet.py:12-66)."""
     # like rot_trans, the K @ E composition is evaluated where the reference's CPU forward
     # evaluates it (host) unless told otherwise: the depth is sensitive to its rounding
@@ -73,8 +73,12 @@ def depthnet_forward(features, cas_proj, depth_values, costreg_params, prob_volu
         proj = compose_cas_proj(cas_proj.cpu() if proj_where == "host" else cas_proj)
         rts = ops.rot_trans_all(proj, proj_where, device=dev)
     with ops.stage(tag + "to_channels_last"):
-        ref = ops.nchw_to_nhwc(features[0])
-        srcs = torch.stack([ops.nchw_to_nhwc(f) for f in features[1:]])
+        if features_cl:   # [B,H,W,C] already (the HIP FeatureNet's layout)
+            ref = features[0].contiguous()
+            srcs = torch.stack([f for f in features[1:]])
+        else:
+            ref = ops.nchw_to_nhwc(features[0])
+            srcs = torch.stack([ops.nchw_to_nhwc(f) for f in features[1:]])
     with ops.stage(tag + "costvol_variance"):
         var = ops.costvol_variance_cl(ref, srcs, rts, depth_values)
     with ops.stage(tag + "costreg"):

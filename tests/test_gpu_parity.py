@@ -649,6 +649,18 @@ def test_cascade_stages_golden(dev):
             np.testing.assert_allclose(out["photometric_confidence"].cpu().numpy(), g[key + "_conf"], atol=2e-4)
 
 
+def test_cascade_fpn_hip_golden(dev):
+    """FPN FeatureNet on the HIP 2D kernels (trunk, 1x1 laterals, 3x3 heads incl. the shifted
+    Cout = 8 form) vs the reference's FeatureNet outputs for the reference view."""
+    g, net, _ = _cascade_case(dev)
+    assert net.feature.hip_supported()
+    with torch.no_grad():
+        pyr = net.feature.forward_hip(G(g["imgs"], dev)[0])
+    for key in ("stage1", "stage2", "stage3"):
+        got = pyr[key][0].permute(2, 0, 1).cpu().numpy()
+        np.testing.assert_allclose(got, g[key + "_feat_ref"][0], atol=2e-5, rtol=1e-4)
+
+
 def test_cascade_end_to_end_golden(dev):
     """The whole cascade through the reference's model API: final and per-stage depth maps."""
     g, net, proj = _cascade_case(dev)
