@@ -368,7 +368,7 @@ int conv2d_launch(const float *in, const float *packed, const float *scale, cons
                   int in_planar, float *out, hipStream_t st) {
     Persist2Info pi;
     if (!in_planar && persist2_enabled() && lookup_persist2(Cin, Cout, ksize, stride, pi)) {
-        if ((int64_t)B * H * W * Cin >= (1ll << 40)) return MVS_EINVAL;
+        if ((int64_t)H * W * Cin * 4 >= 0xffffff00LL) return MVS_EINVAL;   // 32-bit offsets inside one image
         ConvArgs a;
         a.in = in; a.wpk = packed; a.scale = scale; a.shift = shift; a.residual = nullptr; a.out = out;
         a.B = 1; a.D = B; a.H = H; a.W = W;

@@ -1059,7 +1059,9 @@ int conv3d_mfma_launch(const float *in, const float *packed, const float *scale,
                               ((Cin == 8 && Cout == 16) || (Cin == 16 && Cout == 32));
         const char *var = getenv("MVS_CONV0_VARIANT");
         const int v = var ? atoi(var) : 0;
-        if ((c8_class || s2_class) && (v == 0 || v >= 20)) {
+        // (its copies address a tile's halo planes with 32-bit byte offsets)
+        const bool window_ok = (int64_t)9 * H * W * Cin * 4 < 0xffffff00LL;
+        if ((c8_class || s2_class) && window_ok && (v == 0 || v >= 20)) {
             static int n_cu = 0;
             if (n_cu == 0) {
                 int dev = 0, cu = 0;

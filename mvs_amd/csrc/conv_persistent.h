@@ -205,33 +205,38 @@ __global__ __launch_bounds__(512) void conv3d_c8_persistent_kernel(ConvArgs a, i
     const int vox_in = a.in_c8 ? 8 : CIN;                // floats between x neighbours
     const int ch_step = a.in_c8 ? a.W * 8 : 8;           // floats between 8-channel chunks
 
-    // geometry of one tile: source pointer of every DMA item for chunk 0, and its
-    // per-chunk step (0 for halo voxels outside the volume: they read the zero page)
-    const float *src[IPW];
-    int step[IPW];
+    // geometry of one tile.  The copies are buffer-addressed: a resource descriptor whose base
+    // is the first halo plane of the tile (wave-uniform, SGPRs), a per-lane byte offset that
+    // is the same for every channel chunk, and the chunk offset in an SGPR -- re-issuing the
+    // copy for the next chunk costs no vector ALU work (a wave's VALU issue crawls beside its
+    // partner's MFMA stream).  Halo voxels outside the volume get an offset past
+    // num_records: the hardware returns zeros for them.
+    unsigned voff[IPW];
+    mvs_srd_t srd;
     TileIdx tile;
+    const unsigned window_bytes = (unsigned)min((int64_t)P::ZT * plane_in * 4, (int64_t)0xffffff00u);
     auto geometry = [&](int t) {
         tile = decode_ordered_tile(a, t);
         const int ix0 = tile.tx * P::XOUT * (MODE == 1 ? 2 : 1) - P::KH / 2;
         const int iy0 = tile.ty * P::TY * SZY - P::KH / 2, iz0 = tile.tz * P::TZ * P::SZ - P::KD / 2;
-        const float *in_b = a.in + (int64_t)tile.b * a.D * plane_in;
+        srd = make_srd(a.in + ((int64_t)tile.b * a.D + iz0) * plane_in, window_bytes);
 #pragma unroll
         for (int i = 0; i < IPW; ++i) {
             const int gx = ix0 + (loc[i] & 255), gy = iy0 + ((loc[i] >> 8) & 255);
-            const int gz = iz0 + ((loc[i] >> 16) & 255), h = (loc[i] >> 24) & 1;
+            const int lz = (loc[i] >> 16) & 255, h = (loc[i] >> 24) & 1;
             const bool ok = loc[i] >= 0 && (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H &&
-                            (unsigned)gz < (unsigned)a.D;
-            const float *p = in_b + (int64_t)gz * plane_in + (int64_t)gy * row_in + gx * vox_in + h * 4;
-            src[i] = ok ? p : g_zero_page;
-            step[i] = ok ? ch_step : 0;
+                            (unsigned)(iz0 + lz) < (unsigned)a.D;
+            voff[i] = ok ? (unsigned)(((int64_t)lz * plane_in + (int64_t)gy * row_in + gx * vox_in + h * 4) * 4)
+                         : 0xffffff00u;
         }
     };
     auto issue = [&](int ch, int parity) {
         const unsigned base = lds_base + (unsigned)(P::W_FLOATS + parity * P::BUF_FLOATS) * 4u;
+        const unsigned soff = (unsigned)(ch * ch_step * 4);
 #pragma unroll
         for (int i = 0; i < IPW; ++i) {
             if (P::NDMA % 8 != 0 && i * 8 + wv >= P::NDMA) continue;   // wave-uniform
-            glds16(src[i] + (int64_t)ch * step[i], base + (unsigned)(i * 8 + wv) * 1024u);
+            glds16_buf(voff[i], srd, soff, base + (unsigned)(i * 8 + wv) * 1024u);
         }
     };
 

@@ -109,6 +109,29 @@ __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_byte_addr)
                  : "v"(gsrc), "s"(lds_byte_addr)
                  : "memory");
 }
+// The same copy addressed through a buffer resource: 16 bytes at (srd.base + soffset +
+// voffset) per lane.  voffset is a per-lane VGPR that does not change between chunks and
+// soffset a wave-uniform SGPR, so re-issuing a tile's copy for the next channel chunk costs
+// no vector ALU work; lanes whose voffset is beyond srd.num_records fetch zeros.
+typedef int mvs_srd_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ mvs_srd_t make_srd(const void *base, unsigned bytes) {
+    const unsigned long long b = (unsigned long long)base;
+    mvs_srd_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));   // stride 0, no swizzle
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;                                                  // raw dword buffer
+    return r;
+}
+__device__ __forceinline__ void glds16_buf(unsigned voffset, mvs_srd_t srd, unsigned soffset,
+                                           unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voffset), "s"(srd), "s"(soffset), "s"(lds_byte_addr)
+                 : "memory");
+}
 #endif
 
 }  // namespace mvs
