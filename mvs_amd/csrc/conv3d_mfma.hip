@@ -752,12 +752,16 @@ __global__ __launch_bounds__(256) void conv3d_cout1_kernel(ConvArgs a, const flo
     const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
     const float *in_b = a.in + (int64_t)b * a.D * a.H * a.W * CIN;
     {
-        // halo tile HBM -> LDS by DMA, planes [q][voxel][4 channels]: instruction i of wave
-        // w covers voxels (i*4 + w)*64 + lane of every channel quad q; out-of-volume
-        // voxels (and the plane's tail) read the zero page
+        // halo tile HBM -> LDS by buffer-addressed DMA, planes [q][voxel][4 channels]:
+        // instruction i of wave w covers voxels (i*4 + w)*64 + lane of every channel quad q;
+        // the descriptor's base is the tile's first halo plane, out-of-volume voxels (and the
+        // plane's tail) get an offset past num_records and fetch zeros
         const int lane = tid & 63;
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
         const unsigned lds_base = (unsigned)(uintptr_t)lds;
+        const int64_t plane_in = (int64_t)a.H * a.W * CIN;
+        const mvs_srd_t srd = make_srd(in_b + (int64_t)(z0 - 1) * plane_in,
+                                       (unsigned)min((int64_t)ZT * plane_in * 4, (int64_t)0xffffff00u));
         constexpr int NI = PLANE / 64 / 4;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -768,10 +772,11 @@ __global__ __launch_bounds__(256) void conv3d_cout1_kernel(ConvArgs a, const flo
             const int gx = x0 + vx - 1, gy = y0 + vy - 1, gz = z0 + vz - 1;
             const bool ok = v < NVOX && (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H &&
                             (unsigned)gz < (unsigned)a.D;
-            const float *p = in_b + (((int64_t)gz * a.H + gy) * a.W + gx) * CIN;
+            const unsigned off = ok ? (unsigned)(((int64_t)vz * plane_in + ((int64_t)gy * a.W + gx) * CIN) * 4)
+                                    : 0xffffff00u;
 #pragma unroll
             for (int q = 0; q < CQ; ++q)
-                glds16(ok ? p + q * 4 : g_zero_page, lds_base + (unsigned)((q * PLANE + vb * 64) * 16));
+                glds16_buf(off, srd, (unsigned)(q * 16), lds_base + (unsigned)((q * PLANE + vb * 64) * 16));
         }
         for (int i = tid; i < 27 * CIN; i += 256) {
             const int kyx = i / (3 * CIN), r = i - kyx * (3 * CIN), kz = r / CIN, ci = r - kz * CIN;

@@ -81,7 +81,6 @@ __device__ __forceinline__ TileIdx decode_tile(const ConvArgs &a, int blk, int n
 // x de-interleaved as in MODE 2; lane (n,kq) reads channels 2kq, 2kq+1 of voxel n with
 // one ds_read_b64 -- the same channel <-> (k-step, kq) assignment as the kernel above,
 // so the packed weights are shared.
-static __device__ const float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};   // source of out-of-volume halo voxels
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 

@@ -786,14 +786,18 @@ __global__ __launch_bounds__(256, 3) void variance_fwd_dma_kernel(
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             if (!staged[v] || (ablate & 1)) continue;
-            const float *src = srcs16 + (((size_t)v * p.B + b) * ngroups + g) * grp_floats + wv * 4;
+            // buffer-addressed: descriptor = this view's 16-channel group (SGPRs), per-lane
+            // offsets fixed for the whole block -> no vector ALU work per copy
+            const mvs_srd_t srd = make_srd(
+                srcs16 + (((size_t)v * p.B + b) * ngroups + g) * grp_floats + wv * 4,
+                (unsigned)(grp_floats * 4));
             const int n = bw[v] * bh[v];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 if (j * 64 >= n) continue;                       // wave-uniform
                 if (j * 64 + lane < cap)                         // the last instruction may be partial
-                    glds16(src + soff[v][j],
-                           lds_base + (unsigned)(((v * 4 + wv) * cap + j * 64) * 16));
+                    glds16_buf((unsigned)soff[v][j] * 4u, srd, 0u,
+                               lds_base + (unsigned)(((v * 4 + wv) * cap + j * 64) * 16));
             }
         }
     };
