@@ -113,9 +113,14 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
     // and its ds_writes land on 16 consecutive slots of one plane (conflict-free).
     constexpr int NITEMS = round_up_c(NVOX, 16) * 4;   // whole 64-item groups (16 voxels x 4 pieces)
     constexpr int NIT = (NITEMS + 255) / 256;
-    static_assert(NIT <= 32, "okmask is 32 bits");
-    int g_off[NIT];
-    unsigned okmask = 0;
+    // Loads are buffer-addressed: descriptor base = the tile's first halo plane, a per-lane
+    // byte offset fixed for all chunks (halo voxels outside the volume get one past
+    // num_records and load zeros: no clamps, no selects), the chunk offset in an SGPR.
+    unsigned voff[NIT];
+    const int64_t plane_in = (int64_t)a.H * a.W * CIN;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(in_b + (int64_t)iz0 * plane_in), 0,
+        (int)(unsigned)min((int64_t)Cfg::ZT * plane_in * 4, (int64_t)0xffffff00u), 0x00020000);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int e = tid + it * 256;
@@ -128,11 +133,9 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
         const int gx = ix0 + lx, gy = iy0 + ly, gz = iz0 + lz;
         const bool ok = v < NVOX && lx < XT && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H &&
                         gz >= 0 && gz < a.D;
-        const int cx = min(max(gx, 0), a.W - 1), cy = min(max(gy, 0), a.H - 1);
-        const int cz = min(max(gz, 0), a.D - 1);
-        g_off[it] = a.in_c8 ? (((cz * a.H + cy) * (CIN / 8)) * a.W + cx) * 8 + ekq * KS
-                            : ((cz * a.H + cy) * a.W + cx) * CIN + ekq * KS;
-        okmask |= ok ? (1u << it) : 0u;
+        const int64_t off = a.in_c8 ? ((((int64_t)lz * a.H + gy) * (CIN / 8)) * a.W + gx) * 8 + ekq * KS
+                                    : (((int64_t)lz * a.H + gy) * a.W + gx) * CIN + ekq * KS;
+        voff[it] = ok ? (unsigned)(off * 4) : 0xffffff00u;
     }
     const int ch_step = a.in_c8 ? a.W * 8 * (CK / 8) : CK;
     MVS_STAMP(1);
@@ -168,16 +171,16 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < SB; ++j) {
                     if (it0 + j >= NIT) continue;
-                    const float *src = in_b + g_off[it0 + j] + ch * ch_step;
                     if constexpr (ABL & 1) {
 #pragma unroll
-                        for (int k = 0; k < KS; ++k) stg[j][k] = (float)(g_off[it0 + j] + k);
+                        for (int k = 0; k < KS; ++k) stg[j][k] = (float)(voff[it0 + j] + k);
                     } else if constexpr (KS == 4) {
-                        const float4 val = *reinterpret_cast<const float4 *>(src);
-                        stg[j][0] = val.x; stg[j][1] = val.y; stg[j][2] = val.z; stg[j][3] = val.w;
+                        const auto val = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[it0 + j], ch * ch_step * 4, 0);
+                        stg[j][0] = __uint_as_float(val[0]); stg[j][1] = __uint_as_float(val[1]);
+                        stg[j][2] = __uint_as_float(val[2]); stg[j][3] = __uint_as_float(val[3]);
                     } else {
-                        const float2 val = *reinterpret_cast<const float2 *>(src);
-                        stg[j][0] = val.x; stg[j][1] = val.y;
+                        const auto val = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff[it0 + j], ch * ch_step * 4, 0);
+                        stg[j][0] = __uint_as_float(val[0]); stg[j][1] = __uint_as_float(val[1]);
                     }
                 }
 #pragma unroll
@@ -186,15 +189,11 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
                     const int e = tid + (it0 + j) * 256;
                     const int ekq = (e >> 4) & 3, v = ((e >> 6) << 4) | (e & 15);
                     if (e >= NITEMS || v >= NVOX) continue;
-                    const bool ok = (okmask >> (it0 + j)) & 1u;
                     float *dst = lds + (ekq * PLANE + v) * KS;
                     if constexpr (KS == 4)
-                        *reinterpret_cast<float4 *>(dst) =
-                            make_float4(ok ? stg[j][0] : 0.f, ok ? stg[j][1] : 0.f,
-                                        ok ? stg[j][2] : 0.f, ok ? stg[j][3] : 0.f);
+                        *reinterpret_cast<float4 *>(dst) = make_float4(stg[j][0], stg[j][1], stg[j][2], stg[j][3]);
                     else
-                        *reinterpret_cast<float2 *>(dst) =
-                            make_float2(ok ? stg[j][0] : 0.f, ok ? stg[j][1] : 0.f);
+                        *reinterpret_cast<float2 *>(dst) = make_float2(stg[j][0], stg[j][1]);
                 }
             }
         }
