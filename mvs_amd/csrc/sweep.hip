@@ -730,7 +730,7 @@ __device__ __forceinline__ void accumulate_taps_planar(const float *__restrict__
 }
 
 template <int NV, bool CORNER>
-__global__ __launch_bounds__(256, 3) void variance_fwd_dma_kernel(
+__global__ __launch_bounds__(256, 2) void variance_fwd_dma_kernel(
     const float *__restrict__ ref16, const float *__restrict__ srcs16,
     const float *__restrict__ rt, const float *__restrict__ depth, SweepParams p,
     int tiles_x, int tiles_y, float *__restrict__ out, int out_c8, int ablate) {
