@@ -68,9 +68,7 @@ struct ConvCfg {
 
 
 
-// ABL (tuning builds only, selected by env MVS_CONV_ABLATE for the conv0 shape):
-// 1 = no staging loads, 2 = no A (weight) loads, 4 = no B (LDS) reads, 8 = no MFMA.
-template <class Cfg, int ABL = 0>
+template <class Cfg>
 __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
     constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, MODE = Cfg::MODE, CK = Cfg::CK;
     constexpr int KS = Cfg::KS, MT = Cfg::MT, RPW = Cfg::RPW, TY = Cfg::TY, TZ = Cfg::TZ;
@@ -87,14 +85,6 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
     const int ox0 = tx * Cfg::XOUT, oy0 = ty * TY, oz0 = tz * TZ;
     const int ix0 = (MODE == 1 ? 2 * ox0 : ox0) - 1;
     const int iy0 = oy0 * SZY - 1, iz0 = oz0 * SZY - 1;
-
-    // ABL & 16 (tuning): phase timestamps of wave 0 into the buffer passed as `residual`
-    long long *dbg = nullptr;
-    if constexpr (ABL & 16) {
-        dbg = reinterpret_cast<long long *>(const_cast<float *>(a.residual)) + (int64_t)blockIdx.x * 32;
-        if (tid == 0) dbg[0] = clock64();
-    }
-#define MVS_STAMP(k) do { if constexpr (ABL & 16) { if (tid == 0) dbg[k] = clock64(); } } while (0)
 
     f32x4 acc[RPW][MT];
 #pragma unroll
@@ -138,13 +128,12 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
         voff[it] = ok ? (unsigned)(off * 4) : 0xffffff00u;
     }
     const int ch_step = a.in_c8 ? a.W * 8 * (CK / 8) : CK;
-    MVS_STAMP(1);
 
 #pragma unroll 1
     for (int ch = 0; ch < Cfg::NCHUNK; ++ch) {
         const float *wch = a.wpk + (int64_t)ch * NTAPS * MT * 64 * KS + lane * KS;
         float apre[Cfg::PREA ? NTAPS : 1][MT][KS];
-        if constexpr (Cfg::PREA && !(ABL & 2)) {
+        if constexpr (Cfg::PREA) {
 #pragma unroll
             for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
@@ -160,7 +149,6 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
                 }
         }
         if (ch) __syncthreads();
-        MVS_STAMP(2 + ch * 4);
         // ---- stage the halo tile of CK channels: global -> LDS planes, SB loads in
         // flight per thread per batch (the volume streams from HBM)
         {
@@ -171,10 +159,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < SB; ++j) {
                     if (it0 + j >= NIT) continue;
-                    if constexpr (ABL & 1) {
-#pragma unroll
-                        for (int k = 0; k < KS; ++k) stg[j][k] = (float)(voff[it0 + j] + k);
-                    } else if constexpr (KS == 4) {
+                    if constexpr (KS == 4) {
                         const auto val = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[it0 + j], ch * ch_step * 4, 0);
                         stg[j][0] = __uint_as_float(val[0]); stg[j][1] = __uint_as_float(val[1]);
                         stg[j][2] = __uint_as_float(val[2]); stg[j][3] = __uint_as_float(val[3]);
@@ -197,9 +182,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
                 }
             }
         }
-        MVS_STAMP(3 + ch * 4);
         __syncthreads();
-        MVS_STAMP(4 + ch * 4);
 
         constexpr int KZ_UNROLL = Cfg::PREA ? 3 : 1;
 #pragma unroll KZ_UNROLL
@@ -214,10 +197,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     const float *wp = wkz + (kyx * MT + m) * 64 * KS;
-                    if constexpr (ABL & 2) {
-#pragma unroll
-                        for (int k = 0; k < KS; ++k) af[m][k] = (float)(lane + kyx + k);
-                    } else if constexpr (Cfg::PREA) {
+                    if constexpr (Cfg::PREA) {
 #pragma unroll
                         for (int k = 0; k < KS; ++k) af[m][k] = apre[kz * 3 * NKX + kyx][m][k];
                     } else if constexpr (KS == 4) {
@@ -234,10 +214,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
                     const int zr = row / TY, yr = row % TY;
                     const float *rp = rdz + (((zr * SZY) * YT + (yr * SZY + ky)) * XTP + xoff) * KS;
                     float bf[KS];
-                    if constexpr (ABL & 4) {
-#pragma unroll
-                        for (int k = 0; k < KS; ++k) bf[k] = (float)(lane + r + k);
-                    } else if constexpr (KS == 4) {
+                    if constexpr (KS == 4) {
                         float4 t = *reinterpret_cast<const float4 *>(rp);
                         bf[0] = t.x; bf[1] = t.y; bf[2] = t.z; bf[3] = t.w;
                     } else {
@@ -248,221 +225,13 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
                         for (int s = 0; s < KS; ++s) {
-                            if constexpr (ABL & 8) {
-                                asm volatile("" ::"v"(af[m][s]), "v"(bf[s]));   // keep the loads live
-                            } else {
-                                acc[r][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                    af[m][s], bf[s], acc[r][m], 0, 0, 0);
-                            }
+                            acc[r][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][s], bf[s], acc[r][m], 0, 0, 0);
                         }
                 }
             }
         }
-        MVS_STAMP(5 + ch * 4);
     }
-    {
     // ---- epilogue: BN affine, ReLU, skip add, one 16-byte store per lane
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-        const int row = wv * RPW + r;
-        const int oz = oz0 + row / TY, oy = oy0 + row % TY;
-        if (oz >= a.Do || oy >= a.Ho) continue;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            int ox, c0;
-            if (MODE == 2) {
-                ox = ox0 + 2 * n + (kq >> 1);
-                c0 = (kq & 1) * 4;
-            } else {
-                ox = ox0 + n;
-                c0 = m * 16 + kq * 4;
-            }
-            if (ox >= a.Wo || c0 >= COUT) continue;
-            f32x4 v = acc[r][m];
-            if (a.scale) {
-                const float4 sc = *reinterpret_cast<const float4 *>(a.scale + c0);
-                v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
-            }
-            if (a.shift) {
-                const float4 sh = *reinterpret_cast<const float4 *>(a.shift + c0);
-                v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w;
-            }
-            if (a.relu) {
-                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
-                v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-            }
-            const int64_t o = ((((int64_t)b * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * COUT + c0;
-            if (a.residual && !(ABL & 16)) {
-                const float4 rs = *reinterpret_cast<const float4 *>(a.residual + o);
-                v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
-            }
-            *reinterpret_cast<float4 *>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
-        }
-    }
-    }
-    if constexpr (ABL & 16) {
-        if (tid == 0) {
-            dbg[18] = clock64();
-            unsigned xcc, hwid;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-            dbg[19] = ((long long)xcc << 32) | hwid;
-        }
-    }
-#undef MVS_STAMP
-}
-
-
-// ---------------------------------------------------------------------
-// Double-buffered form of the same convolution (one 512-thread block per CU, two LDS
-// halo tiles).  While the 8 waves run the MFMA loop on chunk c out of buffer c&1, the
-// halo of chunk c+1 is already in flight from HBM into registers (issued before the
-// loop, written to the other buffer after it): HBM latency sits entirely under the
-// matrix phase, and there is ONE barrier per chunk.  The chunk's weight fragments are
-// loaded into registers first, so every wait inside the MFMA loop is on loads older
-// than the prefetch (vmcnt retires in order) or on LDS.
-template <class Cfg>
-__global__ __launch_bounds__(512) void conv3d_mfma_db_kernel(ConvArgs a) {
-    constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, MODE = Cfg::MODE, CK = Cfg::CK;
-    constexpr int KS = Cfg::KS, MT = Cfg::MT, TY = Cfg::TY, TZ = Cfg::TZ;
-    constexpr int SX = Cfg::SX, SZY = Cfg::SZY, NKX = Cfg::NKX, NTAPS = Cfg::NTAPS;
-    constexpr int XT = Cfg::XT, YT = Cfg::YT, XH = Cfg::XH, XTP = Cfg::XTP;
-    constexpr int NVOX = Cfg::NVOX, PLANE = Cfg::PLANE, NCHUNK = Cfg::NCHUNK;
-    constexpr int RPW = Cfg::ROWS / 8;                       // rows per wave, 8 waves
-    constexpr int NIT = (4 * NVOX + 511) / 512;              // staging items per thread
-    constexpr int BUF = Cfg::LDS_FLOATS;
-    static_assert(Cfg::ROWS % 8 == 0, "rows split over 8 waves");
-    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int n = lane & 15, kq = lane >> 4;
-    const TileIdx tile = decode_tile(a, blockIdx.x, gridDim.x);
-    const int tx = tile.tx, ty = tile.ty, tz = tile.tz, b = tile.b;
-    const int ox0 = tx * Cfg::XOUT, oy0 = ty * TY, oz0 = tz * TZ;
-    const int ix0 = (MODE == 1 ? 2 * ox0 : ox0) - 1;
-    const int iy0 = oy0 * SZY - 1, iz0 = oz0 * SZY - 1;
-    const float *in_b = a.in + (int64_t)b * a.D * a.H * a.W * CIN;
-
-    // ---- staging geometry of this thread's items (the same for every chunk)
-    int g_off[NIT];        // element offset of the item's voxel inside the batch item
-    int l_off[NIT];        // LDS float offset inside a buffer, -1 = no item
-    unsigned okmask = 0;   // bit it: the item lies inside the volume (else zero padding)
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int e = tid + it * 512;
-        const int ec = min(e, 4 * NVOX - 1);
-        const int ekq = ec & 3, v = ec >> 2;
-        const int lxp = v % XTP, t2 = v / XTP;
-        const int ly = t2 % YT, lz = t2 / YT;
-        const int lx = (SX == 2) ? (lxp < XH ? 2 * lxp : 2 * (lxp - XH) + 1) : lxp;
-        const int gx = ix0 + lx, gy = iy0 + ly, gz = iz0 + lz;
-        const bool ok = lx < XT && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H && gz >= 0 &&
-                        gz < a.D;
-        const int cx = min(max(gx, 0), a.W - 1), cy = min(max(gy, 0), a.H - 1);
-        const int cz = min(max(gz, 0), a.D - 1);
-        // chunk-independent part; the chunk adds ch*CK (NHWC) or ch*W*8 (C8, CK == 8)
-        g_off[it] = a.in_c8 ? (((cz * a.H + cy) * (CIN / 8)) * a.W + cx) * 8 + ekq * KS
-                            : ((cz * a.H + cy) * a.W + cx) * CIN + ekq * KS;
-        l_off[it] = e < 4 * NVOX ? (ekq * PLANE + v) * KS : -1;
-        okmask |= ok ? (1u << it) : 0u;
-    }
-    const int ch_step = a.in_c8 ? a.W * 8 * (CK / 8) : CK;
-    static_assert(NIT <= 32, "okmask is 32 bits");
-
-    float pre[NIT][KS];
-    auto issue = [&](int ch) {
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const float *src = in_b + g_off[it] + ch * ch_step;
-            if constexpr (KS == 4) {
-                const float4 t = *reinterpret_cast<const float4 *>(src);
-                pre[it][0] = t.x; pre[it][1] = t.y; pre[it][2] = t.z; pre[it][3] = t.w;
-            } else {
-                const float2 t = *reinterpret_cast<const float2 *>(src);
-                pre[it][0] = t.x; pre[it][1] = t.y;
-            }
-        }
-    };
-    auto commit = [&](float *buf) {
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            if (l_off[it] < 0) continue;
-            const bool ok = (okmask >> it) & 1u;
-            if constexpr (KS == 4)
-                *reinterpret_cast<float4 *>(buf + l_off[it]) =
-                    make_float4(ok ? pre[it][0] : 0.f, ok ? pre[it][1] : 0.f,
-                                ok ? pre[it][2] : 0.f, ok ? pre[it][3] : 0.f);
-            else
-                *reinterpret_cast<float2 *>(buf + l_off[it]) =
-                    make_float2(ok ? pre[it][0] : 0.f, ok ? pre[it][1] : 0.f);
-        }
-    };
-
-    f32x4 acc[RPW][MT];
-#pragma unroll
-    for (int r = 0; r < RPW; ++r)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[r][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int rd_base = (kq * PLANE + n) * KS;
-
-    issue(0);
-    commit(lds);
-    __syncthreads();
-
-#pragma unroll 1
-    for (int ch = 0; ch < NCHUNK; ++ch) {
-        const float *buf = lds + (ch & 1) * BUF;
-        // weight fragments of this chunk first (older than the prefetch below)
-        const float *wch = a.wpk + (int64_t)ch * NTAPS * MT * 64 * KS + lane * KS;
-        float apre[NTAPS][MT][KS];
-#pragma unroll
-        for (int t = 0; t < NTAPS; ++t)
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const float *wp = wch + (t * MT + m) * 64 * KS;
-                if constexpr (KS == 4) {
-                    const float4 w4 = *reinterpret_cast<const float4 *>(wp);
-                    apre[t][m][0] = w4.x; apre[t][m][1] = w4.y; apre[t][m][2] = w4.z; apre[t][m][3] = w4.w;
-                } else {
-                    const float2 w2 = *reinterpret_cast<const float2 *>(wp);
-                    apre[t][m][0] = w2.x; apre[t][m][1] = w2.y;
-                }
-            }
-        if (ch + 1 < NCHUNK) issue(ch + 1);   // next halo: in flight during the MFMA loop
-
-#pragma unroll
-        for (int kz = 0; kz < 3; ++kz) {
-            const float *rdz = buf + rd_base + kz * (YT * XTP) * KS;
-#pragma unroll
-            for (int kyx = 0; kyx < 3 * NKX; ++kyx) {
-                const int ky = kyx / NKX, kx = kyx % NKX;
-                const int xoff = (SX == 2) ? ((kx & 1) * XH + (kx >> 1)) : kx;
-#pragma unroll
-                for (int r = 0; r < RPW; ++r) {
-                    const int row = wv * RPW + r;
-                    const int zr = row / TY, yr = row % TY;
-                    const float *rp = rdz + (((zr * SZY) * YT + (yr * SZY + ky)) * XTP + xoff) * KS;
-                    float bf[KS];
-                    if constexpr (KS == 4) {
-                        const float4 t = *reinterpret_cast<const float4 *>(rp);
-                        bf[0] = t.x; bf[1] = t.y; bf[2] = t.z; bf[3] = t.w;
-                    } else {
-                        const float2 t = *reinterpret_cast<const float2 *>(rp);
-                        bf[0] = t.x; bf[1] = t.y;
-                    }
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-#pragma unroll
-                        for (int s2 = 0; s2 < KS; ++s2)
-                            acc[r][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                apre[kz * 3 * NKX + kyx][m][s2], bf[s2], acc[r][m], 0, 0, 0);
-                }
-            }
-        }
-        if (ch + 1 < NCHUNK) commit(lds + ((ch + 1) & 1) * BUF);
-        __syncthreads();
-    }
-
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const int row = wv * RPW + r;
@@ -909,7 +678,7 @@ struct CfgInfo {
 template <class Cfg>
 static CfgInfo info_of() {
     return CfgInfo{Cfg::MODE, Cfg::CK, Cfg::MT, Cfg::TZ, Cfg::TY, Cfg::XOUT, Cfg::NTAPS,
-                   conv3d_mfma_kernel<Cfg, 0>};
+                   conv3d_mfma_kernel<Cfg>};
 }
 
 template <class Cfg>
@@ -1101,39 +870,7 @@ int conv3d_mfma_launch(const float *in, const float *packed, const float *scale,
             return check_launch("mvs_conv3d_f32(mfma, persistent)");
         }
     }
-    void (*kern)(ConvArgs) = ci.kernel;
-    int threads = 256;
-    if (!transposed && Cin == 32 && Cout == 8 && stride == 1) {   // tuning hook, conv0 only
-        const char *abl = getenv("MVS_CONV_ABLATE");
-        using C0 = ConvCfg<32, 8, 2, 8, 4, 8>;
-        switch (abl ? atoi(abl) : 0) {
-            case 1: kern = conv3d_mfma_kernel<C0, 1>; break;
-            case 2: kern = conv3d_mfma_kernel<C0, 2>; break;
-            case 4: kern = conv3d_mfma_kernel<C0, 4>; break;
-            case 8: kern = conv3d_mfma_kernel<C0, 8>; break;
-            case 3: kern = conv3d_mfma_kernel<C0, 3>; break;
-            case 7: kern = conv3d_mfma_kernel<C0, 7>; break;
-            case 9: kern = conv3d_mfma_kernel<C0, 9>; break;
-            case 10: kern = conv3d_mfma_kernel<C0, 10>; break;
-            case 12: kern = conv3d_mfma_kernel<C0, 12>; break;
-            case 14: kern = conv3d_mfma_kernel<C0, 14>; break;
-            case 15: kern = conv3d_mfma_kernel<C0, 15>; break;
-            case 16: kern = conv3d_mfma_kernel<ConvCfg<32, 8, 2, 8, 4, 8, 16, 0>, 16>; break;
-            case 23: kern = conv3d_mfma_kernel<ConvCfg<32, 8, 2, 8, 4, 8, 16, 0>, 23>; break;
-            default: break;
-        }
-        const char *var = getenv("MVS_CONV0_VARIANT");   // tuning: staging depth / A preload
-        switch (var ? atoi(var) : 0) {
-            case 1: kern = conv3d_mfma_kernel<ConvCfg<32, 8, 2, 8, 4, 8, 8, 0>, 0>; break;
-            case 2: kern = conv3d_mfma_kernel<ConvCfg<32, 8, 2, 8, 4, 8, 16, 0>, 0>; break;
-            case 3: kern = conv3d_mfma_kernel<ConvCfg<32, 8, 2, 8, 4, 8, 32, 0>, 0>; break;
-            case 4: kern = conv3d_mfma_kernel<ConvCfg<32, 8, 2, 8, 4, 8, 16, 1>, 0>; break;
-            case 5: kern = conv3d_mfma_kernel<ConvCfg<32, 8, 2, 8, 4, 8, 32, 1>, 0>; break;
-            case 9: kern = conv3d_mfma_db_kernel<ConvCfg<32, 8, 2, 8, 4, 8>>; threads = 512; break;
-            default: break;
-        }
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(threads), 0, st, a);
+    hipLaunchKernelGGL(ci.kernel, dim3((unsigned)nblk), dim3(256), 0, st, a);
     return check_launch("mvs_conv3d_f32(mfma)");
 }
 

@@ -343,16 +343,13 @@ __global__ __launch_bounds__(256) void variance_fwd_cl_kernel(
 // over 4 consecutive depth planes (256 voxels, lane = voxel).  For every source
 // view the block computes, at run time, the bounding box of all texels its
 // voxels' bilinear taps touch (an arbitrary homography: no geometry is assumed),
-// copies that footprint into LDS 16 channels at a time, and samples from LDS
-// (256 B/clk/CU, conflict-free: a 16-channel texel half is padded from 64 to
-// 80 bytes so 16 neighbouring texels cover all 64 banks).  A footprint that does
-// not fit its LDS share (extreme baselines) falls back to global gathers for that
-// view -- same arithmetic, slower.  Features come 16-channel blocked:
-// [B,C/16,H,W,16], so a footprint row is one contiguous run in memory.
-// Arithmetic is identical to the other kernels (pre-masked weights, FMA order):
-// results are bit-identical to them.
+// copies that footprint into LDS 16 channels at a time by DMA, and samples from LDS
+// (256 B/clk/CU).  A footprint that does not fit its LDS share (extreme baselines)
+// falls back to global gathers for that view -- same arithmetic, slower.  Features
+// come 16-channel blocked: [B,C/16,H,W,16], so a footprint row is one contiguous run
+// in memory.  Arithmetic is identical to the other kernels (pre-masked weights, FMA
+// order): results are bit-identical to them.
 constexpr int kTileW = 8, kTileH = 8, kTileD = 4;   // square tile: compact footprints under rotation
-constexpr int kTexelPad = 20;   // floats per staged 16-channel texel half (16 + 4 pad)
 
 // 16 channels of one view: bilinear blend of the four taps, then S += w, Q += w*w
 // (mvsnet.py:164-165).  Four channels at a time so at most 4 float4 loads are live.
@@ -381,11 +378,6 @@ __device__ __forceinline__ void accumulate_taps(const float *__restrict__ t00,
     }
 }
 
-// LDS share per view (texels): 48 KiB in total keeps 2-3 blocks per CU
-__host__ __device__ constexpr int lds_cap(int nv) {
-    return (48 * 1024) / (nv * kTexelPad * 4) > 256 ? 256 : (48 * 1024) / (nv * kTexelPad * 4);
-}
-
 // CORNER (shared depth planes only): the footprint box of a source view is taken from
 // the projections of the block's 8 corner voxels instead of a reduction over all 256
 // voxels.  Per depth plane the map pixel -> source is a homography, so (all Z > 0) the
@@ -395,308 +387,15 @@ __host__ __device__ constexpr int lds_cap(int nv) {
 // barriers fewer, and the staging loads go out before the per-voxel arithmetic.  A wave
 // whose taps are not all inside the (1-texel padded) box -- never observed -- samples
 // that view from global memory instead, so the result cannot depend on the argument.
-template <int NV, bool CORNER>
-__global__ __launch_bounds__(256, 3) void variance_fwd_lds_kernel(
-    const float *__restrict__ ref16, const float *__restrict__ srcs16,
-    const float *__restrict__ rt, const float *__restrict__ depth, SweepParams p,
-    int tiles_x, int tiles_y, float *__restrict__ out, int out_c8, int ablate) {
-    constexpr int cap = lds_cap(NV);
-    constexpr int MAXIT = (cap * 4 + 255) / 256;
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // NV * cap * kTexelPad
-    __shared__ int s_box[NV][4];                                   // xmin, ymin, xmax, ymax
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    // Block order: depth chunk fastest, and consecutive blocks on the same XCD (blockIdx
-    // round-robins the 8 XCDs).  The footprints of one pixel tile move by a fraction of a
-    // texel per depth plane, so the depth chunks of a tile re-read the same source lines out
-    // of that XCD's L2; ordered by tile first, every depth chunk swept all source maps
-    // (61 MB at config 2, > L2) again.  (ablate & 64: the plain x, y, depth order.)
-    int tx, ty, dc;
-    if (!(ablate & 64)) {
-        const int nwg = gridDim.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
-        int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + ((int)blockIdx.x >> 3);
-        const int ndc = nwg / (tiles_x * tiles_y);
-        dc = bid % ndc; bid /= ndc;
-        tx = bid % tiles_x;
-        ty = bid / tiles_x;
-    } else {
-        int bid = blockIdx.x;
-        tx = bid % tiles_x; bid /= tiles_x;
-        ty = bid % tiles_y;
-        dc = bid / tiles_y;
-    }
-    const int b = blockIdx.y;
-    const int px = tx * kTileW + (lane & (kTileW - 1)), py = ty * kTileH + lane / kTileW;
-    const int d = dc * kTileD + wv;
-    const bool live = px < p.W && py < p.H && d < p.D;
-    const int cx = min(px, p.W - 1), cy = min(py, p.H - 1), cd = min(d, p.D - 1);
-    const int plane = p.H * p.W;
-    const int pix = cy * p.W + cx;
-    const float dv = p.depth_mode == 0 ? depth[(int64_t)b * p.D + cd]
-                                       : depth[((int64_t)b * p.D + cd) * plane + pix];
-    int bx0[NV], by0[NV], bw[NV], bh[NV];
-    bool staged[NV];
-    if constexpr (CORNER) {
-        // ---- phase 0: boxes from the 8 corner voxels, lane = (view, corner)
-        const int v0 = lane >> 3, k = lane & 7;
-        const int xlo = tx * kTileW, xhi = min(tx * kTileW + kTileW - 1, p.W - 1);
-        const int ylo = ty * kTileH, yhi = min(ty * kTileH + kTileH - 1, p.H - 1);
-        const int dlo = dc * kTileD, dhi = min(dc * kTileD + kTileD - 1, p.D - 1);
-        const float *r = rt + ((int64_t)min(v0, NV - 1) * p.B + b) * 12;
-        const float cxk = (float)((k & 1) ? xhi : xlo), cyk = (float)((k & 2) ? yhi : ylo);
-        const float dk = depth[(int64_t)b * p.D + ((k & 4) ? dhi : dlo)];
-        float rx, ry, rz, ix, iy;
-        sweep_ray(r, cxk, cyk, rx, ry, rz);
-        sweep_coord(r, rx, ry, rz, dk, p.half_w, p.half_h, p.unn_w, p.unn_h, p.align_corners, ix,
-                    iy);
-        const bool zok = (rz * dk + r[11]) > 1e-6f && fabsf(ix) < 1.0e9f && fabsf(iy) < 1.0e9f;
-        int lo_x = (int)floorf(ix) - 1, hi_x = (int)floorf(ix) + 2;
-        int lo_y = (int)floorf(iy) - 1, hi_y = (int)floorf(iy) + 2;
-        int bad = zok ? 0 : 1;
-#pragma unroll
-        for (int off = 1; off <= 4; off <<= 1) {
-            lo_x = min(lo_x, __shfl_xor(lo_x, off)); hi_x = max(hi_x, __shfl_xor(hi_x, off));
-            lo_y = min(lo_y, __shfl_xor(lo_y, off)); hi_y = max(hi_y, __shfl_xor(hi_y, off));
-            bad |= __shfl_xor(bad, off);
-        }
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            int x0 = max(__builtin_amdgcn_readlane(lo_x, v * 8), 0);
-            int x1 = min(__builtin_amdgcn_readlane(hi_x, v * 8), p.W - 1);
-            int y0 = max(__builtin_amdgcn_readlane(lo_y, v * 8), 0);
-            int y1 = min(__builtin_amdgcn_readlane(hi_y, v * 8), p.H - 1);
-            const int vbad = __builtin_amdgcn_readlane(bad, v * 8);
-            const bool empty = x1 < x0 || y1 < y0;       // footprint entirely off the image
-            if (empty) { x0 = y0 = x1 = y1 = 0; }
-            bx0[v] = x0; by0[v] = y0; bw[v] = x1 - x0 + 1; bh[v] = y1 - y0 + 1;
-            staged[v] = !vbad && bw[v] * bh[v] <= cap;
-        }
-    } else {
-        if (tid < NV) {
-            s_box[tid][0] = 0x7fffffff; s_box[tid][1] = 0x7fffffff;
-            s_box[tid][2] = -1; s_box[tid][3] = -1;
-        }
-        __syncthreads();
-    }
-
-    // ---- phase A: homography + tap set per source view (registers), footprint boxes
-    float wnw[NV], wne[NV], wsw[NV], wse[NV];
-    int tx0[NV], ty0[NV];
-    bool wave_in[NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) wave_in[v] = true;
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        const float *r = rt + ((int64_t)v * p.B + b) * 12;
-        float rx, ry, rz, ix, iy;
-        if (ablate & 4) {   // tuning: no homography arithmetic
-            ix = (float)cx + 0.25f + r[3] * 1e-30f; iy = (float)cy + 0.25f;
-        } else {
-            sweep_ray(r, (float)cx, (float)cy, rx, ry, rz);
-            sweep_coord(r, rx, ry, rz, dv, p.half_w, p.half_h, p.unn_w, p.unn_h, p.align_corners,
-                        ix, iy);
-        }
-        Taps t = make_taps(ix, iy, p.H, p.W);
-        const bool fin = (fabsf(ix) <= 3.0e38f) && (fabsf(iy) <= 3.0e38f);
-        const float dead = fin ? 0.0f : __int_as_float(0x7fc00000);
-        const bool m00 = t.x0ok && t.y0ok, m01 = t.x1ok && t.y0ok;
-        const bool m10 = t.x0ok && t.y1ok, m11 = t.x1ok && t.y1ok;
-        wnw[v] = m00 ? t.nw : dead; wne[v] = m01 ? t.ne : dead;
-        wsw[v] = m10 ? t.sw : dead; wse[v] = m11 ? t.se : dead;
-        // integer position of the (x0,y0) tap; x1 = x0+1, y1 = y0+1.  Saturate far-away
-        // coordinates so the int conversion is defined; their weights are dead anyway.
-        const float x0f = fminf(fmaxf(floorf(ix), -4.0f), (float)p.W + 4.0f);
-        const float y0f = fminf(fmaxf(floorf(iy), -4.0f), (float)p.H + 4.0f);
-        tx0[v] = fin ? (int)x0f : -4;
-        ty0[v] = fin ? (int)y0f : -4;
-        // box over the texels that carry a live weight
-        const bool anyx = t.x0ok || t.x1ok, anyy = t.y0ok || t.y1ok;
-        int lo_x = 0x7fffffff, hi_x = -1, lo_y = 0x7fffffff, hi_y = -1;
-        if (anyx && anyy) {
-            lo_x = t.x0ok ? tx0[v] : tx0[v] + 1;
-            hi_x = t.x1ok ? tx0[v] + 1 : tx0[v];
-            lo_y = t.y0ok ? ty0[v] : ty0[v] + 1;
-            hi_y = t.y1ok ? ty0[v] + 1 : ty0[v];
-        }
-        if constexpr (CORNER) {
-            // safety net: is every live tap of this wave inside the staged box?
-            const bool inbox = !(anyx && anyy) ||
-                               (lo_x >= bx0[v] && hi_x < bx0[v] + bw[v] && lo_y >= by0[v] &&
-                                hi_y < by0[v] + bh[v]);
-            wave_in[v] = __all(inbox);
-        } else {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                lo_x = min(lo_x, __shfl_xor(lo_x, off)); hi_x = max(hi_x, __shfl_xor(hi_x, off));
-                lo_y = min(lo_y, __shfl_xor(lo_y, off)); hi_y = max(hi_y, __shfl_xor(hi_y, off));
-            }
-            if (lane == 0) {
-                atomicMin(&s_box[v][0], lo_x); atomicMin(&s_box[v][1], lo_y);
-                atomicMax(&s_box[v][2], hi_x); atomicMax(&s_box[v][3], hi_y);
-            }
-        }
-    }
-    if constexpr (!CORNER) __syncthreads();
-
-#pragma unroll
-    for (int v = 0; v < NV && !CORNER; ++v) {
-        // block-uniform: keep the boxes in SGPRs
-        int x0 = __builtin_amdgcn_readfirstlane(s_box[v][0]);
-        int y0 = __builtin_amdgcn_readfirstlane(s_box[v][1]);
-        int x1 = __builtin_amdgcn_readfirstlane(s_box[v][2]);
-        int y1 = __builtin_amdgcn_readfirstlane(s_box[v][3]);
-        if (x1 < x0 || y1 < y0) { x0 = y0 = x1 = y1 = 0; }   // no live tap in this block
-        bx0[v] = x0; by0[v] = y0; bw[v] = x1 - x0 + 1; bh[v] = y1 - y0 + 1;
-        staged[v] = bw[v] * bh[v] <= cap;
-    }
-
-    const int ngroups = p.C >> 4;
-    const float rV = 1.0f / p.fV;
-    const size_t grp_floats = (size_t)plane * 16;   // one 16-channel group of one map
-#pragma unroll 1
-    for (int g = 0; g < ngroups; ++g) {
-        if (g) __syncthreads();
-        // make the tap positions opaque per iteration: otherwise LICM hoists every
-        // view's 4 LDS offsets + 4 64-bit fallback pointers out of this loop and spills
-#pragma unroll
-        for (int v = 0; v < NV; ++v) asm volatile("" : "+v"(tx0[v]), "+v"(ty0[v]));
-        // reference-view channels of this voxel: issued first, consumed after the barrier
-        float4 ref4[4];
-        {
-            const float4 *rp = reinterpret_cast<const float4 *>(
-                ref16 + ((size_t)b * ngroups + g) * grp_floats + (size_t)pix * 16);
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                ref4[k] = (ablate & 16) ? make_float4(1.f, 2.f, 3.f, 4.f) : rp[k];
-        }
-        // ---- stage the footprints of this channel group.  All loads of all views
-        // are issued before the first LDS write (MAXIT*NV float4 in flight per thread):
-        // a one-load-at-a-time copy loop is pure L2 latency.
-        {
-            float4 sv4[NV][MAXIT];
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const float *src = srcs16 + (((size_t)v * p.B + b) * ngroups + g) * grp_floats;
-                const int n4 = (staged[v] && !(ablate & 1)) ? bw[v] * bh[v] * 4 : 0;
-                const unsigned inv = (65536u + bw[v] - 1) / bw[v];   // t / bw for t < cap
-#pragma unroll
-                for (int it = 0; it < MAXIT; ++it) {
-                    const int e = tid + it * 256;
-                    const int ec = min(e, max(n4 - 1, 0));
-                    const int t = ec >> 2, piece = ec & 3;
-                    const int ly = (int)(((unsigned)t * inv) >> 16), lx = t - ly * bw[v];
-                    sv4[v][it] = *reinterpret_cast<const float4 *>(
-                        src + ((size_t)(by0[v] + ly) * p.W + (bx0[v] + lx)) * 16 + piece * 4);
-                }
-            }
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const int n4 = staged[v] ? bw[v] * bh[v] * 4 : 0;
-                float *dst = lds + v * cap * kTexelPad;
-#pragma unroll
-                for (int it = 0; it < MAXIT; ++it) {
-                    const int e = tid + it * 256;
-                    if (e < n4)
-                        *reinterpret_cast<float4 *>(dst + (e >> 2) * kTexelPad + (e & 3) * 4) =
-                            sv4[v][it];
-                }
-            }
-        }
-        __syncthreads();
-
-        // ---- accumulate S, Q over the views for this voxel's 16 channels
-        float S[16], Q[16];
-        {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float4 r4 = ref4[k];
-                const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    Q[k * 4 + c] = rr[c] * rr[c];
-                    S[k * 4 + c] = p.alias_quirk ? Q[k * 4 + c] : rr[c];
-                }
-            }
-        }
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            if (ablate & 2) continue;   // tuning: no tap accumulation
-            // staged: clamp the tap into the staged box (typed LDS pointer -> ds_read);
-            // else: clamp into the image and gather from global.  Taps that fall outside
-            // carry a zero (or NaN) weight, so any in-range finite texel will do.
-            if (staged[v] && wave_in[v]) {
-                const int x0c = min(max(tx0[v], bx0[v]), bx0[v] + bw[v] - 1) - bx0[v];
-                const int x1c = min(max(tx0[v] + 1, bx0[v]), bx0[v] + bw[v] - 1) - bx0[v];
-                const int y0c = min(max(ty0[v], by0[v]), by0[v] + bh[v] - 1) - by0[v];
-                const int y1c = min(max(ty0[v] + 1, by0[v]), by0[v] + bh[v] - 1) - by0[v];
-                const float *base = lds + v * cap * kTexelPad;
-                accumulate_taps(base + (y0c * bw[v] + x0c) * kTexelPad,
-                                base + (y0c * bw[v] + x1c) * kTexelPad,
-                                base + (y1c * bw[v] + x0c) * kTexelPad,
-                                base + (y1c * bw[v] + x1c) * kTexelPad, wnw[v], wne[v], wsw[v],
-                                wse[v], S, Q);
-            } else {
-                const float *base = srcs16 + (((size_t)v * p.B + b) * ngroups + g) * grp_floats;
-                const int x0c = min(max(tx0[v], 0), p.W - 1), x1c = min(max(tx0[v] + 1, 0), p.W - 1);
-                const int y0c = min(max(ty0[v], 0), p.H - 1), y1c = min(max(ty0[v] + 1, 0), p.H - 1);
-                accumulate_taps(base + ((size_t)y0c * p.W + x0c) * 16,
-                                base + ((size_t)y0c * p.W + x1c) * 16,
-                                base + ((size_t)y1c * p.W + x0c) * 16,
-                                base + ((size_t)y1c * p.W + x1c) * 16, wnw[v], wne[v], wsw[v],
-                                wse[v], S, Q);
-            }
-        }
-        // ---- variance, store
-        float var[16];
-        bool tiny = false;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const float m = div_views_fast(S[c], p.fV, rV);
-            var[c] = div_views_fast(Q[c], p.fV, rV) - m * m;
-            tiny = tiny || div_views_tiny(S[c]) || div_views_tiny(Q[c]);
-        }
-        if (__any(tiny)) {
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const float m = S[c] / p.fV;
-                var[c] = Q[c] / p.fV - m * m;
-            }
-        }
-        if (ablate & 8) {   // tuning: keep the results live without the stores
-#pragma unroll
-            for (int c = 0; c < 16; ++c) asm volatile("" ::"v"(var[c]));
-        }
-        if (live && !(ablate & 8)) {
-            const size_t vox = ((size_t)b * p.D + d) * plane + pix;
-            if (out_c8) {
-                const size_t row = ((size_t)b * p.D + d) * p.H + py;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    float *o = out + ((row * (p.C >> 3) + (g * 2 + h)) * p.W + px) * 8;
-                    reinterpret_cast<float4 *>(o)[0] = make_float4(var[h * 8 + 0], var[h * 8 + 1], var[h * 8 + 2], var[h * 8 + 3]);
-                    reinterpret_cast<float4 *>(o)[1] = make_float4(var[h * 8 + 4], var[h * 8 + 5], var[h * 8 + 6], var[h * 8 + 7]);
-                }
-            } else {
-                float4 *o = reinterpret_cast<float4 *>(out + vox * p.C + g * 16);
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    o[k] = make_float4(var[k * 4], var[k * 4 + 1], var[k * 4 + 2], var[k * 4 + 3]);
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------
-// The same kernel with the footprints moved HBM -> LDS by DMA (global_load_lds_dwordx4):
-// no staging registers (the register-staged form above keeps NV x 3 float4 per thread in
-// flight), no ds_write pass, and the copy for channel group g+1 is issued before group
-// g's variances are formed and stored, so it lands under that work; the first group's
-// copy lands under the per-voxel homography arithmetic.  LDS image of a view: 4 planes
+//
+// The footprints move HBM -> LDS by buffer-addressed DMA (buffer_load_dwordx4 ... lds):
+// no staging registers (a register-staged form kept NV x 3 float4 per thread in
+// flight: 2.68 vs 2.0 ms), no ds_write pass, and the copy for channel group g+1 is issued
+// before group g's variances are formed and stored, so it lands under that work; the
+// first group's copy lands under the per-voxel homography arithmetic.  LDS image of a view: 4 planes
 // [channel quad k][texel][4 floats] -- a DMA instruction fills 64 consecutive texels of a
 // plane, 16 neighbouring texels cover all 64 banks without padding, and the four
-// quads of a tap sit at immediate offsets k * plane.  Arithmetic and results identical
-// to the kernels above.
+// quads of a tap sit at immediate offsets k * plane.
 // texels per view: 48 KiB in total (3 workgroups per CU; the register budget allows no
 // more), whole 64-lane DMA instructions where that costs little
 __host__ __device__ constexpr int dma_cap(int nv) {
@@ -742,7 +441,11 @@ __global__ __launch_bounds__(256, 2) void variance_fwd_dma_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tx, ty, dc;
-    {   // depth chunk fastest, consecutive blocks on one XCD (see the kernel above)
+    {   // Block order: depth chunk fastest, and consecutive blocks on the same XCD (blockIdx
+        // round-robins the 8 XCDs).  The footprints of one pixel tile move by a fraction of
+        // a texel per depth plane, so the depth chunks of a tile re-read the same source lines
+        // out of that XCD's L2; ordered by tile first, every depth chunk swept all source
+        // maps (61 MB at config 2, > L2) again: 13x the HBM-side fetch.
         const int nwg = gridDim.x;
         const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
         int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + ((int)blockIdx.x >> 3);
@@ -912,7 +615,8 @@ __global__ __launch_bounds__(256, 2) void variance_fwd_dma_kernel(
     const float rV = 1.0f / p.fV;
 #pragma unroll 1
     for (int g = 0; g < ngroups; ++g) {
-        // make the tap positions opaque per iteration (see the kernel above)
+        // make the tap positions opaque per iteration: otherwise LICM hoists every view's 4
+        // LDS offsets + 4 64-bit fallback pointers out of this loop and spills
 #pragma unroll
         for (int v = 0; v < NV; ++v) asm volatile("" : "+v"(tx0[v]), "+v"(ty0[v]));
         float4 ref4[4];
@@ -1228,31 +932,22 @@ extern "C" int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *s
         const int dchunks = (D + kTileD - 1) / kTileD;
         const int64_t nblk = (int64_t)tiles_x * tiles_y * dchunks;
         if (nblk > 0x7fffffffLL) return MVS_EINVAL;
-        const size_t shmem = (size_t)NV * lds_cap(NV) * kTexelPad * sizeof(float);
         const char *abl_env = getenv("MVS_SWEEP_ABLATE");   // tuning only
         const int lds_ablate = abl_env ? atoi(abl_env) : 0;
         const dim3 g((unsigned)nblk, (unsigned)B);
 #define MVS_LDS_CASE(n)                                                                        \
-    case n:                                                                                    \
-        if (!(lds_ablate & 128)) {   /* DMA-staged form (default) */                           \
-            const size_t sh2 = (size_t)n * 4 * dma_cap(n) * 16;                                \
-            if (depth_mode == 0 && !(lds_ablate & 32))                                         \
-                hipLaunchKernelGGL((variance_fwd_dma_kernel<n, true>), g, dim3(256), sh2, st,  \
-                                   ref_fea, src_feas, rot_trans, depth_values, p, tiles_x,     \
-                                   tiles_y, out_var, out_c8, lds_ablate);                      \
-            else                                                                               \
-                hipLaunchKernelGGL((variance_fwd_dma_kernel<n, false>), g, dim3(256), sh2, st, \
-                                   ref_fea, src_feas, rot_trans, depth_values, p, tiles_x,     \
-                                   tiles_y, out_var, out_c8, lds_ablate);                      \
-        } else if (depth_mode == 0 && !(lds_ablate & 32))                                      \
-            hipLaunchKernelGGL((variance_fwd_lds_kernel<n, true>), g, dim3(256), shmem, st,    \
+    case n: {                                                                                  \
+        const size_t shmem = (size_t)n * 4 * dma_cap(n) * 16;                                  \
+        if (depth_mode == 0 && !(lds_ablate & 32))                                             \
+            hipLaunchKernelGGL((variance_fwd_dma_kernel<n, true>), g, dim3(256), shmem, st,    \
                                ref_fea, src_feas, rot_trans, depth_values, p, tiles_x,         \
                                tiles_y, out_var, out_c8, lds_ablate);                          \
         else                                                                                   \
-            hipLaunchKernelGGL((variance_fwd_lds_kernel<n, false>), g, dim3(256), shmem, st,   \
+            hipLaunchKernelGGL((variance_fwd_dma_kernel<n, false>), g, dim3(256), shmem, st,   \
                                ref_fea, src_feas, rot_trans, depth_values, p, tiles_x,         \
                                tiles_y, out_var, out_c8, lds_ablate);                          \
-        break;
+        break;                                                                                 \
+    }
         switch (NV) {
             MVS_LDS_CASE(1) MVS_LDS_CASE(2) MVS_LDS_CASE(3) MVS_LDS_CASE(4) MVS_LDS_CASE(5)
             MVS_LDS_CASE(6) MVS_LDS_CASE(7) MVS_LDS_CASE(8)
