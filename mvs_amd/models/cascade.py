@@ -45,14 +45,15 @@ def pack_costreg(sd, prefix=""):
     return P
 
 
-def costreg_forward(x_cl, P, impl=ops.IMPL_AUTO):
-    """x_cl [B,D,H,W,Cin] channels-last -> cost [B,D,H,W] (module.py:429-438)."""
-    def run(name, t, skip=None, relu=True):
+def costreg_forward(x_cl, P, impl=ops.IMPL_AUTO, in_c8=False):
+    """x_cl [B,D,H,W,Cin] channels-last (in_c8: [B,D,H,Cin/8,W,8]) -> cost [B,D,H,W]
+    (module.py:429-438)."""
+    def run(name, t, skip=None, relu=True, c8=False):
         p = P[name]
         return ops.conv3d(t, p["weight"], p["scale"], p["shift"], skip, relu, p["transposed"],
-                          p["stride"], channels_last=True, packed=p["packed"], impl=impl)
+                          p["stride"], channels_last=True, packed=p["packed"], impl=impl, in_c8=c8)
 
-    c0 = run("conv0", x_cl)
+    c0 = run("conv0", x_cl, c8=in_c8)
     c2 = run("conv2", run("conv1", c0))
     c4 = run("conv4", run("conv3", c2))
     t = run("conv6", run("conv5", c4))
@@ -74,15 +75,20 @@ def depthnet_forward(features, cas_proj, depth_values, costreg_params, prob_volu
         rts = ops.rot_trans_all(proj, proj_where, device=dev)
     with ops.stage(tag + "to_channels_last"):
         if features_cl:   # [B,H,W,C] already (the HIP FeatureNet's layout)
-            ref = features[0].contiguous()
-            srcs = torch.stack([f for f in features[1:]])
+            fcl = torch.stack([f for f in features])
         else:
-            ref = ops.nchw_to_nhwc(features[0])
-            srcs = torch.stack([ops.nchw_to_nhwc(f) for f in features[1:]])
+            fcl = torch.stack([ops.nchw_to_nhwc(f) for f in features])      # [V,B,H,W,C]
+        C = fcl.shape[-1]
+        use_dma = C % 16 == 0    # the LDS/DMA sweep kernel takes 16-channel-blocked maps
+        if use_dma:              # [V,B,H,W,C] -> [V,B,C/16,H,W,16] (a view when C = 16)
+            f16 = fcl.reshape(*fcl.shape[:4], C // 16, 16).permute(0, 1, 4, 2, 3, 5).contiguous()
     with ops.stage(tag + "costvol_variance"):
-        var = ops.costvol_variance_cl(ref, srcs, rts, depth_values)
+        if use_dma:
+            var = ops.costvol_variance_c16(f16[0], f16[1:], rts, depth_values, out_c8=True)
+        else:
+            var = ops.costvol_variance_cl(fcl[0], fcl[1:], rts, depth_values, out_c8=True)
     with ops.stage(tag + "costreg"):
-        cost = costreg_forward(var, costreg_params)
+        cost = costreg_forward(var, costreg_params, in_c8=True)
         if prob_volume_init is not None:
             cost = cost + prob_volume_init
     with ops.stage(tag + "softmax_regress_conf"):
