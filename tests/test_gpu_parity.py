@@ -559,6 +559,30 @@ def test_mvsnet_eval_alternate_paths(dev, weights, feature_impl, variance_impl, 
     np.testing.assert_allclose(out["photometric_confidence"].cpu().numpy(), g["confidence"], atol=1e-4)
 
 
+def test_mvsnet_eval_batch_of_two_equals_single_samples(dev, weights):
+    """B = 2 through the whole HIP path (FeatureNet batches all B*V views, the sweep and the
+    persistent kernels index the batch) against two B = 1 calls.  Sample 0 is bit-identical;
+    sample 1 may differ by a few ulp of depth because the reference's own host arithmetic
+    (batched torch.inverse / matmul of module.py:63-65, mirrored exactly) rounds the second
+    matrix of a batch differently from the same matrix alone."""
+    from mvs_amd.models import MVSNet
+    g = load_golden("g6_e2e_64x96_v3_d8")
+    model = MVSNet(refine=False)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    model = model.to(dev).eval()
+    imgs, proj, dv = G(g["imgs"], dev), G(g["proj"], dev), G(g["depth_values"], dev)
+    imgs2 = torch.cat([imgs, imgs.flip(1)], 0)          # second sample: views in reverse order
+    proj2 = torch.cat([proj, proj.flip(1)], 0)
+    dv2 = torch.cat([dv, dv + 3.0], 0)
+    with torch.no_grad():
+        both = model(imgs2, proj2, dv2)
+        one = [model(imgs2[i:i + 1], proj2[i:i + 1], dv2[i:i + 1]) for i in range(2)]
+    for key in ("depth", "photometric_confidence"):
+        for i in range(2):
+            d = (both[key][i] - one[i][key][0]).abs().max().item()
+            assert d == 0.0 if i == 0 else d < (DEPTH_TOL_MM if key == "depth" else 1e-4), (key, i, d)
+
+
 def test_mvsnet_eval_from_reference_features(dev, weights):
     """Same gate with FeatureNet taken out of the loop (features from the
     reference): isolates the HIP cost-volume path proper."""
