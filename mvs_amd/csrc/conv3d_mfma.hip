@@ -815,6 +815,22 @@ int conv3d_mfma_launch(const float *in, const float *packed, const float *scale,
         a.tiles_x = (a.Wo + ci.xout - 1) / ci.xout;
         a.tiles_y = (a.Ho + ci.ty - 1) / ci.ty;
         a.tiles_z = (a.Do + ci.tz - 1) / ci.tz;
+        // small volumes (the bottom of the U-Net: 24x37x50 at config 2 is 120 tiles for 256
+        // CUs): a quarter-size tile of the same layer -- same packed weights -- fills the chip
+        if (stride == 1 && ci.mode == 0 && ci.tz == 4 && ci.ty == 8 &&
+            (int64_t)B * a.tiles_x * a.tiles_y * a.tiles_z < 1024) {
+            CfgInfo small;
+            bool have = true;
+            if (Cin == 64 && Cout == 64) small = info_of<ConvCfg<64, 64, 0, 16, 2, 4>>();
+            else if (Cin == 32 && Cout == 32) small = info_of<ConvCfg<32, 32, 0, 16, 2, 4>>();
+            else if (Cin == 16 && Cout == 16) small = info_of<ConvCfg<16, 16, 0, 16, 2, 4>>();
+            else have = false;
+            if (have) {
+                ci = small;
+                a.tiles_y = (a.Ho + ci.ty - 1) / ci.ty;
+                a.tiles_z = (a.Do + ci.tz - 1) / ci.tz;
+            }
+        }
     }
     const int64_t nblk = (int64_t)B * a.tiles_x * a.tiles_y * a.tiles_z;
     if (nblk <= 0 || nblk > 0x7fffffffLL) {
