@@ -1,0 +1,221 @@
+// Weight gradient of the 3x3x3 convolutions of CostRegNet (training path, BASELINE config 5)
+// on the fp32 matrix cores.
+//
+//   dW[co][ci][kz,ky,kx] = sum over output voxels o of  g[o][co] * x[o*s + k - 1][ci]
+//
+// (x = layer input, g = gradient of the layer output, both channels-last, s = stride; the
+// transposed layers' weight gradient is the same sum with the roles of x and g swapped --
+// see mvs_conv3d_wgrad_f32 in mvs_hip.h).  It replaces 27 strided-view GEMMs per layer in
+// torch (each a copy of the input + a split-K bmm): 44 of the 68 ms of a training step.
+//
+// GEMM orientation: the reduction dimension is the VOXELS.  One MFMA = D[16 co x 16 ci] +=
+// A[16 co x 4 voxels] * B[4 voxels x 16 ci]; A is a fragment of g, B a fragment of x at the
+// tap's offset, 4 consecutive output voxels along x per MFMA.  Accumulators are the weight
+// gradient itself, so they stay in registers for the whole kernel: a workgroup is PERSISTENT,
+// owns one 16-channel slice of ci and a stream of output tiles, its 4 waves split the 27
+// taps, and the result goes out once, with atomics (256 workgroups x |dW| atomic adds).
+// Tiles (g: TZ x TY x 16 voxels, x: its halo) are staged through LDS with buffer loads
+// (out-of-volume voxels load zeros = the convolution's padding and the tile overhang).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mvs_common.h"
+
+namespace mvs {
+
+typedef float wg_f32x4 __attribute__((ext_vector_type(4)));
+
+struct WgradArgs {
+    const float *x, *g;
+    float *gw;
+    int B, Cin, Cout;
+    int D, H, W;          // input (x) grid
+    int Do, Ho, Wo;       // output (g) grid
+    int tiles_x, tiles_y, tiles_z;
+};
+
+template <int COUT_T, int CK, int S>
+struct WgradCfg {
+    static constexpr int TZ = (S == 1) ? 2 : 1, TY = (S == 1) ? 4 : 2;
+    static constexpr int ROWS = TZ * TY, NOUT = ROWS * 16;
+    static constexpr int XT = 15 * S + 3, YT = (TY - 1) * S + 3, ZT = (TZ - 1) * S + 3;
+    static constexpr int NVOX = ZT * YT * XT;
+    static constexpr int MT = COUT_T / 16;
+    // voxel strides (floats) chosen so the two 16-lane runs of a ds_read_b32 half-wave land
+    // on different banks: consecutive voxels of a fragment are GP apart in g, S*XP in x
+    static constexpr int GP = (COUT_T % 32 == 0) ? COUT_T + 16 : COUT_T;
+    static constexpr int XP = (S == 1) ? 16 : 24;
+    static constexpr int LDS_FLOATS = NOUT * GP + NVOX * XP;
+    static constexpr int TAPS_PER_WAVE = 7;
+};
+
+template <int COUT_T, int CK, int S>
+__global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(WgradArgs a, int ntiles, int ncc) {
+    using C = WgradCfg<COUT_T, CK, S>;
+    constexpr int MT = C::MT, GP = C::GP, XP = C::XP, XT = C::XT, YT = C::YT;
+    constexpr int TPW = C::TAPS_PER_WAVE;
+    __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+    float *gl = lds, *xl = lds + C::NOUT * GP;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, kv = lane >> 4;
+    const int cc = blockIdx.x % ncc;                      // this workgroup's ci slice
+    const int t0 = blockIdx.x / ncc, tstep = gridDim.x / ncc;
+    const int tap0 = wv * TPW, ntap = min(TPW, 27 - tap0);
+
+    wg_f32x4 acc[TPW][MT];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[t][m] = (wg_f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (t0 < ntiles && blockIdx.x < tstep * ncc) {
+        const int64_t gplane = (int64_t)a.Ho * a.Wo * a.Cout, xplane = (int64_t)a.H * a.W * a.Cin;
+        for (int t = t0; t < ntiles; t += tstep) {
+            int bid = t;
+            const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+            const int ty = bid % a.tiles_y; bid /= a.tiles_y;
+            const int tz = bid % a.tiles_z;
+            const int b = bid / a.tiles_z;
+            const int ox0 = tx * 16, oy0 = ty * C::TY, oz0 = tz * C::TZ;
+            const int ix0 = ox0 * S - 1, iy0 = oy0 * S - 1, iz0 = oz0 * S - 1;
+            __syncthreads();   // every wave is done with the previous tile
+            {   // g tile: [row][x][Cout] -> gl[voxel * GP + co]; zero beyond Cout and the volume
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float *>(a.g + ((int64_t)b * a.Do + oz0) * gplane), 0,
+                    (int)(unsigned)min((int64_t)C::TZ * gplane * 4, (int64_t)0xffffff00u), 0x00020000);
+                constexpr int Q = COUT_T / 4;   // float4 pieces per voxel
+                for (int e = tid; e < C::NOUT * Q; e += 256) {
+                    const int q = e % Q, v = e / Q;
+                    const int x = v & 15, row = v >> 4;
+                    const int oz = row / C::TY, oy = oy0 + row % C::TY, ox = ox0 + x;
+                    const bool ok = oz0 + oz < a.Do && oy < a.Ho && ox < a.Wo && q * 4 < a.Cout;
+                    const unsigned off = ok ? (unsigned)(((int64_t)oz * gplane + ((int64_t)oy * a.Wo + ox) * a.Cout + q * 4) * 4)
+                                            : 0xffffff00u;
+                    const auto val = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+                    *reinterpret_cast<float4 *>(gl + v * GP + q * 4) =
+                        make_float4(__uint_as_float(val[0]), __uint_as_float(val[1]), __uint_as_float(val[2]),
+                                    __uint_as_float(val[3]));
+                }
+            }
+            {   // x halo: channels cc*CK .. +CK of every halo voxel -> xl[voxel * XP + ci]
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float *>(a.x + ((int64_t)b * a.D + iz0) * xplane), 0,
+                    (int)(unsigned)min((int64_t)C::ZT * xplane * 4, (int64_t)0xffffff00u), 0x00020000);
+                constexpr int Q = 4;            // 16 columns per voxel, the upper ones zero if CK = 8
+                for (int e = tid; e < C::NVOX * Q; e += 256) {
+                    const int q = e % Q, v = e / Q;
+                    const int lx = v % XT, t2 = v / XT, ly = t2 % YT, lz = t2 / YT;
+                    const int gx = ix0 + lx, gy = iy0 + ly, gz = iz0 + lz;
+                    const bool ok = (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H &&
+                                    (unsigned)gz < (unsigned)a.D && q * 4 < CK;
+                    const unsigned off = ok ? (unsigned)(((int64_t)lz * xplane + ((int64_t)gy * a.W + gx) * a.Cin +
+                                                          cc * CK + q * 4) * 4)
+                                            : 0xffffff00u;
+                    const auto val = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+                    *reinterpret_cast<float4 *>(xl + v * XP + q * 4) =
+                        make_float4(__uint_as_float(val[0]), __uint_as_float(val[1]), __uint_as_float(val[2]),
+                                    __uint_as_float(val[3]));
+                }
+            }
+            __syncthreads();
+            // ---- K loop: 4 output voxels along x per MFMA
+#pragma unroll 1
+            for (int row = 0; row < C::ROWS; ++row) {
+                const int rz = row / C::TY, ry = row % C::TY;
+#pragma unroll
+                for (int xs = 0; xs < 4; ++xs) {
+                    float af[MT];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) af[m] = gl[(row * 16 + xs * 4 + kv) * GP + m * 16 + c];
+                    const float *xb = xl + (((rz * S) * YT + ry * S) * XT + (xs * 4 + kv) * S) * XP + c;
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) {
+                        if (t >= ntap) break;                       // wave-uniform
+                        const int tap = tap0 + t;
+                        const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+                        const float bf = xb[((kz * YT + ky) * XT + kx) * XP];
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+                            acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf, acc[t][m], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // ---- flush: D lane (n = ci, q) holds co = m*16 + 4q + j
+    const int ci = cc * CK + c;
+    if (c < CK && ci < a.Cin) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            if (t >= ntap) break;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int co = m * 16 + kv * 4 + j;
+                    if (co < a.Cout) unsafeAtomicAdd(a.gw + ((int64_t)co * a.Cin + ci) * 27 + tap0 + t, acc[t][m][j]);
+                }
+        }
+    }
+}
+
+template <int COUT_T, int CK, int S>
+static int launch_wgrad(const WgradArgs &a, int ntiles, hipStream_t st) {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0, cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0)
+            cu = 256;
+        n_cu = cu;
+    }
+    const int ncc = (a.Cin + CK - 1) / CK;
+    int streams = (2 * n_cu) / ncc;               // tile streams per ci slice
+    if (streams > ntiles) streams = ntiles;
+    if (streams < 1) streams = 1;
+    hipLaunchKernelGGL((conv3d_wgrad_kernel<COUT_T, CK, S>), dim3((unsigned)(streams * ncc)), dim3(256), 0, st,
+                       a, ntiles, ncc);
+    return check_launch("mvs_conv3d_wgrad_f32");
+}
+
+}  // namespace mvs
+
+using namespace mvs;
+
+extern "C" int mvs_conv3d_wgrad_supported(int Cin, int Cout, int stride) {
+    const bool cin_ok = Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64;
+    const bool cout_ok = Cout == 8 || Cout == 16 || Cout == 32 || Cout == 64;
+    return (cin_ok && cout_ok && (stride == 1 || stride == 2)) ? 1 : 0;
+}
+
+extern "C" int mvs_conv3d_wgrad_f32(const float *in, const float *grad_out, int B, int Cin, int Cout,
+                                    int D, int H, int W, int stride, float *grad_weight, void *stream) {
+    if (!in || !grad_out || !grad_weight || B <= 0 || D <= 0 || H <= 0 || W <= 0) {
+        set_error("mvs_conv3d_wgrad_f32: bad argument");
+        return MVS_EINVAL;
+    }
+    if (!mvs_conv3d_wgrad_supported(Cin, Cout, stride)) {
+        set_error("mvs_conv3d_wgrad_f32: no kernel for Cin=%d Cout=%d stride=%d", Cin, Cout, stride);
+        return MVS_EUNSUPPORTED;
+    }
+    WgradArgs a;
+    a.x = in; a.g = grad_out; a.gw = grad_weight;
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
+    a.Do = (D - 1) / stride + 1; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;
+    const int tz = stride == 1 ? 2 : 1, ty = stride == 1 ? 4 : 2;
+    a.tiles_x = (a.Wo + 15) / 16; a.tiles_y = (a.Ho + ty - 1) / ty; a.tiles_z = (a.Do + tz - 1) / tz;
+    const int64_t nt = (int64_t)B * a.tiles_x * a.tiles_y * a.tiles_z;
+    if (nt <= 0 || nt > 0x7fffffffLL || (int64_t)9 * H * W * Cin * 4 >= 0xffffff00LL) return MVS_EINVAL;
+    hipStream_t st = as_stream(stream);
+    const int ck = Cin >= 16 ? 16 : 8;
+#define MVS_WG(co)                                                                               \
+    if (Cout <= co) {                                                                            \
+        if (stride == 1) return ck == 16 ? launch_wgrad<co, 16, 1>(a, (int)nt, st) : launch_wgrad<co, 8, 1>(a, (int)nt, st); \
+        return ck == 16 ? launch_wgrad<co, 16, 2>(a, (int)nt, st) : launch_wgrad<co, 8, 2>(a, (int)nt, st);                 \
+    }
+    MVS_WG(16) MVS_WG(32) MVS_WG(64)
+#undef MVS_WG
+    return MVS_EUNSUPPORTED;
+}

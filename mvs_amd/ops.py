@@ -490,6 +490,22 @@ def pack_conv2d_weight(weight, stride):
     return packed
 
 
+def conv3d_wgrad(x_cl, g_cl, stride):
+    """Weight gradient of a 3x3x3 layer on the matrix cores: x_cl [B,D,H,W,Cin], g_cl
+    [B,Do,Ho,Wo,Cout] channels-last -> (Cout,Cin,3,3,3), or None when the shape has no kernel.
+    For a transposed layer pass (grad_out, input, 2): the result is its (Cin,Cout,3,3,3)."""
+    x_cl, g_cl = _f32c(x_cl), _f32c(g_cl)
+    B, D, H, W, cin = x_cl.shape
+    cout = g_cl.shape[-1]
+    lib = _lib.load()
+    if not lib.mvs_conv3d_wgrad_supported(cin, cout, stride):
+        return None
+    gw = torch.zeros((cout, cin, 3, 3, 3), device=x_cl.device, dtype=torch.float32)
+    check(lib.mvs_conv3d_wgrad_f32(ptr(x_cl), ptr(g_cl), B, cin, cout, D, H, W, stride, ptr(gw), stream()),
+          "mvs_conv3d_wgrad_f32")
+    return gw
+
+
 def conv2d(x, packed, cin, cout, ksize, stride, scale=None, shift=None, relu=False, planar=False):
     """FeatureNet convolution.  x: [B,H,W,cin] channels-last, or (planar) the [B,3,H,W]
     image.  Returns [B,Ho,Wo,cout] channels-last."""

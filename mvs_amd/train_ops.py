@@ -76,7 +76,12 @@ def _tall_gemm_t(a, b):
 
 
 def _wgrad(x, g, transposed, stride, wshape):
-    """dW by 27 split-K batched GEMMs over strided views (fp32; torch / hipBLASLt)."""
+    """dW on the HIP weight-gradient kernel (voxels as the MFMA reduction dimension); shapes
+    it does not cover (the Cout = 1 `prob` layer) fall back to 27 split-K batched GEMMs over
+    strided views in torch -- still on the GPU, never on the host."""
+    gw = ops.conv3d_wgrad(g, x, 2) if transposed else ops.conv3d_wgrad(x, g, stride)
+    if gw is not None:
+        return gw
     gw = torch.empty(wshape, device=x.device, dtype=torch.float32)
     if not transposed:
         _, Do, Ho, Wo, Co = g.shape

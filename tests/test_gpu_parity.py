@@ -698,7 +698,9 @@ def test_cascade_end_to_end_golden(dev):
 
 
 @pytest.mark.parametrize("cfg", [(32, 8, False, 1), (8, 16, False, 2), (16, 16, False, 1),
-                                 (64, 32, True, 2), (16, 8, True, 2), (8, 1, False, 1)])
+                                 (64, 32, True, 2), (16, 8, True, 2), (8, 1, False, 1),
+                                 (16, 32, False, 2), (32, 64, False, 2), (64, 64, False, 1),
+                                 (32, 32, False, 1), (32, 16, True, 2)])
 def test_conv3d_autograd_vs_torch(dev, cfg):
     """Forward, input gradient (HIP kernels) and weight gradient of the training-path
     convolution against torch's own conv3d / conv_transpose3d autograd."""
@@ -721,6 +723,36 @@ def test_conv3d_autograd_vs_torch(dev, cfg):
     np.testing.assert_allclose(x.grad.permute(0, 4, 1, 2, 3).cpu().numpy(), xr.grad.cpu().numpy(),
                                atol=2e-5, rtol=1e-4)
     np.testing.assert_allclose(w.grad.cpu().numpy(), wr.grad.cpu().numpy(), atol=2e-4, rtol=1e-3)
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 7, 19), (1, 9, 6, 33)])
+@pytest.mark.parametrize("cfg", [(32, 8, 1), (8, 16, 2), (16, 32, 2), (64, 64, 1)])
+def test_conv3d_wgrad_ragged_vs_torch(dev, shape, cfg):
+    """The weight-gradient kernel on ragged volumes (tile overhang on every axis, batch > 1,
+    odd sizes under stride 2) against torch's conv3d weight gradient; and the transposed
+    layer's form (roles of input and output gradient swapped)."""
+    import torch.nn.functional as F
+    from mvs_amd import ops
+    B, D, H, W = shape
+    cin, cout, stride = cfg
+    g = torch.Generator(device=dev).manual_seed(cin * 7 + cout + D)
+    x = torch.randn(B, D, H, W, cin, device=dev, generator=g)
+    Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
+    go = torch.randn(B, Do, Ho, Wo, cout, device=dev, generator=g)
+    gw = ops.conv3d_wgrad(x, go, stride)
+    assert gw is not None and gw.shape == (cout, cin, 3, 3, 3)
+    w = torch.zeros(cout, cin, 3, 3, 3, device=dev, requires_grad=True)
+    F.conv3d(x.permute(0, 4, 1, 2, 3), w, None, stride, 1).backward(go.permute(0, 4, 1, 2, 3))
+    scale = float(w.grad.abs().max())
+    np.testing.assert_allclose(gw.cpu().numpy(), w.grad.cpu().numpy(), atol=2e-5 * scale + 1e-5, rtol=2e-4)
+    if stride == 2:   # also the transposed layer's gradient: fine grid = 2x the coarse one
+        xc = torch.randn(B, D, H, W, cout, device=dev, generator=g)          # deconv input (Cin_t = cout)
+        gf = torch.randn(B, 2 * D, 2 * H, 2 * W, cin, device=dev, generator=g)   # its grad_out (Cout_t = cin)
+        gwt = ops.conv3d_wgrad(gf, xc, 2)                                     # -> (Cin_t, Cout_t, 3,3,3)
+        wt = torch.zeros(cout, cin, 3, 3, 3, device=dev, requires_grad=True)
+        F.conv_transpose3d(xc.permute(0, 4, 1, 2, 3), wt, None, 2, 1, 1).backward(gf.permute(0, 4, 1, 2, 3))
+        sc = float(wt.grad.abs().max())
+        np.testing.assert_allclose(gwt.cpu().numpy(), wt.grad.cpu().numpy(), atol=2e-5 * sc + 1e-5, rtol=2e-4)
 
 
 @pytest.mark.parametrize("cfg", [(3, 8, 3, 1), (8, 8, 3, 1), (8, 16, 5, 2), (16, 32, 5, 2),
