@@ -140,7 +140,7 @@ int mvs_conv3d_mfma_supported(int transposed, int Cin, int Cout, int stride);
  * Transposed layer (stride 2, weight (Cin_t,Cout_t,3,3,3)): call with in := its grad_out
  * (the fine grid, Cout_t channels), grad_out := its input (Cin_t channels), stride 2; the
  * result is already in the transposed layer's weight layout.
- * Cin, Cout in {8,16,32,64}, stride in {1,2}. */
+ * Cin in {8,16,32,64}, Cout in {1,8,16,32,64}, stride in {1,2}. */
 int mvs_conv3d_wgrad_f32(const float *in, const float *grad_out, int B, int Cin, int Cout, int D,
                          int H, int W, int stride, float *grad_weight, void *stream);
 int mvs_conv3d_wgrad_supported(int Cin, int Cout, int stride);

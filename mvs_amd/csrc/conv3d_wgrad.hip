@@ -93,10 +93,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(WgradArgs a, int n
                     const bool ok = oz0 + oz < a.Do && oy < a.Ho && ox < a.Wo && q * 4 < a.Cout;
                     const unsigned off = ok ? (unsigned)(((int64_t)oz * gplane + ((int64_t)oy * a.Wo + ox) * a.Cout + q * 4) * 4)
                                             : 0xffffff00u;
-                    const auto val = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
-                    *reinterpret_cast<float4 *>(gl + v * GP + q * 4) =
-                        make_float4(__uint_as_float(val[0]), __uint_as_float(val[1]), __uint_as_float(val[2]),
-                                    __uint_as_float(val[3]));
+                    float4 val4;
+                    if (a.Cout == 1) {   // the `prob` layer: one channel per voxel, no 16-byte pieces
+                        val4 = make_float4(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0)), 0.f, 0.f, 0.f);
+                    } else {
+                        const auto val = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+                        val4 = make_float4(__uint_as_float(val[0]), __uint_as_float(val[1]), __uint_as_float(val[2]),
+                                           __uint_as_float(val[3]));
+                    }
+                    *reinterpret_cast<float4 *>(gl + v * GP + q * 4) = val4;
                 }
             }
             {   // x halo: channels cc*CK .. +CK of every halo voxel -> xl[voxel * XP + ci]
@@ -186,7 +191,7 @@ using namespace mvs;
 
 extern "C" int mvs_conv3d_wgrad_supported(int Cin, int Cout, int stride) {
     const bool cin_ok = Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64;
-    const bool cout_ok = Cout == 8 || Cout == 16 || Cout == 32 || Cout == 64;
+    const bool cout_ok = Cout == 1 || Cout == 8 || Cout == 16 || Cout == 32 || Cout == 64;
     return (cin_ok && cout_ok && (stride == 1 || stride == 2)) ? 1 : 0;
 }
 

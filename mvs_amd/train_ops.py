@@ -76,9 +76,9 @@ def _tall_gemm_t(a, b):
 
 
 def _wgrad(x, g, transposed, stride, wshape):
-    """dW on the HIP weight-gradient kernel (voxels as the MFMA reduction dimension); shapes
-    it does not cover (the Cout = 1 `prob` layer) fall back to 27 split-K batched GEMMs over
-    strided views in torch -- still on the GPU, never on the host."""
+    """dW on the HIP weight-gradient kernel (voxels as the MFMA reduction dimension); a shape
+    it does not cover falls back to 27 split-K batched GEMMs over strided views in torch --
+    still on the GPU, never on the host."""
     gw = ops.conv3d_wgrad(g, x, 2) if transposed else ops.conv3d_wgrad(x, g, stride)
     if gw is not None:
         return gw
