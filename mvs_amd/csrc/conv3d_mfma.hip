@@ -722,6 +722,7 @@ static bool lookup(int transposed, int Cin, int Cout, int stride, CfgInfo &ci) {
         MVS_CFG(64, 64, 0, 16, 4, 8)
         MVS_CFG(16, 32, 0, 16, 4, 8)
         MVS_CFG(32, 64, 0, 16, 4, 8)
+        MVS_CFG(64, 32, 0, 16, 4, 8)    // CVP-MVSNet's stride-1 transposed layer as a convolution
     } else if (stride == 2) {
         MVS_CFG(8, 16, 1, 8, 2, 4)
         MVS_CFG(16, 32, 1, 8, 2, 4)

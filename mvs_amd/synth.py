@@ -175,3 +175,37 @@ def cas_random_state_dict(seed=0, peaked=100.0):
             elif k.endswith("prob.weight"):
                 v.mul_(peaked)
     return {k: v.clone() for k, v in sd.items()}
+
+
+def cvp_cameras(nsrc, img_h, img_w, batch=1):
+    """CVP-MVSNet convention (CVP-MVSNet/models/net.py:106): full-image intrinsics
+    ref_in [B,3,3], src_in [B,nsrc,3,3], extrinsics ref_ex [B,4,4], src_ex [B,nsrc,4,4]
+    (float32), depth range [B] each."""
+    K = feature_intrinsics(img_h, img_w).astype(np.float32)
+    E = arc_extrinsics(nsrc + 1).astype(np.float32)
+    rep = lambda a: np.broadcast_to(a, (batch,) + a.shape).copy()
+    return {"ref_in": rep(K), "src_in": rep(np.stack([K] * nsrc)), "ref_ex": rep(E[0]), "src_ex": rep(E[1:]),
+            "depth_min": np.full((batch,), DTU_DEPTH_MIN, dtype=np.float32),
+            "depth_max": np.full((batch,), DTU_DEPTH_MIN + 47 * 13.5, dtype=np.float32)}   # 48 planes, exact step
+
+
+def cvp_random_state_dict(seed=0, peaked=60.0):
+    """Seeded CVP-MVSNet state_dict (reference key names, 551,585 parameters): default conv
+    init, BatchNorm affine/statistics perturbed away from identity, `prob0` scaled so the
+    softmax over depth is peaked.  Deterministic for a given torch build."""
+    import torch
+    from .models.cvp_mvsnet import CVPMVSNet
+    torch.manual_seed(seed)
+    net = CVPMVSNet(nscale=2, nsrc=2)
+    g = torch.Generator().manual_seed(seed + 1)
+    sd = net.state_dict()
+    with torch.no_grad():
+        for k, v in sd.items():
+            if ".bn." in k or k.startswith("cost_reg_refine.conv5.1.") or k.startswith("cost_reg_refine.conv6.1."):
+                if k.endswith("weight") or k.endswith("running_var"):
+                    v.copy_(0.5 + torch.rand(v.shape, generator=g))
+                elif k.endswith("bias") or k.endswith("running_mean"):
+                    v.copy_(0.1 * torch.randn(v.shape, generator=g))
+            elif k.endswith("prob0.weight"):
+                v.mul_(peaked)
+    return {k: v.clone() for k, v in sd.items()}

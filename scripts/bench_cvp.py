@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""BASELINE configs[3]: CVP-MVSNet coarse-to-fine forward at 1920x1056, 7 views (6 sources),
+5 pyramid levels, on cuda:0 -- ms per reference view and peak memory.
+    python scripts/bench_cvp.py [H W nsrc nscale] [--steps K]"""
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from mvs_amd import synth  # noqa: E402
+from mvs_amd.models.cvp_mvsnet import network  # noqa: E402
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    H, W, nsrc, nscale = (int(x) for x in (args[:4] or (1056, 1920, 6, 5)))
+    steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 5
+    dev = torch.device("cuda:0")
+    torch.backends.cudnn.benchmark = True
+    rng = np.random.default_rng(0)
+    imgs = torch.from_numpy(synth.images(rng, 1, nsrc + 1, H, W)).to(dev)
+    cams = {k: torch.from_numpy(v).to(dev) for k, v in synth.cvp_cameras(nsrc, H, W).items()}
+    sd = synth.cvp_random_state_dict(0)
+    net = network(types.SimpleNamespace(nscale=nscale, nsrc=nsrc, mode="test"))
+    net.load_state_dict(sd)
+    net.eval().to(dev)
+
+    def step():
+        with torch.no_grad():
+            return net(imgs[:, 0], imgs[:, 1:], cams["ref_in"], cams["src_in"], cams["ref_ex"], cams["src_ex"],
+                       cams["depth_min"], cams["depth_max"])
+
+    for _ in range(2):
+        out = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    res = {"config": {"H": H, "W": W, "views": nsrc + 1, "nscale": nscale},
+           "ms_per_ref_view": round((time.perf_counter() - t0) / steps * 1e3, 3),
+           "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+           "depth_shapes": [list(d.shape) for d in out["depth_est_list"]],
+           "finite": bool(all(torch.isfinite(d).all() for d in out["depth_est_list"]))}
+    print(json.dumps(res))
+    os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(REPO, "gpurun_out", "bench_cvp.json"), "w") as f:
+        json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

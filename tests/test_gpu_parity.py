@@ -697,6 +697,30 @@ def test_cascade_end_to_end_golden(dev):
         assert err.max() < DEPTH_TOL_MM, (key, err.max())
 
 
+def test_cvp_mvsnet_golden(dev):
+    """CVP-MVSNet coarse-to-fine forward (BASELINE configs[3], small): feature pyramid and glue
+    in torch, per level the aliased variance volume over all views, the stride-1-transposed
+    U-Net and the softmax regression on the kernels; vs the reference `network` CPU forward
+    (tests/golden/make_golden_cvp.py)."""
+    from mvs_amd import synth
+    from mvs_amd.models.cvp_mvsnet import network
+    import types
+    g = load_golden("g11_cvp")
+    net = network(types.SimpleNamespace(nscale=int(g["nscale"]), nsrc=int(g["nsrc"]), mode="test"))
+    net.load_state_dict(synth.cvp_random_state_dict(int(g["seed"])))
+    net.eval().to(dev)
+    imgs = G(g["imgs"], dev)
+    with torch.no_grad():
+        out = net(imgs[:, 0], imgs[:, 1:], *(G(g[k], dev) for k in
+                                             ("ref_in", "src_in", "ref_ex", "src_ex", "depth_min", "depth_max")))
+    assert len(out["depth_est_list"]) == int(g["nscale"])
+    for i, d in enumerate(out["depth_est_list"]):
+        err = np.abs(d.cpu().numpy() - g[f"depth_level{i}"])
+        print("level", i, "max depth err", err.max(), "median", np.median(err))
+        assert err.max() < DEPTH_TOL_MM, (i, err.max())
+    np.testing.assert_allclose(out["prob_confidence"].cpu().numpy(), g["prob_confidence"], atol=2e-4)
+
+
 @pytest.mark.parametrize("cfg", [(32, 8, False, 1), (8, 16, False, 2), (16, 16, False, 1),
                                  (64, 32, True, 2), (16, 8, True, 2), (8, 1, False, 1),
                                  (16, 32, False, 2), (32, 64, False, 2), (64, 64, False, 1),
