@@ -13,6 +13,7 @@ with the reference's key names -- of:
   softmax/regression    MVSNet/models/mvsnet.py:183-185, module.py:91-103
   photometric conf.     MVSNet/models/mvsnet.py:187-191
   CasMVSNet cascade     CasMVSNet/models/cas_mvsnet.py:12-66,108-164; module.py:304-438,485-524
+  CVP-MVSNet            CVP-MVSNet/models/net.py:22-207; modules.py:29-78,122-275,338-355
 
 Parity status: PINNED -- tests/test_oracle_golden.py checks every stage against
 golden vectors captured from the imported reference.
@@ -230,6 +231,113 @@ def cascade_forward(imgs, projs, depth_values, sd, ndepths=(48, 32, 8), ratios=(
         if stages is not None:
             stages[key] = time.perf_counter() - t0
     return out
+
+
+# ---- CVP-MVSNet (BASELINE configs[3]) --------------------------------------------------
+
+def cvp_feature_pyramid(img, sd, nscale, prefix="featurePyramid."):
+    """[B,3,H,W] -> nscale maps [B,16,H/2^l,W/2^l] (net.py:22-51: 9 x (3x3 conv + LeakyReLU 0.1)
+    on a bilinear x0.5 image pyramid)."""
+    names = ("conv0aa", "conv0ba", "conv0bb", "conv0bc", "conv0bd", "conv0be", "conv0bf", "conv0bg", "conv0bh")
+
+    def cnn(x):
+        for n in names:
+            x = F.leaky_relu(F.conv2d(x, sd[f"{prefix}{n}.0.weight"], sd[f"{prefix}{n}.0.bias"], 1, 1), 0.1)
+        return x
+
+    out = [cnn(img)]
+    for _ in range(nscale - 1):
+        img = F.interpolate(img, scale_factor=0.5, mode="bilinear", align_corners=None)
+        out.append(cnn(img))
+    return out
+
+
+def cvp_cost_reg_net(x, sd, prefix="cost_reg_refine."):
+    """[B,16,D,H,W] -> [B,D,H,W]  (net.py:53-97)."""
+    def cbr(name, t, stride=1):
+        t = F.conv3d(t, sd[f"{prefix}{name}.conv.weight"], None, stride, 1)
+        return F.relu(_bn_eval(t, sd, f"{prefix}{name}.bn"))
+
+    def up(name, t, stride, outpad):
+        t = F.conv_transpose3d(t, sd[f"{prefix}{name}.0.weight"], None, stride, 1, outpad)
+        return F.relu(_bn_eval(t, sd, f"{prefix}{name}.1"))
+
+    c0 = cbr("conv0a", cbr("conv0", x))
+    c2 = cbr("conv2a", cbr("conv2", cbr("conv1", c0, 2)))
+    c4 = cbr("conv4a", cbr("conv4", cbr("conv3", c2)))
+    c5 = c2 + up("conv5", c4, 1, 0)
+    c6 = c0 + up("conv6", c5, 2, 1)
+    return F.conv3d(c6, sd[prefix + "prob0.weight"], sd[prefix + "prob0.bias"], 1, 1).squeeze(1)
+
+
+def _cvp_proj(K, E):
+    P = torch.zeros_like(E)
+    P[..., :3, :] = K @ E[..., :3, :]
+    P[..., 3, 3] = 1.0
+    return P
+
+
+def cvp_refine_hypotheses(depth_up, Kr, Ks, Er, Es, d=4):
+    """modules.py:147-219 (test branch): depth_up [B,H,W] -> [B,2d,H,W], float64 geometry."""
+    B, H, W = depth_up.shape
+    out = depth_up.unsqueeze(1).repeat(1, 2 * d, 1, 1)
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float64), torch.arange(W, dtype=torch.float64), indexing="ij")
+    pix = torch.stack((xs.reshape(-1), ys.reshape(-1), torch.ones(H * W, dtype=torch.float64)))
+    for b in range(B):
+        kr, ks, er, es = Kr[b].double(), Ks[b].double(), Er[b].double(), Es[b].double()
+        d1 = depth_up[b].reshape(-1).double()
+
+        def src_pixel(depth):
+            cam = torch.inverse(kr) @ (pix * depth)
+            world = torch.inverse(er) @ torch.cat((cam, torch.ones_like(cam[:1])), 0)
+            p = ks @ (es @ world)[:3]
+            return p / p[2], p[2].clone()
+
+        x1, z1 = src_pixel(d1)
+        x2, _ = src_pixel(d1 + 1)
+        th = torch.atan((x2[1] - x1[1]) / (x2[0] - x1[0]))
+        x3 = x1 + torch.stack((torch.cos(th), torch.sin(th), torch.zeros_like(th)))
+        A = (kr @ er[:3, :3]) @ torch.inverse(ks @ es[:3, :3])
+        t1, t2 = z1 * (A @ x1), A @ x3
+        M = torch.stack((pix.t()[:, 1:], t2.t()[:, 1:]), 2)
+        step = (torch.inverse(M) @ t1.t()[:, 1:].unsqueeze(2))[:, 0, 0].abs().mean().float()
+        for k in range(-d, d):
+            out[b, k + d] += k * step
+    return out.float()
+
+
+def cvp_forward(ref_img, src_imgs, ref_in, src_in, ref_ex, src_ex, depth_min, depth_max, sd, nscale):
+    """CVP-MVSNet `network.forward` in test mode (net.py:106-207) -> {"depth_est_list" (finest
+    first), "prob_confidence"}."""
+    import warnings
+    nsrc = src_imgs.shape[1]
+    pyr = [cvp_feature_pyramid(ref_img, sd, nscale)] + [cvp_feature_pyramid(src_imgs[:, i], sd, nscale) for i in range(nsrc)]
+    H0 = ref_img.shape[2]
+
+    def K_at(K, level):
+        K = K.clone()
+        K[:, :2, :] = K[:, :2, :] / (H0 / pyr[0][level].shape[2])
+        return K
+
+    def level_cost(level, hyp):
+        feats = [p[level] for p in pyr]
+        projs = [_cvp_proj(K_at(ref_in, level), ref_ex)] + \
+                [_cvp_proj(K_at(src_in[:, i], level), src_ex[:, i]) for i in range(nsrc)]
+        return cvp_cost_reg_net(variance_volume(feats, projs, hyp, alias_quirk=True), sd)
+
+    step = (depth_max[0] - depth_min[0]) / 47
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        hyp = torch.range(float(depth_min[0]), float(depth_max[0]), float(step)).unsqueeze(0).repeat(ref_img.shape[0], 1)
+    depth, conf, _ = regress(level_cost(nscale - 1, hyp), hyp)
+    depths = [depth]
+    for level in range(nscale - 2, -1, -1):
+        up = F.interpolate(depth[None], scale_factor=2, mode="bicubic", align_corners=None).squeeze(0)
+        hyp = cvp_refine_hypotheses(up, K_at(ref_in, level), K_at(src_in[:, 0], level), ref_ex, src_ex[:, 0])
+        depth, conf, _ = regress(level_cost(level, hyp), hyp)
+        depths.append(depth)
+    depths.reverse()
+    return {"depth_est_list": depths, "prob_confidence": conf}
 
 
 def masked_smooth_l1(est, gt, mask):

@@ -173,3 +173,20 @@ def test_torch_ref_cascade_matches_reference():
     for k in ("stage1", "stage2", "stage3"):
         assert np.abs(out[k]["depth"].numpy() - g[k + "_depth"]).max() < 1e-3, k
         np.testing.assert_allclose(out[k]["photometric_confidence"].numpy(), g[k + "_conf"], atol=1e-4)
+
+
+def test_torch_ref_cvp_matches_reference():
+    """oracle/torch_ref.cvp_forward (CVP-MVSNet coarse-to-fine) vs the imported reference's
+    `network` forward (golden g11, made by tests/golden/make_golden_cvp.py)."""
+    from mvs_amd import synth
+    from oracle import torch_ref
+    g = load_golden("g11_cvp")
+    sd = synth.cvp_random_state_dict(int(g["seed"]))
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    imgs = T(g["imgs"])
+    with torch.no_grad():
+        out = torch_ref.cvp_forward(imgs[:, 0], imgs[:, 1:], *(T(g[k]) for k in (
+            "ref_in", "src_in", "ref_ex", "src_ex", "depth_min", "depth_max")), sd, int(g["nscale"]))
+    for i, d in enumerate(out["depth_est_list"]):
+        assert np.abs(d.numpy() - g[f"depth_level{i}"]).max() < 1e-3, i
+    np.testing.assert_allclose(out["prob_confidence"].numpy(), g["prob_confidence"], atol=1e-4)
