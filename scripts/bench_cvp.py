@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """BASELINE configs[3]: CVP-MVSNet coarse-to-fine forward at 1920x1056, 7 views (6 sources),
 5 pyramid levels, on cuda:0 -- ms per reference view and peak memory.
-    python scripts/bench_cvp.py [H W nsrc nscale] [--steps K]"""
+    python scripts/bench_cvp.py [H W nsrc nscale] [--steps K] [--parity]
+Test/measurement infrastructure (imports oracle/ for the checker only)."""
 import json
 import os
 import sys
@@ -48,6 +49,16 @@ def main():
            "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
            "depth_shapes": [list(d.shape) for d in out["depth_est_list"]],
            "finite": bool(all(torch.isfinite(d).all() for d in out["depth_est_list"]))}
+    if "--parity" in sys.argv:   # the checker: ATen CPU restatement on the same inputs
+        from oracle import torch_ref as tr
+        torch.set_num_threads(os.cpu_count())
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            ref = tr.cvp_forward(imgs[:, 0].cpu(), imgs[:, 1:].cpu(), *(cams[k].cpu() for k in (
+                "ref_in", "src_in", "ref_ex", "src_ex", "depth_min", "depth_max")), sd, nscale)
+        res["cpu_seconds"] = round(time.perf_counter() - t0, 1)
+        res["depth_maxabs_mm_per_level"] = [float((a.cpu() - b).abs().max())
+                                            for a, b in zip(out["depth_est_list"], ref["depth_est_list"])]
     print(json.dumps(res))
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
     with open(os.path.join(REPO, "gpurun_out", "bench_cvp.json"), "w") as f:
