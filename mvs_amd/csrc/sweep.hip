@@ -704,6 +704,273 @@ __global__ __launch_bounds__(256, 2) void variance_fwd_dma_kernel(
     }
 }
 
+// ---------------------------------------------------------------------
+// Backward of the fused variance in the layouts of variance_fwd_dma_kernel (training, shared
+// depth planes): grad_var [B,D,H,W,C] -> grad_ref, grad_srcs in the 16-channel-blocked
+// feature layout.  d var / d w_v = 2 w_v / V - 2 S / V^2 (same for the reference features).
+// The planar kernel sends every tap's share straight to HBM: (1 + 4 (V-1)) C atomics per
+// voxel, 1.1 G at config 5, and those atomics are its whole cost.  Here a block (8x8 pixels
+// x 4 depth planes) stages the source footprints as the forward kernel does, accumulates
+// the gradients of the same footprints (and of its 64 reference pixels) in LDS with
+// ds_add_f32, and flushes each texel ONCE: ~8x fewer global atomics.  A view whose
+// footprint does not fit, or a wave with a tap outside the box, adds to HBM directly.
+__host__ __device__ constexpr int bwd_cap(int nv) {   // texels per view: features + gradients in 56 KiB
+    const int raw = (56 * 1024) / (nv * 128);
+    return raw >= 192 ? 192 : (raw >= 128 ? 128 : raw);
+}
+
+template <int NV>
+__global__ __launch_bounds__(256, 2) void variance_bwd_dma_kernel(
+    const float *__restrict__ gvar, const float *__restrict__ ref16, const float *__restrict__ srcs16,
+    const float *__restrict__ rt, const float *__restrict__ depth, SweepParams p, int tiles_x,
+    int tiles_y, float *__restrict__ gref16, float *__restrict__ gsrcs16) {
+    constexpr int cap = bwd_cap(NV);
+    constexpr int NJ = (cap + 63) / 64;
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // features | gradients | ref gradients
+    float *fea = lds;                                 // [NV][4][cap][4]
+    float *grd = lds + NV * 4 * cap * 4;              // same shape
+    float *rgr = grd + NV * 4 * cap * 4;              // [4 quads][64 pixels][4]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tx, ty, dc;
+    {
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + ((int)blockIdx.x >> 3);
+        const int ndc = nwg / (tiles_x * tiles_y);
+        dc = bid % ndc; bid /= ndc;
+        tx = bid % tiles_x;
+        ty = bid / tiles_x;
+    }
+    const int b = blockIdx.y;
+    const int px = tx * kTileW + (lane & (kTileW - 1)), py = ty * kTileH + lane / kTileW;
+    const int d = dc * kTileD + wv;
+    const bool live = px < p.W && py < p.H && d < p.D;
+    const int cx = min(px, p.W - 1), cy = min(py, p.H - 1), cd = min(d, p.D - 1);
+    const int plane = p.H * p.W;
+    const int pix = cy * p.W + cx;
+    const float dv = depth[(int64_t)b * p.D + cd];
+    const int ngroups = p.C >> 4;
+    const size_t grp_floats = (size_t)plane * 16;
+    const unsigned lds_base = (unsigned)(uintptr_t)lds;
+
+    // ---- footprint boxes from the 8 corner voxels (see variance_fwd_dma_kernel)
+    int bx0[NV], by0[NV], bw[NV], bh[NV];
+    bool staged[NV];
+    {
+        const int v0 = lane >> 3, k = lane & 7;
+        const int xlo = tx * kTileW, xhi = min(tx * kTileW + kTileW - 1, p.W - 1);
+        const int ylo = ty * kTileH, yhi = min(ty * kTileH + kTileH - 1, p.H - 1);
+        const int dlo = dc * kTileD, dhi = min(dc * kTileD + kTileD - 1, p.D - 1);
+        const float *r = rt + ((int64_t)min(v0, NV - 1) * p.B + b) * 12;
+        const float cxk = (float)((k & 1) ? xhi : xlo), cyk = (float)((k & 2) ? yhi : ylo);
+        const float dk = depth[(int64_t)b * p.D + ((k & 4) ? dhi : dlo)];
+        float rx, ry, rz, ix, iy;
+        sweep_ray(r, cxk, cyk, rx, ry, rz);
+        sweep_coord(r, rx, ry, rz, dk, p.half_w, p.half_h, p.unn_w, p.unn_h, p.align_corners, ix, iy);
+        const bool zok = (rz * dk + r[11]) > 1e-6f && fabsf(ix) < 1.0e9f && fabsf(iy) < 1.0e9f;
+        int lo_x = (int)floorf(ix) - 1, hi_x = (int)floorf(ix) + 2;
+        int lo_y = (int)floorf(iy) - 1, hi_y = (int)floorf(iy) + 2;
+        int bad = zok ? 0 : 1;
+#pragma unroll
+        for (int off = 1; off <= 4; off <<= 1) {
+            lo_x = min(lo_x, __shfl_xor(lo_x, off)); hi_x = max(hi_x, __shfl_xor(hi_x, off));
+            lo_y = min(lo_y, __shfl_xor(lo_y, off)); hi_y = max(hi_y, __shfl_xor(hi_y, off));
+            bad |= __shfl_xor(bad, off);
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            int x0 = max(__builtin_amdgcn_readlane(lo_x, v * 8), 0);
+            int x1 = min(__builtin_amdgcn_readlane(hi_x, v * 8), p.W - 1);
+            int y0 = max(__builtin_amdgcn_readlane(lo_y, v * 8), 0);
+            int y1 = min(__builtin_amdgcn_readlane(hi_y, v * 8), p.H - 1);
+            const int vbad = __builtin_amdgcn_readlane(bad, v * 8);
+            if (x1 < x0 || y1 < y0) { x0 = y0 = x1 = y1 = 0; }
+            bx0[v] = x0; by0[v] = y0; bw[v] = x1 - x0 + 1; bh[v] = y1 - y0 + 1;
+            staged[v] = !vbad && bw[v] * bh[v] <= cap;
+        }
+    }
+    // source offset (floats, inside a 16-channel group) of this lane's texels
+    int soff[NV][NJ];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int n = bw[v] * bh[v];
+        const unsigned inv = (65536u + bw[v] - 1) / bw[v];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int t = min(j * 64 + lane, max(n - 1, 0));
+            const int ly = (int)(((unsigned)t * inv) >> 16), lx = t - ly * bw[v];
+            soff[v][j] = ((by0[v] + ly) * p.W + (bx0[v] + lx)) * 16;
+        }
+    }
+
+    // ---- taps of this voxel per view
+    float wnw[NV], wne[NV], wsw[NV], wse[NV];
+    int o00[NV], o01[NV], o10[NV], o11[NV];   // texel index inside the box (clamped), or image offset
+    bool m00[NV], m01[NV], m10[NV], m11[NV];  // tap inside the image
+    bool wave_in[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const float *r = rt + ((int64_t)v * p.B + b) * 12;
+        float rx, ry, rz, ix, iy;
+        sweep_ray(r, (float)cx, (float)cy, rx, ry, rz);
+        sweep_coord(r, rx, ry, rz, dv, p.half_w, p.half_h, p.unn_w, p.unn_h, p.align_corners, ix, iy);
+        Taps t = make_taps(ix, iy, p.H, p.W);
+        m00[v] = t.x0ok && t.y0ok; m01[v] = t.x1ok && t.y0ok;
+        m10[v] = t.x0ok && t.y1ok; m11[v] = t.x1ok && t.y1ok;
+        wnw[v] = t.nw; wne[v] = t.ne; wsw[v] = t.sw; wse[v] = t.se;
+        const bool any = m00[v] || m01[v] || m10[v] || m11[v];
+        const int lo_x = t.x0ok ? t.x0 : t.x1, hi_x = t.x1ok ? t.x1 : t.x0;
+        const int lo_y = t.y0ok ? t.y0 : t.y1, hi_y = t.y1ok ? t.y1 : t.y0;
+        const bool inbox = !any || (lo_x >= bx0[v] && hi_x < bx0[v] + bw[v] && lo_y >= by0[v] &&
+                                    hi_y < by0[v] + bh[v]);
+        wave_in[v] = __all(inbox) && staged[v];
+        const int x0c = min(max(t.x0, 0), p.W - 1), x1c = min(max(t.x1, 0), p.W - 1);
+        const int y0c = min(max(t.y0, 0), p.H - 1), y1c = min(max(t.y1, 0), p.H - 1);
+        if (wave_in[v]) {
+            const int ax0 = min(max(x0c - bx0[v], 0), bw[v] - 1), ax1 = min(max(x1c - bx0[v], 0), bw[v] - 1);
+            const int ay0 = min(max(y0c - by0[v], 0), bh[v] - 1), ay1 = min(max(y1c - by0[v], 0), bh[v] - 1);
+            o00[v] = ay0 * bw[v] + ax0; o01[v] = ay0 * bw[v] + ax1;
+            o10[v] = ay1 * bw[v] + ax0; o11[v] = ay1 * bw[v] + ax1;
+        } else {
+            o00[v] = y0c * p.W + x0c; o01[v] = y0c * p.W + x1c;
+            o10[v] = y1c * p.W + x0c; o11[v] = y1c * p.W + x1c;
+        }
+    }
+
+    const float inv_v = 1.0f / p.fV;
+    const int NG4 = NV * 4 * cap;   // float4 slots of the gradient image
+#pragma unroll 1
+    for (int g = 0; g < ngroups; ++g) {
+        __syncthreads();   // previous group's flush is complete
+        for (int i = tid; i < NG4 + 256; i += 256)
+            reinterpret_cast<float4 *>(grd)[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // incl. ref gradients
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if (!staged[v]) continue;
+            const mvs_srd_t srd = make_srd(srcs16 + (((size_t)v * p.B + b) * ngroups + g) * grp_floats + wv * 4,
+                                           (unsigned)(grp_floats * 4));
+            const int n = bw[v] * bh[v];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if (j * 64 >= n) continue;
+                if (j * 64 + lane < cap)
+                    glds16_buf((unsigned)soff[v][j] * 4u, srd, 0u,
+                               lds_base + (unsigned)(((v * 4 + wv) * cap + j * 64) * 16));
+            }
+        }
+        float4 ref4[4], gv4[4];
+        {
+            const float4 *rp = reinterpret_cast<const float4 *>(
+                ref16 + ((size_t)b * ngroups + g) * grp_floats + (size_t)pix * 16);
+            const float4 *gp = reinterpret_cast<const float4 *>(
+                gvar + (((size_t)b * p.D + cd) * plane + pix) * p.C + g * 16);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                ref4[k] = rp[k];
+                gv4[k] = live ? gp[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        // the four taps of view v, channel quad k, as float4
+        auto taps = [&](int v, int k, float4 &a, float4 &bq, float4 &c, float4 &e) {
+            if (wave_in[v]) {
+                const float *base = fea + (v * 4 + k) * cap * 4;
+                a = *reinterpret_cast<const float4 *>(base + o00[v] * 4);
+                bq = *reinterpret_cast<const float4 *>(base + o01[v] * 4);
+                c = *reinterpret_cast<const float4 *>(base + o10[v] * 4);
+                e = *reinterpret_cast<const float4 *>(base + o11[v] * 4);
+            } else {
+                const float *base = srcs16 + (((size_t)v * p.B + b) * ngroups + g) * grp_floats + k * 4;
+                a = *reinterpret_cast<const float4 *>(base + (size_t)o00[v] * 16);
+                bq = *reinterpret_cast<const float4 *>(base + (size_t)o01[v] * 16);
+                c = *reinterpret_cast<const float4 *>(base + (size_t)o10[v] * 16);
+                e = *reinterpret_cast<const float4 *>(base + (size_t)o11[v] * 16);
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float rr[4] = {ref4[k].x, ref4[k].y, ref4[k].z, ref4[k].w};
+            const float gg[4] = {gv4[k].x, gv4[k].y, gv4[k].z, gv4[k].w};
+            float S[4] = {rr[0], rr[1], rr[2], rr[3]};
+            float w[NV][4];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                float4 a, bq, c, e;
+                taps(v, k, a, bq, c, e);
+                const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {bq.x, bq.y, bq.z, bq.w};
+                const float cv[4] = {c.x, c.y, c.z, c.w}, ev[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    w[v][cc] = __fmaf_rn(m11[v] ? ev[cc] : 0.f, wse[v],
+                               __fmaf_rn(m10[v] ? cv[cc] : 0.f, wsw[v],
+                               __fmaf_rn(m01[v] ? bv[cc] : 0.f, wne[v], (m00[v] ? av[cc] : 0.f) * wnw[v])));
+                    S[cc] += w[v][cc];
+                }
+            }
+            float kk[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) kk[cc] = 2.0f * S[cc] * inv_v * inv_v;
+            // reference features: the 4 depth planes of the block meet in LDS
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+                atomicAdd(rgr + (k * 64 + lane) * 4 + cc, gg[cc] * (2.0f * rr[cc] * inv_v - kk[cc]));
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                float gw[4];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) gw[cc] = gg[cc] * (2.0f * w[v][cc] * inv_v - kk[cc]);
+                if (wave_in[v]) {
+                    float *base = grd + (v * 4 + k) * cap * 4;
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        if (m00[v]) atomicAdd(base + o00[v] * 4 + cc, gw[cc] * wnw[v]);
+                        if (m01[v]) atomicAdd(base + o01[v] * 4 + cc, gw[cc] * wne[v]);
+                        if (m10[v]) atomicAdd(base + o10[v] * 4 + cc, gw[cc] * wsw[v]);
+                        if (m11[v]) atomicAdd(base + o11[v] * 4 + cc, gw[cc] * wse[v]);
+                    }
+                } else if (live) {
+                    float *base = gsrcs16 + (((size_t)v * p.B + b) * ngroups + g) * grp_floats + k * 4;
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        if (m00[v]) unsafeAtomicAdd(base + (size_t)o00[v] * 16 + cc, gw[cc] * wnw[v]);
+                        if (m01[v]) unsafeAtomicAdd(base + (size_t)o01[v] * 16 + cc, gw[cc] * wne[v]);
+                        if (m10[v]) unsafeAtomicAdd(base + (size_t)o10[v] * 16 + cc, gw[cc] * wsw[v]);
+                        if (m11[v]) unsafeAtomicAdd(base + (size_t)o11[v] * 16 + cc, gw[cc] * wse[v]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- flush: every staged texel once, every reference pixel once
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if (!staged[v]) continue;
+            const int n = bw[v] * bh[v];
+            const unsigned inv = (65536u + bw[v] - 1) / bw[v];
+            float *dst = gsrcs16 + (((size_t)v * p.B + b) * ngroups + g) * grp_floats;
+            for (int e = tid; e < n * 16; e += 256) {
+                const int t = e >> 4, ch = e & 15;
+                const float val = grd[((v * 4 + (ch >> 2)) * cap + t) * 4 + (ch & 3)];
+                if (val != 0.0f) {
+                    const int ly = (int)(((unsigned)t * inv) >> 16), lx = t - ly * bw[v];
+                    unsafeAtomicAdd(dst + ((size_t)(by0[v] + ly) * p.W + (bx0[v] + lx)) * 16 + ch, val);
+                }
+            }
+        }
+        for (int e = tid; e < 64 * 16; e += 256) {
+            const int pl = e >> 4, ch = e & 15;
+            const int qx = tx * kTileW + (pl & (kTileW - 1)), qy = ty * kTileH + pl / kTileW;
+            const float val = rgr[((ch >> 2) * 64 + pl) * 4 + (ch & 3)];
+            if (qx < p.W && qy < p.H && val != 0.0f)
+                unsafeAtomicAdd(gref16 + ((size_t)b * ngroups + g) * grp_floats + ((size_t)qy * p.W + qx) * 16 + ch, val);
+        }
+    }
+}
+
 // Exhaustive check of div_views against IEEE division: every float bit pattern.
 __global__ __launch_bounds__(256) void div_selftest_kernel(float fV, unsigned long long *mismatch) {
     const float rV = 1.0f / fV;
@@ -996,12 +1263,42 @@ extern "C" int mvs_costvol_variance_bwd_f32(const float *grad_var, const float *
         return MVS_EINVAL;
     }
     if (NV < 1 || NV > kMaxSrcViews) return MVS_EUNSUPPORTED;
-    if (fea_layout != MVS_LAYOUT_NCHW || out_layout != MVS_LAYOUT_NCHW) {
-        set_error("mvs_costvol_variance_bwd_f32: only the planar layout is implemented");
-        return MVS_EUNSUPPORTED;
-    }
     SweepParams p = make_params(B, V, C, D, H, W, depth_mode, align_corners, 0);
     hipStream_t st = as_stream(stream);
+    if (fea_layout == MVS_LAYOUT_C16 && out_layout == MVS_LAYOUT_NHWC) {
+        // channels-last training form: LDS-accumulated footprints (shared depth planes)
+        if (depth_mode != 0 || C % 16 || C > 64) {
+            set_error("mvs_costvol_variance_bwd_f32: the C16 form needs [B,D] depth planes and C in {16,32,48,64}");
+            return MVS_EUNSUPPORTED;
+        }
+        const size_t fb = sizeof(float) * (size_t)B * C * H * W;
+        if (hipMemsetAsync(grad_ref, 0, fb, st) != hipSuccess ||
+            hipMemsetAsync(grad_srcs, 0, fb * NV, st) != hipSuccess)
+            return check_launch("mvs_costvol_variance_bwd_f32 memset");
+        const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (H + kTileH - 1) / kTileH;
+        const int dchunks = (D + kTileD - 1) / kTileD;
+        const int64_t nblk = (int64_t)tiles_x * tiles_y * dchunks;
+        if (nblk > 0x7fffffffLL || B > 65535) return MVS_EINVAL;
+        const dim3 g((unsigned)nblk, (unsigned)B);
+#define MVS_BWD_CASE(n)                                                                             \
+    case n: {                                                                                       \
+        const size_t shmem = ((size_t)2 * n * 4 * bwd_cap(n) * 4 + 4 * 64 * 4) * sizeof(float);     \
+        hipLaunchKernelGGL((variance_bwd_dma_kernel<n>), g, dim3(256), shmem, st, grad_var, ref_fea, \
+                           src_feas, rot_trans, depth_values, p, tiles_x, tiles_y, grad_ref,        \
+                           grad_srcs);                                                              \
+        break;                                                                                      \
+    }
+        switch (NV) {
+            MVS_BWD_CASE(1) MVS_BWD_CASE(2) MVS_BWD_CASE(3) MVS_BWD_CASE(4) MVS_BWD_CASE(5)
+            MVS_BWD_CASE(6) MVS_BWD_CASE(7) MVS_BWD_CASE(8)
+        }
+#undef MVS_BWD_CASE
+        return check_launch("mvs_costvol_variance_bwd_f32(c16)");
+    }
+    if (fea_layout != MVS_LAYOUT_NCHW || out_layout != MVS_LAYOUT_NCHW) {
+        set_error("mvs_costvol_variance_bwd_f32: layouts are NCHW/NCHW or C16 features with an NHWC volume");
+        return MVS_EUNSUPPORTED;
+    }
     unsigned grid;
     if (!grid_for((int64_t)B * D * H * W, 256, grid)) return MVS_EINVAL;
     const size_t fbytes = sizeof(float) * (size_t)B * C * H * W;

@@ -280,12 +280,22 @@ class MVSNet(nn.Module):
                     feats = [self.feature.forward_train_hip(imgs[:, v]) for v in range(V)]
                 else:
                     feats = [self.feature(imgs[:, v]) for v in range(V)]
-            var = ops.costvol_variance(feats[0], torch.stack(feats[1:]), rts, depth_values,
-                                       self.align_corners)              # [B,32,D,h,w]
-            if self.train_impl == "hip":
-                cost = self.cost_regularization.forward_train_hip(var.permute(0, 2, 3, 4, 1))
+            C = feats[0].shape[1]
+            if self.train_impl == "hip" and C % 16 == 0 and depth_values.dim() == 2:
+                # channels-last all the way: 16-channel-blocked maps (torch layout ops, in the
+                # autograd graph) -> DMA sweep kernel -> [B,D,h,w,C] for the conv kernels;
+                # backward on the LDS-accumulating kernel
+                f16 = torch.stack(feats)                                # [V,B,C,h,w]
+                f16 = f16.reshape(V, f16.shape[1], C // 16, 16, *f16.shape[3:]).permute(0, 1, 2, 4, 5, 3).contiguous()
+                var = ops.costvol_variance_c16_autograd(f16[0], f16[1:], rts, depth_values, self.align_corners)
+                cost = self.cost_regularization.forward_train_hip(var)
             else:
-                cost = self.cost_regularization(var).squeeze(1)
+                var = ops.costvol_variance(feats[0], torch.stack(feats[1:]), rts, depth_values,
+                                           self.align_corners)          # [B,32,D,h,w]
+                if self.train_impl == "hip":
+                    cost = self.cost_regularization.forward_train_hip(var.permute(0, 2, 3, 4, 1))
+                else:
+                    cost = self.cost_regularization(var).squeeze(1)
         else:
             B = imgs.shape[0]
             # the host hop of rot_trans runs while FeatureNet occupies the GPU

@@ -336,6 +336,40 @@ class _CostVolVariance(torch.autograd.Function):
         return g_ref, g_src, None, None, None, None
 
 
+class _CostVolVarianceC16(torch.autograd.Function):
+    """Channels-last training form: 16-channel-blocked feature maps in, [B,D,H,W,C] volume out
+    (DMA sweep kernel), backward on the LDS-accumulating kernel.  Shared depth planes only."""
+
+    @staticmethod
+    def forward(ctx, ref16, srcs16, rts, depth_values, align_corners):
+        ref16, srcs16, depth_values = _f32c(ref16), _f32c(srcs16), _f32c(depth_values)
+        if _depth_mode(depth_values) != 0:
+            raise MvsHipError("the differentiable channels-last variance takes [B,D] depth planes")
+        out = costvol_variance_c16(ref16, srcs16, rts, depth_values, align_corners)
+        ctx.save_for_backward(ref16, srcs16, rts, depth_values)
+        ctx.ac = int(align_corners)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_var):
+        ref16, srcs16, rts, depth_values = ctx.saved_tensors
+        B, G, H, W, _ = ref16.shape
+        V, D = srcs16.shape[0] + 1, depth_values.shape[1]
+        grad_var = _f32c(grad_var)
+        g_ref, g_src = torch.empty_like(ref16), torch.empty_like(srcs16)
+        check(_lib.load().mvs_costvol_variance_bwd_f32(
+            ptr(grad_var), ptr(ref16), ptr(srcs16), ptr(rts), ptr(depth_values), 0, B, V, G * 16, D, H, W,
+            ctx.ac, MVS_LAYOUT_C16, MVS_LAYOUT_NHWC, ptr(g_ref), ptr(g_src), stream()),
+            "mvs_costvol_variance_bwd_f32")
+        return g_ref, g_src, None, None, None
+
+
+def costvol_variance_c16_autograd(ref16, srcs16, rts, depth_values, align_corners=False):
+    """ref16 [B,C/16,H,W,16]; srcs16 [V-1,B,C/16,H,W,16] -> [B,D,H,W,C], differentiable w.r.t.
+    the feature maps."""
+    return _CostVolVarianceC16.apply(ref16, srcs16, rts, depth_values, align_corners)
+
+
 def costvol_variance(ref_fea, src_feas, rts, depth_values, align_corners=False, alias_quirk=False):
     """ref_fea [B,C,H,W]; src_feas [V-1,B,C,H,W]; rts [V-1,B,12] -> [B,C,D,H,W]
     (differentiable w.r.t. the feature maps)."""

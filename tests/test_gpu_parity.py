@@ -232,6 +232,34 @@ def test_variance_backward_golden(dev):
     np.testing.assert_allclose(srcs.grad.cpu().numpy(), g["grad_feats"][1:], atol=2e-5)
 
 
+@pytest.mark.parametrize("case", [(1, 3, 32, 7, 20, 28), (2, 2, 16, 5, 13, 37), (1, 5, 32, 9, 24, 40)])
+def test_variance_backward_channels_last_vs_planar(dev, case):
+    """The LDS-accumulating channels-last backward (16-channel-blocked maps, [B,D,H,W,C] volume)
+    against the planar backward kernel on the same data: gradients of every feature map,
+    ragged tiles, footprints leaving the image."""
+    from mvs_amd import ops, synth
+    B, V, C, D, H, W = case
+    rng = np.random.default_rng(sum(case))
+    proj = G(synth.proj_matrices(V, H, W, batch=B), dev)
+    dv = G(synth.depth_values(D, batch=B, interval=synth.sweep_interval(D)), dev)
+    feats = [G(synth.smooth_features(rng, (B, C, H, W)), dev).requires_grad_(True) for _ in range(V)]
+    rts = ops.rot_trans_all(proj)
+    var_p = ops.costvol_variance(feats[0], torch.stack(feats[1:]), rts, dv)           # [B,C,D,H,W]
+    go = torch.randn(B, D, H, W, C, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    var_p.backward(go.permute(0, 4, 1, 2, 3))
+    want = [f.grad.clone() for f in feats]
+    for f in feats:
+        f.grad = None
+    f16 = torch.stack(feats).reshape(V, B, C // 16, 16, H, W).permute(0, 1, 2, 4, 5, 3).contiguous()
+    var_c = ops.costvol_variance_c16_autograd(f16[0], f16[1:], rts, dv)               # [B,D,H,W,C]
+    assert torch.equal(var_c.permute(0, 4, 1, 2, 3), var_p)
+    var_c.backward(go)
+    for v in range(V):
+        scale = float(want[v].abs().max())
+        np.testing.assert_allclose(feats[v].grad.cpu().numpy(), want[v].cpu().numpy(),
+                                   atol=2e-5 * scale + 1e-6, rtol=2e-4)
+
+
 def test_variance_vs_oracle_seeded_midsize(dev):
     """C oracle vs HIP on a seeded mid-size case incl. ragged sizes (W not a
     multiple of the wave) and per-pixel hypotheses."""
