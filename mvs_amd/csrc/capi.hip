@@ -149,7 +149,10 @@ extern "C" int mvs_conv3d_f32(const float *in, const float *weight, const float 
         return MVS_EINVAL;
     }
     hipStream_t st = as_stream(stream);
-    const bool mfma_ok = layout != MVS_LAYOUT_NCHW && packed_weight &&
+    // the MFMA kernels address a tile's halo planes with 32-bit byte offsets: 9 input planes
+    // (the deepest halo, stride 2) must stay below 4 GiB -- 12 M pixels at 8 channels
+    const bool window_ok = (int64_t)9 * H * W * Cin * 4 < 0xffffff00LL;
+    const bool mfma_ok = layout != MVS_LAYOUT_NCHW && packed_weight && window_ok &&
                          conv3d_mfma_supported(transposed, Cin, Cout, stride);
     if (impl == 2 && !mfma_ok) {
         set_error("mvs_conv3d_f32: MFMA path needs channels-last, packed weights and a supported "
