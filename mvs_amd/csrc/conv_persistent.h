@@ -89,18 +89,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // for the 16-byte voxel stride used below): hipcc merges neighbouring b64 loads into
 // ds_read2_b64, which is serviced under 32-bank rules in 16-lane groups -- a 2-way
 // conflict on this layout that makes the reads, not the MFMAs, set the pace.  The
-// compiler does not see these loads complete: lds_wait<N>() is the matching s_waitcnt.
+// compiler does not see these loads complete: lds_wait_n<N>() is the matching s_waitcnt.
 template <int OFF>
 __device__ __forceinline__ f32x2 lds_read_b64(unsigned addr) {
     static_assert(OFF >= 0 && OFF < 65536 && OFF % 8 == 0, "ds_read_b64 offset field");
     f32x2 v;
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
     return v;
-}
-// wait until at most N LDS reads issued after the three tied ones are outstanding
-template <int N>
-__device__ __forceinline__ void lds_wait(f32x2 &a, f32x2 &b, f32x2 &c) {
-    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N));
 }
 // wait until at most N LDS operations are outstanding (pair with an empty asm "+v" on the
 // registers the landed reads wrote, so their consumers stay behind the wait)
