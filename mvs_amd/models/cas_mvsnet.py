@@ -214,6 +214,10 @@ class CascadeMVSNet(nn.Module):
         B, V, _, H, W = imgs.shape
         depth_min, depth_max = float(depth_values[0, 0]), float(depth_values[0, -1])
         depth_interval = (depth_max - depth_min) / depth_values.size(1)
+        # the three stages' host hops (K @ E, inverse, product on the CPU like the reference's CPU
+        # forward) depend on the inputs only: start them now, under the feature pyramid
+        jobs = {k: ops.HostRotTrans(proj_matrices[k], cas_pairs=True) for k in self.stage_scale} \
+            if self.proj_where == "host" else {}
         use_hip = self.feature_impl == "hip" and not self.training and self.feature.hip_supported()
         with ops.stage("feature"):
             if use_hip:   # all views in one batch; channels-last pyramids, split per view
@@ -241,7 +245,7 @@ class CascadeMVSNet(nn.Module):
             out = cascade.depthnet_forward(stage_feats, proj_matrices[key], hyp,
                                            self.cost_regularization[s].hip_params(),
                                            proj_where=self.proj_where, tag=key + ".",
-                                           features_cl=use_hip)
+                                           features_cl=use_hip, rts_job=jobs.get(key))
             depth = out["depth"]
             outputs[key] = out
             outputs.update(out)

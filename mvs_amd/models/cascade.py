@@ -64,15 +64,18 @@ def costreg_forward(x_cl, P, impl=ops.IMPL_AUTO, in_c8=False):
 
 
 def depthnet_forward(features, cas_proj, depth_values, costreg_params, prob_volume_init=None,
-                     proj_where="host", tag="", features_cl=False):
+                     proj_where="host", tag="", features_cl=False, rts_job=None):
     """features: list of V tensors [B,C,H,W] ([B,H,W,C] with features_cl); cas_proj [B,V,2,4,4]; depth_values [B,D,H,W]
     -> {"depth", "photometric_confidence"} as DepthNet.forward (cas_mvsnet.py:12-66)."""
     # like rot_trans, the K @ E composition is evaluated where the reference's CPU forward
     # evaluates it (host) unless told otherwise: the depth is sensitive to its rounding
     dev = cas_proj.device
     with ops.stage(tag + "rot_trans"):
-        proj = compose_cas_proj(cas_proj.cpu() if proj_where == "host" else cas_proj)
-        rts = ops.rot_trans_all(proj, proj_where, device=dev)
+        if rts_job is not None:          # a host hop started earlier (ops.HostRotTrans(cas_pairs=True))
+            rts = rts_job.result()
+        else:
+            proj = compose_cas_proj(cas_proj.cpu() if proj_where == "host" else cas_proj)
+            rts = ops.rot_trans_all(proj, proj_where, device=dev)
     with ops.stage(tag + "to_channels_last"):
         if features_cl:   # [B,H,W,C] already (the HIP FeatureNet's layout)
             fcl = torch.stack([f for f in features])

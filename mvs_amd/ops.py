@@ -199,6 +199,15 @@ class _HostHop:
         return out
 
 
+def _cas_rot_trans_host_math(host):
+    """[B,V,2,4,4] (extrinsic, intrinsic) pairs, CPU fp32 -> [V-1,B,12]: K @ E[:3,:4] composed as
+    CasMVSNet does (cas_mvsnet.py:30-33), then the reference's rot_trans algebra."""
+    E, K = host[:, :, 0], host[:, :, 1]
+    P = E.clone()
+    P[:, :, :3, :4] = torch.matmul(K[:, :, :3, :3], E[:, :, :3, :4])
+    return _rot_trans_host_math(P)
+
+
 class HostRotTrans:
     """rot_trans_all(where="host") as a stream-ordered job that overlaps GPU work:
 
@@ -212,9 +221,10 @@ class HostRotTrans:
     never waits for the GPU.  blocking=True (or a runtime without hipLaunchHostFunc) does
     the hop synchronously in result().  Values are bit-identical to rot_trans_all."""
 
-    def __init__(self, proj_matrices, blocking=False):
+    def __init__(self, proj_matrices, blocking=False, cas_pairs=False):
         self.P = proj_matrices.detach()
         self.dev = proj_matrices.device
+        self.math = _cas_rot_trans_host_math if cas_pairs else _rot_trans_host_math
         ev = torch.cuda.Event()
         ev.record()
         side = _side_stream(self.dev)
@@ -222,7 +232,7 @@ class HostRotTrans:
         self.out = self.done = None
         if not blocking and _HostHop.hip():
             B, V = self.P.shape[0], self.P.shape[1]
-            hop = _HostHop.get(self.dev, (B, V, 4, 4), (V - 1, B, 12), _rot_trans_host_math)
+            hop = _HostHop.get(self.dev, tuple(self.P.shape), (V - 1, B, 12), self.math)
             with torch.no_grad(), torch.cuda.stream(side):
                 self.out = hop.enqueue(self.P.float(), side)
                 self.done = torch.cuda.Event()
@@ -239,7 +249,7 @@ class HostRotTrans:
             with torch.cuda.stream(side):
                 host = self.P.float().to("cpu", non_blocking=True)
             side.synchronize()
-            return _rot_trans_host_math(host).to(self.dev, non_blocking=True)
+            return self.math(host).to(self.dev, non_blocking=True)
 
 
 def _depth_mode(depth_values):
