@@ -148,10 +148,13 @@ int mvs_conv3d_wgrad_supported(int Cin, int Cout, int stride);
 /* ---- FeatureNet layers -- mvsnet.py:8-45 ("next" row 1) ---- */
 /* One 2D convolution of FeatureNet on the fp32 matrix cores: k x k (3 stride 1, or 5
  * stride 2), pad k/2, no conv bias, then y = acc*scale[co] + shift[co] (BatchNorm(eval)
- * folded; for the last layer scale = NULL and shift = the conv bias) and optional ReLU.
+ * folded; for the last layer scale = NULL and shift = the conv bias) and the activation
+ * `relu`: 0 none, 1 ReLU, 2 LeakyReLU(0.1) (CVP-MVSNet/models/modules.py:22-26).
  * in: [B,H,W,Cin] channels-last, or with in_planar the reference's [B,3,H,W] image
  * (3-channel layer only).  out: [B,Ho,Wo,Cout] channels-last.  Supported (Cin,Cout,k,
- * stride): (3,8,3,1) (8,8,3,1) (8,16,5,2) (16,16,3,1) (16,32,5,2) (32,32,3,1). */
+ * stride): (3,8,3,1) (8,8,3,1) (8,16,5,2) (16,16,3,1) (16,32,5,2) (32,32,3,1); the
+ * CasMVSNet FPN heads (32,32,1,1) (16,32,1,1) (8,32,1,1) (32,16,3,1) (32,8,3,1); the
+ * CVP-MVSNet pyramid (3,64,3,1) (64,64,3,1) (64,32,3,1) (32,16,3,1). */
 int mvs_conv2d_f32(const float *in, const float *packed_weight, const float *scale,
                    const float *shift, int relu, int B, int Cin, int Cout, int H, int W,
                    int ksize, int stride, int in_planar, float *out, void *stream);

@@ -199,9 +199,12 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(Conv2Args a) {
                 const float4 sh = *reinterpret_cast<const float4 *>(a.shift + c0);
                 v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w;
             }
-            if (a.relu) {
+            if (a.relu == 1) {
                 v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
                 v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+            } else if (a.relu == 2) {   // LeakyReLU(0.1)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * 0.1f;
             }
             *reinterpret_cast<float4 *>(a.out + (((int64_t)b * a.Ho + oy) * a.Wo + ox) * COUT + c0) =
                 make_float4(v[0], v[1], v[2], v[3]);
@@ -289,6 +292,9 @@ static bool lookup_persist2(int Cin, int Cout, int ksize, int stride, Persist2In
     MVS_P2(8, 32, 1, 1, 0, 32)    // inner2
     MVS_P2(32, 16, 3, 1, 0, 32)   // out2
     MVS_P2(32, 8, 3, 1, 2, 32)    // out3
+    // CVP-MVSNet feature pyramid
+    MVS_P2(64, 32, 3, 1, 0, 32)   // conv0bc
+    // ((32,16) conv0bf, (32,32) conv0bd/be and (16,16) conv0bg/bh: entries above)
 #undef MVS_P2
     return false;
 }
@@ -320,6 +326,9 @@ static bool lookup2(int Cin, int Cout, int ksize, int stride, Cfg2Info &ci) {
     MVS_C2(16, 16, 16, 3, 1, 16, 32)  // feature.conv3, conv4
     MVS_C2(16, 16, 32, 5, 2, 16, 8)   // feature.conv5
     MVS_C2(32, 32, 32, 3, 1, 16, 32)  // feature.conv6, feature.feature
+    // CVP-MVSNet feature pyramid (CVP-MVSNet/models/net.py:28-37)
+    MVS_C2(3, 4, 64, 3, 1, 4, 16)     // conv0aa (RGB, planar input)
+    MVS_C2(64, 64, 64, 3, 1, 16, 16)  // conv0ba, conv0bb
 #undef MVS_C2
     return false;
 }

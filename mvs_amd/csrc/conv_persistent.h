@@ -366,9 +366,12 @@ __global__ __launch_bounds__(512) void conv3d_c8_persistent_kernel(ConvArgs a, i
                     const int c0 = (MODE == 2) ? (kq & 1) * 4 : m * 16 + kq * 4;
                     v[0] = v[0] * sc[m].x + sh[m].x; v[1] = v[1] * sc[m].y + sh[m].y;
                     v[2] = v[2] * sc[m].z + sh[m].z; v[3] = v[3] * sc[m].w + sh[m].w;
-                    if (a.relu) {
+                    if (a.relu == 1) {
                         v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
                         v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                    } else if (a.relu == 2) {   // LeakyReLU(0.1): CVP-MVSNet's feature pyramid
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * 0.1f;
                     }
                     const int64_t o = ((((int64_t)cur.b * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * COUT + c0;
                     if (a.residual && !(ABL & 16)) {

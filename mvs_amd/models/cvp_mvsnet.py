@@ -50,6 +50,41 @@ class FeaturePyramid(nn.Module):
             out.append(self._cnn(img))
         return out
 
+    # -- inference path on the HIP 2D kernels: conv bias in the epilogue, LeakyReLU(0.1)
+    def _hip_params(self):
+        key = tuple((p._version, p.data_ptr()) for p in self.parameters())
+        cache = getattr(self, "_hip_cache", None)
+        if cache is not None and cache[0] == key:
+            return cache[1]
+        P = []
+        with torch.no_grad():
+            for name in self._ORDER:
+                conv = getattr(self, name)[0]
+                w = conv.weight.detach().float().contiguous()
+                P.append(dict(cin=w.shape[1], cout=w.shape[0], packed=ops.pack_conv2d_weight(w, 1),
+                              shift=conv.bias.detach().float().contiguous()))
+        self._hip_cache = (key, P)
+        return P
+
+    def hip_supported(self):
+        return all(p["packed"] is not None for p in self._hip_params())
+
+    def forward_hip(self, img, scales=5):
+        """[N,3,H,W] -> `scales` channels-last maps [N,H/2^l,W/2^l,16] (the image pyramid's
+        bilinear x0.5 stays a torch op)."""
+        P = self._hip_params()
+
+        def cnn(x):
+            for i, p in enumerate(P):
+                x = ops.conv2d(x, p["packed"], p["cin"], p["cout"], 3, 1, None, p["shift"], 2, planar=(i == 0))
+            return x
+
+        out = [cnn(img)]
+        for _ in range(scales - 1):
+            img = F.interpolate(img, scale_factor=0.5, mode="bilinear", align_corners=None)
+            out.append(cnn(img))
+        return out
+
 
 class _CBR3d(nn.Module):
     def __init__(self, cin, cout, stride=1):
@@ -205,8 +240,9 @@ def refine_hypotheses(depth_up, K_ref, K_src0, E_ref, E_src0, d=4, pixel_interva
 
 
 class CVPMVSNet(nn.Module):
-    def __init__(self, args=None, nscale=2, nsrc=2, proj_where="host"):
+    def __init__(self, args=None, nscale=2, nsrc=2, proj_where="host", feature_impl="hip"):
         super().__init__()
+        self.feature_impl = feature_impl   # "hip": 2D MFMA kernels; "torch": PyTorch-ROCm / MIOpen
         self.nscale = args.nscale if args is not None else nscale
         self.nsrc = args.nsrc if args is not None else nsrc
         self.args = args
@@ -232,13 +268,24 @@ class CVPMVSNet(nn.Module):
         if self.training:
             raise NotImplementedError("CVPMVSNet here is the inference path (BASELINE configs[3])")
         nsrc, nscale = self.nsrc, self.nscale
-        pyr = [self.featurePyramid(ref_img, nscale)] + \
-              [self.featurePyramid(src_imgs[:, i], nscale) for i in range(nsrc)]
-        K_ref = condition_intrinsics(ref_in, ref_img.shape, [f.shape for f in pyr[0]])          # [B,nscale,3,3]
-        K_src = torch.stack([condition_intrinsics(src_in[:, i], ref_img.shape, [f.shape for f in pyr[i + 1]])
+        use_hip = self.feature_impl == "hip" and self.featurePyramid.hip_supported()
+        if use_hip:   # all views as one batch, channels-last maps
+            B = ref_img.shape[0]
+            allv = torch.cat((ref_img.unsqueeze(1), src_imgs), 1).reshape(B * (nsrc + 1), *ref_img.shape[1:])
+            maps = self.featurePyramid.forward_hip(allv, nscale)
+            pyr = [[m.reshape(B, nsrc + 1, *m.shape[1:])[:, v] for m in maps] for v in range(nsrc + 1)]
+            shapes = [(B, 16, m.shape[1], m.shape[2]) for m in maps]
+        else:
+            pyr = [self.featurePyramid(ref_img, nscale)] + \
+                  [self.featurePyramid(src_imgs[:, i], nscale) for i in range(nsrc)]
+            shapes = [f.shape for f in pyr[0]]
+        K_ref = condition_intrinsics(ref_in, ref_img.shape, shapes)                             # [B,nscale,3,3]
+        K_src = torch.stack([condition_intrinsics(src_in[:, i], ref_img.shape, shapes)
                              for i in range(nsrc)], 1)                                         # [B,nsrc,nscale,3,3]
 
         def level_feats(level):
+            if use_hip:
+                return [p[level].contiguous() for p in pyr]
             return [ops.nchw_to_nhwc(p[level]) for p in pyr]
 
         depths = []

@@ -552,7 +552,7 @@ def conv3d_wgrad(x_cl, g_cl, stride):
 
 def conv2d(x, packed, cin, cout, ksize, stride, scale=None, shift=None, relu=False, planar=False):
     """FeatureNet convolution.  x: [B,H,W,cin] channels-last, or (planar) the [B,3,H,W]
-    image.  Returns [B,Ho,Wo,cout] channels-last."""
+    image.  relu: False/True, or 2 for LeakyReLU(0.1).  Returns [B,Ho,Wo,cout] channels-last."""
     x = _f32c(x)
     if planar:
         B, _, H, W = x.shape

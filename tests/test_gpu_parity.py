@@ -470,10 +470,14 @@ def test_costregnet_hip_golden(dev, weights):
 
 # ------------------------------------------------------------ FeatureNet
 @pytest.mark.parametrize("cfg", [(3, 8, 3, 1), (8, 8, 3, 1), (8, 16, 5, 2), (16, 16, 3, 1),
-                                 (16, 32, 5, 2), (32, 32, 3, 1)])
+                                 (16, 32, 5, 2), (32, 32, 3, 1),
+                                 # CasMVSNet FPN heads, CVP-MVSNet pyramid
+                                 (32, 32, 1, 1), (16, 32, 1, 1), (8, 32, 1, 1), (32, 16, 3, 1), (32, 8, 3, 1),
+                                 (3, 64, 3, 1), (64, 64, 3, 1), (64, 32, 3, 1)])
 @pytest.mark.parametrize("shape", [(2, 37, 53), (1, 64, 96), (1, 17, 130)])
 def test_conv2d_mfma_vs_aten(dev, cfg, shape):
-    """2D MFMA kernels of FeatureNet vs ATen's CPU conv2d on ragged images."""
+    """2D MFMA kernels of the feature networks vs ATen's CPU conv2d on ragged images
+    (BatchNorm affine + ReLU epilogue, and the bias + LeakyReLU(0.1) form)."""
     import torch.nn.functional as F
     from mvs_amd import ops
     cin, cout, k, stride = cfg
@@ -492,6 +496,9 @@ def test_conv2d_mfma_vs_aten(dev, cfg, shape):
                      planar=(cin == 3))
     np.testing.assert_allclose(got.permute(0, 3, 1, 2).cpu().numpy(), want.numpy(), atol=3e-5,
                                rtol=1e-5)
+    want2 = F.leaky_relu(F.conv2d(x, w, shift, stride, k // 2), 0.1)
+    got2 = ops.conv2d(xin, packed, cin, cout, k, stride, None, shift.to(dev), 2, planar=(cin == 3))
+    np.testing.assert_allclose(got2.permute(0, 3, 1, 2).cpu().numpy(), want2.numpy(), atol=3e-5, rtol=1e-5)
 
 
 @pytest.mark.parametrize("name", ["g6_e2e_64x96_v3_d8", "g6_e2e_128x160_v3_d16"])
