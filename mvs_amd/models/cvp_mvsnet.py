@@ -229,11 +229,11 @@ def refine_hypotheses(depth_up, K_ref, K_src0, E_ref, E_src0, d=4, pixel_interva
         A = torch.matmul(torch.matmul(Kr, Er[:3, :3]), torch.inverse(torch.matmul(Ks, Es[:3, :3])))
         t1 = z1 * torch.matmul(A, x1)
         t2 = torch.matmul(A, x3)
-        # rows y and 1 of   pix * a + t2 * b = t1   ->  a is the depth at which the shifted
-        # source pixel's ray meets the reference ray; minus ... the reference keeps ans[0]
-        M = torch.stack((pix.t()[:, 1:], t2.t()[:, 1:]), 2)            # [N,2,2]
-        ans = torch.matmul(torch.inverse(M), t1.t()[:, 1:].unsqueeze(2))
-        interval = ans[:, 0, 0].abs().mean().float()
+        # first unknown of the 2x2 system  [y t2_y; 1 t2_z] [a; b] = [t1_y; t1_z]  per pixel
+        # (Cramer's rule; the reference inverts the N 2x2 matrices with a batched LU)
+        det = pix[1] * t2[2] - t2[1] * pix[2]
+        ans0 = (t1[1] * t2[2] - t2[1] * t1[2]) / det
+        interval = ans0.abs().mean().float()
         for k in range(-d, d):
             out[b, k + d] += k * interval
     return out.float()
