@@ -72,8 +72,9 @@ __device__ __forceinline__ TileIdx decode_tile(const ConvArgs &a, int blk, int n
 // pipe idled ~30 %.  Here
 //   * the whole layer's A fragments (Cin/8 x 18 KiB) live in LDS for the kernel's
 //     lifetime: no global load is ever waited on inside the MFMA loop;
-//   * the input halo of an 8-channel chunk goes HBM -> LDS with global_load_lds_dwordx4
-//     (no staging VGPRs, no ds_write pass, 5 DMA instructions per thread per chunk) into
+//   * the input halo of an 8-channel chunk goes HBM -> LDS by buffer-addressed DMA
+//     (buffer_load_dwordx4 ... lds: no staging VGPRs, no ds_write pass, no vector ALU work per
+//     copy, 5 DMA instructions per thread per chunk, zero fill by the range check) into
 //     the buffer the MFMAs are NOT reading; chunk k+1 (of this tile or the next) is in
 //     flight during the MFMAs of chunk k, and there is one barrier per chunk;
 //   * all 8 waves do both jobs, so the two waves of a SIMD are always in the same phase.
