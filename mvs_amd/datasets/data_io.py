@@ -8,39 +8,42 @@ import sys
 
 import numpy as np
 
+_CHANNELS = {b"Pf": 1, b"PF": 3}
 _DIMS = re.compile(rb"^(\d+)\s(\d+)\s$")
 
 
+def _parse_header(stream):
+    """-> (channels, width, height, byte-order char, |scale|); raises on a malformed header."""
+    channels = _CHANNELS.get(stream.readline().rstrip())
+    if channels is None:
+        raise Exception("Not a PFM file.")
+    dims = _DIMS.match(stream.readline())
+    if dims is None:
+        raise Exception("Malformed PFM header.")
+    signed_scale = float(stream.readline().rstrip())
+    return channels, int(dims.group(1)), int(dims.group(2)), ("<" if signed_scale < 0 else ">"), abs(signed_scale)
+
+
 def read_pfm(filename):
-    """-> (array [H,W] or [H,W,3] float32 in file byte order, top row first; scale > 0)."""
-    with open(filename, "rb") as f:
-        magic = f.readline().rstrip()
-        if magic not in (b"PF", b"Pf"):
-            raise Exception("Not a PFM file.")
-        m = _DIMS.match(f.readline())
-        if not m:
-            raise Exception("Malformed PFM header.")
-        width, height = int(m.group(1)), int(m.group(2))
-        scale = float(f.readline().rstrip())
-        order = "<" if scale < 0 else ">"
-        data = np.fromfile(f, order + "f")
-    shape = (height, width, 3) if magic == b"PF" else (height, width)
-    return np.flipud(data.reshape(shape)), abs(scale)
+    """-> (float32 array [H,W] or [H,W,3] in the file's byte order, top row first; scale > 0)."""
+    with open(filename, "rb") as stream:
+        channels, width, height, order, scale = _parse_header(stream)
+        payload = np.frombuffer(stream.read(), dtype=order + "f4")
+    rows = payload.reshape((height, width, 3) if channels == 3 else (height, width))
+    return rows[::-1], scale      # stored bottom-to-top
 
 
 def save_pfm(filename, image, scale=1):
     """image: float32 [H,W], [H,W,1] or [H,W,3]."""
     if image.dtype.name != "float32":
         raise Exception("Image dtype must be float32.")
-    if image.ndim == 3 and image.shape[2] == 3:
-        magic = b"PF\n"
-    elif image.ndim == 2 or (image.ndim == 3 and image.shape[2] == 1):
-        magic = b"Pf\n"
-    else:
+    grey = image.ndim == 2 or (image.ndim == 3 and image.shape[2] == 1)
+    if not grey and not (image.ndim == 3 and image.shape[2] == 3):
         raise Exception("Image must have H x W x 3, H x W x 1 or H x W dimensions.")
-    little = image.dtype.byteorder == "<" or (image.dtype.byteorder == "=" and sys.byteorder == "little")
-    with open(filename, "wb") as f:
-        f.write(magic)
-        f.write(b"%d %d\n" % (image.shape[1], image.shape[0]))
-        f.write(b"%f\n" % (-scale if little else scale))
-        np.flipud(image).tofile(f)
+    order = image.dtype.byteorder
+    little_endian = order == "<" or (order == "=" and sys.byteorder == "little")
+    header = b"%s\n%d %d\n%f\n" % (b"Pf" if grey else b"PF", image.shape[1], image.shape[0],
+                                  -scale if little_endian else scale)
+    with open(filename, "wb") as stream:
+        stream.write(header)
+        stream.write(np.ascontiguousarray(image[::-1]).tobytes())
