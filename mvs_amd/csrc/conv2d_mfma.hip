@@ -391,14 +391,7 @@ int conv2d_launch(const float *in, const float *packed, const float *scale, cons
         a.relu = relu; a.in_c8 = 0; a.ystrip = 4;
         const int64_t nt = (int64_t)a.tiles_x * a.tiles_y * a.tiles_z;
         if (nt <= 0 || nt > 0x7fffffffLL) return MVS_EINVAL;
-        static int n_cu = 0;
-        if (n_cu == 0) {
-            int dev = 0, cu = 0;
-            if (hipGetDevice(&dev) != hipSuccess ||
-                hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0)
-                cu = 256;
-            n_cu = cu;
-        }
+        const int n_cu = device_cu_count();
         hipLaunchKernelGGL(pi.kernel, dim3((unsigned)(nt < n_cu ? nt : n_cu)), dim3(512), 0, st, a, (int)nt);
         return check_launch("mvs_conv2d_f32(persistent)");
     }

@@ -852,14 +852,7 @@ int conv3d_mfma_launch(const float *in, const float *packed, const float *scale,
         // (its copies address a tile's halo planes with 32-bit byte offsets)
         const bool window_ok = (int64_t)9 * H * W * Cin * 4 < 0xffffff00LL;
         if ((c8_class || s2_class) && window_ok && (v == 0 || v >= 20)) {
-            static int n_cu = 0;
-            if (n_cu == 0) {
-                int dev = 0, cu = 0;
-                if (hipGetDevice(&dev) != hipSuccess ||
-                    hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0)
-                    cu = 256;
-                n_cu = cu;
-            }
+            const int n_cu = device_cu_count();
             if (c8_class) {
                 a.tiles_x = (a.Wo + 31) / 32; a.tiles_y = (a.Ho + 3) / 4; a.tiles_z = (a.Do + 3) / 4;
             } else {

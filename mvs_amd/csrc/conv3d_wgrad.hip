@@ -168,14 +168,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(WgradArgs a, int n
 
 template <int COUT_T, int CK, int S>
 static int launch_wgrad(const WgradArgs &a, int ntiles, hipStream_t st) {
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0, cu = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0)
-            cu = 256;
-        n_cu = cu;
-    }
+    const int n_cu = device_cu_count();
     const int ncc = (a.Cin + CK - 1) / CK;
     int streams = (2 * n_cu) / ncc;               // tile streams per ci slice
     if (streams > ntiles) streams = ntiles;

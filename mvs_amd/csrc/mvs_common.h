@@ -23,6 +23,16 @@ inline int check_launch(const char *what) {
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Compute units of the current device (grid size of the persistent kernels); 256 if the
+// runtime cannot tell.  Queried per call: cheap, and correct when a process drives several GPUs.
+inline int device_cu_count() {
+    int dev = 0, cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0)
+        cu = 256;
+    return cu;
+}
+
 constexpr int kWave = 64;  // CDNA wavefront
 
 // ---------------------------------------------------------------------
