@@ -711,25 +711,62 @@ __global__ __launch_bounds__(256, 2) void variance_fwd_dma_kernel(
 // The planar kernel sends every tap's share straight to HBM: (1 + 4 (V-1)) C atomics per
 // voxel, 1.1 G at config 5, and those atomics are its whole cost.  Here a block (8x8 pixels
 // x 4 depth planes) stages the source footprints as the forward kernel does, accumulates
-// the gradients of the same footprints (and of its 64 reference pixels) in LDS with
-// ds_add_f32, and flushes each texel ONCE: ~8x fewer global atomics.  A view whose
-// footprint does not fit, or a wave with a tap outside the box, adds to HBM directly.
-__host__ __device__ constexpr int bwd_cap(int nv) {   // texels per view: features + gradients in 56 KiB
-    const int raw = (56 * 1024) / (nv * 128);
-    return raw >= 192 ? 192 : (raw >= 128 ? 128 : raw);
+// the gradients of the same footprints (and of its 64 reference pixels) in LDS, and flushes
+// each texel ONCE: ~8x fewer global atomics.  A view whose footprint does not fit, or a wave
+// with a tap outside the box, adds to HBM directly.
+//
+// The LDS accumulators are 64-bit fixed point, not floats: on gfx950 ds_add_f32 retires one
+// lane every ~3 cycles (194 cycles per wave instruction whatever the bank pattern,
+// scripts/micro/lds_atomic.hip), ds_add_u64 a whole wave in 7.  Per 16-channel group the block
+// bounds its contributions, |g (2 w / V - 2 S / V^2) weight| <= 4 max|g| max|f| / V < 2^e,
+// scales by 2^(52-e) (exact) and adds integers: a texel collects at most 2^8 such terms, so
+// the sum stays below 2^61, every term is rounded at 2^-52 of the bound (fp32 accumulation
+// rounds at 2^-24 of the running sum), and the block's sum no longer depends on the order of
+// the adds.  Non-finite gradients or features poison the block's footprint with NaN.
+// Channel quads per pass: a whole 16-channel group while two blocks per CU still hold a
+// typical footprint (11x11 texels for a translation, more under rotation), else half a group
+// -- a view whose footprint does not fit falls back to HBM atomics, ~50x slower.
+__host__ __device__ constexpr int bwd_quads(int nv) { return nv <= 2 ? 4 : 2; }
+__host__ __device__ constexpr int bwd_fixed_bytes(int nv) { return bwd_quads(nv) * 4 * 64 * 8 + 64; }
+__host__ __device__ constexpr int bwd_cap_for(int nv, int budget) {
+    const int raw = (budget - bwd_fixed_bytes(nv)) / (nv * 48 * bwd_quads(nv));   // 16 B features + 32 B sums per quad
+    return raw >= 160 ? 160 : raw;
+}
+__host__ __device__ constexpr int bwd_blocks_per_cu(int nv) { return bwd_cap_for(nv, 80 * 1024) >= 160 ? 2 : 1; }
+__host__ __device__ constexpr int bwd_cap(int nv) {   // texels per view
+    return bwd_cap_for(nv, bwd_blocks_per_cu(nv) == 2 ? 80 * 1024 : 160 * 1024);
+}
+__host__ __device__ constexpr int bwd_lds_bytes(int nv) {
+    return nv * bwd_cap(nv) * 48 * bwd_quads(nv) + bwd_fixed_bytes(nv);
+}
+
+// x * 2^k (|result| < 2^62) as a two's-complement 64-bit integer, floor rounding.
+__device__ __forceinline__ unsigned long long fixed64(float y) {
+    const float hi = floorf(y * 0x1p-32f);
+    const float lo = __fmaf_rn(hi, -0x1p32f, y);   // exact, in [0, 2^32)
+    return ((unsigned long long)(unsigned)(int)hi << 32) | (unsigned long long)(unsigned)lo;
+}
+
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x = fmaxf(x, __shfl_xor(x, off));
+    return x;
 }
 
 template <int NV>
-__global__ __launch_bounds__(256, 2) void variance_bwd_dma_kernel(
+__global__ __launch_bounds__(256, bwd_blocks_per_cu(NV)) void variance_bwd_dma_kernel(
     const float *__restrict__ gvar, const float *__restrict__ ref16, const float *__restrict__ srcs16,
     const float *__restrict__ rt, const float *__restrict__ depth, SweepParams p, int tiles_x,
     int tiles_y, float *__restrict__ gref16, float *__restrict__ gsrcs16) {
     constexpr int cap = bwd_cap(NV);
     constexpr int NJ = (cap + 63) / 64;
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // features | gradients | ref gradients
-    float *fea = lds;                                 // [NV][4][cap][4]
-    float *grd = lds + NV * 4 * cap * 4;              // same shape
-    float *rgr = grd + NV * 4 * cap * 4;              // [4 quads][64 pixels][4]
+    constexpr int NQ = bwd_quads(NV), NPASS = 4 / NQ;   // quads per pass, passes per group
+    typedef unsigned long long u64;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[bwd_lds_bytes(NV)];
+    float *fea = reinterpret_cast<float *>(lds_raw);                       // [NV][NQ quads][cap][4]
+    u64 *grd = reinterpret_cast<u64 *>(lds_raw + NV * NQ * cap * 16);       // [NV][4 NQ channels][cap]
+    u64 *rgr = grd + NV * NQ * 4 * cap;                                     // [4 NQ channels][64 pixels]
+    unsigned *bound = reinterpret_cast<unsigned *>(rgr + NQ * 4 * 64);      // max|g|, max|f| (float bits)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -753,7 +790,7 @@ __global__ __launch_bounds__(256, 2) void variance_bwd_dma_kernel(
     const float dv = depth[(int64_t)b * p.D + cd];
     const int ngroups = p.C >> 4;
     const size_t grp_floats = (size_t)plane * 16;
-    const unsigned lds_base = (unsigned)(uintptr_t)lds;
+    const unsigned lds_base = (unsigned)(uintptr_t)lds_raw;
 
     // ---- footprint boxes from the 8 corner voxels (see variance_fwd_dma_kernel)
     int bx0[NV], by0[NV], bw[NV], bh[NV];
@@ -840,34 +877,38 @@ __global__ __launch_bounds__(256, 2) void variance_bwd_dma_kernel(
     }
 
     const float inv_v = 1.0f / p.fV;
-    const int NG4 = NV * 4 * cap;   // float4 slots of the gradient image
+    constexpr int KU = NV <= 4 ? NQ : 1;
+    constexpr int NZ = (NV * NQ * 4 * cap + NQ * 4 * 64) / 2;   // uint4 slots of the sums (+ ref sums)
+    const int dq = wv % NQ, dj = wv / NQ;   // this wave's share of the staging: quad dq, every NPASS-th granule
 #pragma unroll 1
-    for (int g = 0; g < ngroups; ++g) {
-        __syncthreads();   // previous group's flush is complete
-        for (int i = tid; i < NG4 + 256; i += 256)
-            reinterpret_cast<float4 *>(grd)[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // incl. ref gradients
+    for (int pass = 0; pass < ngroups * NPASS; ++pass) {
+        const int g = pass / NPASS, q0 = (pass % NPASS) * NQ;   // group, first quad of the pass
+        __syncthreads();   // previous pass's flush is complete
+        for (int i = tid; i < NZ; i += 256)
+            reinterpret_cast<uint4 *>(grd)[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (tid < 2) bound[tid] = 0u;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             if (!staged[v]) continue;
-            const mvs_srd_t srd = make_srd(srcs16 + (((size_t)v * p.B + b) * ngroups + g) * grp_floats + wv * 4,
+            const mvs_srd_t srd = make_srd(srcs16 + (((size_t)v * p.B + b) * ngroups + g) * grp_floats + (q0 + dq) * 4,
                                            (unsigned)(grp_floats * 4));
             const int n = bw[v] * bh[v];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                if (j * 64 >= n) continue;
+                if (j * 64 >= n || (j % NPASS) != dj) continue;
                 if (j * 64 + lane < cap)
                     glds16_buf((unsigned)soff[v][j] * 4u, srd, 0u,
-                               lds_base + (unsigned)(((v * 4 + wv) * cap + j * 64) * 16));
+                               lds_base + (unsigned)(((v * NQ + dq) * cap + j * 64) * 16));
             }
         }
-        float4 ref4[4], gv4[4];
+        float4 ref4[NQ], gv4[NQ];
         {
             const float4 *rp = reinterpret_cast<const float4 *>(
-                ref16 + ((size_t)b * ngroups + g) * grp_floats + (size_t)pix * 16);
+                ref16 + ((size_t)b * ngroups + g) * grp_floats + (size_t)pix * 16 + q0 * 4);
             const float4 *gp = reinterpret_cast<const float4 *>(
-                gvar + (((size_t)b * p.D + cd) * plane + pix) * p.C + g * 16);
+                gvar + (((size_t)b * p.D + cd) * plane + pix) * p.C + g * 16 + q0 * 4);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < NQ; ++k) {
                 ref4[k] = rp[k];
                 gv4[k] = live ? gp[k] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -875,26 +916,73 @@ __global__ __launch_bounds__(256, 2) void variance_bwd_dma_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
+        // ---- the block's bound: max |g| and max |f| over what will meet in LDS.  fmaxf drops
+        // NaNs, so the integer max of the raw magnitudes carries them (NaN patterns sort above inf).
+        {
+            unsigned gm = 0u, fm = 0u;
+            auto mag = [](float x) { return __float_as_uint(x) & 0x7fffffffu; };
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) {
+                gm = max(max(gm, mag(gv4[k].x)), max(mag(gv4[k].y), max(mag(gv4[k].z), mag(gv4[k].w))));
+                fm = max(max(fm, mag(ref4[k].x)), max(mag(ref4[k].y), max(mag(ref4[k].z), mag(ref4[k].w))));
+            }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                if (!staged[v]) continue;
+                const int n = bw[v] * bh[v];
+                for (int i = tid; i < NQ * cap; i += 256) {
+                    const int t = i % cap;
+                    if (t < n) {
+                        const float4 f = *reinterpret_cast<const float4 *>(fea + (v * NQ * cap + i) * 4);
+                        fm = max(max(fm, mag(f.x)), max(mag(f.y), max(mag(f.z), mag(f.w))));
+                    }
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                gm = max(gm, (unsigned)__shfl_xor((int)gm, off));
+                fm = max(fm, (unsigned)__shfl_xor((int)fm, off));
+            }
+            if (lane == 0) { atomicMax(bound, gm); atomicMax(bound + 1, fm); }
+        }
+        __syncthreads();
+        float scale, inv_scale;
+        bool poison;
+        {
+            const unsigned gm = bound[0], fm = bound[1];
+            poison = gm >= 0x7f800000u || fm >= 0x7f800000u;
+            const float m = 4.0f * __uint_as_float(gm) * __uint_as_float(fm) * inv_v;
+            poison = poison || !(m < 3.0e38f);
+            int e = (int)((__float_as_uint(m) >> 23) & 0xffu) - 126;   // m < 2^e
+            e = max(e, -74);
+            scale = __uint_as_float((unsigned)(127 + 52 - e) << 23);
+            inv_scale = __uint_as_float((unsigned)(127 - 52 + e) << 23);
+        }
+
         // the four taps of view v, channel quad k, as float4
         auto taps = [&](int v, int k, float4 &a, float4 &bq, float4 &c, float4 &e) {
             if (wave_in[v]) {
-                const float *base = fea + (v * 4 + k) * cap * 4;
+                const float *base = fea + (v * NQ + k) * cap * 4;
                 a = *reinterpret_cast<const float4 *>(base + o00[v] * 4);
                 bq = *reinterpret_cast<const float4 *>(base + o01[v] * 4);
                 c = *reinterpret_cast<const float4 *>(base + o10[v] * 4);
                 e = *reinterpret_cast<const float4 *>(base + o11[v] * 4);
             } else {
-                const float *base = srcs16 + (((size_t)v * p.B + b) * ngroups + g) * grp_floats + k * 4;
+                const float *base = srcs16 + (((size_t)v * p.B + b) * ngroups + g) * grp_floats + (q0 + k) * 4;
                 a = *reinterpret_cast<const float4 *>(base + (size_t)o00[v] * 16);
                 bq = *reinterpret_cast<const float4 *>(base + (size_t)o01[v] * 16);
                 c = *reinterpret_cast<const float4 *>(base + (size_t)o10[v] * 16);
                 e = *reinterpret_cast<const float4 *>(base + (size_t)o11[v] * 16);
             }
         };
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float rr[4] = {ref4[k].x, ref4[k].y, ref4[k].z, ref4[k].w};
-            const float gg[4] = {gv4[k].x, gv4[k].y, gv4[k].z, gv4[k].w};
+        // One channel quad at a time; unrolled while the registers last (the rolled form picks
+        // the quad's reference/gradient values with selects).
+#pragma unroll KU
+        for (int k = 0; k < NQ; ++k) {
+            const float4 r4 = k == 0 ? ref4[0] : (k == 1 ? ref4[1] : (k == 2 ? ref4[NQ - 2] : ref4[NQ - 1]));
+            const float4 g4 = k == 0 ? gv4[0] : (k == 1 ? gv4[1] : (k == 2 ? gv4[NQ - 2] : gv4[NQ - 1]));
+            const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
+            const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
             float S[4] = {rr[0], rr[1], rr[2], rr[3]};
             float w[NV][4];
 #pragma unroll
@@ -915,25 +1003,30 @@ __global__ __launch_bounds__(256, 2) void variance_bwd_dma_kernel(
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) kk[cc] = 2.0f * S[cc] * inv_v * inv_v;
             // reference features: the 4 depth planes of the block meet in LDS
+            if (!poison) {
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc)
-                atomicAdd(rgr + (k * 64 + lane) * 4 + cc, gg[cc] * (2.0f * rr[cc] * inv_v - kk[cc]));
+                for (int cc = 0; cc < 4; ++cc)
+                    atomicAdd(rgr + (k * 4 + cc) * 64 + lane,
+                              fixed64(gg[cc] * (2.0f * rr[cc] * inv_v - kk[cc]) * scale));
+            }
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 float gw[4];
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) gw[cc] = gg[cc] * (2.0f * w[v][cc] * inv_v - kk[cc]);
                 if (wave_in[v]) {
-                    float *base = grd + (v * 4 + k) * cap * 4;
+                    if (poison) continue;
 #pragma unroll
                     for (int cc = 0; cc < 4; ++cc) {
-                        if (m00[v]) atomicAdd(base + o00[v] * 4 + cc, gw[cc] * wnw[v]);
-                        if (m01[v]) atomicAdd(base + o01[v] * 4 + cc, gw[cc] * wne[v]);
-                        if (m10[v]) atomicAdd(base + o10[v] * 4 + cc, gw[cc] * wsw[v]);
-                        if (m11[v]) atomicAdd(base + o11[v] * 4 + cc, gw[cc] * wse[v]);
+                        u64 *base = grd + ((v * NQ + k) * 4 + cc) * cap;
+                        const float gs = gw[cc] * scale;
+                        if (m00[v]) atomicAdd(base + o00[v], fixed64(gs * wnw[v]));
+                        if (m01[v]) atomicAdd(base + o01[v], fixed64(gs * wne[v]));
+                        if (m10[v]) atomicAdd(base + o10[v], fixed64(gs * wsw[v]));
+                        if (m11[v]) atomicAdd(base + o11[v], fixed64(gs * wse[v]));
                     }
                 } else if (live) {
-                    float *base = gsrcs16 + (((size_t)v * p.B + b) * ngroups + g) * grp_floats + k * 4;
+                    float *base = gsrcs16 + (((size_t)v * p.B + b) * ngroups + g) * grp_floats + (q0 + k) * 4;
 #pragma unroll
                     for (int cc = 0; cc < 4; ++cc) {
                         if (m00[v]) unsafeAtomicAdd(base + (size_t)o00[v] * 16 + cc, gw[cc] * wnw[v]);
@@ -946,27 +1039,32 @@ __global__ __launch_bounds__(256, 2) void variance_bwd_dma_kernel(
         }
         __syncthreads();
         // ---- flush: every staged texel once, every reference pixel once
+        const double inv_scale_d = (double)inv_scale;
+        const float qnan = __uint_as_float(0x7fc00000u);
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             if (!staged[v]) continue;
             const int n = bw[v] * bh[v];
             const unsigned inv = (65536u + bw[v] - 1) / bw[v];
-            float *dst = gsrcs16 + (((size_t)v * p.B + b) * ngroups + g) * grp_floats;
-            for (int e = tid; e < n * 16; e += 256) {
-                const int t = e >> 4, ch = e & 15;
-                const float val = grd[((v * 4 + (ch >> 2)) * cap + t) * 4 + (ch & 3)];
-                if (val != 0.0f) {
+            float *dst = gsrcs16 + (((size_t)v * p.B + b) * ngroups + g) * grp_floats + q0 * 4;
+            for (int e = tid; e < n * NQ * 4; e += 256) {
+                const int t = e / (NQ * 4), ch = e % (NQ * 4);
+                const long long q = (long long)grd[(v * NQ * 4 + ch) * cap + t];
+                if (q != 0 || poison) {
+                    const float val = poison ? qnan : (float)((double)q * inv_scale_d);
                     const int ly = (int)(((unsigned)t * inv) >> 16), lx = t - ly * bw[v];
                     unsafeAtomicAdd(dst + ((size_t)(by0[v] + ly) * p.W + (bx0[v] + lx)) * 16 + ch, val);
                 }
             }
         }
-        for (int e = tid; e < 64 * 16; e += 256) {
-            const int pl = e >> 4, ch = e & 15;
+        for (int e = tid; e < 64 * NQ * 4; e += 256) {
+            const int pl = e / (NQ * 4), ch = e % (NQ * 4);
             const int qx = tx * kTileW + (pl & (kTileW - 1)), qy = ty * kTileH + pl / kTileW;
-            const float val = rgr[((ch >> 2) * 64 + pl) * 4 + (ch & 3)];
-            if (qx < p.W && qy < p.H && val != 0.0f)
-                unsafeAtomicAdd(gref16 + ((size_t)b * ngroups + g) * grp_floats + ((size_t)qy * p.W + qx) * 16 + ch, val);
+            const long long q = (long long)rgr[ch * 64 + pl];
+            if (qx < p.W && qy < p.H && (q != 0 || poison)) {
+                const float val = poison ? qnan : (float)((double)q * inv_scale_d);
+                unsafeAtomicAdd(gref16 + ((size_t)b * ngroups + g) * grp_floats + ((size_t)qy * p.W + qx) * 16 + q0 * 4 + ch, val);
+            }
         }
     }
 }
@@ -1282,8 +1380,7 @@ extern "C" int mvs_costvol_variance_bwd_f32(const float *grad_var, const float *
         const dim3 g((unsigned)nblk, (unsigned)B);
 #define MVS_BWD_CASE(n)                                                                             \
     case n: {                                                                                       \
-        const size_t shmem = ((size_t)2 * n * 4 * bwd_cap(n) * 4 + 4 * 64 * 4) * sizeof(float);     \
-        hipLaunchKernelGGL((variance_bwd_dma_kernel<n>), g, dim3(256), shmem, st, grad_var, ref_fea, \
+        hipLaunchKernelGGL((variance_bwd_dma_kernel<n>), g, dim3(256), 0, st, grad_var, ref_fea,    \
                            src_feas, rot_trans, depth_values, p, tiles_x, tiles_y, grad_ref,        \
                            grad_srcs);                                                              \
         break;                                                                                      \
