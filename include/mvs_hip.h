@@ -135,14 +135,19 @@ int mvs_conv3d_mfma_supported(int transposed, int Cin, int Cout, int stride);
  * autograd through nn.Conv3d / nn.ConvTranspose3d, module.py:26-33, mvsnet.py:66-79):
  *   grad_weight[co][ci][kz][ky][kx] += sum_o grad_out[o][co] * in[o*stride + k - 1][ci]
  * in [B,D,H,W,Cin] and grad_out [B,Do,Ho,Wo,Cout] channels-last, Do = (D-1)/stride + 1, ...;
- * grad_weight (Cout,Cin,3,3,3) must be ZERO on entry (partial sums arrive by atomic adds; the
- * summation order, hence the last bits, is not deterministic -- as with the reference's cuDNN).
+ * grad_weight (Cout,Cin,3,3,3) is ACCUMULATED into (zero it for a plain gradient).
+ * workspace: device scratch of mvs_conv3d_wgrad_workspace_bytes(...) bytes for the per-workgroup
+ * partial sums (reduced by a second kernel); with NULL / too few bytes the partials meet in
+ * grad_weight by atomic adds instead -- same result up to summation order, several times
+ * slower for the small layers.  The last bits are not deterministic (as with the reference's cuDNN).
  * Transposed layer (stride 2, weight (Cin_t,Cout_t,3,3,3)): call with in := its grad_out
  * (the fine grid, Cout_t channels), grad_out := its input (Cin_t channels), stride 2; the
  * result is already in the transposed layer's weight layout.
  * Cin in {8,16,32,64}, Cout in {1,8,16,32,64}, stride in {1,2}. */
 int mvs_conv3d_wgrad_f32(const float *in, const float *grad_out, int B, int Cin, int Cout, int D,
-                         int H, int W, int stride, float *grad_weight, void *stream);
+                         int H, int W, int stride, float *grad_weight, void *workspace,
+                         size_t workspace_bytes, void *stream);
+size_t mvs_conv3d_wgrad_workspace_bytes(int B, int Cin, int Cout, int D, int H, int W, int stride);
 int mvs_conv3d_wgrad_supported(int Cin, int Cout, int stride);
 
 /* ---- FeatureNet layers -- mvsnet.py:8-45 ("next" row 1) ---- */

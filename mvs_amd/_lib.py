@@ -37,7 +37,8 @@ _SIGS = {
     "mvs_conv3d_packed_weight_floats": (_c_l, [_c_i] * 4),
     "mvs_conv3d_pack_weights_f32": (_c_i, [_c_f] + [_c_i] * 4 + [_c_f, _c_f]),
     "mvs_conv3d_mfma_supported": (_c_i, [_c_i] * 4),
-    "mvs_conv3d_wgrad_f32": (_c_i, [_c_f, _c_f] + [_c_i] * 7 + [_c_f, _c_f]),
+    "mvs_conv3d_wgrad_f32": (_c_i, [_c_f, _c_f] + [_c_i] * 7 + [_c_f, _c_f, ctypes.c_size_t, _c_f]),
+    "mvs_conv3d_wgrad_workspace_bytes": (ctypes.c_size_t, [_c_i] * 7),
     "mvs_conv3d_wgrad_supported": (_c_i, [_c_i] * 3),
     "mvs_conv2d_f32": (_c_i, [_c_f] * 4 + [_c_i] * 9 + [_c_f, _c_f]),
     "mvs_conv2d_packed_weight_floats": (_c_l, [_c_i] * 4),

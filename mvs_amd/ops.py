@@ -545,8 +545,10 @@ def conv3d_wgrad(x_cl, g_cl, stride):
     if not lib.mvs_conv3d_wgrad_supported(cin, cout, stride):
         return None
     gw = torch.zeros((cout, cin, 3, 3, 3), device=x_cl.device, dtype=torch.float32)
-    check(lib.mvs_conv3d_wgrad_f32(ptr(x_cl), ptr(g_cl), B, cin, cout, D, H, W, stride, ptr(gw), stream()),
-          "mvs_conv3d_wgrad_f32")
+    nbytes = int(lib.mvs_conv3d_wgrad_workspace_bytes(B, cin, cout, D, H, W, stride))
+    ws = torch.empty((nbytes // 4,), device=x_cl.device, dtype=torch.float32)   # per-workgroup partial sums
+    check(lib.mvs_conv3d_wgrad_f32(ptr(x_cl), ptr(g_cl), B, cin, cout, D, H, W, stride, ptr(gw), ptr(ws), nbytes,
+                                   stream()), "mvs_conv3d_wgrad_f32")
     return gw
 
 
