@@ -225,6 +225,174 @@ static int launch_wgrad(WgradArgs a, int ntiles, void *workspace, size_t workspa
     return check_launch("mvs_conv3d_wgrad_f32");
 }
 
+// ---------------------------------------------------------------------
+// Stride-1 layers with few output channels (conv0: 32 -> 8, `prob`: 8 -> 1): anchored on the
+// INPUT voxel,
+//   dW[co][ci][tap] = sum over input voxels v of  g[v - (tap - 1)][co] * x[v][ci],
+// every row of the MFMA's A operand may look at a different tap: A[(h, co)][k] =
+// g[v_k - off(tap_h)][co], B[k][ci] = x[v_k][ci], so one MFMA carries 16 / Cout taps instead
+// of one padded with zeros (27 -> 14 MFMAs per 4 voxels for Cout = 8, 27 -> 2 for Cout = 1).
+// The halo moves to g (8 or 1 channels, cheap) and the wide operand x is staged without a halo
+// and read ONCE: a workgroup covers all of Cin.  Units = (tap slot) x (16-channel ci tile); a
+// wave owns NU of them (its accumulators) and, when there are fewer than 4 NU units, a share
+// of the tile's rows.  x and g tiles arrive by LDS-DMA (x granules XOR-swizzled on the source
+// side so the B reads of 4 voxels x 16 channels hit 64 banks).  Needs the workspace.
+template <int CIN, int COUT>
+struct WgradXCfg {
+    static constexpr int TZ = 2, TY = 4, ROWS = TZ * TY, NOUT = ROWS * 16;
+    static constexpr int TPM = 16 / COUT;                  // taps per MFMA
+    static constexpr int NP = (27 + TPM - 1) / TPM;        // tap slots
+    static constexpr int NT = CIN >= 16 ? CIN / 16 : 1;    // ci tiles
+    static constexpr int NU = TPM == 2 ? 7 : 2;            // units per wave
+    static constexpr int UNITS = NP * NT, NG = UNITS / NU, NRS = 4 / NG;
+    static_assert(NG * NU == UNITS && (NG == 1 || NG == 2 || NG == 4), "unit split");
+    static constexpr int Q = CIN / 4;                      // 16-byte granules per x voxel
+    static constexpr int GZT = TZ + 2, GYT = TY + 2, GXT = 18, GVOX = GZT * GYT * GXT;
+    static constexpr int X_FLOATS = NOUT * CIN;
+    static constexpr int G_INSTR = (GVOX * COUT / 4 + 255) / 256;          // DMA instructions per wave (Cout = 8)
+    static constexpr int G_FLOATS = COUT == 1 ? ((GVOX + 3) & ~3) : G_INSTR * 1024;
+    static constexpr int PB = 4 * NU * 256;                // floats of one workgroup's partials
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256, 2) void conv3d_wgrad_xanchor_kernel(WgradArgs a, int ntiles) {
+    using C = WgradXCfg<CIN, COUT>;
+    constexpr int NU = C::NU, Q = C::Q, GYT = C::GYT, GXT = C::GXT;
+    __shared__ __attribute__((aligned(16))) float lds[C::X_FLOATS + C::G_FLOATS];
+    float *xl = lds, *gl = lds + C::X_FLOATS;
+    const unsigned lds_base = (unsigned)(uintptr_t)lds;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kv = lane >> 4;
+    const int grp = wv % C::NG, rs = wv / C::NG;
+    const int nt = (grp * NU) / C::NP;
+
+    // A operand: row m = lane & 15 -> (tap slot half h, co); offset of g[v - off(tap)][co] from g[v]'s halo slot
+    int aoff[NU];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        const int p = (grp * NU + i) % C::NP;
+        const int tap = min(p * C::TPM + n / COUT, 26);   // slot past the 27th tap: computed, never read back
+        const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+        aoff[i] = ((((2 - kz) * GYT + (2 - ky)) * GXT + (2 - kx)) + kv) * COUT + n % COUT;
+    }
+    // B operand: x[v][ch]; granule (v, ch / 4) sits in slot v * Q + ((ch / 4) ^ swz(v))
+    const int ch = nt * 16 + (CIN >= 16 ? n : (n & (CIN - 1)));
+    const int boff = (((ch >> 2) ^ (CIN == 32 ? (kv >> 1) * 4 : 0)) + kv * Q) * 4 + (ch & 3);
+
+    wg_f32x4 acc[NU];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) acc[i] = (wg_f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int64_t plane = (int64_t)a.H * a.W;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        int bid = t;
+        const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+        const int ty = bid % a.tiles_y; bid /= a.tiles_y;
+        const int tz = bid % a.tiles_z;
+        const int b = bid / a.tiles_z;
+        const int x0 = tx * 16, y0 = ty * C::TY, z0 = tz * C::TZ;
+        __syncthreads();   // every wave is done with the previous tile
+        {   // x tile, no halo: slot s <- granule (v = s / Q, q = (s % Q) ^ swz(v))
+            const mvs_srd_t srd = make_srd(a.x + ((int64_t)b * a.D + z0) * plane * CIN,
+                                           (unsigned)min((int64_t)C::TZ * plane * CIN * 4, (int64_t)0xffffff00u));
+#pragma unroll
+            for (int it = 0; it < C::NOUT * Q / 256; ++it) {
+                const int s = (it * 4 + wv) * 64 + lane;
+                const int v = s / Q, q = (s % Q) ^ (CIN == 32 ? ((v >> 1) & 1) * 4 : 0);
+                const int x = v & 15, row = v >> 4, rz = row / C::TY, ry = row % C::TY;
+                const bool ok = z0 + rz < a.D && y0 + ry < a.H && x0 + x < a.W;
+                const unsigned off = ok ? (unsigned)(((rz * plane + (int64_t)(y0 + ry) * a.W + x0 + x) * CIN + q * 4) * 4)
+                                        : 0xffffff00u;
+                glds16_buf(off, srd, 0u, lds_base + (unsigned)((it * 4 + wv) * 1024));
+            }
+        }
+        if (COUT == 1) {   // g halo, one float per voxel
+            const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float *>(a.g + ((int64_t)b * a.D + z0 - 1) * plane), 0,
+                (int)(unsigned)min((int64_t)C::GZT * plane * 4, (int64_t)0xffffff00u), 0x00020000);
+            for (int e = tid; e < C::GVOX; e += 256) {
+                const int lx = e % GXT, t2 = e / GXT, ly = t2 % GYT, lz = t2 / GYT;
+                const int gx = x0 - 1 + lx, gy = y0 - 1 + ly, gz = z0 - 1 + lz;
+                const bool ok = (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H && (unsigned)gz < (unsigned)a.D;
+                const unsigned off = ok ? (unsigned)((lz * plane + (int64_t)gy * a.W + gx) * 4) : 0xffffff00u;
+                gl[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsg, off, 0, 0));
+            }
+        } else {           // g halo: [halo voxel][Cout], 16-byte granules by DMA
+            constexpr int GQ = COUT / 4;
+            const mvs_srd_t srd = make_srd(a.g + ((int64_t)b * a.D + z0 - 1) * plane * COUT,
+                                           (unsigned)min((int64_t)C::GZT * plane * COUT * 4, (int64_t)0xffffff00u));
+#pragma unroll
+            for (int it = 0; it < C::G_INSTR; ++it) {
+                const int s = (it * 4 + wv) * 64 + lane;
+                const int hv = s / GQ, q = s % GQ;
+                const int lx = hv % GXT, t2 = hv / GXT, ly = t2 % GYT, lz = t2 / GYT;
+                const int gx = x0 - 1 + lx, gy = y0 - 1 + ly, gz = z0 - 1 + lz;
+                const bool ok = hv < C::GVOX && (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H &&
+                                (unsigned)gz < (unsigned)a.D;
+                const unsigned off = ok ? (unsigned)(((lz * plane + (int64_t)gy * a.W + gx) * COUT + q * 4) * 4) : 0xffffff00u;
+                glds16_buf(off, srd, 0u, lds_base + (unsigned)(C::X_FLOATS * 4 + (it * 4 + wv) * 1024));
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // ---- K loop over this wave's rows: 4 input voxels along x per MFMA
+        constexpr int RPW = C::ROWS / C::NRS;
+#pragma unroll 1
+        for (int r = 0; r < RPW; ++r) {
+            const int row = rs * RPW + r, rz = row / C::TY, ry = row % C::TY;
+#pragma unroll
+            for (int xs = 0; xs < 4; ++xs) {
+                const float bf = xl[(row * 16 + xs * 4) * CIN + boff];
+                const float *gb = gl + ((rz * GYT + ry) * GXT + xs * 4) * COUT;
+#pragma unroll
+                for (int i = 0; i < NU; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(gb[aoff[i]], bf, acc[i], 0, 0, 0);
+            }
+        }
+    }
+    float *dst = a.partial + ((size_t)blockIdx.x * 4 + wv) * (NU * 256) + lane;
+#pragma unroll
+    for (int i = 0; i < NU; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[(i * 4 + j) * 64] = acc[i][j];
+}
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void wgrad_xanchor_reduce_kernel(const float *__restrict__ partial, int nblocks,
+                                                                   float *__restrict__ gw) {
+    using C = WgradXCfg<CIN, COUT>;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= C::PB) return;
+    const int lane = r & 63, j = (r >> 6) & 3, i = (r >> 8) % C::NU, wv = r / (256 * C::NU);
+    const int u = (wv % C::NG) * C::NU + i, nt = u / C::NP, p = u % C::NP;
+    const int m = (lane >> 4) * 4 + j, tap = p * C::TPM + m / COUT, co = m % COUT, ci = nt * 16 + (lane & 15);
+    if (tap >= 27 || ci >= CIN) return;
+    float sum = 0.f;
+    for (int s = blockIdx.y; s < nblocks; s += gridDim.y) sum += partial[(size_t)s * C::PB + r];
+    unsafeAtomicAdd(gw + ((int64_t)co * CIN + ci) * 27 + tap, sum);
+}
+
+static bool wgrad_xanchor_shape(int Cin, int Cout, int stride) {
+    return stride == 1 && (Cout == 8 || Cout == 1) && (Cin == 8 || Cin == 16 || Cin == 32);
+}
+static int wgrad_xanchor_blocks(int ntiles) { return min(ntiles, 2 * device_cu_count()); }
+static size_t wgrad_xanchor_bytes(int Cout, int ntiles) {
+    return (size_t)wgrad_xanchor_blocks(ntiles) * (4 * (Cout == 8 ? 7 : 2) * 256) * sizeof(float);
+}
+
+template <int CIN, int COUT>
+static int launch_wgrad_xanchor(WgradArgs a, int ntiles, void *workspace, hipStream_t st) {
+    using C = WgradXCfg<CIN, COUT>;
+    const int nblocks = wgrad_xanchor_blocks(ntiles);
+    a.partial = static_cast<float *>(workspace);
+    hipLaunchKernelGGL((conv3d_wgrad_xanchor_kernel<CIN, COUT>), dim3((unsigned)nblocks), dim3(256), 0, st, a, ntiles);
+    hipLaunchKernelGGL((wgrad_xanchor_reduce_kernel<CIN, COUT>), dim3((unsigned)((C::PB + 255) / 256), 8u), dim3(256),
+                       0, st, a.partial, nblocks, a.gw);
+    return check_launch("mvs_conv3d_wgrad_f32(x-anchored)");
+}
+
 }  // namespace mvs
 
 using namespace mvs;
@@ -250,6 +418,7 @@ extern "C" size_t mvs_conv3d_wgrad_workspace_bytes(int B, int Cin, int Cout, int
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || !mvs_conv3d_wgrad_supported(Cin, Cout, stride) ||
         !wgrad_geometry(B, Cin, Cout, D, H, W, stride, a, nt))
         return 0;
+    if (wgrad_xanchor_shape(Cin, Cout, stride)) return wgrad_xanchor_bytes(Cout, (int)nt);
     const int ck = Cin >= 16 ? 16 : 8, ncc = (Cin + ck - 1) / ck;
     const int mt = Cout <= 16 ? 1 : (Cout <= 32 ? 2 : 4);
     return (size_t)wgrad_streams((int)nt, ncc) * ncc * (4 * 7 * mt * 256) * sizeof(float);
@@ -271,6 +440,11 @@ extern "C" int mvs_conv3d_wgrad_f32(const float *in, const float *grad_out, int 
     if (!wgrad_geometry(B, Cin, Cout, D, H, W, stride, a, nt)) return MVS_EINVAL;
     a.x = in; a.g = grad_out; a.gw = grad_weight; a.partial = nullptr;
     hipStream_t st = as_stream(stream);
+    if (wgrad_xanchor_shape(Cin, Cout, stride) && workspace && workspace_bytes >= wgrad_xanchor_bytes(Cout, (int)nt)) {
+#define MVS_WX(ci, co) if (Cin == ci && Cout == co) return launch_wgrad_xanchor<ci, co>(a, (int)nt, workspace, st);
+        MVS_WX(32, 8) MVS_WX(16, 8) MVS_WX(8, 8) MVS_WX(32, 1) MVS_WX(16, 1) MVS_WX(8, 1)
+#undef MVS_WX
+    }
     const int ck = Cin >= 16 ? 16 : 8;
 #define MVS_WG(co)                                                                               \
     if (Cout <= co) {                                                                            \

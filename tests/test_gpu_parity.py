@@ -813,7 +813,8 @@ def test_conv3d_autograd_vs_torch(dev, cfg):
 
 
 @pytest.mark.parametrize("shape", [(2, 5, 7, 19), (1, 9, 6, 33)])
-@pytest.mark.parametrize("cfg", [(32, 8, 1), (8, 16, 2), (16, 32, 2), (64, 64, 1)])
+@pytest.mark.parametrize("cfg", [(32, 8, 1), (8, 16, 2), (16, 32, 2), (64, 64, 1), (8, 1, 1), (16, 8, 1),
+                                 (8, 8, 1), (32, 1, 1), (16, 1, 1), (16, 16, 1)])
 def test_conv3d_wgrad_ragged_vs_torch(dev, shape, cfg):
     """The weight-gradient kernel on ragged volumes (tile overhang on every axis, batch > 1,
     odd sizes under stride 2) against torch's conv3d weight gradient; and the transposed
@@ -832,6 +833,13 @@ def test_conv3d_wgrad_ragged_vs_torch(dev, shape, cfg):
     F.conv3d(x.permute(0, 4, 1, 2, 3), w, None, stride, 1).backward(go.permute(0, 4, 1, 2, 3))
     scale = float(w.grad.abs().max())
     np.testing.assert_allclose(gw.cpu().numpy(), w.grad.cpu().numpy(), atol=2e-5 * scale + 1e-5, rtol=2e-4)
+    # the C ABI without a workspace (atomic flush), accumulating onto what is already there
+    from mvs_amd import _lib
+    from mvs_amd.ops import check, ptr, stream
+    acc = gw.clone()
+    check(_lib.load().mvs_conv3d_wgrad_f32(ptr(x), ptr(go), B, cin, cout, D, H, W, stride, ptr(acc), None, 0, stream()),
+          "mvs_conv3d_wgrad_f32")
+    np.testing.assert_allclose(acc.cpu().numpy(), 2 * w.grad.cpu().numpy(), atol=4e-5 * scale + 2e-5, rtol=2e-4)
     if stride == 2:   # also the transposed layer's gradient: fine grid = 2x the coarse one
         xc = torch.randn(B, D, H, W, cout, device=dev, generator=g)          # deconv input (Cin_t = cout)
         gf = torch.randn(B, 2 * D, 2 * H, 2 * W, cin, device=dev, generator=g)   # its grad_out (Cout_t = cin)
