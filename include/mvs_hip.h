@@ -150,6 +150,27 @@ int mvs_conv3d_wgrad_f32(const float *in, const float *grad_out, int B, int Cin,
 size_t mvs_conv3d_wgrad_workspace_bytes(int B, int Cin, int Cout, int D, int H, int W, int stride);
 int mvs_conv3d_wgrad_supported(int Cin, int Cout, int stride);
 
+/* Training-mode BatchNorm fused with the ReLU and skip add that follow it in the reference's
+ * blocks (module.py:26-33 ConvBnReLU3D = relu(bn(conv(x))); mvsnet.py:80-92 skip + relu(bn(deconv)));
+ * channels-last rows x [N][C], N = B*D*H*W, C in {8,16,32,64}:
+ *   y = relu((x - mean) * invstd * weight + bias) [+ skip]     (relu != 0; skip may be NULL)
+ * mean / biased variance over the N rows (nn.BatchNorm3d in training mode); running_mean /
+ * running_var (momentum, unbiased variance) and num_batches_tracked are updated in place when
+ * not NULL; save_mean / save_invstd [C] are outputs for the backward.
+ * The backward takes grad_y (gradient of y; the skip's gradient is grad_y itself) and returns
+ * grad_x, grad_weight, grad_bias; the ReLU mask is recomputed from x.
+ * workspace: mvs_bn_train_workspace_bytes(C) bytes of device scratch (fp64 partial sums). */
+size_t mvs_bn_train_workspace_bytes(int C);
+int mvs_bn_train_fwd_f32(const float *x, const float *weight, const float *bias, const float *skip,
+                         int64_t N, int C, float eps, float momentum, int relu, float *running_mean,
+                         float *running_var, long long *num_batches_tracked, float *save_mean,
+                         float *save_invstd, float *y, void *workspace, size_t workspace_bytes,
+                         void *stream);
+int mvs_bn_train_bwd_f32(const float *grad_y, const float *x, const float *weight, const float *bias,
+                         const float *save_mean, const float *save_invstd, int64_t N, int C, int relu,
+                         float *grad_x, float *grad_weight, float *grad_bias, void *workspace,
+                         size_t workspace_bytes, void *stream);
+
 /* ---- FeatureNet layers -- mvsnet.py:8-45 ("next" row 1) ---- */
 /* One 2D convolution of FeatureNet on the fp32 matrix cores: k x k (3 stride 1, or 5
  * stride 2), pad k/2, no conv bias, then y = acc*scale[co] + shift[co] (BatchNorm(eval)

@@ -40,6 +40,10 @@ _SIGS = {
     "mvs_conv3d_wgrad_f32": (_c_i, [_c_f, _c_f] + [_c_i] * 7 + [_c_f, _c_f, ctypes.c_size_t, _c_f]),
     "mvs_conv3d_wgrad_workspace_bytes": (ctypes.c_size_t, [_c_i] * 7),
     "mvs_conv3d_wgrad_supported": (_c_i, [_c_i] * 3),
+    "mvs_bn_train_workspace_bytes": (ctypes.c_size_t, [_c_i]),
+    "mvs_bn_train_fwd_f32": (_c_i, [_c_f] * 4 + [_c_l, _c_i, ctypes.c_float, ctypes.c_float, _c_i] + [_c_f] * 7
+                             + [ctypes.c_size_t, _c_f]),
+    "mvs_bn_train_bwd_f32": (_c_i, [_c_f] * 6 + [_c_l, _c_i, _c_i] + [_c_f] * 4 + [ctypes.c_size_t, _c_f]),
     "mvs_conv2d_f32": (_c_i, [_c_f] * 4 + [_c_i] * 9 + [_c_f, _c_f]),
     "mvs_conv2d_packed_weight_floats": (_c_l, [_c_i] * 4),
     "mvs_conv2d_pack_weights_f32": (_c_i, [_c_f] + [_c_i] * 4 + [_c_f, _c_f]),

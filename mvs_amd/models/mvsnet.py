@@ -153,17 +153,17 @@ class CostRegNet(nn.Module):
             m = getattr(self, name)
             return conv_bn_relu_cl(t, m.conv, m.bn, False, stride)
 
-        def up(name, t):
+        def up(name, t, skip):
             m = getattr(self, name)
-            return conv_bn_relu_cl(t, m[0], m[1], True, 2)
+            return conv_bn_relu_cl(t, m[0], m[1], True, 2, skip=skip)
 
         c0 = blk("conv0", x_cl)
         c2 = blk("conv2", blk("conv1", c0, 2))
         c4 = blk("conv4", blk("conv3", c2, 2))
         t = blk("conv6", blk("conv5", c4, 2))
-        t = c4 + up("conv7", t)
-        t = c2 + up("conv9", t)
-        t = c0 + up("conv11", t)
+        t = up("conv7", t, c4)     # c4 + relu(bn(deconv))
+        t = up("conv9", t, c2)
+        t = up("conv11", t, c0)
         return (conv3d_cl(t, self.prob.weight) + self.prob.bias).squeeze(-1)
 
     # -- inference path: HIP kernels, BN folded to a per-channel affine

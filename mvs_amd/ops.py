@@ -552,6 +552,60 @@ def conv3d_wgrad(x_cl, g_cl, stride):
     return gw
 
 
+class _BnReluCL(torch.autograd.Function):
+    """Training-mode BatchNorm + optional ReLU + optional skip add on channels-last rows
+    (mvs_bn_train_fwd_f32 / mvs_bn_train_bwd_f32); running statistics are updated in place."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, skip, running_mean, running_var, nbt, momentum, eps, relu):
+        x = _f32c(x)
+        C = x.shape[-1]
+        N = x.numel() // C
+        lib = _lib.load()
+        nbytes = int(lib.mvs_bn_train_workspace_bytes(C))
+        if nbytes == 0:
+            raise MvsHipError(f"bn_relu_cl: C={C} not supported")
+        ws = torch.empty((nbytes // 4,), device=x.device, dtype=torch.float32)
+        w, b = _f32c(weight.detach()), _f32c(bias.detach())
+        sk = _f32c(skip) if skip is not None else None
+        mean = torch.empty((C,), device=x.device, dtype=torch.float32)
+        invstd = torch.empty_like(mean)
+        y = torch.empty_like(x)
+        check(lib.mvs_bn_train_fwd_f32(ptr(x), ptr(w), ptr(b), ptr(sk), N, C, float(eps), float(momentum), int(relu),
+                                       ptr(running_mean), ptr(running_var),
+                                       ctypes.c_void_p(nbt.data_ptr()) if nbt is not None else None,
+                                       ptr(mean), ptr(invstd), ptr(y),
+                                       ptr(ws), nbytes, stream()), "mvs_bn_train_fwd_f32")
+        ctx.save_for_backward(x, w, b, mean, invstd)
+        ctx.relu, ctx.has_skip = int(relu), skip is not None
+        ctx.mark_non_differentiable(*[t for t in (running_mean, running_var, nbt) if t is not None])
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, b, mean, invstd = ctx.saved_tensors
+        gy = _f32c(gy)
+        C = x.shape[-1]
+        N = x.numel() // C
+        lib = _lib.load()
+        nbytes = int(lib.mvs_bn_train_workspace_bytes(C))
+        ws = torch.empty((nbytes // 4,), device=x.device, dtype=torch.float32)
+        gx = torch.empty_like(x)
+        gw, gb = torch.empty_like(w), torch.empty_like(b)
+        check(lib.mvs_bn_train_bwd_f32(ptr(gy), ptr(x), ptr(w), ptr(b), ptr(mean), ptr(invstd), N, C, ctx.relu,
+                                       ptr(gx), ptr(gw), ptr(gb), ptr(ws), nbytes, stream()), "mvs_bn_train_bwd_f32")
+        return gx, gw, gb, (gy if ctx.has_skip else None), None, None, None, None, None, None
+
+
+def bn_relu_cl(x, bn, relu=True, skip=None):
+    """relu(bn(x)) [+ skip] with batch statistics for a channels-last tensor [..., C] and an
+    nn.BatchNorm module in training mode (momentum must be a number, affine + running stats)."""
+    if bn.momentum is None or bn.weight is None:
+        raise MvsHipError("bn_relu_cl: needs an affine BatchNorm with a numeric momentum")
+    return _BnReluCL.apply(x, bn.weight, bn.bias, skip, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                           bn.momentum, bn.eps, relu)
+
+
 def conv2d(x, packed, cin, cout, ksize, stride, scale=None, shift=None, relu=False, planar=False):
     """FeatureNet convolution.  x: [B,H,W,cin] channels-last, or (planar) the [B,3,H,W]
     image.  relu: False/True, or 2 for LeakyReLU(0.1).  Returns [B,Ho,Wo,cout] channels-last."""

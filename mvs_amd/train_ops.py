@@ -10,8 +10,8 @@ layer shapes:
     conv   k3 s2 (Ci->Co)   dgrad = deconv k3 s2 (Co->Ci), same weight tensor
     deconv k3 s2 (Ci->Co)   dgrad = conv   k3 s2 (Co->Ci), same weight tensor
 
-The weight gradient (a reduction over all voxels) is 27 strided-view GEMMs in torch for
-now; BatchNorm (batch statistics), ReLU and the skip adds stay torch autograd ops.
+The weight gradient is its own MFMA kernel (csrc/conv3d_wgrad.hip); BatchNorm (batch
+statistics) + ReLU + skip add are one fused op (csrc/bnorm.hip).
 """
 import torch
 import torch.nn.functional as F
@@ -109,10 +109,20 @@ def conv3d_cl(x, weight, transposed=False, stride=1):
     return _Conv3dCL.apply(x, weight, transposed, stride)
 
 
-def conv_bn_relu_cl(x, conv, bn, transposed=False, stride=1):
+def conv_bn_relu_cl(x, conv, bn, transposed=False, stride=1, skip=None):
     """ConvBnReLU3D / deconv block of the reference (module.py:26-33, mvsnet.py:66-79) in
-    channels-last with batch statistics when bn.training (running stats are updated)."""
+    channels-last with batch statistics when bn.training (running stats are updated); `skip`
+    is added after the ReLU (mvsnet.py:90-92).  BatchNorm + ReLU + skip are one fused HIP op
+    when the channel count has a kernel, torch ops otherwise."""
     y = conv3d_cl(x, conv.weight, transposed, stride)
+    C = y.shape[-1]
+    if bn.training and C in (8, 16, 32, 64) and bn.momentum is not None and bn.weight is not None:
+        return ops.bn_relu_cl(y, bn, True, skip)
+    out = _bn_relu_torch(y, bn)
+    return out if skip is None else skip + out
+
+
+def _bn_relu_torch(y, bn):
     C = y.shape[-1]
     y2 = F.batch_norm(y.reshape(-1, C), bn.running_mean, bn.running_var, bn.weight, bn.bias,
                       bn.training, bn.momentum, bn.eps)

@@ -28,10 +28,10 @@ def step():
 for _ in range(2): step()
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+with profile(activities=[ProfilerActivity.CUDA]) as prof:     # kernels only
     step(); torch.cuda.synchronize()
-rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:22]
+rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:40]
 tot = sum(e.device_time_total for e in prof.key_averages())
-print("feature_hip", feat_hip, "total device ms", round(tot / 1e3, 1))
+print("feature_hip", feat_hip, "total kernel ms", round(tot / 1e3, 2))
 for e in rows:
-    print(f"{e.key[:90]:90s} n={e.count:4d} dev_ms={e.device_time_total/1e3:8.2f}")
+    print(f"{e.key[:110]:110s} n={e.count:4d} ms={e.device_time_total/1e3:7.2f}")

@@ -903,3 +903,37 @@ def test_cpu_tensors_rejected():
     from mvs_amd._lib import MvsHipError
     with pytest.raises(MvsHipError):
         ops.softmax_regress_conf(torch.zeros(1, 4, 2, 2), torch.zeros(1, 4))
+
+
+@pytest.mark.parametrize("C,shape", [(8, (1, 5, 7, 19)), (16, (2, 3, 6, 10)), (32, (1, 4, 5, 9)), (64, (1, 3, 4, 6))])
+@pytest.mark.parametrize("with_skip", [False, True])
+def test_bn_relu_fused_vs_torch(dev, C, shape, with_skip):
+    """Fused training BatchNorm + ReLU (+ skip) against nn.BatchNorm3d / F.relu autograd: output,
+    the three gradients (and the skip's), running statistics and num_batches_tracked."""
+    import torch.nn.functional as F
+    from mvs_amd import ops
+    g = torch.Generator(device=dev).manual_seed(C + len(shape) + int(with_skip))
+    x = (torch.randn(*shape, C, device=dev, generator=g) * 2 + 3).requires_grad_(True)   # mean far from 0
+    skip = torch.randn(*shape, C, device=dev, generator=g).requires_grad_(True) if with_skip else None
+    go = torch.randn(*shape, C, device=dev, generator=g)
+    bn = torch.nn.BatchNorm3d(C).to(dev).train()
+    with torch.no_grad():
+        bn.weight.copy_(0.5 + torch.rand(C, device=dev, generator=g))
+        bn.bias.copy_(torch.randn(C, device=dev, generator=g) * 0.3)
+    import copy
+    bn_ref = copy.deepcopy(bn)
+    y = ops.bn_relu_cl(x, bn, True, skip)
+    y.backward(go)
+    got = [y.detach(), x.grad, bn.weight.grad, bn.bias.grad] + ([skip.grad] if with_skip else [])
+    xr = x.detach().clone().requires_grad_(True)
+    sr = skip.detach().clone().requires_grad_(True) if with_skip else None
+    yr = F.relu(bn_ref(xr.permute(0, 4, 1, 2, 3))).permute(0, 2, 3, 4, 1)
+    if with_skip:
+        yr = sr + yr
+    yr.backward(go)
+    want = [yr.detach(), xr.grad, bn_ref.weight.grad, bn_ref.bias.grad] + ([sr.grad] if with_skip else [])
+    for a, b in zip(got, want):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-5 * float(b.abs().max()) + 1e-6, rtol=1e-4)
+    np.testing.assert_allclose(bn.running_mean.cpu().numpy(), bn_ref.running_mean.cpu().numpy(), atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), bn_ref.running_var.cpu().numpy(), atol=1e-6, rtol=1e-5)
+    assert int(bn.num_batches_tracked) == int(bn_ref.num_batches_tracked) == 1
