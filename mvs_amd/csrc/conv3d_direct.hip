@@ -81,6 +81,48 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(
     out[o] = epilogue(acc, co, o, scale, shift, residual, g.relu);
 }
 
+// One input channel, CO output channels, stride 1, channels-last (the input gradient of the
+// `prob` layer, mvsnet.py:81: a 1 -> 8 convolution with the flipped weights): one thread per
+// voxel keeps the CO sums, reads its 27 neighbours once (the general kernel reads them once
+// per output channel) and writes CO contiguous floats.  Weights are uniform: scalar loads.
+template <int CO>
+__global__ __launch_bounds__(256) void conv3d_cin1_cl_kernel(
+    const float *__restrict__ in, const float *__restrict__ w, const float *__restrict__ scale,
+    const float *__restrict__ shift, const float *__restrict__ residual, ConvGeom g,
+    float *__restrict__ out) {
+    const int64_t total = (int64_t)g.B * g.D * g.H * g.W;
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int64_t vox = idx;
+    const int x = (int)(idx % g.W); idx /= g.W;
+    const int y = (int)(idx % g.H); idx /= g.H;
+    const int z = (int)(idx % g.D);
+    float acc[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) acc[co] = 0.0f;
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iz = z + kz - 1, iy = y + ky - 1, ix = x + kx - 1;
+                const bool ok = (unsigned)iz < (unsigned)g.D && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+                const int64_t off = vox + ((int64_t)(kz - 1) * g.H + (ky - 1)) * g.W + (kx - 1);
+                const float v = ok ? in[off] : 0.0f;
+#pragma unroll
+                for (int co = 0; co < CO; ++co) acc[co] = fmaf(v, w[co * 27 + (kz * 3 + ky) * 3 + kx], acc[co]);
+            }
+        }
+    }
+    float o[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) o[co] = epilogue(acc[co], co, vox * CO + co, scale, shift, residual, g.relu);
+#pragma unroll
+    for (int q = 0; q < CO / 4; ++q)
+        reinterpret_cast<float4 *>(out + vox * CO)[q] = make_float4(o[q * 4], o[q * 4 + 1], o[q * 4 + 2], o[q * 4 + 3]);
+}
+
 // weight (Ci,Co,3,3,3); out[o] += in[i] * w[k] for o = stride*i - 1 + k
 __global__ __launch_bounds__(256) void deconv3d_direct_kernel(
     const float *__restrict__ in, const float *__restrict__ w, const float *__restrict__ scale,
@@ -147,6 +189,12 @@ int conv3d_direct_launch(const float *in, const float *weight, const float *scal
     if (blocks > 0x7fffffffLL) {
         set_error("conv3d(direct): problem too large");
         return MVS_EINVAL;
+    }
+    if (!transposed && stride == 1 && Cin == 1 && Cout == 8 && g.channels_last) {
+        const int64_t vblocks = ((int64_t)B * D * H * W + 255) / 256;
+        hipLaunchKernelGGL((conv3d_cin1_cl_kernel<8>), dim3((unsigned)vblocks), dim3(256), 0, st, in, weight, scale,
+                           shift, residual, g, out);
+        return check_launch("mvs_conv3d_f32(direct, Cin=1)");
     }
     if (transposed)
         hipLaunchKernelGGL(deconv3d_direct_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in,

@@ -90,6 +90,19 @@ class FeatureNet(nn.Module):
         x = conv2d_cl(x, self.feature.weight, 1) + self.feature.bias
         return x.permute(0, 3, 1, 2).contiguous()
 
+    def forward_train_cl(self, img_nchw):
+        """Autograd path in channels-last: torch's conv2d (MIOpen NHWC kernels, forward and both
+        gradients) + the fused HIP BatchNorm/ReLU op (batch statistics, as in forward()).
+        [N,3,H,W] -> [N,H/4,W/4,32] channels-last."""
+        x = ops.nchw_to_nhwc(img_nchw).permute(0, 3, 1, 2)        # NCHW view of NHWC storage
+        for name, stride in self._PLAN:
+            m = getattr(self, name)
+            y = F.conv2d(x, m.conv.weight, None, stride, m.conv.padding)
+            y = ops.bn_relu_cl(y.permute(0, 2, 3, 1).contiguous(), m.bn)   # no copy when y is NHWC
+            x = y.permute(0, 3, 1, 2)
+        y = F.conv2d(x, self.feature.weight, self.feature.bias, 1, 1)
+        return y.permute(0, 2, 3, 1).contiguous()
+
     def forward_hip(self, imgs_nchw):
         """[N,3,H,W] image batch (the reference's layout) -> [N,H/4,W/4,32] channels-last."""
         x = imgs_nchw
@@ -256,7 +269,9 @@ class MVSNet(nn.Module):
         self.variance_impl = "lds"      # "lds" (LDS-staged source tiles) | "gather"
         self.feature_impl = "hip"       # "hip" (2D MFMA kernels) | "torch" (PyTorch-ROCm / MIOpen)
         self.train_impl = "hip"         # CostRegNet autograd convs: "hip" (MFMA fwd+dgrad) | "torch"
-        self.train_feature_impl = "torch"   # FeatureNet autograd: MIOpen's 2D fp32 path is fast
+        # FeatureNet autograd: "torch_cl" = MIOpen's NHWC 2D kernels + the fused HIP BatchNorm/ReLU
+        # (fastest), "torch" = plain nn modules, "hip" = the 2D MFMA kernels (torch-side wgrad)
+        self.train_feature_impl = "torch_cl"
                                             # (1.6 ms backward); "hip" = mvs_amd.train_ops.conv2d_cl
         self._feature_cl = False
         self.feature = FeatureNet()
@@ -276,8 +291,12 @@ class MVSNet(nn.Module):
             with ops.stage("feature"):
                 # per-view calls: BatchNorm batch statistics are per call in the
                 # reference (mvsnet.py:146)
+                feats_cl = None
                 if self.train_feature_impl == "hip" and self.feature.hip_supported():
                     feats = [self.feature.forward_train_hip(imgs[:, v]) for v in range(V)]
+                elif self.train_feature_impl == "torch_cl" and self.feature.training:
+                    feats_cl = [self.feature.forward_train_cl(imgs[:, v]) for v in range(V)]   # [B,h,w,C]
+                    feats = [f.permute(0, 3, 1, 2) for f in feats_cl]
                 else:
                     feats = [self.feature(imgs[:, v]) for v in range(V)]
             C = feats[0].shape[1]
@@ -285,8 +304,12 @@ class MVSNet(nn.Module):
                 # channels-last all the way: 16-channel-blocked maps (torch layout ops, in the
                 # autograd graph) -> DMA sweep kernel -> [B,D,h,w,C] for the conv kernels;
                 # backward on the LDS-accumulating kernel
-                f16 = torch.stack(feats)                                # [V,B,C,h,w]
-                f16 = f16.reshape(V, f16.shape[1], C // 16, 16, *f16.shape[3:]).permute(0, 1, 2, 4, 5, 3).contiguous()
+                if feats_cl is not None:
+                    f16 = torch.stack(feats_cl)                         # [V,B,h,w,C]
+                    f16 = f16.reshape(*f16.shape[:4], C // 16, 16).permute(0, 1, 4, 2, 3, 5).contiguous()
+                else:
+                    f16 = torch.stack(feats)                            # [V,B,C,h,w]
+                    f16 = f16.reshape(V, f16.shape[1], C // 16, 16, *f16.shape[3:]).permute(0, 1, 2, 4, 5, 3).contiguous()
                 var = ops.costvol_variance_c16_autograd(f16[0], f16[1:], rts, depth_values, self.align_corners)
                 cost = self.cost_regularization.forward_train_hip(var)
             else:

@@ -7,11 +7,11 @@ sys.path.insert(0, REPO)
 from mvs_amd import synth
 from mvs_amd.models import MVSNet, mvsnet_loss
 dev = torch.device("cuda:0")
-feat_hip = (sys.argv[1] if len(sys.argv) > 1 else "hip") == "hip"
+feat_impl = sys.argv[1] if len(sys.argv) > 1 else None
 torch.manual_seed(1)
 model = MVSNet(refine=False).to(dev).train()
-if not feat_hip:
-    model.feature.hip_supported = lambda: False
+if feat_impl:
+    model.train_feature_impl = feat_impl
 opt = torch.optim.Adam(model.parameters(), lr=1e-3)
 H, W, V, D = 512, 640, 3, 192
 rng = np.random.default_rng(0)
@@ -32,6 +32,6 @@ with profile(activities=[ProfilerActivity.CUDA]) as prof:     # kernels only
     step(); torch.cuda.synchronize()
 rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:40]
 tot = sum(e.device_time_total for e in prof.key_averages())
-print("feature_hip", feat_hip, "total kernel ms", round(tot / 1e3, 2))
+print("train_feature_impl", model.train_feature_impl, "total kernel ms", round(tot / 1e3, 2))
 for e in rows:
     print(f"{e.key[:110]:110s} n={e.count:4d} ms={e.device_time_total/1e3:7.2f}")
