@@ -295,6 +295,9 @@ class MVSNet(nn.Module):
                 if self.train_feature_impl == "hip" and self.feature.hip_supported():
                     feats = [self.feature.forward_train_hip(imgs[:, v]) for v in range(V)]
                 elif self.train_feature_impl == "torch_cl" and self.feature.training:
+                    if not self._feature_cl:   # weights in NHWC once, not re-laid-out by every conv2d call
+                        self.feature.to(memory_format=torch.channels_last)
+                        self._feature_cl = True
                     feats_cl = [self.feature.forward_train_cl(imgs[:, v]) for v in range(V)]   # [B,h,w,C]
                     feats = [f.permute(0, 3, 1, 2) for f in feats_cl]
                 else:
