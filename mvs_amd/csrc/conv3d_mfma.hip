@@ -704,7 +704,7 @@ static bool lookup(int transposed, int Cin, int Cout, int stride, CfgInfo &ci) {
         // two waves per SIMD hide the epilogue's residual loads and the staging latency
         MVS_DCFG(64, 32, 16, 2, 2, false)
         MVS_DCFG(32, 16, 16, 2, 4, false)
-        MVS_DCFG(16, 8, 16, 2, 8, true)
+        MVS_DCFG(16, 8, 16, 2, 4, true)
         return false;
     }
     if (stride == 1) {
