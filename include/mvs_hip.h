@@ -151,7 +151,7 @@ size_t mvs_conv3d_wgrad_workspace_bytes(int B, int Cin, int Cout, int D, int H, 
 int mvs_conv3d_wgrad_supported(int Cin, int Cout, int stride);
 
 /* Training-mode BatchNorm fused with the ReLU and skip add that follow it in the reference's
- * blocks (module.py:26-33 ConvBnReLU3D = relu(bn(conv(x))); mvsnet.py:80-92 skip + relu(bn(deconv)));
+ * blocks (module.py:26-33 ConvBnReLU3D = relu(bn(conv(x))); mvsnet.py:89-91 skip + relu(bn(deconv)));
  * channels-last rows x [N][C], N = B*D*H*W, C in {8,16,32,64}:
  *   y = relu((x - mean) * invstd * weight + bias) [+ skip]     (relu != 0; skip may be NULL)
  * mean / biased variance over the N rows (nn.BatchNorm3d in training mode); running_mean /

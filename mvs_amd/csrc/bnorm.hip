@@ -1,6 +1,6 @@
 // Training-mode BatchNorm (batch statistics) fused with the ReLU and the skip add that follow
 // it in the reference's blocks: ConvBnReLU3D = relu(bn(conv(x))) (module.py:26-33) and the
-// CostRegNet decoder's `skip + relu(bn(deconv(x)))` (mvsnet.py:80-92).  Channels-last rows
+// CostRegNet decoder's `skip + relu(bn(deconv(x)))` (mvsnet.py:89-91).  Channels-last rows
 // [N][C] (N = B*D*H*W voxels, C in {8,16,32,64}).
 //
 // As torch ops these are 4 (forward) + 5 (backward) full passes over the activations per layer

@@ -112,7 +112,7 @@ def conv3d_cl(x, weight, transposed=False, stride=1):
 def conv_bn_relu_cl(x, conv, bn, transposed=False, stride=1, skip=None):
     """ConvBnReLU3D / deconv block of the reference (module.py:26-33, mvsnet.py:66-79) in
     channels-last with batch statistics when bn.training (running stats are updated); `skip`
-    is added after the ReLU (mvsnet.py:90-92).  BatchNorm + ReLU + skip are one fused HIP op
+    is added after the ReLU (mvsnet.py:89-91).  BatchNorm + ReLU + skip are one fused HIP op
     when the channel count has a kernel, torch ops otherwise."""
     y = conv3d_cl(x, conv.weight, transposed, stride)
     C = y.shape[-1]
