@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE configs[3]: CVP-MVSNet coarse-to-fine forward at 1920x1056, 7 views (6 sources),
 5 pyramid levels, on cuda:0 -- ms per reference view and peak memory.
-    python scripts/bench_cvp.py [H W nsrc nscale] [--steps K] [--parity]
+    python scripts/bench_cvp.py [H W nsrc nscale] [--steps K] [--parity] [--profile]
 Test/measurement infrastructure (imports oracle/ for the checker only)."""
 import json
 import os
@@ -44,6 +44,18 @@ def main():
     for _ in range(steps):
         out = step()
     torch.cuda.synchronize()
+    if "--profile" in sys.argv:   # kernel breakdown of one steady-state forward
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            step()
+            torch.cuda.synchronize()
+        rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)
+        print("total kernel ms", round(sum(e.device_time_total for e in rows) / 1e3, 2), file=sys.stderr)
+        for e in rows[:30]:
+            print(f"{e.key[:120]:120s} n={e.count:4d} ms={e.device_time_total / 1e3:7.2f}", file=sys.stderr)
+        for name in [r.key for r in rows[:4]]:   # per-launch durations of the heaviest kernels, in launch order
+            durs = [round(ev.device_time_total / 1e3, 3) for ev in prof.events() if ev.key == name]
+            print(name[:70], durs, file=sys.stderr)
     res = {"config": {"H": H, "W": W, "views": nsrc + 1, "nscale": nscale},
            "ms_per_ref_view": round((time.perf_counter() - t0) / steps * 1e3, 3),
            "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
