@@ -180,10 +180,14 @@ int mvs_bn_train_bwd_f32(const float *grad_y, const float *x, const float *weigh
  * (3-channel layer only).  out: [B,Ho,Wo,Cout] channels-last.  Supported (Cin,Cout,k,
  * stride): (3,8,3,1) (8,8,3,1) (8,16,5,2) (16,16,3,1) (16,32,5,2) (32,32,3,1); the
  * CasMVSNet FPN heads (32,32,1,1) (16,32,1,1) (8,32,1,1) (32,16,3,1) (32,8,3,1); the
- * CVP-MVSNet pyramid (3,64,3,1) (64,64,3,1) (64,32,3,1) (32,16,3,1). */
+ * CVP-MVSNet pyramid (3,64,3,1) (64,64,3,1) (64,32,3,1) (32,16,3,1).
+ * coarse (or NULL): [B,Ho/2,Wo/2,Cout] channels-last, added to the result through a nearest-
+ * neighbour x2 upsample -- the FPN top-down step `F.interpolate(intra_feat, scale_factor=2,
+ * mode="nearest") + inner(conv)` of CasMVSNet/models/module.py:392,396 fused into the lateral
+ * 1x1 convolution; stride-1 layers of the persistent kernel with even H, W only. */
 int mvs_conv2d_f32(const float *in, const float *packed_weight, const float *scale,
-                   const float *shift, int relu, int B, int Cin, int Cout, int H, int W,
-                   int ksize, int stride, int in_planar, float *out, void *stream);
+                   const float *shift, const float *coarse, int relu, int B, int Cin, int Cout, int H,
+                   int W, int ksize, int stride, int in_planar, float *out, void *stream);
 int64_t mvs_conv2d_packed_weight_floats(int Cin, int Cout, int ksize, int stride);
 /* weight: PyTorch layout (Cout,Cin,k,k) -> MFMA A-fragment order. */
 int mvs_conv2d_pack_weights_f32(const float *weight, int Cin, int Cout, int ksize, int stride,

@@ -373,13 +373,20 @@ int conv2d_pack_launch(const float *weight, int Cin, int Cout, int ksize, int st
 }
 
 int conv2d_launch(const float *in, const float *packed, const float *scale, const float *shift,
-                  int relu, int B, int Cin, int Cout, int H, int W, int ksize, int stride,
+                  const float *coarse, int relu, int B, int Cin, int Cout, int H, int W, int ksize, int stride,
                   int in_planar, float *out, hipStream_t st) {
     Persist2Info pi;
-    if (!in_planar && persist2_enabled() && lookup_persist2(Cin, Cout, ksize, stride, pi)) {
+    const bool persistent = !in_planar && lookup_persist2(Cin, Cout, ksize, stride, pi);
+    if (coarse && (!persistent || stride != 1 || (H & 1) || (W & 1))) {
+        set_error("mvs_conv2d_f32: the upsampled residual needs a stride-1 layer of the persistent kernel "
+                  "and even H, W (Cin=%d Cout=%d k=%d)", Cin, Cout, ksize);
+        return MVS_EUNSUPPORTED;
+    }
+    if (persistent && (coarse || persist2_enabled())) {
         if ((int64_t)H * W * Cin * 4 >= 0xffffff00LL) return MVS_EINVAL;   // 32-bit offsets inside one image
         ConvArgs a;
-        a.in = in; a.wpk = packed; a.scale = scale; a.shift = shift; a.residual = nullptr; a.out = out;
+        a.in = in; a.wpk = packed; a.scale = scale; a.shift = shift; a.residual = coarse; a.out = out;
+        a.res_up2 = coarse ? 1 : 0;
         a.B = 1; a.D = B; a.H = H; a.W = W;
         const int pad = ksize / 2;
         a.Do = B;
@@ -451,12 +458,12 @@ extern "C" int mvs_conv2d_pack_weights_f32(const float *weight, int Cin, int Cou
 }
 
 extern "C" int mvs_conv2d_f32(const float *in, const float *packed_weight, const float *scale,
-                              const float *shift, int relu, int B, int Cin, int Cout, int H, int W,
-                              int ksize, int stride, int in_planar, float *out, void *stream) {
+                              const float *shift, const float *coarse, int relu, int B, int Cin, int Cout,
+                              int H, int W, int ksize, int stride, int in_planar, float *out, void *stream) {
     if (!in || !packed_weight || !out || B <= 0 || H <= 0 || W <= 0) {
         set_error("mvs_conv2d_f32: invalid argument");
         return MVS_EINVAL;
     }
-    return conv2d_launch(in, packed_weight, scale, shift, relu, B, Cin, Cout, H, W, ksize, stride,
+    return conv2d_launch(in, packed_weight, scale, shift, coarse, relu, B, Cin, Cout, H, W, ksize, stride,
                          in_planar, out, as_stream(stream));
 }

@@ -780,6 +780,7 @@ int conv3d_mfma_launch(const float *in, const float *packed, const float *scale,
     a.B = B; a.D = D; a.H = H; a.W = W;
     a.relu = relu;
     a.in_c8 = in_c8;
+    a.res_up2 = 0;
     {
         const char *ys = getenv("MVS_CONV_YSTRIP");   // tuning; default: strips of 4 tile rows
         a.ystrip = ys ? atoi(ys) : 4;

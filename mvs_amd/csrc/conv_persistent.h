@@ -24,6 +24,7 @@ struct ConvArgs {
     int relu;
     int in_c8;   // input is [B,D,H,C/8,W,8] (8-channel blocked) instead of [B,D,H,W,C]
     int ystrip;  // tile order: 0 = x, y, z; n > 0 = y within strips of n tile rows, then z, then x
+    int res_up2; // residual is [B,Do,Ho/2,Wo/2,C]: added through a nearest x2 upsample in y and x (FPN top-down path)
 };
 
 // XCD-aware bijective remap: consecutive tiles land on the same XCD (same L2)
@@ -376,7 +377,9 @@ __global__ __launch_bounds__(512) void conv3d_c8_persistent_kernel(ConvArgs a, i
                     }
                     const int64_t o = ((((int64_t)cur.b * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * COUT + c0;
                     if (a.residual && !(ABL & 16)) {
-                        const float4 rs = *reinterpret_cast<const float4 *>(a.residual + o);
+                        const int64_t ro = a.res_up2 ? ((((int64_t)cur.b * a.Do + oz) * (a.Ho >> 1) + (oy >> 1)) * (a.Wo >> 1) +
+                                                        (ox >> 1)) * COUT + c0 : o;
+                        const float4 rs = *reinterpret_cast<const float4 *>(a.residual + ro);
                         v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
                     }
                     *reinterpret_cast<float4 *>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);

@@ -114,15 +114,18 @@ class FeatureNet(nn.Module):
 
     def forward_hip(self, imgs_nchw):
         """[N,3,H,W] -> {"stage1": [N,H/4,W/4,32], "stage2": [N,H/2,W/2,16], "stage3": [N,H,W,8]}
-        channels-last (module.py:343-405; the nearest x2 upsample + lateral add stay torch ops)."""
+        channels-last (module.py:343-405; the nearest x2 upsample + lateral add ride in the 1x1 kernels)."""
         P = self._hip_params()
 
-        def run(x, p, planar=False):
+        def run(x, p, planar=False, coarse=None):
             return ops.conv2d(x, p["packed"], p["cin"], p["cout"], p["k"], p["stride"], p["scale"], p["shift"],
-                              p["relu"], planar=planar)
+                              p["relu"], planar=planar, coarse=coarse)
 
-        def up2(t):   # nearest-neighbour x2 on [N,H,W,C]
-            return t.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+        def lateral(top, x, p):   # F.interpolate(top, x2, nearest) + inner(x)  (module.py:392,396)
+            if top.shape[1] * 2 == x.shape[1] and top.shape[2] * 2 == x.shape[2]:
+                return run(x, p, coarse=top)            # fused into the 1x1 convolution's epilogue
+            up = top.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)   # odd sizes: as the reference
+            return up + run(x, p)
 
         c0 = run(run(imgs_nchw, P["conv0"][0], planar=True), P["conv0"][1])
         c1 = c0
@@ -132,9 +135,9 @@ class FeatureNet(nn.Module):
         for p in P["conv2"]:
             top = run(top, p)
         out = {"stage1": run(top, P["out1"])}
-        top = up2(top) + run(c1, P["inner1"])
+        top = lateral(top, c1, P["inner1"])
         out["stage2"] = run(top, P["out2"])
-        top = up2(top) + run(c0, P["inner2"])
+        top = lateral(top, c0, P["inner2"])
         out["stage3"] = run(top, P["out3"])
         return out
 

@@ -606,9 +606,10 @@ def bn_relu_cl(x, bn, relu=True, skip=None):
                            bn.momentum, bn.eps, relu)
 
 
-def conv2d(x, packed, cin, cout, ksize, stride, scale=None, shift=None, relu=False, planar=False):
+def conv2d(x, packed, cin, cout, ksize, stride, scale=None, shift=None, relu=False, planar=False, coarse=None):
     """FeatureNet convolution.  x: [B,H,W,cin] channels-last, or (planar) the [B,3,H,W]
-    image.  relu: False/True, or 2 for LeakyReLU(0.1).  Returns [B,Ho,Wo,cout] channels-last."""
+    image.  relu: False/True, or 2 for LeakyReLU(0.1).  coarse: [B,Ho/2,Wo/2,cout], added through
+    a nearest x2 upsample (FPN top-down step).  Returns [B,Ho,Wo,cout] channels-last."""
     x = _f32c(x)
     if planar:
         B, _, H, W = x.shape
@@ -617,7 +618,11 @@ def conv2d(x, packed, cin, cout, ksize, stride, scale=None, shift=None, relu=Fal
     pad = ksize // 2
     Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
     out = torch.empty((B, Ho, Wo, cout), device=x.device, dtype=torch.float32)
-    check(_lib.load().mvs_conv2d_f32(ptr(x), ptr(packed), ptr(scale), ptr(shift), int(relu), B, cin,
+    if coarse is not None:
+        coarse = _f32c(coarse)
+        if tuple(coarse.shape) != (B, Ho // 2, Wo // 2, cout) or Ho % 2 or Wo % 2:
+            raise MvsHipError(f"conv2d: coarse {tuple(coarse.shape)} is not half of {(B, Ho, Wo, cout)}")
+    check(_lib.load().mvs_conv2d_f32(ptr(x), ptr(packed), ptr(scale), ptr(shift), ptr(coarse), int(relu), B, cin,
                                      cout, H, W, ksize, stride, int(planar), ptr(out), stream()),
           "mvs_conv2d_f32")
     return out

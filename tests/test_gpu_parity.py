@@ -937,3 +937,24 @@ def test_bn_relu_fused_vs_torch(dev, C, shape, with_skip):
     np.testing.assert_allclose(bn.running_mean.cpu().numpy(), bn_ref.running_mean.cpu().numpy(), atol=1e-6, rtol=1e-5)
     np.testing.assert_allclose(bn.running_var.cpu().numpy(), bn_ref.running_var.cpu().numpy(), atol=1e-6, rtol=1e-5)
     assert int(bn.num_batches_tracked) == int(bn_ref.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("cin,shape", [(16, (2, 18, 26)), (8, (1, 40, 72))])
+def test_conv2d_fused_upsample_add(dev, cin, shape):
+    """FPN top-down step fused into the lateral 1x1 convolution: conv(x) + nearest_x2(coarse)
+    must equal the unfused kernel's output plus torch's F.interpolate, bit for bit."""
+    import torch.nn.functional as F
+    from mvs_amd import ops
+    B, H, W = shape
+    g = torch.Generator(device=dev).manual_seed(cin)
+    x = torch.randn(B, H, W, cin, device=dev, generator=g)
+    coarse = torch.randn(B, H // 2, W // 2, 32, device=dev, generator=g)
+    w = torch.randn(32, cin, 1, 1, device=dev, generator=g) * 0.2
+    bias = torch.randn(32, device=dev, generator=g)
+    packed = ops.pack_conv2d_weight(w, 1)
+    plain = ops.conv2d(x, packed, cin, 32, 1, 1, None, bias, False)
+    fused = ops.conv2d(x, packed, cin, 32, 1, 1, None, bias, False, coarse=coarse)
+    up = F.interpolate(coarse.permute(0, 3, 1, 2), scale_factor=2, mode="nearest").permute(0, 2, 3, 1)
+    assert torch.equal(fused, up + plain)
+    with pytest.raises(ops.MvsHipError):
+        ops.conv2d(x, packed, cin, 32, 1, 1, None, bias, False, coarse=coarse[:, :-1])
