@@ -353,14 +353,15 @@ constexpr int kTileW = 8, kTileH = 8, kTileD = 4;   // square tile: compact foot
 
 // 16 channels of one view: bilinear blend of the four taps, then S += w, Q += w*w
 // (mvsnet.py:164-165).  Four channels at a time so at most 4 float4 loads are live.
+template <int NQ = 4>
 __device__ __forceinline__ void accumulate_taps(const float *__restrict__ t00,
                                                 const float *__restrict__ t01,
                                                 const float *__restrict__ t10,
                                                 const float *__restrict__ t11, float wnw, float wne,
-                                                float wsw, float wse, float (&S)[16],
-                                                float (&Q)[16]) {
+                                                float wsw, float wse, float (&S)[4 * NQ],
+                                                float (&Q)[4 * NQ]) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NQ; ++k) {
         const float4 a = reinterpret_cast<const float4 *>(t00)[k];
         const float4 bq = reinterpret_cast<const float4 *>(t01)[k];
         const float4 c = reinterpret_cast<const float4 *>(t10)[k];
@@ -398,19 +399,19 @@ __device__ __forceinline__ void accumulate_taps(const float *__restrict__ t00,
 // quads of a tap sit at immediate offsets k * plane.
 // texels per view: 48 KiB in total (3 workgroups per CU; the register budget allows no
 // more), whole 64-lane DMA instructions where that costs little
-__host__ __device__ constexpr int dma_cap(int nv) {
-    const int raw = (48 * 1024) / (nv * 64);
+__host__ __device__ constexpr int dma_cap(int nv, int nq = 4) {   // nq = channel quads per group
+    const int raw = (48 * 1024) / (nv * 16 * nq);
     return raw >= 256 ? 256 : (raw >= 192 ? 192 : raw);
 }
 
 // taps from the planar LDS image: o?? = texel index of the tap, PL = plane stride (texels)
-template <int PL>
+template <int PL, int NQ>
 __device__ __forceinline__ void accumulate_taps_planar(const float *__restrict__ base, int o00,
                                                        int o01, int o10, int o11, float wnw,
                                                        float wne, float wsw, float wse,
-                                                       float (&S)[16], float (&Q)[16]) {
+                                                       float (&S)[4 * NQ], float (&Q)[4 * NQ]) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NQ; ++k) {
         const float4 a = *reinterpret_cast<const float4 *>(base + (k * PL + o00) * 4);
         const float4 bq = *reinterpret_cast<const float4 *>(base + (k * PL + o01) * 4);
         const float4 c = *reinterpret_cast<const float4 *>(base + (k * PL + o10) * 4);
@@ -428,14 +429,18 @@ __device__ __forceinline__ void accumulate_taps_planar(const float *__restrict__
     }
 }
 
-template <int NV, bool CORNER>
+// NQ = 4: features [B,C/16,H,W,16]; NQ = 2: 8-channel maps [B,H,W,8] (the cascade's finest
+// stage) -- the same layout with one group of two quads, waves 2 and 3 take every other
+// DMA instruction instead of their own quad.
+template <int NV, bool CORNER, int NQ = 4>
 __global__ __launch_bounds__(256, 2) void variance_fwd_dma_kernel(
     const float *__restrict__ ref16, const float *__restrict__ srcs16,
     const float *__restrict__ rt, const float *__restrict__ depth, SweepParams p,
     int tiles_x, int tiles_y, float *__restrict__ out, int out_c8, int ablate) {
-    constexpr int cap = dma_cap(NV);
+    constexpr int cap = dma_cap(NV, NQ);
     constexpr int NJ = (cap + 63) / 64;          // DMA instructions per plane
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // NV * 4 * cap * 4 floats
+    constexpr int GC = 4 * NQ, NSH = 4 / NQ;     // channels per group; waves sharing a quad
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // NV * NQ * cap * 4 floats
     __shared__ int s_box[NV][4];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -463,13 +468,14 @@ __global__ __launch_bounds__(256, 2) void variance_fwd_dma_kernel(
     const int pix = cy * p.W + cx;
     const float dv = p.depth_mode == 0 ? depth[(int64_t)b * p.D + cd]
                                        : depth[((int64_t)b * p.D + cd) * plane + pix];
-    const int ngroups = p.C >> 4;
-    const size_t grp_floats = (size_t)plane * 16;
+    const int ngroups = p.C / GC;
+    const size_t grp_floats = (size_t)plane * GC;
     const unsigned lds_base = (unsigned)(uintptr_t)lds;
+    const int dq = wv % NQ, dj = wv / NQ;        // this wave's quad and share of the DMA instructions
 
     int bx0[NV], by0[NV], bw[NV], bh[NV];
     bool staged[NV];
-    // per-view source offsets (floats, inside one 16-channel group) of this lane's texels
+    // per-view source offsets (floats, inside one channel group) of this lane's texels
     int soff[NV][NJ];
     auto plan_dma = [&]() {
 #pragma unroll
@@ -480,7 +486,7 @@ __global__ __launch_bounds__(256, 2) void variance_fwd_dma_kernel(
             for (int j = 0; j < NJ; ++j) {
                 const int t = min(j * 64 + lane, max(n - 1, 0));
                 const int ly = (int)(((unsigned)t * inv) >> 16), lx = t - ly * bw[v];
-                soff[v][j] = ((by0[v] + ly) * p.W + (bx0[v] + lx)) * 16;
+                soff[v][j] = ((by0[v] + ly) * p.W + (bx0[v] + lx)) * GC;
             }
         }
     };
@@ -492,15 +498,15 @@ __global__ __launch_bounds__(256, 2) void variance_fwd_dma_kernel(
             // buffer-addressed: descriptor = this view's 16-channel group (SGPRs), per-lane
             // offsets fixed for the whole block -> no vector ALU work per copy
             const mvs_srd_t srd = make_srd(
-                srcs16 + (((size_t)v * p.B + b) * ngroups + g) * grp_floats + wv * 4,
+                srcs16 + (((size_t)v * p.B + b) * ngroups + g) * grp_floats + dq * 4,
                 (unsigned)(grp_floats * 4));
             const int n = bw[v] * bh[v];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                if (j * 64 >= n) continue;                       // wave-uniform
+                if (j * 64 >= n || (j % NSH) != dj) continue;    // wave-uniform
                 if (j * 64 + lane < cap)                         // the last instruction may be partial
                     glds16_buf((unsigned)soff[v][j] * 4u, srd, 0u,
-                               lds_base + (unsigned)(((v * 4 + wv) * cap + j * 64) * 16));
+                               lds_base + (unsigned)(((v * NQ + dq) * cap + j * 64) * 16));
             }
         }
     };
@@ -619,20 +625,20 @@ __global__ __launch_bounds__(256, 2) void variance_fwd_dma_kernel(
         // LDS offsets + 4 64-bit fallback pointers out of this loop and spills
 #pragma unroll
         for (int v = 0; v < NV; ++v) asm volatile("" : "+v"(tx0[v]), "+v"(ty0[v]));
-        float4 ref4[4];
+        float4 ref4[NQ];
         {
             const float4 *rp = reinterpret_cast<const float4 *>(
-                ref16 + ((size_t)b * ngroups + g) * grp_floats + (size_t)pix * 16);
+                ref16 + ((size_t)b * ngroups + g) * grp_floats + (size_t)pix * GC);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) ref4[k] = rp[k];
+            for (int k = 0; k < NQ; ++k) ref4[k] = rp[k];
         }
         // this group's footprints have landed for every wave
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
-        float S[16], Q[16];
+        float S[GC], Q[GC];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NQ; ++k) {
             const float4 r4 = ref4[k];
             const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
 #pragma unroll
@@ -649,18 +655,18 @@ __global__ __launch_bounds__(256, 2) void variance_fwd_dma_kernel(
                 const int x1c = min(max(tx0[v] + 1, bx0[v]), bx0[v] + bw[v] - 1) - bx0[v];
                 const int y0c = min(max(ty0[v], by0[v]), by0[v] + bh[v] - 1) - by0[v];
                 const int y1c = min(max(ty0[v] + 1, by0[v]), by0[v] + bh[v] - 1) - by0[v];
-                accumulate_taps_planar<cap>(lds + v * 4 * cap * 4, y0c * bw[v] + x0c,
+                accumulate_taps_planar<cap, NQ>(lds + v * NQ * cap * 4, y0c * bw[v] + x0c,
                                             y0c * bw[v] + x1c, y1c * bw[v] + x0c,
                                             y1c * bw[v] + x1c, wnw[v], wne[v], wsw[v], wse[v], S, Q);
             } else {
                 const float *base = srcs16 + (((size_t)v * p.B + b) * ngroups + g) * grp_floats;
                 const int x0c = min(max(tx0[v], 0), p.W - 1), x1c = min(max(tx0[v] + 1, 0), p.W - 1);
                 const int y0c = min(max(ty0[v], 0), p.H - 1), y1c = min(max(ty0[v] + 1, 0), p.H - 1);
-                accumulate_taps(base + ((size_t)y0c * p.W + x0c) * 16,
-                                base + ((size_t)y0c * p.W + x1c) * 16,
-                                base + ((size_t)y1c * p.W + x0c) * 16,
-                                base + ((size_t)y1c * p.W + x1c) * 16, wnw[v], wne[v], wsw[v],
-                                wse[v], S, Q);
+                accumulate_taps<NQ>(base + ((size_t)y0c * p.W + x0c) * GC,
+                                    base + ((size_t)y0c * p.W + x1c) * GC,
+                                    base + ((size_t)y1c * p.W + x0c) * GC,
+                                    base + ((size_t)y1c * p.W + x1c) * GC, wnw[v], wne[v], wsw[v],
+                                    wse[v], S, Q);
             }
         }
         // every wave is done with this group's LDS image: start the next group's copy; it
@@ -669,17 +675,17 @@ __global__ __launch_bounds__(256, 2) void variance_fwd_dma_kernel(
             __syncthreads();
             issue_dma(g + 1);
         }
-        float var[16];
+        float var[GC];
         bool tiny = false;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
+        for (int c = 0; c < GC; ++c) {
             const float m = div_views_fast(S[c], p.fV, rV);
             var[c] = div_views_fast(Q[c], p.fV, rV) - m * m;
             tiny = tiny || div_views_tiny(S[c]) || div_views_tiny(Q[c]);
         }
         if (__any(tiny)) {
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
+            for (int c = 0; c < GC; ++c) {
                 const float m = S[c] / p.fV;
                 var[c] = Q[c] / p.fV - m * m;
             }
@@ -689,15 +695,15 @@ __global__ __launch_bounds__(256, 2) void variance_fwd_dma_kernel(
             if (out_c8) {
                 const size_t row = ((size_t)b * p.D + d) * p.H + py;
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    float *o = out + ((row * (p.C >> 3) + (g * 2 + h)) * p.W + px) * 8;
+                for (int h = 0; h < NQ / 2; ++h) {
+                    float *o = out + ((row * (p.C >> 3) + (g * (NQ / 2) + h)) * p.W + px) * 8;
                     reinterpret_cast<float4 *>(o)[0] = make_float4(var[h * 8 + 0], var[h * 8 + 1], var[h * 8 + 2], var[h * 8 + 3]);
                     reinterpret_cast<float4 *>(o)[1] = make_float4(var[h * 8 + 4], var[h * 8 + 5], var[h * 8 + 6], var[h * 8 + 7]);
                 }
             } else {
-                float4 *o = reinterpret_cast<float4 *>(out + vox * p.C + g * 16);
+                float4 *o = reinterpret_cast<float4 *>(out + vox * p.C + g * GC);
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
+                for (int k = 0; k < NQ; ++k)
                     o[k] = make_float4(var[k * 4], var[k * 4 + 1], var[k * 4 + 2], var[k * 4 + 3]);
             }
         }
@@ -1321,6 +1327,33 @@ extern "C" int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *s
         return check_launch("mvs_costvol_variance_fwd_f32(lds)");
     }
     if (fea_layout != MVS_LAYOUT_NHWC) return MVS_EINVAL;
+    if (C == 8 && (int64_t)H * W < (1 << 26) && B <= 65535 && !getenv("MVS_SWEEP_C8_GATHER")) {
+        // 8-channel maps (the cascade's finest stage): the LDS-staged kernel with one group of two quads
+        const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (H + kTileH - 1) / kTileH;
+        const int dchunks = (D + kTileD - 1) / kTileD;
+        const int64_t nblk = (int64_t)tiles_x * tiles_y * dchunks;
+        if (nblk > 0x7fffffffLL) return MVS_EINVAL;
+        const dim3 g((unsigned)nblk, (unsigned)B);
+#define MVS_LDS8_CASE(n)                                                                          \
+    case n: {                                                                                     \
+        const size_t shmem = (size_t)n * 2 * dma_cap(n, 2) * 16;                                  \
+        if (depth_mode == 0)                                                                      \
+            hipLaunchKernelGGL((variance_fwd_dma_kernel<n, true, 2>), g, dim3(256), shmem, st,    \
+                               ref_fea, src_feas, rot_trans, depth_values, p, tiles_x, tiles_y,   \
+                               out_var, out_c8, 0);                                               \
+        else                                                                                      \
+            hipLaunchKernelGGL((variance_fwd_dma_kernel<n, false, 2>), g, dim3(256), shmem, st,   \
+                               ref_fea, src_feas, rot_trans, depth_values, p, tiles_x, tiles_y,   \
+                               out_var, out_c8, 0);                                               \
+        break;                                                                                    \
+    }
+        switch (NV) {
+            MVS_LDS8_CASE(1) MVS_LDS8_CASE(2) MVS_LDS8_CASE(3) MVS_LDS8_CASE(4) MVS_LDS8_CASE(5)
+            MVS_LDS8_CASE(6) MVS_LDS8_CASE(7) MVS_LDS8_CASE(8)
+        }
+#undef MVS_LDS8_CASE
+        return check_launch("mvs_costvol_variance_fwd_f32(lds, 8 channels)");
+    }
     int rc;
     switch (C) {
         case 8: rc = launch_variance_cl<2>(NV, ref_fea, src_feas, rot_trans, depth_values, p, out_var, out_c8, st); break;

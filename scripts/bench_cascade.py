@@ -49,6 +49,15 @@ def main():
         ops.set_timer(None)
         res["stages_ms"] = {k: [c // steps, round(ms, 3)] for k, (c, ms) in sorted(timer.summary_ms().items())}
         res["peak_mem_gb"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
+        if "--profile" in sys.argv:   # kernel breakdown of one steady-state forward
+            from torch.profiler import profile, ProfilerActivity
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                net(gi, gp, gd)
+                torch.cuda.synchronize()
+            rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)
+            print("total kernel ms", round(sum(e.device_time_total for e in rows) / 1e3, 2), file=sys.stderr)
+            for e in rows[:36]:
+                print(f"{e.key[:120]:120s} n={e.count:4d} ms={e.device_time_total / 1e3:7.2f}", file=sys.stderr)
         if "--parity" in sys.argv:
             from oracle import torch_ref as tr
             torch.set_num_threads(os.cpu_count())

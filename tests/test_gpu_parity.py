@@ -958,3 +958,26 @@ def test_conv2d_fused_upsample_add(dev, cin, shape):
     assert torch.equal(fused, up + plain)
     with pytest.raises(ops.MvsHipError):
         ops.conv2d(x, packed, cin, 32, 1, 1, None, bias, False, coarse=coarse[:, :-1])
+
+
+@pytest.mark.parametrize("V,per_pixel,c8", [(5, True, True), (3, False, False), (2, True, False), (7, False, True)])
+def test_variance_8ch_lds_kernel_bit_equal_to_planar(dev, V, per_pixel, c8):
+    """8-channel maps (the cascade's finest stage) on the LDS-staged sweep kernel (one group of
+    two channel quads): bit-equal to the planar kernel, shared planes and per-pixel hypotheses,
+    ragged tiles, both output layouts, and the alias quirk."""
+    from mvs_amd import ops, synth
+    B, C, D, H, W = 2, 8, 7, 27, 45
+    rng = np.random.default_rng(V)
+    proj = G(synth.proj_matrices(V, H, W, batch=B), dev)
+    feats = G(synth.smooth_features(rng, (V, B, C, H, W)), dev)
+    base = synth.depth_values(D, batch=B, interval=synth.sweep_interval(D))
+    depth = (base[:, :, None, None] + 4 * rng.standard_normal((B, D, H, W))).astype(np.float32) if per_pixel else base
+    depth = G(depth, dev)
+    rts = ops.rot_trans_all(proj)
+    fcl = feats.permute(0, 1, 3, 4, 2).contiguous()                       # [V,B,H,W,8]
+    for quirk in (False, True):
+        want = ops.costvol_variance(feats[0], feats[1:], rts, depth, alias_quirk=quirk)   # [B,C,D,H,W]
+        got = ops.costvol_variance_cl(fcl[0], fcl[1:], rts, depth, alias_quirk=quirk, out_c8=c8)
+        if c8:   # [B,D,H,1,W,8]
+            got = got.squeeze(3)
+        assert torch.equal(got.permute(0, 4, 1, 2, 3), want)
