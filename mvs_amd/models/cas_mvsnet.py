@@ -223,9 +223,9 @@ class CascadeMVSNet(nn.Module):
             if self.proj_where == "host" else {}
         use_hip = self.feature_impl == "hip" and not self.training and self.feature.hip_supported()
         with ops.stage("feature"):
-            if use_hip:   # all views in one batch; channels-last pyramids, split per view
-                pyr = self.feature.forward_hip(imgs.reshape(B * V, 3, H, W))
-                feats = [{k: t.reshape(B, V, *t.shape[1:])[:, v] for k, t in pyr.items()} for v in range(V)]
+            if use_hip:   # all views in one view-major batch: the pyramids come out as [V,B,h,w,C]
+                pyr = self.feature.forward_hip(imgs.transpose(0, 1).reshape(V * B, 3, H, W))
+                pyr = {k: t.reshape(V, B, *t.shape[1:]) for k, t in pyr.items()}
             else:
                 feats = [self.feature(imgs[:, v]) for v in range(V)]
         outputs, depth = {}, None
@@ -242,7 +242,7 @@ class CascadeMVSNet(nn.Module):
                                        (B, H, W))
                 hyp = F.interpolate(hyp.unsqueeze(1), [self.ndepths[s], H // scale, W // scale],
                                     mode="trilinear", align_corners=False).squeeze(1).contiguous()
-            stage_feats = [f[key] for f in feats]
+            stage_feats = pyr[key] if use_hip else [f[key] for f in feats]
             if self.training:
                 raise NotImplementedError("CascadeMVSNet here is the inference path (config 3)")
             out = cascade.depthnet_forward(stage_feats, proj_matrices[key], hyp,

@@ -77,8 +77,8 @@ def depthnet_forward(features, cas_proj, depth_values, costreg_params, prob_volu
             proj = compose_cas_proj(cas_proj.cpu() if proj_where == "host" else cas_proj)
             rts = ops.rot_trans_all(proj, proj_where, device=dev)
     with ops.stage(tag + "to_channels_last"):
-        if features_cl:   # [B,H,W,C] already (the HIP FeatureNet's layout)
-            fcl = torch.stack([f for f in features])
+        if features_cl:   # [B,H,W,C] already (the HIP FeatureNet's layout); a [V,B,H,W,C] tensor as is
+            fcl = features if torch.is_tensor(features) else torch.stack([f for f in features])
         else:
             fcl = torch.stack([ops.nchw_to_nhwc(f) for f in features])      # [V,B,H,W,C]
         C = fcl.shape[-1]
