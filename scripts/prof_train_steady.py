@@ -30,7 +30,7 @@ torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CUDA]) as prof:     # kernels only
     step(); torch.cuda.synchronize()
-rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:40]
+rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:70]
 tot = sum(e.device_time_total for e in prof.key_averages())
 print("train_feature_impl", model.train_feature_impl, "total kernel ms", round(tot / 1e3, 2))
 for e in rows:
