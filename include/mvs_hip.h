@@ -171,6 +171,15 @@ int mvs_bn_train_bwd_f32(const float *grad_y, const float *x, const float *weigh
                          float *grad_x, float *grad_weight, float *grad_bias, void *workspace,
                          size_t workspace_bytes, void *stream);
 
+/* Per-pixel depth hypotheses of a cascade stage after the first (CasMVSNet/models/cas_mvsnet.py:129-152
+ * + get_cur_depth_range_samples, module.py:485-502): prev_depth [B,hp,wp] (the previous stage's depth
+ * map) is resized to [H,W] (bilinear, align_corners=False), each pixel gets D samples from
+ * cur - half_range to cur + half_range (half_range = ndepth / 2 * interval), and that volume is resized
+ * to [D,Hs,Ws] (trilinear, align_corners=False) -- evaluated directly at the output resolution.
+ * out [B,D,Hs,Ws]. */
+int mvs_cas_depth_hypotheses_f32(const float *prev_depth, int B, int hp, int wp, int H, int W, int Hs,
+                                 int Ws, int D, float half_range, float *out, void *stream);
+
 /* ---- FeatureNet layers -- mvsnet.py:8-45 ("next" row 1) ---- */
 /* One 2D convolution of FeatureNet on the fp32 matrix cores: k x k (3 stride 1, or 5
  * stride 2), pad k/2, no conv bias, then y = acc*scale[co] + shift[co] (BatchNorm(eval)

@@ -233,15 +233,23 @@ class CascadeMVSNet(nn.Module):
             key = f"stage{s + 1}"
             scale = self.stage_scale[key]
             with ops.stage(key + ".hypotheses"):
+                interval = self.depth_interals_ratio[s] * depth_interval
                 if depth is None:
-                    cur = depth_values
+                    # first stage: planes shared by all pixels.  The reference repeats them to [B,D,H,W]
+                    # and resizes (cas_mvsnet.py:150); a resize of constant planes returns the planes, so
+                    # the [B,D] values go to the kernels as shared depth planes
+                    lo, hi = depth_values[:, 0], depth_values[:, -1]
+                    ramp = torch.arange(self.ndepths[s], device=depth_values.device, dtype=depth_values.dtype)
+                    hyp = lo.unsqueeze(1) + ramp.reshape(1, -1) * ((hi - lo) / (self.ndepths[s] - 1)).unsqueeze(1)
+                elif use_hip:
+                    hyp = ops.cas_depth_hypotheses(depth.detach(), self.ndepths[s], interval, (H, W),
+                                                   (H // scale, W // scale))
                 else:
                     cur = F.interpolate(depth.detach().unsqueeze(1), [H, W], mode="bilinear",
                                         align_corners=False).squeeze(1)
-                hyp = depth_hypotheses(cur, self.ndepths[s], self.depth_interals_ratio[s] * depth_interval,
-                                       (B, H, W))
-                hyp = F.interpolate(hyp.unsqueeze(1), [self.ndepths[s], H // scale, W // scale],
-                                    mode="trilinear", align_corners=False).squeeze(1).contiguous()
+                    hyp = depth_hypotheses(cur, self.ndepths[s], interval, (B, H, W))
+                    hyp = F.interpolate(hyp.unsqueeze(1), [self.ndepths[s], H // scale, W // scale],
+                                        mode="trilinear", align_corners=False).squeeze(1).contiguous()
             stage_feats = pyr[key] if use_hip else [f[key] for f in feats]
             if self.training:
                 raise NotImplementedError("CascadeMVSNet here is the inference path (config 3)")

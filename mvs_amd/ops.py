@@ -552,6 +552,19 @@ def conv3d_wgrad(x_cl, g_cl, stride):
     return gw
 
 
+def cas_depth_hypotheses(prev_depth, ndepth, interval, full_hw, stage_hw):
+    """Hypothesis volume [B,ndepth,Hs,Ws] of a cascade stage after the first from the previous
+    stage's depth map [B,hp,wp] (cas_mvsnet.py:129-152, module.py:485-502) in one kernel."""
+    prev_depth = _f32c(prev_depth)
+    B, hp, wp = prev_depth.shape
+    (H, W), (Hs, Ws) = full_hw, stage_hw
+    out = torch.empty((B, ndepth, Hs, Ws), device=prev_depth.device, dtype=torch.float32)
+    check(_lib.load().mvs_cas_depth_hypotheses_f32(ptr(prev_depth), B, hp, wp, H, W, Hs, Ws, ndepth,
+                                                   float(ndepth / 2 * interval), ptr(out), stream()),
+          "mvs_cas_depth_hypotheses_f32")
+    return out
+
+
 class _BnReluCL(torch.autograd.Function):
     """Training-mode BatchNorm + optional ReLU + optional skip add on channels-last rows
     (mvs_bn_train_fwd_f32 / mvs_bn_train_bwd_f32); running statistics are updated in place."""

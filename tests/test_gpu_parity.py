@@ -981,3 +981,25 @@ def test_variance_8ch_lds_kernel_bit_equal_to_planar(dev, V, per_pixel, c8):
         if c8:   # [B,D,H,1,W,8]
             got = got.squeeze(3)
         assert torch.equal(got.permute(0, 4, 1, 2, 3), want)
+
+
+@pytest.mark.parametrize("case", [((2, 37, 50), (148, 200), 2, 32), ((1, 74, 100), (148, 200), 1, 8),
+                                  ((1, 20, 30), (80, 120), 4, 5)])
+def test_cas_hypotheses_kernel_vs_torch_ops(dev, case):
+    """The fused cascade-hypotheses kernel against the reference's op sequence run with ATen on
+    the CPU (bilinear resize -> per-pixel range -> trilinear resize, cas_mvsnet.py:129-152)."""
+    import torch.nn.functional as F
+    from mvs_amd import ops
+    from mvs_amd.models.cas_mvsnet import depth_hypotheses
+    (B, hp, wp), (H, W), scale, nd = case
+    g = torch.Generator().manual_seed(hp)
+    prev = 500 + 300 * torch.rand(B, hp, wp, generator=g)
+    interval = 2.65 * scale
+    cur = F.interpolate(prev.unsqueeze(1), [H, W], mode="bilinear", align_corners=False).squeeze(1)
+    want = depth_hypotheses(cur, nd, interval, (B, H, W))
+    want = F.interpolate(want.unsqueeze(1), [nd, H // scale, W // scale], mode="trilinear",
+                         align_corners=False).squeeze(1)
+    got = ops.cas_depth_hypotheses(prev.to(dev), nd, interval, (H, W), (H // scale, W // scale)).cpu()
+    assert got.shape == want.shape
+    # a few ulps at ~800 mm: ATen's vectorised CPU kernels may contract a*b + c*d into an FMA
+    np.testing.assert_allclose(got.numpy(), want.numpy(), atol=3e-4, rtol=0)
