@@ -140,12 +140,15 @@ def _gloo_worker(rank, world, port, q):
     torch.manual_seed(100 + rank)            # different init per rank ...
     net = FeatureNet()
     broadcast_parameters(net, 0)             # ... made identical here
+    net.to(memory_format=torch.channels_last)   # strided (NHWC) weight gradients, as in the training path
     torch.manual_seed(0)
     data = torch.rand(4, 3, 16, 16)          # the global batch, same on every rank
     mine = shard_ref_views(4, rank, world)
     net.train()
     loss = net(data[mine]).square().mean()
     loss.backward()
+    if rank == 1:
+        net.feature.bias.grad = None         # a parameter without a gradient counts as zeros
     FlatGradAllReduce(net.parameters())()
     flat = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
     sc = reduce_scalars({"loss": loss.item()})
@@ -189,4 +192,6 @@ def test_flat_gradient_allreduce_gloo_world2():
         net.zero_grad()
         net(data[shard]).square().mean().backward()
         grads.append(torch.cat([p.grad.reshape(-1) for p in net.parameters()]).numpy())
+    nb = net.feature.bias.numel()            # the last parameter: rank 1 contributed zeros for it
+    grads[1][-nb:] = 0
     np.testing.assert_allclose(g0, (grads[0] + grads[1]) / 2, atol=1e-6)
