@@ -684,13 +684,18 @@ __global__ __launch_bounds__(256, 2) void variance_fwd_dma_kernel(
             issue_dma(g + 1);
         }
         float var[GC];
-        bool tiny = false;
+        // any |S|, |Q| outside [1e-30, 3e38] (div_views_tiny) sends the wave to the true division:
+        // one min / max chain over the magnitudes instead of two compares per value (a NaN slips
+        // through fminf / fmaxf, and through either division as NaN)
+        float amin = 3.0e38f, amax = 0.0f;
 #pragma unroll
         for (int c = 0; c < GC; ++c) {
             const float m = div_views_fast(S[c], p.fV, rV);
             var[c] = div_views_fast(Q[c], p.fV, rV) - m * m;
-            tiny = tiny || div_views_tiny(S[c]) || div_views_tiny(Q[c]);
+            amin = fminf(amin, fminf(fabsf(S[c]), fabsf(Q[c])));
+            amax = fmaxf(amax, fmaxf(fabsf(S[c]), fabsf(Q[c])));
         }
+        const bool tiny = !(amin >= 1e-30f && amax <= 3.0e38f);
         if (__any(tiny)) {
 #pragma unroll
             for (int c = 0; c < GC; ++c) {
