@@ -485,8 +485,10 @@ __global__ __launch_bounds__(256, 2) void variance_fwd_dma_kernel(
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int t = min(j * 64 + lane, max(n - 1, 0));
-                const int ly = (int)(((unsigned)t * inv) >> 16), lx = t - ly * bw[v];
-                soff[v][j] = ((by0[v] + ly) * p.W + (bx0[v] + lx)) * GC;
+                // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): t < 256, inv <= 65536,
+                // rows and columns < 2^13 (H * W < 2^26 is checked at launch)
+                const int ly = (int)(__umul24((unsigned)t, inv) >> 16), lx = t - __mul24(ly, bw[v]);
+                soff[v][j] = (__mul24(by0[v] + ly, p.W) + (bx0[v] + lx)) * GC;
             }
         }
     };
@@ -856,8 +858,8 @@ __global__ __launch_bounds__(256, bwd_blocks_per_cu(NV)) void variance_bwd_dma_k
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int t = min(j * 64 + lane, max(n - 1, 0));
-            const int ly = (int)(((unsigned)t * inv) >> 16), lx = t - ly * bw[v];
-            soff[v][j] = ((by0[v] + ly) * p.W + (bx0[v] + lx)) * 16;
+            const int ly = (int)(__umul24((unsigned)t, inv) >> 16), lx = t - __mul24(ly, bw[v]);
+            soff[v][j] = (__mul24(by0[v] + ly, p.W) + (bx0[v] + lx)) * 16;
         }
     }
 
@@ -1311,7 +1313,7 @@ extern "C" int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *s
             set_error("mvs_costvol_variance_fwd_f32: C16 features need C in {16,32,48,64}, got %d", C);
             return MVS_EUNSUPPORTED;
         }
-        if ((int64_t)H * W >= (1 << 26) || B > 65535) return MVS_EINVAL;
+        if ((int64_t)H * W >= (1 << 26) || H >= (1 << 23) || W >= (1 << 23) || B > 65535) return MVS_EINVAL;
         const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (H + kTileH - 1) / kTileH;
         const int dchunks = (D + kTileD - 1) / kTileD;
         const int64_t nblk = (int64_t)tiles_x * tiles_y * dchunks;
@@ -1340,7 +1342,8 @@ extern "C" int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *s
         return check_launch("mvs_costvol_variance_fwd_f32(lds)");
     }
     if (fea_layout != MVS_LAYOUT_NHWC) return MVS_EINVAL;
-    if (C == 8 && (int64_t)H * W < (1 << 26) && B <= 65535 && !getenv("MVS_SWEEP_C8_GATHER")) {
+    if (C == 8 && (int64_t)H * W < (1 << 26) && H < (1 << 23) && W < (1 << 23) && B <= 65535 &&
+        !getenv("MVS_SWEEP_C8_GATHER")) {
         // 8-channel maps (the cascade's finest stage): the LDS-staged kernel with one group of two quads
         const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (H + kTileH - 1) / kTileH;
         const int dchunks = (D + kTileD - 1) / kTileD;
@@ -1422,7 +1425,8 @@ extern "C" int mvs_costvol_variance_bwd_f32(const float *grad_var, const float *
         const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (H + kTileH - 1) / kTileH;
         const int dchunks = (D + kTileD - 1) / kTileD;
         const int64_t nblk = (int64_t)tiles_x * tiles_y * dchunks;
-        if (nblk > 0x7fffffffLL || B > 65535) return MVS_EINVAL;
+        if (nblk > 0x7fffffffLL || B > 65535 || (int64_t)H * W >= (1 << 26) || H >= (1 << 23) || W >= (1 << 23))
+            return MVS_EINVAL;
         const dim3 g((unsigned)nblk, (unsigned)B);
 #define MVS_BWD_CASE(n)                                                                             \
     case n: {                                                                                       \
