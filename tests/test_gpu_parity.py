@@ -1003,3 +1003,15 @@ def test_cas_hypotheses_kernel_vs_torch_ops(dev, case):
     assert got.shape == want.shape
     # a few ulps at ~800 mm: ATen's vectorised CPU kernels may contract a*b + c*d into an FMA
     np.testing.assert_allclose(got.numpy(), want.numpy(), atol=3e-4, rtol=0)
+
+
+def test_training_ops_reject_unsupported_shapes(dev):
+    """The fused BatchNorm op and the weight-gradient kernel fail loudly (no silent torch
+    fallback inside ops) on shapes they have no kernel for."""
+    from mvs_amd import ops
+    bn = torch.nn.BatchNorm3d(12).to(dev).train()
+    with pytest.raises(ops.MvsHipError):
+        ops.bn_relu_cl(torch.randn(2, 3, 4, 5, 12, device=dev), bn)
+    assert ops.conv3d_wgrad(torch.randn(1, 4, 4, 8, 12, device=dev), torch.randn(1, 4, 4, 8, 8, device=dev), 1) is None
+    with pytest.raises(ops.MvsHipError):
+        ops.cas_depth_hypotheses(torch.rand(1, 4, 4, device=dev), 1, 2.0, (8, 8), (8, 8))   # D < 2
