@@ -286,8 +286,8 @@ class MVSNet(nn.Module):
         autograd_path = self.training or (torch.is_grad_enabled() and
                                           any(p.requires_grad for p in self.parameters()))
         if autograd_path:
-            with ops.stage("rot_trans"):
-                rts = ops.rot_trans_all(proj_matrices, self.proj_where)  # [V-1,B,12]
+            # the host hop of rot_trans is stream-ordered and runs under FeatureNet (no device sync)
+            rt_job = ops.HostRotTrans(proj_matrices) if self.proj_where == "host" and proj_matrices.is_cuda else None
             with ops.stage("feature"):
                 # per-view calls: BatchNorm batch statistics are per call in the
                 # reference (mvsnet.py:146)
@@ -302,6 +302,9 @@ class MVSNet(nn.Module):
                     feats = [f.permute(0, 3, 1, 2) for f in feats_cl]
                 else:
                     feats = [self.feature(imgs[:, v]) for v in range(V)]
+            with ops.stage("rot_trans"):
+                rts = rt_job.result() if rt_job is not None else \
+                    ops.rot_trans_all(proj_matrices, self.proj_where)   # [V-1,B,12]
             C = feats[0].shape[1]
             if self.train_impl == "hip" and C % 16 == 0 and depth_values.dim() == 2:
                 # channels-last all the way: 16-channel-blocked maps (torch layout ops, in the
@@ -370,9 +373,14 @@ class MVSNet(nn.Module):
 
 
 def mvsnet_loss(depth_est, depth_gt, mask):
-    """mvsnet.py:201-203: smooth-L1 (beta 1), mean over mask > 0.5."""
+    """mvsnet.py:201-203: smooth-L1 (beta 1), mean over mask > 0.5.  On the GPU the mean is taken
+    as sum / count over the full map: boolean indexing (the reference's `depth_est[mask]`) needs
+    the element count on the host, i.e. a device sync in the middle of every training step."""
     m = mask > 0.5
-    return F.smooth_l1_loss(depth_est[m], depth_gt[m], reduction="mean")
+    if not depth_est.is_cuda:
+        return F.smooth_l1_loss(depth_est[m], depth_gt[m], reduction="mean")
+    per_pixel = F.smooth_l1_loss(depth_est, depth_gt, reduction="none")
+    return torch.where(m, per_pixel, torch.zeros_like(per_pixel)).sum() / m.sum()
 
 
 def load_reference_checkpoint(model, ckpt):
