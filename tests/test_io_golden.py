@@ -9,7 +9,7 @@ import pytest
 from conftest import load_golden
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
-from io_fixture import build_scan  # noqa: E402
+from io_fixture import build_scan, build_train_set  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -100,3 +100,27 @@ def test_eval_tool_writes_reference_output_tree(scan, tmp_path):
             arr, scale = read_pfm(os.path.join(outdir, s["filename"].format(kind, ".pfm")))
             assert scale == 1.0 and arr.shape == (296, 400)
             assert np.array_equal(arr, out[key][0].cpu().numpy())
+
+
+def test_train_samples_match_reference_loader(tmp_path):
+    """Yao's training layout through the mirror of MVSNet/datasets/dtu_yao.py: sample list
+    (scan x reference view x 7 lights), projection matrices, depth hypotheses, ground-truth
+    depth, mask and images -- bit-identical to what the reference's loader returned."""
+    from mvs_amd.datasets import find_dataset_def
+    root = str(tmp_path)
+    listfile = build_train_set(root)
+    g = load_golden("g10_io")
+    ds = find_dataset_def("dtu_yao")(root, listfile, "train", 3, 192, 1.06)
+    assert len(ds) == int(g["t_n_samples"]) == 21
+    assert [[m[1], m[2]] + list(m[3]) for m in ds.metas] == g["t_metas"].tolist()
+    for i in (0, 9, len(ds) - 1):
+        s = ds[i]
+        assert set(s) == {"imgs", "proj_matrices", "depth", "depth_values", "mask"}
+        assert np.array_equal(s["proj_matrices"], g[f"t{i}_proj"])
+        assert np.array_equal(s["depth_values"], g[f"t{i}_depth_values"]) and s["depth_values"].dtype == np.float32
+        assert np.array_equal(s["depth"], g[f"t{i}_depth"]) and s["depth"].dtype == np.float32
+        assert np.array_equal(s["mask"], g[f"t{i}_mask"])
+        assert list(s["imgs"].shape) == g[f"t{i}_imgs_shape"].tolist()
+        assert np.array_equal(s["imgs"][:, :, ::37, ::41], g[f"t{i}_imgs_probe"])
+    # the loss keeps mask > 0.5 (train.py:224 / mvsnet.py:201-203): the fixture has both kinds of pixels
+    assert 0 < float((ds[0]["mask"] > 0.5).mean()) < 1
