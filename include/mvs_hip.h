@@ -180,6 +180,21 @@ int mvs_bn_train_bwd_f32(const float *grad_y, const float *x, const float *weigh
 int mvs_cas_depth_hypotheses_f32(const float *prev_depth, int B, int hp, int wp, int H, int W, int Hs,
                                  int Ws, int D, float half_range, float *out, void *stream);
 
+/* Geometric-consistency check of the depth filter that follows the path (SURVEY.md 8f rank 2;
+ * MVSNet/eval.py:136-214 reproject_with_depth + check_geometric_consistency, sums of eval.py:239-262):
+ * for one reference depth map [H,W] and S source depth maps [S,H,W] (all at the same resolution),
+ * per source view: project the reference pixels with their depth into the source view, sample the
+ * source depth there (cv2.remap INTER_LINEAR semantics), project back, and accept where the pixel
+ * moved < 1 px and the depth changed < 1 %.
+ * mats: [18 + 50 S] floats = inverse(K_ref), K_ref, then per view K_src, inverse(K_src),
+ * E_src @ inverse(E_ref) (4x4), E_ref @ inverse(E_src) (4x4), row-major, computed by the caller as the
+ * reference does (float32 numpy).  Outputs: mask [S,H,W] u8, depth_reprojected [S,H,W] (0 outside the
+ * mask), xy_src [S,2,H,W] (all three optional: NULL), geo_mask_sum [H,W] int32, depth_averaged [H,W]
+ * float64 = (sum of reprojected depths + reference depth) / (geo_mask_sum + 1). */
+int mvs_geo_consistency_f32(const float *depth_ref, const float *depth_src, const float *mats, int S, int H,
+                            int W, unsigned char *mask, float *depth_reprojected, float *xy_src,
+                            int *geo_mask_sum, double *depth_averaged, void *stream);
+
 /* ---- FeatureNet layers -- mvsnet.py:8-45 ("next" row 1) ---- */
 /* One 2D convolution of FeatureNet on the fp32 matrix cores: k x k (3 stride 1, or 5
  * stride 2), pad k/2, no conv bias, then y = acc*scale[co] + shift[co] (BatchNorm(eval)

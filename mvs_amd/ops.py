@@ -552,6 +552,46 @@ def conv3d_wgrad(x_cl, g_cl, stride):
     return gw
 
 
+def geo_consistency_matrices(K_ref, E_ref, src_Ks, src_Es):
+    """The fp32 matrices of mvs_geo_consistency_f32, composed on the host with the numpy calls
+    the reference makes per pair (eval.py:155-178): inverse(K_ref), K_ref, then per source view
+    K_src, inverse(K_src), E_src @ inverse(E_ref), E_ref @ inverse(E_src)."""
+    import numpy as np
+    K_ref, E_ref = np.asarray(K_ref, dtype=np.float32), np.asarray(E_ref, dtype=np.float32)
+    parts = [np.linalg.inv(K_ref).ravel(), K_ref.ravel()]
+    for K, E in zip(src_Ks, src_Es):
+        K, E = np.asarray(K, dtype=np.float32), np.asarray(E, dtype=np.float32)
+        parts += [K.ravel(), np.linalg.inv(K).ravel(), np.matmul(E, np.linalg.inv(E_ref)).ravel(),
+                  np.matmul(E_ref, np.linalg.inv(E)).ravel()]
+    return np.concatenate(parts).astype(np.float32)
+
+
+def geo_consistency(depth_ref, K_ref, E_ref, src_depths, src_Ks, src_Es, per_view=True):
+    """Geometric-consistency check of one reference depth map [H,W] against S source depth maps
+    [S,H,W] (device tensors; cameras as numpy) -- check_geometric_consistency for every source view
+    and the sums of filter_depth (eval.py:190-262) in one kernel.  Returns a dict: geo_mask_sum
+    [H,W] int32, depth_averaged [H,W] float64 and, with per_view, mask [S,H,W] bool,
+    depth_reprojected [S,H,W], x_src / y_src [S,H,W]."""
+    depth_ref, src_depths = _f32c(depth_ref), _f32c(src_depths)
+    S, H, W = src_depths.shape
+    if tuple(depth_ref.shape) != (H, W) or len(src_Ks) != S or len(src_Es) != S:
+        raise MvsHipError("geo_consistency: depth_ref [H,W], src_depths [S,H,W], S cameras")
+    dev = depth_ref.device
+    mats = torch.from_numpy(geo_consistency_matrices(K_ref, E_ref, src_Ks, src_Es)).to(dev)
+    geo_sum = torch.empty((H, W), device=dev, dtype=torch.int32)
+    avg = torch.empty((H, W), device=dev, dtype=torch.float64)
+    mask = torch.empty((S, H, W), device=dev, dtype=torch.uint8) if per_view else None
+    drep = torch.empty((S, H, W), device=dev, dtype=torch.float32) if per_view else None
+    xy = torch.empty((S, 2, H, W), device=dev, dtype=torch.float32) if per_view else None
+    vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    check(_lib.load().mvs_geo_consistency_f32(ptr(depth_ref), ptr(src_depths), ptr(mats), S, H, W, vp(mask), ptr(drep),
+                                              ptr(xy), vp(geo_sum), vp(avg), stream()), "mvs_geo_consistency_f32")
+    out = {"geo_mask_sum": geo_sum, "depth_averaged": avg}
+    if per_view:
+        out.update(mask=mask.bool(), depth_reprojected=drep, x_src=xy[:, 0], y_src=xy[:, 1])
+    return out
+
+
 def cas_depth_hypotheses(prev_depth, ndepth, interval, full_hw, stage_hw):
     """Hypothesis volume [B,ndepth,Hs,Ws] of a cascade stage after the first from the previous
     stage's depth map [B,hp,wp] (cas_mvsnet.py:129-152, module.py:485-502) in one kernel."""

@@ -209,3 +209,34 @@ def cvp_random_state_dict(seed=0, peaked=60.0):
             elif k.endswith("prob0.weight"):
                 v.mul_(peaked)
     return {k: v.clone() for k, v in sd.items()}
+
+
+def plane_depth_from_cameras(Ks, Es, h, w, normal=(0.05, -0.08, 1.0), offset=DTU_TARGET_Z):
+    """Depth maps [V,h,w] float32 of the world plane normal . X = offset for arbitrary pinhole cameras
+    (K [3,3] at this resolution, E [4,4] world->camera)."""
+    n = np.asarray(normal, dtype=np.float64)
+    ys, xs = np.mgrid[0:h, 0:w]
+    pix = np.stack([xs.ravel(), ys.ravel(), np.ones(xs.size)])
+    out = []
+    for K, E in zip(Ks, Es):
+        K, E = np.asarray(K, dtype=np.float64), np.asarray(E, dtype=np.float64)
+        rays = np.linalg.inv(K) @ pix
+        R, t = E[:3, :3], E[:3, 3]
+        out.append(((offset + n @ R.T @ t) / (n @ R.T @ rays)).reshape(h, w))
+    return np.stack(out).astype(np.float32)
+
+
+def plane_depth_maps(nviews, feat_h, feat_w, normal=(0.05, -0.08, 1.0), offset=DTU_TARGET_Z):
+    """Exact per-view depth maps [V,h,w] (float32) of the world plane normal . X = offset seen from the
+    arc cameras of proj_matrices() -- geometrically consistent across views by construction
+    (inputs for the depth-map filter that follows the path).  Also returns K [3,3], E [V,4,4] float32."""
+    K = feature_intrinsics(feat_h, feat_w)
+    E = arc_extrinsics(nviews)
+    n = np.asarray(normal, dtype=np.float64)
+    ys, xs = np.mgrid[0:feat_h, 0:feat_w]
+    rays = np.linalg.inv(K) @ np.stack([xs.ravel(), ys.ravel(), np.ones(xs.size)])     # camera-frame rays, z = 1
+    out = []
+    for v in range(nviews):
+        R, t = E[v, :3, :3], E[v, :3, 3]
+        out.append(((offset + n @ R.T @ t) / (n @ R.T @ rays)).reshape(feat_h, feat_w))
+    return np.stack(out).astype(np.float32), K.astype(np.float32), E.astype(np.float32)

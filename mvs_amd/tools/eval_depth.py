@@ -6,7 +6,7 @@
 
 reads each scan's pair.txt / cams / images, runs MVSNet (refine=False) on cuda:0 and writes
 {outdir}/{scan}/depth_est/{ref:08d}.pfm and .../confidence/{ref:08d}.pfm.  The filter /
-fusion stage after it (eval.py:136-342) is a "next" row and not part of this.
+fusion stage after it (eval.py:136-342) is `python -m mvs_amd.tools.fuse_depth`.
 """
 import argparse
 import os

@@ -1015,3 +1015,36 @@ def test_training_ops_reject_unsupported_shapes(dev):
     assert ops.conv3d_wgrad(torch.randn(1, 4, 4, 8, 12, device=dev), torch.randn(1, 4, 4, 8, 8, device=dev), 1) is None
     with pytest.raises(ops.MvsHipError):
         ops.cas_depth_hypotheses(torch.rand(1, 4, 4, device=dev), 1, 2.0, (8, 8), (8, 8))   # D < 2
+
+
+def test_geo_consistency_kernel_vs_numpy_restatement(dev):
+    """The depth-filter kernel (one thread per reference pixel, all source views) against the numpy
+    restatement of eval.py:136-262 on depth maps of a plane seen from 5 arc cameras, with a band of
+    outliers, a hole (depth 0) and pixels that leave the source images: masks, reprojected depths,
+    source coordinates, consistent-view counts and the averaged depth."""
+    from mvs_amd import ops, synth
+    from oracle import geo_filter as gf
+    H, W, V = 74, 100, 5
+    depths, K, E = synth.plane_depth_maps(V, H, W)
+    depths[0, 20:30, 40:60] *= 1.05        # inconsistent band in the reference view
+    depths[2, 10:25, 10:30] *= 0.9         # ... and in one source view
+    depths[0, 50:55, 5:15] = 0.0           # hole: 0 / 0 -> NaN -> rejected
+    want_sum, want_avg, want_mask, want_dep = gf.fuse_reference_view(depths[0], K, E[0], depths[1:], [K] * 4, E[1:])
+    got = ops.geo_consistency(G(depths[0], dev), K, E[0], G(depths[1:], dev), [K] * 4, E[1:])
+    mask = got["mask"].cpu().numpy()
+    # fp64 sums of 3-4 products may be fused differently by BLAS: allow a handful of threshold flips
+    flips = int((mask != want_mask).sum())
+    assert flips <= 4, flips
+    same = mask == want_mask
+    np.testing.assert_allclose(got["depth_reprojected"].cpu().numpy()[same], want_dep[same], rtol=1e-6, atol=1e-4)
+    stable = same.all(axis=0)
+    assert np.array_equal(got["geo_mask_sum"].cpu().numpy()[stable], want_sum[stable])
+    with np.errstate(invalid="ignore"):
+        np.testing.assert_allclose(got["depth_averaged"].cpu().numpy()[stable], want_avg[stable], rtol=1e-6, atol=1e-4)
+    for s in range(4):
+        _, _, xs, ys = gf.check_geometric_consistency(depths[0], K, E[0], depths[1 + s], K, E[1 + s])
+        fin = np.isfinite(xs)
+        np.testing.assert_allclose(got["x_src"][s].cpu().numpy()[fin], xs[fin], rtol=1e-6, atol=1e-4)
+        np.testing.assert_allclose(got["y_src"][s].cpu().numpy()[fin], ys[fin], rtol=1e-6, atol=1e-4)
+    # the construction itself: a consistent plane passes in every view it is visible in, the band does not
+    assert want_sum[35:45, 30:70].min() >= 3 and want_sum[22:28, 45:55].max() == 0 and want_sum[52, 8] == 0
