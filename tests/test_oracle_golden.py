@@ -190,3 +190,27 @@ def test_torch_ref_cvp_matches_reference():
     for i, d in enumerate(out["depth_est_list"]):
         assert np.abs(d.numpy() - g[f"depth_level{i}"]).max() < 1e-3, i
     np.testing.assert_allclose(out["prob_confidence"].numpy(), g["prob_confidence"], atol=1e-4)
+
+
+def test_geo_filter_restatement_known_answers():
+    """oracle/geo_filter.py: the cv2.remap restatement on known answers (integer coordinates return
+    the pixel, halves average, 1/32-pixel rounding, constant border 0, NaN -> 0) and the consistency
+    check on exact depth maps of a plane (every visible pixel passes; a 5 % error fails)."""
+    from mvs_amd import synth
+    from oracle import geo_filter as gf
+    img = np.arange(20, dtype=np.float32).reshape(4, 5) ** 2
+    xs, ys = np.meshgrid(np.arange(5, dtype=np.float32), np.arange(4, dtype=np.float32))
+    assert np.array_equal(gf.remap_linear(img, xs, ys), img)
+    half = gf.remap_linear(img, xs[:, :-1] + 0.5, ys[:, :-1])
+    assert np.array_equal(half, (img[:, :-1] + img[:, 1:]) * np.float32(0.5))
+    q = gf.remap_linear(img, np.float32([[1.01, 1.02]]), np.float32([[2.0, 2.0]]))     # 1.01 -> 32/32.., 1.02 -> 33/32
+    assert q[0, 0] == img[2, 1] and q[0, 1] == img[2, 1] * np.float32(31 / 32) + img[2, 2] * np.float32(1 / 32)
+    edge = gf.remap_linear(img, np.float32([[-0.5, 4.5, np.nan, 100.0]]), np.float32([[0.0, 3.0, 1.0, 1.0]]))
+    assert edge[0, 0] == img[0, 0] * np.float32(0.5) and edge[0, 1] == img[3, 4] * np.float32(0.5)
+    assert edge[0, 2] == 0 and edge[0, 3] == 0
+    depths, K, E = synth.plane_depth_maps(3, 40, 56)
+    mask, dep, x_src, y_src = gf.check_geometric_consistency(depths[0], K, E[0], depths[1], K, E[1])
+    inside = (x_src > 1) & (x_src < 54) & (y_src > 1) & (y_src < 38)
+    assert mask[inside].all() and np.abs(dep[mask] - depths[0][mask]).max() < 0.05
+    bad = depths[0] * np.float32(1.05)
+    assert not gf.check_geometric_consistency(bad, K, E[0], depths[1], K, E[1])[0].any()
