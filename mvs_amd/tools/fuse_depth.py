@@ -110,14 +110,18 @@ def main(argv=None):
     ap.add_argument("--testpath", required=True)
     ap.add_argument("--testlist", required=True)
     ap.add_argument("--outdir", default="./outputs")
-    ap.add_argument("--min_views", type=int, default=3, help="consistent source views required (the reference hard-codes 3)")
+    ap.add_argument("--min_views", type=int, default=3,
+                    help="consistent source views required (3 hard-coded in eval.py:260; CasMVSNet/test.py --num_consistent)")
+    ap.add_argument("--conf", type=float, default=0.8,
+                    help="photometric confidence threshold (0.8 hard-coded in eval.py:237; CasMVSNet/test.py --conf)")
     args = ap.parse_args(argv)
     with open(args.testlist) as f:
         scans = [ln.rstrip() for ln in f.readlines()]
     for scan in scans:
         scan_id = int(scan[4:])
         filter_depth(os.path.join(args.testpath, scan), os.path.join(args.outdir, scan),
-                     os.path.join(args.outdir, "mvsnet{:0>3}_l3.ply".format(scan_id)), min_views=args.min_views)
+                     os.path.join(args.outdir, "mvsnet{:0>3}_l3.ply".format(scan_id)), conf_thresh=args.conf,
+                     min_views=args.min_views)
 
 
 if __name__ == "__main__":
