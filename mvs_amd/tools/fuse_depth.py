@@ -111,7 +111,7 @@ def main(argv=None):
     ap.add_argument("--testlist", required=True)
     ap.add_argument("--outdir", default="./outputs")
     ap.add_argument("--min_views", type=int, default=3,
-                    help="consistent source views required (3 hard-coded in eval.py:260; CasMVSNet/test.py --num_consistent)")
+                    help="consistent source views required (3 hard-coded in eval.py:260; CasMVSNet/test.py --thres_view)")
     ap.add_argument("--conf", type=float, default=0.8,
                     help="photometric confidence threshold (0.8 hard-coded in eval.py:237; CasMVSNet/test.py --conf)")
     args = ap.parse_args(argv)
