@@ -180,6 +180,14 @@ int mvs_bn_train_bwd_f32(const float *grad_y, const float *x, const float *weigh
 int mvs_cas_depth_hypotheses_f32(const float *prev_depth, int B, int hp, int wp, int H, int W, int Hs,
                                  int Ws, int D, float half_range, float *out, void *stream);
 
+/* Sum over the image of |depth step| that moves a reference pixel's projection into the first source
+ * view by `pixel_interval` along its epipolar line (CVP-MVSNet/models/modules.py:147-219, calDepthHypo
+ * in test mode; the level's hypothesis interval is this sum / (H W)).  depth [H,W] float32;
+ * mats: 59 doubles on the device = inverse(K_ref) (9), inverse(E_ref) (16), K_src (9), E_src (16),
+ * K_ref R_ref inverse(K_src R_src) (9), row-major; sum_abs: one double on the device (set here). */
+int mvs_cvp_interval_sum_f64(const float *depth, const double *mats, int H, int W, double pixel_interval,
+                             double *sum_abs, void *stream);
+
 /* Geometric-consistency check of the depth filter that follows the path (SURVEY.md 8f rank 2;
  * MVSNet/eval.py:136-214 reproject_with_depth + check_geometric_consistency, sums of eval.py:239-262):
  * for one reference depth map [H,W] and S source depth maps [S,H,W] (all at the same resolution),

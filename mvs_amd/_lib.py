@@ -46,6 +46,7 @@ _SIGS = {
     "mvs_bn_train_bwd_f32": (_c_i, [_c_f] * 6 + [_c_l, _c_i, _c_i] + [_c_f] * 4 + [ctypes.c_size_t, _c_f]),
     "mvs_cas_depth_hypotheses_f32": (_c_i, [_c_f] + [_c_i] * 8 + [ctypes.c_float, _c_f, _c_f]),
     "mvs_geo_consistency_f32": (_c_i, [_c_f] * 3 + [_c_i] * 3 + [_c_f] * 6),
+    "mvs_cvp_interval_sum_f64": (_c_i, [_c_f, _c_f, _c_i, _c_i, ctypes.c_double, _c_f, _c_f]),
     "mvs_conv2d_f32": (_c_i, [_c_f] * 5 + [_c_i] * 9 + [_c_f, _c_f]),
     "mvs_conv2d_packed_weight_floats": (_c_l, [_c_i] * 4),
     "mvs_conv2d_pack_weights_f32": (_c_i, [_c_f] + [_c_i] * 4 + [_c_f, _c_f]),

@@ -199,6 +199,30 @@ def _full_proj(K, E):
     return P
 
 
+def refine_hypotheses_hip(depth_up, K_ref, K_src0, E_ref, E_src0, d=4, pixel_interval=1.0):
+    """refine_hypotheses with the per-pixel fp64 arithmetic and the mean in one kernel
+    (mvs_cvp_interval_sum_f64); the 3x3 / 4x4 matrix algebra stays fp64 torch ops on the device."""
+    import ctypes
+    from .._lib import check, load, stream
+    B, H, W = depth_up.shape
+    dev = depth_up.device
+    depth_up = depth_up.float().contiguous()
+    ks = torch.arange(-d, d, device=dev, dtype=torch.float32).view(1, -1, 1, 1)
+    intervals = []
+    for b in range(B):
+        Kr, Ks, Er, Es = (t[b].double() for t in (K_ref, K_src0, E_ref, E_src0))
+        A = torch.matmul(torch.matmul(Kr, Er[:3, :3]), torch.inverse(torch.matmul(Ks, Es[:3, :3])))
+        mats = torch.cat((torch.inverse(Kr).reshape(-1), torch.inverse(Er).reshape(-1), Ks.reshape(-1),
+                          Es.reshape(-1), A.reshape(-1))).contiguous()
+        total = torch.empty((1,), device=dev, dtype=torch.float64)
+        vp = lambda t: ctypes.c_void_p(t.data_ptr())
+        check(load().mvs_cvp_interval_sum_f64(vp(depth_up[b]), vp(mats), H, W, float(pixel_interval), vp(total),
+                                              stream()), "mvs_cvp_interval_sum_f64")
+        intervals.append((total / (H * W)).float())
+    interval = torch.stack(intervals).view(B, 1, 1, 1)
+    return depth_up.unsqueeze(1) + ks * interval
+
+
 def refine_hypotheses(depth_up, K_ref, K_src0, E_ref, E_src0, d=4, pixel_interval=1.0):
     """[B,H,W] upsampled depth -> [B,2d,H,W] hypotheses depth_up + k * interval, k = -d..d-1,
     where `interval` is the mean over the pixels of the depth step that moves the projection
@@ -295,7 +319,8 @@ class CVPMVSNet(nn.Module):
         depths.append(depth)
         for level in range(nscale - 2, -1, -1):
             up = F.interpolate(depth[None], scale_factor=2, mode="bicubic", align_corners=None).squeeze(0)
-            hypos = refine_hypotheses(up, K_ref[:, level], K_src[:, 0, level], ref_ex, src_ex[:, 0]).contiguous()
+            refine = refine_hypotheses_hip if use_hip else refine_hypotheses
+            hypos = refine(up, K_ref[:, level], K_src[:, 0, level], ref_ex, src_ex[:, 0]).contiguous()
             cost = self._level(level_feats(level), K_ref[:, level], K_src[:, :, level], ref_ex, src_ex, hypos)
             depth, conf, _ = ops.softmax_regress_conf(cost, hypos)
             depths.append(depth)

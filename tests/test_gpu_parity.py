@@ -1048,3 +1048,21 @@ def test_geo_consistency_kernel_vs_numpy_restatement(dev):
         np.testing.assert_allclose(got["y_src"][s].cpu().numpy()[fin], ys[fin], rtol=1e-6, atol=1e-4)
     # the construction itself: a consistent plane passes in every view it is visible in, the band does not
     assert want_sum[35:45, 30:70].min() >= 3 and want_sum[22:28, 45:55].max() == 0 and want_sum[52, 8] == 0
+
+
+def test_cvp_interval_kernel_vs_torch_mirror(dev):
+    """CVP refinement hypotheses: the fused fp64 interval kernel against the torch mirror of
+    calDepthHypo (modules.py:147-219) on the same inputs."""
+    from mvs_amd import synth
+    from mvs_amd.models.cvp_mvsnet import refine_hypotheses, refine_hypotheses_hip
+    H, W = 66, 120
+    cams = {k: torch.from_numpy(v).to(dev) for k, v in synth.cvp_cameras(2, H, W, batch=2).items()}
+    g = torch.Generator(device=dev).manual_seed(4)
+    depth = 500 + 300 * torch.rand(2, H, W, device=dev, generator=g)
+    args = (depth, cams["ref_in"], cams["src_in"][:, 0], cams["ref_ex"], cams["src_ex"][:, 0])
+    want = refine_hypotheses(*args)
+    got = refine_hypotheses_hip(*args)
+    assert got.shape == want.shape == (2, 8, H, W)
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=0, atol=2e-4)
+    step = (got[:, 1] - got[:, 0]).mean().item()
+    assert 1.0 < step < 50.0     # a millimetre-scale interval for DTU-like cameras
