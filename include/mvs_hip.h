@@ -31,6 +31,12 @@
  *                        fea_layout of the LDS-staged variance kernel (a source
  *                        footprint row is one contiguous run); build it with
  *                        mvs_nchw_to_nhwc_f32(in, out, B*C/16, 16, H*W).
+ *   MVS_LAYOUT_C4   (4): [B,C/4,H,W,4]    4-channel blocked FEATURE maps, the layout the
+ *                        persistent variance kernel copies fastest (a footprint row of one
+ *                        channel quad is one contiguous run, so an LDS-DMA instruction touches
+ *                        a quarter of the cache lines it touches with C16); only for
+ *                        mvs_costvol_variance_fwd_ws_f32 where
+ *                        mvs_costvol_variance_workspace_bytes(..., MVS_LAYOUT_C4) > 0.
  * depth_mode
  *   0: depth_values [B,D]        (MVSNet, module.py:74)
  *   1: depth_values [B,D,H,W]    (CasMVSNet/models/module.py:249,267;
@@ -56,6 +62,7 @@ extern "C" {
 #define MVS_LAYOUT_NHWC 1
 #define MVS_LAYOUT_C8 2
 #define MVS_LAYOUT_C16 3
+#define MVS_LAYOUT_C4 4
 
 /* Library version: major*10000 + minor*100 + patch. */
 int mvs_version(void);
@@ -95,6 +102,26 @@ int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *src_feas,
                                  int depth_mode, int B, int V, int C, int D, int H, int W,
                                  int align_corners, int alias_quirk, int fea_layout,
                                  int out_layout, float *out_var, void *stream);
+/* The same operation with a caller workspace: for shared depth planes (depth_mode 0) and C16
+ * features this runs the persistent kernel -- one workgroup per CU walks (16x4 pixels x 16 depth
+ * planes) tiles, the source footprints of the next tile land in LDS by DMA while the current one
+ * is sampled -- and the workspace holds the queue of its cold path (waves whose footprint does
+ * not fit LDS are served by a second, gather-based kernel).  Every other shape takes the kernels
+ * of mvs_costvol_variance_fwd_f32 and ignores the workspace (which may then be NULL / 0 bytes:
+ * mvs_costvol_variance_workspace_bytes returns 0).  Results are bit-identical to
+ * mvs_costvol_variance_fwd_f32 unless flags has MVS_SWEEP_FAST: coordinates from one refined
+ * reciprocal per voxel and view with the reference's normalise / un-normalise pair
+ * (module.py:78-79 + grid_sample) folded into one FMA, Q += w*w as an FMA, multiplication by
+ * 1/V -- sampling positions within ~1e-4 texel of the reference's. */
+#define MVS_SWEEP_FAST 1
+size_t mvs_costvol_variance_workspace_bytes(int depth_mode, int B, int V, int C, int D, int H, int W,
+                                            int fea_layout);
+int mvs_costvol_variance_fwd_ws_f32(const float *ref_fea, const float *src_feas,
+                                    const float *rot_trans, const float *depth_values,
+                                    int depth_mode, int B, int V, int C, int D, int H, int W,
+                                    int align_corners, int alias_quirk, int fea_layout,
+                                    int out_layout, int flags, float *out_var, void *workspace,
+                                    size_t workspace_bytes, void *stream);
 /* Self-test: the variance kernel divides by the view count V with a 3-op
  * multiply/FMA sequence instead of an IEEE division; this checks it against
  * x / V for EVERY float bit pattern on the device and writes the number of

@@ -17,6 +17,7 @@ MVS_LAYOUT_NCHW = 0
 MVS_LAYOUT_NHWC = 1
 MVS_LAYOUT_C8 = 2
 MVS_LAYOUT_C16 = 3
+MVS_LAYOUT_C4 = 4
 
 _c_f = ctypes.c_void_p   # device pointers travel as integers
 _c_i = ctypes.c_int
@@ -31,6 +32,8 @@ _SIGS = {
     "mvs_warp_fwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i] + [_c_i] * 6 + [_c_f, _c_f]),
     "mvs_warp_bwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i] + [_c_i] * 6 + [_c_f, _c_f]),
     "mvs_costvol_variance_fwd_f32": (_c_i, [_c_f] * 4 + [_c_i] * 11 + [_c_f, _c_f]),
+    "mvs_costvol_variance_workspace_bytes": (ctypes.c_size_t, [_c_i] * 8),
+    "mvs_costvol_variance_fwd_ws_f32": (_c_i, [_c_f] * 4 + [_c_i] * 12 + [_c_f, _c_f, ctypes.c_size_t, _c_f]),
     "mvs_selftest_div_by_views_f32": (_c_i, [_c_i, _c_f, _c_f]),
     "mvs_costvol_variance_bwd_f32": (_c_i, [_c_f] * 5 + [_c_i] * 10 + [_c_f, _c_f, _c_f]),
     "mvs_conv3d_f32": (_c_i, [_c_f] * 6 + [_c_i] * 11 + [_c_f, _c_f]),

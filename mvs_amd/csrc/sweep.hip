@@ -8,38 +8,12 @@
 //
 // Compiled with -ffp-contract=off: the coordinate arithmetic mirrors the
 // reference op for op (see mvs_common.h) and is bit-exact with it.
-#include "mvs_common.h"
+#include "sweep_common.h"
 
 #include <cstdlib>
+#include <cstring>
 
 namespace mvs {
-
-constexpr int kMaxSrcViews = 8;
-
-__device__ __forceinline__ float4 sel4(bool keep, float4 v) {
-    return make_float4(keep ? v.x : 0.f, keep ? v.y : 0.f, keep ? v.z : 0.f, keep ? v.w : 0.f);
-}
-// value at idx if idx >= 0 else 0, without a branch around the load
-__device__ __forceinline__ float ldz(const float *__restrict__ p, int idx) {
-    float v = p[max(idx, 0)];
-    return idx >= 0 ? v : 0.0f;
-}
-
-struct SweepParams {
-    int B, C, D, H, W, V;     // V = total views (ref + sources)
-    int depth_mode;           // 0: [B,D]   1: [B,D,H,W]
-    int align_corners;
-    int alias_quirk;
-    float half_w, half_h;     // (W-1)/2, (H-1)/2
-    float unn_w, unn_h;       // un-normalisation scale
-    float fV;
-};
-
-__device__ __forceinline__ float depth_at(const float *__restrict__ depth, const SweepParams &p,
-                                          int b, int d, int64_t pix) {
-    return p.depth_mode == 0 ? depth[(int64_t)b * p.D + d]
-                             : depth[((int64_t)b * p.D + d) * ((int64_t)p.H * p.W) + pix];
-}
 
 // ---------------------------------------------------------------------
 // K1: warp, planar.  One thread per (b, d, y, x); loops over channels.
@@ -205,24 +179,6 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv &f) {
     return (t + ((n - t) >> f.s1)) >> f.s2;
 }
 
-// x / V, correctly rounded, for the small integer V = number of views:
-// q = RN(x*(1/V)); r = x - q*V exactly (one FMA); q' = RN(q + r*(1/V)).
-// Equal to IEEE x / V for every finite x outside the subnormal-result range
-// (checked exhaustively on the GPU: mvs_selftest_div_by_views_f32); tiny |x| take
-// the true division so the result is the reference's in every case.
-__device__ __forceinline__ float div_views_fast(float x, float fV, float rV) {
-    const float q = x * rV;
-    const float r = __fmaf_rn(-q, fV, x);
-    return __fmaf_rn(r, rV, q);
-}
-// tiny (subnormal-range quotient) or non-finite (inf*rV would poison the FMA)
-__device__ __forceinline__ bool div_views_tiny(float x) {
-    const float ax = fabsf(x);
-    return !(ax >= 1e-30f && ax <= 3.0e38f);
-}
-__device__ __forceinline__ float div_views(float x, float fV, float rV) {
-    return div_views_tiny(x) ? x / fV : div_views_fast(x, fV, rV);
-}
 
 template <int CQ, int NV>
 __global__ __launch_bounds__(256) void variance_fwd_cl_kernel(
@@ -350,34 +306,6 @@ __global__ __launch_bounds__(256) void variance_fwd_cl_kernel(
 // in memory.  Arithmetic is identical to the other kernels (pre-masked weights, FMA
 // order): results are bit-identical to them.
 constexpr int kTileW = 8, kTileH = 8, kTileD = 4;   // square tile: compact footprints under rotation
-
-// 16 channels of one view: bilinear blend of the four taps, then S += w, Q += w*w
-// (mvsnet.py:164-165).  Four channels at a time so at most 4 float4 loads are live.
-template <int NQ = 4>
-__device__ __forceinline__ void accumulate_taps(const float *__restrict__ t00,
-                                                const float *__restrict__ t01,
-                                                const float *__restrict__ t10,
-                                                const float *__restrict__ t11, float wnw, float wne,
-                                                float wsw, float wse, float (&S)[4 * NQ],
-                                                float (&Q)[4 * NQ]) {
-#pragma unroll
-    for (int k = 0; k < NQ; ++k) {
-        const float4 a = reinterpret_cast<const float4 *>(t00)[k];
-        const float4 bq = reinterpret_cast<const float4 *>(t01)[k];
-        const float4 c = reinterpret_cast<const float4 *>(t10)[k];
-        const float4 e = reinterpret_cast<const float4 *>(t11)[k];
-        const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {bq.x, bq.y, bq.z, bq.w};
-        const float cv[4] = {c.x, c.y, c.z, c.w}, ev[4] = {e.x, e.y, e.z, e.w};
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-            const float w = __fmaf_rn(ev[cc], wse, __fmaf_rn(cv[cc], wsw,
-                                      __fmaf_rn(bv[cc], wne, av[cc] * wnw)));
-            S[k * 4 + cc] = S[k * 4 + cc] + w;
-            Q[k * 4 + cc] = Q[k * 4 + cc] + w * w;
-        }
-        if (k == 1) __builtin_amdgcn_sched_barrier(0);   // 8 tap loads in flight, not 16
-    }
-}
 
 // CORNER (shared depth planes only): the footprint box of a source view is taken from
 // the projections of the block's 8 corner voxels instead of a reduction over all 256
@@ -1172,28 +1100,6 @@ __global__ __launch_bounds__(256) void variance_bwd_planar_kernel(
 }
 
 // ---------------------------------------------------------------------
-static SweepParams make_params(int B, int V, int C, int D, int H, int W, int depth_mode,
-                               int align_corners, int alias_quirk) {
-    SweepParams p;
-    p.B = B; p.C = C; p.D = D; p.H = H; p.W = W; p.V = V;
-    p.depth_mode = depth_mode;
-    p.align_corners = align_corners;
-    p.alias_quirk = alias_quirk;
-    p.half_w = (float)((W - 1) / 2.0);
-    p.half_h = (float)((H - 1) / 2.0);
-    p.unn_w = align_corners ? (float)((W - 1) / 2.0) : (float)(W / 2.0);
-    p.unn_h = align_corners ? (float)((H - 1) / 2.0) : (float)(H / 2.0);
-    p.fV = (float)V;
-    return p;
-}
-
-static bool grid_for(int64_t total, int per_block, unsigned &grid) {
-    int64_t g = (total + per_block - 1) / per_block;
-    if (g <= 0 || g > 0x7fffffffLL) return false;
-    grid = (unsigned)g;
-    return true;
-}
-
 template <int CQ>
 static int launch_variance_cl(int NV, const float *ref, const float *srcs, const float *rt,
                               const float *depth, const SweepParams &p, float *out, int out_c8,
@@ -1382,6 +1288,66 @@ extern "C" int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *s
     }
     if (rc != MVS_OK) return rc;
     return check_launch("mvs_costvol_variance_fwd_f32(channels-last)");
+}
+
+// Shape of the persistent kernel's workgroup: waves (= depth planes per tile) and channel quads
+// per stage.  tuning: MVS_SWEEP_PERSIST = "<waves>[,<flags>[,<quads>]]", 0 = always the per-tile kernels
+static int persist_waves(int *flags, int *quads) {
+    const char *pe = getenv("MVS_SWEEP_PERSIST");
+    int nw = 16;
+    *flags = 0;
+    *quads = 2;
+    if (pe) {
+        nw = atoi(pe);
+        const char *c = strchr(pe, ',');
+        if (c) {
+            *flags = atoi(c + 1);
+            c = strchr(c + 1, ',');
+            if (c) *quads = atoi(c + 1);
+        }
+    }
+    return nw;
+}
+
+extern "C" size_t mvs_costvol_variance_workspace_bytes(int depth_mode, int B, int V, int C, int D,
+                                                       int H, int W, int fea_layout) {
+    if ((fea_layout != MVS_LAYOUT_C16 && fea_layout != MVS_LAYOUT_C4) || B <= 0 || D <= 0 || H <= 1 || W <= 1) return 0;
+    int flags, quads;
+    const int nw = persist_waves(&flags, &quads);
+    if (nw <= 0) return 0;
+    return variance_persist_workspace_bytes(make_params(B, V, C, D, H, W, depth_mode, 0, 0), nw);
+}
+
+extern "C" int mvs_costvol_variance_fwd_ws_f32(const float *ref_fea, const float *src_feas,
+                                               const float *rot_trans, const float *depth_values,
+                                               int depth_mode, int B, int V, int C, int D, int H,
+                                               int W, int align_corners, int alias_quirk,
+                                               int fea_layout, int out_layout, int flags,
+                                               float *out_var, void *workspace,
+                                               size_t workspace_bytes, void *stream) {
+    const bool c4 = fea_layout == MVS_LAYOUT_C4;
+    if (ref_fea && src_feas && rot_trans && depth_values && out_var && B > 0 && D > 0 && H > 1 &&
+        W > 1 && depth_mode == 0 && (fea_layout == MVS_LAYOUT_C16 || c4) &&
+        (out_layout == MVS_LAYOUT_C8 || out_layout == MVS_LAYOUT_NHWC)) {
+        int tune, quads;
+        const int nw = persist_waves(&tune, &quads);
+        if (nw > 0) {
+            const SweepParams p = make_params(B, V, C, D, H, W, depth_mode, align_corners, alias_quirk);
+            const int rc = launch_variance_persist(ref_fea, src_feas, rot_trans, depth_values, p, out_var,
+                                                   out_layout == MVS_LAYOUT_C8, c4, flags & MVS_SWEEP_FAST,
+                                                   nw, quads, tune, workspace, workspace_bytes, as_stream(stream));
+            if (rc == MVS_OK) return check_launch("mvs_costvol_variance_fwd_ws_f32(persistent)");
+            if (rc != MVS_EUNSUPPORTED) return rc;
+        }
+    }
+    if (c4) {
+        set_error("mvs_costvol_variance_fwd_ws_f32: C4 features are the persistent kernel's layout "
+                  "(shared depth planes, mvs_costvol_variance_workspace_bytes > 0); use C16 for this shape");
+        return MVS_EUNSUPPORTED;
+    }
+    return mvs_costvol_variance_fwd_f32(ref_fea, src_feas, rot_trans, depth_values, depth_mode, B, V, C,
+                                        D, H, W, align_corners, alias_quirk, fea_layout, out_layout,
+                                        out_var, stream);
 }
 
 extern "C" int mvs_selftest_div_by_views_f32(int V, unsigned long long *mismatch_count,

@@ -1,0 +1,114 @@
+// Pieces shared by the plane-sweep translation units (sweep.hip, sweep_persist.hip).
+#pragma once
+#include "mvs_common.h"
+
+namespace mvs {
+
+constexpr int kMaxSrcViews = 8;
+
+__device__ __forceinline__ float4 sel4(bool keep, float4 v) {
+    return make_float4(keep ? v.x : 0.f, keep ? v.y : 0.f, keep ? v.z : 0.f, keep ? v.w : 0.f);
+}
+// value at idx if idx >= 0 else 0, without a branch around the load
+__device__ __forceinline__ float ldz(const float *__restrict__ p, int idx) {
+    float v = p[max(idx, 0)];
+    return idx >= 0 ? v : 0.0f;
+}
+
+struct SweepParams {
+    int B, C, D, H, W, V;     // V = total views (ref + sources)
+    int depth_mode;           // 0: [B,D]   1: [B,D,H,W]
+    int align_corners;
+    int alias_quirk;
+    float half_w, half_h;     // (W-1)/2, (H-1)/2
+    float unn_w, unn_h;       // un-normalisation scale
+    float fV;
+};
+
+__device__ __forceinline__ float depth_at(const float *__restrict__ depth, const SweepParams &p,
+                                          int b, int d, int64_t pix) {
+    return p.depth_mode == 0 ? depth[(int64_t)b * p.D + d]
+                             : depth[((int64_t)b * p.D + d) * ((int64_t)p.H * p.W) + pix];
+}
+
+
+// x / V, correctly rounded, for the small integer V = number of views:
+// q = RN(x*(1/V)); r = x - q*V exactly (one FMA); q' = RN(q + r*(1/V)).
+// Equal to IEEE x / V for every finite x outside the subnormal-result range
+// (checked exhaustively on the GPU: mvs_selftest_div_by_views_f32); tiny |x| take
+// the true division so the result is the reference's in every case.
+__device__ __forceinline__ float div_views_fast(float x, float fV, float rV) {
+    const float q = x * rV;
+    const float r = __fmaf_rn(-q, fV, x);
+    return __fmaf_rn(r, rV, q);
+}
+// tiny (subnormal-range quotient) or non-finite (inf*rV would poison the FMA)
+__device__ __forceinline__ bool div_views_tiny(float x) {
+    const float ax = fabsf(x);
+    return !(ax >= 1e-30f && ax <= 3.0e38f);
+}
+__device__ __forceinline__ float div_views(float x, float fV, float rV) {
+    return div_views_tiny(x) ? x / fV : div_views_fast(x, fV, rV);
+}
+
+// 16 channels of one view: bilinear blend of the four taps, then S += w, Q += w*w
+// (mvsnet.py:164-165).  Four channels at a time so at most 4 float4 loads are live.
+template <int NQ = 4>
+__device__ __forceinline__ void accumulate_taps(const float *__restrict__ t00,
+                                                const float *__restrict__ t01,
+                                                const float *__restrict__ t10,
+                                                const float *__restrict__ t11, float wnw, float wne,
+                                                float wsw, float wse, float (&S)[4 * NQ],
+                                                float (&Q)[4 * NQ]) {
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        const float4 a = reinterpret_cast<const float4 *>(t00)[k];
+        const float4 bq = reinterpret_cast<const float4 *>(t01)[k];
+        const float4 c = reinterpret_cast<const float4 *>(t10)[k];
+        const float4 e = reinterpret_cast<const float4 *>(t11)[k];
+        const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {bq.x, bq.y, bq.z, bq.w};
+        const float cv[4] = {c.x, c.y, c.z, c.w}, ev[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const float w = __fmaf_rn(ev[cc], wse, __fmaf_rn(cv[cc], wsw,
+                                      __fmaf_rn(bv[cc], wne, av[cc] * wnw)));
+            S[k * 4 + cc] = S[k * 4 + cc] + w;
+            Q[k * 4 + cc] = Q[k * 4 + cc] + w * w;
+        }
+        if (k == 1) __builtin_amdgcn_sched_barrier(0);   // 8 tap loads in flight, not 16
+    }
+}
+
+inline SweepParams make_params(int B, int V, int C, int D, int H, int W, int depth_mode,
+                               int align_corners, int alias_quirk) {
+    SweepParams p;
+    p.B = B; p.C = C; p.D = D; p.H = H; p.W = W; p.V = V;
+    p.depth_mode = depth_mode;
+    p.align_corners = align_corners;
+    p.alias_quirk = alias_quirk;
+    p.half_w = (float)((W - 1) / 2.0);
+    p.half_h = (float)((H - 1) / 2.0);
+    p.unn_w = align_corners ? (float)((W - 1) / 2.0) : (float)(W / 2.0);
+    p.unn_h = align_corners ? (float)((H - 1) / 2.0) : (float)(H / 2.0);
+    p.fV = (float)V;
+    return p;
+}
+
+inline bool grid_for(int64_t total, int per_block, unsigned &grid) {
+    int64_t g = (total + per_block - 1) / per_block;
+    if (g <= 0 || g > 0x7fffffffLL) return false;
+    grid = (unsigned)g;
+    return true;
+}
+
+
+// sweep_persist.hip: the persistent kernel for shared depth planes and 16-channel-blocked
+// features (+ its cold-path kernel); MVS_EUNSUPPORTED (nothing launched) when the shape is not
+// its own.  The workspace holds the cold path's queue.
+size_t variance_persist_workspace_bytes(const SweepParams &p, int nw);
+int launch_variance_persist(const float *ref16, const float *srcs16, const float *rt,
+                            const float *depth, const SweepParams &p, float *out, int out_c8,
+                            int fea_c4, int fast, int nw, int nq, int flags, void *workspace,
+                            size_t workspace_bytes, hipStream_t st);
+
+}  // namespace mvs

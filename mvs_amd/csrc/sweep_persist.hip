@@ -1,0 +1,659 @@
+// Fused plane-sweep warp + variance for shared depth planes as ONE persistent workgroup
+// per CU (MVSNet/models/module.py:46-87 + mvsnet.py:152-170; the kernel north_star names).
+//
+// The per-tile kernel of sweep.hip (8x8 pixels x 4 planes per 256-thread block) spends two
+// thirds of its life waiting: every block computes its footprint boxes, plans and issues its
+// copies and then sits on their latency, and it copies 2-3 bytes of footprint per byte it
+// stores.  Here a workgroup of 16 waves walks a contiguous list of tiles (16x4 pixels x 16
+// depth planes, wave = plane, depth chunk fastest: a CU climbs the depth column of one pixel
+// tile, its footprints slide by a fraction of a texel per step and come out of L2):
+//
+//   stage s = (tile, 8-channel group), LDS buffer s & 1:
+//     [last stage of a tile: plan the next tile -- footprint boxes from its 8 corner voxels,
+//      per-lane source offsets]
+//     s_waitcnt vmcnt(<stores of the previous stage>); s_barrier
+//                                  <- stage s has landed; buffer (s+1)&1 is free
+//     issue the LDS-DMA of stage s+1 into buffer (s+1)&1   (lands during this stage)
+//     blend the four taps of every source view out of buffer s&1, form variances, store
+//
+// One barrier per stage; inside the loop only the copies and the stores touch vector memory
+// (the reference view's pixels ride along as one more DMA piece; camera rows and depth planes
+// sit in LDS), so a counted vmcnt waits for the copies without waiting for the HBM write
+// latency of the stores issued behind them.  Eight channels per stage (not 16) because a
+// 16-plane tile's bounding boxes (~300 texels per view under a diagonal baseline) must fit
+// twice: 2 buffers x 4 views x 512 texels x 32 B = 128 KiB.  A lane's four taps are
+// ds_read_b128 at box offsets {0, 1, bw, bw + 1} texels: the box is NOT clamped to the image
+// (the copy clamps the SOURCE address instead; out-of-image taps carry weight 0), and the lanes
+// of one ds_read_b128 service group (MI355X: {0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) own
+// 16 pixels of one row, so a group's texels are consecutive and cover all 64 banks.  With
+// 4-channel-blocked features (MVS_LAYOUT_C4) a footprint row of one channel quad is contiguous
+// in memory and a DMA instruction touches ~19 cache lines instead of 64.
+//
+// EXACT = the reference's coordinate arithmetic op for op (mvs_common.h) and its
+// E[x^2] - E[x]^2 with IEEE divisions: bit-identical to the other variance kernels.
+// FAST  = one reciprocal (+1 Newton step) shared by X/Z and Y/Z, normalise/un-normalise
+// folded into one FMA, Q accumulated with an FMA, multiplication by 1/V.
+//
+// Measured at BASELINE configs[1] (22.7 M voxels x 32 channels x 4 source views): 1.46-1.56 ms
+// EXACT, 1.21-1.25 ms FAST against 1.85 ms for the per-tile kernel.  SQ counters (profiles/):
+// 1614 VALU instructions per wave-tile-plane FAST (2216 EXACT; per-tile kernel 2103), LDS
+// array busy 46 % of the kernel, 17 % of its cycles conflicted (per-tile kernel: 54 %).
+#include "sweep_common.h"
+
+#include <cstdlib>
+#include <type_traits>
+
+namespace mvs {
+
+constexpr int kPW = 16, kPH = 4;   // pixels of a tile; a wave owns one depth plane of it
+
+// texels per source view and buffer: two buffers of (nv views x nq channel quads x cap x 16 B +
+// nq KiB of reference pixels) inside ~140 KiB (the camera matrices and depth planes take up to
+// 12 KiB more), whole 64-lane DMA instructions
+__host__ __device__ constexpr int persist_cap(int nv, int nq) {
+    const int raw = (140 * 1024 - 2 * nq * 1024) / (nv * nq * 32);
+    const int top = 1024 / nq;
+    return raw >= top ? top : (raw / 64) * 64;
+}
+constexpr int kPMaxCamFloats = 512, kPMaxDepthFloats = 1024;   // LDS copies of rot_trans / depth_values
+
+struct PersistArgs {
+    const float *ref16, *srcs16, *rt, *depth;
+    float *out;
+    unsigned *queue;        // workspace: [0] = records, [1..] = (tile << 4 | wave) for the cold kernel
+    SweepParams p;
+    int tiles_x, tiles_y, nchunks, total_tiles;
+    int out_c8, flags;
+    int fea_c4;             // features [B,C/4,H,W,4] (1) or [B,C/16,H,W,16] (0)
+    float sx, ox, sy, oy;   // FAST: ix = (X/Z) * sx + ox
+};
+constexpr int kPFlagLinearLanes = 1;   // tuning: lane = (x = lane & 15, y = lane >> 4)
+constexpr int kPFlagNoStore = 2;       // tuning
+constexpr int kPFlagNoBlend = 4;       // tuning
+constexpr int kPFlagNoDma = 8;         // tuning (results are garbage)
+constexpr int kPFlagNoPlan = 16;       // tuning: every tile reuses the first tile's plan (garbage)
+constexpr int kPFlagNoTaps = 32;       // tuning: constant tap set (garbage)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ f32x4 lds_rd16(unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536 && OFF % 16 == 0, "ds_read_b128 offset field");
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+// wait until at most N LDS operations are outstanding (follow with an empty asm "+v" on the
+// registers the landed reads wrote, so their consumers stay behind the wait)
+template <int N>
+__device__ __forceinline__ void lds_wait_n() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// Homography + bilinear tap set of one voxel in one source view.  EXACT (FAST = false) is the
+// reference's arithmetic op for op (mvs_common.h); both kernels below call this one function, so
+// a voxel gets the same taps whichever of them serves it.  Tap weights come pre-masked: 0 for a
+// tap outside the image, NaN for a non-finite coordinate (the reference's 0 * NaN); tx0, ty0 =
+// floor of the sampling coordinate clamped to [-4, size + 4]; has = some tap lies in the image.
+template <bool FAST>
+__device__ __forceinline__ void tap_setup(const float *__restrict__ r, int cx, int cy, float dv,
+                                          const SweepParams &p, float sx, float ox, float sy,
+                                          float oy, float &wnw, float &wne, float &wsw, float &wse,
+                                          int &tx0, int &ty0, bool &has) {
+    float ix, iy, nw, ne, sw, se;
+    bool x0ok, x1ok, y0ok, y1ok, fin;
+    if constexpr (FAST) {
+        const float fx = (float)cx, fy = (float)cy;
+        const float rx = __fmaf_rn(r[0], fx, __fmaf_rn(r[1], fy, r[2]));
+        const float ry = __fmaf_rn(r[4], fx, __fmaf_rn(r[5], fy, r[6]));
+        const float rz = __fmaf_rn(r[8], fx, __fmaf_rn(r[9], fy, r[10]));
+        const float X = __fmaf_rn(rx, dv, r[3]), Y = __fmaf_rn(ry, dv, r[7]);
+        const float Z = __fmaf_rn(rz, dv, r[11]);
+        float inv = __builtin_amdgcn_rcpf(Z);
+        inv = __fmaf_rn(__fmaf_rn(-Z, inv, 1.0f), inv, inv);
+        ix = __fmaf_rn(X * inv, sx, ox);
+        iy = __fmaf_rn(Y * inv, sy, oy);
+        fin = (fabsf(ix) <= 3.0e38f) && (fabsf(iy) <= 3.0e38f);
+        const float x0f = floorf(ix), y0f = floorf(iy);
+        const float wx = ix - x0f, wy = iy - y0f, ex = 1.0f - wx, ey = 1.0f - wy;
+        nw = ey * ex; ne = ey * wx; sw = wy * ex; se = wy * wx;
+        tx0 = fin ? (int)fminf(fmaxf(x0f, -4.0f), (float)p.W + 4.0f) : -4;
+        ty0 = fin ? (int)fminf(fmaxf(y0f, -4.0f), (float)p.H + 4.0f) : -4;
+        x0ok = (unsigned)tx0 < (unsigned)p.W; x1ok = (unsigned)(tx0 + 1) < (unsigned)p.W;
+        y0ok = (unsigned)ty0 < (unsigned)p.H; y1ok = (unsigned)(ty0 + 1) < (unsigned)p.H;
+    } else {
+        float rx, ry, rz;
+        sweep_ray(r, (float)cx, (float)cy, rx, ry, rz);
+        sweep_coord(r, rx, ry, rz, dv, p.half_w, p.half_h, p.unn_w, p.unn_h, p.align_corners, ix, iy);
+        const Taps t = make_taps(ix, iy, p.H, p.W);
+        fin = (fabsf(ix) <= 3.0e38f) && (fabsf(iy) <= 3.0e38f);
+        nw = t.nw; ne = t.ne; sw = t.sw; se = t.se;
+        x0ok = t.x0ok; x1ok = t.x1ok; y0ok = t.y0ok; y1ok = t.y1ok;
+        const float x0f = fminf(fmaxf(floorf(ix), -4.0f), (float)p.W + 4.0f);
+        const float y0f = fminf(fmaxf(floorf(iy), -4.0f), (float)p.H + 4.0f);
+        tx0 = fin ? (int)x0f : -4;
+        ty0 = fin ? (int)y0f : -4;
+    }
+    const float dead = fin ? 0.0f : __int_as_float(0x7fc00000);
+    wnw = (x0ok && y0ok) ? nw : dead; wne = (x1ok && y0ok) ? ne : dead;
+    wsw = (x0ok && y1ok) ? sw : dead; wse = (x1ok && y1ok) ? se : dead;
+    has = (x0ok || x1ok) && (y0ok || y1ok);
+}
+
+// Cold path of the persistent kernel.  A wave of it that cannot serve its voxels from LDS -- a
+// footprint too large for its LDS share, a corner voxel behind the camera, a tap outside the
+// box; never seen with DTU-like rigs -- appends (tile, wave) to a queue in the caller's
+// workspace and moves on; this kernel, launched right behind it, drains the queue with global
+// gathers (one wave per record, one channel quad at a time; same tap_setup, same blend and
+// accumulation order, IEEE divisions in EXACT mode).  An empty queue costs one launch.
+template <int NV, bool FAST>
+__global__ __launch_bounds__(256) void variance_fwd_cold_kernel(PersistArgs a, int nw) {
+    const SweepParams &p = a.p;
+    const unsigned count = a.queue[0];
+    const int lane = threadIdx.x & 63;
+    const int plane = p.H * p.W, ngroups = p.C >> 4;
+    const size_t grp_floats = (size_t)plane * 16, map_floats = (size_t)plane * p.C;
+    const unsigned tex = a.fea_c4 ? 4u : 16u;   // floats between neighbouring texels of one quad
+    const float rV = 1.0f / p.fV;
+    for (unsigned rec = blockIdx.x * 4 + (threadIdx.x >> 6); rec < count; rec += gridDim.x * 4) {
+        const unsigned q = a.queue[1 + rec];
+        int t = (int)(q >> 4);
+        const int wv = (int)(q & 15u);
+        const int dc = t % a.nchunks; t /= a.nchunks;
+        const int tx = t % a.tiles_x; t /= a.tiles_x;
+        const int ty = t % a.tiles_y, b = t / a.tiles_y;
+        const int px = tx * kPW + (lane & 15), py = ty * kPH + (lane >> 4), d = dc * nw + wv;
+        if (d >= p.D) continue;
+        const bool live = px < p.W && py < p.H;
+        const int cx = min(px, p.W - 1), cy = min(py, p.H - 1);
+        const int pix = cy * p.W + cx;
+        const float dv = a.depth[(int64_t)b * p.D + d];
+        float wnw[NV], wne[NV], wsw[NV], wse[NV];
+        unsigned o00[NV], o01[NV], o10[NV], o11[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            int tx0, ty0;
+            bool has;
+            tap_setup<FAST>(a.rt + ((int64_t)v * p.B + b) * 12, cx, cy, dv, p, a.sx, a.ox, a.sy, a.oy,
+                            wnw[v], wne[v], wsw[v], wse[v], tx0, ty0, has);
+            const int x0c = min(max(tx0, 0), p.W - 1), x1c = min(max(tx0 + 1, 0), p.W - 1);
+            const int y0c = min(max(ty0, 0), p.H - 1), y1c = min(max(ty0 + 1, 0), p.H - 1);
+            o00[v] = (unsigned)(y0c * p.W + x0c) * tex; o01[v] = (unsigned)(y0c * p.W + x1c) * tex;
+            o10[v] = (unsigned)(y1c * p.W + x0c) * tex; o11[v] = (unsigned)(y1c * p.W + x1c) * tex;
+        }
+        float *pl = a.out + ((size_t)b * p.D + d) * ((size_t)plane * p.C);
+#pragma unroll 1
+        for (int gk = 0; gk < ngroups * 4; ++gk) {
+            const int g = gk >> 2, k = gk & 3;
+            // quad gk of a feature map: C4 = plane gk of [C/4,H,W,4]; C16 = quad k of block g of [C/16,H,W,16]
+            const size_t qbase = a.fea_c4 ? (size_t)gk * plane * 4 : (size_t)g * grp_floats + k * 4;
+            const float4 r4 = *reinterpret_cast<const float4 *>(
+                a.ref16 + (size_t)b * map_floats + qbase + (size_t)pix * tex);
+            float S[4] = {r4.x, r4.y, r4.z, r4.w}, Q[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                Q[c] = S[c] * S[c];
+                if (p.alias_quirk) S[c] = Q[c];
+            }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const float *base = a.srcs16 + ((size_t)v * p.B + b) * map_floats + qbase;
+                const float4 qa = *reinterpret_cast<const float4 *>(base + o00[v]);
+                const float4 qb = *reinterpret_cast<const float4 *>(base + o01[v]);
+                const float4 qc = *reinterpret_cast<const float4 *>(base + o10[v]);
+                const float4 qe = *reinterpret_cast<const float4 *>(base + o11[v]);
+                const float av[4] = {qa.x, qa.y, qa.z, qa.w}, bv[4] = {qb.x, qb.y, qb.z, qb.w};
+                const float cv[4] = {qc.x, qc.y, qc.z, qc.w}, ev[4] = {qe.x, qe.y, qe.z, qe.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float w = __fmaf_rn(ev[c], wse[v], __fmaf_rn(cv[c], wsw[v],
+                                              __fmaf_rn(bv[c], wne[v], av[c] * wnw[v])));
+                    S[c] = S[c] + w;
+                    if constexpr (FAST) Q[c] = __fmaf_rn(w, w, Q[c]);
+                    else Q[c] = Q[c] + w * w;
+                }
+            }
+            float var[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if constexpr (FAST) {
+                    const float m = S[c] * rV;
+                    var[c] = __fmaf_rn(Q[c], rV, -(m * m));
+                } else {
+                    const float m = S[c] / p.fV;
+                    var[c] = Q[c] / p.fV - m * m;
+                }
+            }
+            if (live && !(a.flags & kPFlagNoStore)) {
+                float *o = a.out_c8
+                    ? pl + ((unsigned)(py * (p.C >> 3) + (g * 2 + (k >> 1))) * (unsigned)p.W + (unsigned)px) * 8u + (k & 1) * 4
+                    : pl + (unsigned)pix * (unsigned)p.C + (unsigned)(g * 16 + k * 4);
+                *reinterpret_cast<float4 *>(o) = make_float4(var[0], var[1], var[2], var[3]);
+            }
+        }
+    }
+}
+
+template <int NV, int NW, int NQ, bool FAST>
+__global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistArgs a) {
+    constexpr int cap = persist_cap(NV, NQ);
+    constexpr int NJ = cap / 64;                 // DMA instructions per (view, quad) plane
+    constexpr int WQ = NW / NQ;                  // waves sharing a channel quad
+    constexpr int NP = (NJ + WQ - 1) / WQ;       // pieces of a plane one wave may copy
+    constexpr int GC = 4 * NQ;                   // channels per stage
+    constexpr int NST = NQ;                      // 16-byte stores per lane and stage
+    constexpr unsigned kViewBytes = (unsigned)NQ * cap * 16u;
+    constexpr unsigned kRefOff = NV * kViewBytes;
+    constexpr unsigned kBufBytes = kRefOff + NQ * 1024u;
+    static_assert(NW % NQ == 0 && NV <= 8 && (NQ == 2 || NQ == 4), "8 corner lanes per view");
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * kBufBytes];
+    __shared__ float s_cam[kPMaxCamFloats];      // rot_trans [NV][B][12]
+    __shared__ float s_depth[kPMaxDepthFloats];  // depth_values [B][D]
+
+    const SweepParams &p = a.p;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kq = wv % NQ, mj = wv / NQ;
+    const unsigned lds_base = (unsigned)(uintptr_t)lds_raw;
+    const int plane = p.H * p.W;
+    const int nstage = p.C / GC;                 // stages per tile
+    const unsigned tstride = a.fea_c4 ? 16u : 64u;   // bytes between neighbouring texels of one quad
+
+    int lx, ly;   // this lane's pixel inside the 16x4 tile
+    if (a.flags & kPFlagLinearLanes) {
+        lx = lane & 15; ly = lane >> 4;
+    } else {
+        const unsigned l5 = lane & 31, g0 = 0x0FF0F00Fu, below = (1u << l5) - 1u;
+        const bool in0 = (g0 >> l5) & 1u;
+        lx = __popc((in0 ? g0 : ~g0) & below);
+        ly = (lane >> 5) * 2 + (in0 ? 0 : 1);
+    }
+
+    // this CU's tiles: XCD x owns a contiguous range of the list, its CUs contiguous parts of it
+    int t_begin, t_end;
+    {
+        const int nblk = gridDim.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + ((int)blockIdx.x >> 3);
+        t_begin = (int)((int64_t)a.total_tiles * L / nblk);
+        t_end = (int)((int64_t)a.total_tiles * (L + 1) / nblk);
+    }
+    if (t_begin >= t_end) return;
+
+    // camera rows and depth planes into LDS: inside the loop nothing but the copies and the
+    // stores touches vector memory, so a counted vmcnt can tell them apart
+    for (int i = tid; i < NV * p.B * 12; i += NW * 64) s_cam[i] = a.rt[i];
+    for (int i = tid; i < p.B * p.D; i += NW * 64) s_depth[i] = a.depth[i];
+    __syncthreads();
+
+    // ---- the planned tile: the one whose copies are issued next
+    int pdc, ptx, pty, pb;
+    {
+        int qq = t_begin;
+        pdc = qq % a.nchunks; qq /= a.nchunks;
+        ptx = qq % a.tiles_x; qq /= a.tiles_x;
+        pty = qq % a.tiles_y; pb = qq / a.tiles_y;
+    }
+    int pbx0[NV], pby0[NV], pbw[NV], pbh[NV];
+    unsigned pstaged = 0;
+    unsigned soff[NV][NP];
+    unsigned roff = 0;
+
+    auto plan = [&]() {
+        const int v0 = min(lane >> 3, NV - 1), k = lane & 7;
+        const int xlo = ptx * kPW, xhi = min(xlo + kPW - 1, p.W - 1);
+        const int ylo = pty * kPH, yhi = min(ylo + kPH - 1, p.H - 1);
+        const int dlo = pdc * NW, dhi = min(dlo + NW - 1, p.D - 1);
+        const float *r = s_cam + (v0 * p.B + pb) * 12;
+        const float cxk = (float)((k & 1) ? xhi : xlo), cyk = (float)((k & 2) ? yhi : ylo);
+        const float dk = s_depth[pb * p.D + ((k & 4) ? dhi : dlo)];
+        // Per depth plane pixel -> source is a homography, so (all Z > 0) the tile's image is
+        // the convex hull of its corner images; along depth each coordinate is a Moebius
+        // function of d, monotone between the extreme planes.  Approximate arithmetic is
+        // enough: the box is padded by a texel and every wave checks its own taps against it.
+        const float rx = __fmaf_rn(r[0], cxk, __fmaf_rn(r[1], cyk, r[2]));
+        const float ry = __fmaf_rn(r[4], cxk, __fmaf_rn(r[5], cyk, r[6]));
+        const float rz = __fmaf_rn(r[8], cxk, __fmaf_rn(r[9], cyk, r[10]));
+        const float X = __fmaf_rn(rx, dk, r[3]), Y = __fmaf_rn(ry, dk, r[7]), Z = __fmaf_rn(rz, dk, r[11]);
+        const float inv = __builtin_amdgcn_rcpf(Z);
+        const float ix = __fmaf_rn(X * inv, a.sx, a.ox), iy = __fmaf_rn(Y * inv, a.sy, a.oy);
+        const bool zok = Z > 1e-6f && fabsf(ix) < 1.0e9f && fabsf(iy) < 1.0e9f;
+        const int fxi = zok ? (int)floorf(ix) : 0, fyi = zok ? (int)floorf(iy) : 0;
+        int lo_x = fxi - 1, hi_x = fxi + 2, lo_y = fyi - 1, hi_y = fyi + 2;
+        int bad = zok ? 0 : 1;
+#pragma unroll
+        for (int off = 1; off <= 4; off <<= 1) {
+            lo_x = min(lo_x, __shfl_xor(lo_x, off)); hi_x = max(hi_x, __shfl_xor(hi_x, off));
+            lo_y = min(lo_y, __shfl_xor(lo_y, off)); hi_y = max(hi_y, __shfl_xor(hi_y, off));
+            bad |= __shfl_xor(bad, off);
+        }
+        pstaged = 0;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            // one texel beyond the image on every side stays in the box, so a tap pair that
+            // straddles the border is addressed like any other
+            int x0 = max(__builtin_amdgcn_readlane(lo_x, v * 8), -1);
+            int x1 = min(__builtin_amdgcn_readlane(hi_x, v * 8), p.W);
+            int y0 = max(__builtin_amdgcn_readlane(lo_y, v * 8), -1);
+            int y1 = min(__builtin_amdgcn_readlane(hi_y, v * 8), p.H);
+            const int vbad = __builtin_amdgcn_readlane(bad, v * 8);
+            if (x1 <= x0 || y1 <= y0) { x0 = 0; y0 = 0; x1 = 1; y1 = 1; }   // nothing of this view in sight
+            pbx0[v] = x0; pby0[v] = y0; pbw[v] = x1 - x0 + 1; pbh[v] = y1 - y0 + 1;
+            if (!vbad && pbw[v] * pbh[v] <= cap) pstaged |= 1u << v;
+            const float rb = __builtin_amdgcn_rcpf((float)pbw[v]);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int t = (mj + i * WQ) * 64 + lane;
+                const int tyy = (int)(((float)t + 0.5f) * rb);      // t / bw (t < 2^10: exact)
+                const int txx = t - __mul24(tyy, pbw[v]);
+                const int sxx = min(max(x0 + txx, 0), p.W - 1), syy = min(max(y0 + tyy, 0), p.H - 1);
+                soff[v][i] = (unsigned)(__mul24(syy, p.W) + sxx) * tstride;
+            }
+        }
+        roff = (unsigned)(__mul24(min(pty * kPH + ly, p.H - 1), p.W) + min(ptx * kPW + lx, p.W - 1)) * tstride;
+    };
+
+    // Stage st of the planned tile = channel quads [st * NQ, st * NQ + NQ); this wave copies quad
+    // st * NQ + kq.  ONE buffer descriptor per tensor for the whole kernel; view, batch item and
+    // quad travel in the 32-bit scalar offset of the instruction, so a copy costs a handful of
+    // scalar instructions (the CU has one scalar unit for its 16 waves).
+    const unsigned map_bytes = (unsigned)plane * (unsigned)p.C * 4u;
+    const mvs_srd_t srd_src = make_srd(a.srcs16, map_bytes * (unsigned)(NV * p.B));
+    const mvs_srd_t srd_ref = make_srd(a.ref16, map_bytes * (unsigned)p.B);
+    auto issue_dma = [&](int st, unsigned buf_off) {
+        if (a.flags & kPFlagNoDma) return;
+        const int q = st * NQ + kq;
+        const unsigned qoff = a.fea_c4 ? (unsigned)q * (unsigned)plane * 16u
+                                       : (unsigned)(q >> 2) * (unsigned)plane * 64u + (unsigned)(q & 3) * 16u;
+        const unsigned boff = (unsigned)pb * map_bytes + qoff;
+        const unsigned ldst = lds_base + buf_off + (unsigned)kq * cap * 16u;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if (!((pstaged >> v) & 1u)) continue;
+            const unsigned so = (unsigned)(v * p.B) * map_bytes + boff;
+            const int n = pbw[v] * pbh[v];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int j = mj + i * WQ;
+                if (j >= NJ || j * 64 >= n) continue;    // wave-uniform
+                glds16_buf(soff[v][i], srd_src, so, ldst + (unsigned)((v * NQ * cap + j * 64) * 16));
+            }
+        }
+        if (mj == 0)   // the reference view's 64 pixels, slot = consumer lane
+            glds16_buf(roff, srd_ref, boff, lds_base + buf_off + kRefOff + (unsigned)kq * 1024u);
+    };
+
+    plan();
+    issue_dma(0, 0u);
+    unsigned buf_off = 0;
+    const float rV = 1.0f / p.fV;
+    bool stored = false;   // did this wave issue its NST stores after the last copy it issued?
+
+#pragma unroll 1
+    for (int T = t_begin; T < t_end; ++T) {
+        // ---- adopt the planned tile; per-voxel homography + tap set of every source view
+        const int cb = pb;
+        const int px = ptx * kPW + lx, py = pty * kPH + ly, d = pdc * NW + wv;
+        const bool live = px < p.W && py < p.H && d < p.D;
+        const bool wave_live = d < p.D;
+        const int cx = min(px, p.W - 1), cy = min(py, p.H - 1), cd = min(d, p.D - 1);
+        const int pix = cy * p.W + cx;
+        const unsigned cstaged = pstaged;
+        int cbw16[NV];
+        float wnw[NV], wne[NV], wsw[NV], wse[NV];
+        unsigned aoff[NV];
+        unsigned win = 0;
+        if (a.flags & kPFlagNoTaps) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                wnw[v] = wne[v] = wsw[v] = wse[v] = 0.25f;
+                aoff[v] = (unsigned)v * kViewBytes + (unsigned)lane * 16u;
+                cbw16[v] = pbw[v] * 16;
+            }
+            win = (1u << NV) - 1u;
+        } else {
+            const float dv = s_depth[cb * p.D + cd];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                int tx0, ty0;
+                bool has;
+                tap_setup<FAST>(s_cam + (v * p.B + cb) * 12, cx, cy, dv, p, a.sx, a.ox, a.sy, a.oy,
+                                wnw[v], wne[v], wsw[v], wse[v], tx0, ty0, has);
+                const int bx0 = pbx0[v], by0 = pby0[v], bw = pbw[v], bh = pbh[v];
+                const bool inbox = !has || (tx0 >= bx0 && tx0 + 1 < bx0 + bw && ty0 >= by0 && ty0 + 1 < by0 + bh);
+                if (__all(inbox)) win |= 1u << v;
+                const int ccx = min(max(tx0, bx0), bx0 + bw - 2) - bx0;
+                const int ccy = min(max(ty0, by0), by0 + bh - 2) - by0;
+                aoff[v] = (unsigned)v * kViewBytes + (unsigned)(__mul24(ccy, bw) + ccx) * 16u;
+                cbw16[v] = bw * 16;
+                __builtin_amdgcn_sched_barrier(0);   // one view at a time
+            }
+        }
+        // a wave that cannot serve this tile from LDS hands its plane to the cold kernel
+        const bool hot = (cstaged & win) == (1u << NV) - 1u;
+        if (!hot && wave_live && lane == 0) {
+            const unsigned slot = atomicAdd(a.queue, 1u);
+            a.queue[1 + slot] = ((unsigned)T << 4) | (unsigned)wv;
+            stored = false;   // more vector-memory traffic behind the last copy: wait for all of it
+        }
+        const bool has_next = T + 1 < t_end;
+        const bool any_live = __ballot(live) != 0ull;
+        float *const pl = a.out + ((size_t)cb * p.D + cd) * ((size_t)plane * p.C);   // wave-uniform plane base
+
+#pragma unroll 1
+        for (int st = 0; st < nstage; ++st) {
+            const bool last = st + 1 == nstage;
+            // opaque per iteration: otherwise every tap address of every view is hoisted out of
+            // this loop and held in registers
+#pragma unroll
+            for (int v = 0; v < NV; ++v) asm volatile("" : "+v"(aoff[v]));
+            if (last && has_next) {   // plan the next tile before the barrier: off the critical path
+                if (++pdc == a.nchunks) {
+                    pdc = 0;
+                    if (++ptx == a.tiles_x) {
+                        ptx = 0;
+                        if (++pty == a.tiles_y) { pty = 0; ++pb; }
+                    }
+                }
+                if (!(a.flags & kPFlagNoPlan)) plan();
+            }
+            // This stage's copies have landed (vector memory retires in order: at most the NST
+            // stores issued behind them are still in flight -- waiting for those too would put a
+            // full HBM write latency into every stage), for every wave, and nobody still reads
+            // the other buffer.
+            if (stored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (!last) issue_dma(st + 1, buf_off ^ kBufBytes);
+            else if (has_next) issue_dma(0, buf_off ^ kBufBytes);
+            stored = false;
+
+            if (wave_live && hot && !(a.flags & kPFlagNoBlend)) {
+                // Taps by hand-issued ds_read_b128, one (view, channel quad) batch of four ahead of
+                // the batch being blended: left to the compiler, a branch-free body hoists every
+                // read of a stage above the arithmetic.  Nothing else that counts in lgkmcnt may
+                // sit inside this section.
+                float S[GC], Q[GC];
+                const unsigned la = lds_base + buf_off;
+                constexpr int PD = 3;                     // batches in flight (1 being blended)
+                constexpr int NB = NV * NQ;
+                f32x4 rr[NQ], tb[PD][4];
+                static_for<0, NQ>([&](auto K) {
+                    constexpr int k = K;
+                    rr[k] = lds_rd16<k * 1024>(la + kRefOff + (unsigned)lane * 16u);
+                });
+                auto issue_batch = [&](auto I) {
+                    constexpr int i = I;
+                    constexpr int v = i / NQ, k = i % NQ, sl = i % PD;
+                    const unsigned a0 = la + aoff[v], a1 = a0 + (unsigned)cbw16[v];
+                    tb[sl][0] = lds_rd16<k * cap * 16>(a0);
+                    tb[sl][1] = lds_rd16<k * cap * 16 + 16>(a0);
+                    tb[sl][2] = lds_rd16<k * cap * 16>(a1);
+                    tb[sl][3] = lds_rd16<k * cap * 16 + 16>(a1);
+                };
+                static_for<0, (PD - 1 < NB ? PD - 1 : NB)>(issue_batch);   // prologue: PD-1 batches out
+                {   // the reference pixels are the oldest reads
+                    constexpr int ahead = (PD - 1 < NB ? PD - 1 : NB);
+                    lds_wait_n<4 * ahead>();
+                    static_for<0, NQ>([&](auto K) {
+                        constexpr int k = K;
+                        asm volatile("" : "+v"(rr[k]));
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            Q[k * 4 + c] = rr[k][c] * rr[k][c];
+                            S[k * 4 + c] = rr[k][c];
+                        }
+                    });
+                }
+                static_for<0, NB>([&](auto J) {
+                    constexpr int j = J, v = j / NQ, k = j % NQ, sl = j % PD;
+                    if constexpr (j + PD - 1 < NB) issue_batch(std::integral_constant<int, j + PD - 1>{});
+                    // batches issued after batch j and still allowed in flight
+                    constexpr int newer = (j + PD - 1 < NB ? PD - 1 : NB - 1 - j);
+                    lds_wait_n<4 * newer>();
+                    asm volatile("" : "+v"(tb[sl][0]), "+v"(tb[sl][1]), "+v"(tb[sl][2]), "+v"(tb[sl][3]));
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float w = __fmaf_rn(tb[sl][3][c], wse[v], __fmaf_rn(tb[sl][2][c], wsw[v],
+                                                  __fmaf_rn(tb[sl][1][c], wne[v], tb[sl][0][c] * wnw[v])));
+                        S[k * 4 + c] = S[k * 4 + c] + w;
+                        if constexpr (FAST) Q[k * 4 + c] = __fmaf_rn(w, w, Q[k * 4 + c]);
+                        else Q[k * 4 + c] = Q[k * 4 + c] + w * w;
+                    }
+                    // this batch is blended before the next reads go out (and the arithmetic is
+                    // not sunk into the store's `if`, leaving every tap register live)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(S[k * 4 + c]), "+v"(Q[k * 4 + c]));
+                });
+                float var[GC];
+                if constexpr (FAST) {
+#pragma unroll
+                    for (int c = 0; c < GC; ++c) {
+                        const float m = S[c] * rV;
+                        var[c] = __fmaf_rn(Q[c], rV, -(m * m));
+                    }
+                } else {
+                    // any |S|, |Q| outside [1e-30, 3e38] sends the wave to the true division
+                    float amin = 3.0e38f, amax = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < GC; ++c) {
+                        const float m = div_views_fast(S[c], p.fV, rV);
+                        var[c] = div_views_fast(Q[c], p.fV, rV) - m * m;
+                        amin = fminf(amin, fminf(fabsf(S[c]), fabsf(Q[c])));
+                        amax = fmaxf(amax, fmaxf(fabsf(S[c]), fabsf(Q[c])));
+                    }
+                    const bool tiny = !(amin >= 1e-30f && amax <= 3.0e38f);
+                    if (__any(tiny)) {
+#pragma unroll
+                        for (int c = 0; c < GC; ++c) {
+                            const float m = S[c] / p.fV;
+                            var[c] = Q[c] / p.fV - m * m;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < GC; ++c) asm volatile("" : "+v"(var[c]));   // formed here, not inside the `if`
+                if (any_live && !(a.flags & kPFlagNoStore)) {
+                    // exactly NST store instructions per wave (lanes outside the volume masked off)
+                    float *o = a.out_c8
+                        ? pl + ((unsigned)(cy * (p.C >> 3) + st * (NQ / 2)) * (unsigned)p.W + (unsigned)cx) * 8u   // [B,D,H,C/8,W,8]
+                        : pl + (unsigned)pix * (unsigned)p.C + (unsigned)(st * GC);
+                    const unsigned step = a.out_c8 ? (unsigned)p.W * 8u : 8u;   // floats between 8-channel blocks
+                    if (live) {
+#pragma unroll
+                        for (int h = 0; h < NQ / 2; ++h) {
+                            reinterpret_cast<float4 *>(o + h * step)[0] = make_float4(var[h * 8 + 0], var[h * 8 + 1], var[h * 8 + 2], var[h * 8 + 3]);
+                            reinterpret_cast<float4 *>(o + h * step)[1] = make_float4(var[h * 8 + 4], var[h * 8 + 5], var[h * 8 + 6], var[h * 8 + 7]);
+                        }
+                    }
+                    stored = true;
+                }
+            }
+            buf_off ^= kBufBytes;
+        }
+    }
+}
+
+// Launch table.  MVS_EUNSUPPORTED (nothing launched) when the shape is not this kernel's.
+template <int NW, int NQ, bool FAST>
+static int launch_persist_nv(int NV, const PersistArgs &a, int grid, hipStream_t st) {
+#define MVS_PERSIST_CASE(n)                                                                           \
+    case n:                                                                                           \
+        hipLaunchKernelGGL((variance_fwd_persist_kernel<n, NW, NQ, FAST>), dim3(grid), dim3(NW * 64), \
+                           0, st, a);                                                                 \
+        hipLaunchKernelGGL((variance_fwd_cold_kernel<n, FAST>), dim3(grid), dim3(256), 0, st, a,      \
+                           NW);                                                                       \
+        return MVS_OK;
+    switch (NV) {
+        MVS_PERSIST_CASE(1) MVS_PERSIST_CASE(2) MVS_PERSIST_CASE(3) MVS_PERSIST_CASE(4)
+        MVS_PERSIST_CASE(5) MVS_PERSIST_CASE(6) MVS_PERSIST_CASE(7) MVS_PERSIST_CASE(8)
+    }
+#undef MVS_PERSIST_CASE
+    return MVS_EUNSUPPORTED;
+}
+
+static bool persist_shape_ok(const SweepParams &p) {
+    const int NV = p.V - 1;
+    return p.depth_mode == 0 && !p.alias_quirk && p.C % 16 == 0 && p.C <= 64 && NV >= 1 && NV <= kMaxSrcViews &&
+           (int64_t)p.H * p.W < (1 << 26) && p.H < 32760 && p.W < 32760 &&
+           (int64_t)p.H * p.W * p.C * 4 * NV * p.B < (1ll << 32) && (int64_t)NV * p.B * 12 <= kPMaxCamFloats &&
+           (int64_t)p.B * p.D <= kPMaxDepthFloats;
+}
+
+static int64_t persist_tiles(const SweepParams &p, int nw) {
+    return (int64_t)((p.W + kPW - 1) / kPW) * ((p.H + kPH - 1) / kPH) * ((p.D + nw - 1) / nw) * p.B;
+}
+
+size_t variance_persist_workspace_bytes(const SweepParams &p, int nw) {
+    if (!persist_shape_ok(p)) return 0;
+    const int64_t total = persist_tiles(p, nw);
+    if (total >= (1 << 27)) return 0;
+    return 4 + 4 * (size_t)total * nw;   // counter + one record per (tile, wave)
+}
+
+int launch_variance_persist(const float *ref16, const float *srcs16, const float *rt,
+                            const float *depth, const SweepParams &p, float *out, int out_c8,
+                            int fea_c4, int fast, int nw, int nq, int flags, void *workspace,
+                            size_t workspace_bytes, hipStream_t st) {
+    if ((nw != 8 && nw != 16) || nq != 2) return MVS_EUNSUPPORTED;
+    const size_t need = variance_persist_workspace_bytes(p, nw);
+    if (need == 0) return MVS_EUNSUPPORTED;
+    if (!workspace || workspace_bytes < need) {
+        set_error("mvs_costvol_variance_fwd_ws_f32: workspace of %zu bytes, need %zu", workspace_bytes, need);
+        return MVS_EWORKSPACE;
+    }
+    PersistArgs a;
+    a.ref16 = ref16; a.srcs16 = srcs16; a.rt = rt; a.depth = depth; a.out = out; a.p = p;
+    a.queue = static_cast<unsigned *>(workspace);
+    a.tiles_x = (p.W + kPW - 1) / kPW;
+    a.tiles_y = (p.H + kPH - 1) / kPH;
+    a.nchunks = (p.D + nw - 1) / nw;
+    a.total_tiles = (int)persist_tiles(p, nw);
+    a.out_c8 = out_c8;
+    a.flags = flags;
+    a.fea_c4 = fea_c4;
+    if (p.align_corners) { a.sx = 1.0f; a.ox = 0.0f; a.sy = 1.0f; a.oy = 0.0f; }
+    else {
+        a.sx = (float)((double)p.W / (double)(p.W - 1)); a.ox = -0.5f;
+        a.sy = (float)((double)p.H / (double)(p.H - 1)); a.oy = -0.5f;
+    }
+    if (hipMemsetAsync(workspace, 0, 4, st) != hipSuccess) return check_launch("variance workspace memset");
+    const int grid = device_cu_count();
+    const int NV = p.V - 1;
+#define MVS_PERSIST_PICK(W_, Q_)                                                             \
+    if (nw == W_ && nq == Q_)                                                                \
+        return fast ? launch_persist_nv<W_, Q_, true>(NV, a, grid, st)                       \
+                    : launch_persist_nv<W_, Q_, false>(NV, a, grid, st);
+    MVS_PERSIST_PICK(16, 2) MVS_PERSIST_PICK(8, 2)
+#undef MVS_PERSIST_PICK
+    return MVS_EUNSUPPORTED;
+}
+
+}  // namespace mvs

@@ -83,8 +83,11 @@ def depthnet_forward(features, cas_proj, depth_values, costreg_params, prob_volu
             fcl = torch.stack([ops.nchw_to_nhwc(f) for f in features])      # [V,B,H,W,C]
         C = fcl.shape[-1]
         use_dma = C % 16 == 0    # the LDS/DMA sweep kernel takes 16-channel-blocked maps
-        if use_dma:              # [V,B,H,W,C] -> [V,B,C/16,H,W,16] (a view when C = 16)
-            f16 = fcl.reshape(*fcl.shape[:4], C // 16, 16).permute(0, 1, 4, 2, 3, 5).contiguous()
+        if use_dma:              # [V,B,H,W,C] -> [V,B,C/blk,H,W,blk] (a view when C = blk)
+            # shared depth planes (the first stage): 4-channel blocks for the persistent kernel
+            blk = 4 if ops.variance_persistent_supported(depth_values, fcl.shape[1], fcl.shape[0], C,
+                                                         fcl.shape[2], fcl.shape[3]) else 16
+            f16 = fcl.reshape(*fcl.shape[:4], C // blk, blk).permute(0, 1, 4, 2, 3, 5).contiguous()
     with ops.stage(tag + "costvol_variance"):
         if use_dma:
             var = ops.costvol_variance_c16(f16[0], f16[1:], rts, depth_values, out_c8=True)

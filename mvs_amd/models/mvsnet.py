@@ -267,6 +267,9 @@ class MVSNet(nn.Module):
         self.align_corners = align_corners
         self.proj_where = proj_where
         self.variance_impl = "lds"      # "lds" (LDS-staged source tiles) | "gather"
+        # False: the reference's coordinate arithmetic op for op (variance bit-identical to its CPU
+        # forward); True: MVS_SWEEP_FAST (sampling positions within ~1e-4 texel), 0.25 ms less per view
+        self.variance_fast = False
         self.feature_impl = "hip"       # "hip" (2D MFMA kernels) | "torch" (PyTorch-ROCm / MIOpen)
         self.train_impl = "hip"         # CostRegNet autograd convs: "hip" (MFMA fwd+dgrad) | "torch"
         # FeatureNet autograd: "torch_cl" = MIOpen's NHWC 2D kernels + the fused HIP BatchNorm/ReLU
@@ -352,14 +355,17 @@ class MVSNet(nn.Module):
             c8 = self.cost_regularization.wants_c8_input()
             use_lds = self.variance_impl == "lds" and C % 16 == 0
             with ops.stage("to_channels_last"):
-                if use_lds:   # [B*V,h,w,C] -> [V,B,C/16,h,w,16]
-                    f16 = f.reshape(B, V, h, w, C // 16, 16).permute(1, 0, 4, 2, 3, 5).contiguous()
+                if use_lds:
+                    # [B*V,h,w,C] -> [V,B,C/blk,h,w,blk]: 4-channel blocks for the persistent sweep
+                    # kernel (shared depth planes), 16-channel blocks for the per-tile kernels
+                    blk = 4 if ops.variance_persistent_supported(depth_values, B, V, C, h, w) else 16
+                    f16 = f.reshape(B, V, h, w, C // blk, blk).permute(1, 0, 4, 2, 3, 5).contiguous()
                 else:
                     fcl = f.reshape(B, V, h, w, C).transpose(0, 1).contiguous()   # [V,B,h,w,C]
             with ops.stage("costvol_variance"):
                 if use_lds:
                     var = ops.costvol_variance_c16(f16[0], f16[1:], rts, depth_values,
-                                                   self.align_corners, out_c8=c8)
+                                                   self.align_corners, out_c8=c8, fast=self.variance_fast)
                 else:
                     var = ops.costvol_variance_cl(fcl[0], fcl[1:], rts, depth_values,
                                                   self.align_corners, out_c8=c8)

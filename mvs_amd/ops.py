@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import (MVS_LAYOUT_C8, MVS_LAYOUT_C16, MVS_LAYOUT_NCHW, MVS_LAYOUT_NHWC, MvsHipError, check, ptr,
+from ._lib import (MVS_LAYOUT_C4, MVS_LAYOUT_C8, MVS_LAYOUT_C16, MVS_LAYOUT_NCHW, MVS_LAYOUT_NHWC, MvsHipError, check, ptr,
                    stream)
 
 _I = ctypes.c_int
@@ -423,22 +423,68 @@ def nchw_to_c16(x):
     return out
 
 
+_variance_ws = {}
+
+
+def _variance_workspace(dev, nbytes):
+    """Scratch of the persistent variance kernel's cold-path queue: one buffer per device and
+    stream, grown on demand (kernels on one stream run in order, so they can share it)."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _variance_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _variance_ws[key] = torch.empty(max(nbytes, 1 << 20), device=dev, dtype=torch.uint8)
+    return ws
+
+
 def costvol_variance_c16(ref16, srcs16, rts, depth_values, align_corners=False, alias_quirk=False,
-                         out_c8=False):
+                         out_c8=False, fast=False):
     """LDS-staged fused warp+variance.  ref16 [B,C/16,H,W,16]; srcs16 [V-1,B,C/16,H,W,16]
-    -> [B,D,H,W,C] or (out_c8) [B,D,H,C/8,W,8]."""
+    -> [B,D,H,W,C] or (out_c8) [B,D,H,C/8,W,8].  Shared depth planes run the persistent
+    kernel (mvs_costvol_variance_fwd_ws_f32); `fast` selects its fast-coordinate mode
+    (MVS_SWEEP_FAST), otherwise the result is bit-identical to the reference's arithmetic."""
     ref16, srcs16, depth_values = _f32c(ref16), _f32c(srcs16), _f32c(depth_values)
-    B, G, H, W, _ = ref16.shape
-    C = G * 16
+    B, G, H, W, blk = ref16.shape
+    if blk not in (4, 16):
+        raise MvsHipError(f"blocked features come 16 or 4 channels to a block, got {blk}")
+    layout = MVS_LAYOUT_C16 if blk == 16 else MVS_LAYOUT_C4
+    C = G * blk
     V = srcs16.shape[0] + 1
     D = depth_values.shape[1]
     shape = (B, D, H, C // 8, W, 8) if out_c8 else (B, D, H, W, C)
     out = torch.empty(shape, device=ref16.device, dtype=torch.float32)
-    check(_lib.load().mvs_costvol_variance_fwd_f32(
-        ptr(ref16), ptr(srcs16), ptr(rts), ptr(depth_values), _depth_mode(depth_values), B, V, C,
-        D, H, W, int(align_corners), int(alias_quirk), MVS_LAYOUT_C16,
-        MVS_LAYOUT_C8 if out_c8 else MVS_LAYOUT_NHWC, ptr(out), stream()),
-        "mvs_costvol_variance_fwd_f32")
+    lib = _lib.load()
+    mode = _depth_mode(depth_values)
+    need = lib.mvs_costvol_variance_workspace_bytes(mode, B, V, C, D, H, W, layout)
+    ws = _variance_workspace(ref16.device, need) if need else None
+    check(lib.mvs_costvol_variance_fwd_ws_f32(
+        ptr(ref16), ptr(srcs16), ptr(rts), ptr(depth_values), mode, B, V, C,
+        D, H, W, int(align_corners), int(alias_quirk), layout,
+        MVS_LAYOUT_C8 if out_c8 else MVS_LAYOUT_NHWC, 1 if fast else 0, ptr(out),
+        ctypes.c_void_p(ws.data_ptr()) if ws is not None else None, ws.numel() if ws is not None else 0,
+        stream()), "mvs_costvol_variance_fwd_ws_f32")
+    return out
+
+
+def variance_persistent_supported(depth_values, B, V, C, H, W):
+    """True when mvs_costvol_variance_fwd_ws_f32 serves this shape with the persistent kernel
+    (then 4-channel-blocked features, nchw_to_c4, are its fastest input)."""
+    depth_values = _f32c(depth_values)
+    return _lib.load().mvs_costvol_variance_workspace_bytes(
+        _depth_mode(depth_values), B, V, C, depth_values.shape[1], H, W, MVS_LAYOUT_C4) > 0
+
+
+def nchw_to_c4(x):
+    """[...,C,H,W] -> [...,C/4,H,W,4]: 4-channel blocked feature maps (MVS_LAYOUT_C4)."""
+    x = _f32c(x)
+    *lead, C, H, W = x.shape
+    if C % 4:
+        raise MvsHipError(f"nchw_to_c4 needs C % 4 == 0, got {C}")
+    n = 1
+    for v in lead:
+        n *= v
+    out = torch.empty(tuple(lead) + (C // 4, H, W, 4), device=x.device, dtype=torch.float32)
+    check(_lib.load().mvs_nchw_to_nhwc_f32(ptr(x), ptr(out), n * (C // 4), 4, H * W, stream()),
+          "mvs_nchw_to_nhwc_f32")
     return out
 
 

@@ -76,9 +76,12 @@ def main():
     if want("variance_lds"):
         proj = torch.from_numpy(synth.proj_matrices(V, h, w)).to(dev)
         dv = torch.from_numpy(synth.depth_values(D)).to(dev)
-        f16 = torch.randn(V, 1, 2, h, w, 16, device=dev, generator=g)
+        feats = torch.randn(V, 1, 32, h, w, device=dev, generator=g)
+        fast = os.environ.get("MVS_BENCH_FAST", "0") == "1"
+        c4 = ops.variance_persistent_supported(dv, 1, V, 32, h, w) and os.environ.get("MVS_BENCH_C16", "0") != "1"
+        f16 = ops.nchw_to_c4(feats) if c4 else ops.nchw_to_c16(feats)
         rts = torch.stack([ops.rot_trans(proj[:, v], proj[:, 0]) for v in range(1, V)])
-        med, best = timeit(lambda: ops.costvol_variance_c16(f16[0], f16[1:], rts, dv, out_c8=True), reps)
+        med, best = timeit(lambda: ops.costvol_variance_c16(f16[0], f16[1:], rts, dv, out_c8=True, fast=fast), reps)
         byt = (V * 32 * h * w + D + 32 * D * h * w) * 4
         res["variance_lds"] = {"ms": round(med, 4), "best_ms": round(best, 4), "GBs": round(byt / med / 1e6, 1),
                                "frac_hbm": round(byt / med / 1e6 / 8000, 4)}

@@ -38,8 +38,12 @@ def test_variance_two_kernels_agree_bit_for_bit_and_scale_exactly(dev, scene):
     cl = ops.nchw_to_nhwc(feats.reshape(V, C, H, W)).reshape(V, 1, H, W, C)
     v_gather = ops.costvol_variance_cl(cl[0], cl[1:], rts, dv)
     f16 = ops.nchw_to_c16(feats)
-    v_lds = ops.costvol_variance_c16(f16[0], f16[1:], rts, dv)
+    v_lds = ops.costvol_variance_c16(f16[0], f16[1:], rts, dv)       # persistent kernel, 16-channel blocks
     assert torch.equal(v_gather, v_lds)
+    f4 = ops.nchw_to_c4(feats)
+    assert torch.equal(ops.costvol_variance_c16(f4[0], f4[1:], rts, dv), v_lds)   # 4-channel blocks
+    v_fast = ops.costvol_variance_c16(f4[0], f4[1:], rts, dv, fast=True)
+    assert float((v_fast - v_lds).abs().max()) < 2e-5     # features ~N(0, 0.1^2): variances ~1e-2
     f16x2 = ops.nchw_to_c16(feats * 2)
     v_lds2 = ops.costvol_variance_c16(f16x2[0], f16x2[1:], rts, dv)
     assert torch.equal(v_lds2, v_lds * 4)

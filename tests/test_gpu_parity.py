@@ -173,6 +173,63 @@ def test_variance_lds_staged_vs_oracle_ragged_and_fallback(dev):
             np.testing.assert_allclose(got, want, atol=1e-7, rtol=0)
 
 
+def _persist_scene(dev, B, V, C, D, H, W, seed, wide=False):
+    from mvs_amd import ops, synth
+    g = torch.Generator(device=dev).manual_seed(seed)
+    feats = torch.randn(V, B, C, H, W, device=dev, generator=g)
+    proj = synth.proj_matrices(V, H, W, batch=B)
+    if wide:   # a scaled source camera: footprints larger than any LDS share -> the cold kernel
+        proj[:, 1, :2, :] *= 3.0
+    proj = torch.from_numpy(proj).to(dev)
+    dv = torch.from_numpy(synth.depth_values(D, batch=B, interval=synth.sweep_interval(D))).to(dev)
+    return feats, ops.rot_trans_all(proj), dv
+
+
+@pytest.mark.parametrize("case", [(2, 3, 32, 9, 13, 37, False), (1, 5, 32, 20, 30, 50, False),
+                                  (1, 5, 32, 17, 41, 67, False), (1, 3, 32, 12, 40, 64, True),
+                                  (1, 2, 16, 16, 24, 48, False), (2, 7, 32, 5, 18, 35, False)],
+                         ids=["b2v3", "b1v5", "d17", "wide_cold_path", "c16ch", "b2v7"])
+def test_variance_persistent_kernel_bit_equal_to_per_tile_kernel(dev, case, monkeypatch):
+    """mvs_costvol_variance_fwd_ws_f32 (persistent workgroups + cold-path kernel, both feature
+    layouts, both tile depths) == the per-tile kernel, which the golden tests pin to the
+    reference: ragged sizes, partial depth chunks, two batch items, 1..6 source views, and a rig
+    whose footprints do not fit LDS."""
+    from mvs_amd import ops
+    B, V, C, D, H, W, wide = case
+    feats, rts, dv = _persist_scene(dev, B, V, C, D, H, W, seed=B * 100 + V, wide=wide)
+    f16, f4 = ops.nchw_to_c16(feats), ops.nchw_to_c4(feats)
+    monkeypatch.setenv("MVS_SWEEP_PERSIST", "0")
+    want = ops.costvol_variance_c16(f16[0], f16[1:], rts, dv)
+    want8 = ops.costvol_variance_c16(f16[0], f16[1:], rts, dv, out_c8=True)
+    for waves in ("16", "8"):
+        monkeypatch.setenv("MVS_SWEEP_PERSIST", waves)
+        for f in (f16, f4):
+            assert torch.equal(ops.costvol_variance_c16(f[0], f[1:], rts, dv), want)
+            assert torch.equal(ops.costvol_variance_c16(f[0], f[1:], rts, dv, out_c8=True), want8)
+        fast = ops.costvol_variance_c16(f4[0], f4[1:], rts, dv, fast=True)
+        # white-noise features (|gradient| ~ 1 per texel) x sampling positions within ~1e-4 texel
+        assert float((fast - want).abs().max()) < 5e-4 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("name", ["g6_e2e_64x96_v3_d8", "g3_e2e_64x64_v5_d8_b2"])
+def test_variance_persistent_golden_and_fast_mode(dev, name):
+    """The persistent kernel (4-channel blocked features) against the reference's own variance
+    volume: exact mode to the bit fraction the per-tile kernels reach, fast mode within 2e-6."""
+    from mvs_amd import ops
+    g = load_golden(name)
+    f = g["features"]
+    V = f.shape[1]
+    ref4 = ops.nchw_to_c4(G(f[:, 0], dev))
+    srcs4 = ops.nchw_to_c4(G(np.stack([f[:, v] for v in range(1, V)]), dev))
+    rts, dv = G(_rts(g["proj"]), dev), G(g["depth_values"], dev)
+    assert ops.variance_persistent_supported(dv, f.shape[0], V, f.shape[2], f.shape[3], f.shape[4])
+    got = ops.costvol_variance_c16(ref4, srcs4, rts, dv).permute(0, 4, 1, 2, 3).contiguous().cpu().numpy()
+    np.testing.assert_allclose(got, g["variance"], atol=1e-7, rtol=0)
+    assert (got == g["variance"]).mean() > 0.999
+    fast = ops.costvol_variance_c16(ref4, srcs4, rts, dv, fast=True).permute(0, 4, 1, 2, 3).contiguous()
+    np.testing.assert_allclose(fast.cpu().numpy(), g["variance"], atol=2e-6, rtol=0)
+
+
 @pytest.mark.parametrize("V", [2, 3, 5, 7])
 def test_division_by_view_count_is_ieee_exact(dev, V):
     """The variance kernel's 3-op division by V equals IEEE x / V for all 2^32
