@@ -158,6 +158,27 @@ int mvs_conv3d_pack_weights_f32(const float *weight, int transposed, int Cin, in
 /* 1 if impl 2 (MFMA) supports this layer shape, else 0. */
 int mvs_conv3d_mfma_supported(int transposed, int Cin, int Cout, int stride);
 
+/* The whole 3D U-Net in one call -- CostRegNet.forward, mvsnet.py:83-93 (also the cascade's
+ * CostRegNet, CasMVSNet/models/module.py:407-438): conv0 .. conv6 (3x3x3 + folded BN + ReLU, strides
+ * 1 2 1 2 1 2 1), conv7 / conv9 / conv11 (transposed, stride 2, + BN + ReLU, skip-add of conv4 /
+ * conv2 / conv0 after the ReLU), prob (3x3x3 to one channel, `shift` = its bias or NULL, no ReLU).
+ * layers[11] in that order; widths Cin -> base, 2 base, 2 base, 4 base, 4 base, 8 base, 8 base,
+ * 4 base, 2 base, base, 1 (base = 8 in both networks).  in: the variance volume, channels-last
+ * [B,D,H,W,Cin] (MVS_LAYOUT_NHWC) or 8-channel blocked [B,D,H,Cin/8,W,8] (MVS_LAYOUT_C8);
+ * out_cost [B,D,H,W].  D, H, W multiples of 8.  Every intermediate activation lives in
+ * `workspace` (mvs_costreg_workspace_bytes; nothing is allocated), the layers are the kernels
+ * of mvs_conv3d_f32 enqueued back to back on `stream`. */
+typedef struct mvs_conv_layer {
+    const float *weight; /* PyTorch layout: conv (Cout,Cin,3,3,3), transposed (Cin,Cout,3,3,3) */
+    const float *packed; /* mvs_conv3d_pack_weights_f32 output, or NULL (direct kernels) */
+    const float *scale;  /* folded BatchNorm scale [Cout], or NULL */
+    const float *shift;  /* folded BatchNorm shift / conv bias [Cout], or NULL */
+} mvs_conv_layer;
+size_t mvs_costreg_workspace_bytes(int B, int base, int D, int H, int W);
+int mvs_costreg_fwd_f32(const float *in, int in_layout, const mvs_conv_layer *layers, int B, int Cin,
+                        int base, int D, int H, int W, int impl, void *workspace,
+                        size_t workspace_bytes, float *out_cost, void *stream);
+
 /* Weight gradient of one 3x3x3 layer (training, BASELINE config 5; the reference gets it from
  * autograd through nn.Conv3d / nn.ConvTranspose3d, module.py:26-33, mvsnet.py:66-79):
  *   grad_weight[co][ci][kz][ky][kx] += sum_o grad_out[o][co] * in[o*stride + k - 1][ci]

@@ -37,6 +37,8 @@ _SIGS = {
     "mvs_selftest_div_by_views_f32": (_c_i, [_c_i, _c_f, _c_f]),
     "mvs_costvol_variance_bwd_f32": (_c_i, [_c_f] * 5 + [_c_i] * 10 + [_c_f, _c_f, _c_f]),
     "mvs_conv3d_f32": (_c_i, [_c_f] * 6 + [_c_i] * 11 + [_c_f, _c_f]),
+    "mvs_costreg_workspace_bytes": (ctypes.c_size_t, [_c_i] * 5),
+    "mvs_costreg_fwd_f32": (_c_i, [_c_f, _c_i, _c_f] + [_c_i] * 7 + [_c_f, ctypes.c_size_t, _c_f, _c_f]),
     "mvs_conv3d_packed_weight_floats": (_c_l, [_c_i] * 4),
     "mvs_conv3d_pack_weights_f32": (_c_i, [_c_f] + [_c_i] * 4 + [_c_f, _c_f]),
     "mvs_conv3d_mfma_supported": (_c_i, [_c_i] * 4),
@@ -57,6 +59,12 @@ _SIGS = {
     "mvs_softmax_regress_conf_f32": (_c_i, [_c_f, _c_f] + [_c_i] * 6 + [_c_f] * 4),
     "mvs_softmax_regress_bwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_f] + [_c_i] * 4 + [_c_f, _c_f]),
 }
+
+class ConvLayer(ctypes.Structure):
+    """mvs_conv_layer of include/mvs_hip.h"""
+    _fields_ = [("weight", ctypes.c_void_p), ("packed", ctypes.c_void_p),
+                ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p)]
+
 
 _lib = None
 

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(CSRC, "libmvs_hip.so")
-SOURCES = ("capi", "sweep", "sweep_persist", "regress", "conv3d_direct", "conv3d_mfma", "conv2d_mfma", "conv3d_wgrad", "bnorm", "cas_hypo", "geo_filter", "cvp_hypo")
+SOURCES = ("capi", "sweep", "sweep_persist", "regress", "conv3d_direct", "conv3d_mfma", "costreg", "conv2d_mfma", "conv3d_wgrad", "bnorm", "cas_hypo", "geo_filter", "cvp_hypo")
 HEADERS = (os.path.join(CSRC, "mvs_common.h"), os.path.join(CSRC, "sweep_common.h"), os.path.join(CSRC, "conv_persistent.h"),
            os.path.join(os.path.dirname(HERE), "include", "mvs_hip.h"))
 # -ffp-contract=off: the plane-sweep coordinate arithmetic places its FMAs by
@@ -67,5 +67,24 @@ def build(force=False, verbose=False):
     return LIB
 
 
+ABI_TEST_SRC = os.path.join(os.path.dirname(HERE), "tests", "cpp", "abi_chain.cpp")
+ABI_TEST_BIN = os.path.join(os.path.dirname(HERE), "tests", "cpp", "abi_chain")
+
+
+def build_abi_test(force=False):
+    """The standalone C++ caller of include/mvs_hip.h (tests/cpp/abi_chain.cpp), linked against
+    the in-tree libmvs_hip.so; like the library it is built here and travels with the snapshot."""
+    if not os.path.exists(ABI_TEST_SRC):
+        return None
+    if force or _stale(ABI_TEST_BIN, (ABI_TEST_SRC, LIB, HEADERS[-1])):
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-I" + os.path.join(os.path.dirname(HERE), "include"),
+               ABI_TEST_SRC, "-L" + CSRC, "-lmvs_hip", "-Wl,-rpath,$ORIGIN/../../mvs_amd/csrc", "-o", ABI_TEST_BIN]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    return ABI_TEST_BIN
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_abi_test(force="--force" in sys.argv))

@@ -48,6 +48,10 @@ def pack_costreg(sd, prefix=""):
 def costreg_forward(x_cl, P, impl=ops.IMPL_AUTO, in_c8=False):
     """x_cl [B,D,H,W,Cin] channels-last (in_c8: [B,D,H,Cin/8,W,8]) -> cost [B,D,H,W]
     (module.py:429-438)."""
+    D, H, W = x_cl.shape[1], x_cl.shape[2], x_cl.shape[4 if in_c8 else 3]
+    if D % 8 == 0 and H % 8 == 0 and W % 8 == 0:
+        return ops.costreg_forward(x_cl, P, in_c8=in_c8, impl=impl)   # one C call: mvs_costreg_fwd_f32
+
     def run(name, t, skip=None, relu=True, c8=False):
         p = P[name]
         return ops.conv3d(t, p["weight"], p["scale"], p["shift"], skip, relu, p["transposed"],

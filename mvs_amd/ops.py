@@ -58,6 +58,10 @@ def set_timer(t):
     _timer = t
 
 
+def timing_enabled():
+    return _timer is not None
+
+
 class stage:
     """with ops.stage("name"): ...  -- no-op unless a StageTimer is installed."""
 
@@ -559,6 +563,50 @@ def conv3d(x, weight, scale=None, shift=None, residual=None, relu=False, transpo
         B, cin, cout, D, H, W, stride,
         MVS_LAYOUT_C8 if in_c8 else (MVS_LAYOUT_NHWC if channels_last else MVS_LAYOUT_NCHW),
         impl, ptr(out), stream()), "mvs_conv3d_f32")
+    return out
+
+
+COSTREG_ORDER = ("conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv9", "conv11", "prob")
+_costreg_ws = {}
+
+
+def costreg_forward(x, params, in_c8=False, impl=IMPL_AUTO):
+    """The whole 3D U-Net in one C call (mvs_costreg_fwd_f32; mvsnet.py:83-93).  x: variance
+    volume [B,D,H,W,Cin] or (in_c8) [B,D,H,Cin/8,W,8]; params: name -> dict(weight, packed, scale,
+    shift) for the eleven layers of COSTREG_ORDER.  -> cost [B,D,H,W].  The activations live in a
+    per-(device, stream) workspace that the next call on the same stream reuses."""
+    x = _f32c(x)
+    if in_c8:
+        B, D, H, G, W, _ = x.shape
+        cin = G * 8
+    else:
+        B, D, H, W, cin = x.shape
+    base = params["conv0"]["weight"].shape[0]
+    lib = _lib.load()
+    need = lib.mvs_costreg_workspace_bytes(B, base, D, H, W)
+    if need == 0:
+        raise MvsHipError(f"mvs_costreg_fwd_f32 needs D, H, W multiples of 8, got {D}, {H}, {W}")
+    key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
+    ws = _costreg_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _costreg_ws[key] = torch.empty(need, device=x.device, dtype=torch.uint8)
+    layers = (_lib.ConvLayer * 11)()
+    keep = []
+    for i, name in enumerate(COSTREG_ORDER):
+        p = params[name]
+        for field in ("weight", "packed", "scale", "shift"):
+            t = p.get(field)
+            if t is not None:
+                t = _f32c(t)
+                keep.append(t)
+                if not t.is_cuda:
+                    raise MvsHipError("costreg_forward needs device tensors")
+                setattr(layers[i], field, t.data_ptr())
+    out = torch.empty((B, D, H, W), device=x.device, dtype=torch.float32)
+    check(lib.mvs_costreg_fwd_f32(ptr(x), MVS_LAYOUT_C8 if in_c8 else MVS_LAYOUT_NHWC,
+                                  ctypes.cast(layers, ctypes.c_void_p), B, cin, base, D, H, W, impl,
+                                  ctypes.c_void_p(ws.data_ptr()), ws.numel(), ptr(out), stream()),
+          "mvs_costreg_fwd_f32")
     return out
 
 

@@ -1,0 +1,67 @@
+"""The C ABI driven by a caller that is not Python: tests/cpp/abi_chain.cpp runs
+warp -> fused variance (workspace entry) -> CostRegNet in one call -> softmax regression on a dump
+of a reference-generated golden case and compares with the reference's own outputs."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, load_golden, rot_trans_torch
+
+BIN = os.path.join(REPO, "tests", "cpp", "abi_chain")
+ORDER = ("conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv9", "conv11")
+
+
+def write_dump(path, g, W, warped1=None):
+    f = g["features"]                                   # [B,V,C,h,w]
+    B, V, C, H, Wd = f.shape
+    D = g["depth_values"].shape[1]
+    arrs = [("features", np.ascontiguousarray(f.transpose(1, 0, 2, 3, 4))),
+            ("rot_trans", np.stack([rot_trans_torch(g["proj"], v) for v in range(1, V)])),
+            ("depth_values", g["depth_values"]), ("variance", g["variance"]), ("cost", g["cost"]),
+            ("depth", g["depth"]), ("confidence", g["confidence"])]
+    if warped1 is not None:
+        arrs.append(("warped1", warped1))
+    pre = "cost_regularization."
+    for n in ORDER:
+        conv, bn = (".conv", ".bn") if n in ORDER[:7] else (".0", ".1")
+        scale = W[pre + n + bn + ".weight"] / np.sqrt(W[pre + n + bn + ".running_var"] + np.float32(1e-5))
+        arrs += [(n + ".weight", W[pre + n + conv + ".weight"]), (n + ".scale", scale),
+                 (n + ".shift", W[pre + n + bn + ".bias"] - W[pre + n + bn + ".running_mean"] * scale)]
+    arrs += [("prob.weight", W[pre + "prob.weight"]), ("prob.shift", W[pre + "prob.bias"])]
+    os.makedirs(path, exist_ok=True)
+    with open(os.path.join(path, "manifest.txt"), "w") as m, open(os.path.join(path, "blob.bin"), "wb") as b:
+        for k, v in (("B", B), ("V", V), ("C", C), ("D", D), ("H", H), ("W", Wd)):
+            m.write(f"#{k} {v}\n")
+        for k, v in arrs:
+            v = np.ascontiguousarray(v, dtype=np.float32)
+            m.write(f"{k} {v.size}\n")
+            b.write(v.tobytes())
+
+
+def test_abi_binary_is_built_and_links_the_in_tree_library():
+    """build() compiles the caller; it must resolve libmvs_hip.so next to the sources (rpath)."""
+    from mvs_amd import build
+    assert build.build_abi_test() == BIN and os.path.exists(BIN)
+    out = subprocess.run(["readelf", "-d", BIN], capture_output=True, text=True).stdout
+    assert "libmvs_hip.so" in out and "$ORIGIN/../../mvs_amd/csrc" in out
+
+
+@pytest.mark.gpu
+def test_cpp_caller_matches_reference_outputs(tmp_path, weights):
+    from oracle import c_oracle as co
+    assert torch.cuda.is_available()
+    g = load_golden("g6_e2e_64x96_v3_d8")
+    f = g["features"]
+    warped1 = co.warp(f[:, 1], rot_trans_torch(g["proj"], 1), g["depth_values"])   # bit-exact with the reference (test_oracle_golden)
+    write_dump(str(tmp_path), g, weights, warped1)
+    r = subprocess.run([BIN, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["ok"] and res["arch"] == "gfx950"
+    assert res["warp_maxabs"] < 1e-6 and res["variance_maxabs"] < 1e-6
+    assert res["depth_maxabs_mm"] < 1e-3 and res["confidence_maxabs"] < 2e-4
+    assert res["variance_workspace_bytes"] > 0 and res["costreg_workspace_bytes"] > 0
