@@ -97,6 +97,84 @@ def _roofline_entry(name, kind, amount, ms):
             "algorithmic_flops": amount, "ms": round(ms, 4)}
 
 
+def train_main(args, rank, world, dev, dist):
+    """BASELINE configs[4]: MVSNet DTU training, one reference view (3 views 640x512, D=192) per GPU
+    per step, the batch sharded across ranks, ONE all-reduce of the flat 1.35 MB gradient over RCCL
+    per step (MVSNet/train.py:204-248 with CasMVSNet/train.py:365-393's one-process-per-GPU launch).
+    A step = zero_grad -> forward(train) -> mvsnet_loss -> backward -> all-reduce -> Adam step."""
+    from mvs_amd import parallel
+    from mvs_amd.models import mvsnet_loss
+    H, W, V, D = (512, 640, 3, 192) if (args.height, args.width, args.views) == (1184, 1600, 5) else \
+        (args.height, args.width, args.views, args.ndepth)
+    h, w = H // 4, W // 4
+    torch.manual_seed(1)
+    model = MVSNet(refine=False).to(dev)
+    parallel.broadcast_parameters(model, 0)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.0)   # train.py:98
+    reduce_grads = parallel.FlatGradAllReduce(model.parameters())
+    rng = np.random.default_rng(100 + rank)
+    proj = torch.from_numpy(synth.proj_matrices(V, h, w)).to(dev)
+    dvals = torch.from_numpy(synth.depth_values(D)).to(dev)
+    # a fixed pool of synthetic samples resident in HBM (the loader is not part of the metric)
+    pool = [(torch.from_numpy(synth.images(rng, 1, V, H, W)).to(dev),
+             torch.from_numpy((synth.DTU_TARGET_Z + 20 * rng.standard_normal((1, h, w))).astype(np.float32)).to(dev))
+            for _ in range(4)]
+    mask = torch.ones(1, h, w, device=dev)
+    model.train()
+    ar_events = []
+
+    def step(i, timed):
+        imgs, gt = pool[i % len(pool)]
+        opt.zero_grad()
+        out = model(imgs, proj, dvals)
+        loss = mvsnet_loss(out["depth"], gt, mask)
+        loss.backward()
+        if timed and world > 1:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); reduce_grads(); b.record()
+            ar_events.append((a, b))
+        else:
+            reduce_grads()
+        opt.step()
+        return loss
+
+    for i in range(args.warmup):
+        step(i, False)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i, True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(loss).all()
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        line = {"metric": "training ref-views/sec", "value": round(world * args.steps / elapsed, 4),
+                "unit": "ref-views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"MVSNet DTU training {W}x{H}, N={V} views, D={D} (BASELINE configs[4]); "
+                                       f"global batch {world} reference views, 1 per GPU; Adam 1e-3",
+                           "sharding": f"data parallel x{world}, one flat {reduce_grads.numel * 4 / 1e6:.2f} MB "
+                                       "gradient all-reduce per step (RCCL)", "grad_floats": reduce_grads.numel},
+                "allreduce_us": (round(1e3 * sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events), 1)
+                                 if ar_events else None),
+                "loss": round(float(loss.item()), 4),
+                "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+                "roofline": None, "cpu_baseline": None}
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,6 +185,9 @@ def main():
     ap.add_argument("--views", type=int, default=5)
     ap.add_argument("--ndepth", type=int, default=192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="infer: BASELINE configs[1] (the headline metric); train: configs[4], MVSNet DTU "
+                         "training 640x512 V=3 D=192, one reference view per GPU, RCCL all-reduce of the flat gradient")
     ap.add_argument("--conv-impl", choices=["auto", "direct", "mfma"], default="auto")
     args = ap.parse_args()
 
@@ -131,6 +212,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)   # RCCL over xGMI
 
+    if args.mode == "train":
+        return train_main(args, rank, world, dev, dist)
     H, W, V, D = args.height, args.width, args.views, args.ndepth
     h, w = H // 4, W // 4
     # --- synthetic DTU-shaped workload; each rank = its own ref views

@@ -109,6 +109,11 @@ def ptr(t):
         raise MvsHipError("mvs_amd ops need device (HIP) tensors; got a CPU tensor")
     if t.dtype != torch.float32 or not t.is_contiguous():
         raise MvsHipError(f"expected contiguous float32, got {t.dtype} contiguous={t.is_contiguous()}")
+    if t.device.index != torch.cuda.current_device():
+        # kernels launch on the CURRENT device and its current stream (stream() below): a tensor
+        # of another GPU would be dereferenced there.  nn.DataParallel sets the device per replica.
+        raise MvsHipError(f"tensor on cuda:{t.device.index} but the current device is "
+                          f"cuda:{torch.cuda.current_device()}: wrap the call in torch.cuda.device(...)")
     return ctypes.c_void_p(t.data_ptr())
 
 

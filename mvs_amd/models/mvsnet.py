@@ -143,7 +143,7 @@ class CostRegNet(nn.Module):
         self.conv9 = _deconv_block(32, 16)
         self.conv11 = _deconv_block(16, 8)
         self.prob = nn.Conv3d(8, 1, 3, stride=1, padding=1)
-        self._hip_cache = None
+        self._hip_cache = {}
         self.conv_impl = ops.IMPL_AUTO
 
     # -- autograd path (training): PyTorch-ROCm ops, batch-statistics BN
@@ -194,8 +194,11 @@ class CostRegNet(nn.Module):
                     for p in (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var))
         key += ((self.prob.weight._version, self.prob.weight.data_ptr()),
                 (self.prob.bias._version, self.prob.bias.data_ptr()))
-        if self._hip_cache is not None and self._hip_cache[0] == key:
-            return self._hip_cache[1]
+        dev = self.prob.weight.device
+        cache = self._hip_cache   # {device: (key, params)}: shared by the replicas of nn.DataParallel
+        hit = cache.get(dev)
+        if hit is not None and hit[0] == key:
+            return hit[1]
         params = {}
         with torch.no_grad():
             for name, kind, stride, conv, bn in layers:
@@ -209,7 +212,7 @@ class CostRegNet(nn.Module):
             params["prob"] = dict(weight=w, scale=None,
                                   shift=self.prob.bias.detach().float().contiguous(), stride=1,
                                   transposed=False, packed=ops.pack_conv3d_weight(w, False, 1))
-        self._hip_cache = (key, params)
+        cache[dev] = (key, params)
         return params
 
     def wants_c8_input(self):

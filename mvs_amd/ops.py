@@ -5,6 +5,7 @@ every FLOP of the cost-volume path runs in the hand-written HIP kernels.
 There is no fallback: CPU tensors or a missing library raise MvsHipError.
 """
 import ctypes
+import threading
 
 import torch
 
@@ -50,16 +51,20 @@ class StageTimer:
         return {k: min(a.elapsed_time(b) for a, b in v) for k, v in self.pairs.items()}
 
 
-_timer = None
+_tls = threading.local()   # the timer belongs to the thread that installed it: nn.DataParallel runs
+                           # one forward per device on worker threads, which must not share event lists
+
+
+def _get_timer():
+    return getattr(_tls, "timer", None)
 
 
 def set_timer(t):
-    global _timer
-    _timer = t
+    _tls.timer = t
 
 
 def timing_enabled():
-    return _timer is not None
+    return _get_timer() is not None
 
 
 class stage:
@@ -70,13 +75,14 @@ class stage:
         self.ev = None
 
     def __enter__(self):
-        if _timer is not None:
-            self.ev = _timer.begin(self.name)
+        self.timer = _get_timer()
+        if self.timer is not None:
+            self.ev = self.timer.begin(self.name)
         return self
 
     def __exit__(self, *exc):
-        if _timer is not None:
-            _timer.end(self.name, self.ev)
+        if self.timer is not None:
+            self.timer.end(self.name, self.ev)
         return False
 
 
@@ -120,13 +126,15 @@ def rot_trans_all(proj_matrices, where="host", device=None):
 
 
 _side_streams = {}
+_state_lock = threading.Lock()   # guards the small per-device caches below (DataParallel worker threads)
 
 
 def _side_stream(dev):
     key = (dev.type, dev.index)
-    side = _side_streams.get(key)
-    if side is None:
-        side = _side_streams[key] = torch.cuda.Stream(device=dev)
+    with _state_lock:
+        side = _side_streams.get(key)
+        if side is None:
+            side = _side_streams[key] = torch.cuda.Stream(device=dev)
     return side
 
 
@@ -172,27 +180,39 @@ class _HostHop:
         self.error = None
 
         def _cb(_):
+            # Runs on a HIP runtime thread and needs the GIL: a Python thread that holds the GIL
+            # while it waits for this stream (torch.cuda.synchronize() releases it; a hipFree from
+            # torch.cuda.empty_cache() does not) can deadlock against it -- HostRotTrans(blocking=True)
+            # is the hop without this hazard.
             try:
                 with torch.no_grad():
                     self.pin_out.copy_(fn(self.pin_in))
             except BaseException as e:   # cannot propagate out of a runtime thread
+                # the upload behind this callback still runs: poison it, so the forward that
+                # consumes it yields NaN depths instead of the previous sample's matrices
+                self.pin_out.fill_(float("nan"))
                 self.error = e
         self._cb = ctypes.CFUNCTYPE(None, ctypes.c_void_p)(_cb)   # keep alive
 
     @classmethod
     def get(cls, dev, shape_in, shape_out, fn):
         key = (dev.type, dev.index, tuple(shape_in), fn)
-        inst = cls._instances.get(key)
-        if inst is None:
-            inst = cls._instances[key] = cls(shape_in, shape_out, fn)
+        with _state_lock:
+            inst = cls._instances.get(key)
+            if inst is None:
+                inst = cls._instances[key] = cls(shape_in, shape_out, fn)
         return inst
+
+    def raise_pending(self):
+        """Raise the failure of a hop whose callback has already run."""
+        if self.error is not None:
+            e, self.error = self.error, None
+            raise MvsHipError(f"host hop failed (its output was poisoned with NaN): {e!r}")
 
     def enqueue(self, src, side):
         """On `side` (current stream = side): src (device) -> fn on the host -> new device tensor."""
         import ctypes
-        if self.error is not None:
-            e, self.error = self.error, None
-            raise MvsHipError(f"host hop failed: {e!r}")
+        self.raise_pending()
         self.pin_in.copy_(src, non_blocking=True)
         rc = self.hip().hipLaunchHostFunc(ctypes.c_void_p(side.cuda_stream),
                                           ctypes.cast(self._cb, ctypes.c_void_p), None)
@@ -201,6 +221,15 @@ class _HostHop:
         out = torch.empty(self.pin_out.shape, dtype=torch.float32, device=src.device)
         out.copy_(self.pin_out, non_blocking=True)
         return out
+
+
+def check_host_hops():
+    """After a device synchronisation: raise if any stream-ordered host hop failed (also the
+    last sample's, which no later enqueue would report)."""
+    with _state_lock:
+        hops = list(_HostHop._instances.values())
+    for h in hops:
+        h.raise_pending()
 
 
 def _cas_rot_trans_host_math(host):
@@ -233,10 +262,10 @@ class HostRotTrans:
         ev.record()
         side = _side_stream(self.dev)
         side.wait_event(ev)
-        self.out = self.done = None
+        self.out = self.done = self.hop = None
         if not blocking and _HostHop.hip():
             B, V = self.P.shape[0], self.P.shape[1]
-            hop = _HostHop.get(self.dev, tuple(self.P.shape), (V - 1, B, 12), self.math)
+            hop = self.hop = _HostHop.get(self.dev, tuple(self.P.shape), (V - 1, B, 12), self.math)
             with torch.no_grad(), torch.cuda.stream(side):
                 self.out = hop.enqueue(self.P.float(), side)
                 self.done = torch.cuda.Event()
@@ -244,6 +273,9 @@ class HostRotTrans:
 
     def result(self):
         if self.out is not None:
+            # a callback that has already failed is reported here; one that fails later has
+            # poisoned this result with NaN and is reported by the next hop / check_host_hops()
+            self.hop.raise_pending()
             cur = torch.cuda.current_stream(self.dev)
             cur.wait_event(self.done)
             self.out.record_stream(cur)   # allocated on the side stream, consumed here

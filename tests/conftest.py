@@ -15,6 +15,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """`gpu` tests skip (not fail) on a box without a GPU or without the built library."""
+    try:
+        import torch
+        have = torch.cuda.is_available()
+    except Exception:  # noqa: BLE001
+        have = False
+    have = have and os.path.exists(os.path.join(REPO, "mvs_amd", "csrc", "libmvs_hip.so"))
+    if have:
+        return
+    skip = pytest.mark.skip(reason="needs an MI355X and the built libmvs_hip.so (python -m mvs_amd.build)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
 

@@ -1123,3 +1123,49 @@ def test_cvp_interval_kernel_vs_torch_mirror(dev):
     np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=0, atol=2e-4)
     step = (got[:, 1] - got[:, 0]).mean().item()
     assert 1.0 < step < 50.0     # a millimetre-scale interval for DTU-like cameras
+
+
+# ------------------------------------------------ the reference's drivers wrap the model (eval.py:103-116)
+def test_mvsnet_survives_dataparallel_like_reference_eval(dev, weights):
+    """MVSNet/eval.py:103-116: model = MVSNet(refine=False); model = nn.DataParallel(model);
+    model.cuda(); load_state_dict(ckpt['model']) with `module.`-prefixed keys; model.eval();
+    outputs = model(imgs, proj, depth_values) under no_grad."""
+    from mvs_amd.models import MVSNet
+    g = load_golden("g6_e2e_128x160_v3_d16")
+    model = MVSNet(refine=False)
+    model = torch.nn.DataParallel(model)
+    model.cuda()
+    model.load_state_dict({"module." + k: torch.from_numpy(v) for k, v in weights.items()})
+    model.eval()
+    with torch.no_grad():
+        out = model(G(g["imgs"], dev), G(g["proj"], dev), G(g["depth_values"], dev))
+    assert float(np.abs(out["depth"].cpu().numpy() - g["depth"]).max()) < 1e-3
+    assert float(np.abs(out["photometric_confidence"].cpu().numpy() - g["confidence"]).max()) < 2e-4
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_mvsnet_dataparallel_two_gpus_batch_of_two(dev, weights):
+    """The same wrapper scattering a batch of two samples over two GPUs (one replica thread per
+    device: per-device weight caches, per-thread timers, kernels on each replica's own device)."""
+    from mvs_amd.models import MVSNet
+    g = load_golden("g6_e2e_128x160_v3_d16")
+    model = torch.nn.DataParallel(MVSNet(refine=False), device_ids=[0, 1])
+    model.cuda()
+    model.load_state_dict({"module." + k: torch.from_numpy(v) for k, v in weights.items()})
+    model.eval()
+    two = lambda a: G(np.concatenate([a, a]), dev)   # noqa: E731
+    with torch.no_grad():
+        for _ in range(2):
+            out = model(two(g["imgs"]), two(g["proj"]), two(g["depth_values"]))
+    d = out["depth"].cpu().numpy()
+    assert d.shape[0] == 2 and float(np.abs(d - g["depth"]).max()) < 1e-3
+
+
+def test_tensor_on_other_device_is_rejected(dev):
+    """Kernels launch on the current device: a tensor of another GPU must raise, not be dereferenced."""
+    from mvs_amd import _lib
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    t = torch.zeros(4, device="cuda:1")
+    with pytest.raises(_lib.MvsHipError):
+        _lib.ptr(t)
