@@ -84,7 +84,7 @@ extern "C" int mvs_cas_depth_hypotheses_f32(const float *prev_depth, int B, int 
     }
     HypoArgs a{prev_depth, out, B, hp, wp, H, W, Hs, Ws, D, half_range};
     const int64_t n = (int64_t)B * Hs * Ws;
-    if ((n + 255) / 256 > 0x7fffffffLL) return MVS_EINVAL;
+    if ((n + 255) / 256 > 0x7fffffffLL) return bare_error(MVS_EINVAL, __func__, __LINE__);
     hipLaunchKernelGGL(cas_hypotheses_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), a);
     return check_launch("mvs_cas_depth_hypotheses_f32");
 }

@@ -383,7 +383,7 @@ int conv2d_launch(const float *in, const float *packed, const float *scale, cons
         return MVS_EUNSUPPORTED;
     }
     if (persistent && (coarse || persist2_enabled())) {
-        if ((int64_t)H * W * Cin * 4 >= 0xffffff00LL) return MVS_EINVAL;   // 32-bit offsets inside one image
+        if ((int64_t)H * W * Cin * 4 >= 0xffffff00LL) return bare_error(MVS_EINVAL, __func__, __LINE__);   // 32-bit offsets inside one image
         ConvArgs a;
         a.in = in; a.wpk = packed; a.scale = scale; a.shift = shift; a.residual = coarse; a.out = out;
         a.res_up2 = coarse ? 1 : 0;
@@ -397,7 +397,7 @@ int conv2d_launch(const float *in, const float *packed, const float *scale, cons
         a.tiles_z = B;
         a.relu = relu; a.in_c8 = 0; a.ystrip = 4;
         const int64_t nt = (int64_t)a.tiles_x * a.tiles_y * a.tiles_z;
-        if (nt <= 0 || nt > 0x7fffffffLL) return MVS_EINVAL;
+        if (nt <= 0 || nt > 0x7fffffffLL) return bare_error(MVS_EINVAL, __func__, __LINE__);
         const int n_cu = device_cu_count();
         hipLaunchKernelGGL(pi.kernel, dim3((unsigned)(nt < n_cu ? nt : n_cu)), dim3(512), 0, st, a, (int)nt);
         return check_launch("mvs_conv2d_f32(persistent)");
@@ -431,7 +431,7 @@ int conv2d_launch(const float *in, const float *packed, const float *scale, cons
     a.tiles_y = (a.Ho + ci.ty - 1) / ci.ty;
     a.relu = relu;
     const int64_t nblk = (int64_t)B * a.tiles_x * a.tiles_y;
-    if (nblk <= 0 || nblk > 0x7fffffffLL) return MVS_EINVAL;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return bare_error(MVS_EINVAL, __func__, __LINE__);
     hipLaunchKernelGGL(ci.kernel, dim3((unsigned)nblk), dim3(256), 0, st, a);
     return check_launch("mvs_conv2d_f32");
 }

@@ -794,7 +794,7 @@ int conv3d_mfma_launch(const float *in, const float *packed, const float *scale,
         a.Do = D; a.Ho = H; a.Wo = W;
         a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 7) / 8; a.tiles_z = (D + 3) / 4;
         const int64_t nblk = (int64_t)B * a.tiles_x * a.tiles_y * a.tiles_z;
-        if (nblk <= 0 || nblk > 0x7fffffffLL) return MVS_EINVAL;
+        if (nblk <= 0 || nblk > 0x7fffffffLL) return bare_error(MVS_EINVAL, __func__, __LINE__);
         if (Cin == 8)
             hipLaunchKernelGGL(conv3d_cout1_kernel<8>, dim3((unsigned)nblk), dim3(256), 0, st, a, packed);
         else
@@ -864,7 +864,7 @@ int conv3d_mfma_launch(const float *in, const float *packed, const float *scale,
                 a.tiles_x = (a.Wo + 15) / 16; a.tiles_y = (a.Ho + 3) / 4; a.tiles_z = (a.Do + 1) / 2;
             }
             const int64_t nt = (int64_t)B * a.tiles_x * a.tiles_y * a.tiles_z;
-            if (nt <= 0 || nt > 0x7fffffffLL) return MVS_EINVAL;
+            if (nt <= 0 || nt > 0x7fffffffLL) return bare_error(MVS_EINVAL, __func__, __LINE__);
             if (!getenv("MVS_CONV_YSTRIP")) a.ystrip = 8;
             const dim3 grid((unsigned)(nt < n_cu ? nt : n_cu)), blk(512);
             const int ntl = (int)nt;

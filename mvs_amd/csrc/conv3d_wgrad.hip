@@ -437,7 +437,7 @@ extern "C" int mvs_conv3d_wgrad_f32(const float *in, const float *grad_out, int 
     }
     WgradArgs a;
     int64_t nt;
-    if (!wgrad_geometry(B, Cin, Cout, D, H, W, stride, a, nt)) return MVS_EINVAL;
+    if (!wgrad_geometry(B, Cin, Cout, D, H, W, stride, a, nt)) return bare_error(MVS_EINVAL, __func__, __LINE__);
     a.x = in; a.g = grad_out; a.gw = grad_weight; a.partial = nullptr;
     hipStream_t st = as_stream(stream);
     if (wgrad_xanchor_shape(Cin, Cout, stride) && workspace && workspace_bytes >= wgrad_xanchor_bytes(Cout, (int)nt)) {
@@ -456,5 +456,5 @@ extern "C" int mvs_conv3d_wgrad_f32(const float *in, const float *grad_out, int 
     }
     MVS_WG(16) MVS_WG(32) MVS_WG(64)
 #undef MVS_WG
-    return MVS_EUNSUPPORTED;
+    return bare_error(MVS_EUNSUPPORTED, __func__, __LINE__);
 }

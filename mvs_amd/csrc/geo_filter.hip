@@ -103,7 +103,7 @@ extern "C" int mvs_geo_consistency_f32(const float *depth_ref, const float *dept
     }
     GeoArgs a{depth_ref, depth_src, mats, mask, depth_reprojected, xy_src, geo_mask_sum, depth_averaged, H, W, S};
     const int64_t n = (int64_t)H * W;
-    if ((n + 255) / 256 > 0x7fffffffLL) return MVS_EINVAL;
+    if ((n + 255) / 256 > 0x7fffffffLL) return bare_error(MVS_EINVAL, __func__, __LINE__);
     hipLaunchKernelGGL(geo_consistency_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), a);
     return check_launch("mvs_geo_consistency_f32");
 }

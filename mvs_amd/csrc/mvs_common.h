@@ -12,6 +12,14 @@ namespace mvs {
 
 void set_error(const char *fmt, ...);
 
+// A size / argument guard that has no message of its own: still leaves a fresh error text behind
+// (mvs_last_error_string() must never describe an earlier call).
+inline int bare_error(int code, const char *func, int line) {
+    set_error("%s: %s (guard at line %d)", func,
+              code == MVS_EUNSUPPORTED ? "shape or layout not supported by this build" : "invalid argument or size", line);
+    return code;
+}
+
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

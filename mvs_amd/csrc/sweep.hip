@@ -865,6 +865,22 @@ __global__ __launch_bounds__(256, bwd_blocks_per_cu(NV)) void variance_bwd_dma_k
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
+        // the four taps of view v, channel quad k, as float4
+        auto taps = [&](int v, int k, float4 &a, float4 &bq, float4 &c, float4 &e) {
+            if (wave_in[v]) {
+                const float *base = fea + (v * NQ + k) * cap * 4;
+                a = *reinterpret_cast<const float4 *>(base + o00[v] * 4);
+                bq = *reinterpret_cast<const float4 *>(base + o01[v] * 4);
+                c = *reinterpret_cast<const float4 *>(base + o10[v] * 4);
+                e = *reinterpret_cast<const float4 *>(base + o11[v] * 4);
+            } else {
+                const float *base = srcs16 + (((size_t)v * p.B + b) * ngroups + g) * grp_floats + (q0 + k) * 4;
+                a = *reinterpret_cast<const float4 *>(base + (size_t)o00[v] * 16);
+                bq = *reinterpret_cast<const float4 *>(base + (size_t)o01[v] * 16);
+                c = *reinterpret_cast<const float4 *>(base + (size_t)o10[v] * 16);
+                e = *reinterpret_cast<const float4 *>(base + (size_t)o11[v] * 16);
+            }
+        };
         // ---- the block's bound: max |g| and max |f| over what will meet in LDS.  fmaxf drops
         // NaNs, so the integer max of the raw magnitudes carries them (NaN patterns sort above inf).
         {
@@ -885,6 +901,21 @@ __global__ __launch_bounds__(256, bwd_blocks_per_cu(NV)) void variance_bwd_dma_k
                         const float4 f = *reinterpret_cast<const float4 *>(fea + (v * NQ * cap + i) * 4);
                         fm = max(max(fm, mag(f.x)), max(mag(f.y), max(mag(f.z), mag(f.w))));
                     }
+                }
+            }
+            // Views this wave samples from HBM (footprint not staged, or a tap outside the box) enter
+            // S -- hence kk = 2 S / V^2 -- just the same: their magnitudes belong in the bound too
+            // (cold path; the taps are read once more here).
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                if (wave_in[v]) continue;
+#pragma unroll 1
+                for (int k = 0; k < NQ; ++k) {
+                    float4 a, bq, c, e;
+                    taps(v, k, a, bq, c, e);
+                    fm = max(max(fm, max(mag(a.x), mag(a.y))), max(max(mag(a.z), mag(a.w)), max(mag(bq.x), mag(bq.y))));
+                    fm = max(max(fm, max(mag(bq.z), mag(bq.w))), max(max(mag(c.x), mag(c.y)), max(mag(c.z), mag(c.w))));
+                    fm = max(max(fm, max(mag(e.x), mag(e.y))), max(mag(e.z), mag(e.w)));
                 }
             }
 #pragma unroll
@@ -908,22 +939,6 @@ __global__ __launch_bounds__(256, bwd_blocks_per_cu(NV)) void variance_bwd_dma_k
             inv_scale = __uint_as_float((unsigned)(127 - 52 + e) << 23);
         }
 
-        // the four taps of view v, channel quad k, as float4
-        auto taps = [&](int v, int k, float4 &a, float4 &bq, float4 &c, float4 &e) {
-            if (wave_in[v]) {
-                const float *base = fea + (v * NQ + k) * cap * 4;
-                a = *reinterpret_cast<const float4 *>(base + o00[v] * 4);
-                bq = *reinterpret_cast<const float4 *>(base + o01[v] * 4);
-                c = *reinterpret_cast<const float4 *>(base + o10[v] * 4);
-                e = *reinterpret_cast<const float4 *>(base + o11[v] * 4);
-            } else {
-                const float *base = srcs16 + (((size_t)v * p.B + b) * ngroups + g) * grp_floats + (q0 + k) * 4;
-                a = *reinterpret_cast<const float4 *>(base + (size_t)o00[v] * 16);
-                bq = *reinterpret_cast<const float4 *>(base + (size_t)o01[v] * 16);
-                c = *reinterpret_cast<const float4 *>(base + (size_t)o10[v] * 16);
-                e = *reinterpret_cast<const float4 *>(base + (size_t)o11[v] * 16);
-            }
-        };
         // One channel quad at a time; unrolled while the registers last (the rolled form picks
         // the quad's reference/gradient values with selects).
 #pragma unroll KU
@@ -1123,7 +1138,7 @@ static int launch_variance_cl(int NV, const float *ref, const float *srcs, const
         MVS_CL_CASE(7) MVS_CL_CASE(8)
     }
 #undef MVS_CL_CASE
-    return MVS_EUNSUPPORTED;
+    return bare_error(MVS_EUNSUPPORTED, __func__, __LINE__);
 }
 
 }  // namespace mvs
@@ -1159,7 +1174,7 @@ extern "C" int mvs_warp_bwd_f32(const float *grad_out, const float *rot_trans,
     }
     SweepParams p = make_params(B, 2, C, D, H, W, depth_mode, align_corners, 0);
     unsigned grid;
-    if (!grid_for((int64_t)B * D * H * W, 256, grid)) return MVS_EINVAL;
+    if (!grid_for((int64_t)B * D * H * W, 256, grid)) return bare_error(MVS_EINVAL, __func__, __LINE__);
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(grad_src, 0, sizeof(float) * (size_t)B * C * H * W, st) != hipSuccess)
         return check_launch("mvs_warp_bwd_f32 memset");
@@ -1223,7 +1238,7 @@ extern "C" int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *s
         const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (H + kTileH - 1) / kTileH;
         const int dchunks = (D + kTileD - 1) / kTileD;
         const int64_t nblk = (int64_t)tiles_x * tiles_y * dchunks;
-        if (nblk > 0x7fffffffLL) return MVS_EINVAL;
+        if (nblk > 0x7fffffffLL) return bare_error(MVS_EINVAL, __func__, __LINE__);
         const char *abl_env = getenv("MVS_SWEEP_ABLATE");   // tuning only
         const int lds_ablate = abl_env ? atoi(abl_env) : 0;
         const dim3 g((unsigned)nblk, (unsigned)B);
@@ -1247,14 +1262,14 @@ extern "C" int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *s
 #undef MVS_LDS_CASE
         return check_launch("mvs_costvol_variance_fwd_f32(lds)");
     }
-    if (fea_layout != MVS_LAYOUT_NHWC) return MVS_EINVAL;
+    if (fea_layout != MVS_LAYOUT_NHWC) return bare_error(MVS_EINVAL, __func__, __LINE__);
     if (C == 8 && (int64_t)H * W < (1 << 26) && H < (1 << 23) && W < (1 << 23) && B <= 65535 &&
         !getenv("MVS_SWEEP_C8_GATHER")) {
         // 8-channel maps (the cascade's finest stage): the LDS-staged kernel with one group of two quads
         const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (H + kTileH - 1) / kTileH;
         const int dchunks = (D + kTileD - 1) / kTileD;
         const int64_t nblk = (int64_t)tiles_x * tiles_y * dchunks;
-        if (nblk > 0x7fffffffLL) return MVS_EINVAL;
+        if (nblk > 0x7fffffffLL) return bare_error(MVS_EINVAL, __func__, __LINE__);
         const dim3 g((unsigned)nblk, (unsigned)B);
 #define MVS_LDS8_CASE(n)                                                                          \
     case n: {                                                                                     \
@@ -1392,7 +1407,7 @@ extern "C" int mvs_costvol_variance_bwd_f32(const float *grad_var, const float *
         const int dchunks = (D + kTileD - 1) / kTileD;
         const int64_t nblk = (int64_t)tiles_x * tiles_y * dchunks;
         if (nblk > 0x7fffffffLL || B > 65535 || (int64_t)H * W >= (1 << 26) || H >= (1 << 23) || W >= (1 << 23))
-            return MVS_EINVAL;
+            return bare_error(MVS_EINVAL, __func__, __LINE__);
         const dim3 g((unsigned)nblk, (unsigned)B);
 #define MVS_BWD_CASE(n)                                                                             \
     case n: {                                                                                       \
