@@ -348,13 +348,20 @@ def main():
                      "one_thread": {"seconds": round(one_s, 2), "value": round(1.0 / one_s, 5),
                                     "stages_s": {k: round(v, 3) for k, v in one_st.items()}}}
         else:
+            # all host cores is not the fast configuration on a 256-core host (69 s against 29 s on ONE
+            # thread, profiles/r02_cpu_baseline_protocol.json: the reference composition is memory-bound
+            # and ATen's small per-view ops drown in thread hand-off): pick the thread count on the short
+            # slice, time the full forward with it
             cpu_forward(cores, planes=16)
-            cpu_s, st, ref_out = cpu_forward(cores)
-            sample = ("1 reference view of the same workload: one timed full forward on all host cores after a "
-                      "warm-up forward on its first 16 depth planes; ATen CPU restatement of the reference "
-                      "forward (oracle/torch_ref.py); the full section-4 protocol: --cpu-protocol, "
-                      "profiles/r02_cpu_baseline_protocol.json")
-            extra = {}
+            sweep = {t: cpu_forward(t, planes=16)[0] for t in sorted({1, 8, 32, cores}) if t <= cores}
+            threads = min(sweep, key=sweep.get)
+            cpu_s, st, ref_out = cpu_forward(threads)
+            sample = (f"1 reference view of the same workload: one timed full forward on {threads} host threads -- the "
+                      "fastest of 1 / 8 / 32 / all cores on a warm-up slice (the first 16 depth planes); ATen CPU "
+                      "restatement of the reference forward (oracle/torch_ref.py); BASELINE.md section 4 in full "
+                      "(1 warm-up + 3 timed on all cores, 1-thread run): --cpu-protocol, profiles/r02_cpu_baseline_protocol.json")
+            extra = {"thread_sweep_16_planes_s": {str(k): round(v, 2) for k, v in sweep.items()}}
+            cores = threads
         err = float((out["depth"].cpu() - ref_out["depth"]).abs().max())
         line["cpu_baseline"] = {
             "value": round(1.0 / cpu_s, 5), "unit": "depth-maps/s", "cores": cores,

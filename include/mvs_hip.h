@@ -76,6 +76,19 @@ const char *mvs_arch(void);
 int mvs_nchw_to_nhwc_f32(const float *in, float *out, int B, int C, int64_t S, void *stream);
 int mvs_nhwc_to_nchw_f32(const float *in, float *out, int B, int C, int64_t S, void *stream);
 
+/* ---- input pipeline on the device ----------------- */
+/* What the reference's loader does to a decoded image, MVSNet/datasets/dtu_yao_eval.py:60-67,102:
+ * np.array(img, float32) / 255. (IEEE division), crop to the top-left H x W (the loader drops the
+ * bottom 16 rows of 1600x1200), HWC -> CHW.  in: N decoded images [N,Hs,Ws,3] uint8 on the device;
+ * out [N,3,H,W] float32 -- bit-identical to the loader's tensors. */
+int mvs_images_u8_to_planar_f32(const unsigned char *in, int N, int Hs, int Ws, int H, int W, float *out,
+                                void *stream);
+/* dtu_yao_eval.py:54,93-95: out = E with its top 3x4 block replaced by (K with rows 0 and 1 divided by
+ * intrinsics_div) @ E[:3,:4]; K [N,3,3], E [N,4,4], out [N,4,4].  The dot products are evaluated as
+ * numpy's float32 matmul evaluates them (rounded first product, two FMAs). */
+int mvs_proj_matrices_f32(const float *K, const float *E, float intrinsics_div, int N, float *out,
+                          void *stream);
+
 /* ---- K1: plane-sweep warp -- MVSNet/models/module.py:46-87 ---------- */
 /* src_fea [B,C,H,W]; rot_trans [B,12] = rows of (src_proj @ inverse(ref_proj))[:3,:4]
  * (module.py:63-65, evaluated by the caller with torch); out [B,C,D,H,W].
@@ -235,6 +248,22 @@ int mvs_cas_depth_hypotheses_f32(const float *prev_depth, int B, int hp, int wp,
  * K_ref R_ref inverse(K_src R_src) (9), row-major; sum_abs: one double on the device (set here). */
 int mvs_cvp_interval_sum_f64(const float *depth, const double *mats, int H, int W, double pixel_interval,
                              double *sum_abs, void *stream);
+
+/* Glue between the levels of the CVP-MVSNet pyramid, CVP-MVSNet/models/net.py:45,171
+ * and modules.py:149-152,205-219:
+ *   mvs_downsample_bilinear_half_f32  F.interpolate(x, scale_factor=0.5, mode='bilinear'): in [planes,H,W] ->
+ *       out [planes,H/2,W/2], bit-identical to ATen's CPU kernel (the 2x2 block, weights 0.25, its summation order);
+ *   mvs_upsample_bicubic2x_f32        F.interpolate(x, scale_factor=2, mode='bicubic'): in [planes,H,W] ->
+ *       out [planes,2H,2W] (A = -0.75, border indices clamped; within 2 ulp of ATen's CPU kernel);
+ *   mvs_cvp_hypothesis_mats_f64       the 59 doubles mvs_cvp_interval_sum_f64 takes, from the float32 camera
+ *       matrices K_ref, K_src [3,3], E_ref, E_src [4,4] of one batch item (fp64 inverses and products on the device);
+ *   mvs_cvp_hypotheses_f32            out [2d,H,W] = depth_up + (k - d) * float(sum_abs / (H W)), k = 0..2d-1. */
+int mvs_downsample_bilinear_half_f32(const float *in, int64_t planes, int H, int W, float *out, void *stream);
+int mvs_upsample_bicubic2x_f32(const float *in, int64_t planes, int H, int W, float *out, void *stream);
+int mvs_cvp_hypothesis_mats_f64(const float *K_ref, const float *K_src, const float *E_ref, const float *E_src,
+                                double *mats, void *stream);
+int mvs_cvp_hypotheses_f32(const float *depth_up, const double *sum_abs, int H, int W, int d, float *out,
+                           void *stream);
 
 /* Geometric-consistency check of the depth filter that follows the path (SURVEY.md 8f rank 2;
  * MVSNet/eval.py:136-214 reproject_with_depth + check_geometric_consistency, sums of eval.py:239-262):

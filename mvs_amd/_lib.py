@@ -29,6 +29,8 @@ _SIGS = {
     "mvs_arch": (ctypes.c_char_p, []),
     "mvs_nchw_to_nhwc_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_l, _c_f]),
     "mvs_nhwc_to_nchw_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_l, _c_f]),
+    "mvs_images_u8_to_planar_f32": (_c_i, [_c_f] + [_c_i] * 5 + [_c_f, _c_f]),
+    "mvs_proj_matrices_f32": (_c_i, [_c_f, _c_f, ctypes.c_float, _c_i, _c_f, _c_f]),
     "mvs_warp_fwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i] + [_c_i] * 6 + [_c_f, _c_f]),
     "mvs_warp_bwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i] + [_c_i] * 6 + [_c_f, _c_f]),
     "mvs_costvol_variance_fwd_f32": (_c_i, [_c_f] * 4 + [_c_i] * 11 + [_c_f, _c_f]),
@@ -52,6 +54,10 @@ _SIGS = {
     "mvs_cas_depth_hypotheses_f32": (_c_i, [_c_f] + [_c_i] * 8 + [ctypes.c_float, _c_f, _c_f]),
     "mvs_geo_consistency_f32": (_c_i, [_c_f] * 3 + [_c_i] * 3 + [_c_f] * 6),
     "mvs_cvp_interval_sum_f64": (_c_i, [_c_f, _c_f, _c_i, _c_i, ctypes.c_double, _c_f, _c_f]),
+    "mvs_downsample_bilinear_half_f32": (_c_i, [_c_f, _c_l, _c_i, _c_i, _c_f, _c_f]),
+    "mvs_upsample_bicubic2x_f32": (_c_i, [_c_f, _c_l, _c_i, _c_i, _c_f, _c_f]),
+    "mvs_cvp_hypothesis_mats_f64": (_c_i, [_c_f] * 6),
+    "mvs_cvp_hypotheses_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "mvs_conv2d_f32": (_c_i, [_c_f] * 5 + [_c_i] * 9 + [_c_f, _c_f]),
     "mvs_conv2d_packed_weight_floats": (_c_l, [_c_i] * 4),
     "mvs_conv2d_pack_weights_f32": (_c_i, [_c_f] + [_c_i] * 4 + [_c_f, _c_f]),

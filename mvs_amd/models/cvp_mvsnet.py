@@ -70,8 +70,8 @@ class FeaturePyramid(nn.Module):
         return all(p["packed"] is not None for p in self._hip_params())
 
     def forward_hip(self, img, scales=5):
-        """[N,3,H,W] -> `scales` channels-last maps [N,H/2^l,W/2^l,16] (the image pyramid's
-        bilinear x0.5 stays a torch op)."""
+        """[N,3,H,W] -> `scales` channels-last maps [N,H/2^l,W/2^l,16]; the image pyramid's
+        bilinear x0.5 is mvs_downsample_bilinear_half_f32 (bit-identical to ATen's CPU kernel)."""
         P = self._hip_params()
 
         def cnn(x):
@@ -81,7 +81,7 @@ class FeaturePyramid(nn.Module):
 
         out = [cnn(img)]
         for _ in range(scales - 1):
-            img = F.interpolate(img, scale_factor=0.5, mode="bilinear", align_corners=None)
+            img = ops.downsample_bilinear_half(img)
             out.append(cnn(img))
         return out
 
@@ -318,9 +318,12 @@ class CVPMVSNet(nn.Module):
         depth, conf, _ = ops.softmax_regress_conf(cost, hypos)
         depths.append(depth)
         for level in range(nscale - 2, -1, -1):
-            up = F.interpolate(depth[None], scale_factor=2, mode="bicubic", align_corners=None).squeeze(0)
-            refine = refine_hypotheses_hip if use_hip else refine_hypotheses
-            hypos = refine(up, K_ref[:, level], K_src[:, 0, level], ref_ex, src_ex[:, 0]).contiguous()
+            if use_hip:   # bicubic x2, fp64 camera algebra, epipolar step, hypotheses: all HIP kernels
+                up = ops.upsample_bicubic2x(depth)
+                hypos = ops.cvp_refine_hypotheses(up, K_ref[:, level], K_src[:, 0, level], ref_ex, src_ex[:, 0])
+            else:
+                up = F.interpolate(depth[None], scale_factor=2, mode="bicubic", align_corners=None).squeeze(0)
+                hypos = refine_hypotheses(up, K_ref[:, level], K_src[:, 0, level], ref_ex, src_ex[:, 0]).contiguous()
             cost = self._level(level_feats(level), K_ref[:, level], K_src[:, :, level], ref_ex, src_ex, hypos)
             depth, conf, _ = ops.softmax_regress_conf(cost, hypos)
             depths.append(depth)

@@ -598,6 +598,85 @@ def conv3d(x, weight, scale=None, shift=None, residual=None, relu=False, transpo
     return out
 
 
+# ------------------------------------------------------------ input pipeline (device side)
+def images_u8_to_planar(u8, H=None, W=None):
+    """Decoded images [N,Hs,Ws,3] uint8 on the device -> [N,3,H,W] float32 = np.array(img, float32) / 255.
+    cropped to the top-left H x W and transposed (dtu_yao_eval.py:60-67,102), bit-identical to the
+    reference loader's tensors."""
+    if not u8.is_cuda or u8.dtype != torch.uint8 or not u8.is_contiguous() or u8.dim() != 4 or u8.shape[3] != 3:
+        raise MvsHipError("images_u8_to_planar needs a contiguous device uint8 tensor [N,Hs,Ws,3]")
+    if u8.device.index != torch.cuda.current_device():
+        raise MvsHipError("images_u8_to_planar: tensor is not on the current device")
+    N, Hs, Ws, _ = u8.shape
+    H, W = (Hs if H is None else H), (Ws if W is None else W)
+    out = torch.empty((N, 3, H, W), device=u8.device, dtype=torch.float32)
+    check(_lib.load().mvs_images_u8_to_planar_f32(ctypes.c_void_p(u8.data_ptr()), N, Hs, Ws, H, W, ptr(out), stream()),
+          "mvs_images_u8_to_planar_f32")
+    return out
+
+
+def proj_matrices(K, E, intrinsics_div=4.0):
+    """K [N,3,3], E [N,4,4] (device, as parsed from the cam files) -> [N,4,4] with top 3x4 =
+    (K, rows 0-1 / intrinsics_div) @ E[:3,:4] (dtu_yao_eval.py:54,93-95), bit-identical to the loader's."""
+    K, E = _f32c(K), _f32c(E)
+    out = torch.empty_like(E)
+    check(_lib.load().mvs_proj_matrices_f32(ptr(K), ptr(E), float(intrinsics_div), K.shape[0], ptr(out), stream()),
+          "mvs_proj_matrices_f32")
+    return out
+
+
+# ------------------------------------------------------------ CVP-MVSNet glue (device side)
+def downsample_bilinear_half(x):
+    """F.interpolate(x, scale_factor=0.5, mode='bilinear') for [..., H, W] (net.py:45), bit-identical
+    to ATen's CPU kernel."""
+    x = _f32c(x)
+    *lead, H, W = x.shape
+    planes = 1
+    for v in lead:
+        planes *= v
+    out = torch.empty(tuple(lead) + (H // 2, W // 2), device=x.device, dtype=torch.float32)
+    check(_lib.load().mvs_downsample_bilinear_half_f32(ptr(x), planes, H, W, ptr(out), stream()),
+          "mvs_downsample_bilinear_half_f32")
+    return out
+
+
+def upsample_bicubic2x(x):
+    """F.interpolate(x, scale_factor=2, mode='bicubic') for [..., H, W] (net.py:171)."""
+    x = _f32c(x)
+    *lead, H, W = x.shape
+    planes = 1
+    for v in lead:
+        planes *= v
+    out = torch.empty(tuple(lead) + (2 * H, 2 * W), device=x.device, dtype=torch.float32)
+    check(_lib.load().mvs_upsample_bicubic2x_f32(ptr(x), planes, H, W, ptr(out), stream()),
+          "mvs_upsample_bicubic2x_f32")
+    return out
+
+
+def cvp_refine_hypotheses(depth_up, K_ref, K_src0, E_ref, E_src0, d=4, pixel_interval=1.0):
+    """calDepthHypo in test mode (modules.py:147-219) entirely on the device: per batch item the fp64
+    camera algebra (mvs_cvp_hypothesis_mats_f64), the per-pixel fp64 epipolar step and its mean
+    (mvs_cvp_interval_sum_f64) and depth_up + k * interval (mvs_cvp_hypotheses_f32).
+    depth_up [B,H,W] -> [B,2d,H,W]."""
+    depth_up = _f32c(depth_up)
+    B, H, W = depth_up.shape
+    dev = depth_up.device
+    lib = _lib.load()
+    out = torch.empty((B, 2 * d, H, W), device=dev, dtype=torch.float32)
+    mats = torch.empty((B, 59), device=dev, dtype=torch.float64)
+    total = torch.empty((B,), device=dev, dtype=torch.float64)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    Kr, Ks, Er, Es = (_f32c(t) for t in (K_ref, K_src0, E_ref, E_src0))
+    for b in range(B):
+        check(lib.mvs_cvp_hypothesis_mats_f64(ptr(Kr[b]), ptr(Ks[b]), ptr(Er[b]), ptr(Es[b]), vp(mats[b]), stream()),
+              "mvs_cvp_hypothesis_mats_f64")
+        check(lib.mvs_cvp_interval_sum_f64(ptr(depth_up[b]), vp(mats[b]), H, W, float(pixel_interval), vp(total[b:]),
+                                           stream()), "mvs_cvp_interval_sum_f64")
+        check(lib.mvs_cvp_hypotheses_f32(ptr(depth_up[b]), vp(total[b:]), H, W, d, ptr(out[b]), stream()),
+              "mvs_cvp_hypotheses_f32")
+    return out
+
+
 COSTREG_ORDER = ("conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv9", "conv11", "prob")
 _costreg_ws = {}
 

@@ -18,27 +18,68 @@ from ..datasets import find_dataset_def, save_pfm
 from ..models import MVSNet, load_reference_checkpoint
 
 
+def _write(outdir, names, depth, conf):
+    for name, d, c in zip(names, depth, conf):
+        for kind, arr in (("depth_est", d), ("confidence", c)):
+            path = os.path.join(outdir, name.format(kind, ".pfm"))
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            save_pfm(path, arr)
+
+
 def save_depth(args):
-    dataset = find_dataset_def(args.dataset)(args.testpath, args.testlist, "test", args.nviews, args.numdepth,
-                                             args.interval_scale)
-    loader = torch.utils.data.DataLoader(dataset, args.batch_size, shuffle=False, num_workers=args.num_workers,
-                                         drop_last=False)
     model = MVSNet(refine=False)
     if args.loadckpt:
         load_reference_checkpoint(model, torch.load(args.loadckpt, map_location="cpu"))
     model = model.cuda().eval()
+    if args.device_pipeline:
+        # images decoded once per scan, uploaded as uint8, normalised / cropped / transposed and the
+        # projection matrices composed on the GPU; PFM writing on a worker thread (datasets/device_pipeline.py)
+        from concurrent.futures import ThreadPoolExecutor
+        from ..datasets.device_pipeline import DeviceScanPipeline
+        pipe = DeviceScanPipeline(args.testpath, args.testlist, args.nviews, args.numdepth, args.interval_scale,
+                                  decode_workers=args.decode_workers or None)
+        writer, ring, RING = ThreadPoolExecutor(max_workers=2), [], 8
+
+        def flush(slot):
+            ev, buf, names = slot
+            ev.synchronize()
+            _write(args.outdir, names, buf[0].numpy().copy(), buf[1].numpy().copy())
+
+        pending = []
+        with torch.no_grad():
+            for it, sample in enumerate(pipe):
+                out = model(sample["imgs"], sample["proj_matrices"], sample["depth_values"])
+                # results leave through a ring of pinned buffers: the launching thread never waits
+                # for the GPU, it runs whole reference views ahead of it
+                if len(ring) < RING:
+                    ring.append(torch.empty((2,) + tuple(out["depth"].shape), dtype=torch.float32).pin_memory())
+                    buf = ring[-1]
+                else:
+                    pending[it - RING].result()          # that slot's file has been written
+                    buf = ring[it % RING]
+                buf[0].copy_(out["depth"], non_blocking=True)
+                buf[1].copy_(out["photometric_confidence"], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                pending.append(writer.submit(flush, (ev, buf, sample["filename"])))
+                if not args.quiet:
+                    print(f"Iter {it}/{len(pipe)}")
+        for p in pending:
+            p.result()
+        return
+    dataset = find_dataset_def(args.dataset)(args.testpath, args.testlist, "test", args.nviews, args.numdepth,
+                                             args.interval_scale)
+    loader = torch.utils.data.DataLoader(dataset, args.batch_size, shuffle=False, num_workers=args.num_workers,
+                                         drop_last=False)
     with torch.no_grad():
         for it, sample in enumerate(loader):
             out = model(sample["imgs"].cuda(non_blocking=True), sample["proj_matrices"].cuda(non_blocking=True),
                         sample["depth_values"].cuda(non_blocking=True))
             depth = out["depth"].cpu().numpy().astype(np.float32)
             conf = out["photometric_confidence"].cpu().numpy().astype(np.float32)
-            print(f"Iter {it}/{len(loader)}")
-            for name, d, c in zip(sample["filename"], depth, conf):
-                for kind, arr in (("depth_est", d), ("confidence", c)):
-                    path = os.path.join(args.outdir, name.format(kind, ".pfm"))
-                    os.makedirs(os.path.dirname(path), exist_ok=True)
-                    save_pfm(path, arr)
+            if not args.quiet:
+                print(f"Iter {it}/{len(loader)}")
+            _write(args.outdir, sample["filename"], depth, conf)
 
 
 def main(argv=None):
@@ -53,6 +94,10 @@ def main(argv=None):
     ap.add_argument("--num_workers", type=int, default=4)
     ap.add_argument("--loadckpt", default=None)
     ap.add_argument("--outdir", default="./outputs")
+    ap.add_argument("--device_pipeline", action="store_true",
+                    help="decode each image once per scan, normalise / crop / transpose on the GPU (batch size 1)")
+    ap.add_argument("--decode_workers", type=int, default=0)
+    ap.add_argument("--quiet", action="store_true")
     save_depth(ap.parse_args(argv))
 
 

@@ -1169,3 +1169,42 @@ def test_tensor_on_other_device_is_rejected(dev):
     t = torch.zeros(4, device="cuda:1")
     with pytest.raises(_lib.MvsHipError):
         _lib.ptr(t)
+
+
+# ------------------------------------------------ CVP-MVSNet glue kernels
+@pytest.mark.parametrize("shape", [(2, 3, 36, 52), (1, 3, 37, 51), (5, 1, 8, 10)])
+def test_downsample_bilinear_half_bit_equal_to_aten_cpu(dev, shape):
+    """net.py:45: F.interpolate(img, scale_factor=0.5, mode='bilinear') on the CPU is the reference."""
+    from mvs_amd import ops
+    x = torch.rand(shape, generator=torch.Generator().manual_seed(1))
+    want = torch.nn.functional.interpolate(x, scale_factor=0.5, mode="bilinear", align_corners=None)
+    got = ops.downsample_bilinear_half(x.to(dev)).cpu()
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("shape", [(1, 33, 47), (2, 5, 4), (1, 66, 120)])
+def test_upsample_bicubic2x_vs_aten_cpu(dev, shape):
+    """net.py:171: F.interpolate(depth[None], scale_factor=2, mode='bicubic') on depths of 400-800 mm
+    (fp32 ulp 6e-5): within 2.5e-4 of ATen's CPU kernel (its vector code sums in another order)."""
+    from mvs_amd import ops
+    x = torch.rand(shape, generator=torch.Generator().manual_seed(2)) * 400 + 400
+    want = torch.nn.functional.interpolate(x[None], scale_factor=2, mode="bicubic", align_corners=None)[0]
+    got = ops.upsample_bicubic2x(x.to(dev)).cpu()
+    assert got.shape == want.shape and float((got - want).abs().max()) < 2.5e-4
+
+
+def test_cvp_refine_hypotheses_kernels_vs_torch_fp64_mirror(dev):
+    """calDepthHypo (modules.py:147-219): device-side fp64 algebra + epipolar step + hypotheses vs the
+    fp64 torch restatement of the reference's lines (refine_hypotheses), on CPU."""
+    from mvs_amd import ops, synth
+    from mvs_amd.models.cvp_mvsnet import refine_hypotheses
+    cams = {k: torch.from_numpy(v) for k, v in synth.cvp_cameras(2, 128, 160, batch=2).items()}
+    g = torch.Generator().manual_seed(5)
+    depth = torch.rand((2, 64, 80), generator=g) * 300 + 500
+    K_ref = cams["ref_in"].clone(); K_ref[:, :2] /= 2
+    K_src = cams["src_in"][:, 0].clone(); K_src[:, :2] /= 2
+    want = refine_hypotheses(depth, K_ref, K_src, cams["ref_ex"], cams["src_ex"][:, 0])
+    got = ops.cvp_refine_hypotheses(depth.to(dev), K_ref.to(dev), K_src.to(dev), cams["ref_ex"].to(dev),
+                                    cams["src_ex"][:, 0].to(dev)).cpu()
+    assert got.shape == want.shape == (2, 8, 64, 80)
+    assert float((got - want).abs().max()) < 2e-4

@@ -184,3 +184,59 @@ def test_fuse_tool_masks_and_point_cloud(scan, tmp_path):
     assert np.array_equal(rgb[:int(m0.sum())], (img0[1:-16:4, 1::4, :][m0] * 255).astype(np.uint8))
     g1 = np.array(Image.open(os.path.join(outdir, "scan1", "mask", "00000001_geo.png"))) > 0
     assert not g1[110:130, 160:190].any()                     # view 1's wrong depths pass nowhere
+
+
+@pytest.mark.gpu
+def test_device_pipeline_tensors_bit_equal_to_reference_loader(scan):
+    """uint8 upload + mvs_images_u8_to_planar_f32 + mvs_proj_matrices_f32 give the
+    tensors the reference's loader gave (g10_io.npz), and every sample equals the host loader's."""
+    import torch
+    from mvs_amd.datasets import MVSDataset
+    from mvs_amd.datasets.device_pipeline import DeviceScanPipeline
+    root, listfile = scan
+    g = load_golden("g10_io")
+    ds = MVSDataset(root, listfile, "test", 3, 192, 1.06)
+    pipe = DeviceScanPipeline(root, listfile, 3, 192, 1.06)
+    samples = list(pipe)
+    torch.cuda.synchronize()
+    assert len(samples) == len(ds) == int(g["n_samples"]) and pipe.stats["decoded"] == 3   # each JPEG once
+    for i, s in enumerate(samples):
+        host = ds[i]
+        assert np.array_equal(s["imgs"][0].cpu().numpy(), host["imgs"])                     # bit-identical pixels
+        assert np.array_equal(s["proj_matrices"][0].cpu().numpy(), host["proj_matrices"])
+        assert np.array_equal(s["depth_values"][0].cpu().numpy(), host["depth_values"])
+        assert s["filename"][0] == host["filename"]
+    for i in (0, len(ds) - 1):
+        assert np.array_equal(samples[i]["proj_matrices"][0].cpu().numpy(), g[f"s{i}_proj"])
+        assert np.array_equal(samples[i]["imgs"][0].cpu().numpy()[:, :, ::97, ::131], g[f"s{i}_imgs_probe"])
+
+
+@pytest.mark.gpu
+def test_images_u8_kernel_odd_sizes(scan):
+    """widths that are not multiples of 4, crops on both axes"""
+    import torch
+    from mvs_amd import ops
+    rng = np.random.default_rng(3)
+    for (n, hs, ws, h, w) in ((2, 9, 13, 7, 13), (1, 5, 16, 5, 10), (3, 4, 7, 3, 5)):
+        a = rng.integers(0, 256, (n, hs, ws, 3), dtype=np.uint8)
+        got = ops.images_u8_to_planar(torch.from_numpy(a).cuda(), h, w).cpu().numpy()
+        want = (a.astype(np.float32) / 255.)[:, :h, :w].transpose(0, 3, 1, 2)
+        assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_eval_tool_device_pipeline_writes_the_same_files(scan, tmp_path):
+    import torch
+    from mvs_amd import synth
+    from mvs_amd.tools import eval_depth
+    root, listfile = scan
+    ckpt = str(tmp_path / "m.ckpt")
+    torch.save({"model": synth.random_state_dict(0)}, ckpt)
+    common = ["--testpath", root, "--testlist", listfile, "--loadckpt", ckpt, "--nviews", "3", "--numdepth", "48", "--quiet"]
+    eval_depth.main(common + ["--outdir", str(tmp_path / "a"), "--num_workers", "0"])
+    eval_depth.main(common + ["--outdir", str(tmp_path / "b"), "--device_pipeline"])
+    for kind in ("depth_est", "confidence"):
+        for i in range(3):
+            fa = tmp_path / "a" / "scan1" / kind / f"{i:08d}.pfm"
+            fb = tmp_path / "b" / "scan1" / kind / f"{i:08d}.pfm"
+            assert fa.read_bytes() == fb.read_bytes()
