@@ -280,6 +280,17 @@ int mvs_geo_consistency_f32(const float *depth_ref, const float *depth_src, cons
                             int W, unsigned char *mask, float *depth_reprojected, float *xy_src,
                             int *geo_mask_sum, double *depth_averaged, void *stream);
 
+/* Depth-map fusion (fusibile/fusibile.cu:138-277, launched per reference camera as
+ * fusibile.cu:425-430 does).  normals_depths [N,H,W,4] = (nx, ny, nz, depth) per view; colors [N,H,W,4] or
+ * NULL; cams [N,28] = per view P (3x4 row major), inverse(P[:, :3]) (3x3), P[:, 3], camera centre, f.
+ * For reference view `ref`: out_points / out_normals (/ out_colors) [H,W,4]; a pixel without a fused point
+ * gets zeros (the host keeps points whose three coordinates are non-zero, fusibile.cu:309).
+ * Parity of this entry point is unpinned (CUDA texture filtering restated from its documentation): see
+ * the header of csrc/fusibile.hip. */
+int mvs_fusibile_fuse_f32(const float *normals_depths, const float *colors, const float *cams, int N, int H,
+                          int W, int ref, float disp_thresh, float normal_thresh, int num_consistent,
+                          float *out_points, float *out_normals, float *out_colors, void *stream);
+
 /* ---- FeatureNet layers -- mvsnet.py:8-45 ("next" row 1) ---- */
 /* One 2D convolution of FeatureNet on the fp32 matrix cores: k x k (3 stride 1, or 5
  * stride 2), pad k/2, no conv bias, then y = acc*scale[co] + shift[co] (BatchNorm(eval)
