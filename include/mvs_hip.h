@@ -121,6 +121,7 @@ int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *src_feas,
  * is sampled -- and the workspace holds the queue of its cold path (waves whose footprint does
  * not fit LDS are served by a second, gather-based kernel).  Every other shape takes the kernels
  * of mvs_costvol_variance_fwd_f32 and ignores the workspace (which may then be NULL / 0 bytes:
+ * the persistent kernel also reads channels-last maps [B,H,W,C] (MVS_LAYOUT_NHWC) in place;
  * mvs_costvol_variance_workspace_bytes returns 0).  Results are bit-identical to
  * mvs_costvol_variance_fwd_f32 unless flags has MVS_SWEEP_FAST: coordinates from one refined
  * reciprocal per voxel and view with the reference's normalise / un-normalise pair
@@ -296,8 +297,10 @@ int mvs_fusibile_fuse_f32(const float *normals_depths, const float *colors, cons
  * stride 2), pad k/2, no conv bias, then y = acc*scale[co] + shift[co] (BatchNorm(eval)
  * folded; for the last layer scale = NULL and shift = the conv bias) and the activation
  * `relu`: 0 none, 1 ReLU, 2 LeakyReLU(0.1) (CVP-MVSNet/models/modules.py:22-26).
- * in: [B,H,W,Cin] channels-last, or with in_planar the reference's [B,3,H,W] image
- * (3-channel layer only).  out: [B,Ho,Wo,Cout] channels-last.  Supported (Cin,Cout,k,
+ * layout_flags: bit 0 -- in is the reference's planar [B,3,H,W] image (3-channel layer only) instead
+ * of channels-last [B,H,W,Cin]; bit 1 -- out is 4-channel blocked [B,Cout/4,Ho,Wo,4] (MVS_LAYOUT_C4,
+ * what the persistent sweep kernel copies fastest; layers of the persistent kernel only) instead of
+ * channels-last [B,Ho,Wo,Cout].  Supported (Cin,Cout,k,
  * stride): (3,8,3,1) (8,8,3,1) (8,16,5,2) (16,16,3,1) (16,32,5,2) (32,32,3,1); the
  * CasMVSNet FPN heads (32,32,1,1) (16,32,1,1) (8,32,1,1) (32,16,3,1) (32,8,3,1); the
  * CVP-MVSNet pyramid (3,64,3,1) (64,64,3,1) (64,32,3,1) (32,16,3,1).
@@ -307,7 +310,7 @@ int mvs_fusibile_fuse_f32(const float *normals_depths, const float *colors, cons
  * 1x1 convolution; stride-1 layers of the persistent kernel with even H, W only. */
 int mvs_conv2d_f32(const float *in, const float *packed_weight, const float *scale,
                    const float *shift, const float *coarse, int relu, int B, int Cin, int Cout, int H,
-                   int W, int ksize, int stride, int in_planar, float *out, void *stream);
+                   int W, int ksize, int stride, int layout_flags, float *out, void *stream);
 int64_t mvs_conv2d_packed_weight_floats(int Cin, int Cout, int ksize, int stride);
 /* weight: PyTorch layout (Cout,Cin,k,k) -> MFMA A-fragment order. */
 int mvs_conv2d_pack_weights_f32(const float *weight, int Cin, int Cout, int ksize, int stride,

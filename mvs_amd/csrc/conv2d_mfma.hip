@@ -374,9 +374,15 @@ int conv2d_pack_launch(const float *weight, int Cin, int Cout, int ksize, int st
 
 int conv2d_launch(const float *in, const float *packed, const float *scale, const float *shift,
                   const float *coarse, int relu, int B, int Cin, int Cout, int H, int W, int ksize, int stride,
-                  int in_planar, float *out, hipStream_t st) {
+                  int layout_flags, float *out, hipStream_t st) {
+    const int in_planar = layout_flags & 1, out_c4 = (layout_flags >> 1) & 1;
     Persist2Info pi;
     const bool persistent = !in_planar && lookup_persist2(Cin, Cout, ksize, stride, pi);
+    if (out_c4 && (!persistent || !persist2_enabled() || coarse || (Cout & 3))) {
+        set_error("mvs_conv2d_f32: 4-channel blocked output is written by the persistent kernel's layers only "
+                  "(Cin=%d Cout=%d k=%d stride=%d)", Cin, Cout, ksize, stride);
+        return MVS_EUNSUPPORTED;
+    }
     if (coarse && (!persistent || stride != 1 || (H & 1) || (W & 1))) {
         set_error("mvs_conv2d_f32: the upsampled residual needs a stride-1 layer of the persistent kernel "
                   "and even H, W (Cin=%d Cout=%d k=%d)", Cin, Cout, ksize);
@@ -395,7 +401,7 @@ int conv2d_launch(const float *in, const float *packed, const float *scale, cons
         a.tiles_x = (a.Wo + pi.xout - 1) / pi.xout;
         a.tiles_y = (a.Ho + pi.ty - 1) / pi.ty;
         a.tiles_z = B;
-        a.relu = relu; a.in_c8 = 0; a.ystrip = 4;
+        a.relu = relu; a.in_c8 = 0; a.ystrip = 4; a.out_c4 = out_c4;
         const int64_t nt = (int64_t)a.tiles_x * a.tiles_y * a.tiles_z;
         if (nt <= 0 || nt > 0x7fffffffLL) return bare_error(MVS_EINVAL, __func__, __LINE__);
         const int n_cu = device_cu_count();
@@ -459,11 +465,11 @@ extern "C" int mvs_conv2d_pack_weights_f32(const float *weight, int Cin, int Cou
 
 extern "C" int mvs_conv2d_f32(const float *in, const float *packed_weight, const float *scale,
                               const float *shift, const float *coarse, int relu, int B, int Cin, int Cout,
-                              int H, int W, int ksize, int stride, int in_planar, float *out, void *stream) {
+                              int H, int W, int ksize, int stride, int layout_flags, float *out, void *stream) {
     if (!in || !packed_weight || !out || B <= 0 || H <= 0 || W <= 0) {
         set_error("mvs_conv2d_f32: invalid argument");
         return MVS_EINVAL;
     }
     return conv2d_launch(in, packed_weight, scale, shift, coarse, relu, B, Cin, Cout, H, W, ksize, stride,
-                         in_planar, out, as_stream(stream));
+                         layout_flags, out, as_stream(stream));
 }

@@ -25,6 +25,7 @@ struct ConvArgs {
     int in_c8;   // input is [B,D,H,C/8,W,8] (8-channel blocked) instead of [B,D,H,W,C]
     int ystrip;  // tile order: 0 = x, y, z; n > 0 = y within strips of n tile rows, then z, then x
     int res_up2; // residual is [B,Do,Ho/2,Wo/2,C]: added through a nearest x2 upsample in y and x (FPN top-down path)
+    int out_c4 = 0;   // 2D layers: write [image,C/4,Ho,Wo,4] (4-channel blocked, the sweep kernel's fastest input) instead of [image,Ho,Wo,C]
 };
 
 // XCD-aware bijective remap: consecutive tiles land on the same XCD (same L2)
@@ -375,7 +376,11 @@ __global__ __launch_bounds__(512) void conv3d_c8_persistent_kernel(ConvArgs a, i
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * 0.1f;
                     }
-                    const int64_t o = ((((int64_t)cur.b * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * COUT + c0;
+                    // out_c4: a lane's four channels are one block of [image,C/4,Ho,Wo,4]; the 16 lanes of an
+                    // MFMA column group then write 256 contiguous bytes
+                    const int64_t o = a.out_c4
+                        ? (((((int64_t)cur.b * a.Do + oz) * (COUT / 4) + (c0 >> 2)) * a.Ho + oy) * a.Wo + ox) * 4
+                        : ((((int64_t)cur.b * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * COUT + c0;
                     if (a.residual && !(ABL & 16)) {
                         const int64_t ro = a.res_up2 ? ((((int64_t)cur.b * a.Do + oz) * (a.Ho >> 1) + (oy >> 1)) * (a.Wo >> 1) +
                                                         (ox >> 1)) * COUT + c0 : o;

@@ -1326,7 +1326,9 @@ static int persist_waves(int *flags, int *quads) {
 
 extern "C" size_t mvs_costvol_variance_workspace_bytes(int depth_mode, int B, int V, int C, int D,
                                                        int H, int W, int fea_layout) {
-    if ((fea_layout != MVS_LAYOUT_C16 && fea_layout != MVS_LAYOUT_C4) || B <= 0 || D <= 0 || H <= 1 || W <= 1) return 0;
+    if ((fea_layout != MVS_LAYOUT_C16 && fea_layout != MVS_LAYOUT_C4 && fea_layout != MVS_LAYOUT_NHWC) || B <= 0 || D <= 0 ||
+        H <= 1 || W <= 1)
+        return 0;
     int flags, quads;
     const int nw = persist_waves(&flags, &quads);
     if (nw <= 0) return 0;
@@ -1342,14 +1344,14 @@ extern "C" int mvs_costvol_variance_fwd_ws_f32(const float *ref_fea, const float
                                                size_t workspace_bytes, void *stream) {
     const bool c4 = fea_layout == MVS_LAYOUT_C4;
     if (ref_fea && src_feas && rot_trans && depth_values && out_var && B > 0 && D > 0 && H > 1 &&
-        W > 1 && depth_mode == 0 && (fea_layout == MVS_LAYOUT_C16 || c4) &&
+        W > 1 && depth_mode == 0 && (fea_layout == MVS_LAYOUT_C16 || c4 || fea_layout == MVS_LAYOUT_NHWC) &&
         (out_layout == MVS_LAYOUT_C8 || out_layout == MVS_LAYOUT_NHWC)) {
         int tune, quads;
         const int nw = persist_waves(&tune, &quads);
         if (nw > 0) {
             const SweepParams p = make_params(B, V, C, D, H, W, depth_mode, align_corners, alias_quirk);
             const int rc = launch_variance_persist(ref_fea, src_feas, rot_trans, depth_values, p, out_var,
-                                                   out_layout == MVS_LAYOUT_C8, c4, flags & MVS_SWEEP_FAST,
+                                                   out_layout == MVS_LAYOUT_C8, c4 ? 1 : (fea_layout == MVS_LAYOUT_NHWC ? 2 : 0), flags & MVS_SWEEP_FAST,
                                                    nw, quads, tune, workspace, workspace_bytes, as_stream(stream));
             if (rc == MVS_OK) return check_launch("mvs_costvol_variance_fwd_ws_f32(persistent)");
             if (rc != MVS_EUNSUPPORTED) return rc;

@@ -64,7 +64,7 @@ struct PersistArgs {
     SweepParams p;
     int tiles_x, tiles_y, nchunks, total_tiles;
     int out_c8, flags;
-    int fea_c4;             // features [B,C/4,H,W,4] (1) or [B,C/16,H,W,16] (0)
+    int fea_c4;             // features: 0 = [B,C/16,H,W,16], 1 = [B,C/4,H,W,4], 2 = [B,H,W,C]
     float sx, ox, sy, oy;   // FAST: ix = (X/Z) * sx + ox
 };
 constexpr int kPFlagLinearLanes = 1;   // tuning: lane = (x = lane & 15, y = lane >> 4)
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void variance_fwd_cold_kernel(PersistArgs a, i
     const int lane = threadIdx.x & 63;
     const int plane = p.H * p.W, ngroups = p.C >> 4;
     const size_t grp_floats = (size_t)plane * 16, map_floats = (size_t)plane * p.C;
-    const unsigned tex = a.fea_c4 ? 4u : 16u;   // floats between neighbouring texels of one quad
+    const unsigned tex = a.fea_c4 == 1 ? 4u : a.fea_c4 == 2 ? (unsigned)p.C : 16u;   // floats between neighbouring texels of one quad
     const float rV = 1.0f / p.fV;
     for (unsigned rec = blockIdx.x * 4 + (threadIdx.x >> 6); rec < count; rec += gridDim.x * 4) {
         const unsigned q = a.queue[1 + rec];
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void variance_fwd_cold_kernel(PersistArgs a, i
         for (int gk = 0; gk < ngroups * 4; ++gk) {
             const int g = gk >> 2, k = gk & 3;
             // quad gk of a feature map: C4 = plane gk of [C/4,H,W,4]; C16 = quad k of block g of [C/16,H,W,16]
-            const size_t qbase = a.fea_c4 ? (size_t)gk * plane * 4 : (size_t)g * grp_floats + k * 4;
+            const size_t qbase = a.fea_c4 == 1 ? (size_t)gk * plane * 4 : a.fea_c4 == 2 ? (size_t)gk * 4 : (size_t)g * grp_floats + k * 4;
             const float4 r4 = *reinterpret_cast<const float4 *>(
                 a.ref16 + (size_t)b * map_floats + qbase + (size_t)pix * tex);
             float S[4] = {r4.x, r4.y, r4.z, r4.w}, Q[4];
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
     const unsigned lds_base = (unsigned)(uintptr_t)lds_raw;
     const int plane = p.H * p.W;
     const int nstage = p.C / GC;                 // stages per tile
-    const unsigned tstride = a.fea_c4 ? 16u : 64u;   // bytes between neighbouring texels of one quad
+    const unsigned tstride = a.fea_c4 == 1 ? 16u : a.fea_c4 == 2 ? (unsigned)p.C * 4u : 64u;   // bytes between neighbouring texels of one quad
 
     int lx, ly;   // this lane's pixel inside the 16x4 tile
     if (a.flags & kPFlagLinearLanes) {
@@ -369,8 +369,9 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
     auto issue_dma = [&](int st, unsigned buf_off) {
         if (a.flags & kPFlagNoDma) return;
         const int q = st * NQ + kq;
-        const unsigned qoff = a.fea_c4 ? (unsigned)q * (unsigned)plane * 16u
-                                       : (unsigned)(q >> 2) * (unsigned)plane * 64u + (unsigned)(q & 3) * 16u;
+        const unsigned qoff = a.fea_c4 == 1 ? (unsigned)q * (unsigned)plane * 16u
+                            : a.fea_c4 == 2 ? (unsigned)q * 16u
+                                            : (unsigned)(q >> 2) * (unsigned)plane * 64u + (unsigned)(q & 3) * 16u;
         const unsigned boff = (unsigned)pb * map_bytes + qoff;
         const unsigned ldst = lds_base + buf_off + (unsigned)kq * cap * 16u;
 #pragma unroll

@@ -47,7 +47,7 @@ class DeviceScanPipeline:
         with Image.open(path) as im:
             a = np.asarray(im.convert("RGB") if im.mode != "RGB" else im)
         assert a.shape[:2] == self.image_hw, f"{path}: {a.shape[:2]} != {self.image_hw}"
-        dst.copy_(torch.from_numpy(np.ascontiguousarray(a)) if not a.flags.writeable else torch.from_numpy(a))
+        np.copyto(dst.numpy(), a)     # decoder buffer -> pinned staging buffer, one copy
 
     def _prepare(self, scan):
         metas = self.metas[scan]

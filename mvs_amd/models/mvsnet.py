@@ -103,13 +103,15 @@ class FeatureNet(nn.Module):
         y = F.conv2d(x, self.feature.weight, self.feature.bias, 1, 1)
         return y.permute(0, 2, 3, 1).contiguous()
 
-    def forward_hip(self, imgs_nchw):
-        """[N,3,H,W] image batch (the reference's layout) -> [N,H/4,W/4,32] channels-last."""
+    def forward_hip(self, imgs_nchw, out_c4=False):
+        """[N,3,H,W] image batch (the reference's layout) -> [N,H/4,W/4,32] channels-last, or with
+        out_c4 the last layer's epilogue writes 4-channel blocks [N,8,H/4,W/4,4] (MVS_LAYOUT_C4)."""
         x = imgs_nchw
-        for i, p in enumerate(self._hip_params()):
+        P = self._hip_params()
+        for i, p in enumerate(P):
             with ops.stage("feature." + p["name"]):
                 x = ops.conv2d(x, p["packed"], p["cin"], p["cout"], p["k"], p["stride"], p["scale"],
-                               p["shift"], p["relu"], planar=(i == 0))
+                               p["shift"], p["relu"], planar=(i == 0), out_c4=(out_c4 and i == len(P) - 1))
         return x
 
 
@@ -345,8 +347,18 @@ class MVSNet(nn.Module):
             flat = imgs.reshape(B * V, *imgs.shape[2:])
             # eval: running-stat BN is per-sample, so all B*V views go through FeatureNet
             # as one batch (same values as the reference's per-view loop, mvsnet.py:146)
+            half = lambda n: (n - 1) // 2 + 1            # a 5x5 stride-2 layer with padding 2
+            h, w, C = half(half(imgs.shape[3])), half(half(imgs.shape[4])), 32
+            use_lds = self.variance_impl == "lds"
+            # shared depth planes: the persistent sweep kernel copies 4-channel blocked maps fastest, and
+            # FeatureNet's last layer writes them directly (a lane of its MFMA epilogue holds 4 channels)
+            c4 = use_lds and ops.variance_persistent_supported(depth_values, B, V, C, h, w)
+            f4 = None
             if self.feature_impl == "hip" and self.feature.hip_supported():
-                f = self.feature.forward_hip(flat)           # [B*V,h,w,32]: HIP 2D MFMA kernels
+                if c4 and ops.conv2d_persistent_enabled():
+                    f4 = self.feature.forward_hip(flat, out_c4=True)     # [B*V,8,h,w,4]
+                else:
+                    f = self.feature.forward_hip(flat)                   # [B*V,h,w,32]: HIP 2D MFMA kernels
             else:
                 with ops.stage("feature"):
                     # PyTorch-ROCm in channels_last: MIOpen's NHWC kernels are the faster
@@ -358,17 +370,17 @@ class MVSNet(nn.Module):
                         self._feature_cl = True
                     f = self.feature(ops.nchw_to_nhwc(flat).permute(0, 3, 1, 2))
                     f = f.permute(0, 2, 3, 1)                # [B*V,h,w,32] view of NHWC storage
-            h, w, C = f.shape[1], f.shape[2], f.shape[3]
             with ops.stage("rot_trans"):
                 rts = rt_job.result() if rt_job is not None else \
                     ops.rot_trans_all(proj_matrices, self.proj_where)   # [V-1,B,12]
             c8 = self.cost_regularization.wants_c8_input()
-            use_lds = self.variance_impl == "lds" and C % 16 == 0
             with ops.stage("to_channels_last"):
-                if use_lds:
+                if f4 is not None:     # [B*V,8,h,w,4] -> [V,B,8,h,w,4]: a view for one sample
+                    f16 = f4.reshape(B, V, C // 4, h, w, 4).transpose(0, 1).contiguous()
+                elif use_lds:
                     # [B*V,h,w,C] -> [V,B,C/blk,h,w,blk]: 4-channel blocks for the persistent sweep
                     # kernel (shared depth planes), 16-channel blocks for the per-tile kernels
-                    blk = 4 if ops.variance_persistent_supported(depth_values, B, V, C, h, w) else 16
+                    blk = 4 if c4 else 16
                     f16 = f.reshape(B, V, h, w, C // blk, blk).permute(1, 0, 4, 2, 3, 5).contiguous()
                 else:
                     fcl = f.reshape(B, V, h, w, C).transpose(0, 1).contiguous()   # [V,B,h,w,C]

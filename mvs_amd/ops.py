@@ -501,6 +501,27 @@ def costvol_variance_c16(ref16, srcs16, rts, depth_values, align_corners=False, 
     return out
 
 
+def costvol_variance_nhwc_ws(ref_cl, srcs_cl, rts, depth_values, align_corners=False, out_c8=False, fast=False):
+    """Channels-last maps [B,H,W,C] / [V-1,B,H,W,C] through the workspace entry: the persistent kernel
+    reads them in place (no re-blocking copy) when the shape is its own, else the gather kernel runs."""
+    ref_cl, srcs_cl, depth_values = _f32c(ref_cl), _f32c(srcs_cl), _f32c(depth_values)
+    B, H, W, C = ref_cl.shape
+    V = srcs_cl.shape[0] + 1
+    D = depth_values.shape[1]
+    shape = (B, D, H, C // 8, W, 8) if out_c8 else (B, D, H, W, C)
+    out = torch.empty(shape, device=ref_cl.device, dtype=torch.float32)
+    lib = _lib.load()
+    mode = _depth_mode(depth_values)
+    need = lib.mvs_costvol_variance_workspace_bytes(mode, B, V, C, D, H, W, MVS_LAYOUT_NHWC)
+    ws = _variance_workspace(ref_cl.device, need) if need else None
+    check(lib.mvs_costvol_variance_fwd_ws_f32(
+        ptr(ref_cl), ptr(srcs_cl), ptr(rts), ptr(depth_values), mode, B, V, C, D, H, W, int(align_corners), 0,
+        MVS_LAYOUT_NHWC, MVS_LAYOUT_C8 if out_c8 else MVS_LAYOUT_NHWC, 1 if fast else 0, ptr(out),
+        ctypes.c_void_p(ws.data_ptr()) if ws is not None else None, ws.numel() if ws is not None else 0,
+        stream()), "mvs_costvol_variance_fwd_ws_f32")
+    return out
+
+
 def variance_persistent_supported(depth_values, B, V, C, H, W):
     """True when mvs_costvol_variance_fwd_ws_f32 serves this shape with the persistent kernel
     (then 4-channel-blocked features, nchw_to_c4, are its fastest input)."""
@@ -722,6 +743,12 @@ def costreg_forward(x, params, in_c8=False, impl=IMPL_AUTO):
 
 
 # ------------------------------------------------------------ FeatureNet convs
+def conv2d_persistent_enabled():
+    """False when MVS_CONV2D_PERSISTENT=0 selects the per-tile 2D kernels (which write channels-last only)."""
+    import os
+    return os.environ.get("MVS_CONV2D_PERSISTENT", "1") != "0"
+
+
 def conv2d_supported(cin, cout, ksize, stride):
     return bool(_lib.load().mvs_conv2d_supported(cin, cout, ksize, stride))
 
@@ -864,10 +891,12 @@ def bn_relu_cl(x, bn, relu=True, skip=None):
                            bn.momentum, bn.eps, relu)
 
 
-def conv2d(x, packed, cin, cout, ksize, stride, scale=None, shift=None, relu=False, planar=False, coarse=None):
+def conv2d(x, packed, cin, cout, ksize, stride, scale=None, shift=None, relu=False, planar=False, coarse=None,
+           out_c4=False):
     """FeatureNet convolution.  x: [B,H,W,cin] channels-last, or (planar) the [B,3,H,W]
     image.  relu: False/True, or 2 for LeakyReLU(0.1).  coarse: [B,Ho/2,Wo/2,cout], added through
-    a nearest x2 upsample (FPN top-down step).  Returns [B,Ho,Wo,cout] channels-last."""
+    a nearest x2 upsample (FPN top-down step).  Returns [B,Ho,Wo,cout] channels-last, or with out_c4
+    the 4-channel blocked [B,cout/4,Ho,Wo,4] (MVS_LAYOUT_C4)."""
     x = _f32c(x)
     if planar:
         B, _, H, W = x.shape
@@ -875,13 +904,13 @@ def conv2d(x, packed, cin, cout, ksize, stride, scale=None, shift=None, relu=Fal
         B, H, W, _ = x.shape
     pad = ksize // 2
     Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
-    out = torch.empty((B, Ho, Wo, cout), device=x.device, dtype=torch.float32)
+    out = torch.empty((B, cout // 4, Ho, Wo, 4) if out_c4 else (B, Ho, Wo, cout), device=x.device, dtype=torch.float32)
     if coarse is not None:
         coarse = _f32c(coarse)
         if tuple(coarse.shape) != (B, Ho // 2, Wo // 2, cout) or Ho % 2 or Wo % 2:
             raise MvsHipError(f"conv2d: coarse {tuple(coarse.shape)} is not half of {(B, Ho, Wo, cout)}")
     check(_lib.load().mvs_conv2d_f32(ptr(x), ptr(packed), ptr(scale), ptr(shift), ptr(coarse), int(relu), B, cin,
-                                     cout, H, W, ksize, stride, int(planar), ptr(out), stream()),
+                                     cout, H, W, ksize, stride, int(planar) | (2 if out_c4 else 0), ptr(out), stream()),
           "mvs_conv2d_f32")
     return out
 

@@ -44,6 +44,8 @@ def main():
     for _ in range(steps):
         out = step()
     torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    groups = None
     if "--profile" in sys.argv:   # kernel breakdown of one steady-state forward
         from torch.profiler import profile, ProfilerActivity
         with profile(activities=[ProfilerActivity.CUDA]) as prof:
@@ -53,14 +55,39 @@ def main():
         print("total kernel ms", round(sum(e.device_time_total for e in rows) / 1e3, 2), file=sys.stderr)
         for e in rows[:30]:
             print(f"{e.key[:120]:120s} n={e.count:4d} ms={e.device_time_total / 1e3:7.2f}", file=sys.stderr)
+        groups = {"feature_pyramid_2d_convs": 0.0, "costreg_3d_convs": 0.0, "sweep_variance": 0.0, "other": 0.0}
+        for e in rows:
+            is2d = "conv2d" in e.key or ("PersistCfg<" in e.key and ", 1, 32, 1, 3>" in e.key)   # one-plane-deep persistent tiles
+            k = ("feature_pyramid_2d_convs" if is2d else "costreg_3d_convs" if "conv3d" in e.key
+                 else "sweep_variance" if "variance" in e.key else "other")
+            groups[k] += e.device_time_total / 1e3
         for name in [r.key for r in rows[:4]]:   # per-launch durations of the heaviest kernels, in launch order
             durs = [round(ev.device_time_total / 1e3, 3) for ev in prof.events() if ev.key == name]
             print(name[:70], durs, file=sys.stderr)
     res = {"config": {"H": H, "W": W, "views": nsrc + 1, "nscale": nscale},
-           "ms_per_ref_view": round((time.perf_counter() - t0) / steps * 1e3, 3),
+           "ms_per_ref_view": round(elapsed / steps * 1e3, 3),
            "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
            "depth_shapes": [list(d.shape) for d in out["depth_est_list"]],
            "finite": bool(all(torch.isfinite(d).all() for d in out["depth_est_list"]))}
+    # algorithmic FLOPs (2 * k^d * Cin * Cout * outputs): the 9-layer pyramid CNN on every view and level
+    # (net.py:22-51) and the refinement U-Net per level (net.py:52-89; its stride-2 level is 1/8 of the voxels)
+    pyr_per_px = 2 * 9 * (3 * 64 + 64 * 64 * 2 + 64 * 32 + 32 * 32 * 2 + 32 * 16 + 16 * 16 * 2)
+    reg_full = 2 * 27 * (16 * 16 * 2 + 16 * 1)                     # 16->16 x2, prob 16->1 at the level's resolution
+    reg_half = 2 * 27 * (16 * 32 + 32 * 32 * 2 + 32 * 64 + 64 * 64 * 2 + 64 * 32) / 8 + 2 * 27 * 32 * 16 / 8
+    flops = {"feature_pyramid": 0.0, "costreg": 0.0}
+    for lvl in range(nscale):
+        px = (H >> lvl) * (W >> lvl)
+        flops["feature_pyramid"] += pyr_per_px * px * (nsrc + 1)
+        flops["costreg"] += (reg_full + reg_half) * px * (48 if lvl == nscale - 1 else 8)
+    total = sum(flops.values())
+    res["algorithmic_TFLOP"] = {k: round(v / 1e12, 3) for k, v in flops.items()}
+    res["achieved_TFLOPs"] = round(total / res["ms_per_ref_view"] / 1e9, 1)
+    res["frac_fp32_mfma_peak"] = round(total / res["ms_per_ref_view"] / 1e9 / 157.3, 3)
+    res["floor_ms_at_fp32_mfma_peak"] = round(total / 157.3e9, 1)
+    if groups is not None:
+        res["kernel_ms_by_group"] = {k: round(v, 2) for k, v in groups.items()}
+        res["group_TFLOPs"] = {"feature_pyramid": round(flops["feature_pyramid"] / groups["feature_pyramid_2d_convs"] / 1e9, 1),
+                               "costreg": round(flops["costreg"] / groups["costreg_3d_convs"] / 1e9, 1)}
     if "--parity" in sys.argv:   # the checker: ATen CPU restatement on the same inputs
         from oracle import torch_ref as tr
         torch.set_num_threads(os.cpu_count())

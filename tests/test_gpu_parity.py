@@ -206,6 +206,9 @@ def test_variance_persistent_kernel_bit_equal_to_per_tile_kernel(dev, case, monk
         for f in (f16, f4):
             assert torch.equal(ops.costvol_variance_c16(f[0], f[1:], rts, dv), want)
             assert torch.equal(ops.costvol_variance_c16(f[0], f[1:], rts, dv, out_c8=True), want8)
+        fcl = feats.permute(0, 1, 3, 4, 2).contiguous()     # [V,B,H,W,C]: read in place by the persistent kernel
+        assert torch.equal(ops.costvol_variance_nhwc_ws(fcl[0], fcl[1:], rts, dv), want)
+        assert torch.equal(ops.costvol_variance_nhwc_ws(fcl[0], fcl[1:], rts, dv, out_c8=True), want8)
         fast = ops.costvol_variance_c16(f4[0], f4[1:], rts, dv, fast=True)
         # white-noise features (|gradient| ~ 1 per texel) x sampling positions within ~1e-4 texel
         assert float((fast - want).abs().max()) < 5e-4 * float(want.abs().max())
@@ -1208,3 +1211,18 @@ def test_cvp_refine_hypotheses_kernels_vs_torch_fp64_mirror(dev):
                                     cams["src_ex"][:, 0].to(dev)).cpu()
     assert got.shape == want.shape == (2, 8, 64, 80)
     assert float((got - want).abs().max()) < 2e-4
+
+
+def test_conv2d_c4_blocked_output_equals_channels_last(dev, weights):
+    """FeatureNet's last layer writing MVS_LAYOUT_C4 (layout_flags bit 1) holds the same numbers as its
+    channels-last output, only re-blocked."""
+    from mvs_amd import ops
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn(3, 37, 50, 32, device=dev, generator=g)
+    w = torch.randn(32, 32, 3, 3, device=dev, generator=g) * 0.1
+    bias = torch.randn(32, device=dev, generator=g)
+    pk = ops.pack_conv2d_weight(w, 1)
+    cl = ops.conv2d(x, pk, 32, 32, 3, 1, None, bias, False)
+    c4 = ops.conv2d(x, pk, 32, 32, 3, 1, None, bias, False, out_c4=True)
+    assert c4.shape == (3, 8, 37, 50, 4)
+    assert torch.equal(c4.permute(0, 2, 3, 1, 4).reshape(3, 37, 50, 32), cl)
