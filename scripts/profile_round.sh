@@ -2,7 +2,7 @@
 # Round profile on the GPU box: rocprofv3 kernel trace + stats of the bench command,
 # then HBM-traffic counters in their own passes (no tracing mixed in).
 # Usage: bash scripts/profile_round.sh r01     (writes gpurun_out/prof_<tag>/...)
-TAG=${1:-r01}
+TAG=${1:-r02}
 cd "$(dirname "$0")/.." ; mkdir -p gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 CMD="python bench.py --steps 10 --warmup 3 --no-cpu-baseline"
@@ -29,7 +29,7 @@ for name in ("fetch", "write"):
                                                  sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]}
 json.dump(out, open(f"{root}/summary.json", "w"), indent=1)
 # per-stage HBM-side traffic for bench.py's roofline.traffic (2*FETCH + WRITE, bytes)
-names = {"costvol_variance": "variance_fwd_dma_kernel", "costreg.conv0": "PersistCfg<32, 8, 2, 4, 4, 3",
+names = {"costvol_variance": "variance_fwd_persist_kernel", "costreg.conv0": "PersistCfg<32, 8, 2, 4, 4, 3",
          "costreg.conv1": "PersistCfg<8, 16, 1, 2, 4, 3", "costreg.conv2": "ConvCfg<16, 16, 0",
          "costreg.conv4": "ConvCfg<32, 32, 0", "costreg.conv11": "DeconvCfg<16, 8",
          "costreg.prob": "conv3d_cout1_kernel<8>", "softmax_regress_conf": "softmax_regress_conf_kernel",
