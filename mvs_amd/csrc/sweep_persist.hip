@@ -63,6 +63,7 @@ struct PersistArgs {
     unsigned *queue;        // workspace: [0] = records, [1..] = (tile << 4 | wave) for the cold kernel
     SweepParams p;
     int tiles_x, tiles_y, nchunks, total_tiles;
+    int nseg, cps;          // a pixel tile's depth chunks are walked in nseg segments of cps chunks (the work units)
     int out_c8, flags;
     int fea_c4;             // features: 0 = [B,C/16,H,W,16], 1 = [B,C/4,H,W,4], 2 = [B,H,W,C]
     float sx, ox, sy, oy;   // FAST: ix = (X/Z) * sx + ox
@@ -73,6 +74,7 @@ constexpr int kPFlagNoBlend = 4;       // tuning
 constexpr int kPFlagNoDma = 8;         // tuning (results are garbage)
 constexpr int kPFlagNoPlan = 16;       // tuning: every tile reuses the first tile's plan (garbage)
 constexpr int kPFlagNoTaps = 32;       // tuning: constant tap set (garbage)
+constexpr int kPFlagContiguous = 64;   // tuning: one contiguous, pixel-tile-major unit range per CU (round 2's first schedule)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int OFF>
@@ -275,16 +277,30 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
         ly = (lane >> 5) * 2 + (in0 ? 0 : 1);
     }
 
-    // this CU's tiles: XCD x owns a contiguous range of the list, its CUs contiguous parts of it
-    int t_begin, t_end;
+    // Work units = (depth segment, pixel tile), segment-major.  XCD x (= blockIdx & 7) owns a contiguous
+    // range of the unit list and its CUs take that range round-robin: the ~32 units in flight on an XCD
+    // are neighbouring pixel tiles at the same depths, their footprints overlap and stay within its 4 MiB
+    // L2 (with one contiguous range per CU the CUs of an XCD were 7 pixel tiles apart and every footprint
+    // came from the Infinity Cache: 2.0 GB of fabric reads per launch).
+    const int ptiles = a.tiles_x * a.tiles_y * p.B, nunits = ptiles * a.nseg;
+    int u, u_end, u_step;
+    const bool contiguous = a.flags & kPFlagContiguous;
     {
-        const int nblk = gridDim.x;
-        const int q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7;
-        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + ((int)blockIdx.x >> 3);
-        t_begin = (int)((int64_t)a.total_tiles * L / nblk);
-        t_end = (int)((int64_t)a.total_tiles * (L + 1) / nblk);
+        const int nb = gridDim.x;
+        if (contiguous) {
+            const int q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7;
+            const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + ((int)blockIdx.x >> 3);
+            u = (int)((int64_t)nunits * L / nb); u_end = (int)((int64_t)nunits * (L + 1) / nb); u_step = 1;
+        } else if ((nb & 7) == 0) {
+            const int xcd = blockIdx.x & 7;
+            u = (int)((int64_t)nunits * xcd / 8) + ((int)blockIdx.x >> 3);
+            u_end = (int)((int64_t)nunits * (xcd + 1) / 8);
+            u_step = nb >> 3;
+        } else {
+            u = blockIdx.x; u_end = nunits; u_step = nb;
+        }
     }
-    if (t_begin >= t_end) return;
+    if (u >= u_end) return;
 
     // camera rows and depth planes into LDS: inside the loop nothing but the copies and the
     // stores touches vector memory, so a counted vmcnt can tell them apart
@@ -293,13 +309,16 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
     __syncthreads();
 
     // ---- the planned tile: the one whose copies are issued next
-    int pdc, ptx, pty, pb;
-    {
-        int qq = t_begin;
-        pdc = qq % a.nchunks; qq /= a.nchunks;
+    int pdc, ptx, pty, pb, seg_end;
+    auto open_unit = [&]() {   // unit u -> its pixel tile and first chunk
+        const int sg = contiguous ? u % a.nseg : u / ptiles;
+        int qq = contiguous ? u / a.nseg : u - sg * ptiles;
         ptx = qq % a.tiles_x; qq /= a.tiles_x;
         pty = qq % a.tiles_y; pb = qq / a.tiles_y;
-    }
+        pdc = sg * a.cps;
+        seg_end = min(pdc + a.cps, a.nchunks);
+    };
+    open_unit();
     int pbx0[NV], pby0[NV], pbw[NV], pbh[NV];
     unsigned pstaged = 0;
     unsigned soff[NV][NP];
@@ -397,7 +416,8 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
     bool stored = false;   // did this wave issue its NST stores after the last copy it issued?
 
 #pragma unroll 1
-    for (int T = t_begin; T < t_end; ++T) {
+    for (;;) {
+        const int T = ((pb * a.tiles_y + pty) * a.tiles_x + ptx) * a.nchunks + pdc;   // tile id (cold-path records)
         // ---- adopt the planned tile; per-voxel homography + tap set of every source view
         const int cb = pb;
         const int px = ptx * kPW + lx, py = pty * kPH + ly, d = pdc * NW + wv;
@@ -443,7 +463,7 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
             a.queue[1 + slot] = ((unsigned)T << 4) | (unsigned)wv;
             stored = false;   // more vector-memory traffic behind the last copy: wait for all of it
         }
-        const bool has_next = T + 1 < t_end;
+        const bool has_next = pdc + 1 < seg_end || u + u_step < u_end;
         const bool any_live = __ballot(live) != 0ull;
         float *const pl = a.out + ((size_t)cb * p.D + cd) * ((size_t)plane * p.C);   // wave-uniform plane base
 
@@ -455,12 +475,9 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
 #pragma unroll
             for (int v = 0; v < NV; ++v) asm volatile("" : "+v"(aoff[v]));
             if (last && has_next) {   // plan the next tile before the barrier: off the critical path
-                if (++pdc == a.nchunks) {
-                    pdc = 0;
-                    if (++ptx == a.tiles_x) {
-                        ptx = 0;
-                        if (++pty == a.tiles_y) { pty = 0; ++pb; }
-                    }
+                if (++pdc == seg_end) {
+                    u += u_step;
+                    open_unit();
                 }
                 if (!(a.flags & kPFlagNoPlan)) plan();
             }
@@ -579,6 +596,7 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
             }
             buf_off ^= kBufBytes;
         }
+        if (!has_next) break;
     }
 }
 
@@ -637,6 +655,15 @@ int launch_variance_persist(const float *ref16, const float *srcs16, const float
     a.tiles_y = (p.H + kPH - 1) / kPH;
     a.nchunks = (p.D + nw - 1) / nw;
     a.total_tiles = (int)persist_tiles(p, nw);
+    {   // segments: enough work units for ~16 per CU (balance), each as long as that allows (a CU that stays
+        // on a pixel tile re-reads its sliding footprints out of L2)
+        const int64_t ptiles = (int64_t)a.tiles_x * a.tiles_y * p.B;
+        const int ncu = device_cu_count();
+        int nseg = (int)((16ll * ncu + ptiles - 1) / ptiles);
+        nseg = nseg < 1 ? 1 : (nseg > a.nchunks ? a.nchunks : nseg);
+        a.cps = (a.nchunks + nseg - 1) / nseg;
+        a.nseg = (a.nchunks + a.cps - 1) / a.cps;
+    }
     a.out_c8 = out_c8;
     a.flags = flags;
     a.fea_c4 = fea_c4;

@@ -71,7 +71,7 @@ def main():
         want8 = run(f16, rts, dv, "0", out_c8=True)
         C4 = True
         f16, rts, dv = scene(B, V, C, D, H, W, seed, wide)
-        for nw in ("16,0,2", "16,0,4", "8,0,2", "8,0,4", "8,64,2"):
+        for nw in ("16,0,2", "8,0,2", "16,64,2"):
             got = run(f16, rts, dv, nw)
             got8 = run(f16, rts, dv, nw, out_c8=True)
             res["equal"][f"{name}/nw{nw}"] = bool(torch.equal(got, want)) and bool(torch.equal(got8, want8))
@@ -98,7 +98,7 @@ def main():
     want = run(f16, rts, dv, "0", out_c8=True)
     f4 = ops.nchw_to_c4(feats)
     byt = (V * 32 * h * w + D + 32 * D * h * w) * 4
-    for persist in ("0", "16,0,2", "8,0,2", "8,64,2", "8,66,2", "8,68,2"):
+    for persist in ("0", "16,0,2", "16,64,2", "16,0,2", "16,64,2", "16,8,2", "16,72,2"):
         for fast in (False, True):
             if persist == "0" and fast:
                 continue
