@@ -15,10 +15,16 @@ namespace mvs {
 // Block = 64 pixels x 4 depth quarters (wave w owns depths [w*D/4, (w+1)*D/4)):
 // 4x the memory-level parallelism of one thread per pixel at the 118k-pixel sizes of
 // this path; the three partial reductions go through a few hundred bytes of LDS.
+// REG = 1 (quarters of up to 64 planes, i.e. D <= 256): a thread's slice of the cost column is
+// read ONCE into registers and the three passes run from there (the memory version re-read it
+// per pass: 276 MB of HBM-side traffic for a 92 MB volume, rocprofv3 FETCH_SIZE); same
+// arithmetic, same results.
+template <int REG>
 __global__ __launch_bounds__(256) void softmax_regress_conf_kernel(
     const float *__restrict__ cost, const float *__restrict__ depth, int depth_mode,
     int clamp_idx, int B, int D, int64_t plane, float *__restrict__ out_depth,
     float *__restrict__ out_conf, float *__restrict__ out_prob) {
+    constexpr int NR = 64;
     __shared__ float s_f[4][64];
     __shared__ double s_d[2][4][64];
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
@@ -29,9 +35,19 @@ __global__ __launch_bounds__(256) void softmax_regress_conf_kernel(
     const int64_t pix = ic % plane;
     const float *c = cost + (int64_t)b * D * plane + pix;
     const int d0 = (int)((int64_t)D * part / 4), d1 = (int)((int64_t)D * (part + 1) / 4);
+    float v[REG ? NR : 1];
+    if constexpr (REG) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) v[k] = d0 + k < d1 ? c[(int64_t)(d0 + k) * plane] : -INFINITY;
+    }
     // max
     float m = -INFINITY;
-    for (int d = d0; d < d1; ++d) m = fmaxf(m, c[(int64_t)d * plane]);
+    if constexpr (REG) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) m = fmaxf(m, v[k]);
+    } else {
+        for (int d = d0; d < d1; ++d) m = fmaxf(m, c[(int64_t)d * plane]);
+    }
     s_f[part][lane] = m;
     __syncthreads();
     m = fmaxf(fmaxf(s_f[0][lane], s_f[1][lane]), fmaxf(s_f[2][lane], s_f[3][lane]));
@@ -40,7 +56,13 @@ __global__ __launch_bounds__(256) void softmax_regress_conf_kernel(
     // correctly rounded sum -- whatever order ATen's vectorised fp32 reduction uses, this
     // is within its rounding error, and it does not depend on the quarter split
     double psum = 0.0;
-    for (int d = d0; d < d1; ++d) psum += (double)expf(c[(int64_t)d * plane] - m);
+    if constexpr (REG) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k)
+            if (d0 + k < d1) psum += (double)expf(v[k] - m);
+    } else {
+        for (int d = d0; d < d1; ++d) psum += (double)expf(c[(int64_t)d * plane] - m);
+    }
     s_d[0][part][lane] = psum;
     __syncthreads();
     const float sum =
@@ -53,11 +75,18 @@ __global__ __launch_bounds__(256) void softmax_regress_conf_kernel(
     const float *dv = depth_mode == 0 ? depth + (int64_t)b * D : depth + (int64_t)b * D * plane + pix;
     const int64_t dstride = depth_mode == 0 ? 1 : plane;
     float *pp = (out_prob && live) ? out_prob + (int64_t)b * D * plane + pix : nullptr;
-    for (int d = d0; d < d1; ++d) {
-        const float pr = expf(c[(int64_t)d * plane] - m) / sum;
+    auto step = [&](int d, float cv) {
+        const float pr = expf(cv - m) / sum;
         dep += (double)(pr * dv[(int64_t)d * dstride]);   // module.py:102
         fidx += (double)(pr * (float)d);                  // mvsnet.py:189
         if (pp) pp[(int64_t)d * plane] = pr;
+    };
+    if constexpr (REG) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k)
+            if (d0 + k < d1) step(d0 + k, v[k]);
+    } else {
+        for (int d = d0; d < d1; ++d) step(d, c[(int64_t)d * plane]);
     }
     s_d[0][part][lane] = dep;
     s_d[1][part][lane] = fidx;
@@ -121,9 +150,14 @@ extern "C" int mvs_softmax_regress_conf_f32(const float *cost, const float *dept
     const int64_t plane = (int64_t)H * W;
     const int64_t n = (int64_t)B * plane;
     unsigned grid = (unsigned)((n + 63) / 64);
-    hipLaunchKernelGGL(softmax_regress_conf_kernel, dim3(grid), dim3(256), 0, as_stream(stream),
-                       cost, depth_values, depth_mode, clamp_idx, B, D, plane, out_depth, out_conf,
-                       out_prob);
+    if (D <= 256)   // a quarter of the column (<= 64 planes) fits a thread's registers
+        hipLaunchKernelGGL(softmax_regress_conf_kernel<1>, dim3(grid), dim3(256), 0, as_stream(stream),
+                           cost, depth_values, depth_mode, clamp_idx, B, D, plane, out_depth, out_conf,
+                           out_prob);
+    else
+        hipLaunchKernelGGL(softmax_regress_conf_kernel<0>, dim3(grid), dim3(256), 0, as_stream(stream),
+                           cost, depth_values, depth_mode, clamp_idx, B, D, plane, out_depth, out_conf,
+                           out_prob);
     return check_launch("mvs_softmax_regress_conf_f32");
 }
 

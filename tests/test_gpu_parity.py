@@ -1226,3 +1226,26 @@ def test_conv2d_c4_blocked_output_equals_channels_last(dev, weights):
     c4 = ops.conv2d(x, pk, 32, 32, 3, 1, None, bias, False, out_c4=True)
     assert c4.shape == (3, 8, 37, 50, 4)
     assert torch.equal(c4.permute(0, 2, 3, 1, 4).reshape(3, 37, 50, 32), cl)
+
+
+# ------------------------------------------------ glue kernels against the reference's OWN functions (g16)
+@pytest.mark.parametrize("name", ["s2", "s3"])
+def test_cas_hypotheses_kernel_reference_golden(dev, name):
+    """mvs_cas_depth_hypotheses_f32 vs the reference's lines between two cascade stages run by the
+    reference itself: F.interpolate(bilinear) -> models.module.get_depth_range_samples ->
+    F.interpolate(trilinear) (cas_mvsnet.py:129-152; tests/golden/make_golden_glue.py)."""
+    from mvs_amd import ops
+    g = load_golden("g16_glue")
+    H, W, scale, nd = (int(x) for x in g[f"cas_{name}_meta"])
+    got = ops.cas_depth_hypotheses(G(g[f"cas_{name}_prev"], dev), nd, float(g[f"cas_{name}_interval"]), (H, W),
+                                   (H // scale, W // scale)).cpu().numpy()
+    np.testing.assert_allclose(got, g[f"cas_{name}_out"], atol=3e-4, rtol=0)   # depths ~800 mm: a few ulps
+
+
+def test_cvp_refine_hypotheses_reference_golden(dev):
+    """The device-side calDepthHypo chain vs the reference's own models.modules.calDepthHypo (test mode)."""
+    from mvs_amd import ops
+    g = load_golden("g16_glue")
+    got = ops.cvp_refine_hypotheses(G(g["cvp_depth_up"], dev), G(g["cvp_K_ref"], dev), G(g["cvp_K_src"][:, 0], dev),
+                                    G(g["cvp_ref_ex"], dev), G(g["cvp_src_ex"][:, 0], dev)).cpu().numpy()
+    np.testing.assert_allclose(got, g["cvp_hypos"], atol=2e-4, rtol=0)

@@ -214,3 +214,17 @@ def test_geo_filter_restatement_known_answers():
     assert mask[inside].all() and np.abs(dep[mask] - depths[0][mask]).max() < 0.05
     bad = depths[0] * np.float32(1.05)
     assert not gf.check_geometric_consistency(bad, K, E[0], depths[1], K, E[1])[0].any()
+
+
+def test_cvp_refine_mirror_matches_reference_caldepthhypo():
+    """The fp64 torch restatement of calDepthHypo (mvs_amd.models.cvp_mvsnet.refine_hypotheses, the CPU
+    checker of the CVP tests) against the reference's own function (g16)."""
+    import torch
+    from conftest import load_golden
+    from mvs_amd.models.cvp_mvsnet import refine_hypotheses
+    g = load_golden("g16_glue")
+    T = torch.from_numpy
+    got = refine_hypotheses(T(g["cvp_depth_up"]), T(g["cvp_K_ref"]), T(g["cvp_K_src"][:, 0]), T(g["cvp_ref_ex"]),
+                            T(g["cvp_src_ex"][:, 0])).numpy()
+    import numpy as np
+    np.testing.assert_allclose(got, g["cvp_hypos"], atol=2e-4, rtol=0)
