@@ -172,6 +172,19 @@ int mvs_conv3d_pack_weights_f32(const float *weight, int transposed, int Cin, in
 /* 1 if impl 2 (MFMA) supports this layer shape, else 0. */
 int mvs_conv3d_mfma_supported(int transposed, int Cin, int Cout, int stride);
 
+/* Cout = 8, stride-1 layers over an 8-channel-blocked input (conv0 of every CostRegNet: mvsnet.py:66,
+ * CasMVSNet/models/module.py:411) on the BF16 matrix pipe at fp32 accuracy: every fp32 operand is split
+ * exactly into three bf16 numbers (hi + mid + lo) and the six largest partial products are accumulated in
+ * fp32 -- error <= the fp32 kernels' own (mvs_amd/csrc/conv_bf16x6.hip), 2.7x less matrix time.
+ * `packed` = mvs_conv3d_pack_weights_bf16x6_f32 of the PyTorch-layout (8, Cin, 3, 3, 3) weight,
+ * mvs_conv3d_bf16x6_packed_bytes(Cin) bytes (0 = unsupported Cin; supported: 8, 16, 32).
+ * in [B,D,H,Cin/8,W,8]; out / residual [B,D,H,W,8]; scale/shift/relu/residual as mvs_conv3d_f32. */
+size_t mvs_conv3d_bf16x6_packed_bytes(int Cin);
+int mvs_conv3d_pack_weights_bf16x6_f32(const float *weight, int Cin, void *packed, void *stream);
+int mvs_conv3d_c8_bf16x6_f32(const float *in, const void *packed, const float *scale, const float *shift,
+                             const float *residual, int relu, int B, int Cin, int D, int H, int W,
+                             float *out, void *stream);
+
 /* The whole 3D U-Net in one call -- CostRegNet.forward, mvsnet.py:83-93 (also the cascade's
  * CostRegNet, CasMVSNet/models/module.py:407-438): conv0 .. conv6 (3x3x3 + folded BN + ReLU, strides
  * 1 2 1 2 1 2 1), conv7 / conv9 / conv11 (transposed, stride 2, + BN + ReLU, skip-add of conv4 /
@@ -187,6 +200,9 @@ typedef struct mvs_conv_layer {
     const float *packed; /* mvs_conv3d_pack_weights_f32 output, or NULL (direct kernels) */
     const float *scale;  /* folded BatchNorm scale [Cout], or NULL */
     const float *shift;  /* folded BatchNorm shift / conv bias [Cout], or NULL */
+    const void *packed_split; /* conv0 only: mvs_conv3d_pack_weights_bf16x6_f32 output -- with an
+                               * MVS_LAYOUT_C8 input the layer then runs as mvs_conv3d_c8_bf16x6_f32;
+                               * NULL = the fp32 MFMA kernel */
 } mvs_conv_layer;
 size_t mvs_costreg_workspace_bytes(int B, int base, int D, int H, int W);
 int mvs_costreg_fwd_f32(const float *in, int in_layout, const mvs_conv_layer *layers, int B, int Cin,

@@ -44,6 +44,9 @@ _SIGS = {
     "mvs_conv3d_packed_weight_floats": (_c_l, [_c_i] * 4),
     "mvs_conv3d_pack_weights_f32": (_c_i, [_c_f] + [_c_i] * 4 + [_c_f, _c_f]),
     "mvs_conv3d_mfma_supported": (_c_i, [_c_i] * 4),
+    "mvs_conv3d_bf16x6_packed_bytes": (ctypes.c_size_t, [_c_i]),
+    "mvs_conv3d_pack_weights_bf16x6_f32": (_c_i, [_c_f, _c_i, _c_f, _c_f]),
+    "mvs_conv3d_c8_bf16x6_f32": (_c_i, [_c_f] * 5 + [_c_i] * 6 + [_c_f, _c_f]),
     "mvs_conv3d_wgrad_f32": (_c_i, [_c_f, _c_f] + [_c_i] * 7 + [_c_f, _c_f, ctypes.c_size_t, _c_f]),
     "mvs_conv3d_wgrad_workspace_bytes": (ctypes.c_size_t, [_c_i] * 7),
     "mvs_conv3d_wgrad_supported": (_c_i, [_c_i] * 3),
@@ -70,7 +73,7 @@ _SIGS = {
 class ConvLayer(ctypes.Structure):
     """mvs_conv_layer of include/mvs_hip.h"""
     _fields_ = [("weight", ctypes.c_void_p), ("packed", ctypes.c_void_p),
-                ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p)]
+                ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("packed_split", ctypes.c_void_p)]
 
 
 _lib = None

@@ -1,0 +1,487 @@
+// conv0-class layers (3x3x3, Cout = 8, stride 1, 8-channel-blocked input: MVSNet's conv0 32 -> 8 and
+// the cascade's first layers; mvsnet.py:66, module.py:26-33) on the BF16 matrix pipe at FP32 accuracy.
+//
+// gfx950 has no reduced-precision fast path for fp32 operands (no xf32), and its fp32 MFMA runs at the
+// vector rate: conv0 is 314 GFLOP at 157 TFLOP/s = 2.0 ms before the 25 % padding of its Cout = 8 shifted
+// form.  The bf16 MFMA is 16x faster.  Every fp32 number is EXACTLY the sum of three bf16 numbers
+// (8 + 8 + 8 significand bits: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid), each
+// subtraction exact), so a product a b = (ah + am + al)(bh + bm + bl); the six terms ah bh, ah bm, am bh,
+// ah bl, al bh, am bm carry it to 2^-25 relative (the three dropped terms are below fp32's own product
+// rounding), each term is exact in the fp32 accumulator's multiplier, and the matrix pipe sums in fp32.
+// Measured on the golden conv0 case against fp64: max error 2.4e-10 for the six-term form with exact
+// accumulation vs 2.1e-9 for ATen's fp32 convolution -- the split form is not the less accurate one.
+// Six bf16 MFMAs of K = 32 replace eight fp32 MFMAs of K = 4: 2.7x less matrix time.
+//
+// Structure = the persistent DMA-fed kernel of conv_persistent.h (one 512-thread workgroup per CU walks
+// (4,4,32)-voxel tiles, the fp32 halo of an 8-channel chunk lands in LDS by buffer-addressed DMA while the
+// previous chunk is multiplied, same tile order, same epilogue), with
+//   * one v_mfma_f32_16x16x32_bf16 covering the FOUR x-taps of the shifted form x 8 channels (K = 32):
+//     lane (n, kq) holds the 8 channels of voxel x = 2n + kq -- two ds_read_b128 of fp32 -- and splits them
+//     in registers (v_cvt_pk_bf16_f32, shifts, v_pk_add_f32: ~36 VALU per fragment, beside the other wave's
+//     MFMAs); a wave's two output rows are y-neighbours, so the 12 distinct (z, y) input rows of a chunk
+//     are split once and used by both rows;
+//   * the weights pre-split on the host side of the call (mvs_conv3d_pack_weights_bf16x6_f32) into A
+//     fragments [chunk][kz,ky][hi,mid,lo][lane][8 bf16], streamed per chunk by DMA beside the halo
+//     (27 KiB per chunk, double-buffered: all four chunks do not fit LDS next to the halo buffers).
+#include "conv_persistent.h"
+
+#include <cstdlib>
+
+namespace mvs {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// c - (a.lo * b.lo + a.hi * b.hi) with a, b pairs of bf16: v_dot2c_f32_bf16 (gfx950).  With b = (-1, 0) or (0, -1)
+// it subtracts one bf16 of a packed pair from an fp32 number in ONE instruction (no unpack); the difference
+// of a number and its own bf16 rounding is exactly representable, so the result is exact whatever the
+// instruction's internal rounding.  (The compiler cannot select the builtin on this target; the assembler
+// knows the instruction.)
+__device__ __forceinline__ float sub_bf16_half(float c, unsigned pair, unsigned sel) {
+    asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(c) : "s"(sel), "v"(pair));
+    return c;
+}
+
+// x (8 fp32 channels of one voxel) -> hi, mid, lo with x = hi + mid + lo exactly.
+// DOT2: 7 VALU per pair of values (3 cvt_pk + 4 dot2c) instead of 11 (3 cvt_pk + 4 unpack + 4 sub).
+template <bool DOT2>
+__device__ __forceinline__ void split3(const f32x4 &a, const f32x4 &b, bf16x8 &h, bf16x8 &m, bf16x8 &l) {
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const f32x2 x = (i < 4) ? (f32x2){a[i], a[i + 1]} : (f32x2){b[i - 4], b[i - 3]};
+        const bf16x2 hh = __builtin_convertvector(x, bf16x2);
+        f32x2 r1, r2;
+        if constexpr (DOT2) {
+            const unsigned hu = __builtin_bit_cast(unsigned, hh);
+            r1[0] = sub_bf16_half(x[0], hu, 0x0000bf80u);
+            r1[1] = sub_bf16_half(x[1], hu, 0xbf800000u);
+        } else {
+            r1 = x - __builtin_convertvector(hh, f32x2);
+        }
+        const bf16x2 mm = __builtin_convertvector(r1, bf16x2);
+        if constexpr (DOT2) {
+            const unsigned mu = __builtin_bit_cast(unsigned, mm);
+            r2[0] = sub_bf16_half(r1[0], mu, 0x0000bf80u);
+            r2[1] = sub_bf16_half(r1[1], mu, 0xbf800000u);
+        } else {
+            r2 = r1 - __builtin_convertvector(mm, f32x2);
+        }
+        const bf16x2 ll = __builtin_convertvector(r2, bf16x2);
+        h[i] = hh[0]; h[i + 1] = hh[1];
+        m[i] = mm[0]; m[i + 1] = mm[1];
+        l[i] = ll[0]; l[i + 1] = ll[1];
+    }
+}
+
+
+// the same split of one fragment as ONE scheduled block.  A dot instruction's result may be read by a
+// different VALU instruction only 3 issue slots later (the compiler's hazard recogniser inserts the nops for
+// code it generates, it does not look inside inline assembly): all eight subtractions of a level are issued
+// before the first conversion of the next.
+__device__ __forceinline__ void split3_block(f32x4 &a, f32x4 &b, bf16x8 &h, bf16x8 &m, bf16x8 &l) {
+    unsigned h0, h1, h2, h3, m0, m1, m2, m3, l0, l1, l2, l3;
+    float x0 = a[0], x1 = a[1], x2 = a[2], x3 = a[3], x4 = b[0], x5 = b[1], x6 = b[2], x7 = b[3];
+    asm volatile(
+        "v_cvt_pk_bf16_f32 %8, %0, %1\n\tv_cvt_pk_bf16_f32 %9, %2, %3\n\t"
+        "v_cvt_pk_bf16_f32 %10, %4, %5\n\tv_cvt_pk_bf16_f32 %11, %6, %7\n\t"
+        "v_dot2c_f32_bf16 %0, %20, %8\n\tv_dot2c_f32_bf16 %1, %21, %8\n\t"
+        "v_dot2c_f32_bf16 %2, %20, %9\n\tv_dot2c_f32_bf16 %3, %21, %9\n\t"
+        "v_dot2c_f32_bf16 %4, %20, %10\n\tv_dot2c_f32_bf16 %5, %21, %10\n\t"
+        "v_dot2c_f32_bf16 %6, %20, %11\n\tv_dot2c_f32_bf16 %7, %21, %11\n\t"
+        "v_cvt_pk_bf16_f32 %12, %0, %1\n\tv_cvt_pk_bf16_f32 %13, %2, %3\n\t"
+        "v_cvt_pk_bf16_f32 %14, %4, %5\n\ts_nop 0\n\tv_cvt_pk_bf16_f32 %15, %6, %7\n\t"
+        "v_dot2c_f32_bf16 %0, %20, %12\n\tv_dot2c_f32_bf16 %1, %21, %12\n\t"
+        "v_dot2c_f32_bf16 %2, %20, %13\n\tv_dot2c_f32_bf16 %3, %21, %13\n\t"
+        "v_dot2c_f32_bf16 %4, %20, %14\n\tv_dot2c_f32_bf16 %5, %21, %14\n\t"
+        "v_dot2c_f32_bf16 %6, %20, %15\n\tv_dot2c_f32_bf16 %7, %21, %15\n\t"
+        "v_cvt_pk_bf16_f32 %16, %0, %1\n\tv_cvt_pk_bf16_f32 %17, %2, %3\n\t"
+        "v_cvt_pk_bf16_f32 %18, %4, %5\n\ts_nop 0\n\tv_cvt_pk_bf16_f32 %19, %6, %7\n\ts_nop 1"
+        : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7),
+          "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3), "=&v"(m0), "=&v"(m1), "=&v"(m2), "=&v"(m3),
+          "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+        : "s"(0x0000bf80u), "s"(0xbf800000u));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    h = __builtin_bit_cast(bf16x8, (u32x4){h0, h1, h2, h3});
+    m = __builtin_bit_cast(bf16x8, (u32x4){m0, m1, m2, m3});
+    l = __builtin_bit_cast(bf16x8, (u32x4){l0, l1, l2, l3});
+}
+
+template <int OFF>
+__device__ __forceinline__ f32x4 lds_read_b128(unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536 && OFF % 16 == 0, "ds_read_b128 offset field");
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+
+constexpr int kSplitChunkBytes = 9 * 3 * 1024;   // A fragments of one 8-channel chunk: (kz,ky) x (hi,mid,lo) x 1 KiB
+
+// Halo of one 8-channel chunk in LDS: [channel half][voxel][4 floats]; voxels = the 36 (z, y) rows' 17 even-x
+// voxels, then -- from voxel kOddBase, a multiple of 16 -- the rows' 17 odd-x voxels.  A wave's B read (lane
+// (n, kq) -> x = 2n + kq of one row) then touches, in each 16-lane service group of ds_read_b128, sixteen
+// different 16-byte slots modulo 256 bytes: conflict-free (an odd half starting 17 voxels after its even
+// half, as in the fp32 kernel's b64 layout, collides in one slot per group).
+constexpr int kRowVox = 17, kRows = 36, kOddBase = 624, kHaloVox = kOddBase + kRows * kRowVox, kHaloPlane = 1280;
+static_assert(kOddBase % 16 == 0 && kOddBase >= kRows * kRowVox && kHaloVox <= kHaloPlane, "halo layout");
+
+template <int OFF>
+__device__ __forceinline__ void lds_write_b128(unsigned addr, const bf16x8 &v) {
+    static_assert(OFF >= 0 && OFF < 65536 && OFF % 16 == 0, "ds_write_b128 offset field");
+    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+
+template <int OFF>
+__device__ __forceinline__ void lds_write_b64(unsigned addr, unsigned lo, unsigned hi) {
+    static_assert(OFF >= 0 && OFF < 65536 && OFF % 8 == 0, "ds_write_b64 offset field");
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 v = {lo, hi};
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+
+// tiles of one group: they share each weight chunk in LDS (one 27-KiB copy per chunk and GROUP instead of per
+// chunk and tile) and keep their accumulators in registers across the chunk loop
+constexpr int kGroup = 4;
+
+template <int CIN, bool DOT2, int ABL = 0>
+__global__ __launch_bounds__(512) void conv3d_c8_bf16x6_kernel(ConvArgs a, int ntiles) {
+    constexpr int NCHUNK = CIN / 8, YT = 6, PLANE = kHaloPlane, T = kGroup;
+    constexpr int NDMA = 2 * PLANE / 64, IPW = NDMA / 8;         // 40 wave-copies per chunk, 5 per wave
+    static_assert(NDMA % 8 == 0, "whole copies per wave");
+    // LDS: two weight chunks (double-buffered), the fp32 halo as the copy engine delivers it, its three bf16 parts
+    constexpr int WBYTES = kSplitChunkBytes, FBYTES = 2 * PLANE * 16, SPART = PLANE * 16, SBYTES = 3 * SPART;
+    constexpr int F_OFF = 2 * WBYTES, S_OFF = F_OFF + FBYTES;
+    static_assert(S_OFF + SBYTES <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[S_OFF + SBYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kq = lane >> 4;
+    const unsigned lds_base = (unsigned)(uintptr_t)lds;
+    const int abl = a.res_up2;   // tuning: 1 = no chunk compute, 2 = no halo copies, 4 = no weight copies
+
+    // this workgroup's tiles: t0 + k * t_step, k < ntw (XCD x owns a contiguous range of the ordered tile list)
+    int t0, t_step, ntw;
+    {
+        const int nb = gridDim.x;
+        if ((nb & 7) == 0) {
+            const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per = nb >> 3;
+            const int lo = (int)((int64_t)ntiles * xcd / 8), hi = (int)((int64_t)ntiles * (xcd + 1) / 8);
+            t0 = lo + j; t_step = per; ntw = (hi - t0 + per - 1) / per;
+        } else {
+            t0 = blockIdx.x; t_step = nb; ntw = (ntiles - t0 + nb - 1) / nb;
+        }
+        if (ntw < 0) ntw = 0;
+    }
+
+    // fp32 halo buffer = the 36 (z, y) rows as they lie in memory: 34 voxels x 32 bytes = 68 16-byte pieces per
+    // row, piece P = row * 68 + q at byte 16 P.  Neighbouring lanes copy neighbouring pieces, so a 64-byte line
+    // is requested once (a de-interleaved destination -- even-x voxels first, channel halves apart -- made every
+    // lane its own 64-byte request for 16 useful bytes: 4x the requests, and the copy rate is set by requests).
+    // This thread's copy items: copy g = i*8 + wv brings pieces g*64 + lane.
+    constexpr int ROWP = 68, NPIECE = kRows * ROWP;               // 2448 pieces = 38.25 wave-copies
+    int loc[IPW];
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+        const int P = (i * 8 + wv) * 64 + lane;
+        const bool ok = P < NPIECE;
+        const int Pc = ok ? P : 0;
+        const int row = Pc / ROWP, q = Pc % ROWP;
+        loc[i] = (q >> 1) | ((row % YT) << 8) | ((row / YT) << 16) | ((q & 1) << 24) | (ok ? 0 : (int)0x80000000);
+    }
+    // the bf16 parts: position p of voxel (row, x) = row*17 + x/2 (+ kOddBase for odd x).  This thread's items of
+    // the split pass: piece P = ps*512 + tid -> 8 bytes at p*16 + half*8 of each part
+    constexpr int NPS = (NPIECE + 511) / 512;                     // 5 passes
+    unsigned spos[NPS];
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {
+        const int P = ps * 512 + tid;
+        const int Pc = P < NPIECE ? P : 0;
+        const int row = Pc / ROWP, q = Pc % ROWP, x = q >> 1;
+        spos[ps] = P < NPIECE ? (unsigned)((row * kRowVox + (x >> 1) + (x & 1) * kOddBase) * 16 + (q & 1) * 8) : 0xffffffffu;
+    }
+    const int64_t plane_in = (int64_t)a.H * a.W * CIN;
+    const int row_in = a.W * CIN;
+    const unsigned window_bytes = (unsigned)min((int64_t)6 * plane_in * 4, (int64_t)0xffffff00u);
+    unsigned voff[T][IPW];
+    mvs_srd_t srd[T];
+    auto geometry = [&](auto jc, int t) {
+        constexpr int j = decltype(jc)::value;
+        const TileIdx tile = decode_ordered_tile(a, t);
+        const int ix0 = tile.tx * 32 - 1, iy0 = tile.ty * 4 - 1, iz0 = tile.tz * 4 - 1;
+        srd[j] = make_srd(a.in + ((int64_t)tile.b * a.D + iz0) * plane_in, window_bytes);
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const int gx = ix0 + (loc[i] & 255), gy = iy0 + ((loc[i] >> 8) & 255);
+            const int lz = (loc[i] >> 16) & 255, h = (loc[i] >> 24) & 1;
+            const bool ok = loc[i] >= 0 && (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H &&
+                            (unsigned)(iz0 + lz) < (unsigned)a.D;
+            voff[j][i] = ok ? (unsigned)(((int64_t)lz * plane_in + (int64_t)gy * row_in + gx * 8 + h * 4) * 4) : 0xffffff00u;
+        }
+    };
+    auto issue_halo = [&](auto jc, int ch) {
+        constexpr int j = decltype(jc)::value;
+        if (abl & 2) return;
+        const unsigned soff = (unsigned)(ch * a.W * 32);
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            if (i * 8 + wv >= (NPIECE + 63) / 64) continue;   // wave-uniform: 39 copies
+            glds16_buf(voff[j][i], srd[j], soff, lds_base + (unsigned)(F_OFF + (i * 8 + wv) * 1024));
+        }
+    };
+    const unsigned char *wsrc = reinterpret_cast<const unsigned char *>(a.wpk);
+    auto issue_weights = [&](int ch, int sel) {   // 27 KiB = 27 wave-copies over the 8 waves
+        if (abl & 4) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int g = i * 8 + wv;
+            if (g < 27) glds16(wsrc + (size_t)ch * WBYTES + (size_t)g * 1024 + lane * 16,
+                               lds_base + (unsigned)(sel * WBYTES + g * 1024));
+        }
+    };
+
+    float4 sc, sh;
+    {
+        const int c0 = (kq & 1) * 4;
+        sc = a.scale ? *reinterpret_cast<const float4 *>(a.scale + c0) : make_float4(1.f, 1.f, 1.f, 1.f);
+        sh = a.shift ? *reinterpret_cast<const float4 *>(a.shift + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    const int z0 = wv >> 1, y0 = (wv & 1) * 2;          // the wave's output rows: (z0, y0) and (z0, y0 + 1)
+    // this lane's B voxel of halo row (z0, y0): x = 2n + kq
+    const unsigned aB = lds_base + (unsigned)(S_OFF + ((z0 * YT + y0) * kRowVox + n + (kq >> 1) + (kq & 1) * kOddBase) * 16);
+
+    f32x4 acc[T][2];
+#pragma unroll
+    for (int j = 0; j < T; ++j) acc[j][0] = acc[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int wsel = 0;
+    if (ntw > 0) {
+        geometry(std::integral_constant<int, 0>{}, t0);
+        issue_halo(std::integral_constant<int, 0>{}, 0);
+        issue_weights(0, 0);
+    }
+    for (int k0 = 0; k0 < ntw; k0 += T) {
+        const int nvalid = min(T, ntw - k0);
+#pragma unroll 1
+        for (int ch = 0; ch < NCHUNK; ++ch) {
+            static_for<0, T>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if (j >= nvalid) return;   // wave-uniform
+                // ---- the copies of this step have landed; every wave is done with the previous step's bf16 parts
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                // ---- split pass: every halo voxel once (the MFMA phase reads each ~5 times), fp32 -> hi, mid, lo
+                if (!(abl & 1)) {
+                    f32x4 x[NPS];
+                    const unsigned fp = lds_base + (unsigned)(F_OFF + tid * 16);
+                    static_for<0, NPS>([&](auto pc) {
+                        constexpr int ps = decltype(pc)::value;
+                        x[ps] = lds_read_b128<ps * 8192>(fp);
+                    });
+                    lds_wait_n<0>();
+                    static_for<0, (NPS + 1) / 2>([&](auto pc) {
+                        constexpr int p0 = 2 * decltype(pc)::value, p1 = (p0 + 1 < NPS) ? p0 + 1 : p0;
+                        asm volatile("" : "+v"(x[p0]), "+v"(x[p1]));
+                        bf16x8 h, m, l;
+                        if constexpr (ABL & 8) {
+                            h = __builtin_bit_cast(bf16x8, x[p0]); m = __builtin_bit_cast(bf16x8, x[p1]); l = h;
+                        } else if constexpr (DOT2) split3_block(x[p0], x[p1], h, m, l);
+                        else split3<false>(x[p0], x[p1], h, m, l);
+                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                        const u32x4 hu = __builtin_bit_cast(u32x4, h), mu = __builtin_bit_cast(u32x4, m), lu = __builtin_bit_cast(u32x4, l);
+                        if (spos[p0] != 0xffffffffu) {
+                            const unsigned sp = lds_base + (unsigned)S_OFF + spos[p0];
+                            lds_write_b64<0>(sp, hu[0], hu[1]);
+                            lds_write_b64<SPART>(sp, mu[0], mu[1]);
+                            lds_write_b64<2 * SPART>(sp, lu[0], lu[1]);
+                        }
+                        if (p1 != p0 && spos[p1] != 0xffffffffu) {
+                            const unsigned sp = lds_base + (unsigned)S_OFF + spos[p1];
+                            lds_write_b64<0>(sp, hu[2], hu[3]);
+                            lds_write_b64<SPART>(sp, mu[2], mu[3]);
+                            lds_write_b64<2 * SPART>(sp, lu[2], lu[3]);
+                        }
+                    });
+                    lds_wait_n<0>();
+                }
+                __syncthreads();
+                // ---- the fp32 buffer is free: next step's halo (and, at a chunk change, the next weight chunk)
+                if (j + 1 < nvalid) {
+                    if (ch == 0) geometry(std::integral_constant<int, (j + 1) % T>{}, t0 + (k0 + j + 1) * t_step);
+                    issue_halo(std::integral_constant<int, (j + 1) % T>{}, ch);
+                } else if (ch + 1 < NCHUNK) {
+                    issue_halo(std::integral_constant<int, 0>{}, ch + 1);
+                    issue_weights(ch + 1, wsel ^ 1);
+                } else if (k0 + T < ntw) {
+                    geometry(std::integral_constant<int, 0>{}, t0 + (k0 + T) * t_step);
+                    issue_halo(std::integral_constant<int, 0>{}, 0);
+                    issue_weights(0, wsel ^ 1);
+                }
+                if (abl & 1) return;
+                // ---- MFMA phase: 12 input-row fragments f = (kz, iy) into row 0 (ky = iy) and row 1 (ky = iy - 1);
+                // the reads of fragment f+1 (and of the weight triple it brings in) go out before the MFMAs of f
+                const unsigned aA = lds_base + (unsigned)(wsel * WBYTES + lane * 16);
+                bf16x8 bs[2][3], A[3][3];
+                auto read_b = [&](auto fc) {
+                    constexpr int f = decltype(fc)::value, off = ((f / 4) * YT + f % 4) * kRowVox * 16;
+                    static_for<0, 3>([&](auto pc) {
+                        constexpr int sp = decltype(pc)::value;
+                        bs[f & 1][sp] = __builtin_bit_cast(bf16x8, lds_read_b128<off + sp * SPART>(aB));
+                    });
+                };
+                auto read_a = [&](auto kzc, auto kyc) {
+                    constexpr int kz = decltype(kzc)::value, ky = decltype(kyc)::value;
+                    static_for<0, 3>([&](auto pc) {
+                        constexpr int sp = decltype(pc)::value;
+                        A[ky][sp] = __builtin_bit_cast(bf16x8, lds_read_b128<((kz * 3 + ky) * 3 + sp) * 1024>(aA));
+                    });
+                };
+                read_a(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+                read_b(std::integral_constant<int, 0>{});
+                static_for<0, 12>([&](auto fc) {
+                    constexpr int f = decltype(fc)::value, iy = f % 4;
+                    constexpr int f1 = f + 1, kz1 = f1 / 4, iy1 = f1 % 4;
+                    lds_wait_n<0>();
+                    asm volatile("" : "+v"(bs[f & 1][0]), "+v"(bs[f & 1][1]), "+v"(bs[f & 1][2]));
+                    if constexpr (iy <= 2) asm volatile("" : "+v"(A[iy][0]), "+v"(A[iy][1]), "+v"(A[iy][2]));
+                    if constexpr (f1 < 12) {
+                        if constexpr (iy1 <= 2) read_a(std::integral_constant<int, kz1>{}, std::integral_constant<int, iy1>{});
+                        read_b(std::integral_constant<int, f1>{});
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // the reads go out BEFORE this fragment's MFMAs
+                    const bf16x8 bh = bs[f & 1][0], bm = bs[f & 1][1], bl = bs[f & 1][2];
+                    // six partial products per output row, small terms first; rows interleaved so that
+                    // neighbouring MFMAs do not wait on each other's accumulator
+                    static_for<0, 6>([&](auto tc) {
+                        constexpr int t = decltype(tc)::value;
+                        constexpr int as = (t == 0 || t == 3) ? 1 : (t == 1 ? 2 : 0);       // am al ah am ah ah
+                        static_for<0, 2>([&](auto rc) {
+                            constexpr int r = decltype(rc)::value, ky = iy - r;
+                            if constexpr (ky >= 0 && ky <= 2) {
+                                const bf16x8 &bb = (t == 0 || t == 4) ? bm : (t == 2 ? bl : bh);   // bm bh bl bh bm bh
+                                const bf16x8 &aa = A[ky][as];
+                                f32x4 &cc = acc[j][r];
+                                if constexpr (ABL & 16) asm volatile("" ::"v"(aa), "v"(bb));
+                                else cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aa, bb, cc, 0, 0, 0);
+                            }
+                        });
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+            wsel ^= 1;
+        }
+        // ---- epilogue of the group: BN affine, ReLU, one 16-byte store per lane and row (as the fp32 kernel's MODE 2)
+        static_for<0, T>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if (j >= nvalid) return;
+            const TileIdx cur = decode_ordered_tile(a, t0 + (k0 + j) * t_step);
+            const int ox = cur.tx * 32 + 2 * n + (kq >> 1);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int oz = cur.tz * 4 + z0, oy = cur.ty * 4 + y0 + r;
+                f32x4 v = acc[j][r];
+                acc[j][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo) continue;
+                const int c0 = (kq & 1) * 4;
+                v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
+                v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+                if (a.relu == 1) {
+                    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+                    v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                }
+                const int64_t o = ((((int64_t)cur.b * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * 8 + c0;
+                if (a.residual) {
+                    const float4 rs = *reinterpret_cast<const float4 *>(a.residual + o);
+                    v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
+                }
+                *reinterpret_cast<float4 *>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        });
+    }
+}
+
+// PyTorch-layout weight (8, Cin, 3, 3, 3) -> [chunk][kz*3+ky][split][lane][8 bf16]; lane (m, kq): row m =
+// (cout = m & 7, x-shift = m >> 3), k = kq * 8 + c: x-tap kx' = kq of the 4-tap window, channel c of the
+// chunk; the weight is w[cout][chunk*8 + c][kz][ky][kx' - shift] (zero outside the 3 real taps).
+__global__ __launch_bounds__(256) void pack_bf16x6_kernel(const float *__restrict__ w, int Cin,
+                                                          unsigned short *__restrict__ out, int total) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int j = i & 7, lane = (i >> 3) & 63, t = (i >> 9) % 9, ch = i / (9 * 512);
+    const int m = lane & 15, kq = lane >> 4, co = m & 7, sft = m >> 3, kx = kq - sft;
+    const int kz = t / 3, ky = t % 3, cin = ch * 8 + j;
+    float x = 0.0f;
+    if (kx >= 0 && kx <= 2) x = w[((int64_t)co * Cin + cin) * 27 + kz * 9 + ky * 3 + kx];
+    const __bf16 h = (__bf16)x;
+    const float r1 = x - (float)h;
+    const __bf16 mm = (__bf16)r1;
+    const float r2 = r1 - (float)mm;
+    const __bf16 l = (__bf16)r2;
+    unsigned short *o = out + ((size_t)(ch * 9 + t) * 3) * 512 + lane * 8 + j;
+    o[0] = __builtin_bit_cast(unsigned short, h);
+    o[512] = __builtin_bit_cast(unsigned short, mm);
+    o[1024] = __builtin_bit_cast(unsigned short, l);
+}
+
+}  // namespace mvs
+
+using namespace mvs;
+
+static bool split_shape_ok(int Cin) { return Cin == 8 || Cin == 16 || Cin == 32; }
+
+extern "C" size_t mvs_conv3d_bf16x6_packed_bytes(int Cin) {
+    return split_shape_ok(Cin) ? (size_t)(Cin / 8) * kSplitChunkBytes : 0;
+}
+
+extern "C" int mvs_conv3d_pack_weights_bf16x6_f32(const float *weight, int Cin, void *packed, void *stream) {
+    if (!weight || !packed || !split_shape_ok(Cin)) {
+        set_error("mvs_conv3d_pack_weights_bf16x6_f32: needs a (8, Cin, 3, 3, 3) weight with Cin in {8, 16, 32}");
+        return MVS_EINVAL;
+    }
+    const int total = (Cin / 8) * 9 * 512;
+    hipLaunchKernelGGL(pack_bf16x6_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), weight, Cin,
+                       static_cast<unsigned short *>(packed), total);
+    return check_launch("mvs_conv3d_pack_weights_bf16x6_f32");
+}
+
+extern "C" int mvs_conv3d_c8_bf16x6_f32(const float *in, const void *packed, const float *scale,
+                                        const float *shift, const float *residual, int relu, int B, int Cin,
+                                        int D, int H, int W, float *out, void *stream) {
+    if (!in || !packed || !out || B <= 0 || D <= 0 || H <= 0 || W <= 0 || !split_shape_ok(Cin)) {
+        set_error("mvs_conv3d_c8_bf16x6_f32: invalid argument (Cin in {8, 16, 32}, Cout = 8, stride 1, 8-channel-blocked input)");
+        return MVS_EINVAL;
+    }
+    if ((int64_t)9 * H * W * Cin * 4 >= 0xffffff00LL) return bare_error(MVS_EINVAL, __func__, __LINE__);
+    ConvArgs a;
+    a.in = in; a.wpk = static_cast<const float *>(packed); a.scale = scale; a.shift = shift; a.residual = residual;
+    a.out = out;
+    a.B = B; a.D = D; a.H = H; a.W = W;
+    a.Do = D; a.Ho = H; a.Wo = W;
+    a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 3) / 4; a.tiles_z = (D + 3) / 4;
+    a.relu = relu; a.in_c8 = 1; a.ystrip = 8;
+    static const int abl = [] { const char *e = getenv("MVS_CONV_SPLIT_ABL"); return e ? atoi(e) : 0; }();
+    a.res_up2 = abl;
+    const int64_t nt = (int64_t)B * a.tiles_x * a.tiles_y * a.tiles_z;
+    if (nt <= 0 || nt > 0x7fffffffLL) return bare_error(MVS_EINVAL, __func__, __LINE__);
+    const int n_cu = device_cu_count();
+    const dim3 grid((unsigned)(nt < n_cu ? nt : n_cu)), blk(512);
+    hipStream_t st = as_stream(stream);
+    // MVS_CONV_SPLIT_DOT2=0: the split written with plain conversions and subtractions (same operands bit for
+    // bit; kept to cross-check the v_dot2c form)
+    static const bool dot2 = [] { const char *e = getenv("MVS_CONV_SPLIT_DOT2"); return !(e && e[0] == '0'); }();
+#define MVS_LAUNCH_SPLIT(C)                                                                                    \
+    do {                                                                                                       \
+        if (dot2) hipLaunchKernelGGL((conv3d_c8_bf16x6_kernel<C, true>), grid, blk, 0, st, a, (int)nt);        \
+        else hipLaunchKernelGGL((conv3d_c8_bf16x6_kernel<C, false>), grid, blk, 0, st, a, (int)nt);           \
+    } while (0)
+    if (Cin == 32 && (abl & 24)) {   // tuning builds: 8 = no split, 16 = no MFMAs (wrong results)
+        if ((abl & 24) == 8) hipLaunchKernelGGL((conv3d_c8_bf16x6_kernel<32, true, 8>), grid, blk, 0, st, a, (int)nt);
+        else if ((abl & 24) == 16) hipLaunchKernelGGL((conv3d_c8_bf16x6_kernel<32, true, 16>), grid, blk, 0, st, a, (int)nt);
+        else hipLaunchKernelGGL((conv3d_c8_bf16x6_kernel<32, true, 24>), grid, blk, 0, st, a, (int)nt);
+    } else if (Cin == 32) MVS_LAUNCH_SPLIT(32);
+    else if (Cin == 16) MVS_LAUNCH_SPLIT(16);
+    else MVS_LAUNCH_SPLIT(8);
+#undef MVS_LAUNCH_SPLIT
+    return check_launch("mvs_conv3d_c8_bf16x6_f32");
+}

@@ -84,6 +84,14 @@ extern "C" int mvs_costreg_fwd_f32(const float *in, int in_layout, const mvs_con
     };
     for (const Step &s : steps) {
         const mvs_conv_layer &L = layers[s.layer];
+        if (s.layer == 0 && L.packed_split && in_layout == MVS_LAYOUT_C8 && b == 8 && impl != 1 &&
+            mvs_conv3d_bf16x6_packed_bytes(Cin) != 0) {
+            // conv0 on the bf16 matrix pipe with exactly split fp32 operands (conv_bf16x6.hip)
+            const int rc = mvs_conv3d_c8_bf16x6_f32(s.src, L.packed_split, L.scale, L.shift, nullptr, s.relu, B, Cin,
+                                                    D, H, W, s.dst, stream);
+            if (rc != MVS_OK) return rc;
+            continue;
+        }
         const int rc = mvs_conv3d_f32(s.src, L.weight, L.packed, L.scale, L.shift, s.skip, s.relu,
                                       s.transposed, B, s.cin, s.cout, D >> s.lvl, H >> s.lvl, W >> s.lvl,
                                       s.stride, s.layout, impl, s.dst, stream);

@@ -38,6 +38,8 @@ def pack_costreg(sd, prefix=""):
             scale = (g / torch.sqrt(var + eps)).float().contiguous()
             P[name] = dict(weight=w, scale=scale, shift=(b - mu * scale).float().contiguous(),
                            stride=stride, transposed=tr, packed=ops.pack_conv3d_weight(w, tr, stride))
+        if ops.conv_split_enabled():
+            P["conv0"]["packed_split"] = ops.pack_conv3d_weight_split(P["conv0"]["weight"])
         w = sd[f"{prefix}prob.weight"].float().contiguous()
         bias = sd.get(f"{prefix}prob.bias")
         P["prob"] = dict(weight=w, scale=None, shift=None if bias is None else bias.float().contiguous(),
@@ -54,6 +56,8 @@ def costreg_forward(x_cl, P, impl=ops.IMPL_AUTO, in_c8=False):
 
     def run(name, t, skip=None, relu=True, c8=False):
         p = P[name]
+        if c8 and p.get("packed_split") is not None and impl != ops.IMPL_DIRECT:
+            return ops.conv3d_c8_split(t, p["packed_split"], p["scale"], p["shift"], skip, relu)
         return ops.conv3d(t, p["weight"], p["scale"], p["shift"], skip, relu, p["transposed"],
                           p["stride"], channels_last=True, packed=p["packed"], impl=impl, in_c8=c8)
 

@@ -210,6 +210,8 @@ class CostRegNet(nn.Module):
                 params[name] = dict(weight=w, scale=scale, shift=shift, stride=stride,
                                     transposed=(kind == "deconv"),
                                     packed=ops.pack_conv3d_weight(w, kind == "deconv", stride))
+            if ops.conv_split_enabled():
+                params["conv0"]["packed_split"] = ops.pack_conv3d_weight_split(params["conv0"]["weight"])
             w = self.prob.weight.detach().float().contiguous()
             params["prob"] = dict(weight=w, scale=None,
                                   shift=self.prob.bias.detach().float().contiguous(), stride=1,
@@ -238,6 +240,8 @@ class CostRegNet(nn.Module):
                 return _conv(p, t, skip, relu)
 
         def _conv(p, t, skip, relu, c8=False):
+            if c8 and p.get("packed_split") is not None and self.conv_impl != ops.IMPL_DIRECT:
+                return ops.conv3d_c8_split(t, p["packed_split"], p["scale"], p["shift"], skip, relu)
             return ops.conv3d(t, p["weight"], p["scale"], p["shift"], skip, relu, p["transposed"],
                               p["stride"], channels_last=True, packed=p["packed"],
                               impl=self.conv_impl, in_c8=c8)

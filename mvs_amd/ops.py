@@ -580,6 +580,43 @@ def pack_conv3d_weight(weight, transposed, stride):
     return packed
 
 
+def conv_split_enabled():
+    """False when MVS_CONV_SPLIT=0 keeps conv0 on the fp32 MFMA kernel (A/B switch; default: the
+    split-operand bf16 kernel, mvs_conv3d_c8_bf16x6_f32)."""
+    import os
+    return os.environ.get("MVS_CONV_SPLIT", "1") != "0"
+
+
+def pack_conv3d_weight_split(weight):
+    """(8, Cin, 3, 3, 3) weight -> the bf16 hi/mid/lo A fragments of conv3d_c8_split (None if the
+    shape has no such kernel)."""
+    weight = _f32c(weight)
+    if weight.dim() != 5 or weight.shape[0] != 8 or tuple(weight.shape[2:]) != (3, 3, 3):
+        return None
+    n = _lib.load().mvs_conv3d_bf16x6_packed_bytes(int(weight.shape[1]))
+    if n == 0:
+        return None
+    packed = torch.empty(n // 4, device=weight.device, dtype=torch.float32)   # opaque bytes
+    check(_lib.load().mvs_conv3d_pack_weights_bf16x6_f32(ptr(weight), int(weight.shape[1]), ptr(packed), stream()),
+          "mvs_conv3d_pack_weights_bf16x6_f32")
+    return packed
+
+
+def conv3d_c8_split(x_c8, packed_split, scale=None, shift=None, residual=None, relu=False):
+    """conv0-class layer (3x3x3, Cout 8, stride 1) on the bf16 matrix pipe with exactly split fp32
+    operands (mvs_conv3d_c8_bf16x6_f32): x_c8 [B,D,H,Cin/8,W,8] -> [B,D,H,W,8]."""
+    x_c8 = _f32c(x_c8)
+    B, D, H, G, W, _ = x_c8.shape
+    out = torch.empty(B, D, H, W, 8, device=x_c8.device, dtype=torch.float32)
+    with stage("conv3d_split"):
+        check(_lib.load().mvs_conv3d_c8_bf16x6_f32(
+            ptr(x_c8), ptr(packed_split), ptr(_f32c(scale)) if scale is not None else None,
+            ptr(_f32c(shift)) if shift is not None else None,
+            ptr(_f32c(residual)) if residual is not None else None, int(bool(relu)), B, G * 8, D, H, W,
+            ptr(out), stream()), "mvs_conv3d_c8_bf16x6_f32")
+    return out
+
+
 def conv3d(x, weight, scale=None, shift=None, residual=None, relu=False, transposed=False,
            stride=1, channels_last=False, packed=None, impl=IMPL_AUTO, in_c8=False):
     """3x3x3 (transposed) convolution + per-channel affine + ReLU + skip add.
@@ -726,7 +763,7 @@ def costreg_forward(x, params, in_c8=False, impl=IMPL_AUTO):
     keep = []
     for i, name in enumerate(COSTREG_ORDER):
         p = params[name]
-        for field in ("weight", "packed", "scale", "shift"):
+        for field in ("weight", "packed", "scale", "shift", "packed_split"):
             t = p.get(field)
             if t is not None:
                 t = _f32c(t)

@@ -1,0 +1,18 @@
+"""time of the split-operand conv0 kernel at one shape (tuning: MVS_CONV_SPLIT_ABL, MVS_CONV_SPLIT_DOT2)"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mvs_amd import ops
+D, H, W = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (192, 296, 400)
+x = torch.randn(1, D, H, 4, W, 8, device="cuda")
+w = torch.randn(8, 32, 3, 3, 3, device="cuda") * 0.1
+pk, pks = ops.pack_conv3d_weight(w, False, 1), ops.pack_conv3d_weight_split(w)
+def t(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    return min(a.elapsed_time(b) for a, b in ev)
+print("ABL", os.environ.get("MVS_CONV_SPLIT_ABL", "0"), "DOT2", os.environ.get("MVS_CONV_SPLIT_DOT2", "1"),
+      "fp32 %.3f ms" % t(lambda: ops.conv3d(x, w, None, None, relu=True, packed=pk, impl=ops.IMPL_MFMA, in_c8=True)),
+      "split %.3f ms" % t(lambda: ops.conv3d_c8_split(x, pks, None, None, relu=True)), flush=True)

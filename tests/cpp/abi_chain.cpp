@@ -133,6 +133,13 @@ int main(int argc, char **argv) {
             MVS_OK_(mvs_conv3d_pack_weights_f32(layers[i].weight, transposed[i], cin[i], cout[i], stride[i], packed, st));
         }
         layers[i].packed = packed;
+        layers[i].packed_split = nullptr;
+        if (i == 0) {   // conv0 on the split-operand bf16 kernel, as the Python host runs it
+            void *ps;
+            HIP_OK(hipMalloc(&ps, mvs_conv3d_bf16x6_packed_bytes(cin[0])));
+            MVS_OK_(mvs_conv3d_pack_weights_bf16x6_f32(layers[0].weight, cin[0], ps, st));
+            layers[0].packed_split = ps;
+        }
     }
     const size_t cws = mvs_costreg_workspace_bytes(B, 8, D, H, W);
     if (!cws) { std::fprintf(stderr, "costreg workspace: unsupported size\n"); return 3; }

@@ -472,6 +472,36 @@ def test_conv3d_mfma_vs_oracle_ragged(dev, shape, cfg):
     np.testing.assert_allclose(ops.nhwc_to_nchw(got).cpu().numpy(), want, atol=2e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [(1, 5, 9, 21), (2, 8, 16, 48), (1, 3, 7, 33), (1, 37, 30, 70), (1, 40, 72, 200)])
+@pytest.mark.parametrize("cin", [32, 16, 8])
+def test_conv3d_split_bf16_vs_fp64_and_fp32_kernel(dev, shape, cin):
+    """conv0 on the bf16 matrix pipe with exactly split fp32 operands (mvs_conv3d_c8_bf16x6_f32): against an
+    fp64 convolution it must be as accurate as the fp32 MFMA kernel (the split loses nothing an fp32 product
+    keeps), on partial tiles of every axis, batch > 1, a last group of fewer than four tiles per workgroup
+    (small shapes) and several groups per workgroup (the last shape), with the BN affine, ReLU and skip add."""
+    from mvs_amd import ops
+    B, D, H, W = shape
+    g = torch.Generator().manual_seed(cin * 1000 + D * 10 + W)
+    # variance-volume-like input: non-negative, six decades of dynamic range
+    x = (torch.randn(B, cin, D, H, W, generator=g) * torch.rand(B, cin, D, H, W, generator=g) ** 4).square()
+    w = torch.randn(8, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5
+    scale, shift = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.1
+    res = torch.randn(B, D, H, W, 8, generator=g)
+    ref = torch.nn.functional.conv3d(x.double(), w.double(), padding=1)
+    ref = torch.relu(ref * scale.double().view(1, 8, 1, 1, 1) + shift.double().view(1, 8, 1, 1, 1))
+    ref = ref.permute(0, 2, 3, 4, 1) + res.double()
+    wt, x8 = w.to(dev), ops.nchw_to_c8(x.to(dev))
+    pks = ops.pack_conv3d_weight_split(wt)
+    assert pks is not None
+    got = ops.conv3d_c8_split(x8, pks, scale.to(dev), shift.to(dev), res.to(dev), True)
+    f32 = ops.conv3d(x8, wt, scale.to(dev), shift.to(dev), res.to(dev), True, False, 1, channels_last=True,
+                     packed=ops.pack_conv3d_weight(wt, False, 1), impl=ops.IMPL_MFMA, in_c8=True)
+    e_split = (got.cpu().double() - ref).abs().max().item()
+    e_f32 = (f32.cpu().double() - ref).abs().max().item()
+    assert e_split <= 1.5 * e_f32 + 1e-7, (e_split, e_f32)
+    assert e_split < 2e-6 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("shape", [(1, 5, 9, 21), (2, 8, 16, 48), (1, 3, 7, 33), (1, 37, 30, 70)])
 @pytest.mark.parametrize("cin", [32, 16, 8])
 def test_conv3d_c8_persistent_vs_oracle_ragged(dev, shape, cin):
@@ -680,6 +710,25 @@ def test_mvsnet_eval_alternate_paths(dev, weights, feature_impl, variance_impl, 
         out = model(G(g["imgs"], dev), G(g["proj"], dev), G(g["depth_values"], dev))
     assert np.abs(out["depth"].cpu().numpy() - g["depth"]).max() < DEPTH_TOL_MM
     np.testing.assert_allclose(out["photometric_confidence"].cpu().numpy(), g["confidence"], atol=1e-4)
+
+
+def test_mvsnet_eval_fp32_conv0_switch(dev, weights, monkeypatch):
+    """MVS_CONV_SPLIT=0 keeps conv0 on the fp32 MFMA kernel (the default is the split-operand bf16 kernel):
+    same 1e-3 mm gate, and the two depth maps agree far inside it."""
+    from mvs_amd.models import MVSNet
+    g = load_golden("g6_e2e_128x160_v3_d16")
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MVS_CONV_SPLIT", flag)
+        model = MVSNet(refine=False)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+        model = model.to(dev).eval()
+        with torch.no_grad():
+            out = model(G(g["imgs"], dev), G(g["proj"], dev), G(g["depth_values"], dev))
+        assert ("packed_split" in model.cost_regularization._hip_params()["conv0"]) == (flag == "1")
+        outs.append(out["depth"].cpu().numpy())
+        assert np.abs(outs[-1] - g["depth"]).max() < DEPTH_TOL_MM
+    assert np.abs(outs[0] - outs[1]).max() < 0.5 * DEPTH_TOL_MM
 
 
 def test_mvsnet_eval_batch_of_two_equals_single_samples(dev, weights):
