@@ -39,6 +39,10 @@ from mvs_amd.models import MVSNet  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_MFMA_PEAK_TF = 157.3    # v_mfma_f32_16x16x4_f32 / 32x32x2, dense fp32
+BF16_MFMA_PEAK_TF = 2500.0   # v_mfma_f32_16x16x32_bf16, dense
+# conv0 computes every fp32 product as six bf16 products (operands split exactly in three,
+# mvs_amd/csrc/conv_bf16x6.hip): its matrix-pipe ceiling in ALGORITHMIC (fp32) flops
+SPLIT_BF16X6_PEAK_TF = BF16_MFMA_PEAK_TF / 6.0
 
 
 def algorithmic_work(V, C, D, h, w):
@@ -92,6 +96,12 @@ def _roofline_entry(name, kind, amount, ms):
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                 "algorithmic_bytes": amount, "ms": round(ms, 4)}
     ach = amount / (ms * 1e-3) / 1e12
+    if name == "costreg.conv0" and ops.conv_split_enabled():
+        return {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": round(SPLIT_BF16X6_PEAK_TF, 1),
+                "unit": "TFLOP/s", "frac": round(ach / SPLIT_BF16X6_PEAK_TF, 4), "traffic": None,
+                "algorithmic_flops": amount, "issued_bf16_flops": 6.0 * amount, "ms": round(ms, 4),
+                "peak_note": "bf16 dense MFMA peak 2500 TFLOP/s / 6 bf16 products per fp32 product "
+                             "(split-operand kernel); the fp32 MFMA peak, 157.3, is the ceiling this kernel left"}
     return {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TF,
             "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": None,
             "algorithmic_flops": amount, "ms": round(ms, 4)}
