@@ -260,6 +260,12 @@ __global__ __launch_bounds__(512) void conv3d_c8_bf16x6_kernel(ConvArgs a, int n
         issue_halo(std::integral_constant<int, 0>{}, 0);
         issue_weights(0, 0);
     }
+    // ABL & 128 (tuning): cycles of each wave per phase, summed over the workgroup's steps, into the buffer passed
+    // as `residual` (int64 [workgroup][wave][8]): copy wait, barrier, split pass, barrier, copy issue, MFMA phase, epilogue
+    long long tsum[7] = {0, 0, 0, 0, 0, 0, 0};
+    long long tprev = 0;
+    if constexpr (ABL & 128) tprev = clock64();
+#define MVS_LAP(k) do { if constexpr (ABL & 128) { const long long tn = clock64(); tsum[k] += tn - tprev; tprev = tn; } } while (0)
     for (int k0 = 0; k0 < ntw; k0 += T) {
         const int nvalid = min(T, ntw - k0);
 #pragma unroll 1
@@ -268,8 +274,11 @@ __global__ __launch_bounds__(512) void conv3d_c8_bf16x6_kernel(ConvArgs a, int n
                 constexpr int j = decltype(jc)::value;
                 if (j >= nvalid) return;   // wave-uniform
                 // ---- the copies of this step have landed; every wave is done with the previous step's bf16 parts
+                MVS_LAP(6);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                MVS_LAP(0);
                 __syncthreads();
+                MVS_LAP(1);
                 // ---- split pass: every halo voxel once (the MFMA phase reads each ~5 times), fp32 -> hi, mid, lo
                 if (!(abl & 1)) {
                     f32x4 x[NPS];
@@ -304,7 +313,9 @@ __global__ __launch_bounds__(512) void conv3d_c8_bf16x6_kernel(ConvArgs a, int n
                     });
                     lds_wait_n<0>();
                 }
+                MVS_LAP(2);
                 __syncthreads();
+                MVS_LAP(3);
                 // ---- the fp32 buffer is free: next step's halo (and, at a chunk change, the next weight chunk)
                 if (j + 1 < nvalid) {
                     if (ch == 0) geometry(std::integral_constant<int, (j + 1) % T>{}, t0 + (k0 + j + 1) * t_step);
@@ -317,6 +328,7 @@ __global__ __launch_bounds__(512) void conv3d_c8_bf16x6_kernel(ConvArgs a, int n
                     issue_halo(std::integral_constant<int, 0>{}, 0);
                     issue_weights(0, wsel ^ 1);
                 }
+                MVS_LAP(4);
                 if (abl & 1) return;
                 // ---- MFMA phase: 12 input-row fragments f = (kz, iy) into row 0 (ky = iy) and row 1 (ky = iy - 1);
                 // the reads of fragment f+1 (and of the weight triple it brings in) go out before the MFMAs of f
@@ -368,6 +380,12 @@ __global__ __launch_bounds__(512) void conv3d_c8_bf16x6_kernel(ConvArgs a, int n
                     });
                     __builtin_amdgcn_sched_barrier(0);
                 });
+                if constexpr (ABL & 128) {
+                    f32x4 &c0 = acc[j][0], &c1 = acc[j][1];
+                    asm volatile("" : "+v"(c0), "+v"(c1));
+                    asm volatile("s_nop 0" ::: "memory");
+                }
+                MVS_LAP(5);
             });
             wsel ^= 1;
         }
@@ -391,7 +409,7 @@ __global__ __launch_bounds__(512) void conv3d_c8_bf16x6_kernel(ConvArgs a, int n
                     v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
                 }
                 const int64_t o = ((((int64_t)cur.b * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * 8 + c0;
-                if (a.residual) {
+                if (a.residual && !(ABL & 128)) {
                     const float4 rs = *reinterpret_cast<const float4 *>(a.residual + o);
                     v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
                 }
@@ -399,6 +417,14 @@ __global__ __launch_bounds__(512) void conv3d_c8_bf16x6_kernel(ConvArgs a, int n
             }
         });
     }
+    if constexpr (ABL & 128) {
+        MVS_LAP(6);
+        if (lane == 0) {
+            long long *dbg = reinterpret_cast<long long *>(const_cast<float *>(a.residual)) + ((int64_t)blockIdx.x * 8 + wv) * 8;
+            for (int k = 0; k < 7; ++k) dbg[k] = tsum[k];
+        }
+    }
+#undef MVS_LAP
 }
 
 // PyTorch-layout weight (8, Cin, 3, 3, 3) -> [chunk][kz*3+ky][split][lane][8 bf16]; lane (m, kq): row m =
@@ -461,7 +487,7 @@ extern "C" int mvs_conv3d_c8_bf16x6_f32(const float *in, const void *packed, con
     a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 3) / 4; a.tiles_z = (D + 3) / 4;
     a.relu = relu; a.in_c8 = 1; a.ystrip = 8;
     static const int abl = [] { const char *e = getenv("MVS_CONV_SPLIT_ABL"); return e ? atoi(e) : 0; }();
-    a.res_up2 = abl;
+    a.res_up2 = abl & 7;
     const int64_t nt = (int64_t)B * a.tiles_x * a.tiles_y * a.tiles_z;
     if (nt <= 0 || nt > 0x7fffffffLL) return bare_error(MVS_EINVAL, __func__, __LINE__);
     const int n_cu = device_cu_count();
@@ -475,7 +501,10 @@ extern "C" int mvs_conv3d_c8_bf16x6_f32(const float *in, const void *packed, con
         if (dot2) hipLaunchKernelGGL((conv3d_c8_bf16x6_kernel<C, true>), grid, blk, 0, st, a, (int)nt);        \
         else hipLaunchKernelGGL((conv3d_c8_bf16x6_kernel<C, false>), grid, blk, 0, st, a, (int)nt);           \
     } while (0)
-    if (Cin == 32 && (abl & 24)) {   // tuning builds: 8 = no split, 16 = no MFMAs (wrong results)
+    if (Cin == 32 && (abl & 128)) {   // tuning build: per-phase cycle counts into `residual` (scripts/exp_conv_split_time.py)
+        if (!residual) return bare_error(MVS_EINVAL, __func__, __LINE__);
+        hipLaunchKernelGGL((conv3d_c8_bf16x6_kernel<32, true, 128>), grid, blk, 0, st, a, (int)nt);
+    } else if (Cin == 32 && (abl & 24)) {   // tuning builds: 8 = no split, 16 = no MFMAs (wrong results)
         if ((abl & 24) == 8) hipLaunchKernelGGL((conv3d_c8_bf16x6_kernel<32, true, 8>), grid, blk, 0, st, a, (int)nt);
         else if ((abl & 24) == 16) hipLaunchKernelGGL((conv3d_c8_bf16x6_kernel<32, true, 16>), grid, blk, 0, st, a, (int)nt);
         else hipLaunchKernelGGL((conv3d_c8_bf16x6_kernel<32, true, 24>), grid, blk, 0, st, a, (int)nt);
