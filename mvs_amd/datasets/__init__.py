@@ -1,9 +1,9 @@
 """Host-side readers/writers of the on-disk contract around the hot path (SURVEY.md
 Appendix A): PFM, camera files, pair.txt, the DTU evaluation and training samples."""
-from .data_io import read_pfm, save_pfm
+from .data_io import read_pfm, save_pfm, save_pfm_rows_bottom_up
 from .dtu_eval import MVSDataset, read_cam_file, read_pair_file
 
-__all__ = ["read_pfm", "save_pfm", "MVSDataset", "read_cam_file", "read_pair_file"]
+__all__ = ["read_pfm", "save_pfm", "save_pfm_rows_bottom_up", "MVSDataset", "read_cam_file", "read_pair_file"]
 
 
 def find_dataset_def(name):

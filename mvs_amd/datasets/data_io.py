@@ -33,6 +33,18 @@ def read_pfm(filename):
     return rows[::-1], scale      # stored bottom-to-top
 
 
+def save_pfm_rows_bottom_up(filename, rows, scale=1):
+    """PFM of a float32 [H,W] image whose rows are ALREADY in file order (bottom row first, as save_pfm stores
+    them) and contiguous: header + the buffer itself, no intermediate copy -- the write releases the GIL, which the
+    eval driver's launching thread needs (mvs_amd/tools/eval_depth.py)."""
+    if rows.dtype.name != "float32" or rows.ndim != 2 or not rows.flags["C_CONTIGUOUS"]:
+        raise Exception("rows must be a C-contiguous float32 [H,W] array.")
+    little_endian = rows.dtype.byteorder == "<" or (rows.dtype.byteorder == "=" and sys.byteorder == "little")
+    with open(filename, "wb") as stream:
+        stream.write(b"Pf\n%d %d\n%f\n" % (rows.shape[1], rows.shape[0], -scale if little_endian else scale))
+        stream.write(memoryview(rows).cast("B"))
+
+
 def save_pfm(filename, image, scale=1):
     """image: float32 [H,W], [H,W,1] or [H,W,3]."""
     if image.dtype.name != "float32":

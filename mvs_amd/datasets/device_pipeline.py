@@ -16,6 +16,7 @@ scan has only 49 distinct images.  Here, per scan:
 The tensors a sample yields are bit-identical to the reference loader's (tests/test_io_golden.py)."""
 import os
 import threading
+import warnings
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -34,7 +35,9 @@ class DeviceScanPipeline:
         with open(listfile) as f:
             self.scans = [ln.rstrip() for ln in f.readlines() if ln.strip()]
         self.metas = {s: read_pair_file(os.path.join(datapath, s, "pair.txt")) for s in self.scans}
-        self.pool = ThreadPoolExecutor(max_workers=decode_workers or min(32, os.cpu_count() or 4))
+        # few decoder threads: a scan's 49 JPEGs take ~0.15 s on four, a scan's sweep ~0.37 s; every further thread
+        # only competes with the kernel-launching thread for the interpreter lock (scripts/pipe_probe.py)
+        self.pool = ThreadPoolExecutor(max_workers=decode_workers or 4)
         self.side = torch.cuda.Stream(device=self.dev)
         self.stats = {"decoded": 0, "scans": 0}
 
@@ -47,7 +50,10 @@ class DeviceScanPipeline:
         with Image.open(path) as im:
             a = np.asarray(im.convert("RGB") if im.mode != "RGB" else im)
         assert a.shape[:2] == self.image_hw, f"{path}: {a.shape[:2]} != {self.image_hw}"
-        np.copyto(dst.numpy(), a)     # decoder buffer -> pinned staging buffer, one copy
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")              # `a` wraps PIL's read-only bytes; it is only read
+            src = torch.from_numpy(a)
+        dst.copy_(src)                # decoder buffer -> pinned staging buffer: a torch copy, outside the interpreter lock
 
     def _prepare(self, scan):
         metas = self.metas[scan]
@@ -61,6 +67,11 @@ class DeviceScanPipeline:
                               intrinsics_div=1.0) for v in views]     # the division happens on the device
         K = torch.from_numpy(np.stack([c[0] for c in cams])).pin_memory()
         E = torch.from_numpy(np.stack([c[1] for c in cams])).pin_memory()
+        # view slots of every sample of the scan, uploaded once: a per-sample torch.tensor(..., device=...) is a
+        # pageable host-to-device copy, which blocks the launching thread until the stream has drained -- the
+        # GPU then idles while the host prepares the next sample
+        idx_all = torch.tensor([[slot[v] for v in [ref] + src[:self.nviews - 1]] for ref, src in metas],
+                               dtype=torch.int64).pin_memory()
         for f in futs:
             f.result()
         self.stats["decoded"] += len(views)
@@ -68,10 +79,12 @@ class DeviceScanPipeline:
             u8 = pinned.to(self.dev, non_blocking=True)
             imgs = ops.images_u8_to_planar(u8, Hs - self.crop_bottom, Ws)
             proj = ops.proj_matrices(K.to(self.dev, non_blocking=True), E.to(self.dev, non_blocking=True), self.div)
+            idx_dev = idx_all.to(self.dev, non_blocking=True)
             done = torch.cuda.Event()
             done.record(self.side)
         self.stats["scans"] += 1
         return {"scan": scan, "slot": slot, "imgs": imgs, "proj": proj, "done": done, "pinned": pinned,
+                "idx": idx_dev, "idx_host": idx_all,
                 "depth": {v: (c[2], c[3]) for v, c in zip(views, cams)}}
 
     def __iter__(self):
@@ -98,14 +111,15 @@ class DeviceScanPipeline:
             torch.cuda.current_stream(self.dev).wait_event(cur["done"])
             cur["imgs"].record_stream(torch.cuda.current_stream(self.dev))
             cur["proj"].record_stream(torch.cuda.current_stream(self.dev))
+            cur["idx"].record_stream(torch.cuda.current_stream(self.dev))
             dv_cache = {}
-            for ref, src in self.metas[scan]:
-                ids = [ref] + src[:self.nviews - 1]
-                idx = torch.tensor([cur["slot"][v] for v in ids], device=self.dev)
+            for k, (ref, src) in enumerate(self.metas[scan]):
+                idx = cur["idx"][k]
                 dmin, dint = cur["depth"][ref]
                 if (dmin, dint) not in dv_cache:
                     dv_cache[(dmin, dint)] = torch.from_numpy(
-                        np.arange(dmin, dint * (self.ndepths - 0.5) + dmin, dint, dtype=np.float32)).to(self.dev)
+                        np.arange(dmin, dint * (self.ndepths - 0.5) + dmin, dint, dtype=np.float32)).pin_memory().to(
+                            self.dev, non_blocking=True)
                 yield {"imgs": cur["imgs"].index_select(0, idx).unsqueeze(0),
                        "proj_matrices": cur["proj"].index_select(0, idx).unsqueeze(0),
                        "depth_values": dv_cache[(dmin, dint)].unsqueeze(0),

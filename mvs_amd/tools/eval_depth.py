@@ -14,7 +14,7 @@ import os
 import numpy as np
 import torch
 
-from ..datasets import find_dataset_def, save_pfm
+from ..datasets import find_dataset_def, save_pfm, save_pfm_rows_bottom_up
 from ..models import MVSNet, load_reference_checkpoint
 
 
@@ -41,9 +41,19 @@ def save_depth(args):
         writer, ring, RING = ThreadPoolExecutor(max_workers=2), [], 8
 
         def flush(slot):
+            # The worker threads share the interpreter lock with the thread that launches the kernels, and whatever
+            # they do under it is GPU idle time (scripts/pipe_probe.py: 9.2 ms per depth map with the copies and
+            # flips of save_pfm here and 32 decoder threads, 7.4 with neither, the model alone 7.5).  So the rows are
+            # flipped on the GPU and the file is the pinned buffer itself.
             ev, buf, names = slot
             ev.synchronize()
-            _write(args.outdir, names, buf[0].numpy().copy(), buf[1].numpy().copy())
+            if os.environ.get("MVS_EVAL_NO_WRITE") == "1":     # (scripts/pipe_probe.py: the driver without its file writes)
+                return
+            for b, name in enumerate(names):
+                for k, kind in enumerate(("depth_est", "confidence")):
+                    path = os.path.join(args.outdir, name.format(kind, ".pfm"))
+                    os.makedirs(os.path.dirname(path), exist_ok=True)
+                    save_pfm_rows_bottom_up(path, buf[k][b].numpy())
 
         pending = []
         with torch.no_grad():
@@ -57,8 +67,8 @@ def save_depth(args):
                 else:
                     pending[it - RING].result()          # that slot's file has been written
                     buf = ring[it % RING]
-                buf[0].copy_(out["depth"], non_blocking=True)
-                buf[1].copy_(out["photometric_confidence"], non_blocking=True)
+                buf[0].copy_(out["depth"].flip(-2), non_blocking=True)                     # PFM stores the bottom row first
+                buf[1].copy_(out["photometric_confidence"].flip(-2), non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
                 pending.append(writer.submit(flush, (ev, buf, sample["filename"])))
@@ -96,7 +106,9 @@ def main(argv=None):
     ap.add_argument("--outdir", default="./outputs")
     ap.add_argument("--device_pipeline", action="store_true",
                     help="decode each image once per scan, normalise / crop / transpose on the GPU (batch size 1)")
-    ap.add_argument("--decode_workers", type=int, default=0)
+    ap.add_argument("--decode_workers", type=int, default=4,
+                    help="JPEG decoder threads of the device pipeline (a scan's 49 images take ~0.15 s on 4; more threads "
+                         "only take the interpreter lock away from the launching thread)")
     ap.add_argument("--quiet", action="store_true")
     save_depth(ap.parse_args(argv))
 

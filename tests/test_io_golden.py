@@ -30,6 +30,13 @@ def test_pfm_bytes_and_roundtrip(tmp_path):
         assert scale == 1.0 and back.dtype.kind == "f" and np.array_equal(back, arr)
     with pytest.raises(Exception):
         save_pfm(str(tmp_path / "x.pfm"), np.zeros((2, 2), dtype=np.float64))
+    # the eval driver's writer: rows already in file order (flipped on the GPU), the buffer written as it is
+    from mvs_amd.datasets import save_pfm_rows_bottom_up
+    grey = np.ascontiguousarray(g["pfm_grey_array"].reshape(g["pfm_grey_array"].shape[:2]))
+    save_pfm_rows_bottom_up(str(tmp_path / "rows.pfm"), np.ascontiguousarray(grey[::-1]))
+    assert (tmp_path / "rows.pfm").read_bytes() == g["pfm_grey_bytes"].tobytes()
+    with pytest.raises(Exception):
+        save_pfm_rows_bottom_up(str(tmp_path / "rows2.pfm"), grey[::-1])      # not contiguous
     bad = tmp_path / "bad.pfm"
     bad.write_bytes(b"P6\n1 1\n255\n\0\0\0")
     with pytest.raises(Exception):
