@@ -142,11 +142,17 @@ __device__ __forceinline__ void lds_write_b64(unsigned addr, unsigned lo, unsign
 // chunk and tile) and keep their accumulators in registers across the chunk loop
 constexpr int kGroup = 4;
 
+// Besides the eight waves that split and multiply, the workgroup has kCopyWaves waves that do nothing but issue the
+// LDS-DMA copies of the next step (and wait for them).  Issued by the eight working waves themselves -- five 1-KiB
+// pieces each, in one burst behind the barrier -- the copies cost every wave ~1300 cycles of a 7700-cycle step: a
+// vector-memory instruction blocks its wave at issue while the address unit is busy, wherever in the stream it sits.
+constexpr int kCopyWaves = 4, kSplitKernelThreads = 512 + 64 * kCopyWaves;
+
 template <int CIN, bool DOT2, int ABL = 0>
-__global__ __launch_bounds__(512) void conv3d_c8_bf16x6_kernel(ConvArgs a, int ntiles) {
+__global__ __launch_bounds__(kSplitKernelThreads) void conv3d_c8_bf16x6_kernel(ConvArgs a, int ntiles) {
     constexpr int NCHUNK = CIN / 8, YT = 6, PLANE = kHaloPlane, T = kGroup;
-    constexpr int NDMA = 2 * PLANE / 64, IPW = NDMA / 8;         // 40 wave-copies per chunk, 5 per wave
-    static_assert(NDMA % 8 == 0, "whole copies per wave");
+    constexpr int NC = kCopyWaves;
+    constexpr int NCOPY = (kRows * 68 + 63) / 64, IPW = (NCOPY + NC - 1) / NC;     // 39 wave-copies per chunk
     // LDS: two weight chunks (double-buffered), the fp32 halo as the copy engine delivers it, its three bf16 parts
     constexpr int WBYTES = kSplitChunkBytes, FBYTES = 2 * PLANE * 16, SPART = PLANE * 16, SBYTES = 3 * SPART;
     constexpr int F_OFF = 2 * WBYTES, S_OFF = F_OFF + FBYTES;
@@ -158,6 +164,8 @@ __global__ __launch_bounds__(512) void conv3d_c8_bf16x6_kernel(ConvArgs a, int n
     const int n = lane & 15, kq = lane >> 4;
     const unsigned lds_base = (unsigned)(uintptr_t)lds;
     const int abl = a.res_up2;   // tuning: 1 = no chunk compute, 2 = no halo copies, 4 = no weight copies
+    const bool copier = wv >= 8;
+    const int cw = wv - 8;       // copy wave index
 
     // this workgroup's tiles: t0 + k * t_step, k < ntw (XCD x owns a contiguous range of the ordered tile list)
     int t0, t_step, ntw;
@@ -177,24 +185,25 @@ __global__ __launch_bounds__(512) void conv3d_c8_bf16x6_kernel(ConvArgs a, int n
     // row, piece P = row * 68 + q at byte 16 P.  Neighbouring lanes copy neighbouring pieces, so a 64-byte line
     // is requested once (a de-interleaved destination -- even-x voxels first, channel halves apart -- made every
     // lane its own 64-byte request for 16 useful bytes: 4x the requests, and the copy rate is set by requests).
-    // This thread's copy items: copy g = i*8 + wv brings pieces g*64 + lane.
+    // A copy wave's items: copy g = i*NC + cw brings pieces g*64 + lane.
     constexpr int ROWP = 68, NPIECE = kRows * ROWP;               // 2448 pieces = 38.25 wave-copies
     int loc[IPW];
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
-        const int P = (i * 8 + wv) * 64 + lane;
+        const int P = ((i * NC + cw) & 63) * 64 + lane;
         const bool ok = P < NPIECE;
         const int Pc = ok ? P : 0;
         const int row = Pc / ROWP, q = Pc % ROWP;
         loc[i] = (q >> 1) | ((row % YT) << 8) | ((row / YT) << 16) | ((q & 1) << 24) | (ok ? 0 : (int)0x80000000);
     }
     // the bf16 parts: position p of voxel (row, x) = row*17 + x/2 (+ kOddBase for odd x).  This thread's items of
-    // the split pass: piece P = ps*512 + tid -> 8 bytes at p*16 + half*8 of each part
-    constexpr int NPS = (NPIECE + 511) / 512;                     // 5 passes
+    // the split pass (every wave of the workgroup takes part, the copy waves too -- they are idle between the two
+    // barriers of a step): piece P = ps*NT + tid -> 8 bytes at p*16 + half*8 of each part
+    constexpr int NT = kSplitKernelThreads, NPS = (NPIECE + NT - 1) / NT;
     unsigned spos[NPS];
 #pragma unroll
     for (int ps = 0; ps < NPS; ++ps) {
-        const int P = ps * 512 + tid;
+        const int P = ps * NT + tid;
         const int Pc = P < NPIECE ? P : 0;
         const int row = Pc / ROWP, q = Pc % ROWP, x = q >> 1;
         spos[ps] = P < NPIECE ? (unsigned)((row * kRowVox + (x >> 1) + (x & 1) * kOddBase) * 16 + (q & 1) * 8) : 0xffffffffu;
@@ -224,20 +233,93 @@ __global__ __launch_bounds__(512) void conv3d_c8_bf16x6_kernel(ConvArgs a, int n
         const unsigned soff = (unsigned)(ch * a.W * 32);
 #pragma unroll
         for (int i = 0; i < IPW; ++i) {
-            if (i * 8 + wv >= (NPIECE + 63) / 64) continue;   // wave-uniform: 39 copies
-            glds16_buf(voff[j][i], srd[j], soff, lds_base + (unsigned)(F_OFF + (i * 8 + wv) * 1024));
+            if (i * NC + cw >= NCOPY) continue;   // wave-uniform
+            glds16_buf(voff[j][i], srd[j], soff, lds_base + (unsigned)(F_OFF + (i * NC + cw) * 1024));
         }
     };
     const unsigned char *wsrc = reinterpret_cast<const unsigned char *>(a.wpk);
-    auto issue_weights = [&](int ch, int sel) {   // 27 KiB = 27 wave-copies over the 8 waves
+    auto issue_weights = [&](int ch, int sel) {   // 27 KiB = 27 wave-copies over the copy waves
         if (abl & 4) return;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int g = i * 8 + wv;
+        for (int i = 0; i < (27 + NC - 1) / NC; ++i) {
+            const int g = i * NC + cw;
             if (g < 27) glds16(wsrc + (size_t)ch * WBYTES + (size_t)g * 1024 + lane * 16,
                                lds_base + (unsigned)(sel * WBYTES + g * 1024));
         }
     };
+
+    // split pass: every halo voxel once (the MFMA phase reads each ~5 times), fp32 -> hi, mid, lo
+    auto split_pass = [&]() {
+        f32x4 x[NPS];
+        const unsigned fp = lds_base + (unsigned)(F_OFF + tid * 16);
+        static_for<0, NPS>([&](auto pc) {
+            constexpr int ps = decltype(pc)::value;
+            x[ps] = lds_read_b128<ps * NT * 16>(fp);
+        });
+        lds_wait_n<0>();
+        static_for<0, (NPS + 1) / 2>([&](auto pc) {
+            constexpr int p0 = 2 * decltype(pc)::value, p1 = (p0 + 1 < NPS) ? p0 + 1 : p0;
+            asm volatile("" : "+v"(x[p0]), "+v"(x[p1]));
+            bf16x8 h, m, l;
+            if constexpr (ABL & 8) {
+                h = __builtin_bit_cast(bf16x8, x[p0]); m = __builtin_bit_cast(bf16x8, x[p1]); l = h;
+            } else if constexpr (DOT2) split3_block(x[p0], x[p1], h, m, l);
+            else split3<false>(x[p0], x[p1], h, m, l);
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 hu = __builtin_bit_cast(u32x4, h), mu = __builtin_bit_cast(u32x4, m), lu = __builtin_bit_cast(u32x4, l);
+            if (spos[p0] != 0xffffffffu) {
+                const unsigned sp = lds_base + (unsigned)S_OFF + spos[p0];
+                lds_write_b64<0>(sp, hu[0], hu[1]);
+                lds_write_b64<SPART>(sp, mu[0], mu[1]);
+                lds_write_b64<2 * SPART>(sp, lu[0], lu[1]);
+            }
+            if (p1 != p0 && spos[p1] != 0xffffffffu) {
+                const unsigned sp = lds_base + (unsigned)S_OFF + spos[p1];
+                lds_write_b64<0>(sp, hu[2], hu[3]);
+                lds_write_b64<SPART>(sp, mu[2], mu[3]);
+                lds_write_b64<2 * SPART>(sp, lu[2], lu[3]);
+            }
+        });
+        lds_wait_n<0>();
+    };
+
+    if (copier) {
+        // ================================================================ copy waves: the walk of steps, two barriers each
+        int wsel = 0;
+        if (ntw > 0) {
+            geometry(std::integral_constant<int, 0>{}, t0);
+            issue_halo(std::integral_constant<int, 0>{}, 0);
+            issue_weights(0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        for (int k0 = 0; k0 < ntw; k0 += T) {
+            const int nvalid = min(T, ntw - k0);
+#pragma unroll 1
+            for (int ch = 0; ch < NCHUNK; ++ch) {
+                static_for<0, T>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    if (j >= nvalid) return;   // wave-uniform
+                    __syncthreads();           // the halo of this step is in the fp32 buffer (this wave has waited for it)
+                    if (!(abl & 1)) split_pass();
+                    __syncthreads();           // ... and has been split: the fp32 buffer is free
+                    if (j + 1 < nvalid) {
+                        if (ch == 0) geometry(std::integral_constant<int, (j + 1) % T>{}, t0 + (k0 + j + 1) * t_step);
+                        issue_halo(std::integral_constant<int, (j + 1) % T>{}, ch);
+                    } else if (ch + 1 < NCHUNK) {
+                        issue_halo(std::integral_constant<int, 0>{}, ch + 1);
+                        issue_weights(ch + 1, wsel ^ 1);
+                    } else if (k0 + T < ntw) {
+                        geometry(std::integral_constant<int, 0>{}, t0 + (k0 + T) * t_step);
+                        issue_halo(std::integral_constant<int, 0>{}, 0);
+                        issue_weights(0, wsel ^ 1);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                });
+                wsel ^= 1;
+            }
+        }
+        return;
+    }
 
     float4 sc, sh;
     {
@@ -255,11 +337,6 @@ __global__ __launch_bounds__(512) void conv3d_c8_bf16x6_kernel(ConvArgs a, int n
     for (int j = 0; j < T; ++j) acc[j][0] = acc[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     int wsel = 0;
-    if (ntw > 0) {
-        geometry(std::integral_constant<int, 0>{}, t0);
-        issue_halo(std::integral_constant<int, 0>{}, 0);
-        issue_weights(0, 0);
-    }
     // ABL & 128 (tuning): cycles of each wave per phase, summed over the workgroup's steps, into the buffer passed
     // as `residual` (int64 [workgroup][wave][8]): copy wait, barrier, split pass, barrier, copy issue, MFMA phase, epilogue
     long long tsum[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -279,55 +356,11 @@ __global__ __launch_bounds__(512) void conv3d_c8_bf16x6_kernel(ConvArgs a, int n
                 MVS_LAP(0);
                 __syncthreads();
                 MVS_LAP(1);
-                // ---- split pass: every halo voxel once (the MFMA phase reads each ~5 times), fp32 -> hi, mid, lo
-                if (!(abl & 1)) {
-                    f32x4 x[NPS];
-                    const unsigned fp = lds_base + (unsigned)(F_OFF + tid * 16);
-                    static_for<0, NPS>([&](auto pc) {
-                        constexpr int ps = decltype(pc)::value;
-                        x[ps] = lds_read_b128<ps * 8192>(fp);
-                    });
-                    lds_wait_n<0>();
-                    static_for<0, (NPS + 1) / 2>([&](auto pc) {
-                        constexpr int p0 = 2 * decltype(pc)::value, p1 = (p0 + 1 < NPS) ? p0 + 1 : p0;
-                        asm volatile("" : "+v"(x[p0]), "+v"(x[p1]));
-                        bf16x8 h, m, l;
-                        if constexpr (ABL & 8) {
-                            h = __builtin_bit_cast(bf16x8, x[p0]); m = __builtin_bit_cast(bf16x8, x[p1]); l = h;
-                        } else if constexpr (DOT2) split3_block(x[p0], x[p1], h, m, l);
-                        else split3<false>(x[p0], x[p1], h, m, l);
-                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                        const u32x4 hu = __builtin_bit_cast(u32x4, h), mu = __builtin_bit_cast(u32x4, m), lu = __builtin_bit_cast(u32x4, l);
-                        if (spos[p0] != 0xffffffffu) {
-                            const unsigned sp = lds_base + (unsigned)S_OFF + spos[p0];
-                            lds_write_b64<0>(sp, hu[0], hu[1]);
-                            lds_write_b64<SPART>(sp, mu[0], mu[1]);
-                            lds_write_b64<2 * SPART>(sp, lu[0], lu[1]);
-                        }
-                        if (p1 != p0 && spos[p1] != 0xffffffffu) {
-                            const unsigned sp = lds_base + (unsigned)S_OFF + spos[p1];
-                            lds_write_b64<0>(sp, hu[2], hu[3]);
-                            lds_write_b64<SPART>(sp, mu[2], mu[3]);
-                            lds_write_b64<2 * SPART>(sp, lu[2], lu[3]);
-                        }
-                    });
-                    lds_wait_n<0>();
-                }
+                if (!(abl & 1)) split_pass();
                 MVS_LAP(2);
                 __syncthreads();
                 MVS_LAP(3);
-                // ---- the fp32 buffer is free: next step's halo (and, at a chunk change, the next weight chunk)
-                if (j + 1 < nvalid) {
-                    if (ch == 0) geometry(std::integral_constant<int, (j + 1) % T>{}, t0 + (k0 + j + 1) * t_step);
-                    issue_halo(std::integral_constant<int, (j + 1) % T>{}, ch);
-                } else if (ch + 1 < NCHUNK) {
-                    issue_halo(std::integral_constant<int, 0>{}, ch + 1);
-                    issue_weights(ch + 1, wsel ^ 1);
-                } else if (k0 + T < ntw) {
-                    geometry(std::integral_constant<int, 0>{}, t0 + (k0 + T) * t_step);
-                    issue_halo(std::integral_constant<int, 0>{}, 0);
-                    issue_weights(0, wsel ^ 1);
-                }
+                // (the copy waves now request the next step's halo and, at a chunk change, the next weight chunk)
                 MVS_LAP(4);
                 if (abl & 1) return;
                 // ---- MFMA phase: 12 input-row fragments f = (kz, iy) into row 0 (ky = iy) and row 1 (ky = iy - 1);
@@ -491,7 +524,7 @@ extern "C" int mvs_conv3d_c8_bf16x6_f32(const float *in, const void *packed, con
     const int64_t nt = (int64_t)B * a.tiles_x * a.tiles_y * a.tiles_z;
     if (nt <= 0 || nt > 0x7fffffffLL) return bare_error(MVS_EINVAL, __func__, __LINE__);
     const int n_cu = device_cu_count();
-    const dim3 grid((unsigned)(nt < n_cu ? nt : n_cu)), blk(512);
+    const dim3 grid((unsigned)(nt < n_cu ? nt : n_cu)), blk(kSplitKernelThreads);
     hipStream_t st = as_stream(stream);
     // MVS_CONV_SPLIT_DOT2=0: the split written with plain conversions and subtractions (same operands bit for
     // bit; kept to cross-check the v_dot2c form)
