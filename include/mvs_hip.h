@@ -185,6 +185,19 @@ int mvs_conv3d_c8_bf16x6_f32(const float *in, const void *packed, const float *s
                              const float *residual, int relu, int B, int Cin, int D, int H, int W,
                              float *out, void *stream);
 
+/* The same split-operand arithmetic for the 3x3(x3), stride-1, pad-1 layers with 16 / 32 / 64 input and output
+ * channels (CostRegNet conv2 / conv4 / conv6, mvsnet.py:68-72; FeatureNet's 16 -> 16 and 32 -> 32 layers,
+ * mvsnet.py:21-27; the same shapes in CasMVSNet/models/module.py and CVP-MVSNet/models/net.py:22-97):
+ * mvs_amd/csrc/conv_split.hip.  kd = 3: volume [B,D,H,W,Cin] -> [B,D,H,W,Cout]; kd = 1: B*D images
+ * [B,D,H,W,Cin] convolved plane by plane (pass D = number of images, B = 1).  weight: PyTorch layout
+ * (Cout, Cin, [kd,] 3, 3); relu: 0 none, 1 ReLU, 2 LeakyReLU(0.1); scale / shift / residual as mvs_conv3d_f32. */
+int mvs_conv_split_supported(int kd, int Cin, int Cout);
+size_t mvs_conv_split_packed_bytes(int kd, int Cin, int Cout);
+int mvs_conv_split_pack_weights_f32(const float *weight, int kd, int Cin, int Cout, void *packed, void *stream);
+int mvs_conv_split_f32(const float *in, const void *packed, const float *scale, const float *shift,
+                       const float *residual, int relu, int kd, int B, int Cin, int Cout, int D, int H, int W,
+                       float *out, void *stream);
+
 /* The whole 3D U-Net in one call -- CostRegNet.forward, mvsnet.py:83-93 (also the cascade's
  * CostRegNet, CasMVSNet/models/module.py:407-438): conv0 .. conv6 (3x3x3 + folded BN + ReLU, strides
  * 1 2 1 2 1 2 1), conv7 / conv9 / conv11 (transposed, stride 2, + BN + ReLU, skip-add of conv4 /
@@ -200,8 +213,9 @@ typedef struct mvs_conv_layer {
     const float *packed; /* mvs_conv3d_pack_weights_f32 output, or NULL (direct kernels) */
     const float *scale;  /* folded BatchNorm scale [Cout], or NULL */
     const float *shift;  /* folded BatchNorm shift / conv bias [Cout], or NULL */
-    const void *packed_split; /* conv0 only: mvs_conv3d_pack_weights_bf16x6_f32 output -- with an
-                               * MVS_LAYOUT_C8 input the layer then runs as mvs_conv3d_c8_bf16x6_f32;
+    const void *packed_split; /* conv0: mvs_conv3d_pack_weights_bf16x6_f32 output -- with an MVS_LAYOUT_C8
+                               * input the layer then runs as mvs_conv3d_c8_bf16x6_f32; conv2 / conv4 / conv6:
+                               * mvs_conv_split_pack_weights_f32 output -> mvs_conv_split_f32;
                                * NULL = the fp32 MFMA kernel */
 } mvs_conv_layer;
 size_t mvs_costreg_workspace_bytes(int B, int base, int D, int H, int W);

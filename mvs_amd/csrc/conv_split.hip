@@ -1,0 +1,450 @@
+// 3x3(x3) stride-1 convolutions with Cout = 16 or 32 per launch (Cin = 16, 32, 64; channels-last) on the BF16
+// matrix pipe at FP32 accuracy: CostRegNet's conv2 / conv4 / conv6 (mvsnet.py:68-72), FeatureNet's 16 -> 16 and
+// 32 -> 32 layers (mvsnet.py:21-27), the same-shaped layers of the cascade (CasMVSNet/models/module.py) and of
+// CVP-MVSNet (net.py:22-97).  Operand splitting and error bound: conv_split_common.h / conv_bf16x6.hip.
+//
+// One step = one 8-channel chunk of one output tile.  A workgroup = 8 multiplying waves + 4 copy waves:
+//   copy waves   request the fp32 halo of the NEXT step by LDS-DMA (`buffer_load ... lds`; a copy blocks the wave
+//                that issues it for ~250 cycles, so the multiplying waves issue none), and at a chunk change the
+//                next weight chunk; wait for them; take part in the split pass
+//   barrier      the halo has landed, every wave is done with the previous step's bf16 parts
+//   split pass   all 12 waves: every halo voxel once, fp32 -> hi, mid, lo -> three bf16 planes in LDS
+//   barrier
+//   MFMA phase   one v_mfma_f32_16x16x32_bf16 = 4 taps x 8 channels (K = 32) x 16 output channels x 16 voxels
+//                along x; per (row block, tap group) the B fragment is three ds_read_b128 (one per part), per
+//                (tap group, 16 output channels) the A fragment three more; six MFMAs per pair
+// Tiles of a group share the chunk's weights in LDS and keep their accumulators in registers over the chunk loop.
+#include "conv_split_common.h"
+
+#include <cstdlib>
+
+namespace mvs {
+
+struct SplitArgs {
+    const float *in;          // [B, D, H, W, Cin]
+    const unsigned char *wpk; // [chunk][group][m-tile][part][lane][8 bf16]
+    const float *scale, *shift, *residual;   // per output channel (of this launch) / [B, D, H, W, ldc] like out
+    float *out;               // [B, D, H, W, ldc], this launch writes channels [0, COUT)
+    int B, D, H, W, ldc;
+    int tiles_x, tiles_y, tiles_z, ystrip;
+    int relu;                 // 0 none, 1 ReLU, 2 LeakyReLU(0.1)
+};
+
+template <int CIN_, int COUT_, int KD_>
+struct SplitCfg {
+    static constexpr int CIN = CIN_, COUT = COUT_, KD = KD_;
+    static constexpr int NCHUNK = CIN / 8, MT = COUT / 16;
+    static constexpr int NTAP = KD * 9, G = (NTAP + 3) / 4;
+    // output tile (TZ, TY, 16 XB) and its halo
+    static constexpr int TZ = KD == 3 ? 4 : 1, TY = KD == 3 ? (COUT_ == 16 ? 8 : 4) : 16, XB = KD == 3 ? 1 : 2, TX = 16 * XB;   // (Cout 32 in 3D: two weight chunks of 42 KiB leave room for the smaller halo only)
+    static constexpr int ZT = TZ + KD - 1, YT = TY + 2, XP = TX + 2, NVOX = ZT * YT * XP;
+    static constexpr int RB = TZ * TY * XB, RPW = RB / 8;                 // 16-voxel row blocks, per multiplying wave
+    static constexpr int NPIECE = 2 * NVOX, NCOPY = (NPIECE + 63) / 64;   // 16-byte pieces (voxel, channel half)
+    static constexpr int FBYTES = NCOPY * 1024, SPART = NVOX * 16, SBYTES = 3 * SPART;
+    static constexpr int WBYTES = G * MT * 3 * 1024;                      // A fragments of one chunk
+    static constexpr int T = MT == 1 ? 4 : 2;                             // tiles per group
+    static constexpr int F_OFF = 2 * WBYTES, S_OFF = F_OFF + FBYTES, LDS_BYTES = S_OFF + SBYTES;
+    static_assert(RB % 8 == 0 && LDS_BYTES <= 160 * 1024 && SPART * 2 + 16 * 1024 < 65536, "tile / LDS budget");
+};
+
+constexpr int kSplitCopyWaves = 4, kSplitThreads = 512 + 64 * kSplitCopyWaves;
+
+__device__ __forceinline__ TileIdx split_decode(const SplitArgs &a, int bid) {
+    TileIdx t;
+    const int per_b = a.tiles_x * a.tiles_y * a.tiles_z;
+    t.b = bid / per_b; bid -= t.b * per_b;
+    const int full = a.ystrip * a.tiles_z * a.tiles_x;
+    const int s = bid / full; bid -= s * full;
+    const int y0 = s * a.ystrip;
+    const int hs = min(a.ystrip, a.tiles_y - y0);   // the last strip may be short
+    t.ty = y0 + bid % hs; bid /= hs;
+    t.tz = bid % a.tiles_z;
+    t.tx = bid / a.tiles_z;
+    return t;
+}
+
+template <class C>
+__global__ __launch_bounds__(kSplitThreads) void conv_split_kernel(SplitArgs a, int ntiles) {
+    constexpr int CIN = C::CIN, NCHUNK = C::NCHUNK, MT = C::MT, G = C::G, T = C::T, RPW = C::RPW;
+    constexpr int YT = C::YT, XP = C::XP, NVOX = C::NVOX, NPIECE = C::NPIECE, NCOPY = C::NCOPY;
+    constexpr int SPART = C::SPART, WBYTES = C::WBYTES, F_OFF = C::F_OFF, S_OFF = C::S_OFF;
+    constexpr int NC = kSplitCopyWaves, IPW = (NCOPY + NC - 1) / NC, NT = kSplitThreads;
+    constexpr int NWC = (WBYTES / 1024 + NC - 1) / NC;            // weight copies per copy wave
+    __shared__ __attribute__((aligned(16))) unsigned char lds[C::LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kq = lane >> 4;
+    const unsigned lds_base = (unsigned)(uintptr_t)lds;
+    const bool copier = wv >= 8;
+    const int cw = wv - 8;
+
+    // this workgroup's tiles: t0 + k * t_step, k < ntw (XCD x owns a contiguous range of the ordered tile list)
+    int t0, t_step, ntw;
+    {
+        const int nb = gridDim.x;
+        if ((nb & 7) == 0) {
+            const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per = nb >> 3;
+            const int lo = (int)((int64_t)ntiles * xcd / 8), hi = (int)((int64_t)ntiles * (xcd + 1) / 8);
+            t0 = lo + j; t_step = per; ntw = (hi - t0 + per - 1) / per;
+        } else {
+            t0 = blockIdx.x; t_step = nb; ntw = (ntiles - t0 + nb - 1) / nb;
+        }
+        if (ntw < 0) ntw = 0;
+    }
+
+    // split pass (all waves): piece P = ps*NT + tid = (voxel P >> 1, channel half P & 1): 16 bytes of the fp32 buffer
+    // -> 8 bytes of each bf16 part at the same position
+    constexpr int NPS = (NPIECE + NT - 1) / NT;
+    auto split_pass = [&]() {
+        f32x4 x[NPS];
+        const unsigned fp = lds_base + (unsigned)(F_OFF + tid * 16), sp = lds_base + (unsigned)(S_OFF + tid * 8);
+        static_for<0, NPS>([&](auto pc) {
+            constexpr int ps = decltype(pc)::value;
+            x[ps] = lds_read_b128<ps * NT * 16>(fp);
+        });
+        lds_wait_n<0>();
+        static_for<0, (NPS + 1) / 2>([&](auto pc) {
+            constexpr int p0 = 2 * decltype(pc)::value, p1 = (p0 + 1 < NPS) ? p0 + 1 : p0;
+            f32x4 &x0 = x[p0], &x1 = x[p1];
+            asm volatile("" : "+v"(x0), "+v"(x1));
+            bf16x8 h, m, l;
+            split3_block(x0, x1, h, m, l);
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 hu = __builtin_bit_cast(u32x4, h), mu = __builtin_bit_cast(u32x4, m), lu = __builtin_bit_cast(u32x4, l);
+            if (p0 * NT + tid < NPIECE) {
+                lds_write_b64<p0 * NT * 8>(sp, hu[0], hu[1]);
+                lds_write_b64<p0 * NT * 8 + SPART>(sp, mu[0], mu[1]);
+                lds_write_b64<p0 * NT * 8 + 2 * SPART>(sp, lu[0], lu[1]);
+            }
+            if (p1 != p0 && p1 * NT + tid < NPIECE) {
+                lds_write_b64<p1 * NT * 8>(sp, hu[2], hu[3]);
+                lds_write_b64<p1 * NT * 8 + SPART>(sp, mu[2], mu[3]);
+                lds_write_b64<p1 * NT * 8 + 2 * SPART>(sp, lu[2], lu[3]);
+            }
+        });
+        lds_wait_n<0>();
+    };
+
+    if (copier) {
+        // ================================================================ copy waves
+        // copy g = i*NC + cw brings pieces g*64 + lane: (voxel, half) of the halo, voxel = (lz, ly, lx) x-fastest
+        int loc[IPW];
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const int P = (i * NC + cw) * 64 + lane;
+            const bool ok = P < NPIECE;
+            const int v = ok ? P >> 1 : 0;
+            loc[i] = (v % XP) | (((v / XP) % YT) << 8) | ((v / (XP * YT)) << 16) | ((P & 1) << 24) | (ok ? 0 : (int)0x80000000);
+        }
+        const int64_t plane_in = (int64_t)a.H * a.W * CIN;
+        const int row_in = a.W * CIN;
+        const unsigned window_bytes = (unsigned)min((int64_t)C::ZT * plane_in * 4, (int64_t)0xffffff00u);
+        unsigned voff[T][IPW];
+        mvs_srd_t srd[T];
+        auto geometry = [&](auto jc, int t) {
+            constexpr int j = decltype(jc)::value;
+            const TileIdx tile = split_decode(a, t);
+            const int ix0 = tile.tx * C::TX - 1, iy0 = tile.ty * C::TY - 1, iz0 = tile.tz * C::TZ - (C::KD == 3 ? 1 : 0);
+            srd[j] = make_srd(a.in + ((int64_t)tile.b * a.D + iz0) * plane_in, window_bytes);
+#pragma unroll
+            for (int i = 0; i < IPW; ++i) {
+                const int gx = ix0 + (loc[i] & 255), gy = iy0 + ((loc[i] >> 8) & 255);
+                const int lz = (loc[i] >> 16) & 255, h = (loc[i] >> 24) & 1;
+                const bool ok = loc[i] >= 0 && (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H &&
+                                (unsigned)(iz0 + lz) < (unsigned)a.D;
+                voff[j][i] = ok ? (unsigned)(((int64_t)lz * plane_in + (int64_t)gy * row_in + gx * CIN + h * 4) * 4) : 0xffffff00u;
+            }
+        };
+        auto issue_halo = [&](auto jc, int ch) {
+            constexpr int j = decltype(jc)::value;
+            const unsigned soff = (unsigned)(ch * 32);
+#pragma unroll
+            for (int i = 0; i < IPW; ++i) {
+                if (i * NC + cw >= NCOPY) continue;   // wave-uniform
+                glds16_buf(voff[j][i], srd[j], soff, lds_base + (unsigned)(F_OFF + (i * NC + cw) * 1024));
+            }
+        };
+        auto issue_weights = [&](int ch, int sel) {
+#pragma unroll
+            for (int i = 0; i < NWC; ++i) {
+                const int g = i * NC + cw;
+                if (g < WBYTES / 1024) glds16(a.wpk + (size_t)ch * WBYTES + (size_t)g * 1024 + lane * 16,
+                                              lds_base + (unsigned)(sel * WBYTES + g * 1024));
+            }
+        };
+        int wsel = 0;
+        if (ntw > 0) {
+            geometry(std::integral_constant<int, 0>{}, t0);
+            issue_halo(std::integral_constant<int, 0>{}, 0);
+            issue_weights(0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        for (int k0 = 0; k0 < ntw; k0 += T) {
+            const int nvalid = min(T, ntw - k0);
+#pragma unroll 1
+            for (int ch = 0; ch < NCHUNK; ++ch) {
+                static_for<0, T>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    if (j >= nvalid) return;   // wave-uniform
+                    __syncthreads();           // the halo of this step is in the fp32 buffer (this wave has waited for it)
+                    split_pass();
+                    __syncthreads();           // ... and has been split: the fp32 buffer is free
+                    if (j + 1 < nvalid) {
+                        if (ch == 0) geometry(std::integral_constant<int, (j + 1) % T>{}, t0 + (k0 + j + 1) * t_step);
+                        issue_halo(std::integral_constant<int, (j + 1) % T>{}, ch);
+                    } else if (ch + 1 < NCHUNK) {
+                        issue_halo(std::integral_constant<int, 0>{}, ch + 1);
+                        issue_weights(ch + 1, wsel ^ 1);
+                    } else if (k0 + T < ntw) {
+                        geometry(std::integral_constant<int, 0>{}, t0 + (k0 + T) * t_step);
+                        issue_halo(std::integral_constant<int, 0>{}, 0);
+                        issue_weights(0, wsel ^ 1);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                });
+                wsel ^= 1;
+            }
+        }
+        return;
+    }
+
+    // ================================================================ multiplying waves
+    // row block rb = wv*RPW + r -> (z, y, x block); this lane's B voxel of tap (dz, dy, dx): (z+dz, y+dy, xb*16 + n + dx)
+    unsigned rbo[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int rb = wv * RPW + r;
+        const int z = rb / (C::TY * C::XB), y = (rb / C::XB) % C::TY, xb = rb % C::XB;
+        rbo[r] = (unsigned)(((z * YT + y) * XP + xb * 16 + n) * 16);
+    }
+    // tap t = 4 g + kq of this lane's K group (taps past the kernel read voxel 0 against zero weights)
+    unsigned tapo[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int t = 4 * g + kq;
+        const int dz = C::KD == 3 ? t / 9 : 0, dy = (t % 9) / 3, dx = t % 3;
+        tapo[g] = t < C::NTAP ? (unsigned)(((dz * YT + dy) * XP + dx) * 16) : 0u;
+    }
+
+    float4 sc[MT], sh[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int c0 = m * 16 + kq * 4;
+        sc[m] = a.scale ? *reinterpret_cast<const float4 *>(a.scale + c0) : make_float4(1.f, 1.f, 1.f, 1.f);
+        sh[m] = a.shift ? *reinterpret_cast<const float4 *>(a.shift + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    f32x4 acc[T][RPW][MT];
+#pragma unroll
+    for (int j = 0; j < T; ++j)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[j][r][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int wsel = 0;
+    for (int k0 = 0; k0 < ntw; k0 += T) {
+        const int nvalid = min(T, ntw - k0);
+#pragma unroll 1
+        for (int ch = 0; ch < NCHUNK; ++ch) {
+            static_for<0, T>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if (j >= nvalid) return;   // wave-uniform
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (this wave's stores of the previous group)
+                __syncthreads();
+                split_pass();
+                __syncthreads();
+                // ---- MFMA phase: items (g, r) = (tap group, row block); the reads of the next item go out before the
+                // MFMAs of the current one
+                const unsigned aA = lds_base + (unsigned)(wsel * WBYTES + lane * 16);
+                const unsigned aS = lds_base + (unsigned)S_OFF;
+                bf16x8 A[2][MT][3], Bf[2][3];
+                auto read_a = [&](auto gc) {
+                    constexpr int g = decltype(gc)::value;
+                    static_for<0, MT * 3>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        A[g & 1][i / 3][i % 3] = __builtin_bit_cast(bf16x8, lds_read_b128<(g * MT * 3 + i) * 1024>(aA));
+                    });
+                };
+                auto read_b = [&](auto ic) {
+                    constexpr int it = decltype(ic)::value, g = it / RPW, r = it % RPW;
+                    const unsigned ad = aS + rbo[r] + tapo[g];
+                    static_for<0, 3>([&](auto pc) {
+                        constexpr int sp = decltype(pc)::value;
+                        Bf[it & 1][sp] = __builtin_bit_cast(bf16x8, lds_read_b128<sp * SPART>(ad));
+                    });
+                };
+                read_a(std::integral_constant<int, 0>{});
+                read_b(std::integral_constant<int, 0>{});
+                static_for<0, G * RPW>([&](auto ic) {
+                    constexpr int it = decltype(ic)::value, g = it / RPW, r = it % RPW;
+                    lds_wait_n<0>();
+                    {
+                        bf16x8 &b0 = Bf[it & 1][0], &b1 = Bf[it & 1][1], &b2 = Bf[it & 1][2];
+                        asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2));
+                    }
+                    if constexpr (r == 0) {
+                        static_for<0, MT * 3>([&](auto qc) {
+                            bf16x8 &aa = A[g & 1][decltype(qc)::value / 3][decltype(qc)::value % 3];
+                            asm volatile("" : "+v"(aa));
+                        });
+                    }
+                    if constexpr (it + 1 < G * RPW) {
+                        if constexpr (r == RPW - 1) read_a(std::integral_constant<int, g + 1>{});
+                        read_b(std::integral_constant<int, it + 1>{});
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // the reads go out BEFORE this item's MFMAs
+                    const bf16x8 bh = Bf[it & 1][0], bm = Bf[it & 1][1], bl = Bf[it & 1][2];
+                    // six partial products per 16 output channels, small terms first; M tiles interleaved
+                    static_for<0, 6>([&](auto tc) {
+                        constexpr int t = decltype(tc)::value;
+                        constexpr int as = (t == 0 || t == 3) ? 1 : (t == 1 ? 2 : 0);       // am al ah am ah ah
+                        static_for<0, MT>([&](auto mc) {
+                            constexpr int m = decltype(mc)::value;
+                            const bf16x8 &bb = (t == 0 || t == 4) ? bm : (t == 2 ? bl : bh);   // bm bh bl bh bm bh
+                            const bf16x8 &aa = A[g & 1][m][as];
+                            f32x4 &cc = acc[j][r][m];
+                            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aa, bb, cc, 0, 0, 0);
+                        });
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+            wsel ^= 1;
+        }
+        // ---- epilogue of the group: per-channel affine, activation, skip add, one 16-byte store per lane, row block, M tile
+        static_for<0, T>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if (j >= nvalid) return;
+            const TileIdx cur = split_decode(a, t0 + (k0 + j) * t_step);
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int rb = wv * RPW + r;
+                const int oz = cur.tz * C::TZ + rb / (C::TY * C::XB), oy = cur.ty * C::TY + (rb / C::XB) % C::TY;
+                const int ox = cur.tx * C::TX + (rb % C::XB) * 16 + n;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    f32x4 v = acc[j][r][m];
+                    acc[j][r][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (oz >= a.D || oy >= a.H || ox >= a.W) continue;
+                    v[0] = v[0] * sc[m].x + sh[m].x; v[1] = v[1] * sc[m].y + sh[m].y;
+                    v[2] = v[2] * sc[m].z + sh[m].z; v[3] = v[3] * sc[m].w + sh[m].w;
+                    if (a.relu == 1) {
+                        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+                        v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                    } else if (a.relu == 2) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : v[q] * 0.1f;
+                    }
+                    const int64_t o = ((((int64_t)cur.b * a.D + oz) * a.H + oy) * a.W + ox) * a.ldc + m * 16 + kq * 4;
+                    if (a.residual) {
+                        const float4 rs = *reinterpret_cast<const float4 *>(a.residual + o);
+                        v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
+                    }
+                    *reinterpret_cast<float4 *>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        });
+    }
+}
+
+// PyTorch-layout weight (Cout_total, Cin, [kd,] 3, 3), output channels [co0, co0 + COUT) ->
+// [chunk][group][m-tile][part][lane][8 bf16]; lane (mrow, kq): output channel co0 + m*16 + mrow, tap 4 g + kq (zero
+// past the kernel), channel chunk*8 + j
+__global__ __launch_bounds__(256) void pack_split_kernel(const float *__restrict__ w, int Cin, int ntap, int G, int MT,
+                                                         int co0, unsigned short *__restrict__ out, int total) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int j = i & 7, lane = (i >> 3) & 63;
+    int rest = i >> 9;
+    const int m = rest % MT; rest /= MT;
+    const int g = rest % G, ch = rest / G;
+    const int mrow = lane & 15, kq = lane >> 4, t = 4 * g + kq;
+    float x = 0.0f;
+    if (t < ntap) x = w[((int64_t)(co0 + m * 16 + mrow) * Cin + ch * 8 + j) * ntap + t];
+    const __bf16 h = (__bf16)x;
+    const float r1 = x - (float)h;
+    const __bf16 mm = (__bf16)r1;
+    const float r2 = r1 - (float)mm;
+    const __bf16 l = (__bf16)r2;
+    unsigned short *o = out + ((size_t)((ch * G + g) * MT + m) * 3) * 512 + lane * 8 + j;
+    o[0] = __builtin_bit_cast(unsigned short, h);
+    o[512] = __builtin_bit_cast(unsigned short, mm);
+    o[1024] = __builtin_bit_cast(unsigned short, l);
+}
+
+template <class C>
+static int launch_split(const SplitArgs &a0, hipStream_t st) {
+    SplitArgs a = a0;
+    a.tiles_x = (a.W + C::TX - 1) / C::TX; a.tiles_y = (a.H + C::TY - 1) / C::TY; a.tiles_z = (a.D + C::TZ - 1) / C::TZ;
+    a.ystrip = C::KD == 3 ? 4 : 2;
+    const int64_t nt = (int64_t)a.B * a.tiles_x * a.tiles_y * a.tiles_z;
+    if (nt <= 0 || nt > 0x7fffffffLL) return bare_error(MVS_EINVAL, __func__, __LINE__);
+    const int n_cu = device_cu_count();
+    hipLaunchKernelGGL((conv_split_kernel<C>), dim3((unsigned)(nt < n_cu ? nt : n_cu)), dim3(kSplitThreads), 0, st, a, (int)nt);
+    return check_launch("mvs_conv_split_f32");
+}
+
+}  // namespace mvs
+
+using namespace mvs;
+
+// Cout of ONE launch: 32 where the layer has a multiple of 32 output channels, else 16
+static int split_cout_step(int Cout) { return Cout % 32 == 0 ? 32 : 16; }
+
+extern "C" int mvs_conv_split_supported(int kd, int Cin, int Cout) {
+    return (kd == 1 || kd == 3) && (Cin == 16 || Cin == 32 || Cin == 64) && (Cout == 16 || Cout == 32 || Cout == 64);
+}
+
+extern "C" size_t mvs_conv_split_packed_bytes(int kd, int Cin, int Cout) {
+    if (!mvs_conv_split_supported(kd, Cin, Cout)) return 0;
+    const int G = (kd * 9 + 3) / 4;
+    return (size_t)(Cin / 8) * G * (Cout / 16) * 3 * 1024;
+}
+
+extern "C" int mvs_conv_split_pack_weights_f32(const float *weight, int kd, int Cin, int Cout, void *packed, void *stream) {
+    if (!weight || !packed || !mvs_conv_split_supported(kd, Cin, Cout)) {
+        set_error("mvs_conv_split_pack_weights_f32: needs a (Cout, Cin, [kd,] 3, 3) weight with kd in {1, 3}, Cin and Cout in {16, 32, 64}");
+        return MVS_EINVAL;
+    }
+    // one block of the packed buffer per launch of the layer (Cout / step launches, each `step` output channels)
+    const int step = split_cout_step(Cout), G = (kd * 9 + 3) / 4, MT = step / 16;
+    const size_t per_launch = (size_t)(Cin / 8) * G * MT * 3 * 1024;
+    for (int co0 = 0; co0 < Cout; co0 += step) {
+        const int total = (Cin / 8) * G * MT * 512;
+        hipLaunchKernelGGL(pack_split_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), weight, Cin, kd * 9, G, MT,
+                           co0, reinterpret_cast<unsigned short *>(static_cast<unsigned char *>(packed) + (co0 / step) * per_launch), total);
+    }
+    return check_launch("mvs_conv_split_pack_weights_f32");
+}
+
+extern "C" int mvs_conv_split_f32(const float *in, const void *packed, const float *scale, const float *shift,
+                                  const float *residual, int relu, int kd, int B, int Cin, int Cout, int D, int H, int W,
+                                  float *out, void *stream) {
+    if (!in || !packed || !out || B <= 0 || D <= 0 || H <= 0 || W <= 0 || relu < 0 || relu > 2 ||
+        !mvs_conv_split_supported(kd, Cin, Cout)) {
+        set_error("mvs_conv_split_f32: invalid argument (kd in {1, 3}; Cin, Cout in {16, 32, 64}; stride 1; channels-last)");
+        return MVS_EINVAL;
+    }
+    if ((int64_t)(kd + 3) * H * W * Cin * 4 >= 0xffffff00LL) return bare_error(MVS_EINVAL, __func__, __LINE__);   // 32-bit halo offsets
+    const int step = split_cout_step(Cout), G = (kd * 9 + 3) / 4;
+    const size_t per_launch = (size_t)(Cin / 8) * G * (step / 16) * 3 * 1024;
+    hipStream_t st = as_stream(stream);
+    for (int co0 = 0; co0 < Cout; co0 += step) {
+        SplitArgs a;
+        a.in = in; a.wpk = static_cast<const unsigned char *>(packed) + (co0 / step) * per_launch;
+        a.scale = scale ? scale + co0 : nullptr; a.shift = shift ? shift + co0 : nullptr;
+        a.residual = residual ? residual + co0 : nullptr; a.out = out + co0;
+        a.B = B; a.D = D; a.H = H; a.W = W; a.ldc = Cout; a.relu = relu;
+        int rc = MVS_EUNSUPPORTED;
+#define MVS_SPLIT_CASE(CI, CO, KD) if (Cin == CI && step == CO && kd == KD) rc = launch_split<SplitCfg<CI, CO, KD>>(a, st);
+        MVS_SPLIT_CASE(16, 16, 3) MVS_SPLIT_CASE(32, 16, 3) MVS_SPLIT_CASE(64, 16, 3)
+        MVS_SPLIT_CASE(16, 32, 3) MVS_SPLIT_CASE(32, 32, 3) MVS_SPLIT_CASE(64, 32, 3)
+        MVS_SPLIT_CASE(16, 16, 1) MVS_SPLIT_CASE(32, 16, 1) MVS_SPLIT_CASE(64, 16, 1)
+        MVS_SPLIT_CASE(16, 32, 1) MVS_SPLIT_CASE(32, 32, 1) MVS_SPLIT_CASE(64, 32, 1)
+#undef MVS_SPLIT_CASE
+        if (rc != MVS_OK) return rc;
+    }
+    return MVS_OK;
+}

@@ -90,12 +90,12 @@ class FeatureNet(nn.Module):
             scale = (m.bn.weight / torch.sqrt(m.bn.running_var + m.bn.eps)).float().contiguous()
             shift = (m.bn.bias - m.bn.running_mean * scale).float().contiguous()
             return dict(cin=w.shape[1], cout=w.shape[0], k=w.shape[2], stride=stride,
-                        packed=ops.pack_conv2d_weight(w, stride), scale=scale, shift=shift, relu=True)
+                        packed=ops.pack_conv2d_weight(w, stride, split=True), scale=scale, shift=shift, relu=True)
 
         def plain(m):
             w = m.weight.detach().float().contiguous()
             return dict(cin=w.shape[1], cout=w.shape[0], k=w.shape[2], stride=1,
-                        packed=ops.pack_conv2d_weight(w, 1), scale=None,
+                        packed=ops.pack_conv2d_weight(w, 1, split=True), scale=None,
                         shift=None if m.bias is None else m.bias.detach().float().contiguous(), relu=False)
 
         with torch.no_grad():

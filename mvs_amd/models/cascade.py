@@ -37,7 +37,7 @@ def pack_costreg(sd, prefix=""):
             mu, var = sd[f"{prefix}{name}.bn.running_mean"], sd[f"{prefix}{name}.bn.running_var"]
             scale = (g / torch.sqrt(var + eps)).float().contiguous()
             P[name] = dict(weight=w, scale=scale, shift=(b - mu * scale).float().contiguous(),
-                           stride=stride, transposed=tr, packed=ops.pack_conv3d_weight(w, tr, stride))
+                           stride=stride, transposed=tr, packed=ops.pack_conv3d_weight(w, tr, stride, split=True))
         if ops.conv_split_enabled():
             P["conv0"]["packed_split"] = ops.pack_conv3d_weight_split(P["conv0"]["weight"])
         w = sd[f"{prefix}prob.weight"].float().contiguous()

@@ -61,7 +61,7 @@ class FeaturePyramid(nn.Module):
             for name in self._ORDER:
                 conv = getattr(self, name)[0]
                 w = conv.weight.detach().float().contiguous()
-                P.append(dict(cin=w.shape[1], cout=w.shape[0], packed=ops.pack_conv2d_weight(w, 1),
+                P.append(dict(cin=w.shape[1], cout=w.shape[0], packed=ops.pack_conv2d_weight(w, 1, split=True),
                               shift=conv.bias.detach().float().contiguous()))
         self._hip_cache = (key, P)
         return P
@@ -134,7 +134,7 @@ class CostRegNet(nn.Module):
             w = w.detach().float().contiguous()
             scale, shift = fold(bn)
             return dict(weight=w, scale=scale, shift=shift, stride=stride, transposed=transposed,
-                        packed=ops.pack_conv3d_weight(w, transposed, stride))
+                        packed=ops.pack_conv3d_weight(w, transposed, stride, split=True))
 
         P = {}
         with torch.no_grad():

@@ -67,11 +67,11 @@ class FeatureNet(nn.Module):
                 scale = (m.bn.weight / torch.sqrt(m.bn.running_var + m.bn.eps)).float().contiguous()
                 shift = (m.bn.bias - m.bn.running_mean * scale).float().contiguous()
                 P.append(dict(name=name, cin=w.shape[1], cout=w.shape[0], k=w.shape[2],
-                              stride=stride, packed=ops.pack_conv2d_weight(w, stride), scale=scale,
+                              stride=stride, packed=ops.pack_conv2d_weight(w, stride, split=True), scale=scale,
                               shift=shift, relu=True))
             w = self.feature.weight.detach().float().contiguous()
             P.append(dict(name="feature", cin=w.shape[1], cout=w.shape[0], k=w.shape[2], stride=1,
-                          packed=ops.pack_conv2d_weight(w, 1), scale=None,
+                          packed=ops.pack_conv2d_weight(w, 1, split=True), scale=None,
                           shift=self.feature.bias.detach().float().contiguous(), relu=False))
         self._hip_cache = (key, P)
         return P
@@ -209,7 +209,7 @@ class CostRegNet(nn.Module):
                 w = conv.weight.detach().float().contiguous()
                 params[name] = dict(weight=w, scale=scale, shift=shift, stride=stride,
                                     transposed=(kind == "deconv"),
-                                    packed=ops.pack_conv3d_weight(w, kind == "deconv", stride))
+                                    packed=ops.pack_conv3d_weight(w, kind == "deconv", stride, split=True))
             if ops.conv_split_enabled():
                 params["conv0"]["packed_split"] = ops.pack_conv3d_weight_split(params["conv0"]["weight"])
             w = self.prob.weight.detach().float().contiguous()

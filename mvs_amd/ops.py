@@ -565,9 +565,25 @@ def conv3d_mfma_supported(transposed, cin, cout, stride):
     return bool(_lib.load().mvs_conv3d_mfma_supported(int(transposed), cin, cout, stride))
 
 
-def pack_conv3d_weight(weight, transposed, stride):
+_split_registry = {}   # id(packed fp32 weights) -> (weakref to them, their split-operand companion)
+
+
+def _register_split(packed, split):
+    import weakref
+    key = id(packed)
+    _split_registry[key] = (weakref.ref(packed, lambda _r, k=key: _split_registry.pop(k, None)), split)
+
+
+def split_companion(packed):
+    """The bf16 hi/mid/lo pack registered for this packed weight tensor (pack_conv*_weight(..., split=True)), or None."""
+    hit = _split_registry.get(id(packed)) if packed is not None else None
+    return hit[1] if hit is not None and hit[0]() is packed else None
+
+
+def pack_conv3d_weight(weight, transposed, stride, split=False):
     """PyTorch-layout weight -> MFMA A-fragment order (None if the shape has no
-    MFMA configuration)."""
+    MFMA configuration).  split: also pack the layer for the split-operand bf16 kernel (mvs_conv_split_f32) where
+    its shape has one and MVS_CONV_SPLIT is not 0; conv3d() then runs the layer there (inference paths opt in)."""
     weight = _f32c(weight)
     cin, cout = (weight.shape[0], weight.shape[1]) if transposed else (weight.shape[1], weight.shape[0])
     n = _lib.load().mvs_conv3d_packed_weight_floats(int(transposed), cin, cout, stride)
@@ -577,6 +593,10 @@ def pack_conv3d_weight(weight, transposed, stride):
     check(_lib.load().mvs_conv3d_pack_weights_f32(ptr(weight), int(transposed), cin, cout, stride,
                                                   ptr(packed), stream()),
           "mvs_conv3d_pack_weights_f32")
+    if split and not transposed and stride == 1 and conv_split_enabled():
+        sp = pack_conv_weight_split(weight)
+        if sp is not None:
+            _register_split(packed, sp)
     return packed
 
 
@@ -617,6 +637,43 @@ def conv3d_c8_split(x_c8, packed_split, scale=None, shift=None, residual=None, r
     return out
 
 
+def pack_conv_weight_split(weight):
+    """(Cout, Cin, [3,] 3, 3) weight -> the bf16 hi/mid/lo A fragments of conv_split (None if the shape has no
+    such kernel: Cin, Cout in {16, 32, 64})."""
+    weight = _f32c(weight)
+    kd = 3 if weight.dim() == 5 else 1
+    if tuple(weight.shape[-2:]) != (3, 3) or (kd == 3 and weight.shape[2] != 3):
+        return None
+    n = _lib.load().mvs_conv_split_packed_bytes(kd, int(weight.shape[1]), int(weight.shape[0]))
+    if n == 0:
+        return None
+    packed = torch.empty(n // 4, device=weight.device, dtype=torch.float32)   # opaque bytes
+    check(_lib.load().mvs_conv_split_pack_weights_f32(ptr(weight), kd, int(weight.shape[1]), int(weight.shape[0]),
+                                                      ptr(packed), stream()), "mvs_conv_split_pack_weights_f32")
+    return packed
+
+
+def conv_split(x_cl, packed_split, cout, scale=None, shift=None, residual=None, relu=1, kd=3):
+    """3x3(x3) stride-1 layer on the bf16 matrix pipe with exactly split fp32 operands (mvs_conv_split_f32).
+    kd = 3: x_cl [B,D,H,W,Cin] -> [B,D,H,W,cout]; kd = 1: images x_cl [N,H,W,Cin] -> [N,H,W,cout].
+    relu: 0 none, 1 ReLU, 2 LeakyReLU(0.1)."""
+    x_cl = _f32c(x_cl)
+    if kd == 3:
+        B, D, H, W, cin = x_cl.shape
+        out = torch.empty(B, D, H, W, cout, device=x_cl.device, dtype=torch.float32)
+    else:
+        D, H, W, cin = x_cl.shape
+        B = 1
+        out = torch.empty(D, H, W, cout, device=x_cl.device, dtype=torch.float32)
+    with stage("conv_split"):
+        check(_lib.load().mvs_conv_split_f32(
+            ptr(x_cl), ptr(packed_split), ptr(_f32c(scale)) if scale is not None else None,
+            ptr(_f32c(shift)) if shift is not None else None,
+            ptr(_f32c(residual)) if residual is not None else None, int(relu), kd, B, cin, cout, D, H, W,
+            ptr(out), stream()), "mvs_conv_split_f32")
+    return out
+
+
 def conv3d(x, weight, scale=None, shift=None, residual=None, relu=False, transposed=False,
            stride=1, channels_last=False, packed=None, impl=IMPL_AUTO, in_c8=False):
     """3x3x3 (transposed) convolution + per-channel affine + ReLU + skip add.
@@ -642,11 +699,15 @@ def conv3d(x, weight, scale=None, shift=None, residual=None, relu=False, transpo
     else:
         Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
     shape = (B, Do, Ho, Wo, cout) if channels_last else (B, cout, Do, Ho, Wo)
-    out = torch.empty(shape, device=x.device, dtype=torch.float32)
     if residual is not None:
         residual = _f32c(residual)
         if tuple(residual.shape) != shape:
             raise MvsHipError(f"residual shape {tuple(residual.shape)} != output shape {shape}")
+    sp = split_companion(packed)
+    if sp is not None and channels_last and not in_c8 and not transposed and stride == 1 and impl != IMPL_DIRECT:
+        # the layer's split-operand pack was registered with its fp32 pack: bf16 matrix pipe, fp32 accuracy
+        return conv_split(x, sp, cout, scale, shift, residual, 1 if relu else 0, kd=3)
+    out = torch.empty(shape, device=x.device, dtype=torch.float32)
     check(_lib.load().mvs_conv3d_f32(
         ptr(x), ptr(weight), ptr(packed), ptr(_f32c(scale)) if scale is not None else None,
         ptr(_f32c(shift)) if shift is not None else None, ptr(residual), int(relu), int(transposed),
@@ -765,6 +826,8 @@ def costreg_forward(x, params, in_c8=False, impl=IMPL_AUTO):
         p = params[name]
         for field in ("weight", "packed", "scale", "shift", "packed_split"):
             t = p.get(field)
+            if field == "packed_split" and t is None:
+                t = split_companion(p.get("packed"))
             if t is not None:
                 t = _f32c(t)
                 keep.append(t)
@@ -790,8 +853,8 @@ def conv2d_supported(cin, cout, ksize, stride):
     return bool(_lib.load().mvs_conv2d_supported(cin, cout, ksize, stride))
 
 
-def pack_conv2d_weight(weight, stride):
-    """(Cout,Cin,k,k) -> MFMA A-fragment order, or None if the layer shape has no kernel."""
+def pack_conv2d_weight(weight, stride, split=False):
+    """(Cout,Cin,k,k) -> MFMA A-fragment order, or None if the layer shape has no kernel.  split: as pack_conv3d_weight."""
     weight = _f32c(weight)
     cout, cin, k, _ = weight.shape
     n = _lib.load().mvs_conv2d_packed_weight_floats(cin, cout, k, stride)
@@ -800,6 +863,10 @@ def pack_conv2d_weight(weight, stride):
     packed = torch.empty(n, device=weight.device, dtype=torch.float32)
     check(_lib.load().mvs_conv2d_pack_weights_f32(ptr(weight), cin, cout, k, stride, ptr(packed),
                                                   stream()), "mvs_conv2d_pack_weights_f32")
+    if split and stride == 1 and k == 3 and conv_split_enabled():
+        sp = pack_conv_weight_split(weight)
+        if sp is not None:
+            _register_split(packed, sp)
     return packed
 
 
@@ -941,6 +1008,9 @@ def conv2d(x, packed, cin, cout, ksize, stride, scale=None, shift=None, relu=Fal
         B, H, W, _ = x.shape
     pad = ksize // 2
     Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
+    sp = split_companion(packed)
+    if sp is not None and ksize == 3 and stride == 1 and not planar and coarse is None and not out_c4:
+        return conv_split(x, sp, cout, scale, shift, None, int(relu), kd=1)
     out = torch.empty((B, cout // 4, Ho, Wo, 4) if out_c4 else (B, Ho, Wo, cout), device=x.device, dtype=torch.float32)
     if coarse is not None:
         coarse = _f32c(coarse)
