@@ -43,6 +43,10 @@ BF16_MFMA_PEAK_TF = 2500.0   # v_mfma_f32_16x16x32_bf16, dense
 # conv0 computes every fp32 product as six bf16 products (operands split exactly in three,
 # mvs_amd/csrc/conv_bf16x6.hip): its matrix-pipe ceiling in ALGORITHMIC (fp32) flops
 SPLIT_BF16X6_PEAK_TF = BF16_MFMA_PEAK_TF / 6.0
+# the stages that run on the split-operand kernels (conv_bf16x6.hip: conv0; conv_split.hip: the stride-1 3x3(x3) layers
+# with 16 / 32 / 64 channels; FeatureNet's last layer writes 4-channel blocks and stays on the fp32 kernel)
+SPLIT_STAGES = {"costreg.conv0", "costreg.conv2", "costreg.conv4", "costreg.conv6", "feature.conv3", "feature.conv4",
+                "feature.conv6"}
 
 
 def algorithmic_work(V, C, D, h, w):
@@ -96,7 +100,7 @@ def _roofline_entry(name, kind, amount, ms):
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                 "algorithmic_bytes": amount, "ms": round(ms, 4)}
     ach = amount / (ms * 1e-3) / 1e12
-    if name == "costreg.conv0" and ops.conv_split_enabled():
+    if name in SPLIT_STAGES and ops.conv_split_enabled():
         return {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": round(SPLIT_BF16X6_PEAK_TF, 1),
                 "unit": "TFLOP/s", "frac": round(ach / SPLIT_BF16X6_PEAK_TF, 4), "traffic": None,
                 "algorithmic_flops": amount, "issued_bf16_flops": 6.0 * amount, "ms": round(ms, 4),

@@ -502,6 +502,56 @@ def test_conv3d_split_bf16_vs_fp64_and_fp32_kernel(dev, shape, cin):
     assert e_split < 2e-6 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("kd,cin,cout,shape,relu", [
+    (3, 16, 16, (1, 5, 9, 21), 1), (3, 32, 32, (2, 6, 7, 33), 1), (3, 64, 64, (1, 4, 10, 18), 0), (3, 16, 32, (1, 9, 17, 40), 1),
+    (3, 32, 16, (1, 13, 20, 50), 1), (3, 64, 32, (1, 3, 5, 16), 0), (3, 16, 64, (1, 6, 34, 70), 1),
+    (1, 16, 16, (3, 21, 45), 2), (1, 32, 32, (2, 40, 70), 1), (1, 64, 32, (1, 33, 35), 2), (1, 64, 64, (1, 18, 50), 2),
+    (1, 16, 32, (5, 50, 97), 0), (1, 32, 16, (2, 16, 32), 1)])
+def test_conv_split_general_vs_fp64(dev, kd, cin, cout, shape, relu):
+    """mvs_conv_split_f32 (3x3(x3) stride-1 layers with 16 / 32 / 64 channels on the bf16 matrix pipe, fp32 operands
+    split exactly in three): against an fp64 convolution at the fp32 kernels' error level, on partial tiles of every
+    axis, batch > 1, one and two launches per layer (Cout 64), all three activations, with affine and skip add."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(kd * 1000 + cin * 10 + cout + shape[-1])
+    if kd == 3:
+        B, D, H, W = shape
+        x = torch.randn(B, cin, D, H, W, generator=g) * torch.rand(B, cin, D, H, W, generator=g) ** 2
+        w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5
+        conv, perm, vs = torch.nn.functional.conv3d, (0, 2, 3, 4, 1), (1, cout, 1, 1, 1)
+    else:
+        x = torch.randn(shape[0], cin, *shape[1:], generator=g) * torch.rand(shape[0], cin, *shape[1:], generator=g) ** 2
+        w = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+        conv, perm, vs = torch.nn.functional.conv2d, (0, 2, 3, 1), (1, cout, 1, 1)
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    ref = conv(x.double(), w.double(), padding=1) * scale.double().view(vs) + shift.double().view(vs)
+    ref = torch.relu(ref) if relu == 1 else (torch.where(ref > 0, ref, ref * 0.1) if relu == 2 else ref)
+    res = torch.randn(ref.permute(perm).shape, generator=g)
+    ref = ref.permute(perm) + res.double()
+    pks = ops.pack_conv_weight_split(w.to(dev))
+    assert pks is not None
+    got = ops.conv_split(x.to(dev).permute(perm).contiguous(), pks, cout, scale.to(dev), shift.to(dev), res.to(dev), relu, kd)
+    err = (got.cpu().double() - ref).abs().max().item()
+    assert err < 2e-6 * max(1.0, ref.abs().max().item()), err
+
+
+def test_conv_layers_take_the_split_kernel_and_the_switch_turns_it_off(dev, monkeypatch):
+    """pack_conv3d_weight / pack_conv2d_weight(..., split=True) register the split-operand pack of a supported layer;
+    conv3d / conv2d then run it there (same result within fp32 rounding), MVS_CONV_SPLIT=0 keeps the fp32 kernels."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 6, 9, 20, 16, generator=g).to(dev)
+    w = (torch.randn(16, 16, 3, 3, 3, generator=g) * 0.05).to(dev)
+    pk = ops.pack_conv3d_weight(w, False, 1, split=True)
+    assert ops.split_companion(pk) is not None
+    a = ops.conv3d(x, w, None, None, None, True, False, 1, channels_last=True, packed=pk)
+    monkeypatch.setenv("MVS_CONV_SPLIT", "0")
+    pk0 = ops.pack_conv3d_weight(w, False, 1, split=True)
+    assert ops.split_companion(pk0) is None
+    b = ops.conv3d(x, w, None, None, None, True, False, 1, channels_last=True, packed=pk0)
+    assert (a - b).abs().max().item() < 2e-6 * max(1.0, b.abs().max().item()) and not torch.equal(a, b)
+    assert ops.split_companion(ops.pack_conv3d_weight(w, False, 2, split=True)) is None      # stride 2: no split kernel
+
+
 @pytest.mark.parametrize("shape", [(1, 5, 9, 21), (2, 8, 16, 48), (1, 3, 7, 33), (1, 37, 30, 70)])
 @pytest.mark.parametrize("cin", [32, 16, 8])
 def test_conv3d_c8_persistent_vs_oracle_ragged(dev, shape, cin):
