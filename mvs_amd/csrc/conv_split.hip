@@ -33,17 +33,26 @@ struct SplitArgs {
 template <int CIN_, int COUT_, int KD_>
 struct SplitCfg {
     static constexpr int CIN = CIN_, COUT = COUT_, KD = KD_;
-    static constexpr int NCHUNK = CIN / 8, MT = COUT / 16;
-    static constexpr int NTAP = KD * 9, G = (NTAP + 3) / 4;
+    // 8-channel chunks per step: two for the 2D layers (a K = 32 step is then 2 taps x 16 channels: 9 taps fill 18 of
+    // 20 slots instead of 9 of 12, and a tile has half as many steps -- barriers, split passes -- for the same MFMAs)
+    static constexpr int CPS = KD == 1 ? 2 : 1;
+    static constexpr int NCHUNK = CIN / (8 * CPS), MT = COUT / 16;
+    static constexpr int NTAP = KD * 9, NSLOT = NTAP * CPS, G = (NSLOT + 3) / 4;
     // output tile (TZ, TY, 16 XB) and its halo
     static constexpr int TZ = KD == 3 ? 4 : 1, TY = KD == 3 ? (COUT_ == 16 ? 8 : 4) : 16, XB = KD == 3 ? 1 : 2, TX = 16 * XB;   // (Cout 32 in 3D: two weight chunks of 42 KiB leave room for the smaller halo only)
     static constexpr int ZT = TZ + KD - 1, YT = TY + 2, XP = TX + 2, NVOX = ZT * YT * XP;
     static constexpr int RB = TZ * TY * XB, RPW = RB / 8;                 // 16-voxel row blocks, per multiplying wave
-    static constexpr int NPIECE = 2 * NVOX, NCOPY = (NPIECE + 63) / 64;   // 16-byte pieces (voxel, channel half)
-    static constexpr int FBYTES = NCOPY * 1024, SPART = NVOX * 16, SBYTES = 3 * SPART;
+    // voxels per chunk plane: a multiple of 16 when a step holds two chunks -- the two 8-lane halves of a ds_read_b128
+    // service group (same tap, chunk 0 / chunk 1) then read voxels n .. and 16 k + n ..: complementary 16-byte slots
+    static constexpr int NVP = CPS == 1 ? NVOX : (NVOX + 15) / 16 * 16;
+    static constexpr int NPIECE = 2 * NVP * CPS, NCOPY = (NPIECE + 63) / 64;   // 16-byte pieces (chunk, voxel, channel half)
+    static constexpr int FBYTES = NCOPY * 1024, SPART = NVP * 16 * CPS, SBYTES = 3 * SPART;
     static constexpr int WBYTES = G * MT * 3 * 1024;                      // A fragments of one chunk
-    static constexpr int T = MT == 1 ? 4 : 2;                             // tiles per group
-    static constexpr int F_OFF = 2 * WBYTES, S_OFF = F_OFF + FBYTES, LDS_BYTES = S_OFF + SBYTES;
+    // tiles per group (they share a chunk's weights and hold their accumulators, RPW x MT x 4 registers each, over the
+    // chunk loop): bounded by the 168 registers of a 12-wave workgroup
+    static constexpr int T = 48 / (RPW * MT * 4) >= 2 ? 2 : 1;
+    static constexpr int F_OFF = 2 * WBYTES, S_OFF = F_OFF + FBYTES, AFF_OFF = S_OFF + SBYTES;   // + scale, shift of the launch
+    static constexpr int LDS_BYTES = AFF_OFF + 2 * COUT * 4;
     static_assert(RB % 8 == 0 && LDS_BYTES <= 160 * 1024 && SPART * 2 + 16 * 1024 < 65536, "tile / LDS budget");
 };
 
@@ -63,7 +72,9 @@ __device__ __forceinline__ TileIdx split_decode(const SplitArgs &a, int bid) {
     return t;
 }
 
-template <class C>
+// LAPS (tuning build, MVS_CONV_SPLIT_LAPS=1): cycles of each multiplying wave per phase, summed over the workgroup's steps,
+// into the buffer passed as `residual` (int64 [workgroup][wave][8]): barrier, split pass, barrier, MFMA phase, epilogue
+template <class C, bool LAPS = false>
 __global__ __launch_bounds__(kSplitThreads) void conv_split_kernel(SplitArgs a, int ntiles) {
     constexpr int CIN = C::CIN, NCHUNK = C::NCHUNK, MT = C::MT, G = C::G, T = C::T, RPW = C::RPW;
     constexpr int YT = C::YT, XP = C::XP, NVOX = C::NVOX, NPIECE = C::NPIECE, NCOPY = C::NCOPY;
@@ -78,6 +89,12 @@ __global__ __launch_bounds__(kSplitThreads) void conv_split_kernel(SplitArgs a, 
     const unsigned lds_base = (unsigned)(uintptr_t)lds;
     const bool copier = wv >= 8;
     const int cw = wv - 8;
+    // the per-channel affine of the epilogue waits in LDS (a global load there would put its latency into every tile)
+    if (tid < 2 * C::COUT) {
+        const int c = tid % C::COUT;
+        const float v = tid < C::COUT ? (a.scale ? a.scale[c] : 1.0f) : (a.shift ? a.shift[c] : 0.0f);
+        *reinterpret_cast<float *>(lds + C::AFF_OFF + tid * 4) = v;
+    }
 
     // this workgroup's tiles: t0 + k * t_step, k < ntw (XCD x owns a contiguous range of the ordered tile list)
     int t0, t_step, ntw;
@@ -134,8 +151,11 @@ __global__ __launch_bounds__(kSplitThreads) void conv_split_kernel(SplitArgs a, 
         for (int i = 0; i < IPW; ++i) {
             const int P = (i * NC + cw) * 64 + lane;
             const bool ok = P < NPIECE;
-            const int v = ok ? P >> 1 : 0;
-            loc[i] = (v % XP) | (((v / XP) % YT) << 8) | ((v / (XP * YT)) << 16) | ((P & 1) << 24) | (ok ? 0 : (int)0x80000000);
+            const int vraw = (P % (2 * C::NVP)) >> 1, c = ok ? P / (2 * C::NVP) : 0;
+            const bool okv = ok && vraw < NVOX;          // (the padding voxels of a chunk plane arrive as zeros)
+            const int v = okv ? vraw : 0;
+            loc[i] = (v % XP) | (((v / XP) % YT) << 8) | ((v / (XP * YT)) << 16) | ((P & 1) << 24) | (c << 25) |
+                     (okv ? 0 : (int)0x80000000);
         }
         const int64_t plane_in = (int64_t)a.H * a.W * CIN;
         const int row_in = a.W * CIN;
@@ -150,15 +170,15 @@ __global__ __launch_bounds__(kSplitThreads) void conv_split_kernel(SplitArgs a, 
 #pragma unroll
             for (int i = 0; i < IPW; ++i) {
                 const int gx = ix0 + (loc[i] & 255), gy = iy0 + ((loc[i] >> 8) & 255);
-                const int lz = (loc[i] >> 16) & 255, h = (loc[i] >> 24) & 1;
+                const int lz = (loc[i] >> 16) & 255, h = (loc[i] >> 24) & 1, c = (loc[i] >> 25) & 3;
                 const bool ok = loc[i] >= 0 && (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H &&
                                 (unsigned)(iz0 + lz) < (unsigned)a.D;
-                voff[j][i] = ok ? (unsigned)(((int64_t)lz * plane_in + (int64_t)gy * row_in + gx * CIN + h * 4) * 4) : 0xffffff00u;
+                voff[j][i] = ok ? (unsigned)(((int64_t)lz * plane_in + (int64_t)gy * row_in + gx * CIN + c * 8 + h * 4) * 4) : 0xffffff00u;
             }
         };
         auto issue_halo = [&](auto jc, int ch) {
             constexpr int j = decltype(jc)::value;
-            const unsigned soff = (unsigned)(ch * 32);
+            const unsigned soff = (unsigned)(ch * 32 * C::CPS);
 #pragma unroll
             for (int i = 0; i < IPW; ++i) {
                 if (i * NC + cw >= NCOPY) continue;   // wave-uniform
@@ -199,11 +219,11 @@ __global__ __launch_bounds__(kSplitThreads) void conv_split_kernel(SplitArgs a, 
                     } else if (k0 + T < ntw) {
                         geometry(std::integral_constant<int, 0>{}, t0 + (k0 + T) * t_step);
                         issue_halo(std::integral_constant<int, 0>{}, 0);
-                        issue_weights(0, wsel ^ 1);
+                        if (NCHUNK > 1) issue_weights(0, wsel ^ 1);      // (one chunk per tile: the weights never change)
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 });
-                wsel ^= 1;
+                if (NCHUNK > 1) wsel ^= 1;
             }
         }
         return;
@@ -218,21 +238,14 @@ __global__ __launch_bounds__(kSplitThreads) void conv_split_kernel(SplitArgs a, 
         const int z = rb / (C::TY * C::XB), y = (rb / C::XB) % C::TY, xb = rb % C::XB;
         rbo[r] = (unsigned)(((z * YT + y) * XP + xb * 16 + n) * 16);
     }
-    // tap t = 4 g + kq of this lane's K group (taps past the kernel read voxel 0 against zero weights)
+    // slot 4 g + kq of this lane's K group = (tap, chunk of the step); slots past the kernel read voxel 0 against
+    // zero weights
     unsigned tapo[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        const int t = 4 * g + kq;
+        const int sl = 4 * g + kq, t = sl / C::CPS, c = sl % C::CPS;
         const int dz = C::KD == 3 ? t / 9 : 0, dy = (t % 9) / 3, dx = t % 3;
-        tapo[g] = t < C::NTAP ? (unsigned)(((dz * YT + dy) * XP + dx) * 16) : 0u;
-    }
-
-    float4 sc[MT], sh[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int c0 = m * 16 + kq * 4;
-        sc[m] = a.scale ? *reinterpret_cast<const float4 *>(a.scale + c0) : make_float4(1.f, 1.f, 1.f, 1.f);
-        sh[m] = a.shift ? *reinterpret_cast<const float4 *>(a.shift + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        tapo[g] = sl < C::NSLOT ? (unsigned)((((dz * YT + dy) * XP + dx) + c * C::NVP) * 16) : 0u;
     }
 
     f32x4 acc[T][RPW][MT];
@@ -243,6 +256,33 @@ __global__ __launch_bounds__(kSplitThreads) void conv_split_kernel(SplitArgs a, 
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[j][r][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // split_decode without integer division: quotients through float reciprocals plus one correction step, exact for
+    // tile indices below 2^23 (the launcher guarantees it)
+    const int per_b = a.tiles_x * a.tiles_y * a.tiles_z, full = a.ystrip * a.tiles_z * a.tiles_x;
+    const float r_per_b = 1.0f / (float)per_b, r_full = 1.0f / (float)full, r_tz = 1.0f / (float)a.tiles_z;
+    const int hs_last = a.tiles_y % a.ystrip ? a.tiles_y % a.ystrip : a.ystrip;
+    const float r_hs = 1.0f / (float)a.ystrip, r_hs_last = 1.0f / (float)hs_last;
+    auto divmod = [](int nn, int d, float rd, int &q, int &r) {
+        q = (int)((float)nn * rd);
+        r = nn - q * d;
+        if (r < 0) { q -= 1; r += d; } else if (r >= d) { q += 1; r -= d; }
+    };
+    auto fast_decode = [&](int t) {
+        TileIdx ti;
+        int rem, strip, rem2, tyl, rem3;
+        divmod(t, per_b, r_per_b, ti.b, rem);
+        divmod(rem, full, r_full, strip, rem2);
+        const int ys = strip * a.ystrip;
+        const bool last = ys + a.ystrip > a.tiles_y;
+        divmod(rem2, last ? hs_last : a.ystrip, last ? r_hs_last : r_hs, rem3, tyl);
+        divmod(rem3, a.tiles_z, r_tz, ti.tx, ti.tz);
+        ti.ty = ys + tyl;
+        return ti;
+    };
+    long long tsum[5] = {0, 0, 0, 0, 0};
+    long long tprev = 0;
+    if constexpr (LAPS) tprev = clock64();
+#define MVS_LAP(k) do { if constexpr (LAPS) { const long long tn = clock64(); tsum[k] += tn - tprev; tprev = tn; } } while (0)
     int wsel = 0;
     for (int k0 = 0; k0 < ntw; k0 += T) {
         const int nvalid = min(T, ntw - k0);
@@ -251,10 +291,14 @@ __global__ __launch_bounds__(kSplitThreads) void conv_split_kernel(SplitArgs a, 
             static_for<0, T>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 if (j >= nvalid) return;   // wave-uniform
+                MVS_LAP(4);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (this wave's stores of the previous group)
                 __syncthreads();
+                MVS_LAP(0);
                 split_pass();
+                MVS_LAP(1);
                 __syncthreads();
+                MVS_LAP(2);
                 // ---- MFMA phase: items (g, r) = (tap group, row block); the reads of the next item go out before the
                 // MFMAs of the current one
                 const unsigned aA = lds_base + (unsigned)(wsel * WBYTES + lane * 16);
@@ -310,14 +354,27 @@ __global__ __launch_bounds__(kSplitThreads) void conv_split_kernel(SplitArgs a, 
                     });
                     __builtin_amdgcn_sched_barrier(0);
                 });
+                if constexpr (LAPS) {
+                    f32x4 &c0 = acc[j][0][0];
+                    asm volatile("" : "+v"(c0));
+                    asm volatile("s_nop 0" ::: "memory");
+                }
+                MVS_LAP(3);
             });
-            wsel ^= 1;
+            if (NCHUNK > 1) wsel ^= 1;
         }
         // ---- epilogue of the group: per-channel affine, activation, skip add, one 16-byte store per lane, row block, M tile
         static_for<0, T>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             if (j >= nvalid) return;
-            const TileIdx cur = split_decode(a, t0 + (k0 + j) * t_step);
+            const TileIdx cur = fast_decode(t0 + (k0 + j) * t_step);
+            float4 sc[MT], sh[MT];      // (read here, once per tile: held over the MFMA phase they cost 8 registers per M tile)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int c0 = m * 16 + kq * 4;
+                sc[m] = *reinterpret_cast<const float4 *>(lds + C::AFF_OFF + c0 * 4);
+                sh[m] = *reinterpret_cast<const float4 *>(lds + C::AFF_OFF + (C::COUT + c0) * 4);
+            }
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
                 const int rb = wv * RPW + r;
@@ -338,7 +395,7 @@ __global__ __launch_bounds__(kSplitThreads) void conv_split_kernel(SplitArgs a, 
                         for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : v[q] * 0.1f;
                     }
                     const int64_t o = ((((int64_t)cur.b * a.D + oz) * a.H + oy) * a.W + ox) * a.ldc + m * 16 + kq * 4;
-                    if (a.residual) {
+                    if (a.residual && !LAPS) {
                         const float4 rs = *reinterpret_cast<const float4 *>(a.residual + o);
                         v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
                     }
@@ -347,12 +404,20 @@ __global__ __launch_bounds__(kSplitThreads) void conv_split_kernel(SplitArgs a, 
             }
         });
     }
+    if constexpr (LAPS) {
+        MVS_LAP(4);
+        if (lane == 0) {
+            long long *dbg = reinterpret_cast<long long *>(const_cast<float *>(a.residual)) + ((int64_t)blockIdx.x * 8 + wv) * 8;
+            for (int k = 0; k < 5; ++k) dbg[k] = tsum[k];
+        }
+    }
+#undef MVS_LAP
 }
 
 // PyTorch-layout weight (Cout_total, Cin, [kd,] 3, 3), output channels [co0, co0 + COUT) ->
-// [chunk][group][m-tile][part][lane][8 bf16]; lane (mrow, kq): output channel co0 + m*16 + mrow, tap 4 g + kq (zero
-// past the kernel), channel chunk*8 + j
-__global__ __launch_bounds__(256) void pack_split_kernel(const float *__restrict__ w, int Cin, int ntap, int G, int MT,
+// [step][group][m-tile][part][lane][8 bf16]; lane (mrow, kq): output channel co0 + m*16 + mrow, slot 4 g + kq = (tap,
+// chunk c of the step) (zero past the kernel), channel (step*cps + c)*8 + j
+__global__ __launch_bounds__(256) void pack_split_kernel(const float *__restrict__ w, int Cin, int ntap, int cps, int G, int MT,
                                                          int co0, unsigned short *__restrict__ out, int total) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
@@ -360,9 +425,9 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const float *__restrict
     int rest = i >> 9;
     const int m = rest % MT; rest /= MT;
     const int g = rest % G, ch = rest / G;
-    const int mrow = lane & 15, kq = lane >> 4, t = 4 * g + kq;
+    const int mrow = lane & 15, kq = lane >> 4, sl = 4 * g + kq, t = sl / cps, c = sl % cps;   // ch = step of the tile
     float x = 0.0f;
-    if (t < ntap) x = w[((int64_t)(co0 + m * 16 + mrow) * Cin + ch * 8 + j) * ntap + t];
+    if (t < ntap) x = w[((int64_t)(co0 + m * 16 + mrow) * Cin + (ch * cps + c) * 8 + j) * ntap + t];
     const __bf16 h = (__bf16)x;
     const float r1 = x - (float)h;
     const __bf16 mm = (__bf16)r1;
@@ -380,9 +445,13 @@ static int launch_split(const SplitArgs &a0, hipStream_t st) {
     a.tiles_x = (a.W + C::TX - 1) / C::TX; a.tiles_y = (a.H + C::TY - 1) / C::TY; a.tiles_z = (a.D + C::TZ - 1) / C::TZ;
     a.ystrip = C::KD == 3 ? 4 : 2;
     const int64_t nt = (int64_t)a.B * a.tiles_x * a.tiles_y * a.tiles_z;
-    if (nt <= 0 || nt > 0x7fffffffLL) return bare_error(MVS_EINVAL, __func__, __LINE__);
+    if (nt <= 0 || nt >= (1 << 23)) return bare_error(MVS_EINVAL, __func__, __LINE__);   // the kernel's float tile decode
     const int n_cu = device_cu_count();
-    hipLaunchKernelGGL((conv_split_kernel<C>), dim3((unsigned)(nt < n_cu ? nt : n_cu)), dim3(kSplitThreads), 0, st, a, (int)nt);
+    static const bool laps = [] { const char *e = getenv("MVS_CONV_SPLIT_LAPS"); return e && e[0] == '1'; }();
+    if (laps && a.residual && (C::CIN == 64 || C::CIN == 16) && C::COUT == 16 * (C::CIN == 64 ? 2 : 1))   // tuning builds: 64 -> 32 and 16 -> 16
+        hipLaunchKernelGGL((conv_split_kernel<C, true>), dim3((unsigned)(nt < n_cu ? nt : n_cu)), dim3(kSplitThreads), 0, st, a, (int)nt);
+    else
+        hipLaunchKernelGGL((conv_split_kernel<C>), dim3((unsigned)(nt < n_cu ? nt : n_cu)), dim3(kSplitThreads), 0, st, a, (int)nt);
     return check_launch("mvs_conv_split_f32");
 }
 
@@ -399,8 +468,8 @@ extern "C" int mvs_conv_split_supported(int kd, int Cin, int Cout) {
 
 extern "C" size_t mvs_conv_split_packed_bytes(int kd, int Cin, int Cout) {
     if (!mvs_conv_split_supported(kd, Cin, Cout)) return 0;
-    const int G = (kd * 9 + 3) / 4;
-    return (size_t)(Cin / 8) * G * (Cout / 16) * 3 * 1024;
+    const int cps = kd == 1 ? 2 : 1, G = (kd * 9 * cps + 3) / 4;
+    return (size_t)(Cin / (8 * cps)) * G * (Cout / 16) * 3 * 1024;
 }
 
 extern "C" int mvs_conv_split_pack_weights_f32(const float *weight, int kd, int Cin, int Cout, void *packed, void *stream) {
@@ -409,11 +478,11 @@ extern "C" int mvs_conv_split_pack_weights_f32(const float *weight, int kd, int 
         return MVS_EINVAL;
     }
     // one block of the packed buffer per launch of the layer (Cout / step launches, each `step` output channels)
-    const int step = split_cout_step(Cout), G = (kd * 9 + 3) / 4, MT = step / 16;
-    const size_t per_launch = (size_t)(Cin / 8) * G * MT * 3 * 1024;
+    const int step = split_cout_step(Cout), cps = kd == 1 ? 2 : 1, G = (kd * 9 * cps + 3) / 4, MT = step / 16;
+    const size_t per_launch = (size_t)(Cin / (8 * cps)) * G * MT * 3 * 1024;
     for (int co0 = 0; co0 < Cout; co0 += step) {
-        const int total = (Cin / 8) * G * MT * 512;
-        hipLaunchKernelGGL(pack_split_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), weight, Cin, kd * 9, G, MT,
+        const int total = (Cin / (8 * cps)) * G * MT * 512;
+        hipLaunchKernelGGL(pack_split_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), weight, Cin, kd * 9, cps, G, MT,
                            co0, reinterpret_cast<unsigned short *>(static_cast<unsigned char *>(packed) + (co0 / step) * per_launch), total);
     }
     return check_launch("mvs_conv_split_pack_weights_f32");
@@ -428,8 +497,8 @@ extern "C" int mvs_conv_split_f32(const float *in, const void *packed, const flo
         return MVS_EINVAL;
     }
     if ((int64_t)(kd + 3) * H * W * Cin * 4 >= 0xffffff00LL) return bare_error(MVS_EINVAL, __func__, __LINE__);   // 32-bit halo offsets
-    const int step = split_cout_step(Cout), G = (kd * 9 + 3) / 4;
-    const size_t per_launch = (size_t)(Cin / 8) * G * (step / 16) * 3 * 1024;
+    const int step = split_cout_step(Cout), cps = kd == 1 ? 2 : 1, G = (kd * 9 * cps + 3) / 4;
+    const size_t per_launch = (size_t)(Cin / (8 * cps)) * G * (step / 16) * 3 * 1024;
     hipStream_t st = as_stream(stream);
     for (int co0 = 0; co0 < Cout; co0 += step) {
         SplitArgs a;
