@@ -198,6 +198,17 @@ int mvs_conv_split_f32(const float *in, const void *packed, const float *scale, 
                        const float *residual, int relu, int kd, int B, int Cin, int Cout, int D, int H, int W,
                        float *out, void *stream);
 
+/* ... and for the transposed layers (3x3x3, stride 2, pad 1, output_padding 1: CostRegNet conv7 / conv9 / conv11,
+ * mvsnet.py:76-81,89-91): mvs_amd/csrc/deconv_split.hip.  in [B,D,H,W,Cin] -> out [B,2D,2H,2W,Cout];
+ * weight: PyTorch layout (Cin, Cout, 3, 3, 3); residual (same shape as out) is added AFTER the ReLU.
+ * Cin in {16, 32, 64}, Cout in {8, 16, 32}. */
+int mvs_deconv_split_supported(int Cin, int Cout);
+size_t mvs_deconv_split_packed_bytes(int Cin, int Cout);
+int mvs_deconv_split_pack_weights_f32(const float *weight, int Cin, int Cout, void *packed, void *stream);
+int mvs_deconv_split_f32(const float *in, const void *packed, const float *scale, const float *shift,
+                         const float *residual, int relu, int B, int Cin, int Cout, int D, int H, int W,
+                         float *out, void *stream);
+
 /* The whole 3D U-Net in one call -- CostRegNet.forward, mvsnet.py:83-93 (also the cascade's
  * CostRegNet, CasMVSNet/models/module.py:407-438): conv0 .. conv6 (3x3x3 + folded BN + ReLU, strides
  * 1 2 1 2 1 2 1), conv7 / conv9 / conv11 (transposed, stride 2, + BN + ReLU, skip-add of conv4 /
@@ -215,7 +226,8 @@ typedef struct mvs_conv_layer {
     const float *shift;  /* folded BatchNorm shift / conv bias [Cout], or NULL */
     const void *packed_split; /* conv0: mvs_conv3d_pack_weights_bf16x6_f32 output -- with an MVS_LAYOUT_C8
                                * input the layer then runs as mvs_conv3d_c8_bf16x6_f32; conv2 / conv4 / conv6:
-                               * mvs_conv_split_pack_weights_f32 output -> mvs_conv_split_f32;
+                               * mvs_conv_split_pack_weights_f32 output -> mvs_conv_split_f32; conv7 / conv9 / conv11:
+                               * mvs_deconv_split_pack_weights_f32 output -> mvs_deconv_split_f32;
                                * NULL = the fp32 MFMA kernel */
 } mvs_conv_layer;
 size_t mvs_costreg_workspace_bytes(int B, int base, int D, int H, int W);

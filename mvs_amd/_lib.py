@@ -51,6 +51,10 @@ _SIGS = {
     "mvs_conv_split_packed_bytes": (ctypes.c_size_t, [_c_i] * 3),
     "mvs_conv_split_pack_weights_f32": (_c_i, [_c_f] + [_c_i] * 3 + [_c_f, _c_f]),
     "mvs_conv_split_f32": (_c_i, [_c_f] * 5 + [_c_i] * 8 + [_c_f, _c_f]),
+    "mvs_deconv_split_supported": (_c_i, [_c_i] * 2),
+    "mvs_deconv_split_packed_bytes": (ctypes.c_size_t, [_c_i] * 2),
+    "mvs_deconv_split_pack_weights_f32": (_c_i, [_c_f] + [_c_i] * 2 + [_c_f, _c_f]),
+    "mvs_deconv_split_f32": (_c_i, [_c_f] * 5 + [_c_i] * 7 + [_c_f, _c_f]),
     "mvs_conv3d_wgrad_f32": (_c_i, [_c_f, _c_f] + [_c_i] * 7 + [_c_f, _c_f, ctypes.c_size_t, _c_f]),
     "mvs_conv3d_wgrad_workspace_bytes": (ctypes.c_size_t, [_c_i] * 7),
     "mvs_conv3d_wgrad_supported": (_c_i, [_c_i] * 3),

@@ -292,7 +292,6 @@ __global__ __launch_bounds__(kSplitThreads) void conv_split_kernel(SplitArgs a, 
                 constexpr int j = decltype(jc)::value;
                 if (j >= nvalid) return;   // wave-uniform
                 MVS_LAP(4);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (this wave's stores of the previous group)
                 __syncthreads();
                 MVS_LAP(0);
                 split_pass();

@@ -92,6 +92,13 @@ extern "C" int mvs_costreg_fwd_f32(const float *in, int in_layout, const mvs_con
             if (rc != MVS_OK) return rc;
             continue;
         }
+        if (L.packed_split && s.transposed && s.stride == 2 && impl != 1 && mvs_deconv_split_supported(s.cin, s.cout)) {
+            // conv7 / conv9 / conv11 (deconv_split.hip); s.lvl is the INPUT level
+            const int rc = mvs_deconv_split_f32(s.src, L.packed_split, L.scale, L.shift, s.skip, s.relu, B, s.cin, s.cout,
+                                                D >> s.lvl, H >> s.lvl, W >> s.lvl, s.dst, stream);
+            if (rc != MVS_OK) return rc;
+            continue;
+        }
         if (L.packed_split && !s.transposed && s.stride == 1 && s.layout == MVS_LAYOUT_NHWC && impl != 1 &&
             mvs_conv_split_supported(3, s.cin, s.cout)) {
             // conv2 / conv4 / conv6: the split-operand kernel for 16 / 32 / 64 channels (conv_split.hip)

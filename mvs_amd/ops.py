@@ -597,6 +597,10 @@ def pack_conv3d_weight(weight, transposed, stride, split=False):
         sp = pack_conv_weight_split(weight)
         if sp is not None:
             _register_split(packed, sp)
+    if split and transposed and stride == 2 and conv_split_enabled():
+        sp = pack_deconv_weight_split(weight)
+        if sp is not None:
+            _register_split(packed, sp)
     return packed
 
 
@@ -674,6 +678,36 @@ def conv_split(x_cl, packed_split, cout, scale=None, shift=None, residual=None, 
     return out
 
 
+def pack_deconv_weight_split(weight):
+    """(Cin, Cout, 3, 3, 3) transposed-layer weight -> the bf16 hi/mid/lo A fragments of deconv_split (None if the
+    shape has no such kernel: Cin in {16, 32, 64}, Cout in {8, 16, 32})."""
+    weight = _f32c(weight)
+    if weight.dim() != 5 or tuple(weight.shape[2:]) != (3, 3, 3):
+        return None
+    n = _lib.load().mvs_deconv_split_packed_bytes(int(weight.shape[0]), int(weight.shape[1]))
+    if n == 0:
+        return None
+    packed = torch.empty(n // 4, device=weight.device, dtype=torch.float32)   # opaque bytes
+    check(_lib.load().mvs_deconv_split_pack_weights_f32(ptr(weight), int(weight.shape[0]), int(weight.shape[1]),
+                                                        ptr(packed), stream()), "mvs_deconv_split_pack_weights_f32")
+    return packed
+
+
+def deconv_split(x_cl, packed_split, cout, scale=None, shift=None, residual=None, relu=True):
+    """Transposed 3x3x3 stride-2 layer on the bf16 matrix pipe with exactly split fp32 operands
+    (mvs_deconv_split_f32): x_cl [B,D,H,W,Cin] -> [B,2D,2H,2W,cout]; residual is added after the ReLU."""
+    x_cl = _f32c(x_cl)
+    B, D, H, W, cin = x_cl.shape
+    out = torch.empty(B, 2 * D, 2 * H, 2 * W, cout, device=x_cl.device, dtype=torch.float32)
+    with stage("deconv_split"):
+        check(_lib.load().mvs_deconv_split_f32(
+            ptr(x_cl), ptr(packed_split), ptr(_f32c(scale)) if scale is not None else None,
+            ptr(_f32c(shift)) if shift is not None else None,
+            ptr(_f32c(residual)) if residual is not None else None, int(bool(relu)), B, cin, cout, D, H, W,
+            ptr(out), stream()), "mvs_deconv_split_f32")
+    return out
+
+
 def conv3d(x, weight, scale=None, shift=None, residual=None, relu=False, transposed=False,
            stride=1, channels_last=False, packed=None, impl=IMPL_AUTO, in_c8=False):
     """3x3x3 (transposed) convolution + per-channel affine + ReLU + skip add.
@@ -707,6 +741,8 @@ def conv3d(x, weight, scale=None, shift=None, residual=None, relu=False, transpo
     if sp is not None and channels_last and not in_c8 and not transposed and stride == 1 and impl != IMPL_DIRECT:
         # the layer's split-operand pack was registered with its fp32 pack: bf16 matrix pipe, fp32 accuracy
         return conv_split(x, sp, cout, scale, shift, residual, 1 if relu else 0, kd=3)
+    if sp is not None and channels_last and not in_c8 and transposed and stride == 2 and impl != IMPL_DIRECT:
+        return deconv_split(x, sp, cout, scale, shift, residual, relu)
     out = torch.empty(shape, device=x.device, dtype=torch.float32)
     check(_lib.load().mvs_conv3d_f32(
         ptr(x), ptr(weight), ptr(packed), ptr(_f32c(scale)) if scale is not None else None,

@@ -534,6 +534,30 @@ def test_conv_split_general_vs_fp64(dev, kd, cin, cout, shape, relu):
     assert err < 2e-6 * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("cin,cout,shape", [(16, 8, (1, 3, 5, 9)), (16, 8, (2, 5, 6, 21)), (32, 16, (1, 4, 7, 19)),
+                                            (64, 32, (1, 3, 5, 17)), (32, 8, (1, 2, 9, 33)), (16, 16, (1, 6, 4, 16)),
+                                            (64, 16, (2, 3, 4, 18)), (16, 32, (1, 5, 5, 35))])
+def test_deconv_split_vs_fp64(dev, cin, cout, shape):
+    """mvs_deconv_split_f32 (transposed 3x3x3 stride-2 layers on the bf16 matrix pipe, fp32 operands split exactly in
+    three) against an fp64 transposed convolution at the fp32 kernels' error level: partial tiles of every axis, batch > 1,
+    the merged-x-parity form (Cout 8), one and two launches per layer, affine + ReLU + skip add after the ReLU."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(cin * 100 + cout + shape[-1])
+    B, D, H, W = shape
+    x = torch.randn(B, cin, D, H, W, generator=g) * torch.rand(B, cin, D, H, W, generator=g) ** 2
+    w = torch.randn(cin, cout, 3, 3, 3, generator=g) / (27 * cin / 8) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(B, 2 * D, 2 * H, 2 * W, cout, generator=g)
+    ref = torch.nn.functional.conv_transpose3d(x.double(), w.double(), stride=2, padding=1, output_padding=1)
+    ref = torch.relu(ref * scale.double().view(1, cout, 1, 1, 1) + shift.double().view(1, cout, 1, 1, 1))
+    ref = ref.permute(0, 2, 3, 4, 1) + res.double()
+    pks = ops.pack_deconv_weight_split(w.to(dev))
+    assert pks is not None
+    got = ops.deconv_split(x.to(dev).permute(0, 2, 3, 4, 1).contiguous(), pks, cout, scale.to(dev), shift.to(dev), res.to(dev), True)
+    err = (got.cpu().double() - ref).abs().max().item()
+    assert err < 2e-6 * max(1.0, ref.abs().max().item()), err
+
+
 def test_conv_layers_take_the_split_kernel_and_the_switch_turns_it_off(dev, monkeypatch):
     """pack_conv3d_weight / pack_conv2d_weight(..., split=True) register the split-operand pack of a supported layer;
     conv3d / conv2d then run it there (same result within fp32 rounding), MVS_CONV_SPLIT=0 keeps the fp32 kernels."""
