@@ -50,7 +50,7 @@ _SIGS = {
     "mvs_conv_split_supported": (_c_i, [_c_i] * 3),
     "mvs_conv_split_packed_bytes": (ctypes.c_size_t, [_c_i] * 3),
     "mvs_conv_split_pack_weights_f32": (_c_i, [_c_f] + [_c_i] * 3 + [_c_f, _c_f]),
-    "mvs_conv_split_f32": (_c_i, [_c_f] * 5 + [_c_i] * 8 + [_c_f, _c_f]),
+    "mvs_conv_split_f32": (_c_i, [_c_f] * 5 + [_c_i] * 9 + [_c_f, _c_f]),
     "mvs_deconv_split_supported": (_c_i, [_c_i] * 2),
     "mvs_deconv_split_packed_bytes": (ctypes.c_size_t, [_c_i] * 2),
     "mvs_deconv_split_pack_weights_f32": (_c_i, [_c_f] + [_c_i] * 2 + [_c_f, _c_f]),

@@ -28,6 +28,8 @@ struct SplitArgs {
     int B, D, H, W, ldc;
     int tiles_x, tiles_y, tiles_z, ystrip;
     int relu;                 // 0 none, 1 ReLU, 2 LeakyReLU(0.1)
+    int nco;                  // output channels of this launch that exist (8 for an 8-channel layer on the 16-row tile)
+    int co0, out_c4;          // out_c4: the WHOLE output tensor is [B*D, ldc/4, H, W, 4] (4-channel blocks), co0 = first channel of the launch
 };
 
 template <int CIN_, int COUT_, int KD_>
@@ -35,7 +37,7 @@ struct SplitCfg {
     static constexpr int CIN = CIN_, COUT = COUT_, KD = KD_;
     // 8-channel chunks per step: two for the 2D layers (a K = 32 step is then 2 taps x 16 channels: 9 taps fill 18 of
     // 20 slots instead of 9 of 12, and a tile has half as many steps -- barriers, split passes -- for the same MFMAs)
-    static constexpr int CPS = KD == 1 ? 2 : 1;
+    static constexpr int CPS = (KD == 1 && CIN_ >= 16) ? 2 : 1;
     static constexpr int NCHUNK = CIN / (8 * CPS), MT = COUT / 16;
     static constexpr int NTAP = KD * 9, NSLOT = NTAP * CPS, G = (NSLOT + 3) / 4;
     // output tile (TZ, TY, 16 XB) and its halo
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(kSplitThreads) void conv_split_kernel(SplitArgs a, 
     // the per-channel affine of the epilogue waits in LDS (a global load there would put its latency into every tile)
     if (tid < 2 * C::COUT) {
         const int c = tid % C::COUT;
-        const float v = tid < C::COUT ? (a.scale ? a.scale[c] : 1.0f) : (a.shift ? a.shift[c] : 0.0f);
+        const float v = c >= a.nco ? 0.0f : tid < C::COUT ? (a.scale ? a.scale[c] : 1.0f) : (a.shift ? a.shift[c] : 0.0f);
         *reinterpret_cast<float *>(lds + C::AFF_OFF + tid * 4) = v;
     }
 
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(kSplitThreads) void conv_split_kernel(SplitArgs a, 
                 for (int m = 0; m < MT; ++m) {
                     f32x4 v = acc[j][r][m];
                     acc[j][r][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (oz >= a.D || oy >= a.H || ox >= a.W) continue;
+                    if (oz >= a.D || oy >= a.H || ox >= a.W || m * 16 + kq * 4 >= a.nco) continue;
                     v[0] = v[0] * sc[m].x + sh[m].x; v[1] = v[1] * sc[m].y + sh[m].y;
                     v[2] = v[2] * sc[m].z + sh[m].z; v[3] = v[3] * sc[m].w + sh[m].w;
                     if (a.relu == 1) {
@@ -393,7 +395,10 @@ __global__ __launch_bounds__(kSplitThreads) void conv_split_kernel(SplitArgs a, 
 #pragma unroll
                         for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : v[q] * 0.1f;
                     }
-                    const int64_t o = ((((int64_t)cur.b * a.D + oz) * a.H + oy) * a.W + ox) * a.ldc + m * 16 + kq * 4;
+                    // out_c4: a lane's four channels are one block of [image, C/4, H, W, 4] (the sweep kernel's input)
+                    const int64_t o = a.out_c4
+                        ? (((((int64_t)cur.b * a.D + oz) * (a.ldc >> 2) + ((a.co0 + m * 16 + kq * 4) >> 2)) * a.H + oy) * a.W + ox) * 4
+                        : ((((int64_t)cur.b * a.D + oz) * a.H + oy) * a.W + ox) * a.ldc + m * 16 + kq * 4;
                     if (a.residual && !LAPS) {
                         const float4 rs = *reinterpret_cast<const float4 *>(a.residual + o);
                         v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
@@ -416,7 +421,7 @@ __global__ __launch_bounds__(kSplitThreads) void conv_split_kernel(SplitArgs a, 
 // PyTorch-layout weight (Cout_total, Cin, [kd,] 3, 3), output channels [co0, co0 + COUT) ->
 // [step][group][m-tile][part][lane][8 bf16]; lane (mrow, kq): output channel co0 + m*16 + mrow, slot 4 g + kq = (tap,
 // chunk c of the step) (zero past the kernel), channel (step*cps + c)*8 + j
-__global__ __launch_bounds__(256) void pack_split_kernel(const float *__restrict__ w, int Cin, int ntap, int cps, int G, int MT,
+__global__ __launch_bounds__(256) void pack_split_kernel(const float *__restrict__ w, int Cin, int Cout, int ntap, int cps, int G, int MT,
                                                          int co0, unsigned short *__restrict__ out, int total) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
@@ -426,7 +431,7 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const float *__restrict
     const int g = rest % G, ch = rest / G;
     const int mrow = lane & 15, kq = lane >> 4, sl = 4 * g + kq, t = sl / cps, c = sl % cps;   // ch = step of the tile
     float x = 0.0f;
-    if (t < ntap) x = w[((int64_t)(co0 + m * 16 + mrow) * Cin + (ch * cps + c) * 8 + j) * ntap + t];
+    if (t < ntap && co0 + m * 16 + mrow < Cout) x = w[((int64_t)(co0 + m * 16 + mrow) * Cin + (ch * cps + c) * 8 + j) * ntap + t];
     const __bf16 h = (__bf16)x;
     const float r1 = x - (float)h;
     const __bf16 mm = (__bf16)r1;
@@ -458,17 +463,19 @@ static int launch_split(const SplitArgs &a0, hipStream_t st) {
 
 using namespace mvs;
 
-// Cout of ONE launch: 32 where the layer has a multiple of 32 output channels, else 16
+// output channels of ONE launch: 32 where the layer has a multiple of 32, else 16 (an 8-channel layer fills half the rows)
 static int split_cout_step(int Cout) { return Cout % 32 == 0 ? 32 : 16; }
+static int split_cps(int kd, int Cin) { return kd == 1 && Cin >= 16 ? 2 : 1; }
 
 extern "C" int mvs_conv_split_supported(int kd, int Cin, int Cout) {
+    // (FeatureNet's 8 -> 8 layer was tried on half-filled 16-row tiles: 0.24 ms against 0.20 for the fp32 shifted form)
     return (kd == 1 || kd == 3) && (Cin == 16 || Cin == 32 || Cin == 64) && (Cout == 16 || Cout == 32 || Cout == 64);
 }
 
 extern "C" size_t mvs_conv_split_packed_bytes(int kd, int Cin, int Cout) {
     if (!mvs_conv_split_supported(kd, Cin, Cout)) return 0;
-    const int cps = kd == 1 ? 2 : 1, G = (kd * 9 * cps + 3) / 4;
-    return (size_t)(Cin / (8 * cps)) * G * (Cout / 16) * 3 * 1024;
+    const int cps = split_cps(kd, Cin), G = (kd * 9 * cps + 3) / 4;
+    return (size_t)(Cin / (8 * cps)) * G * ((Cout + 15) / 16) * 3 * 1024;
 }
 
 extern "C" int mvs_conv_split_pack_weights_f32(const float *weight, int kd, int Cin, int Cout, void *packed, void *stream) {
@@ -477,11 +484,11 @@ extern "C" int mvs_conv_split_pack_weights_f32(const float *weight, int kd, int 
         return MVS_EINVAL;
     }
     // one block of the packed buffer per launch of the layer (Cout / step launches, each `step` output channels)
-    const int step = split_cout_step(Cout), cps = kd == 1 ? 2 : 1, G = (kd * 9 * cps + 3) / 4, MT = step / 16;
+    const int step = split_cout_step(Cout), cps = split_cps(kd, Cin), G = (kd * 9 * cps + 3) / 4, MT = step / 16;
     const size_t per_launch = (size_t)(Cin / (8 * cps)) * G * MT * 3 * 1024;
     for (int co0 = 0; co0 < Cout; co0 += step) {
         const int total = (Cin / (8 * cps)) * G * MT * 512;
-        hipLaunchKernelGGL(pack_split_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), weight, Cin, kd * 9, cps, G, MT,
+        hipLaunchKernelGGL(pack_split_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), weight, Cin, Cout, kd * 9, cps, G, MT,
                            co0, reinterpret_cast<unsigned short *>(static_cast<unsigned char *>(packed) + (co0 / step) * per_launch), total);
     }
     return check_launch("mvs_conv_split_pack_weights_f32");
@@ -489,14 +496,14 @@ extern "C" int mvs_conv_split_pack_weights_f32(const float *weight, int kd, int 
 
 extern "C" int mvs_conv_split_f32(const float *in, const void *packed, const float *scale, const float *shift,
                                   const float *residual, int relu, int kd, int B, int Cin, int Cout, int D, int H, int W,
-                                  float *out, void *stream) {
+                                  int out_c4, float *out, void *stream) {
     if (!in || !packed || !out || B <= 0 || D <= 0 || H <= 0 || W <= 0 || relu < 0 || relu > 2 ||
-        !mvs_conv_split_supported(kd, Cin, Cout)) {
+        !mvs_conv_split_supported(kd, Cin, Cout) || (out_c4 && residual)) {
         set_error("mvs_conv_split_f32: invalid argument (kd in {1, 3}; Cin, Cout in {16, 32, 64}; stride 1; channels-last)");
         return MVS_EINVAL;
     }
     if ((int64_t)(kd + 3) * H * W * Cin * 4 >= 0xffffff00LL) return bare_error(MVS_EINVAL, __func__, __LINE__);   // 32-bit halo offsets
-    const int step = split_cout_step(Cout), cps = kd == 1 ? 2 : 1, G = (kd * 9 * cps + 3) / 4;
+    const int step = split_cout_step(Cout), cps = split_cps(kd, Cin), G = (kd * 9 * cps + 3) / 4;
     const size_t per_launch = (size_t)(Cin / (8 * cps)) * G * (step / 16) * 3 * 1024;
     hipStream_t st = as_stream(stream);
     for (int co0 = 0; co0 < Cout; co0 += step) {
@@ -505,6 +512,8 @@ extern "C" int mvs_conv_split_f32(const float *in, const void *packed, const flo
         a.scale = scale ? scale + co0 : nullptr; a.shift = shift ? shift + co0 : nullptr;
         a.residual = residual ? residual + co0 : nullptr; a.out = out + co0;
         a.B = B; a.D = D; a.H = H; a.W = W; a.ldc = Cout; a.relu = relu;
+        a.nco = Cout - co0 < step ? Cout - co0 : step; a.co0 = co0; a.out_c4 = out_c4;
+        if (out_c4) a.out = out;      // (the block index carries the channel offset)
         int rc = MVS_EUNSUPPORTED;
 #define MVS_SPLIT_CASE(CI, CO, KD) if (Cin == CI && step == CO && kd == KD) rc = launch_split<SplitCfg<CI, CO, KD>>(a, st);
         MVS_SPLIT_CASE(16, 16, 3) MVS_SPLIT_CASE(32, 16, 3) MVS_SPLIT_CASE(64, 16, 3)

@@ -657,7 +657,7 @@ def pack_conv_weight_split(weight):
     return packed
 
 
-def conv_split(x_cl, packed_split, cout, scale=None, shift=None, residual=None, relu=1, kd=3):
+def conv_split(x_cl, packed_split, cout, scale=None, shift=None, residual=None, relu=1, kd=3, out_c4=False):
     """3x3(x3) stride-1 layer on the bf16 matrix pipe with exactly split fp32 operands (mvs_conv_split_f32).
     kd = 3: x_cl [B,D,H,W,Cin] -> [B,D,H,W,cout]; kd = 1: images x_cl [N,H,W,Cin] -> [N,H,W,cout].
     relu: 0 none, 1 ReLU, 2 LeakyReLU(0.1)."""
@@ -668,13 +668,13 @@ def conv_split(x_cl, packed_split, cout, scale=None, shift=None, residual=None, 
     else:
         D, H, W, cin = x_cl.shape
         B = 1
-        out = torch.empty(D, H, W, cout, device=x_cl.device, dtype=torch.float32)
+        out = torch.empty((D, cout // 4, H, W, 4) if out_c4 else (D, H, W, cout), device=x_cl.device, dtype=torch.float32)
     with stage("conv_split"):
         check(_lib.load().mvs_conv_split_f32(
             ptr(x_cl), ptr(packed_split), ptr(_f32c(scale)) if scale is not None else None,
             ptr(_f32c(shift)) if shift is not None else None,
             ptr(_f32c(residual)) if residual is not None else None, int(relu), kd, B, cin, cout, D, H, W,
-            ptr(out), stream()), "mvs_conv_split_f32")
+            int(bool(out_c4)), ptr(out), stream()), "mvs_conv_split_f32")
     return out
 
 
@@ -1045,8 +1045,8 @@ def conv2d(x, packed, cin, cout, ksize, stride, scale=None, shift=None, relu=Fal
     pad = ksize // 2
     Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
     sp = split_companion(packed)
-    if sp is not None and ksize == 3 and stride == 1 and not planar and coarse is None and not out_c4:
-        return conv_split(x, sp, cout, scale, shift, None, int(relu), kd=1)
+    if sp is not None and ksize == 3 and stride == 1 and not planar and coarse is None:
+        return conv_split(x, sp, cout, scale, shift, None, int(relu), kd=1, out_c4=out_c4)
     out = torch.empty((B, cout // 4, Ho, Wo, 4) if out_c4 else (B, Ho, Wo, cout), device=x.device, dtype=torch.float32)
     if coarse is not None:
         coarse = _f32c(coarse)

@@ -532,6 +532,10 @@ def test_conv_split_general_vs_fp64(dev, kd, cin, cout, shape, relu):
     got = ops.conv_split(x.to(dev).permute(perm).contiguous(), pks, cout, scale.to(dev), shift.to(dev), res.to(dev), relu, kd)
     err = (got.cpu().double() - ref).abs().max().item()
     assert err < 2e-6 * max(1.0, ref.abs().max().item()), err
+    if kd == 1:     # the 4-channel-blocked output (the sweep kernel's input layout) holds the same numbers
+        plain = ops.conv_split(x.to(dev).permute(perm).contiguous(), pks, cout, scale.to(dev), shift.to(dev), None, relu, kd)
+        c4 = ops.conv_split(x.to(dev).permute(perm).contiguous(), pks, cout, scale.to(dev), shift.to(dev), None, relu, kd, out_c4=True)
+        assert torch.equal(c4.permute(0, 2, 3, 1, 4).reshape(plain.shape), plain)
 
 
 @pytest.mark.parametrize("cin,cout,shape", [(16, 8, (1, 3, 5, 9)), (16, 8, (2, 5, 6, 21)), (32, 16, (1, 4, 7, 19)),
