@@ -191,12 +191,14 @@ int mvs_conv3d_c8_bf16x6_f32(const float *in, const void *packed, const float *s
  * mvs_amd/csrc/conv_split.hip.  kd = 3: volume [B,D,H,W,Cin] -> [B,D,H,W,Cout]; kd = 1: B*D images
  * [B,D,H,W,Cin] convolved plane by plane (pass D = number of images, B = 1).  weight: PyTorch layout
  * (Cout, Cin, [kd,] 3, 3); relu: 0 none, 1 ReLU, 2 LeakyReLU(0.1); scale / shift / residual as mvs_conv3d_f32;
- * out_c4 = 1: the output is written as 4-channel blocks [B*D, Cout/4, H, W, 4] (MVS_LAYOUT_C4; no residual). */
-int mvs_conv_split_supported(int kd, int Cin, int Cout);
-size_t mvs_conv_split_packed_bytes(int kd, int Cin, int Cout);
-int mvs_conv_split_pack_weights_f32(const float *weight, int kd, int Cin, int Cout, void *packed, void *stream);
+ * out_c4 = 1: the output is written as 4-channel blocks [B*D, Cout/4, H, W, 4] (MVS_LAYOUT_C4; no residual).
+ * stride = 2 (kd = 3 only; Cin in {8, 16, 32}: CostRegNet conv1 / conv3 / conv5, mvsnet.py:67-71): output
+ * [B, (D-1)/2+1, (H-1)/2+1, (W-1)/2+1, Cout]. */
+int mvs_conv_split_supported(int kd, int Cin, int Cout, int stride);
+size_t mvs_conv_split_packed_bytes(int kd, int Cin, int Cout, int stride);
+int mvs_conv_split_pack_weights_f32(const float *weight, int kd, int Cin, int Cout, int stride, void *packed, void *stream);
 int mvs_conv_split_f32(const float *in, const void *packed, const float *scale, const float *shift,
-                       const float *residual, int relu, int kd, int B, int Cin, int Cout, int D, int H, int W,
+                       const float *residual, int relu, int kd, int stride, int B, int Cin, int Cout, int D, int H, int W,
                        int out_c4, float *out, void *stream);
 
 /* ... and for the transposed layers (3x3x3, stride 2, pad 1, output_padding 1: CostRegNet conv7 / conv9 / conv11,

@@ -47,10 +47,10 @@ _SIGS = {
     "mvs_conv3d_bf16x6_packed_bytes": (ctypes.c_size_t, [_c_i]),
     "mvs_conv3d_pack_weights_bf16x6_f32": (_c_i, [_c_f, _c_i, _c_f, _c_f]),
     "mvs_conv3d_c8_bf16x6_f32": (_c_i, [_c_f] * 5 + [_c_i] * 6 + [_c_f, _c_f]),
-    "mvs_conv_split_supported": (_c_i, [_c_i] * 3),
-    "mvs_conv_split_packed_bytes": (ctypes.c_size_t, [_c_i] * 3),
-    "mvs_conv_split_pack_weights_f32": (_c_i, [_c_f] + [_c_i] * 3 + [_c_f, _c_f]),
-    "mvs_conv_split_f32": (_c_i, [_c_f] * 5 + [_c_i] * 9 + [_c_f, _c_f]),
+    "mvs_conv_split_supported": (_c_i, [_c_i] * 4),
+    "mvs_conv_split_packed_bytes": (ctypes.c_size_t, [_c_i] * 4),
+    "mvs_conv_split_pack_weights_f32": (_c_i, [_c_f] + [_c_i] * 4 + [_c_f, _c_f]),
+    "mvs_conv_split_f32": (_c_i, [_c_f] * 5 + [_c_i] * 10 + [_c_f, _c_f]),
     "mvs_deconv_split_supported": (_c_i, [_c_i] * 2),
     "mvs_deconv_split_packed_bytes": (ctypes.c_size_t, [_c_i] * 2),
     "mvs_deconv_split_pack_weights_f32": (_c_i, [_c_f] + [_c_i] * 2 + [_c_f, _c_f]),

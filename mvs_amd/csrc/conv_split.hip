@@ -25,24 +25,28 @@ struct SplitArgs {
     const unsigned char *wpk; // [chunk][group][m-tile][part][lane][8 bf16]
     const float *scale, *shift, *residual;   // per output channel (of this launch) / [B, D, H, W, ldc] like out
     float *out;               // [B, D, H, W, ldc], this launch writes channels [0, COUT)
-    int B, D, H, W, ldc;
+    int B, D, H, W, ldc;      // D, H, W: input dims
+    int Do, Ho, Wo;           // output dims (= input dims for stride 1)
     int tiles_x, tiles_y, tiles_z, ystrip;
     int relu;                 // 0 none, 1 ReLU, 2 LeakyReLU(0.1)
     int nco;                  // output channels of this launch that exist (8 for an 8-channel layer on the 16-row tile)
     int co0, out_c4;          // out_c4: the WHOLE output tensor is [B*D, ldc/4, H, W, 4] (4-channel blocks), co0 = first channel of the launch
 };
 
-template <int CIN_, int COUT_, int KD_>
+template <int CIN_, int COUT_, int KD_, int S_ = 1>
 struct SplitCfg {
-    static constexpr int CIN = CIN_, COUT = COUT_, KD = KD_;
+    static constexpr int CIN = CIN_, COUT = COUT_, KD = KD_, S = S_;      // S: stride (2: the 3D down-sampling layers)
     // 8-channel chunks per step: two for the 2D layers (a K = 32 step is then 2 taps x 16 channels: 9 taps fill 18 of
     // 20 slots instead of 9 of 12, and a tile has half as many steps -- barriers, split passes -- for the same MFMAs)
     static constexpr int CPS = (KD == 1 && CIN_ >= 16) ? 2 : 1;
     static constexpr int NCHUNK = CIN / (8 * CPS), MT = COUT / 16;
     static constexpr int NTAP = KD * 9, NSLOT = NTAP * CPS, G = (NSLOT + 3) / 4;
     // output tile (TZ, TY, 16 XB) and its halo
-    static constexpr int TZ = KD == 3 ? 4 : 1, TY = KD == 3 ? (COUT_ == 16 ? 8 : 4) : 16, XB = KD == 3 ? 1 : 2, TX = 16 * XB;   // (Cout 32 in 3D: two weight chunks of 42 KiB leave room for the smaller halo only)
-    static constexpr int ZT = TZ + KD - 1, YT = TY + 2, XP = TX + 2, NVOX = ZT * YT * XP;
+    // (Cout 32 in 3D: two weight chunks of 42 KiB leave room for the smaller halo only; stride 2: the halo of a (2, 4, 16)
+    // output tile is 5 x 9 x 33 input voxels)
+    static constexpr int TZ = KD == 3 ? (S == 2 ? 2 : 4) : 1, TY = KD == 3 ? (S == 2 || COUT_ == 32 ? 4 : 8) : 16;
+    static constexpr int XB = KD == 3 ? 1 : 2, TX = 16 * XB;
+    static constexpr int ZT = (TZ - 1) * S + KD, YT = (TY - 1) * S + 3, XP = (TX - 1) * S + 3, NVOX = ZT * YT * XP;
     static constexpr int RB = TZ * TY * XB, RPW = RB / 8;                 // 16-voxel row blocks, per multiplying wave
     // voxels per chunk plane: a multiple of 16 when a step holds two chunks -- the two 8-lane halves of a ds_read_b128
     // service group (same tap, chunk 0 / chunk 1) then read voxels n .. and 16 k + n ..: complementary 16-byte slots
@@ -55,7 +59,8 @@ struct SplitCfg {
     static constexpr int T = 48 / (RPW * MT * 4) >= 2 ? 2 : 1;
     static constexpr int F_OFF = 2 * WBYTES, S_OFF = F_OFF + FBYTES, AFF_OFF = S_OFF + SBYTES;   // + scale, shift of the launch
     static constexpr int LDS_BYTES = AFF_OFF + 2 * COUT * 4;
-    static_assert(RB % 8 == 0 && LDS_BYTES <= 160 * 1024 && SPART * 2 + 16 * 1024 < 65536, "tile / LDS budget");
+    static_assert(RB % 8 == 0 && LDS_BYTES <= 160 * 1024 && SPART * 2 + 16 * 1024 < 65536 && (S == 1 || (KD == 3 && MT == 1)),
+                  "tile / LDS budget");
 };
 
 constexpr int kSplitCopyWaves = 4, kSplitThreads = 512 + 64 * kSplitCopyWaves;
@@ -118,6 +123,7 @@ __global__ __launch_bounds__(kSplitThreads) void conv_split_kernel(SplitArgs a, 
     auto split_pass = [&]() {
         f32x4 x[NPS];
         const unsigned fp = lds_base + (unsigned)(F_OFF + tid * 16), sp = lds_base + (unsigned)(S_OFF + tid * 8);
+        const unsigned sp1 = sp + (unsigned)SPART, sp2 = sp + (unsigned)(2 * SPART);     // (offset field: 16 bits)
         static_for<0, NPS>([&](auto pc) {
             constexpr int ps = decltype(pc)::value;
             x[ps] = lds_read_b128<ps * NT * 16>(fp);
@@ -133,13 +139,13 @@ __global__ __launch_bounds__(kSplitThreads) void conv_split_kernel(SplitArgs a, 
             const u32x4 hu = __builtin_bit_cast(u32x4, h), mu = __builtin_bit_cast(u32x4, m), lu = __builtin_bit_cast(u32x4, l);
             if (p0 * NT + tid < NPIECE) {
                 lds_write_b64<p0 * NT * 8>(sp, hu[0], hu[1]);
-                lds_write_b64<p0 * NT * 8 + SPART>(sp, mu[0], mu[1]);
-                lds_write_b64<p0 * NT * 8 + 2 * SPART>(sp, lu[0], lu[1]);
+                lds_write_b64<p0 * NT * 8>(sp1, mu[0], mu[1]);
+                lds_write_b64<p0 * NT * 8>(sp2, lu[0], lu[1]);
             }
             if (p1 != p0 && p1 * NT + tid < NPIECE) {
                 lds_write_b64<p1 * NT * 8>(sp, hu[2], hu[3]);
-                lds_write_b64<p1 * NT * 8 + SPART>(sp, mu[2], mu[3]);
-                lds_write_b64<p1 * NT * 8 + 2 * SPART>(sp, lu[2], lu[3]);
+                lds_write_b64<p1 * NT * 8>(sp1, mu[2], mu[3]);
+                lds_write_b64<p1 * NT * 8>(sp2, lu[2], lu[3]);
             }
         });
         lds_wait_n<0>();
@@ -167,7 +173,8 @@ __global__ __launch_bounds__(kSplitThreads) void conv_split_kernel(SplitArgs a, 
         auto geometry = [&](auto jc, int t) {
             constexpr int j = decltype(jc)::value;
             const TileIdx tile = split_decode(a, t);
-            const int ix0 = tile.tx * C::TX - 1, iy0 = tile.ty * C::TY - 1, iz0 = tile.tz * C::TZ - (C::KD == 3 ? 1 : 0);
+            const int ix0 = tile.tx * C::TX * C::S - 1, iy0 = tile.ty * C::TY * C::S - 1;
+            const int iz0 = tile.tz * C::TZ * C::S - (C::KD == 3 ? 1 : 0);
             srd[j] = make_srd(a.in + ((int64_t)tile.b * a.D + iz0) * plane_in, window_bytes);
 #pragma unroll
             for (int i = 0; i < IPW; ++i) {
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(kSplitThreads) void conv_split_kernel(SplitArgs a, 
     for (int r = 0; r < RPW; ++r) {
         const int rb = wv * RPW + r;
         const int z = rb / (C::TY * C::XB), y = (rb / C::XB) % C::TY, xb = rb % C::XB;
-        rbo[r] = (unsigned)(((z * YT + y) * XP + xb * 16 + n) * 16);
+        rbo[r] = (unsigned)(((z * C::S * YT + y * C::S) * XP + (xb * 16 + n) * C::S) * 16);
     }
     // slot 4 g + kq of this lane's K group = (tap, chunk of the step); slots past the kernel read voxel 0 against
     // zero weights
@@ -385,7 +392,7 @@ __global__ __launch_bounds__(kSplitThreads) void conv_split_kernel(SplitArgs a, 
                 for (int m = 0; m < MT; ++m) {
                     f32x4 v = acc[j][r][m];
                     acc[j][r][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (oz >= a.D || oy >= a.H || ox >= a.W || m * 16 + kq * 4 >= a.nco) continue;
+                    if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo || m * 16 + kq * 4 >= a.nco) continue;
                     v[0] = v[0] * sc[m].x + sh[m].x; v[1] = v[1] * sc[m].y + sh[m].y;
                     v[2] = v[2] * sc[m].z + sh[m].z; v[3] = v[3] * sc[m].w + sh[m].w;
                     if (a.relu == 1) {
@@ -397,8 +404,8 @@ __global__ __launch_bounds__(kSplitThreads) void conv_split_kernel(SplitArgs a, 
                     }
                     // out_c4: a lane's four channels are one block of [image, C/4, H, W, 4] (the sweep kernel's input)
                     const int64_t o = a.out_c4
-                        ? (((((int64_t)cur.b * a.D + oz) * (a.ldc >> 2) + ((a.co0 + m * 16 + kq * 4) >> 2)) * a.H + oy) * a.W + ox) * 4
-                        : ((((int64_t)cur.b * a.D + oz) * a.H + oy) * a.W + ox) * a.ldc + m * 16 + kq * 4;
+                        ? (((((int64_t)cur.b * a.Do + oz) * (a.ldc >> 2) + ((a.co0 + m * 16 + kq * 4) >> 2)) * a.Ho + oy) * a.Wo + ox) * 4
+                        : ((((int64_t)cur.b * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.ldc + m * 16 + kq * 4;
                     if (a.residual && !LAPS) {
                         const float4 rs = *reinterpret_cast<const float4 *>(a.residual + o);
                         v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
@@ -446,7 +453,8 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const float *__restrict
 template <class C>
 static int launch_split(const SplitArgs &a0, hipStream_t st) {
     SplitArgs a = a0;
-    a.tiles_x = (a.W + C::TX - 1) / C::TX; a.tiles_y = (a.H + C::TY - 1) / C::TY; a.tiles_z = (a.D + C::TZ - 1) / C::TZ;
+    a.Do = (a.D - 1) / (C::KD == 3 ? C::S : 1) + 1; a.Ho = (a.H - 1) / C::S + 1; a.Wo = (a.W - 1) / C::S + 1;
+    a.tiles_x = (a.Wo + C::TX - 1) / C::TX; a.tiles_y = (a.Ho + C::TY - 1) / C::TY; a.tiles_z = (a.Do + C::TZ - 1) / C::TZ;
     a.ystrip = C::KD == 3 ? 4 : 2;
     const int64_t nt = (int64_t)a.B * a.tiles_x * a.tiles_y * a.tiles_z;
     if (nt <= 0 || nt >= (1 << 23)) return bare_error(MVS_EINVAL, __func__, __LINE__);   // the kernel's float tile decode
@@ -463,28 +471,31 @@ static int launch_split(const SplitArgs &a0, hipStream_t st) {
 
 using namespace mvs;
 
-// output channels of ONE launch: 32 where the layer has a multiple of 32, else 16 (an 8-channel layer fills half the rows)
-static int split_cout_step(int Cout) { return Cout % 32 == 0 ? 32 : 16; }
+// output channels of ONE launch: 32 where the layer has a multiple of 32, else 16; stride 2: always 16 (its halo fills LDS)
+static int split_cout_step(int Cout, int stride) { return stride == 1 && Cout % 32 == 0 ? 32 : 16; }
 static int split_cps(int kd, int Cin) { return kd == 1 && Cin >= 16 ? 2 : 1; }
 
-extern "C" int mvs_conv_split_supported(int kd, int Cin, int Cout) {
+extern "C" int mvs_conv_split_supported(int kd, int Cin, int Cout, int stride) {
     // (FeatureNet's 8 -> 8 layer was tried on half-filled 16-row tiles: 0.24 ms against 0.20 for the fp32 shifted form)
-    return (kd == 1 || kd == 3) && (Cin == 16 || Cin == 32 || Cin == 64) && (Cout == 16 || Cout == 32 || Cout == 64);
+    const bool cout_ok = Cout == 16 || Cout == 32 || Cout == 64;
+    if (stride == 2) return kd == 3 && cout_ok && (Cin == 8 || Cin == 16 || Cin == 32);     // conv1, conv3, conv5
+    return stride == 1 && (kd == 1 || kd == 3) && (Cin == 16 || Cin == 32 || Cin == 64) && cout_ok;
 }
 
-extern "C" size_t mvs_conv_split_packed_bytes(int kd, int Cin, int Cout) {
-    if (!mvs_conv_split_supported(kd, Cin, Cout)) return 0;
+extern "C" size_t mvs_conv_split_packed_bytes(int kd, int Cin, int Cout, int stride) {
+    if (!mvs_conv_split_supported(kd, Cin, Cout, stride)) return 0;
     const int cps = split_cps(kd, Cin), G = (kd * 9 * cps + 3) / 4;
     return (size_t)(Cin / (8 * cps)) * G * ((Cout + 15) / 16) * 3 * 1024;
 }
 
-extern "C" int mvs_conv_split_pack_weights_f32(const float *weight, int kd, int Cin, int Cout, void *packed, void *stream) {
-    if (!weight || !packed || !mvs_conv_split_supported(kd, Cin, Cout)) {
+extern "C" int mvs_conv_split_pack_weights_f32(const float *weight, int kd, int Cin, int Cout, int stride, void *packed,
+                                               void *stream) {
+    if (!weight || !packed || !mvs_conv_split_supported(kd, Cin, Cout, stride)) {
         set_error("mvs_conv_split_pack_weights_f32: needs a (Cout, Cin, [kd,] 3, 3) weight with kd in {1, 3}, Cin and Cout in {16, 32, 64}");
         return MVS_EINVAL;
     }
     // one block of the packed buffer per launch of the layer (Cout / step launches, each `step` output channels)
-    const int step = split_cout_step(Cout), cps = split_cps(kd, Cin), G = (kd * 9 * cps + 3) / 4, MT = step / 16;
+    const int step = split_cout_step(Cout, stride), cps = split_cps(kd, Cin), G = (kd * 9 * cps + 3) / 4, MT = step / 16;
     const size_t per_launch = (size_t)(Cin / (8 * cps)) * G * MT * 3 * 1024;
     for (int co0 = 0; co0 < Cout; co0 += step) {
         const int total = (Cin / (8 * cps)) * G * MT * 512;
@@ -495,15 +506,15 @@ extern "C" int mvs_conv_split_pack_weights_f32(const float *weight, int kd, int 
 }
 
 extern "C" int mvs_conv_split_f32(const float *in, const void *packed, const float *scale, const float *shift,
-                                  const float *residual, int relu, int kd, int B, int Cin, int Cout, int D, int H, int W,
-                                  int out_c4, float *out, void *stream) {
+                                  const float *residual, int relu, int kd, int stride, int B, int Cin, int Cout, int D, int H,
+                                  int W, int out_c4, float *out, void *stream) {
     if (!in || !packed || !out || B <= 0 || D <= 0 || H <= 0 || W <= 0 || relu < 0 || relu > 2 ||
-        !mvs_conv_split_supported(kd, Cin, Cout) || (out_c4 && residual)) {
-        set_error("mvs_conv_split_f32: invalid argument (kd in {1, 3}; Cin, Cout in {16, 32, 64}; stride 1; channels-last)");
+        !mvs_conv_split_supported(kd, Cin, Cout, stride) || (out_c4 && residual)) {
+        set_error("mvs_conv_split_f32: invalid argument (kd in {1, 3}; Cin, Cout in {16, 32, 64}, stride 1; or kd 3, stride 2, Cin in {8, 16, 32}; channels-last)");
         return MVS_EINVAL;
     }
     if ((int64_t)(kd + 3) * H * W * Cin * 4 >= 0xffffff00LL) return bare_error(MVS_EINVAL, __func__, __LINE__);   // 32-bit halo offsets
-    const int step = split_cout_step(Cout), cps = split_cps(kd, Cin), G = (kd * 9 * cps + 3) / 4;
+    const int step = split_cout_step(Cout, stride), cps = split_cps(kd, Cin), G = (kd * 9 * cps + 3) / 4;
     const size_t per_launch = (size_t)(Cin / (8 * cps)) * G * (step / 16) * 3 * 1024;
     hipStream_t st = as_stream(stream);
     for (int co0 = 0; co0 < Cout; co0 += step) {
@@ -515,12 +526,15 @@ extern "C" int mvs_conv_split_f32(const float *in, const void *packed, const flo
         a.nco = Cout - co0 < step ? Cout - co0 : step; a.co0 = co0; a.out_c4 = out_c4;
         if (out_c4) a.out = out;      // (the block index carries the channel offset)
         int rc = MVS_EUNSUPPORTED;
-#define MVS_SPLIT_CASE(CI, CO, KD) if (Cin == CI && step == CO && kd == KD) rc = launch_split<SplitCfg<CI, CO, KD>>(a, st);
+#define MVS_SPLIT_CASE(CI, CO, KD) if (stride == 1 && Cin == CI && step == CO && kd == KD) rc = launch_split<SplitCfg<CI, CO, KD>>(a, st);
         MVS_SPLIT_CASE(16, 16, 3) MVS_SPLIT_CASE(32, 16, 3) MVS_SPLIT_CASE(64, 16, 3)
         MVS_SPLIT_CASE(16, 32, 3) MVS_SPLIT_CASE(32, 32, 3) MVS_SPLIT_CASE(64, 32, 3)
         MVS_SPLIT_CASE(16, 16, 1) MVS_SPLIT_CASE(32, 16, 1) MVS_SPLIT_CASE(64, 16, 1)
         MVS_SPLIT_CASE(16, 32, 1) MVS_SPLIT_CASE(32, 32, 1) MVS_SPLIT_CASE(64, 32, 1)
 #undef MVS_SPLIT_CASE
+        if (stride == 2 && Cin == 8) rc = launch_split<SplitCfg<8, 16, 3, 2>>(a, st);
+        if (stride == 2 && Cin == 16) rc = launch_split<SplitCfg<16, 16, 3, 2>>(a, st);
+        if (stride == 2 && Cin == 32) rc = launch_split<SplitCfg<32, 16, 3, 2>>(a, st);
         if (rc != MVS_OK) return rc;
     }
     return MVS_OK;

@@ -99,10 +99,10 @@ extern "C" int mvs_costreg_fwd_f32(const float *in, int in_layout, const mvs_con
             if (rc != MVS_OK) return rc;
             continue;
         }
-        if (L.packed_split && !s.transposed && s.stride == 1 && s.layout == MVS_LAYOUT_NHWC && impl != 1 &&
-            mvs_conv_split_supported(3, s.cin, s.cout)) {
-            // conv2 / conv4 / conv6: the split-operand kernel for 16 / 32 / 64 channels (conv_split.hip)
-            const int rc = mvs_conv_split_f32(s.src, L.packed_split, L.scale, L.shift, s.skip, s.relu, 3, B, s.cin, s.cout,
+        if (L.packed_split && !s.transposed && s.layout == MVS_LAYOUT_NHWC && impl != 1 &&
+            mvs_conv_split_supported(3, s.cin, s.cout, s.stride)) {
+            // conv1 .. conv6: the split-operand kernel (conv_split.hip)
+            const int rc = mvs_conv_split_f32(s.src, L.packed_split, L.scale, L.shift, s.skip, s.relu, 3, s.stride, B, s.cin, s.cout,
                                               D >> s.lvl, H >> s.lvl, W >> s.lvl, 0, s.dst, stream);
             if (rc != MVS_OK) return rc;
             continue;

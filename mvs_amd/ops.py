@@ -593,8 +593,11 @@ def pack_conv3d_weight(weight, transposed, stride, split=False):
     check(_lib.load().mvs_conv3d_pack_weights_f32(ptr(weight), int(transposed), cin, cout, stride,
                                                   ptr(packed), stream()),
           "mvs_conv3d_pack_weights_f32")
-    if split and not transposed and stride == 1 and conv_split_enabled():
-        sp = pack_conv_weight_split(weight)
+    # (the stride-2 layers have a split-operand kernel too, but it does not beat the fp32 one -- conv1 0.32 vs 0.33 ms,
+    # conv3 0.17 vs 0.13: their halo is 8x the MFMA work of a stride-1 layer's -- so they are routed there only on request)
+    import os
+    if split and not transposed and conv_split_enabled() and (stride == 1 or os.environ.get("MVS_CONV_SPLIT_STRIDE2") == "1"):
+        sp = pack_conv_weight_split(weight, stride)
         if sp is not None:
             _register_split(packed, sp)
     if split and transposed and stride == 2 and conv_split_enabled():
@@ -641,30 +644,31 @@ def conv3d_c8_split(x_c8, packed_split, scale=None, shift=None, residual=None, r
     return out
 
 
-def pack_conv_weight_split(weight):
+def pack_conv_weight_split(weight, stride=1):
     """(Cout, Cin, [3,] 3, 3) weight -> the bf16 hi/mid/lo A fragments of conv_split (None if the shape has no
-    such kernel: Cin, Cout in {16, 32, 64})."""
+    such kernel: stride 1 with Cin, Cout in {16, 32, 64}; 3D stride 2 with Cin in {8, 16, 32})."""
     weight = _f32c(weight)
     kd = 3 if weight.dim() == 5 else 1
     if tuple(weight.shape[-2:]) != (3, 3) or (kd == 3 and weight.shape[2] != 3):
         return None
-    n = _lib.load().mvs_conv_split_packed_bytes(kd, int(weight.shape[1]), int(weight.shape[0]))
+    n = _lib.load().mvs_conv_split_packed_bytes(kd, int(weight.shape[1]), int(weight.shape[0]), stride)
     if n == 0:
         return None
     packed = torch.empty(n // 4, device=weight.device, dtype=torch.float32)   # opaque bytes
-    check(_lib.load().mvs_conv_split_pack_weights_f32(ptr(weight), kd, int(weight.shape[1]), int(weight.shape[0]),
+    check(_lib.load().mvs_conv_split_pack_weights_f32(ptr(weight), kd, int(weight.shape[1]), int(weight.shape[0]), stride,
                                                       ptr(packed), stream()), "mvs_conv_split_pack_weights_f32")
     return packed
 
 
-def conv_split(x_cl, packed_split, cout, scale=None, shift=None, residual=None, relu=1, kd=3, out_c4=False):
+def conv_split(x_cl, packed_split, cout, scale=None, shift=None, residual=None, relu=1, kd=3, out_c4=False, stride=1):
     """3x3(x3) stride-1 layer on the bf16 matrix pipe with exactly split fp32 operands (mvs_conv_split_f32).
     kd = 3: x_cl [B,D,H,W,Cin] -> [B,D,H,W,cout]; kd = 1: images x_cl [N,H,W,Cin] -> [N,H,W,cout].
     relu: 0 none, 1 ReLU, 2 LeakyReLU(0.1)."""
     x_cl = _f32c(x_cl)
     if kd == 3:
         B, D, H, W, cin = x_cl.shape
-        out = torch.empty(B, D, H, W, cout, device=x_cl.device, dtype=torch.float32)
+        out = torch.empty(B, (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1, cout, device=x_cl.device,
+                          dtype=torch.float32)
     else:
         D, H, W, cin = x_cl.shape
         B = 1
@@ -673,7 +677,7 @@ def conv_split(x_cl, packed_split, cout, scale=None, shift=None, residual=None, 
         check(_lib.load().mvs_conv_split_f32(
             ptr(x_cl), ptr(packed_split), ptr(_f32c(scale)) if scale is not None else None,
             ptr(_f32c(shift)) if shift is not None else None,
-            ptr(_f32c(residual)) if residual is not None else None, int(relu), kd, B, cin, cout, D, H, W,
+            ptr(_f32c(residual)) if residual is not None else None, int(relu), kd, stride, B, cin, cout, D, H, W,
             int(bool(out_c4)), ptr(out), stream()), "mvs_conv_split_f32")
     return out
 
@@ -738,9 +742,9 @@ def conv3d(x, weight, scale=None, shift=None, residual=None, relu=False, transpo
         if tuple(residual.shape) != shape:
             raise MvsHipError(f"residual shape {tuple(residual.shape)} != output shape {shape}")
     sp = split_companion(packed)
-    if sp is not None and channels_last and not in_c8 and not transposed and stride == 1 and impl != IMPL_DIRECT:
+    if sp is not None and channels_last and not in_c8 and not transposed and impl != IMPL_DIRECT:
         # the layer's split-operand pack was registered with its fp32 pack: bf16 matrix pipe, fp32 accuracy
-        return conv_split(x, sp, cout, scale, shift, residual, 1 if relu else 0, kd=3)
+        return conv_split(x, sp, cout, scale, shift, residual, 1 if relu else 0, kd=3, stride=stride)
     if sp is not None and channels_last and not in_c8 and transposed and stride == 2 and impl != IMPL_DIRECT:
         return deconv_split(x, sp, cout, scale, shift, residual, relu)
     out = torch.empty(shape, device=x.device, dtype=torch.float32)

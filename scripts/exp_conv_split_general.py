@@ -80,3 +80,9 @@ if __name__ == "__main__":
         case(1, 32, 32, (5, 296, 400), reps, check=False)         # FeatureNet conv6 / feature
         case(1, 64, 64, (7, 1056, 1920), reps, check=False)       # CVP pyramid, full resolution
         case(3, 16, 16, (1, 8, 528, 960), reps, check=False)      # CVP cost regularisation, level 1
+        for cin, cout, shp in ((8, 16, (1, 192, 296, 400)), (16, 32, (1, 96, 148, 200)), (32, 64, (1, 48, 74, 100))):   # conv1, conv3, conv5
+            x = torch.randn(*shp, cin, device="cuda")
+            w = torch.randn(cout, cin, 3, 3, 3, device="cuda") * 0.05
+            pks, pk = ops.pack_conv_weight_split(w, 2), ops.pack_conv3d_weight(w, False, 2)
+            print(f"stride 2 {cin}->{cout} {shp}: split {timeit(lambda: ops.conv_split(x, pks, cout, None, None, None, 1, 3, stride=2), reps):.3f} ms"
+                  f"  fp32 {timeit(lambda: ops.conv3d(x, w, None, None, None, True, False, 2, channels_last=True, packed=pk, impl=ops.IMPL_MFMA), reps):.3f} ms", flush=True)

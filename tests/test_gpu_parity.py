@@ -538,6 +538,27 @@ def test_conv_split_general_vs_fp64(dev, kd, cin, cout, shape, relu):
         assert torch.equal(c4.permute(0, 2, 3, 1, 4).reshape(plain.shape), plain)
 
 
+@pytest.mark.parametrize("cin,cout,shape", [(8, 16, (1, 5, 9, 21)), (8, 16, (2, 8, 16, 48)), (16, 32, (1, 7, 10, 33)),
+                                            (32, 64, (1, 4, 9, 18)), (16, 16, (1, 3, 7, 70))])
+def test_conv_split_stride2_vs_fp64(dev, cin, cout, shape):
+    """The stride-2 3x3x3 layers (conv1 / conv3 / conv5) on the split-operand kernel: odd and even input sizes, partial
+    tiles, batch > 1, one to four launches per layer, affine + ReLU."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(cin * 100 + cout + shape[-1])
+    B, D, H, W = shape
+    x = torch.randn(B, cin, D, H, W, generator=g) * torch.rand(B, cin, D, H, W, generator=g) ** 2
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    ref = torch.nn.functional.conv3d(x.double(), w.double(), stride=2, padding=1)
+    ref = torch.relu(ref * scale.double().view(1, cout, 1, 1, 1) + shift.double().view(1, cout, 1, 1, 1)).permute(0, 2, 3, 4, 1)
+    pks = ops.pack_conv_weight_split(w.to(dev), stride=2)
+    assert pks is not None
+    got = ops.conv_split(x.to(dev).permute(0, 2, 3, 4, 1).contiguous(), pks, cout, scale.to(dev), shift.to(dev), None, 1, 3, stride=2)
+    assert tuple(got.shape) == tuple(ref.shape)
+    err = (got.cpu().double() - ref).abs().max().item()
+    assert err < 2e-6 * max(1.0, ref.abs().max().item()), err
+
+
 @pytest.mark.parametrize("cin,cout,shape", [(16, 8, (1, 3, 5, 9)), (16, 8, (2, 5, 6, 21)), (32, 16, (1, 4, 7, 19)),
                                             (64, 32, (1, 3, 5, 17)), (32, 8, (1, 2, 9, 33)), (16, 16, (1, 6, 4, 16)),
                                             (64, 16, (2, 3, 4, 18)), (16, 32, (1, 5, 5, 35))])
