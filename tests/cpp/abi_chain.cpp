@@ -133,13 +133,21 @@ int main(int argc, char **argv) {
             MVS_OK_(mvs_conv3d_pack_weights_f32(layers[i].weight, transposed[i], cin[i], cout[i], stride[i], packed, st));
         }
         layers[i].packed = packed;
+        // the split-operand bf16 kernels, as the Python host runs the network: conv0; the stride-1 16/32/64-channel
+        // layers; the transposed layers
         layers[i].packed_split = nullptr;
-        if (i == 0) {   // conv0 on the split-operand bf16 kernel, as the Python host runs it
-            void *ps;
+        void *ps = nullptr;
+        if (i == 0) {
             HIP_OK(hipMalloc(&ps, mvs_conv3d_bf16x6_packed_bytes(cin[0])));
             MVS_OK_(mvs_conv3d_pack_weights_bf16x6_f32(layers[0].weight, cin[0], ps, st));
-            layers[0].packed_split = ps;
+        } else if (!transposed[i] && stride[i] == 1 && mvs_conv_split_supported(3, cin[i], cout[i], 1)) {
+            HIP_OK(hipMalloc(&ps, mvs_conv_split_packed_bytes(3, cin[i], cout[i], 1)));
+            MVS_OK_(mvs_conv_split_pack_weights_f32(layers[i].weight, 3, cin[i], cout[i], 1, ps, st));
+        } else if (transposed[i] && mvs_deconv_split_supported(cin[i], cout[i])) {
+            HIP_OK(hipMalloc(&ps, mvs_deconv_split_packed_bytes(cin[i], cout[i])));
+            MVS_OK_(mvs_deconv_split_pack_weights_f32(layers[i].weight, cin[i], cout[i], ps, st));
         }
+        layers[i].packed_split = ps;
     }
     const size_t cws = mvs_costreg_workspace_bytes(B, 8, D, H, W);
     if (!cws) { std::fprintf(stderr, "costreg workspace: unsupported size\n"); return 3; }
