@@ -12,17 +12,21 @@
 // accumulation vs 2.1e-9 for ATen's fp32 convolution -- the split form is not the less accurate one.
 // Six bf16 MFMAs of K = 32 replace eight fp32 MFMAs of K = 4: 2.7x less matrix time.
 //
-// Structure = the persistent DMA-fed kernel of conv_persistent.h (one 512-thread workgroup per CU walks
-// (4,4,32)-voxel tiles, the fp32 halo of an 8-channel chunk lands in LDS by buffer-addressed DMA while the
-// previous chunk is multiplied, same tile order, same epilogue), with
-//   * one v_mfma_f32_16x16x32_bf16 covering the FOUR x-taps of the shifted form x 8 channels (K = 32):
-//     lane (n, kq) holds the 8 channels of voxel x = 2n + kq -- two ds_read_b128 of fp32 -- and splits them
-//     in registers (v_cvt_pk_bf16_f32, shifts, v_pk_add_f32: ~36 VALU per fragment, beside the other wave's
-//     MFMAs); a wave's two output rows are y-neighbours, so the 12 distinct (z, y) input rows of a chunk
-//     are split once and used by both rows;
-//   * the weights pre-split on the host side of the call (mvs_conv3d_pack_weights_bf16x6_f32) into A
-//     fragments [chunk][kz,ky][hi,mid,lo][lane][8 bf16], streamed per chunk by DMA beside the halo
-//     (27 KiB per chunk, double-buffered: all four chunks do not fit LDS next to the halo buffers).
+// Structure = the persistent DMA-fed kernel of conv_persistent.h ((4,4,32)-voxel tiles, strip order per XCD, same
+// epilogue), a step being one 8-channel chunk of one tile:
+//   * four COPY WAVES beside the eight multiplying ones issue the LDS-DMA copies of the next step's fp32 halo (39 KiB,
+//     the 36 (z, y) rows as they lie in memory: neighbouring lanes = neighbouring 16-byte pieces) and, at a chunk
+//     change, of the next weight chunk -- a copy blocks the wave that issues it for ~250 cycles;
+//   * a split pass between two barriers: every halo voxel once, fp32 -> hi, mid, lo -> three bf16 planes in LDS laid
+//     out [row][even x ... | odd x ...], so that a B fragment (lane (n, kq) = voxel x = 2n + kq, 8 channels) is one
+//     conflict-free ds_read_b128 per part (splitting in registers at fragment-read time was 5x redundant);
+//   * one v_mfma_f32_16x16x32_bf16 covers the FOUR x-taps of the shifted Cout = 8 form x 8 channels (K = 32); a
+//     wave's two output rows are y-neighbours, so the 12 distinct (z, y) input rows of a chunk are read once and
+//     used by both rows: 108 MFMAs and 63 ds_read_b128 per wave and step;
+//   * the weights pre-split on the host side of the call (mvs_conv3d_pack_weights_bf16x6_f32) into A fragments
+//     [chunk][kz,ky][hi,mid,lo][lane][8 bf16], 27 KiB per chunk, double-buffered; groups of four tiles share a
+//     chunk's weights and keep their accumulators in registers across the chunk loop.
+// Measurements, per-phase cycle counts and the variants that did not beat this form: DESIGN.md sections 4 and 6.
 #include "conv_split_common.h"
 
 #include <cstdlib>

@@ -26,7 +26,7 @@ class _Conv3dCL(torch.autograd.Function):
     def forward(ctx, x, weight, transposed, stride):
         x = x.contiguous()
         w = weight.detach().contiguous()
-        packed = ops.pack_conv3d_weight(w, transposed, stride)
+        packed = ops.pack_conv3d_weight(w, transposed, stride, split=True)   # (split-operand bf16 kernels where the shape has one)
         out = ops.conv3d(x, w, None, None, None, False, transposed, stride, channels_last=True,
                          packed=packed)
         ctx.save_for_backward(x, weight)
@@ -43,13 +43,13 @@ class _Conv3dCL(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if not transposed and stride == 1:
                 wt = w.flip(2, 3, 4).permute(1, 0, 2, 3, 4).contiguous()      # (Ci,Co,k) as a conv weight
-                gx = ops.conv3d(g, wt, channels_last=True, packed=ops.pack_conv3d_weight(wt, False, 1))
+                gx = ops.conv3d(g, wt, channels_last=True, packed=ops.pack_conv3d_weight(wt, False, 1, split=True))
             elif not transposed:
                 if any(s % 2 for s in x.shape[1:4]):
                     raise ops.MvsHipError("stride-2 conv backward needs even D, H, W")
                 wc = w.contiguous()                                            # (Co,Ci,k) as a deconv weight
                 gx = ops.conv3d(g, wc, transposed=True, stride=2, channels_last=True,
-                                packed=ops.pack_conv3d_weight(wc, True, 2))
+                                packed=ops.pack_conv3d_weight(wc, True, 2, split=True))
             else:
                 wc = w.contiguous()                                            # (Ci,Co,k) as a conv weight
                 gx = ops.conv3d(g, wc, stride=stride, channels_last=True,
