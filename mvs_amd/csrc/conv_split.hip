@@ -57,13 +57,14 @@ struct SplitCfg {
     // tiles per group (they share a chunk's weights and hold their accumulators, RPW x MT x 4 registers each, over the
     // chunk loop): bounded by the 168 registers of a 12-wave workgroup
     static constexpr int T = 48 / (RPW * MT * 4) >= 2 ? 2 : 1;
+    // copy waves: a stride-2 step carries 47 copies for 42 MFMAs per wave -- eight copy waves (16 waves, 128 registers)
+    static constexpr int NCW = S == 2 ? 8 : 4, NTHREADS = 512 + 64 * NCW;
     static constexpr int F_OFF = 2 * WBYTES, S_OFF = F_OFF + FBYTES, AFF_OFF = S_OFF + SBYTES;   // + scale, shift of the launch
     static constexpr int LDS_BYTES = AFF_OFF + 2 * COUT * 4;
     static_assert(RB % 8 == 0 && LDS_BYTES <= 160 * 1024 && SPART * 2 + 16 * 1024 < 65536 && (S == 1 || (KD == 3 && MT == 1)),
                   "tile / LDS budget");
 };
 
-constexpr int kSplitCopyWaves = 4, kSplitThreads = 512 + 64 * kSplitCopyWaves;
 
 __device__ __forceinline__ TileIdx split_decode(const SplitArgs &a, int bid) {
     TileIdx t;
@@ -82,11 +83,11 @@ __device__ __forceinline__ TileIdx split_decode(const SplitArgs &a, int bid) {
 // LAPS (tuning build, MVS_CONV_SPLIT_LAPS=1): cycles of each multiplying wave per phase, summed over the workgroup's steps,
 // into the buffer passed as `residual` (int64 [workgroup][wave][8]): barrier, split pass, barrier, MFMA phase, epilogue
 template <class C, bool LAPS = false>
-__global__ __launch_bounds__(kSplitThreads) void conv_split_kernel(SplitArgs a, int ntiles) {
+__global__ __launch_bounds__(C::NTHREADS) void conv_split_kernel(SplitArgs a, int ntiles) {
     constexpr int CIN = C::CIN, NCHUNK = C::NCHUNK, MT = C::MT, G = C::G, T = C::T, RPW = C::RPW;
     constexpr int YT = C::YT, XP = C::XP, NVOX = C::NVOX, NPIECE = C::NPIECE, NCOPY = C::NCOPY;
     constexpr int SPART = C::SPART, WBYTES = C::WBYTES, F_OFF = C::F_OFF, S_OFF = C::S_OFF;
-    constexpr int NC = kSplitCopyWaves, IPW = (NCOPY + NC - 1) / NC, NT = kSplitThreads;
+    constexpr int NC = C::NCW, IPW = (NCOPY + NC - 1) / NC, NT = C::NTHREADS;
     constexpr int NWC = (WBYTES / 1024 + NC - 1) / NC;            // weight copies per copy wave
     __shared__ __attribute__((aligned(16))) unsigned char lds[C::LDS_BYTES];
 
@@ -461,9 +462,9 @@ static int launch_split(const SplitArgs &a0, hipStream_t st) {
     const int n_cu = device_cu_count();
     static const bool laps = [] { const char *e = getenv("MVS_CONV_SPLIT_LAPS"); return e && e[0] == '1'; }();
     if (laps && a.residual && (C::CIN == 64 || C::CIN == 16) && C::COUT == 16 * (C::CIN == 64 ? 2 : 1))   // tuning builds: 64 -> 32 and 16 -> 16
-        hipLaunchKernelGGL((conv_split_kernel<C, true>), dim3((unsigned)(nt < n_cu ? nt : n_cu)), dim3(kSplitThreads), 0, st, a, (int)nt);
+        hipLaunchKernelGGL((conv_split_kernel<C, true>), dim3((unsigned)(nt < n_cu ? nt : n_cu)), dim3(C::NTHREADS), 0, st, a, (int)nt);
     else
-        hipLaunchKernelGGL((conv_split_kernel<C>), dim3((unsigned)(nt < n_cu ? nt : n_cu)), dim3(kSplitThreads), 0, st, a, (int)nt);
+        hipLaunchKernelGGL((conv_split_kernel<C>), dim3((unsigned)(nt < n_cu ? nt : n_cu)), dim3(C::NTHREADS), 0, st, a, (int)nt);
     return check_launch("mvs_conv_split_f32");
 }
 

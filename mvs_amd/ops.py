@@ -593,10 +593,12 @@ def pack_conv3d_weight(weight, transposed, stride, split=False):
     check(_lib.load().mvs_conv3d_pack_weights_f32(ptr(weight), int(transposed), cin, cout, stride,
                                                   ptr(packed), stream()),
           "mvs_conv3d_pack_weights_f32")
-    # (the stride-2 layers have a split-operand kernel too, but it does not beat the fp32 one -- conv1 0.32 vs 0.33 ms,
-    # conv3 0.17 vs 0.13: their halo is 8x the MFMA work of a stride-1 layer's -- so they are routed there only on request)
+    # (the stride-2 layers have a split-operand kernel too; it wins only where one launch covers the layer -- conv1, 8 -> 16:
+    # 0.28 vs 0.34 ms -- not where each 16 output channels re-read and re-split the input: conv3 0.17 vs 0.13, conv5
+    # 0.15 vs 0.105: those are routed there only on request)
     import os
-    if split and not transposed and conv_split_enabled() and (stride == 1 or os.environ.get("MVS_CONV_SPLIT_STRIDE2") == "1"):
+    want = stride == 1 or (stride == 2 and (cin == 8 or os.environ.get("MVS_CONV_SPLIT_STRIDE2") == "1"))
+    if split and not transposed and conv_split_enabled() and want:
         sp = pack_conv_weight_split(weight, stride)
         if sp is not None:
             _register_split(packed, sp)
