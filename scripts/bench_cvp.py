@@ -57,8 +57,10 @@ def main():
             print(f"{e.key[:120]:120s} n={e.count:4d} ms={e.device_time_total / 1e3:7.2f}", file=sys.stderr)
         groups = {"feature_pyramid_2d_convs": 0.0, "costreg_3d_convs": 0.0, "sweep_variance": 0.0, "other": 0.0}
         for e in rows:
-            is2d = "conv2d" in e.key or ("PersistCfg<" in e.key and ", 1, 32, 1, 3>" in e.key)   # one-plane-deep persistent tiles
-            k = ("feature_pyramid_2d_convs" if is2d else "costreg_3d_convs" if "conv3d" in e.key
+            is2d = ("conv2d" in e.key or ("PersistCfg<" in e.key and ", 1, 32, 1, 3>" in e.key)   # one-plane-deep persistent tiles
+                    or ("conv_split_kernel" in e.key and ", 1, 1>" in e.key))                    # SplitCfg<Cin, Cout, KD = 1, S = 1>
+            is3d = "conv3d" in e.key or "conv_split_kernel" in e.key or "deconv_split_kernel" in e.key
+            k = ("feature_pyramid_2d_convs" if is2d else "costreg_3d_convs" if is3d
                  else "sweep_variance" if "variance" in e.key else "other")
             groups[k] += e.device_time_total / 1e3
         for name in [r.key for r in rows[:4]]:   # per-launch durations of the heaviest kernels, in launch order
