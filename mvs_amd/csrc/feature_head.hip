@@ -1,0 +1,297 @@
+// FeatureNet's first two layers in one kernel: conv0 (3 -> 8, 3x3) + BN + ReLU and conv1 (8 -> 8, 3x3) + BN + ReLU
+// (MVSNet/models/mvsnet.py:11-12,33-34; the same head opens CasMVSNet's FeatureNet, CasMVSNet/models/module.py:318-321).
+//
+// As two launches the pair moves 0.30 GB of conv0 output out to HBM and back in (1600 x 1184, 5 views) for 0.11 GB of
+// image in and 0.30 GB out.  Here a persistent workgroup (4 waves, two workgroups per CU) walks 32 x 32-pixel tiles:
+//   copy      the image halo of the NEXT tile, 3 planes x 36 rows x 40 columns, by LDS-DMA (double-buffered; zero
+//             fill outside the image by the buffer range check = conv0's zero padding)
+//   conv0     on the vector ALU (216 FMAs per pixel cannot fill a matrix tile): a thread owns five consecutive rows of
+//             one column of the 34 x 34 region conv1 needs, keeps its 7 x 3 x 3 inputs in registers, reads the 27 x 8
+//             weights as broadcast ds_read_b128, applies BN + ReLU and writes the pixels -- zeros outside the image:
+//             conv1 pads conv0's OUTPUT -- in the operand layout of conv1's matrix stream
+//   conv1     the Cout = 8 "shifted" fp32-MFMA stream of conv_persistent.h (same packed weights: rows = channel x
+//             x-shift, 16 even-x pixels per MFMA column group), 8 rows per wave
+// Two workgroups per CU (0.30 ms with one, 0.25 with two at 5 x 1184 x 1600): the phases of a tile add up -- copies +
+// stores 0.10, conv0 0.06-0.09, conv1 0.09 ms (its fp32 MFMAs run at the pipe's rate) -- because a wave's vector
+// instructions crawl beside its SIMD partner's MFMA stream; delaying the second resident by half a tile changed nothing.
+// The two launches this replaces take 0.42 ms.  MVS_HEAD_ABL (1 no conv0, 2 no conv1, 4 no stores, 8 no copies) is the
+// tuning switch those numbers come from.
+#include "conv_persistent.h"
+
+#include <cstdlib>
+
+namespace mvs {
+
+namespace {
+constexpr int kHT = 34, kHXH = 17;                       // conv1's halo of a 32 x 32 tile; half of it (x de-interleaved)
+constexpr int kHPlane = kHT * kHT;                       // pixels of one channel half
+constexpr int kIR = 36, kIP = 40;                        // image tile: rows y0-2 .. y0+33, columns x0-4 .. x0+35
+constexpr int kImgGran = 3 * kIR * kIP / 4;              // 16-byte pieces: 1080
+constexpr int kImgDma = (kImgGran + 63) / 64;            // 17 wave instructions
+constexpr int kImgFloats = kImgDma * 256;                // 4352
+constexpr int kW1Floats = 12 * 64 * 2;                   // conv1 A fragments: 3 x 4 taps
+constexpr int kBFloats = 2 * kHPlane * 4;
+constexpr int kW0Floats = 27 * 8 + 16;                   // conv0 [tap][cout], scale, shift
+constexpr int kHeadWaves = 4, kHeadThreads = 256, kRPW = 8;
+constexpr int kRG = 5, kNRG = 7;                         // conv0: rows per thread, row groups
+constexpr int kW1Off = 0, kBOff = kW1Off + kW1Floats, kImgOff = kBOff + kBFloats, kW0Off = kImgOff + 2 * kImgFloats;
+constexpr int kHeadLdsFloats = kW0Off + kW0Floats;
+static_assert(2 * (kHeadLdsFloats * 4 + 512) <= 160 * 1024, "two workgroups per CU");
+constexpr int kIPW = (kImgDma + kHeadWaves - 1) / kHeadWaves;   // copies per wave
+}  // namespace
+
+struct HeadArgs {
+    const float *img;      // [N,3,H,W]
+    const float *w0, *scale0, *shift0;   // conv0: PyTorch layout (8,3,3,3); BN affine
+    const float *wpk1, *scale1, *shift1; // conv1: packed for the persistent kernel (shifted Cout = 8 form)
+    float *out;            // [N,H,W,8]
+    int N, H, W, tiles_x, tiles_y, ystrip;
+    int abl;               // tuning: 1 no conv0, 2 no conv1, 4 no stores, 8 no copies (results are garbage)
+};
+
+__global__ __launch_bounds__(kHeadThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void feature_head_kernel(HeadArgs a, int ntiles) {
+    __shared__ __attribute__((aligned(16))) float lds[kHeadLdsFloats];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kq = lane >> 4;
+    const unsigned lds_base = (unsigned)(uintptr_t)lds;
+
+    int t_cur, t_end, t_step;
+    {
+        const int nb = gridDim.x;
+        if ((nb & 7) == 0) {
+            const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per = nb >> 3;
+            const int lo = (int)((int64_t)ntiles * xcd / 8), hi = (int)((int64_t)ntiles * (xcd + 1) / 8);
+            t_cur = lo + j; t_end = hi; t_step = per;
+        } else {
+            t_cur = blockIdx.x; t_end = ntiles; t_step = nb;
+        }
+    }
+    // once: conv1's A fragments, conv0's weights and affine
+    for (int i = tid; i < kW1Floats / 4; i += kHeadThreads)
+        reinterpret_cast<float4 *>(lds + kW1Off)[i] = reinterpret_cast<const float4 *>(a.wpk1)[i];
+    for (int i = tid; i < kW0Floats; i += kHeadThreads) {
+        float v;
+        if (i < 216) v = a.w0[(i & 7) * 27 + (i >> 3)];
+        else if (i < 224) v = a.scale0 ? a.scale0[i - 216] : 1.0f;
+        else v = a.shift0 ? a.shift0[i - 224] : 0.0f;
+        lds[kW0Off + i] = v;
+    }
+
+    // tile-independent coordinates of this wave's copies: piece q = (channel, row, 4-column group)
+    int loc[kIPW];
+#pragma unroll
+    for (int i = 0; i < kIPW; ++i) {
+        const int q = (i * kHeadWaves + wv) * 64 + lane;
+        const int qc = min(q, kImgGran - 1);
+        const int c = qc / (kIR * 10), r = (qc / 10) % kIR, g = qc % 10;
+        loc[i] = g | (r << 8) | (c << 16) | (q < kImgGran ? 0 : (int)0x80000000);
+    }
+    const int plane = a.H * a.W;
+    struct Tile { int tx, ty, b; };
+    auto decode = [&](int t) {
+        Tile r;
+        const int per_b = a.tiles_x * a.tiles_y;
+        r.b = t / per_b; t -= r.b * per_b;
+        const int full = a.ystrip * a.tiles_x;
+        const int s = t / full; t -= s * full;
+        const int y0 = s * a.ystrip, hs = min(a.ystrip, a.tiles_y - y0);
+        r.ty = y0 + t % hs;
+        r.tx = t / hs;
+        return r;
+    };
+    Tile nxt = {0, 0, 0};
+    auto issue = [&](int t, int parity) {
+        nxt = decode(t);
+        const mvs_srd_t srd = make_srd(a.img + (int64_t)nxt.b * 3 * plane, (unsigned)(3 * plane) * 4u);
+        const int gx0 = nxt.tx * 32 - 4, gy0 = nxt.ty * 32 - 2;
+        const unsigned base = lds_base + (unsigned)(kImgOff + parity * kImgFloats) * 4u;
+#pragma unroll
+        for (int i = 0; i < kIPW; ++i) {
+            if (i * kHeadWaves + wv >= kImgDma) continue;   // wave-uniform
+            const int gx = gx0 + (loc[i] & 255) * 4, gy = gy0 + ((loc[i] >> 8) & 255), c = (loc[i] >> 16) & 3;
+            const bool ok = loc[i] >= 0 && (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H;
+            const unsigned voff = ok ? (unsigned)((c * plane + gy * a.W + gx) * 4) : 0xffffff00u;
+            glds16_buf(voff, srd, 0u, base + (unsigned)(i * kHeadWaves + wv) * 1024u);
+        }
+    };
+
+    // conv1's BN affine of this lane's four channels
+    const int c0 = (kq & 1) * 4;
+    const float4 sc1 = a.scale1 ? *reinterpret_cast<const float4 *>(a.scale1 + c0) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 sh1 = a.shift1 ? *reinterpret_cast<const float4 *>(a.shift1 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int rdB = ((kq >> 1) * kHPlane + n) * 4 + (kq & 1) * 2;
+    const unsigned aA = lds_base + (unsigned)(kW1Off + lane * 2) * 4u;
+    // conv0: this thread's column and first row of the 34 x 34 region
+    const int hcol = tid % kHT, hrow0 = (tid / kHT) * kRG;
+    const bool conv0_thread = tid < kNRG * kHT;
+    const int hxd = (hcol & 1) ? kHXH + (hcol >> 1) : (hcol >> 1);
+
+    int parity = 0;
+    bool full_stores = false;   // did this wave issue exactly kRPW stores after its last copies?
+    if (t_cur < t_end) issue(t_cur, 0);
+    while (t_cur < t_end) {
+        const Tile cur = nxt;
+        const int t_next = t_cur + t_step;
+        // The image tile was requested before the previous tile's stores; vector memory retires in order, so with
+        // a full set of kRPW stores behind the copies a counted wait leaves the HBM write latency out of the tile.
+        if (full_stores) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // the image tile has landed; every wave is done with conv1 of the previous tile
+        if (t_next < t_end && !(a.abl & 8)) issue(t_next, parity ^ 1);
+        else if (t_next < t_end) nxt = decode(t_next);
+
+        // ---- conv0 + BN + ReLU -> conv1's operand planes
+        if (conv0_thread && !(a.abl & 1)) {
+            const float *im = lds + kImgOff + parity * kImgFloats + hrow0 * kIP + hcol + 2;
+            const float *wl = lds + kW0Off;
+            float acc[kRG][8];
+#pragma unroll
+            for (int r = 0; r < kRG; ++r)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[r][c] = 0.0f;
+            // weights of one (channel, kernel row) = 3 taps x 8 output channels, fetched one group ahead; the
+            // scheduler is fenced per group (left alone it hoists all 54 weight reads: 330 registers, one
+            // workgroup per CU)
+            float4 wq[2][6];
+            auto load_w = [&](int slot, int g) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) wq[slot][i] = *reinterpret_cast<const float4 *>(wl + g * 24 + i * 4);
+            };
+            load_w(0, 0);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float in[kRG + 2][3];
+#pragma unroll
+                for (int r = 0; r < kRG + 2; ++r)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) in[r][kx] = im[(c * kIR + r) * kIP + kx];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int g = c * 3 + ky;
+                    if (g + 1 < 9) load_w((g + 1) & 1, g + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float4 wa = wq[g & 1][kx * 2], wb = wq[g & 1][kx * 2 + 1];
+                        const float w[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+                        for (int r = 0; r < kRG; ++r)
+#pragma unroll
+                            for (int co = 0; co < 8; ++co) acc[r][co] = fmaf(in[r + ky][kx], w[co], acc[r][co]);
+                    }
+                    // (the FMAs have no side effects: without these pins instruction selection sinks all of them
+                    // below the last group's loads)
+#pragma unroll
+                    for (int r = 0; r < kRG; ++r)
+#pragma unroll
+                        for (int co = 0; co < 8; ++co) asm volatile("" : "+v"(acc[r][co]));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            const float4 s0a = *reinterpret_cast<const float4 *>(wl + 216), s0b = *reinterpret_cast<const float4 *>(wl + 220);
+            const float4 h0a = *reinterpret_cast<const float4 *>(wl + 224), h0b = *reinterpret_cast<const float4 *>(wl + 228);
+            const int gx = cur.tx * 32 - 1 + hcol;
+            const bool xin = (unsigned)gx < (unsigned)a.W;
+#pragma unroll
+            for (int r = 0; r < kRG; ++r) {
+                const int hy = hrow0 + r;
+                if (hy >= kHT) continue;
+                const int gy = cur.ty * 32 - 1 + hy;
+                const bool in_img = xin && (unsigned)gy < (unsigned)a.H;
+                float4 lo, hi;
+                lo.x = fmaxf(fmaf(acc[r][0], s0a.x, h0a.x), 0.f); lo.y = fmaxf(fmaf(acc[r][1], s0a.y, h0a.y), 0.f);
+                lo.z = fmaxf(fmaf(acc[r][2], s0a.z, h0a.z), 0.f); lo.w = fmaxf(fmaf(acc[r][3], s0a.w, h0a.w), 0.f);
+                hi.x = fmaxf(fmaf(acc[r][4], s0b.x, h0b.x), 0.f); hi.y = fmaxf(fmaf(acc[r][5], s0b.y, h0b.y), 0.f);
+                hi.z = fmaxf(fmaf(acc[r][6], s0b.z, h0b.z), 0.f); hi.w = fmaxf(fmaf(acc[r][7], s0b.w, h0b.w), 0.f);
+                if (!in_img) lo = hi = make_float4(0.f, 0.f, 0.f, 0.f);
+                float *bp = lds + kBOff + (hy * kHT + hxd) * 4;
+                *reinterpret_cast<float4 *>(bp) = lo;
+                *reinterpret_cast<float4 *>(bp + kHPlane * 4) = hi;
+            }
+        }
+        __syncthreads();
+
+        // ---- conv1: 12 taps (3 rows x 4 shifted columns), per tap one A read and kRPW B reads, one tap ahead
+        f32x4 acc1[kRPW];
+#pragma unroll
+        for (int r = 0; r < kRPW; ++r) acc1[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const unsigned aB = lds_base + (unsigned)(kBOff + rdB + wv * kRPW * kHT * 4) * 4u;
+        f32x2 fa[2], fb[2][kRPW];
+        auto fetch = [&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int ky = t / 4, kx = t % 4;
+            constexpr int boff = (ky * kHT + (kx & 1) * kHXH + (kx >> 1)) * 16;
+            fa[t & 1] = lds_read_b64<t * 512>(aA);
+            static_for<0, kRPW>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                fb[t & 1][r] = lds_read_b64<boff + r * kHT * 16>(aB);
+            });
+        };
+        if (!(a.abl & 2)) {
+        fetch(std::integral_constant<int, 0>{});
+        static_for<0, 12>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int sl = t & 1;
+            if constexpr (t + 1 < 12) fetch(std::integral_constant<int, t + 1>{});
+            lds_wait_n<(t + 1 < 12) ? (1 + kRPW) : 0>();
+            asm volatile("" : "+v"(fa[sl]));
+#pragma unroll
+            for (int r = 0; r < kRPW; ++r) asm volatile("" : "+v"(fb[sl][r]));
+#pragma unroll
+            for (int r = 0; r < kRPW; ++r) {
+                acc1[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl].x, fb[sl][r].x, acc1[r], 0, 0, 0);
+                acc1[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl].y, fb[sl][r].y, acc1[r], 0, 0, 0);
+            }
+        });
+        }
+        // ---- epilogue: BN affine, ReLU, one 16-byte store per lane and row
+        {
+            const int ox = cur.tx * 32 + 2 * n + (kq >> 1);
+#pragma unroll
+            for (int r = 0; r < kRPW; ++r) {
+                const int oy = cur.ty * 32 + wv * kRPW + r;
+                if (oy >= a.H || ox >= a.W || (a.abl & 4)) continue;
+                f32x4 v = acc1[r];
+                v[0] = fmaxf(v[0] * sc1.x + sh1.x, 0.f); v[1] = fmaxf(v[1] * sc1.y + sh1.y, 0.f);
+                v[2] = fmaxf(v[2] * sc1.z + sh1.z, 0.f); v[3] = fmaxf(v[3] * sc1.w + sh1.w, 0.f);
+                const int64_t o = (((int64_t)cur.b * a.H + oy) * a.W + ox) * 8 + c0;
+                *reinterpret_cast<float4 *>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        full_stores = !(a.abl & 4) && cur.ty * 32 + wv * kRPW + kRPW <= a.H;
+        parity ^= 1;
+        t_cur = t_next;
+    }
+}
+
+}  // namespace mvs
+
+using namespace mvs;
+
+extern "C" int mvs_feature_head_supported(int H, int W) {
+    return H > 0 && W > 0 && (W & 3) == 0 && (int64_t)H * W * 12 < 0xffffff00LL;
+}
+
+extern "C" int mvs_feature_head_f32(const float *img, const float *w0, const float *scale0, const float *shift0,
+                                    const float *packed1, const float *scale1, const float *shift1, int N, int H,
+                                    int W, float *out, void *stream) {
+    if (!img || !w0 || !packed1 || !out || N <= 0) return bare_error(MVS_EINVAL, __func__, __LINE__);
+    if (!mvs_feature_head_supported(H, W)) {
+        set_error("mvs_feature_head_f32: needs W %% 4 == 0 and an image below 4 GiB (H=%d W=%d)", H, W);
+        return MVS_EUNSUPPORTED;
+    }
+    HeadArgs a;
+    a.img = img; a.w0 = w0; a.scale0 = scale0; a.shift0 = shift0;
+    a.wpk1 = packed1; a.scale1 = scale1; a.shift1 = shift1; a.out = out;
+    a.N = N; a.H = H; a.W = W;
+    a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 31) / 32; a.ystrip = 4;
+    static const int abl = getenv("MVS_HEAD_ABL") ? atoi(getenv("MVS_HEAD_ABL")) : 0;
+    a.abl = abl;
+    const int64_t nt = (int64_t)a.tiles_x * a.tiles_y * N;
+    if (nt > 0x7fffffffLL) return bare_error(MVS_EINVAL, __func__, __LINE__);
+    const int slots = 2 * device_cu_count();
+    hipLaunchKernelGGL(feature_head_kernel, dim3((unsigned)(nt < slots ? nt : slots)), dim3(kHeadThreads), 0,
+                       (hipStream_t)stream, a, (int)nt);
+    return check_launch("mvs_feature_head_f32");
+}

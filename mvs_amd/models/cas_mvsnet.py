@@ -89,7 +89,7 @@ class FeatureNet(nn.Module):
             w = m.conv.weight.detach().float().contiguous()
             scale = (m.bn.weight / torch.sqrt(m.bn.running_var + m.bn.eps)).float().contiguous()
             shift = (m.bn.bias - m.bn.running_mean * scale).float().contiguous()
-            return dict(cin=w.shape[1], cout=w.shape[0], k=w.shape[2], stride=stride,
+            return dict(cin=w.shape[1], cout=w.shape[0], k=w.shape[2], stride=stride, weight=w,
                         packed=ops.pack_conv2d_weight(w, stride, split=True), scale=scale, shift=shift, relu=True)
 
         def plain(m):
@@ -127,7 +127,13 @@ class FeatureNet(nn.Module):
             up = top.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)   # odd sizes: as the reference
             return up + run(x, p)
 
-        c0 = run(run(imgs_nchw, P["conv0"][0], planar=True), P["conv0"][1])
+        h0, h1 = P["conv0"]
+        if (ops.feature_head_enabled() and (h0["cin"], h0["cout"], h1["cout"]) == (3, 8, 8)
+                and ops.feature_head_supported(imgs_nchw.shape[2], imgs_nchw.shape[3])):
+            c0 = ops.feature_head(imgs_nchw, h0["weight"], h0["scale"], h0["shift"], h1["packed"], h1["scale"],
+                                  h1["shift"])      # the two 3x3 layers of conv0 in one kernel
+        else:
+            c0 = run(run(imgs_nchw, h0, planar=True), h1)
         c1 = c0
         for p in P["conv1"]:
             c1 = run(c1, p)

@@ -68,7 +68,7 @@ class FeatureNet(nn.Module):
                 shift = (m.bn.bias - m.bn.running_mean * scale).float().contiguous()
                 P.append(dict(name=name, cin=w.shape[1], cout=w.shape[0], k=w.shape[2],
                               stride=stride, packed=ops.pack_conv2d_weight(w, stride, split=True), scale=scale,
-                              shift=shift, relu=True))
+                              shift=shift, relu=True, weight=w if name == "conv0" else None))
             w = self.feature.weight.detach().float().contiguous()
             P.append(dict(name="feature", cin=w.shape[1], cout=w.shape[0], k=w.shape[2], stride=1,
                           packed=ops.pack_conv2d_weight(w, 1, split=True), scale=None,
@@ -108,7 +108,15 @@ class FeatureNet(nn.Module):
         out_c4 the last layer's epilogue writes 4-channel blocks [N,8,H/4,W/4,4] (MVS_LAYOUT_C4)."""
         x = imgs_nchw
         P = self._hip_params()
+        first = 0
+        if ops.feature_head_enabled() and ops.feature_head_supported(x.shape[2], x.shape[3]):
+            with ops.stage("feature.head"):   # conv0 + conv1 in one kernel
+                x = ops.feature_head(x, P[0]["weight"], P[0]["scale"], P[0]["shift"], P[1]["packed"], P[1]["scale"],
+                                     P[1]["shift"])
+            first = 2
         for i, p in enumerate(P):
+            if i < first:
+                continue
             with ops.stage("feature." + p["name"]):
                 x = ops.conv2d(x, p["packed"], p["cin"], p["cout"], p["k"], p["stride"], p["scale"],
                                p["shift"], p["relu"], planar=(i == 0), out_c4=(out_c4 and i == len(P) - 1))

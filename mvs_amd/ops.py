@@ -1037,6 +1037,30 @@ def bn_relu_cl(x, bn, relu=True, skip=None):
                            bn.momentum, bn.eps, relu)
 
 
+def feature_head_enabled():
+    """False when MVS_FEATURE_HEAD=0 keeps FeatureNet's first two layers as two launches (A/B switch)."""
+    import os
+    return os.environ.get("MVS_FEATURE_HEAD", "1") != "0"
+
+
+def feature_head_supported(H, W):
+    return bool(_lib.load().mvs_feature_head_supported(int(H), int(W)))
+
+
+def feature_head(img_nchw, w0, scale0, shift0, packed1, scale1, shift1):
+    """FeatureNet's conv0 + BN + ReLU + conv1 + BN + ReLU (mvsnet.py:11-12) in one kernel: the [N,3,H,W] image batch ->
+    [N,H,W,8] channels-last.  w0: conv0's weight in PyTorch layout (8,3,3,3); packed1: conv1's weight from
+    pack_conv2d_weight(w1, 1); scale / shift: the folded BatchNorm affines."""
+    x = _f32c(img_nchw)
+    N, C, H, W = x.shape
+    if C != 3 or tuple(w0.shape) != (8, 3, 3, 3):
+        raise MvsHipError(f"feature_head: image {tuple(x.shape)} / conv0 weight {tuple(w0.shape)} are not the 3 -> 8 head")
+    out = torch.empty((N, H, W, 8), device=x.device, dtype=torch.float32)
+    check(_lib.load().mvs_feature_head_f32(ptr(x), ptr(_f32c(w0)), ptr(scale0), ptr(shift0), ptr(packed1), ptr(scale1),
+                                           ptr(shift1), N, H, W, ptr(out), stream()), "mvs_feature_head_f32")
+    return out
+
+
 def conv2d(x, packed, cin, cout, ksize, stride, scale=None, shift=None, relu=False, planar=False, coarse=None,
            out_c4=False):
     """FeatureNet convolution.  x: [B,H,W,cin] channels-last, or (planar) the [B,3,H,W]

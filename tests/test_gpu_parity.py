@@ -538,6 +538,34 @@ def test_conv_split_general_vs_fp64(dev, kd, cin, cout, shape, relu):
         assert torch.equal(c4.permute(0, 2, 3, 1, 4).reshape(plain.shape), plain)
 
 
+@pytest.mark.parametrize("N,H,W", [(1, 32, 32), (2, 70, 100), (1, 33, 36), (3, 17, 8), (1, 130, 164)])
+def test_feature_head_vs_fp64_and_two_launches(dev, N, H, W):
+    """mvs_feature_head_f32 (FeatureNet's conv0 + BN + ReLU + conv1 + BN + ReLU in one kernel, mvsnet.py:11-12):
+    against the fp64 chain, and against the same two layers as two launches of mvs_conv2d_f32; whole and partial
+    tiles in both axes, images narrower than a tile, batch > 1."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + W)
+    x = torch.rand(N, 3, H, W, generator=g)
+    w0 = torch.randn(8, 3, 3, 3, generator=g) / 27 ** 0.5
+    w1 = torch.randn(8, 8, 3, 3, generator=g) / 72 ** 0.5
+    s0, h0 = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.1
+    s1, h1 = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.1
+    F = torch.nn.functional
+    ref = torch.relu(F.conv2d(x.double(), w0.double(), padding=1) * s0.double().view(1, 8, 1, 1) + h0.double().view(1, 8, 1, 1))
+    ref = torch.relu(F.conv2d(ref, w1.double(), padding=1) * s1.double().view(1, 8, 1, 1) + h1.double().view(1, 8, 1, 1))
+    ref = ref.permute(0, 2, 3, 1)
+    assert ops.feature_head_supported(H, W)
+    pk0, pk1 = ops.pack_conv2d_weight(w0.to(dev), 1), ops.pack_conv2d_weight(w1.to(dev), 1)
+    d = lambda t: t.to(dev)
+    got = ops.feature_head(d(x), d(w0), d(s0), d(h0), pk1, d(s1), d(h1))
+    two = ops.conv2d(d(x), pk0, 3, 8, 3, 1, d(s0), d(h0), True, planar=True)
+    two = ops.conv2d(two, pk1, 8, 8, 3, 1, d(s1), d(h1), True)
+    tol = 3e-6 * max(1.0, ref.abs().max().item())
+    assert (got.cpu().double() - ref).abs().max().item() < tol
+    assert (two.cpu().double() - ref).abs().max().item() < tol
+    assert not ops.feature_head_supported(H, W + 2)
+
+
 @pytest.mark.parametrize("cin,cout,shape", [(8, 16, (1, 5, 9, 21)), (8, 16, (2, 8, 16, 48)), (16, 32, (1, 7, 10, 33)),
                                             (32, 64, (1, 4, 9, 18)), (16, 16, (1, 3, 7, 70))])
 def test_conv_split_stride2_vs_fp64(dev, cin, cout, shape):
