@@ -74,6 +74,8 @@ def algorithmic_work(V, C, D, h, w):
                                   "conv4": (16, 16, 3, 2), "conv5": (16, 32, 5, 4),
                                   "conv6": (32, 32, 3, 4), "feature": (32, 32, 3, 4)}.items():
         work["feature." + name] = ("mfma", 2.0 * k * k * ci * co * V * (4 * h // sc) * (4 * w // sc))
+    # conv0 + conv1 in one launch (feature_head_kernel): HBM-bound, image in + 8-channel map out
+    work["feature.head"] = ("hbm", 4.0 * (3 + 8) * V * (4 * h) * (4 * w))
     return work
 
 
