@@ -120,7 +120,10 @@ class DeviceScanPipeline:
                     dv_cache[(dmin, dint)] = torch.from_numpy(
                         np.arange(dmin, dint * (self.ndepths - 0.5) + dmin, dint, dtype=np.float32)).pin_memory().to(
                             self.dev, non_blocking=True)
-                yield {"imgs": cur["imgs"].index_select(0, idx).unsqueeze(0),
+                # "scan_imgs" / "view_slots": the scan's resident images and this sample's rows of them, for a
+                # driver that runs FeatureNet once per image (MVSNet.extract_features)
+                yield {"scan_imgs": cur["imgs"], "view_slots": idx,
+                       "imgs": cur["imgs"].index_select(0, idx).unsqueeze(0),
                        "proj_matrices": cur["proj"].index_select(0, idx).unsqueeze(0),
                        "depth_values": dv_cache[(dmin, dint)].unsqueeze(0),
                        "filename": [scan + "/{}/" + f"{ref:0>8}" + "{}"]}

@@ -306,12 +306,28 @@ class MVSNet(nn.Module):
         if self.refine:
             self.refine_network = RefineNet()
 
-    def forward(self, imgs, proj_matrices, depth_values):
+    def extract_features(self, imgs_flat, chunk=7):
+        """FeatureNet of a batch of images [N,3,H,W] on the inference kernels -> 4-channel blocked maps [N,8,H/4,W/4,4]
+        (the sweep kernel's input layout), or None when this model / shape does not run that path.  An eval driver
+        that keeps a scan's images on the device calls this once per image and hands forward() the maps of a sample's
+        views (`features=`): the reference runs FeatureNet on all V views of every sample (mvsnet.py:146), i.e. ~V
+        times per image of a scan; eval-mode FeatureNet is per image, so the maps are the same bits either way."""
+        if self.training or not (self.feature_impl == "hip" and self.feature.hip_supported()
+                                 and self.variance_impl == "lds" and ops.conv2d_persistent_enabled()):
+            return None
+        with torch.no_grad():
+            return torch.cat([self.feature.forward_hip(imgs_flat[i:i + chunk], out_c4=True)
+                              for i in range(0, imgs_flat.shape[0], chunk)])
+
+    def forward(self, imgs, proj_matrices, depth_values, features=None):
+        """features (inference only): [B,V,8,h,w,4] from extract_features() -- FeatureNet is then skipped."""
         if imgs.shape[1] != proj_matrices.shape[1]:
             raise AssertionError("Different number of images and projection matrices")
         V = imgs.shape[1]
         autograd_path = self.training or (torch.is_grad_enabled() and
                                           any(p.requires_grad for p in self.parameters()))
+        if autograd_path and features is not None:
+            raise ops.MvsHipError("forward: precomputed features are an inference-path input (model.eval(), torch.no_grad())")
         if autograd_path:
             # the host hop of rot_trans is stream-ordered and runs under FeatureNet (no device sync)
             rt_job = ops.HostRotTrans(proj_matrices) if self.proj_where == "host" and proj_matrices.is_cuda else None
@@ -366,7 +382,12 @@ class MVSNet(nn.Module):
             # FeatureNet's last layer writes them directly (a lane of its MFMA epilogue holds 4 channels)
             c4 = use_lds and ops.variance_persistent_supported(depth_values, B, V, C, h, w)
             f4 = None
-            if self.feature_impl == "hip" and self.feature.hip_supported():
+            if features is not None:
+                if not c4 or tuple(features.shape) != (B, V, C // 4, h, w, 4):
+                    raise ops.MvsHipError(f"forward: features {tuple(features.shape)} do not fit this sample "
+                                          f"({(B, V, C // 4, h, w, 4)}, shared depth planes)")
+                f4 = features.reshape(B * V, C // 4, h, w, 4)
+            elif self.feature_impl == "hip" and self.feature.hip_supported():
                 if c4 and ops.conv2d_persistent_enabled():
                     f4 = self.feature.forward_hip(flat, out_c4=True)     # [B*V,8,h,w,4]
                 else:

@@ -56,9 +56,19 @@ def save_depth(args):
                     save_pfm_rows_bottom_up(path, buf[k][b].numpy())
 
         pending = []
+        scan_imgs, scan_feats = None, None
         with torch.no_grad():
             for it, sample in enumerate(pipe):
-                out = model(sample["imgs"], sample["proj_matrices"], sample["depth_values"])
+                feats = None
+                if args.feature_cache:
+                    # FeatureNet once per image of a scan instead of once per (sample, view): every image is the
+                    # reference view of one sample and a source view of about nviews - 1 others
+                    if sample["scan_imgs"] is not scan_imgs:
+                        scan_imgs = sample["scan_imgs"]
+                        scan_feats = model.extract_features(scan_imgs)
+                    if scan_feats is not None:
+                        feats = scan_feats.index_select(0, sample["view_slots"]).unsqueeze(0)
+                out = model(sample["imgs"], sample["proj_matrices"], sample["depth_values"], features=feats)
                 # results leave through a ring of pinned buffers: the launching thread never waits
                 # for the GPU, it runs whole reference views ahead of it
                 if len(ring) < RING:
@@ -109,6 +119,9 @@ def main(argv=None):
     ap.add_argument("--decode_workers", type=int, default=4,
                     help="JPEG decoder threads of the device pipeline (a scan's 49 images take ~0.15 s on 4; more threads "
                          "only take the interpreter lock away from the launching thread)")
+    ap.add_argument("--no_feature_cache", dest="feature_cache", action="store_false",
+                    help="device pipeline: run FeatureNet on the views of every sample as the reference does, instead of "
+                         "once per image of a scan (same bits either way)")
     ap.add_argument("--quiet", action="store_true")
     save_depth(ap.parse_args(argv))
 

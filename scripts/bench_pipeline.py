@@ -52,7 +52,8 @@ def main():
     res = {"views_in_scan": nview, "scans": nscan}
     nview = nview * nscan
     for name, extra in (("device_pipeline", ["--device_pipeline"]), ("host_loader_4_workers", ["--num_workers", "4"]),
-                        ("device_pipeline_again", ["--device_pipeline"])):
+                        ("device_pipeline_again", ["--device_pipeline"]),
+                        ("device_pipeline_featurenet_per_sample", ["--device_pipeline", "--no_feature_cache"])):
         out = os.path.join(root, "out_" + name)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -61,6 +62,16 @@ def main():
         dt = time.perf_counter() - t0
         res[name] = {"seconds": round(dt, 2), "depth_maps_per_s": round(nview / dt, 2)}
         print(name, res[name], flush=True)
+    # FeatureNet once per image vs once per (sample, view): the files are the same bytes
+    a, b = os.path.join(root, "out_device_pipeline_again"), os.path.join(root, "out_device_pipeline_featurenet_per_sample")
+    same = 0
+    for dp, _, fs in os.walk(a):
+        for fn in fs:
+            pa = os.path.join(dp, fn)
+            with open(pa, "rb") as fa, open(os.path.join(b, os.path.relpath(pa, a)), "rb") as fb:
+                assert fa.read() == fb.read(), pa
+            same += 1
+    res["files_identical_with_and_without_feature_cache"] = same
     print(json.dumps(res))
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
     with open(os.path.join(REPO, "gpurun_out", "bench_pipeline.json"), "w") as f:

@@ -538,6 +538,33 @@ def test_conv_split_general_vs_fp64(dev, kd, cin, cout, shape, relu):
         assert torch.equal(c4.permute(0, 2, 3, 1, 4).reshape(plain.shape), plain)
 
 
+def test_mvsnet_forward_with_precomputed_features_is_bit_equal(dev):
+    """MVSNet.extract_features (FeatureNet once per image, any batching) + forward(features=...) gives the bits of
+    the plain forward, which runs FeatureNet on the V views of the sample (mvsnet.py:146)."""
+    from mvs_amd import synth
+    from mvs_amd.models import MVSNet
+    torch.manual_seed(3)
+    model = MVSNet(refine=False)
+    model.load_state_dict(synth.random_state_dict(5), strict=False)
+    model = model.to(dev).eval()
+    V, H, W, D = 3, 96, 128, 16
+    imgs = torch.rand(1, V, 3, H, W, device=dev)
+    proj = torch.from_numpy(synth.proj_matrices(V, H // 4, W // 4)).to(dev)
+    dv = torch.from_numpy(synth.depth_values(D)).to(dev)
+    with torch.no_grad():
+        plain = model(imgs, proj, dv)
+        pool = torch.cat([torch.rand(2, 3, H, W, device=dev), imgs[0], torch.rand(1, 3, H, W, device=dev)])
+        feats = model.extract_features(pool, chunk=4)
+        assert feats is not None and tuple(feats.shape) == (V + 3, 8, H // 4, W // 4, 4)
+        got = model(imgs, proj, dv, features=feats[2:2 + V].unsqueeze(0))
+    assert torch.equal(got["depth"], plain["depth"])
+    assert torch.equal(got["photometric_confidence"], plain["photometric_confidence"])
+    with pytest.raises(Exception, match="inference-path"):
+        model(imgs, proj, dv, features=feats[2:2 + V].unsqueeze(0))        # autograd path: not taken silently
+    with torch.no_grad(), pytest.raises(Exception, match="do not fit"):
+        model(imgs, proj, dv, features=feats[:V - 1].unsqueeze(0))
+
+
 @pytest.mark.parametrize("N,H,W", [(1, 32, 32), (2, 70, 100), (1, 33, 36), (3, 17, 8), (1, 130, 164)])
 def test_feature_head_vs_fp64_and_two_launches(dev, N, H, W):
     """mvs_feature_head_f32 (FeatureNet's conv0 + BN + ReLU + conv1 + BN + ReLU in one kernel, mvsnet.py:11-12):
