@@ -503,25 +503,28 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_kernel(ConvArgs a) {
 
 // ---------------------------------------------------------------------
 // Cout = 1 convolution (the `prob` layer, mvsnet.py:81,92: 8 -> 1 with bias).
-// One output channel cannot fill an MFMA tile, and the layer is HBM-bound
-// anyway (727 MB in, 91 MB out at config 2), so it runs on the VALU from an LDS
-// halo tile: thread (x,y) of a 32x8 tile produces 4 outputs along z and reads
-// every staged voxel once for all of them; weights are wave-uniform (SGPRs).
-template <int CIN>
-__global__ __launch_bounds__(256) void conv3d_cout1_kernel(ConvArgs a, const float *__restrict__ w) {
+// One output channel cannot fill an MFMA tile, so the layer runs on the VALU from an LDS
+// halo tile: thread (x,y) of a 32x8 tile produces outputs along z and reads every staged
+// voxel once for all of them; weights are broadcast LDS reads.  (Cin = 8 -- MVSNet's `prob` --
+// runs on the marching kernel below; this one serves Cin = 16 and MVS_PROB_MARCH=0.)
+template <int CIN, int NWV>
+__global__ __launch_bounds__(NWV * 64) void conv3d_cout1_kernel(ConvArgs a, const float *__restrict__ w) {
     constexpr int CQ = CIN / 4, TX = 32, TY = 8, TZ = 4;   // (TZ = 2 measured slower: 0.57 vs 0.46 ms)
+    // NWV = 8: waves 0-3 produce the tile's outputs z 0, 1, waves 4-7 z 2, 3 -- a wave issues a vector instruction
+    // every ~6 cycles at best, and every wave is blocked ~250 cycles per copy it issues: twice the waves halve both
+    constexpr int ZS = NWV / 4, TZL = TZ / ZS;             // z slabs of the tile, outputs per thread
     constexpr int XT = TX + 2, YT = TY + 2, ZT = TZ + 2, NVOX = ZT * YT * XT;
     constexpr int PLANE = round_up_c(NVOX, 64);            // whole 64-lane DMA instructions
     __shared__ __attribute__((aligned(16))) float lds[CQ * PLANE * 4];
     __shared__ __attribute__((aligned(16))) float wl[27 * CIN];
-    const int tid = threadIdx.x, lx = tid & 31, ly = tid >> 5;
+    const int tid = threadIdx.x, lx = tid & 31, ly = (tid >> 5) & 7, zh = (tid >> 8) * TZL;
     const TileIdx tile = decode_tile(a, blockIdx.x, gridDim.x);
     const int tx = tile.tx, ty = tile.ty, tz = tile.tz, b = tile.b;
     const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
     const float *in_b = a.in + (int64_t)b * a.D * a.H * a.W * CIN;
     {
         // halo tile HBM -> LDS by buffer-addressed DMA, planes [q][voxel][4 channels]:
-        // instruction i of wave w covers voxels (i*4 + w)*64 + lane of every channel quad q;
+        // instruction i of wave w covers voxels (i*NWV + w)*64 + lane of every channel quad q;
         // the descriptor's base is the tile's first halo plane, out-of-volume voxels (and the
         // plane's tail) get an offset past num_records and fetch zeros
         const int lane = tid & 63;
@@ -530,10 +533,11 @@ __global__ __launch_bounds__(256) void conv3d_cout1_kernel(ConvArgs a, const flo
         const int64_t plane_in = (int64_t)a.H * a.W * CIN;
         const mvs_srd_t srd = make_srd(in_b + (int64_t)(z0 - 1) * plane_in,
                                        (unsigned)min((int64_t)ZT * plane_in * 4, (int64_t)0xffffff00u));
-        constexpr int NI = PLANE / 64 / 4;
+        constexpr int NI = (PLANE / 64 + NWV - 1) / NWV;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int vb = i * 4 + wv;
+            const int vb = i * NWV + wv;
+            if (PLANE / 64 % NWV && vb >= PLANE / 64) continue;   // wave-uniform
             const int v = vb * 64 + lane;
             const int vc = min(v, NVOX - 1);
             const int vx = vc % XT, t2 = vc / XT, vy = t2 % YT, vz = t2 / YT;
@@ -546,16 +550,16 @@ __global__ __launch_bounds__(256) void conv3d_cout1_kernel(ConvArgs a, const flo
             for (int q = 0; q < CQ; ++q)
                 glds16_buf(off, srd, (unsigned)(q * 16), lds_base + (unsigned)((q * PLANE + vb * 64) * 16));
         }
-        for (int i = tid; i < 27 * CIN; i += 256) {
+        for (int i = tid; i < 27 * CIN; i += NWV * 64) {
             const int kyx = i / (3 * CIN), r = i - kyx * (3 * CIN), kz = r / CIN, ci = r - kz * CIN;
             wl[i] = w[ci * 27 + kz * 9 + kyx];   // PyTorch layout (1,CIN,3,3,3)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    float acc[TZ];
+    float acc[TZL];
 #pragma unroll
-    for (int z = 0; z < TZ; ++z) acc[z] = 0.f;
+    for (int z = 0; z < TZL; ++z) acc[z] = 0.f;
     // runtime loop over the 9 (ky,kx) taps; its 3*CIN weights come from LDS as broadcast
     // reads ([kyx][kz][ci], staged once per block).  Scalar loads per tap stalled the loop:
     // SMEM returns out of order, so every LDS wait behind them became lgkmcnt(0).
@@ -571,14 +575,14 @@ __global__ __launch_bounds__(256) void conv3d_cout1_kernel(ConvArgs a, const flo
                 wk[kz][c4 * 4 + 0] = t.x; wk[kz][c4 * 4 + 1] = t.y;
                 wk[kz][c4 * 4 + 2] = t.z; wk[kz][c4 * 4 + 3] = t.w;
             }
-        const float *lp = lds + ((ly + ky) * XT + lx + kx) * 4;
+        const float *lp = lds + ((zh * YT + ly + ky) * XT + lx + kx) * 4;
 #pragma unroll
-        for (int dz = 0; dz < ZT; ++dz)
+        for (int dz = 0; dz < TZL + 2; ++dz)
 #pragma unroll
             for (int q = 0; q < CQ; ++q) {
                 const float4 t = *reinterpret_cast<const float4 *>(lp + (q * PLANE + dz * YT * XT) * 4);
 #pragma unroll
-                for (int z = 0; z < TZ; ++z) {
+                for (int z = 0; z < TZL; ++z) {
                     const int kz = dz - z;
                     if (kz < 0 || kz > 2) continue;
                     acc[z] = fmaf(t.x, wk[kz][q * 4 + 0], acc[z]);
@@ -591,8 +595,8 @@ __global__ __launch_bounds__(256) void conv3d_cout1_kernel(ConvArgs a, const flo
     const int ox = x0 + lx, oy = y0 + ly;
     if (ox >= a.Wo || oy >= a.Ho) return;
 #pragma unroll
-    for (int z = 0; z < TZ; ++z) {
-        const int oz = z0 + z;
+    for (int z = 0; z < TZL; ++z) {
+        const int oz = z0 + zh + z;
         if (oz >= a.Do) continue;
         float v = acc[z];
         if (a.scale) v *= a.scale[0];
@@ -601,6 +605,215 @@ __global__ __launch_bounds__(256) void conv3d_cout1_kernel(ConvArgs a, const flo
         const int64_t o = (((int64_t)b * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
         if (a.residual) v += a.residual[o];
         a.out[o] = v;
+    }
+}
+
+// The same layer (Cin = 8) as a persistent kernel that MARCHES along z.  The per-tile kernel above pays per
+// workgroup: launch, weights from global memory and copy geometry (0.11 ms of its 0.33 at config 2, measured with
+// the copies and the arithmetic removed), and it fetches every z plane 1.5 times (a 6-plane halo per 4 output
+// planes: 1.5 GB through LDS at the ~10-14 B / cycle a CU sustains is 0.23 ms by itself).  Here one workgroup per
+// CU -- 8 computing waves, 4 copy waves -- owns a (y, x) tile and a depth segment: a ring of 12 z planes in LDS,
+// per step the copy waves bring the next FOUR planes (each plane is fetched once per column) while the computing
+// waves produce 4 output planes from the six that are there; one barrier per step; the weights are staged once.
+// A copy wave owns three (channel quad, 64-voxel group) pieces of every plane, so its per-lane offsets are three
+// registers per column and a copy costs one add and one select.
+// Measured at config 2 (MVS_PROB_ABL: 1 no copies, 2 no arithmetic): 0.26-0.28 ms whole, 0.25 arithmetic only,
+// 0.21 copies only, 0.06 neither (stores, barriers).  The arithmetic is what is left: a wave issues one instruction
+// per ~7 cycles whatever its mix (scripts/micro/coissue.hip), 8 waves x (432 FMA + 81 ds_read_b128 + waits) per step
+// are ~4600 cycles, and the same 81 reads x 8 waves x 8 cycles of the 128 B / cycle LDS are 5200 -- more waves trade
+// one bound for the other (16 waves on half the planes each read 1.5x as much), weights held in registers
+// (54 reads) left it at 0.24.  Sixteen accumulator chains per lane instead of four were worth 0.28 -> 0.25.
+namespace march {
+constexpr int TX = 32, TY = 8, TZ = 4, XT = TX + 2, YT = TY + 2;
+constexpr int PVOX = 384;                 // voxels of a plane slot: 340 in whole 64-lane copies
+constexpr int RING = 12;
+constexpr int SLOT_FLOATS = 2 * PVOX * 4; // two channel quads
+constexpr int LDS_FLOATS = RING * SLOT_FLOATS + 27 * 8;
+static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+}  // namespace march
+
+struct MarchArgs {
+    ConvArgs c;
+    int ncols, nseg, sps, nunits;     // (y, x) tiles per batch item x B; depth segments; steps per segment
+    int abl;                          // tuning: 1 no copies, 2 no arithmetic (garbage results)
+};
+
+__global__ __launch_bounds__(768) void conv3d_cout1_march_kernel(MarchArgs m, const float *__restrict__ w) {
+    using namespace march;
+    constexpr int CIN = 8;
+    const ConvArgs &a = m.c;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    float *wl = lds + RING * SLOT_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = (unsigned)(uintptr_t)lds;
+    const int nsteps = (a.D + TZ - 1) / TZ;
+    const int64_t plane_in = (int64_t)a.H * a.W * CIN;
+    int u = blockIdx.x;
+    if (u >= m.nunits) return;
+    // unit -> (segment, batch item, tile); segment-major: the units in flight are neighbouring columns
+    int b, ty, tx, s, s_end;
+    auto open_unit = [&](int uu) {
+        const int seg = uu / m.ncols;
+        int col = uu - seg * m.ncols;
+        tx = col % a.tiles_x; col /= a.tiles_x;
+        ty = col % a.tiles_y; b = col / a.tiles_y;
+        s = seg * m.sps;
+        s_end = min(s + m.sps, nsteps);
+    };
+    open_unit(u);
+    int r0 = 0;     // ring slot of plane z = 4 s - 1 of the current step
+
+    if (wv >= 8) {
+        // ---------------------------------------------------------------- copy waves
+        const int cw = wv - 8;
+        unsigned offxy[3], ldst[3];
+        auto column = [&]() {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int c = cw + 4 * i, q = c / 6, k = c % 6;       // wave-uniform
+                const int v = k * 64 + lane;
+                const int vy = v / XT, vx = v - vy * XT;
+                const int gx = tx * TX + vx - 1, gy = ty * TY + vy - 1;
+                const bool ok = v < XT * YT && (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H;
+                offxy[i] = ok ? (unsigned)((((gy * a.W + gx) * CIN) + q * 4) * 4) : 0xffffff00u;
+                ldst[i] = (unsigned)((q * PVOX + k * 64) * 16);
+            }
+        };
+        column();
+        asm volatile("s_barrier" ::: "memory");   // the computing waves' weight staging
+        mvs_srd_t srd = make_srd(a.in + (int64_t)b * a.D * plane_in,
+                                 (unsigned)min((int64_t)a.D * plane_in * 4, (int64_t)0xffffff00u));
+        const unsigned plane_bytes = (unsigned)(plane_in * 4);
+        auto issue = [&](int gz0, int nplanes, int slot0) {
+            if (m.abl & 1) return;
+            for (int p = 0; p < nplanes; ++p) {
+                const int gz = gz0 + p;
+                int slot = slot0 + p;
+                if (slot >= RING) slot -= RING;
+                const bool zok = (unsigned)gz < (unsigned)a.D;
+                const unsigned zoff = zok ? (unsigned)gz * plane_bytes : 0u;
+                const unsigned base = lds_base + (unsigned)(slot * SLOT_FLOATS * 4);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const unsigned off = (zok && offxy[i] != 0xffffff00u) ? zoff + offxy[i] : 0xffffff00u;
+                    glds16_buf(off, srd, 0u, base + ldst[i]);
+                }
+            }
+        };
+        issue(s * TZ - 1, TZ + 2, r0);
+        for (;;) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (s + 1 < s_end) {
+                issue((s + 1) * TZ + 1, TZ, (r0 + TZ + 2) % RING);
+                r0 = (r0 + TZ) % RING; ++s;
+            } else {
+                u += gridDim.x;
+                if (u >= m.nunits) break;
+                const int bprev = b;
+                open_unit(u);
+                column();
+                if (b != bprev)
+                    srd = make_srd(a.in + (int64_t)b * a.D * plane_in,
+                                   (unsigned)min((int64_t)a.D * plane_in * 4, (int64_t)0xffffff00u));
+                r0 = (r0 + TZ + 2) % RING;
+                issue(s * TZ - 1, TZ + 2, r0);
+            }
+        }
+        return;
+    }
+
+    // -------------------------------------------------------------------- computing waves
+    // The arithmetic is bound by LDS reads (a 16-byte read per lane is 8 cycles of the CU's 128 B / cycle whether it
+    // is data or a broadcast weight), so a wave = one row of the tile, its lower 32 lanes take channels 0-3 and its
+    // upper 32 channels 4-7 of the same 32 pixels, each for all four output planes of the step: 54 data + 27 weight
+    // reads per lane and step instead of 108 + 54; the two halves meet through one cross-lane add per output.
+    const int lx = tid & 31, cq = (tid >> 5) & 1, ly = tid >> 6;
+    const float sc = a.scale ? a.scale[0] : 1.0f, sh = a.shift ? a.shift[0] : 0.0f;
+    for (int i = tid; i < 27 * CIN; i += 512) {
+        const int kyx = i / (3 * CIN), r = i - kyx * (3 * CIN), kz = r / CIN, ci = r - kz * CIN;
+        wl[i] = w[ci * 27 + kz * 9 + kyx];   // PyTorch layout (1,CIN,3,3,3)
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // weights staged (the copy waves take part)
+    for (;;) {
+        __syncthreads();
+        int pl[TZ + 2];     // float offsets of the six input planes (this lane's channel quad)
+#pragma unroll
+        for (int k = 0; k < TZ + 2; ++k) {
+            int slot = r0 + k;
+            if (slot >= RING) slot -= RING;
+            pl[k] = slot * SLOT_FLOATS + cq * PVOX * 4;
+        }
+        // sixteen accumulator chains (output plane x channel): a dependent v_fma_f32 chain advances every ~50 cycles,
+        // with four chains the wave would spend 13 cycles per FMA
+        float acc[TZ], acc4[TZ][4];
+#pragma unroll
+        for (int z = 0; z < TZ; ++z)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc4[z][c] = 0.f;
+        if (!(m.abl & 2)) {
+            // nine batches = taps (ky, kx): six plane reads + three weight reads, one batch ahead of the arithmetic;
+            // fenced per batch (left alone the scheduler gathers the reads of a whole step)
+            float4 t[2][TZ + 2], wk[2][3];
+            auto fetch = [&](int slot, int kyx) {
+                const int ky = kyx / 3, kx = kyx - ky * 3;
+                const int vo = ((ly + ky) * XT + lx + kx) * 4;
+#pragma unroll
+                for (int kz = 0; kz < 3; ++kz) wk[slot][kz] = *reinterpret_cast<const float4 *>(wl + (kyx * 3 + kz) * CIN + cq * 4);
+#pragma unroll
+                for (int i = 0; i < TZ + 2; ++i) t[slot][i] = *reinterpret_cast<const float4 *>(lds + pl[i] + vo);
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int kyx = 0; kyx < 9; ++kyx) {
+                if (kyx + 1 < 9) fetch((kyx + 1) & 1, kyx + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < TZ + 2; ++i) {
+                    const float4 v = t[kyx & 1][i];
+#pragma unroll
+                    for (int z = 0; z < TZ; ++z) {
+                        const int kz = i - z;
+                        if (kz < 0 || kz > 2) continue;
+                        acc4[z][0] = fmaf(v.x, wk[kyx & 1][kz].x, acc4[z][0]);
+                        acc4[z][1] = fmaf(v.y, wk[kyx & 1][kz].y, acc4[z][1]);
+                        acc4[z][2] = fmaf(v.z, wk[kyx & 1][kz].z, acc4[z][2]);
+                        acc4[z][3] = fmaf(v.w, wk[kyx & 1][kz].w, acc4[z][3]);
+                    }
+                }
+#pragma unroll
+                for (int z = 0; z < TZ; ++z)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(acc4[z][c]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int z = 0; z < TZ; ++z) acc[z] = (acc4[z][0] + acc4[z][1]) + (acc4[z][2] + acc4[z][3]);
+#pragma unroll
+        for (int z = 0; z < TZ; ++z) acc[z] += __shfl_xor(acc[z], 32);
+        const int ox = tx * TX + lx, oy = ty * TY + ly;
+        if (ox < a.Wo && oy < a.Ho) {
+#pragma unroll
+            for (int zz = 0; zz < 2; ++zz) {     // lower half stores planes 0, 1 of the step, upper half 2, 3
+                const int oz = s * TZ + cq * 2 + zz;
+                if (oz >= a.Do) continue;
+                float v = (cq ? acc[2 + zz] : acc[zz]) * sc + sh;
+                if (a.relu) v = fmaxf(v, 0.f);
+                const int64_t o = (((int64_t)b * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
+                if (a.residual) v += a.residual[o];
+                a.out[o] = v;
+            }
+        }
+        if (s + 1 < s_end) {
+            r0 = (r0 + TZ) % RING; ++s;
+        } else {
+            u += gridDim.x;
+            if (u >= m.nunits) break;
+            open_unit(u);
+            r0 = (r0 + TZ + 2) % RING;
+        }
     }
 }
 
@@ -795,10 +1008,29 @@ int conv3d_mfma_launch(const float *in, const float *packed, const float *scale,
         a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 7) / 8; a.tiles_z = (D + 3) / 4;
         const int64_t nblk = (int64_t)B * a.tiles_x * a.tiles_y * a.tiles_z;
         if (nblk <= 0 || nblk > 0x7fffffffLL) return bare_error(MVS_EINVAL, __func__, __LINE__);
+        static const bool use_march = !(getenv("MVS_PROB_MARCH") && atoi(getenv("MVS_PROB_MARCH")) == 0);
+        if (Cin == 8 && use_march && (int64_t)D * H * W * Cin * 4 < 0xffffff00LL) {
+            // depth segments: enough units for ~4 per CU, at least 8 steps each
+            MarchArgs m;
+            m.c = a;
+            m.ncols = a.tiles_x * a.tiles_y * B;
+            const int n_cu = device_cu_count();
+            int nseg = (4 * n_cu + m.ncols - 1) / m.ncols;
+            nseg = nseg < 1 ? 1 : nseg;
+            if (nseg > (a.tiles_z + 7) / 8) nseg = (a.tiles_z + 7) / 8;
+            m.sps = (a.tiles_z + nseg - 1) / nseg;
+            m.nseg = (a.tiles_z + m.sps - 1) / m.sps;
+            m.nunits = m.ncols * m.nseg;
+            static const int abl = getenv("MVS_PROB_ABL") ? atoi(getenv("MVS_PROB_ABL")) : 0;
+            m.abl = abl;
+            hipLaunchKernelGGL(conv3d_cout1_march_kernel, dim3((unsigned)(m.nunits < n_cu ? m.nunits : n_cu)), dim3(768), 0, st,
+                               m, packed);
+            return check_launch("mvs_conv3d_f32(cout1, marching)");
+        }
         if (Cin == 8)
-            hipLaunchKernelGGL(conv3d_cout1_kernel<8>, dim3((unsigned)nblk), dim3(256), 0, st, a, packed);
+            hipLaunchKernelGGL((conv3d_cout1_kernel<8, 8>), dim3((unsigned)nblk), dim3(512), 0, st, a, packed);
         else
-            hipLaunchKernelGGL(conv3d_cout1_kernel<16>, dim3((unsigned)nblk), dim3(256), 0, st, a, packed);
+            hipLaunchKernelGGL((conv3d_cout1_kernel<16, 8>), dim3((unsigned)nblk), dim3(512), 0, st, a, packed);
         return check_launch("mvs_conv3d_f32(cout1)");
     }
     CfgInfo ci;

@@ -16,7 +16,7 @@ __global__ __launch_bounds__(512) void k(long long *out, int nm, int nv, int rol
     if ((mf && !(roles & 1)) || (!mf && !(roles & 2))) return;
     __syncthreads();
     long long t0 = clock64();
-    if (mf) {
+    if (mf && MODE != 6) {
         f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
         float a = threadIdx.x * 1e-3f, b = 2e-3f;
         bf16x8 ha, hb;
@@ -84,5 +84,6 @@ int main() {
     run<5, true>("bf16 16x16x32, s_nop 7", 4000, 16000);
     run<4, false>("f32 16x16x4, s_nop 3", 2000, 16000);
     run<5, false>("f32 16x16x4, s_nop 7", 2000, 16000);
+    run<6, false>("both waves of a SIMD: v_fma_f32", 16000, 16000);
     return 0;
 }
