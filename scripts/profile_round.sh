@@ -32,7 +32,7 @@ json.dump(out, open(f"{root}/summary.json", "w"), indent=1)
 names = {"costvol_variance": "variance_fwd_persist_kernel", "costreg.conv0": "conv3d_c8_bf16x6_kernel<32",
          "costreg.conv1": "SplitCfg<8, 16, 3, 2", "costreg.conv2": "SplitCfg<16, 16, 3",
          "costreg.conv4": "SplitCfg<32, 32, 3", "costreg.conv11": "DeconvSplitCfg<16, true",
-         "costreg.prob": "conv3d_cout1_kernel<8>", "softmax_regress_conf": "softmax_regress_conf_kernel",
+         "costreg.prob": "conv3d_cout1_march_kernel", "softmax_regress_conf": "softmax_regress_conf_kernel",
          "feature.head": "feature_head_kernel", "feature.conv2": "PersistCfg<8, 16, 1, 1, 16, 1"}
 F, W = out["FETCH_SIZE_per_launch_KB"], out["WRITE_SIZE_per_launch_KB"]
 def find(d, sub):
