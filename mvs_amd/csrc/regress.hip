@@ -12,21 +12,23 @@
 
 namespace mvs {
 
-// Block = 64 pixels x 4 depth quarters (wave w owns depths [w*D/4, (w+1)*D/4)):
+// Block = 64 pixels x 4 (REG: 8) depth slices (wave w owns depths [w*D/4, (w+1)*D/4)):
 // 4x the memory-level parallelism of one thread per pixel at the 118k-pixel sizes of
 // this path; the three partial reductions go through a few hundred bytes of LDS.
-// REG = 1 (quarters of up to 64 planes, i.e. D <= 256): a thread's slice of the cost column is
+// REG = 1 (slices of up to 32 planes, i.e. D <= 256): a thread's slice of the cost column is
 // read ONCE into registers and the three passes run from there (the memory version re-read it
 // per pass: 276 MB of HBM-side traffic for a 92 MB volume, rocprofv3 FETCH_SIZE); same
 // arithmetic, same results.
 template <int REG>
-__global__ __launch_bounds__(256) void softmax_regress_conf_kernel(
+__global__ __launch_bounds__(REG ? 512 : 256) void softmax_regress_conf_kernel(
     const float *__restrict__ cost, const float *__restrict__ depth, int depth_mode,
     int clamp_idx, int B, int D, int64_t plane, float *__restrict__ out_depth,
     float *__restrict__ out_conf, float *__restrict__ out_prob) {
-    constexpr int NR = 64;
-    __shared__ float s_f[4][64];
-    __shared__ double s_d[2][4][64];
+    // REG > 0: eight depth slices of up to REG planes each, held in registers (REG = 8, 16, 24, 32: the launcher takes
+    // the smallest that covers D / 8 -- a slice shorter than its registers would still run every unrolled step)
+    constexpr int NP = REG ? 8 : 4, NR = REG ? REG : 1;
+    __shared__ float s_f[NP][64];
+    __shared__ double s_d[2][NP][64];
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + lane;
     const bool live = i < (int64_t)B * plane;
@@ -34,39 +36,53 @@ __global__ __launch_bounds__(256) void softmax_regress_conf_kernel(
     const int b = (int)(ic / plane);
     const int64_t pix = ic % plane;
     const float *c = cost + (int64_t)b * D * plane + pix;
-    const int d0 = (int)((int64_t)D * part / 4), d1 = (int)((int64_t)D * (part + 1) / 4);
-    float v[REG ? NR : 1];
+    const int d0 = (int)((int64_t)D * part / NP), d1 = (int)((int64_t)D * (part + 1) / NP);
+    const int n = d1 - d0;               // wave-uniform
+    float v[NR];
     if constexpr (REG) {
+        const float *cp = c + (int64_t)d0 * plane;
 #pragma unroll
-        for (int k = 0; k < NR; ++k) v[k] = d0 + k < d1 ? c[(int64_t)(d0 + k) * plane] : -INFINITY;
+        for (int k = 0; k < NR; ++k) {
+            v[k] = k < n ? *cp : -INFINITY;
+            cp += plane;
+        }
     }
     // max
     float m = -INFINITY;
     if constexpr (REG) {
+        // (four chains each for the max and the three sums below: a dependent chain advances every ~50 cycles)
+        float m4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-        for (int k = 0; k < NR; ++k) m = fmaxf(m, v[k]);
+        for (int k = 0; k < NR; ++k) m4[k & 3] = fmaxf(m4[k & 3], v[k]);
+        m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
     } else {
         for (int d = d0; d < d1; ++d) m = fmaxf(m, c[(int64_t)d * plane]);
     }
     s_f[part][lane] = m;
     __syncthreads();
     m = fmaxf(fmaxf(s_f[0][lane], s_f[1][lane]), fmaxf(s_f[2][lane], s_f[3][lane]));
+    if constexpr (NP == 8) m = fmaxf(m, fmaxf(fmaxf(s_f[4][lane], s_f[5][lane]), fmaxf(s_f[6][lane], s_f[7][lane])));
     __syncthreads();
     // normaliser: the fp32 exponentials are summed in fp64 and rounded once, i.e. the
     // correctly rounded sum -- whatever order ATen's vectorised fp32 reduction uses, this
-    // is within its rounding error, and it does not depend on the quarter split
+    // is within its rounding error, and it does not depend on the slice split
     double psum = 0.0;
     if constexpr (REG) {
+        double p4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int k = 0; k < NR; ++k)
-            if (d0 + k < d1) psum += (double)expf(v[k] - m);
+        for (int k = 0; k < NR; ++k) {
+            v[k] = expf(v[k] - m);       // kept for the expectation pass (padding planes: exp(-inf) = 0)
+            p4[k & 3] += (double)v[k];
+        }
+        psum = (p4[0] + p4[1]) + (p4[2] + p4[3]);
     } else {
         for (int d = d0; d < d1; ++d) psum += (double)expf(c[(int64_t)d * plane] - m);
     }
     s_d[0][part][lane] = psum;
     __syncthreads();
-    const float sum =
-        (float)(((s_d[0][0][lane] + s_d[0][1][lane]) + s_d[0][2][lane]) + s_d[0][3][lane]);
+    double sum_d = ((s_d[0][0][lane] + s_d[0][1][lane]) + s_d[0][2][lane]) + s_d[0][3][lane];
+    if constexpr (NP == 8) sum_d += ((s_d[0][4][lane] + s_d[0][5][lane]) + s_d[0][6][lane]) + s_d[0][7][lane];
+    const float sum = (float)sum_d;
     __syncthreads();
     // The fp32 products p_d * dv_d are the reference's (module.py:102); their SUM is
     // carried in fp64: at D=192 and depths ~900 mm a naive fp32 running sum alone
@@ -75,18 +91,30 @@ __global__ __launch_bounds__(256) void softmax_regress_conf_kernel(
     const float *dv = depth_mode == 0 ? depth + (int64_t)b * D : depth + (int64_t)b * D * plane + pix;
     const int64_t dstride = depth_mode == 0 ? 1 : plane;
     float *pp = (out_prob && live) ? out_prob + (int64_t)b * D * plane + pix : nullptr;
-    auto step = [&](int d, float cv) {
-        const float pr = expf(cv - m) / sum;
-        dep += (double)(pr * dv[(int64_t)d * dstride]);   // module.py:102
-        fidx += (double)(pr * (float)d);                  // mvsnet.py:189
-        if (pp) pp[(int64_t)d * plane] = pr;
-    };
     if constexpr (REG) {
+        double dep4[4] = {0.0, 0.0, 0.0, 0.0}, fidx4[4] = {0.0, 0.0, 0.0, 0.0};
+        const float *dp = dv + (int64_t)d0 * dstride;
+        float *ppk = pp ? pp + (int64_t)d0 * plane : nullptr;
 #pragma unroll
-        for (int k = 0; k < NR; ++k)
-            if (d0 + k < d1) step(d0 + k, v[k]);
+        for (int k = 0; k < NR; ++k) {
+            if (k < n) {
+                const float pr = v[k] / sum;
+                dep4[k & 3] += (double)(pr * *dp);                  // module.py:102
+                fidx4[k & 3] += (double)(pr * (float)(d0 + k));     // mvsnet.py:189
+                if (ppk) *ppk = pr;
+            }
+            dp += dstride;
+            if (ppk) ppk += plane;
+        }
+        dep = (dep4[0] + dep4[1]) + (dep4[2] + dep4[3]);
+        fidx = (fidx4[0] + fidx4[1]) + (fidx4[2] + fidx4[3]);
     } else {
-        for (int d = d0; d < d1; ++d) step(d, c[(int64_t)d * plane]);
+        for (int d = d0; d < d1; ++d) {
+            const float pr = expf(c[(int64_t)d * plane] - m) / sum;
+            dep += (double)(pr * dv[(int64_t)d * dstride]);   // module.py:102
+            fidx += (double)(pr * (float)d);                  // mvsnet.py:189
+            if (pp) pp[(int64_t)d * plane] = pr;
+        }
     }
     s_d[0][part][lane] = dep;
     s_d[1][part][lane] = fidx;
@@ -94,6 +122,10 @@ __global__ __launch_bounds__(256) void softmax_regress_conf_kernel(
     if (part != 0 || !live) return;
     dep = ((s_d[0][0][lane] + s_d[0][1][lane]) + s_d[0][2][lane]) + s_d[0][3][lane];
     fidx = ((s_d[1][0][lane] + s_d[1][1][lane]) + s_d[1][2][lane]) + s_d[1][3][lane];
+    if constexpr (NP == 8) {
+        dep += ((s_d[0][4][lane] + s_d[0][5][lane]) + s_d[0][6][lane]) + s_d[0][7][lane];
+        fidx += ((s_d[1][4][lane] + s_d[1][5][lane]) + s_d[1][6][lane]) + s_d[1][7][lane];
+    }
     // .long() truncates toward zero (mvsnet.py:189); Cas clamps (cas_mvsnet.py:63)
     int idx = (int)(float)fidx;
     if (clamp_idx) idx = min(max(idx, 0), D - 1);
@@ -150,14 +182,16 @@ extern "C" int mvs_softmax_regress_conf_f32(const float *cost, const float *dept
     const int64_t plane = (int64_t)H * W;
     const int64_t n = (int64_t)B * plane;
     unsigned grid = (unsigned)((n + 63) / 64);
-    if (D <= 256)   // a quarter of the column (<= 64 planes) fits a thread's registers
-        hipLaunchKernelGGL(softmax_regress_conf_kernel<1>, dim3(grid), dim3(256), 0, as_stream(stream),
-                           cost, depth_values, depth_mode, clamp_idx, B, D, plane, out_depth, out_conf,
-                           out_prob);
-    else
-        hipLaunchKernelGGL(softmax_regress_conf_kernel<0>, dim3(grid), dim3(256), 0, as_stream(stream),
-                           cost, depth_values, depth_mode, clamp_idx, B, D, plane, out_depth, out_conf,
-                           out_prob);
+#define MVS_SM_LAUNCH(R, T)                                                                                     \
+    hipLaunchKernelGGL(softmax_regress_conf_kernel<R>, dim3(grid), dim3(T), 0, as_stream(stream), cost, depth_values,   \
+                       depth_mode, clamp_idx, B, D, plane, out_depth, out_conf, out_prob)
+    const int per = (D + 7) / 8;   // planes of the longest of eight slices
+    if (per <= 8) MVS_SM_LAUNCH(8, 512);
+    else if (per <= 16) MVS_SM_LAUNCH(16, 512);
+    else if (per <= 24) MVS_SM_LAUNCH(24, 512);
+    else if (per <= 32) MVS_SM_LAUNCH(32, 512);
+    else MVS_SM_LAUNCH(0, 256);
+#undef MVS_SM_LAUNCH
     return check_launch("mvs_softmax_regress_conf_f32");
 }
 
