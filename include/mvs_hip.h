@@ -192,8 +192,10 @@ int mvs_conv3d_c8_bf16x6_f32(const float *in, const void *packed, const float *s
  * [B,D,H,W,Cin] convolved plane by plane (pass D = number of images, B = 1).  weight: PyTorch layout
  * (Cout, Cin, [kd,] 3, 3); relu: 0 none, 1 ReLU, 2 LeakyReLU(0.1); scale / shift / residual as mvs_conv3d_f32;
  * out_c4 = 1: the output is written as 4-channel blocks [B*D, Cout/4, H, W, 4] (MVS_LAYOUT_C4; no residual).
- * stride = 2 (kd = 3 only; Cin in {8, 16, 32}: CostRegNet conv1 / conv3 / conv5, mvsnet.py:67-71): output
- * [B, (D-1)/2+1, (H-1)/2+1, (W-1)/2+1, Cout]. */
+ * stride = 2 with kd = 3 (Cin in {8, 16, 32}: CostRegNet conv1 / conv3 / conv5, mvsnet.py:67-71): output
+ * [B, (D-1)/2+1, (H-1)/2+1, (W-1)/2+1, Cout].  stride = 2 with kd = 1 is FeatureNet's 5x5, pad-2 form
+ * (mvsnet.py:13,16 `ConvBnReLU(8, 16, 5, 2, 2)`, `ConvBnReLU(16, 32, 5, 2, 2)`; CasMVSNet/models/module.py:323,329):
+ * weight (Cout, Cin, 5, 5) with (Cin, Cout) = (8, 16) or (16, 32), output [B*D, (H-1)/2+1, (W-1)/2+1, Cout]. */
 int mvs_conv_split_supported(int kd, int Cin, int Cout, int stride);
 size_t mvs_conv_split_packed_bytes(int kd, int Cin, int Cout, int stride);
 int mvs_conv_split_pack_weights_f32(const float *weight, int kd, int Cin, int Cout, int stride, void *packed, void *stream);

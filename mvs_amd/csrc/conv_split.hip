@@ -1,4 +1,5 @@
-// 3x3(x3) stride-1 convolutions with Cout = 16 or 32 per launch (Cin = 16, 32, 64; channels-last) on the BF16
+// 3x3(x3) convolutions with Cout = 16 or 32 per launch (Cin = 16, 32, 64; stride 2: Cin = 8, 16, 32, and FeatureNet's 5x5
+// layers 8 -> 16, 16 -> 32 of mvsnet.py:13,16; channels-last) on the BF16
 // matrix pipe at FP32 accuracy: CostRegNet's conv2 / conv4 / conv6 (mvsnet.py:68-72), FeatureNet's 16 -> 16 and
 // 32 -> 32 layers (mvsnet.py:21-27), the same-shaped layers of the cascade (CasMVSNet/models/module.py) and of
 // CVP-MVSNet (net.py:22-97).  Operand splitting and error bound: conv_split_common.h / conv_bf16x6.hip.
@@ -33,20 +34,23 @@ struct SplitArgs {
     int co0, out_c4;          // out_c4: the WHOLE output tensor is [B*D, ldc/4, H, W, 4] (4-channel blocks), co0 = first channel of the launch
 };
 
-template <int CIN_, int COUT_, int KD_, int S_ = 1>
+template <int CIN_, int COUT_, int KD_, int S_ = 1, int KH_ = 3>
 struct SplitCfg {
-    static constexpr int CIN = CIN_, COUT = COUT_, KD = KD_, S = S_;      // S: stride (2: the 3D down-sampling layers)
+    // S: stride (2: the 3D down-sampling layers, and FeatureNet's 5x5 layers = KD 1, KH 5)
+    static constexpr int CIN = CIN_, COUT = COUT_, KD = KD_, S = S_, KH = KH_;
     // 8-channel chunks per step: two for the 2D layers (a K = 32 step is then 2 taps x 16 channels: 9 taps fill 18 of
     // 20 slots instead of 9 of 12, and a tile has half as many steps -- barriers, split passes -- for the same MFMAs)
-    static constexpr int CPS = (KD == 1 && CIN_ >= 16) ? 2 : 1;
+    static constexpr int CPS = (KD == 1 && S == 1 && CIN_ >= 16) ? 2 : 1;
     static constexpr int NCHUNK = CIN / (8 * CPS), MT = COUT / 16;
-    static constexpr int NTAP = KD * 9, NSLOT = NTAP * CPS, G = (NSLOT + 3) / 4;
+    static constexpr int NTAP = KD * KH * KH, NSLOT = NTAP * CPS, G = (NSLOT + 3) / 4;
     // output tile (TZ, TY, 16 XB) and its halo
     // (Cout 32 in 3D: two weight chunks of 42 KiB leave room for the smaller halo only; stride 2: the halo of a (2, 4, 16)
     // output tile is 5 x 9 x 33 input voxels)
-    static constexpr int TZ = KD == 3 ? (S == 2 ? 2 : 4) : 1, TY = KD == 3 ? (S == 2 || COUT_ == 32 ? 4 : 8) : 16;
-    static constexpr int XB = KD == 3 ? 1 : 2, TX = 16 * XB;
-    static constexpr int ZT = (TZ - 1) * S + KD, YT = (TY - 1) * S + 3, XP = (TX - 1) * S + 3, NVOX = ZT * YT * XP;
+    // (2D stride 2, 5x5: a 16 x 16 output tile needs 35 x 35 inputs; with 32 output channels the weights leave room for 8 rows)
+    static constexpr int TZ = KD == 3 ? (S == 2 ? 2 : 4) : 1;
+    static constexpr int TY = KD == 3 ? (S == 2 || COUT_ == 32 ? 4 : 8) : (S == 2 && COUT_ == 32 ? 8 : 16);
+    static constexpr int XB = (KD == 3 || S == 2) ? 1 : 2, TX = 16 * XB;
+    static constexpr int ZT = (TZ - 1) * S + KD, YT = (TY - 1) * S + KH, XP = (TX - 1) * S + KH, NVOX = ZT * YT * XP;
     static constexpr int RB = TZ * TY * XB, RPW = RB / 8;                 // 16-voxel row blocks, per multiplying wave
     // voxels per chunk plane: a multiple of 16 when a step holds two chunks -- the two 8-lane halves of a ds_read_b128
     // service group (same tap, chunk 0 / chunk 1) then read voxels n .. and 16 k + n ..: complementary 16-byte slots
@@ -61,8 +65,8 @@ struct SplitCfg {
     static constexpr int NCW = S == 2 ? 8 : 4, NTHREADS = 512 + 64 * NCW;
     static constexpr int F_OFF = 2 * WBYTES, S_OFF = F_OFF + FBYTES, AFF_OFF = S_OFF + SBYTES;   // + scale, shift of the launch
     static constexpr int LDS_BYTES = AFF_OFF + 2 * COUT * 4;
-    static_assert(RB % 8 == 0 && LDS_BYTES <= 160 * 1024 && SPART * 2 + 16 * 1024 < 65536 && (S == 1 || (KD == 3 && MT == 1)),
-                  "tile / LDS budget");
+    static_assert(RB % 8 == 0 && LDS_BYTES <= 160 * 1024 && SPART * 2 + 16 * 1024 < 65536 && (S == 1 || KD == 1 || MT == 1) &&
+                  (KH == 3 || (KH == 5 && KD == 1 && S == 2)), "tile / LDS budget");
 };
 
 
@@ -174,8 +178,8 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_split_kernel(SplitArgs a, in
         auto geometry = [&](auto jc, int t) {
             constexpr int j = decltype(jc)::value;
             const TileIdx tile = split_decode(a, t);
-            const int ix0 = tile.tx * C::TX * C::S - 1, iy0 = tile.ty * C::TY * C::S - 1;
-            const int iz0 = tile.tz * C::TZ * C::S - (C::KD == 3 ? 1 : 0);
+            const int ix0 = tile.tx * C::TX * C::S - C::KH / 2, iy0 = tile.ty * C::TY * C::S - C::KH / 2;
+            const int iz0 = C::KD == 3 ? tile.tz * C::TZ * C::S - 1 : tile.tz * C::TZ;      // (images are not strided)
             srd[j] = make_srd(a.in + ((int64_t)tile.b * a.D + iz0) * plane_in, window_bytes);
 #pragma unroll
             for (int i = 0; i < IPW; ++i) {
@@ -254,7 +258,8 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_split_kernel(SplitArgs a, in
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const int sl = 4 * g + kq, t = sl / C::CPS, c = sl % C::CPS;
-        const int dz = C::KD == 3 ? t / 9 : 0, dy = (t % 9) / 3, dx = t % 3;
+        constexpr int KK = C::KH * C::KH;
+        const int dz = C::KD == 3 ? t / KK : 0, dy = (t % KK) / C::KH, dx = t % C::KH;
         tapo[g] = sl < C::NSLOT ? (unsigned)((((dz * YT + dy) * XP + dx) + c * C::NVP) * 16) : 0u;
     }
 
@@ -490,34 +495,38 @@ static int launch_split(const SplitArgs &a0, hipStream_t st) {
 using namespace mvs;
 
 // output channels of ONE launch: 32 where the layer has a multiple of 32, else 16; stride 2: always 16 (its halo fills LDS)
-static int split_cout_step(int Cout, int stride) { return stride == 1 && Cout % 32 == 0 ? 32 : 16; }
-static int split_cps(int kd, int Cin) { return kd == 1 && Cin >= 16 ? 2 : 1; }
+// (kd = 1 with stride 2 is FeatureNet's 5x5 form: the whole layer, 16 or 32 output channels, in one launch)
+static int split_cout_step(int kd, int Cout, int stride) { return (stride == 1 || kd == 1) && Cout % 32 == 0 ? 32 : 16; }
+static int split_cps(int kd, int Cin, int stride) { return kd == 1 && stride == 1 && Cin >= 16 ? 2 : 1; }
+static int split_ntap(int kd, int stride) { return kd == 1 && stride == 2 ? 25 : kd * 9; }
 
 extern "C" int mvs_conv_split_supported(int kd, int Cin, int Cout, int stride) {
     // (FeatureNet's 8 -> 8 layer was tried on half-filled 16-row tiles: 0.24 ms against 0.20 for the fp32 shifted form)
     const bool cout_ok = Cout == 16 || Cout == 32 || Cout == 64;
+    if (stride == 2 && kd == 1) return (Cin == 8 && Cout == 16) || (Cin == 16 && Cout == 32);   // FeatureNet's 5x5 layers
     if (stride == 2) return kd == 3 && cout_ok && (Cin == 8 || Cin == 16 || Cin == 32);     // conv1, conv3, conv5
     return stride == 1 && (kd == 1 || kd == 3) && (Cin == 16 || Cin == 32 || Cin == 64) && cout_ok;
 }
 
 extern "C" size_t mvs_conv_split_packed_bytes(int kd, int Cin, int Cout, int stride) {
     if (!mvs_conv_split_supported(kd, Cin, Cout, stride)) return 0;
-    const int cps = split_cps(kd, Cin), G = (kd * 9 * cps + 3) / 4;
+    const int cps = split_cps(kd, Cin, stride), G = (split_ntap(kd, stride) * cps + 3) / 4;
     return (size_t)(Cin / (8 * cps)) * G * ((Cout + 15) / 16) * 3 * 1024;
 }
 
 extern "C" int mvs_conv_split_pack_weights_f32(const float *weight, int kd, int Cin, int Cout, int stride, void *packed,
                                                void *stream) {
     if (!weight || !packed || !mvs_conv_split_supported(kd, Cin, Cout, stride)) {
-        set_error("mvs_conv_split_pack_weights_f32: needs a (Cout, Cin, [kd,] 3, 3) weight with kd in {1, 3}, Cin and Cout in {16, 32, 64}");
+        set_error("mvs_conv_split_pack_weights_f32: needs a (Cout, Cin, [kd,] 3, 3) weight with kd in {1, 3}, Cin and Cout in {16, 32, 64} (or a supported stride-2 shape)");
         return MVS_EINVAL;
     }
     // one block of the packed buffer per launch of the layer (Cout / step launches, each `step` output channels)
-    const int step = split_cout_step(Cout, stride), cps = split_cps(kd, Cin), G = (kd * 9 * cps + 3) / 4, MT = step / 16;
+    const int ntap = split_ntap(kd, stride);
+    const int step = split_cout_step(kd, Cout, stride), cps = split_cps(kd, Cin, stride), G = (ntap * cps + 3) / 4, MT = step / 16;
     const size_t per_launch = (size_t)(Cin / (8 * cps)) * G * MT * 3 * 1024;
     for (int co0 = 0; co0 < Cout; co0 += step) {
         const int total = (Cin / (8 * cps)) * G * MT * 512;
-        hipLaunchKernelGGL(pack_split_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), weight, Cin, Cout, kd * 9, cps, G, MT,
+        hipLaunchKernelGGL(pack_split_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), weight, Cin, Cout, ntap, cps, G, MT,
                            co0, reinterpret_cast<unsigned short *>(static_cast<unsigned char *>(packed) + (co0 / step) * per_launch), total);
     }
     return check_launch("mvs_conv_split_pack_weights_f32");
@@ -528,11 +537,11 @@ extern "C" int mvs_conv_split_f32(const float *in, const void *packed, const flo
                                   int W, int out_c4, float *out, void *stream) {
     if (!in || !packed || !out || B <= 0 || D <= 0 || H <= 0 || W <= 0 || relu < 0 || relu > 2 ||
         !mvs_conv_split_supported(kd, Cin, Cout, stride) || (out_c4 && residual)) {
-        set_error("mvs_conv_split_f32: invalid argument (kd in {1, 3}; Cin, Cout in {16, 32, 64}, stride 1; or kd 3, stride 2, Cin in {8, 16, 32}; channels-last)");
+        set_error("mvs_conv_split_f32: invalid argument (kd in {1, 3}; Cin, Cout in {16, 32, 64}, stride 1; or kd 3, stride 2, Cin in {8, 16, 32}; or kd 1, stride 2 = the 5x5 layers 8 -> 16, 16 -> 32; channels-last)");
         return MVS_EINVAL;
     }
     if ((int64_t)(kd + 3) * H * W * Cin * 4 >= 0xffffff00LL) return bare_error(MVS_EINVAL, __func__, __LINE__);   // 32-bit halo offsets
-    const int step = split_cout_step(Cout, stride), cps = split_cps(kd, Cin), G = (kd * 9 * cps + 3) / 4;
+    const int step = split_cout_step(kd, Cout, stride), cps = split_cps(kd, Cin, stride), G = (split_ntap(kd, stride) * cps + 3) / 4;
     const size_t per_launch = (size_t)(Cin / (8 * cps)) * G * (step / 16) * 3 * 1024;
     hipStream_t st = as_stream(stream);
     for (int co0 = 0; co0 < Cout; co0 += step) {
@@ -550,9 +559,11 @@ extern "C" int mvs_conv_split_f32(const float *in, const void *packed, const flo
         MVS_SPLIT_CASE(16, 16, 1) MVS_SPLIT_CASE(32, 16, 1) MVS_SPLIT_CASE(64, 16, 1)
         MVS_SPLIT_CASE(16, 32, 1) MVS_SPLIT_CASE(32, 32, 1) MVS_SPLIT_CASE(64, 32, 1)
 #undef MVS_SPLIT_CASE
-        if (stride == 2 && Cin == 8) rc = launch_split<SplitCfg<8, 16, 3, 2>>(a, st);
-        if (stride == 2 && Cin == 16) rc = launch_split<SplitCfg<16, 16, 3, 2>>(a, st);
-        if (stride == 2 && Cin == 32) rc = launch_split<SplitCfg<32, 16, 3, 2>>(a, st);
+        if (stride == 2 && kd == 3 && Cin == 8) rc = launch_split<SplitCfg<8, 16, 3, 2>>(a, st);
+        if (stride == 2 && kd == 3 && Cin == 16) rc = launch_split<SplitCfg<16, 16, 3, 2>>(a, st);
+        if (stride == 2 && kd == 3 && Cin == 32) rc = launch_split<SplitCfg<32, 16, 3, 2>>(a, st);
+        if (stride == 2 && kd == 1 && Cin == 8) rc = launch_split<SplitCfg<8, 16, 1, 2, 5>>(a, st);
+        if (stride == 2 && kd == 1 && Cin == 16) rc = launch_split<SplitCfg<16, 32, 1, 2, 5>>(a, st);
         if (rc != MVS_OK) return rc;
     }
     return MVS_OK;

@@ -648,10 +648,12 @@ def conv3d_c8_split(x_c8, packed_split, scale=None, shift=None, residual=None, r
 
 def pack_conv_weight_split(weight, stride=1):
     """(Cout, Cin, [3,] 3, 3) weight -> the bf16 hi/mid/lo A fragments of conv_split (None if the shape has no
-    such kernel: stride 1 with Cin, Cout in {16, 32, 64}; 3D stride 2 with Cin in {8, 16, 32})."""
+    such kernel: stride 1 with Cin, Cout in {16, 32, 64}; 3D stride 2 with Cin in {8, 16, 32}; 2D stride 2 = the
+    (16, 8, 5, 5) and (32, 16, 5, 5) layers of FeatureNet)."""
     weight = _f32c(weight)
     kd = 3 if weight.dim() == 5 else 1
-    if tuple(weight.shape[-2:]) != (3, 3) or (kd == 3 and weight.shape[2] != 3):
+    k55 = kd == 1 and stride == 2           # FeatureNet's 5x5 stride-2 layers
+    if tuple(weight.shape[-2:]) != ((5, 5) if k55 else (3, 3)) or (kd == 3 and weight.shape[2] != 3):
         return None
     n = _lib.load().mvs_conv_split_packed_bytes(kd, int(weight.shape[1]), int(weight.shape[0]), stride)
     if n == 0:
@@ -663,8 +665,8 @@ def pack_conv_weight_split(weight, stride=1):
 
 
 def conv_split(x_cl, packed_split, cout, scale=None, shift=None, residual=None, relu=1, kd=3, out_c4=False, stride=1):
-    """3x3(x3) stride-1 layer on the bf16 matrix pipe with exactly split fp32 operands (mvs_conv_split_f32).
-    kd = 3: x_cl [B,D,H,W,Cin] -> [B,D,H,W,cout]; kd = 1: images x_cl [N,H,W,Cin] -> [N,H,W,cout].
+    """3x3(x3) layer (kd = 1 with stride 2: 5x5) on the bf16 matrix pipe with exactly split fp32 operands
+    (mvs_conv_split_f32).  kd = 3: x_cl [B,D,H,W,Cin] -> [B,D,H,W,cout]; kd = 1: images x_cl [N,H,W,Cin] -> [N,H,W,cout].
     relu: 0 none, 1 ReLU, 2 LeakyReLU(0.1)."""
     x_cl = _f32c(x_cl)
     if kd == 3:
@@ -674,7 +676,8 @@ def conv_split(x_cl, packed_split, cout, scale=None, shift=None, residual=None, 
     else:
         D, H, W, cin = x_cl.shape
         B = 1
-        out = torch.empty((D, cout // 4, H, W, 4) if out_c4 else (D, H, W, cout), device=x_cl.device, dtype=torch.float32)
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        out = torch.empty((D, cout // 4, Ho, Wo, 4) if out_c4 else (D, Ho, Wo, cout), device=x_cl.device, dtype=torch.float32)
     with stage("conv_split"):
         check(_lib.load().mvs_conv_split_f32(
             ptr(x_cl), ptr(packed_split), ptr(_f32c(scale)) if scale is not None else None,
@@ -905,8 +908,10 @@ def pack_conv2d_weight(weight, stride, split=False):
     packed = torch.empty(n, device=weight.device, dtype=torch.float32)
     check(_lib.load().mvs_conv2d_pack_weights_f32(ptr(weight), cin, cout, k, stride, ptr(packed),
                                                   stream()), "mvs_conv2d_pack_weights_f32")
-    if split and stride == 1 and k == 3 and conv_split_enabled():
-        sp = pack_conv_weight_split(weight)
+    import os
+    k55 = stride == 2 and k == 5 and os.environ.get("MVS_CONV_SPLIT_55", "1") != "0"   # (A/B switch)
+    if split and ((stride == 1 and k == 3) or k55) and conv_split_enabled():
+        sp = pack_conv_weight_split(weight, stride)
         if sp is not None:
             _register_split(packed, sp)
     return packed
@@ -1075,8 +1080,8 @@ def conv2d(x, packed, cin, cout, ksize, stride, scale=None, shift=None, relu=Fal
     pad = ksize // 2
     Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
     sp = split_companion(packed)
-    if sp is not None and ksize == 3 and stride == 1 and not planar and coarse is None:
-        return conv_split(x, sp, cout, scale, shift, None, int(relu), kd=1, out_c4=out_c4)
+    if sp is not None and (ksize, stride) in ((3, 1), (5, 2)) and not planar and coarse is None:
+        return conv_split(x, sp, cout, scale, shift, None, int(relu), kd=1, out_c4=out_c4, stride=stride)
     out = torch.empty((B, cout // 4, Ho, Wo, 4) if out_c4 else (B, Ho, Wo, cout), device=x.device, dtype=torch.float32)
     if coarse is not None:
         coarse = _f32c(coarse)

@@ -33,7 +33,7 @@ names = {"costvol_variance": "variance_fwd_persist_kernel", "costreg.conv0": "co
          "costreg.conv1": "SplitCfg<8, 16, 3, 2", "costreg.conv2": "SplitCfg<16, 16, 3",
          "costreg.conv4": "SplitCfg<32, 32, 3", "costreg.conv11": "DeconvSplitCfg<16, true",
          "costreg.prob": "conv3d_cout1_march_kernel", "softmax_regress_conf": "softmax_regress_conf_kernel",
-         "feature.head": "feature_head_kernel", "feature.conv2": "PersistCfg<8, 16, 1, 1, 16, 1"}
+         "feature.head": "feature_head_kernel", "feature.conv2": "SplitCfg<8, 16, 1, 2, 5"}
 F, W = out["FETCH_SIZE_per_launch_KB"], out["WRITE_SIZE_per_launch_KB"]
 def find(d, sub):
     return next((v for k, v in d.items() if sub in k), None)

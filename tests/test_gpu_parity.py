@@ -538,6 +538,31 @@ def test_conv_split_general_vs_fp64(dev, kd, cin, cout, shape, relu):
         assert torch.equal(c4.permute(0, 2, 3, 1, 4).reshape(plain.shape), plain)
 
 
+@pytest.mark.parametrize("cin,cout,shape", [(8, 16, (1, 32, 32)), (8, 16, (2, 37, 70)), (16, 32, (1, 16, 32)), (16, 32, (3, 41, 50)),
+                                            (8, 16, (1, 9, 6))])
+def test_conv_split_5x5_stride2_vs_fp64(dev, cin, cout, shape):
+    """FeatureNet's 5x5 stride-2 layers (mvsnet.py:13,16: 8 -> 16, 16 -> 32) on the split-operand kernel: odd and even
+    sizes, partial tiles, batch > 1, affine + ReLU; and the route through ops.conv2d."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(cin * 100 + cout + shape[-1])
+    N, H, W = shape
+    x = torch.randn(N, cin, H, W, generator=g) * torch.rand(N, cin, H, W, generator=g) ** 2
+    w = torch.randn(cout, cin, 5, 5, generator=g) / (25 * cin) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), stride=2, padding=2)
+    ref = torch.relu(ref * scale.double().view(1, cout, 1, 1) + shift.double().view(1, cout, 1, 1)).permute(0, 2, 3, 1)
+    pks = ops.pack_conv_weight_split(w.to(dev), 2)
+    assert pks is not None
+    x_cl = x.to(dev).permute(0, 2, 3, 1).contiguous()
+    got = ops.conv_split(x_cl, pks, cout, scale.to(dev), shift.to(dev), None, 1, kd=1, stride=2)
+    assert tuple(got.shape) == tuple(ref.shape)
+    tol = 2e-6 * max(1.0, ref.abs().max().item())
+    assert (got.cpu().double() - ref).abs().max().item() < tol
+    pk = ops.pack_conv2d_weight(w.to(dev), 2, split=True)
+    via = ops.conv2d(x_cl, pk, cin, cout, 5, 2, scale.to(dev), shift.to(dev), True)
+    assert torch.equal(via, got)
+
+
 def test_mvsnet_forward_with_precomputed_features_is_bit_equal(dev):
     """MVSNet.extract_features (FeatureNet once per image, any batching) + forward(features=...) gives the bits of
     the plain forward, which runs FeatureNet on the V views of the sample (mvsnet.py:146)."""
