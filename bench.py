@@ -45,7 +45,7 @@ BF16_MFMA_PEAK_TF = 2500.0   # v_mfma_f32_16x16x32_bf16, dense
 SPLIT_BF16X6_PEAK_TF = BF16_MFMA_PEAK_TF / 6.0
 # the stages that run on the split-operand kernels (conv_bf16x6.hip: conv0; conv_split.hip: the stride-1 3x3(x3) layers
 # with 16 / 32 / 64 channels; deconv_split.hip: the transposed layers)
-SPLIT_STAGES = {"costreg.conv0", "costreg.conv2", "costreg.conv4", "costreg.conv6", "costreg.conv7", "costreg.conv9",
+SPLIT_STAGES = {"costreg.conv0", "costreg.conv1", "costreg.conv2", "costreg.conv4", "costreg.conv6", "costreg.conv7", "costreg.conv9",
                 "costreg.conv11", "feature.conv2", "feature.conv3", "feature.conv4", "feature.conv5", "feature.conv6",
                 "feature.feature"}
 

@@ -361,13 +361,16 @@ int mvs_conv2d_f32(const float *in, const float *packed_weight, const float *sca
 /* FeatureNet's first two layers in one kernel: conv0 (3 -> 8, 3x3) + BN + ReLU + conv1 (8 -> 8, 3x3) + BN + ReLU
  * (MVSNet/models/mvsnet.py:11-12,33-34 `self.conv0 = ConvBnReLU(3, 8, 3, 1, 1)`, `self.conv1 = ConvBnReLU(8, 8, 3, 1, 1)`;
  * CasMVSNet/models/module.py:318-321 opens with the same pair).  conv0's 8-channel full-resolution output never
- * reaches HBM.  img: the reference's planar [N,3,H,W] batch; weight0: PyTorch layout (8,3,3,3); packed1: conv1's
- * weight from mvs_conv2d_pack_weights_f32(w1, 8, 8, 3, 1, ...); scale / shift (or NULL): folded BatchNorm(eval)
- * affines of the two layers; out: [N,H,W,8] channels-last.  MVS_EUNSUPPORTED unless
- * mvs_feature_head_supported(H, W) (W % 4 == 0). */
+ * reaches HBM: conv0 runs on the vector ALU into LDS, conv1 on the BF16 matrix pipe with exactly split fp32 operands
+ * (mvs_amd/csrc/feature_head.hip).  img: the reference's planar [N,3,H,W] batch; weight0: PyTorch layout (8,3,3,3);
+ * packed1: mvs_feature_head_pack_weights_f32 of conv1's PyTorch-layout (8,8,3,3) weight
+ * (mvs_feature_head_packed_bytes() bytes); scale / shift (or NULL): folded BatchNorm(eval) affines of the two
+ * layers; out: [N,H,W,8] channels-last.  MVS_EUNSUPPORTED unless mvs_feature_head_supported(H, W) (W % 4 == 0). */
 int mvs_feature_head_supported(int H, int W);
+size_t mvs_feature_head_packed_bytes(void);
+int mvs_feature_head_pack_weights_f32(const float *weight1, void *packed, void *stream);
 int mvs_feature_head_f32(const float *img, const float *weight0, const float *scale0, const float *shift0,
-                         const float *packed1, const float *scale1, const float *shift1, int N, int H, int W,
+                         const void *packed1, const float *scale1, const float *shift1, int N, int H, int W,
                          float *out, void *stream);
 int64_t mvs_conv2d_packed_weight_floats(int Cin, int Cout, int ksize, int stride);
 /* weight: PyTorch layout (Cout,Cin,k,k) -> MFMA A-fragment order. */

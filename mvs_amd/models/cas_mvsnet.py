@@ -99,7 +99,7 @@ class FeatureNet(nn.Module):
                         shift=None if m.bias is None else m.bias.detach().float().contiguous(), relu=False)
 
         with torch.no_grad():
-            P = {"conv0": [cbr(self.conv0[0], 1), cbr(self.conv0[1], 1)],
+            P = {"conv0": [cbr(self.conv0[0], 1), cbr(self.conv0[1], 1)],   # ("head": see forward_hip)
                  "conv1": [cbr(self.conv1[0], 2), cbr(self.conv1[1], 1), cbr(self.conv1[2], 1)],
                  "conv2": [cbr(self.conv2[0], 2), cbr(self.conv2[1], 1), cbr(self.conv2[2], 1)],
                  "out1": plain(self.out1), "inner1": plain(self.inner1), "inner2": plain(self.inner2),
@@ -130,7 +130,9 @@ class FeatureNet(nn.Module):
         h0, h1 = P["conv0"]
         if (ops.feature_head_enabled() and (h0["cin"], h0["cout"], h1["cout"]) == (3, 8, 8)
                 and ops.feature_head_supported(imgs_nchw.shape[2], imgs_nchw.shape[3])):
-            c0 = ops.feature_head(imgs_nchw, h0["weight"], h0["scale"], h0["shift"], h1["packed"], h1["scale"],
+            if "head" not in h1:
+                h1["head"] = ops.pack_feature_head_weight(h1["weight"])
+            c0 = ops.feature_head(imgs_nchw, h0["weight"], h0["scale"], h0["shift"], h1["head"], h1["scale"],
                                   h1["shift"])      # the two 3x3 layers of conv0 in one kernel
         else:
             c0 = run(run(imgs_nchw, h0, planar=True), h1)

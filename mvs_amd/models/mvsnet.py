@@ -68,7 +68,8 @@ class FeatureNet(nn.Module):
                 shift = (m.bn.bias - m.bn.running_mean * scale).float().contiguous()
                 P.append(dict(name=name, cin=w.shape[1], cout=w.shape[0], k=w.shape[2],
                               stride=stride, packed=ops.pack_conv2d_weight(w, stride, split=True), scale=scale,
-                              shift=shift, relu=True, weight=w if name == "conv0" else None))
+                              shift=shift, relu=True, weight=w if name == "conv0" else None,
+                              head=ops.pack_feature_head_weight(w) if name == "conv1" else None))
             w = self.feature.weight.detach().float().contiguous()
             P.append(dict(name="feature", cin=w.shape[1], cout=w.shape[0], k=w.shape[2], stride=1,
                           packed=ops.pack_conv2d_weight(w, 1, split=True), scale=None,
@@ -111,7 +112,7 @@ class FeatureNet(nn.Module):
         first = 0
         if ops.feature_head_enabled() and ops.feature_head_supported(x.shape[2], x.shape[3]):
             with ops.stage("feature.head"):   # conv0 + conv1 in one kernel
-                x = ops.feature_head(x, P[0]["weight"], P[0]["scale"], P[0]["shift"], P[1]["packed"], P[1]["scale"],
+                x = ops.feature_head(x, P[0]["weight"], P[0]["scale"], P[0]["shift"], P[1]["head"], P[1]["scale"],
                                      P[1]["shift"])
             first = 2
         for i, p in enumerate(P):

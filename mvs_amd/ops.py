@@ -1052,10 +1052,20 @@ def feature_head_supported(H, W):
     return bool(_lib.load().mvs_feature_head_supported(int(H), int(W)))
 
 
+def pack_feature_head_weight(w1):
+    """conv1's (8, 8, 3, 3) weight -> the bf16 hi/mid/lo A fragments of feature_head (opaque bytes)."""
+    w1 = _f32c(w1)
+    if tuple(w1.shape) != (8, 8, 3, 3):
+        raise MvsHipError(f"pack_feature_head_weight: conv1 weight {tuple(w1.shape)} is not (8, 8, 3, 3)")
+    packed = torch.empty(_lib.load().mvs_feature_head_packed_bytes() // 4, device=w1.device, dtype=torch.float32)
+    check(_lib.load().mvs_feature_head_pack_weights_f32(ptr(w1), ptr(packed), stream()), "mvs_feature_head_pack_weights_f32")
+    return packed
+
+
 def feature_head(img_nchw, w0, scale0, shift0, packed1, scale1, shift1):
     """FeatureNet's conv0 + BN + ReLU + conv1 + BN + ReLU (mvsnet.py:11-12) in one kernel: the [N,3,H,W] image batch ->
-    [N,H,W,8] channels-last.  w0: conv0's weight in PyTorch layout (8,3,3,3); packed1: conv1's weight from
-    pack_conv2d_weight(w1, 1); scale / shift: the folded BatchNorm affines."""
+    [N,H,W,8] channels-last.  w0: conv0's weight in PyTorch layout (8,3,3,3); packed1: pack_feature_head_weight(w1);
+    scale / shift: the folded BatchNorm affines."""
     x = _f32c(img_nchw)
     N, C, H, W = x.shape
     if C != 3 or tuple(w0.shape) != (8, 3, 3, 3):

@@ -590,7 +590,7 @@ def test_mvsnet_forward_with_precomputed_features_is_bit_equal(dev):
         model(imgs, proj, dv, features=feats[:V - 1].unsqueeze(0))
 
 
-@pytest.mark.parametrize("N,H,W", [(1, 32, 32), (2, 70, 100), (1, 33, 36), (3, 17, 8), (1, 130, 164)])
+@pytest.mark.parametrize("N,H,W", [(1, 32, 32), (2, 70, 100), (1, 33, 36), (3, 17, 8), (1, 130, 164), (1, 16, 64), (2, 15, 28)])
 def test_feature_head_vs_fp64_and_two_launches(dev, N, H, W):
     """mvs_feature_head_f32 (FeatureNet's conv0 + BN + ReLU + conv1 + BN + ReLU in one kernel, mvsnet.py:11-12):
     against the fp64 chain, and against the same two layers as two launches of mvs_conv2d_f32; whole and partial
@@ -609,7 +609,7 @@ def test_feature_head_vs_fp64_and_two_launches(dev, N, H, W):
     assert ops.feature_head_supported(H, W)
     pk0, pk1 = ops.pack_conv2d_weight(w0.to(dev), 1), ops.pack_conv2d_weight(w1.to(dev), 1)
     d = lambda t: t.to(dev)
-    got = ops.feature_head(d(x), d(w0), d(s0), d(h0), pk1, d(s1), d(h1))
+    got = ops.feature_head(d(x), d(w0), d(s0), d(h0), ops.pack_feature_head_weight(d(w1)), d(s1), d(h1))
     two = ops.conv2d(d(x), pk0, 3, 8, 3, 1, d(s0), d(h0), True, planar=True)
     two = ops.conv2d(two, pk1, 8, 8, 3, 1, d(s1), d(h1), True)
     tol = 3e-6 * max(1.0, ref.abs().max().item())
