@@ -235,6 +235,9 @@ __global__ __launch_bounds__(kSplitKernelThreads) void conv3d_c8_bf16x6_kernel(C
     }
 
     const int z0 = wv >> 1, y0 = (wv & 1) * 2;          // the wave's output rows: (z0, y0) and (z0, y0 + 1)
+    // epilogue: this lane's x inside a tile and its element offset from the tile's first output (row r adds Wo * 8)
+    const int ex = 2 * n + (kq >> 1);
+    const int eoff = ((z0 * a.Ho + y0) * a.Wo + ex) * 8 + (kq & 1) * 4;
     // this lane's B voxel of halo row (z0, y0): x = 2n + kq
     const unsigned aB = lds_base + (unsigned)(S_OFF + ((z0 * YT + y0) * kRowVox + n + (kq >> 1) + (kq & 1) * kOddBase) * 16);
 
@@ -328,31 +331,36 @@ __global__ __launch_bounds__(kSplitKernelThreads) void conv3d_c8_bf16x6_kernel(C
             });
             wsel ^= 1;
         }
-        // ---- epilogue of the group: BN affine, ReLU, one 16-byte store per lane and row (as the fp32 kernel's MODE 2)
+        // ---- epilogue of the group: BN affine, ReLU, one 16-byte store per lane and row (as the fp32 kernel's MODE 2).
+        // The matrix pipe idles here and a wave issues an instruction every ~7 cycles: the tile's base address is scalar
+        // arithmetic, a lane adds a precomputed in-tile offset.
         static_for<0, T>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             if (j >= nvalid) return;
-            const TileIdx cur = decode_ordered_tile(a, t0 + (k0 + j) * t_step);
-            const int ox = cur.tx * 32 + 2 * n + (kq >> 1);
+            const TileIdx cur = decode_ordered_tile(a, __builtin_amdgcn_readfirstlane(t0 + (k0 + j) * t_step));
+            const int tb = __builtin_amdgcn_readfirstlane(cur.b), oz0 = __builtin_amdgcn_readfirstlane(cur.tz) * 4;
+            const int oy0 = __builtin_amdgcn_readfirstlane(cur.ty) * 4, ox0 = __builtin_amdgcn_readfirstlane(cur.tx) * 32;
+            const int64_t base = ((((int64_t)tb * a.Do + oz0) * a.Ho + oy0) * a.Wo + ox0) * 8;
+            float *const ob = a.out + base;
+            const float *const rp = (a.residual && !(ABL & 128)) ? a.residual + base : nullptr;
+            const bool xz_in = oz0 + z0 < a.Do && ox0 + ex < a.Wo;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                const int oz = cur.tz * 4 + z0, oy = cur.ty * 4 + y0 + r;
                 f32x4 v = acc[j][r];
                 acc[j][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo) continue;
-                const int c0 = (kq & 1) * 4;
+                if (!xz_in || oy0 + y0 + r >= a.Ho) continue;
                 v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
                 v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
                 if (a.relu == 1) {
                     v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
                     v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
                 }
-                const int64_t o = ((((int64_t)cur.b * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * 8 + c0;
-                if (a.residual && !(ABL & 128)) {
-                    const float4 rs = *reinterpret_cast<const float4 *>(a.residual + o);
+                const int o = eoff + r * a.Wo * 8;
+                if (rp) {
+                    const float4 rs = *reinterpret_cast<const float4 *>(rp + o);
                     v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
                 }
-                *reinterpret_cast<float4 *>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4 *>(ob + o) = make_float4(v[0], v[1], v[2], v[3]);
             }
         });
     }
