@@ -1307,9 +1307,13 @@ extern "C" int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *s
 
 // Shape of the persistent kernel's workgroup: waves (= depth planes per tile) and channel quads
 // per stage.  tuning: MVS_SWEEP_PERSIST = "<waves>[,<flags>[,<quads>]]", 0 = always the per-tile kernels
-static int persist_waves(int *flags, int *quads) {
+// Without the variable: 16 waves for D >= 96, the per-tile kernels below that.  What decides is the depth range of a
+// 16-plane tile against the baselines -- its footprint boxes must fit the workgroup's LDS share or its waves go to the cold
+// kernel -- and the host cannot see that; few planes go with coarse intervals in the reference's configurations (CasMVSNet's
+// first stage: 48 planes at 4x the interval, where the per-tile kernel takes 0.66 ms and this one 1.71).
+static int persist_waves(int *flags, int *quads, int D) {
     const char *pe = getenv("MVS_SWEEP_PERSIST");
-    int nw = 16;
+    int nw = D >= 96 ? 16 : 0;
     *flags = 0;
     *quads = 2;
     if (pe) {
@@ -1330,7 +1334,7 @@ extern "C" size_t mvs_costvol_variance_workspace_bytes(int depth_mode, int B, in
         H <= 1 || W <= 1)
         return 0;
     int flags, quads;
-    const int nw = persist_waves(&flags, &quads);
+    const int nw = persist_waves(&flags, &quads, D);
     if (nw <= 0) return 0;
     return variance_persist_workspace_bytes(make_params(B, V, C, D, H, W, depth_mode, 0, 0), nw);
 }
@@ -1347,7 +1351,7 @@ extern "C" int mvs_costvol_variance_fwd_ws_f32(const float *ref_fea, const float
         W > 1 && depth_mode == 0 && (fea_layout == MVS_LAYOUT_C16 || c4 || fea_layout == MVS_LAYOUT_NHWC) &&
         (out_layout == MVS_LAYOUT_C8 || out_layout == MVS_LAYOUT_NHWC)) {
         int tune, quads;
-        const int nw = persist_waves(&tune, &quads);
+        const int nw = persist_waves(&tune, &quads, D);
         if (nw > 0) {
             const SweepParams p = make_params(B, V, C, D, H, W, depth_mode, align_corners, alias_quirk);
             const int rc = launch_variance_persist(ref_fea, src_feas, rot_trans, depth_values, p, out_var,

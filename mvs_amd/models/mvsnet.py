@@ -384,10 +384,13 @@ class MVSNet(nn.Module):
             c4 = use_lds and ops.variance_persistent_supported(depth_values, B, V, C, h, w)
             f4 = None
             if features is not None:
-                if not c4 or tuple(features.shape) != (B, V, C // 4, h, w, 4):
+                if tuple(features.shape) != (B, V, C // 4, h, w, 4):
                     raise ops.MvsHipError(f"forward: features {tuple(features.shape)} do not fit this sample "
-                                          f"({(B, V, C // 4, h, w, 4)}, shared depth planes)")
-                f4 = features.reshape(B * V, C // 4, h, w, 4)
+                                          f"({(B, V, C // 4, h, w, 4)})")
+                if c4:
+                    f4 = features.reshape(B * V, C // 4, h, w, 4)
+                else:      # a sweep kernel that takes other blockings (few depth planes, per-pixel hypotheses)
+                    f = features.permute(0, 1, 3, 4, 2, 5).reshape(B * V, h, w, C)
             elif self.feature_impl == "hip" and self.feature.hip_supported():
                 if c4 and ops.conv2d_persistent_enabled():
                     f4 = self.feature.forward_hip(flat, out_c4=True)     # [B*V,8,h,w,4]

@@ -215,10 +215,11 @@ def test_variance_persistent_kernel_bit_equal_to_per_tile_kernel(dev, case, monk
 
 
 @pytest.mark.parametrize("name", ["g6_e2e_64x96_v3_d8", "g3_e2e_64x64_v5_d8_b2"])
-def test_variance_persistent_golden_and_fast_mode(dev, name):
+def test_variance_persistent_golden_and_fast_mode(dev, name, monkeypatch):
     """The persistent kernel (4-channel blocked features) against the reference's own variance
     volume: exact mode to the bit fraction the per-tile kernels reach, fast mode within 2e-6."""
     from mvs_amd import ops
+    monkeypatch.setenv("MVS_SWEEP_PERSIST", "16")     # (the goldens have 8 planes: by default the per-tile kernels' size)
     g = load_golden(name)
     f = g["features"]
     V = f.shape[1]
@@ -563,9 +564,12 @@ def test_conv_split_5x5_stride2_vs_fp64(dev, cin, cout, shape):
     assert torch.equal(via, got)
 
 
-def test_mvsnet_forward_with_precomputed_features_is_bit_equal(dev):
+@pytest.mark.parametrize("persist", ["16", "0"])
+def test_mvsnet_forward_with_precomputed_features_is_bit_equal(dev, persist, monkeypatch):
     """MVSNet.extract_features (FeatureNet once per image, any batching) + forward(features=...) gives the bits of
-    the plain forward, which runs FeatureNet on the V views of the sample (mvsnet.py:146)."""
+    the plain forward, which runs FeatureNet on the V views of the sample (mvsnet.py:146) -- with the persistent sweep
+    kernel (4-channel blocked maps as they come) and with the per-tile kernels (re-blocked)."""
+    monkeypatch.setenv("MVS_SWEEP_PERSIST", persist)
     from mvs_amd import synth
     from mvs_amd.models import MVSNet
     torch.manual_seed(3)
