@@ -19,14 +19,15 @@ namespace mvs {
 // read ONCE into registers and the three passes run from there (the memory version re-read it
 // per pass: 276 MB of HBM-side traffic for a 92 MB volume, rocprofv3 FETCH_SIZE); same
 // arithmetic, same results.
-template <int REG>
-__global__ __launch_bounds__(REG ? 512 : 256) void softmax_regress_conf_kernel(
+template <int REG, int NPART = (REG ? 8 : 4)>
+__global__ __launch_bounds__(NPART * 64) void softmax_regress_conf_kernel(
     const float *__restrict__ cost, const float *__restrict__ depth, int depth_mode,
     int clamp_idx, int B, int D, int64_t plane, float *__restrict__ out_depth,
     float *__restrict__ out_conf, float *__restrict__ out_prob) {
     // REG > 0: eight depth slices of up to REG planes each, held in registers (REG = 8, 16, 24, 32: the launcher takes
     // the smallest that covers D / 8 -- a slice shorter than its registers would still run every unrolled step)
-    constexpr int NP = REG ? 8 : 4, NR = REG ? REG : 1;
+    // (NPART = 1: up to 32 planes -- the cascade's later stages at full resolution -- a thread takes its whole column)
+    constexpr int NP = NPART, NR = REG ? REG : 1;
     __shared__ float s_f[NP][64];
     __shared__ double s_d[2][NP][64];
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(REG ? 512 : 256) void softmax_regress_conf_kernel(
     }
     s_f[part][lane] = m;
     __syncthreads();
-    m = fmaxf(fmaxf(s_f[0][lane], s_f[1][lane]), fmaxf(s_f[2][lane], s_f[3][lane]));
+    if constexpr (NP >= 4) m = fmaxf(fmaxf(s_f[0][lane], s_f[1][lane]), fmaxf(s_f[2][lane], s_f[3][lane]));
     if constexpr (NP == 8) m = fmaxf(m, fmaxf(fmaxf(s_f[4][lane], s_f[5][lane]), fmaxf(s_f[6][lane], s_f[7][lane])));
     __syncthreads();
     // normaliser: the fp32 exponentials are summed in fp64 and rounded once, i.e. the
@@ -80,7 +81,8 @@ __global__ __launch_bounds__(REG ? 512 : 256) void softmax_regress_conf_kernel(
     }
     s_d[0][part][lane] = psum;
     __syncthreads();
-    double sum_d = ((s_d[0][0][lane] + s_d[0][1][lane]) + s_d[0][2][lane]) + s_d[0][3][lane];
+    double sum_d = psum;
+    if constexpr (NP >= 4) sum_d = ((s_d[0][0][lane] + s_d[0][1][lane]) + s_d[0][2][lane]) + s_d[0][3][lane];
     if constexpr (NP == 8) sum_d += ((s_d[0][4][lane] + s_d[0][5][lane]) + s_d[0][6][lane]) + s_d[0][7][lane];
     const float sum = (float)sum_d;
     __syncthreads();
@@ -120,8 +122,10 @@ __global__ __launch_bounds__(REG ? 512 : 256) void softmax_regress_conf_kernel(
     s_d[1][part][lane] = fidx;
     __syncthreads();
     if (part != 0 || !live) return;
-    dep = ((s_d[0][0][lane] + s_d[0][1][lane]) + s_d[0][2][lane]) + s_d[0][3][lane];
-    fidx = ((s_d[1][0][lane] + s_d[1][1][lane]) + s_d[1][2][lane]) + s_d[1][3][lane];
+    if constexpr (NP >= 4) {
+        dep = ((s_d[0][0][lane] + s_d[0][1][lane]) + s_d[0][2][lane]) + s_d[0][3][lane];
+        fidx = ((s_d[1][0][lane] + s_d[1][1][lane]) + s_d[1][2][lane]) + s_d[1][3][lane];
+    }
     if constexpr (NP == 8) {
         dep += ((s_d[0][4][lane] + s_d[0][5][lane]) + s_d[0][6][lane]) + s_d[0][7][lane];
         fidx += ((s_d[1][4][lane] + s_d[1][5][lane]) + s_d[1][6][lane]) + s_d[1][7][lane];
@@ -183,14 +187,18 @@ extern "C" int mvs_softmax_regress_conf_f32(const float *cost, const float *dept
     const int64_t n = (int64_t)B * plane;
     unsigned grid = (unsigned)((n + 63) / 64);
 #define MVS_SM_LAUNCH(R, T)                                                                                     \
-    hipLaunchKernelGGL(softmax_regress_conf_kernel<R>, dim3(grid), dim3(T), 0, as_stream(stream), cost, depth_values,   \
+    hipLaunchKernelGGL((softmax_regress_conf_kernel<R, (T) / 64>), dim3(grid), dim3(T), 0, as_stream(stream), cost, depth_values,   \
                        depth_mode, clamp_idx, B, D, plane, out_depth, out_conf, out_prob)
     const int per = (D + 7) / 8;   // planes of the longest of eight slices
-    if (per <= 8) MVS_SM_LAUNCH(8, 512);
+    if (D <= 8) MVS_SM_LAUNCH(8, 64);           // a thread per pixel takes the whole column
+    else if (D <= 16) MVS_SM_LAUNCH(16, 64);
+    else if (D <= 32) MVS_SM_LAUNCH(32, 64);
+    else if (per <= 8) MVS_SM_LAUNCH(8, 512);
     else if (per <= 16) MVS_SM_LAUNCH(16, 512);
     else if (per <= 24) MVS_SM_LAUNCH(24, 512);
     else if (per <= 32) MVS_SM_LAUNCH(32, 512);
-    else MVS_SM_LAUNCH(0, 256);
+    else hipLaunchKernelGGL((softmax_regress_conf_kernel<0, 4>), dim3(grid), dim3(256), 0, as_stream(stream), cost, depth_values,
+                            depth_mode, clamp_idx, B, D, plane, out_depth, out_conf, out_prob);
 #undef MVS_SM_LAUNCH
     return check_launch("mvs_softmax_regress_conf_f32");
 }
