@@ -58,7 +58,7 @@ def main():
         groups = {"feature_pyramid_2d_convs": 0.0, "costreg_3d_convs": 0.0, "sweep_variance": 0.0, "other": 0.0}
         for e in rows:
             is2d = ("conv2d" in e.key or ("PersistCfg<" in e.key and ", 1, 32, 1, 3>" in e.key)   # one-plane-deep persistent tiles
-                    or ("conv_split_kernel" in e.key and ", 1, 1>" in e.key))                    # SplitCfg<Cin, Cout, KD = 1, S = 1>
+                    or ("conv_split_kernel" in e.key and ", 1, 1, 3>" in e.key))                 # SplitCfg<Cin, Cout, KD = 1, S = 1, KH = 3>
             is3d = "conv3d" in e.key or "conv_split_kernel" in e.key or "deconv_split_kernel" in e.key
             k = ("feature_pyramid_2d_convs" if is2d else "costreg_3d_convs" if is3d
                  else "sweep_variance" if "variance" in e.key else "other")
