@@ -620,6 +620,11 @@ def test_feature_head_vs_fp64_and_two_launches(dev, N, H, W):
     assert (got.cpu().double() - ref).abs().max().item() < tol
     assert (two.cpu().double() - ref).abs().max().item() < tol
     assert not ops.feature_head_supported(H, W + 2)
+    if W > 4:      # a width the kernel does not take is an error with the library's text, not a silent other path
+        with pytest.raises(Exception, match="W % 4"):
+            ops.feature_head(d(x[..., :W - 2].contiguous()), d(w0), d(s0), d(h0), ops.pack_feature_head_weight(d(w1)), d(s1), d(h1))
+    with pytest.raises(Exception, match="not the 3 -> 8 head"):
+        ops.feature_head(d(x[:, :2].contiguous()), d(w0), d(s0), d(h0), ops.pack_feature_head_weight(d(w1)), d(s1), d(h1))
 
 
 @pytest.mark.parametrize("cin,cout,shape", [(8, 16, (1, 5, 9, 21)), (8, 16, (2, 8, 16, 48)), (16, 32, (1, 7, 10, 33)),
