@@ -1486,3 +1486,67 @@ def test_cvp_refine_hypotheses_reference_golden(dev):
     got = ops.cvp_refine_hypotheses(G(g["cvp_depth_up"], dev), G(g["cvp_K_ref"], dev), G(g["cvp_K_src"][:, 0], dev),
                                     G(g["cvp_ref_ex"], dev), G(g["cvp_src_ex"][:, 0], dev)).cpu().numpy()
     np.testing.assert_allclose(got, g["cvp_hypos"], atol=2e-4, rtol=0)
+
+
+def test_fuzz_round2_kernels_against_fp64(dev):
+    """Seeded random shapes through the kernels added late in round 2 -- the z-marching `prob` kernel (depth segments,
+    ring wrap-around, partial tiles, batch > 1), the register-sliced softmax / regression kernel (every slice width,
+    one and eight slices, per-pixel hypotheses, index clamp), the fused FeatureNet head and the 5x5 stride-2 split
+    layers -- each against an fp64 evaluation of the reference's formula."""
+    from mvs_amd import ops
+    F = torch.nn.functional
+    rng = np.random.default_rng(20260928)
+    g = torch.Generator().manual_seed(7)
+    d = lambda t: t.to(dev)
+    for _ in range(14):                                   # prob: Conv3d(8, 1, 3, padding=1) (+ affine, ReLU, skip)
+        B, D, H, W = int(rng.integers(1, 3)), int(rng.integers(1, 41)), int(rng.integers(3, 60)), int(rng.integers(3, 100))
+        x = torch.randn(B, 8, D, H, W, generator=g)
+        w = torch.randn(1, 8, 3, 3, 3, generator=g) * 0.2
+        sc, sh = torch.rand(1, generator=g) + 0.5, torch.randn(1, generator=g)
+        relu, use_res = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        res = torch.randn(B, D, H, W, 1, generator=g) if use_res else None
+        ref = F.conv3d(x.double(), w.double(), padding=1) * sc.double() + sh.double()
+        ref = (torch.relu(ref) if relu else ref).permute(0, 2, 3, 4, 1)
+        if use_res:
+            ref = ref + res.double()
+        got = ops.conv3d(d(x).permute(0, 2, 3, 4, 1).contiguous(), d(w), d(sc), d(sh), d(res) if use_res else None, relu, False, 1,
+                         channels_last=True, packed=ops.pack_conv3d_weight(d(w), False, 1), impl=ops.IMPL_MFMA)
+        assert (got.cpu().double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), (B, D, H, W)
+    for _ in range(16):                                   # softmax over depth, expectation, 4-plane confidence
+        B, D = int(rng.integers(1, 3)), int(rng.choice([1, 2, 5, 8, 9, 16, 17, 31, 32, 33, 48, 64, 100, 192, 256, 300]))
+        H, W = int(rng.integers(2, 40)), int(rng.integers(2, 70))
+        per_pixel, clamp = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        cost = torch.randn(B, D, H, W, generator=g) * 3
+        dv = (torch.rand(B, D, H, W, generator=g) if per_pixel else torch.rand(B, D, generator=g)) * 500 + 400
+        p = torch.softmax(cost.double(), 1)
+        dvf = dv.double() if per_pixel else dv.double().view(B, D, 1, 1)
+        ref_depth = (p * dvf).sum(1)
+        depth, conf, _ = ops.softmax_regress_conf(d(cost), d(dv), clamp_idx=clamp)
+        assert (depth.cpu().double() - ref_depth).abs().max().item() < 2e-3, (B, D, H, W)       # fp32 products of ~900 mm
+        idx = (p.float() * torch.arange(D, dtype=torch.float32).view(1, D, 1, 1)).sum(1).long()
+        if clamp:
+            idx = idx.clamp(0, D - 1)
+        pad = F.pad(p, (0, 0, 0, 0, 1, 2))                                                  # planes idx-1 .. idx+2
+        ref_conf = sum(pad.gather(1, (idx + k).clamp(0, D + 2).unsqueeze(1)).squeeze(1) for k in range(4))
+        near = (conf.cpu().double() - ref_conf).abs() < 1e-5
+        assert near.float().mean().item() > 0.98, (B, D, H, W)     # (an index at a rounding boundary may differ by one plane)
+    for _ in range(8):                                    # FeatureNet head
+        N, H, W = int(rng.integers(1, 4)), int(rng.integers(3, 90)), 4 * int(rng.integers(1, 40))
+        x = torch.rand(N, 3, H, W, generator=g)
+        w0, w1 = torch.randn(8, 3, 3, 3, generator=g) / 27 ** 0.5, torch.randn(8, 8, 3, 3, generator=g) / 72 ** 0.5
+        s0, h0, s1, h1 = (torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.1,
+                          torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.1)
+        v = lambda t: t.double().view(1, 8, 1, 1)
+        ref = torch.relu(F.conv2d(x.double(), w0.double(), padding=1) * v(s0) + v(h0))
+        ref = torch.relu(F.conv2d(ref, w1.double(), padding=1) * v(s1) + v(h1)).permute(0, 2, 3, 1)
+        got = ops.feature_head(d(x), d(w0), d(s0), d(h0), ops.pack_feature_head_weight(d(w1)), d(s1), d(h1))
+        assert (got.cpu().double() - ref).abs().max().item() < 3e-6 * max(1.0, ref.abs().max().item()), (N, H, W)
+    for _ in range(8):                                    # 5x5 stride-2 layers
+        cin, cout = (8, 16) if rng.integers(0, 2) else (16, 32)
+        N, H, W = int(rng.integers(1, 4)), int(rng.integers(3, 80)), int(rng.integers(3, 90))
+        x = torch.randn(N, cin, H, W, generator=g)
+        w = torch.randn(cout, cin, 5, 5, generator=g) / (25 * cin) ** 0.5
+        ref = F.conv2d(x.double(), w.double(), stride=2, padding=2).permute(0, 2, 3, 1)
+        got = ops.conv_split(d(x).permute(0, 2, 3, 1).contiguous(), ops.pack_conv_weight_split(d(w), 2), cout, None, None, None, 0,
+                             kd=1, stride=2)
+        assert (got.cpu().double() - ref).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item()), (cin, N, H, W)
