@@ -372,6 +372,19 @@ int mvs_feature_head_pack_weights_f32(const float *weight1, void *packed, void *
 int mvs_feature_head_f32(const float *img, const float *weight0, const float *scale0, const float *shift0,
                          const void *packed1, const float *scale1, const float *shift1, int N, int H, int W,
                          float *out, void *stream);
+/* The full-resolution end of CasMVSNet's FPN in one kernel (CasMVSNet/models/module.py:396-398,
+ * `intra_feat = F.interpolate(intra_feat, scale_factor=2, mode="nearest") + self.inner2(conv0)` followed by
+ * `out = self.out3(intra_feat)`, final_chs = 32, base_channels = 8): the 32-channel full-resolution map stays in LDS
+ * (mvs_amd/csrc/fpn_tail.hip).  fine: conv0's output [N,H,W,8]; coarse: the half-resolution map [N,H/2,W/2,32];
+ * weight_inner / bias_inner: inner2 in PyTorch layout (32,8,1,1) / (32) (bias or NULL); packed_out:
+ * mvs_fpn_tail_pack_weights_f32 of out3's PyTorch-layout (8,32,3,3) weight (mvs_fpn_tail_packed_bytes() bytes);
+ * bias_out (8) or NULL; out [N,H,W,8]; all channels-last.  MVS_EUNSUPPORTED unless mvs_fpn_tail_supported(H, W)
+ * (even H, W). */
+int mvs_fpn_tail_supported(int H, int W);
+size_t mvs_fpn_tail_packed_bytes(void);
+int mvs_fpn_tail_pack_weights_f32(const float *weight_out, void *packed, void *stream);
+int mvs_fpn_tail_f32(const float *fine, const float *coarse, const float *weight_inner, const float *bias_inner,
+                     const void *packed_out, const float *bias_out, int N, int H, int W, float *out, void *stream);
 int64_t mvs_conv2d_packed_weight_floats(int Cin, int Cout, int ksize, int stride);
 /* weight: PyTorch layout (Cout,Cin,k,k) -> MFMA A-fragment order. */
 int mvs_conv2d_pack_weights_f32(const float *weight, int Cin, int Cout, int ksize, int stride,

@@ -94,7 +94,7 @@ class FeatureNet(nn.Module):
 
         def plain(m):
             w = m.weight.detach().float().contiguous()
-            return dict(cin=w.shape[1], cout=w.shape[0], k=w.shape[2], stride=1,
+            return dict(cin=w.shape[1], cout=w.shape[0], k=w.shape[2], stride=1, weight=w,
                         packed=ops.pack_conv2d_weight(w, 1, split=True), scale=None,
                         shift=None if m.bias is None else m.bias.detach().float().contiguous(), relu=False)
 
@@ -145,8 +145,16 @@ class FeatureNet(nn.Module):
         out = {"stage1": run(top, P["out1"])}
         top = lateral(top, c1, P["inner1"])
         out["stage2"] = run(top, P["out2"])
-        top = lateral(top, c0, P["inner2"])
-        out["stage3"] = run(top, P["out3"])
+        i2, o3 = P["inner2"], P["out3"]
+        if ((i2["cin"], i2["cout"], o3["cout"]) == (8, 32, 8) and top.shape[1] * 2 == c0.shape[1]
+                and top.shape[2] * 2 == c0.shape[2] and ops.fpn_tail_supported(c0.shape[1], c0.shape[2])):
+            if "tail" not in o3:
+                o3["tail"] = ops.pack_fpn_tail_weight(o3["weight"])
+            # the lateral 1x1 layer, the top-down add and out3 in one kernel: the 32-channel full-resolution map stays in LDS
+            out["stage3"] = ops.fpn_tail(c0, top, i2["weight"], i2["shift"], o3["tail"], o3["shift"])
+        else:
+            top = lateral(top, c0, i2)
+            out["stage3"] = run(top, o3)
         return out
 
 

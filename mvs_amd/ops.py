@@ -1042,6 +1042,34 @@ def bn_relu_cl(x, bn, relu=True, skip=None):
                            bn.momentum, bn.eps, relu)
 
 
+def fpn_tail_supported(H, W):
+    import os
+    return os.environ.get("MVS_FPN_TAIL", "1") != "0" and bool(_lib.load().mvs_fpn_tail_supported(int(H), int(W)))
+
+
+def pack_fpn_tail_weight(w_out):
+    """out3's (8, 32, 3, 3) weight -> the bf16 hi/mid/lo A fragments of fpn_tail (opaque bytes)."""
+    w_out = _f32c(w_out)
+    if tuple(w_out.shape) != (8, 32, 3, 3):
+        raise MvsHipError(f"pack_fpn_tail_weight: out3 weight {tuple(w_out.shape)} is not (8, 32, 3, 3)")
+    packed = torch.empty(_lib.load().mvs_fpn_tail_packed_bytes() // 4, device=w_out.device, dtype=torch.float32)
+    check(_lib.load().mvs_fpn_tail_pack_weights_f32(ptr(w_out), ptr(packed), stream()), "mvs_fpn_tail_pack_weights_f32")
+    return packed
+
+
+def fpn_tail(fine, coarse, w_inner, b_inner, packed_out, b_out=None):
+    """out3(nearest_x2(coarse) + inner2(fine)) of CasMVSNet's FPN (module.py:396-398) in one kernel: fine [N,H,W,8],
+    coarse [N,H/2,W/2,32] channels-last -> [N,H,W,8]."""
+    fine, coarse = _f32c(fine), _f32c(coarse)
+    N, H, W, C = fine.shape
+    if C != 8 or tuple(coarse.shape) != (N, H // 2, W // 2, 32) or w_inner.numel() != 256:
+        raise MvsHipError(f"fpn_tail: fine {tuple(fine.shape)} / coarse {tuple(coarse.shape)} are not the 8- and 32-channel maps")
+    out = torch.empty((N, H, W, 8), device=fine.device, dtype=torch.float32)
+    check(_lib.load().mvs_fpn_tail_f32(ptr(fine), ptr(coarse), ptr(_f32c(w_inner)), ptr(b_inner), ptr(packed_out), ptr(b_out),
+                                       N, H, W, ptr(out), stream()), "mvs_fpn_tail_f32")
+    return out
+
+
 def feature_head_enabled():
     """False when MVS_FEATURE_HEAD=0 keeps FeatureNet's first two layers as two launches (A/B switch)."""
     import os

@@ -1550,3 +1550,28 @@ def test_fuzz_round2_kernels_against_fp64(dev):
         got = ops.conv_split(d(x).permute(0, 2, 3, 1).contiguous(), ops.pack_conv_weight_split(d(w), 2), cout, None, None, None, 0,
                              kd=1, stride=2)
         assert (got.cpu().double() - ref).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item()), (cin, N, H, W)
+
+
+@pytest.mark.parametrize("N,H,W", [(1, 8, 32), (2, 70, 100), (1, 34, 66), (3, 6, 10), (1, 130, 164)])
+def test_fpn_tail_vs_fp64_and_two_launches(dev, N, H, W):
+    """mvs_fpn_tail_f32 (CasMVSNet's inner2 + nearest x2 top-down add + out3 in one kernel, module.py:396-398) against
+    the fp64 chain and against the two launches it replaces; whole and partial tiles, batch > 1."""
+    from mvs_amd import ops
+    F = torch.nn.functional
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + W)
+    fine = torch.randn(N, 8, H, W, generator=g)
+    coarse = torch.randn(N, 32, H // 2, W // 2, generator=g)
+    wi, bi = torch.randn(32, 8, 1, 1, generator=g) / 8 ** 0.5, torch.randn(32, generator=g) * 0.1
+    wo = torch.randn(8, 32, 3, 3, generator=g) / 288 ** 0.5
+    t = F.interpolate(coarse.double(), scale_factor=2, mode="nearest") + F.conv2d(fine.double(), wi.double(), bi.double())
+    ref = F.conv2d(t, wo.double(), padding=1).permute(0, 2, 3, 1)
+    d = lambda x: x.to(dev)
+    cl = lambda x: d(x).permute(0, 2, 3, 1).contiguous()
+    assert ops.fpn_tail_supported(H, W) and not ops.fpn_tail_supported(H + 1, W)
+    got = ops.fpn_tail(cl(fine), cl(coarse), d(wi), d(bi), ops.pack_fpn_tail_weight(d(wo)))
+    pki, pko = ops.pack_conv2d_weight(d(wi), 1), ops.pack_conv2d_weight(d(wo), 1)
+    two = ops.conv2d(cl(fine), pki, 8, 32, 1, 1, None, d(bi), False, coarse=cl(coarse))
+    two = ops.conv2d(two, pko, 32, 8, 3, 1, None, None, False)
+    tol = 3e-6 * max(1.0, ref.abs().max().item())
+    assert (got.cpu().double() - ref).abs().max().item() < tol
+    assert (two.cpu().double() - ref).abs().max().item() < tol
