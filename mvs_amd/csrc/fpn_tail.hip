@@ -11,6 +11,10 @@
 //   out3      on the BF16 matrix pipe at fp32 accuracy: the Cout = 8 "shifted" form of feature_head.hip (MFMA rows =
 //             channel x x-shift, K = 4 x-taps x 8 channels), 3 kernel rows x 4 channel chunks x 6 products per row of
 //             32 pixels; a wave owns one row of the tile
+// 0.77-0.83 ms against 1.30 for the two launches.  By parts (lateral / out3 / stores removed in turn): copies, stores and
+// barriers 0.21, lateral +0.26-0.32, out3 +0.25 -- out3 is bound by LDS reads (every wave reads all 36 A fragments for its
+// one row: 72 ds_read_b128 x 8 waves x 8 cycles per tile; a deeper read pipeline changed nothing), the lateral layer by
+// instruction issue (340 of 512 threads, ~520 instructions each).
 #include "conv_split_common.h"
 
 #include <cstdlib>
