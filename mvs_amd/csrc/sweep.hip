@@ -1307,13 +1307,16 @@ extern "C" int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *s
 
 // Shape of the persistent kernel's workgroup: waves (= depth planes per tile) and channel quads
 // per stage.  tuning: MVS_SWEEP_PERSIST = "<waves>[,<flags>[,<quads>]]", 0 = always the per-tile kernels
-// Without the variable: 16 waves for D >= 96, the per-tile kernels below that.  What decides is the depth range of a
-// 16-plane tile against the baselines -- its footprint boxes must fit the workgroup's LDS share or its waves go to the cold
-// kernel -- and the host cannot see that; few planes go with coarse intervals in the reference's configurations (CasMVSNet's
-// first stage: 48 planes at 4x the interval, where the per-tile kernel takes 0.66 ms and this one 1.71).
+// Without the variable: 16-plane tiles for D >= 160, 8-plane tiles for 72 <= D < 160, the per-tile kernels below that.
+// What decides is the depth range of a tile against the baselines -- its footprint boxes must fit the workgroup's LDS
+// share or its waves go to the cold kernel -- and the host cannot see that (the planes live on the device); the rule
+// assumes what the reference's scripts do when numdepth is reduced: the same depth range in fewer, coarser planes.
+// Measured at 296 x 400, 5 views, microseconds per plane (16-plane tiles / 8-plane tiles / per-tile kernel): interval x1
+// 6.5 / 8.3 / 10.4, x1.5 9.7 / 9.3 / 10.5, x2 12.9 / 8.6 / 11.2, x3 24 / 11.9 / 12.1, x4 (CasMVSNet's first stage,
+// 48 planes) 33 / 14.5 / 13.5.
 static int persist_waves(int *flags, int *quads, int D) {
     const char *pe = getenv("MVS_SWEEP_PERSIST");
-    int nw = D >= 96 ? 16 : 0;
+    int nw = D >= 160 ? 16 : (D >= 72 ? 8 : 0);
     *flags = 0;
     *quads = 2;
     if (pe) {
