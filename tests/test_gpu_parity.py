@@ -1575,3 +1575,23 @@ def test_fpn_tail_vs_fp64_and_two_launches(dev, N, H, W):
     tol = 3e-6 * max(1.0, ref.abs().max().item())
     assert (got.cpu().double() - ref).abs().max().item() < tol
     assert (two.cpu().double() - ref).abs().max().item() < tol
+
+
+def test_forward_is_deterministic(dev):
+    """Repeated forwards on the same input return the same bits (no atomics on results, no order-dependent reductions;
+    scripts/check_determinism.py does the same at configs[1] and [2])."""
+    from mvs_amd import synth
+    from mvs_amd.models import MVSNet
+    model = MVSNet(refine=False)
+    model.load_state_dict(synth.random_state_dict(3), strict=False)
+    model = model.to(dev).eval()
+    V, H, W, D = 4, 256, 320, 192
+    g = torch.Generator(device=dev).manual_seed(2)
+    imgs = torch.rand(1, V, 3, H, W, device=dev, generator=g)
+    proj = torch.from_numpy(synth.proj_matrices(V, H // 4, W // 4)).to(dev)
+    dv = torch.from_numpy(synth.depth_values(D)).to(dev)
+    with torch.no_grad():
+        ref = model(imgs, proj, dv)
+        for _ in range(6):
+            out = model(imgs, proj, dv)
+            assert torch.equal(out["depth"], ref["depth"]) and torch.equal(out["photometric_confidence"], ref["photometric_confidence"])
