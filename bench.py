@@ -103,7 +103,7 @@ def _roofline_entry(name, kind, amount, ms):
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                 "algorithmic_bytes": amount, "ms": round(ms, 4)}
     ach = amount / (ms * 1e-3) / 1e12
-    if name in SPLIT_STAGES and ops.conv_split_enabled():
+    if (name in SPLIT_STAGES or name in ops.split_stage_names) and ops.conv_split_enabled():
         return {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": round(SPLIT_BF16X6_PEAK_TF, 1),
                 "unit": "TFLOP/s", "frac": round(ach / SPLIT_BF16X6_PEAK_TF, 4), "traffic": None,
                 "algorithmic_flops": amount, "issued_bf16_flops": 6.0 * amount, "ms": round(ms, 4),
@@ -112,6 +112,27 @@ def _roofline_entry(name, kind, amount, ms):
     return {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TF,
             "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": None,
             "algorithmic_flops": amount, "ms": round(ms, 4)}
+
+
+def train_work(V, C, D, h, w):
+    """Algorithmic work of the training step's kernels (one reference view): a layer's forward, input-gradient and
+    weight-gradient kernels each perform the layer's 2*27*Cin*Cout*N flops; the fused warp+variance forward reads every
+    feature map once and writes the volume once, its backward reads the volume gradient once and writes the feature
+    gradients once (the re-read features are cache traffic)."""
+    n0 = D * h * w
+    work = {"train.variance.fwd": ("hbm", (V * C * h * w + D + C * n0) * 4.0),
+            "train.variance.bwd": ("hbm", (C * n0 + 2 * V * C * h * w + D) * 4.0)}
+    convs = {"conv0": (32, 8, 1, 0), "conv1": (8, 16, 2, 0), "conv2": (16, 16, 1, 1), "conv3": (16, 32, 2, 1),
+             "conv4": (32, 32, 1, 2), "conv5": (32, 64, 2, 2), "conv6": (64, 64, 1, 3), "prob": (8, 1, 1, 0)}
+    for name, (ci, co, s, lvl) in convs.items():
+        fl = 2.0 * 27 * ci * co * n0 / (8 ** lvl) / (8 if s == 2 else 1)
+        for k in ("fwd", "dgrad", "wgrad"):
+            work[f"train.{name}.{k}"] = ("mfma", fl)
+    for name, (ci, co, lvl_in) in {"conv7": (64, 32, 3), "conv9": (32, 16, 2), "conv11": (16, 8, 1)}.items():
+        fl = 2.0 * 27 * ci * co * n0 / (8 ** lvl_in)
+        for k in ("fwd", "dgrad", "wgrad"):
+            work[f"train.{name}.{k}"] = ("mfma", fl)
+    return work
 
 
 def train_main(args, rank, world, dev, dist):
@@ -127,6 +148,7 @@ def train_main(args, rank, world, dev, dist):
     torch.manual_seed(1)
     model = MVSNet(refine=False).to(dev)
     parallel.broadcast_parameters(model, 0)
+    sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}     # for the CPU baseline
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.0)   # train.py:98
     reduce_grads = parallel.FlatGradAllReduce(model.parameters())
     rng = np.random.default_rng(100 + rank)
@@ -155,8 +177,22 @@ def train_main(args, rank, world, dev, dist):
         opt.step()
         return loss
 
-    for i in range(args.warmup):
+    # W untimed warm-up steps; the last (up to) 3 carry HIP events on every kernel of the step that has a stage hook
+    n_instr = max(1, min(3, args.warmup))
+    for i in range(max(args.warmup - n_instr, 0)):
         step(i, False)
+    torch.cuda.synchronize()
+    full = ops.StageTimer()
+    ops.set_timer(full, all_threads=True)      # backward() runs on autograd's thread
+    for i in range(n_instr):
+        step(i, False)
+    torch.cuda.synchronize()
+    ops.set_timer(None)
+    stages = full.min_ms()
+    work = train_work(V, 32, D, h, w)
+    dominant = max((k for k in stages if k in work), key=lambda k: stages[k])
+    live = ops.StageTimer(only={dominant})
+    ops.set_timer(live, all_threads=True)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -167,6 +203,7 @@ def train_main(args, rank, world, dev, dist):
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    ops.set_timer(None)
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -174,6 +211,12 @@ def train_main(args, rank, world, dev, dist):
     assert torch.isfinite(loss).all()
     if rank == 0:
         ms = elapsed / args.steps * 1e3
+
+        def entry(k, t_ms):
+            kind, amount = work[k]
+            return _roofline_entry(k, kind, amount, t_ms)
+
+        roof = entry(dominant, live.summary_ms()[dominant][1])
         line = {"metric": "training ref-views/sec", "value": round(world * args.steps / elapsed, 4),
                 "unit": "ref-views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -186,7 +229,38 @@ def train_main(args, rank, world, dev, dist):
                                  if ar_events else None),
                 "loss": round(float(loss.item()), 4),
                 "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
-                "roofline": None, "cpu_baseline": None}
+                "roofline": roof,
+                "stages_ms": {k: round(v, 4) for k, v in sorted(stages.items())},
+                "rooflines": [entry(k, stages[k]) for k in sorted(stages) if k in work],
+                "cpu_baseline": None}
+        if world == 1 and not args.no_cpu_baseline:
+            # the ATen CPU restatement of the same step (oracle/torch_ref.py: forward(train) -> masked smooth-L1 ->
+            # backward -> Adam), ONE step on the host cores after a warm-up on 16 depth planes
+            from oracle import torch_ref
+            cores = os.cpu_count() or 1
+            threads = min(32, cores)      # profiles/r02_cpu_baseline_protocol.json: 32 threads beat all 256 on this host
+            torch.set_num_threads(threads)
+            imgs_c, gt_c = pool[0][0].cpu(), pool[0][1].cpu()
+            pc, mc = proj.cpu(), mask.cpu()
+
+            def cpu_step(planes):
+                sdc = {k: (v.clone().requires_grad_(v.is_floating_point() and "running" not in k)) for k, v in sd0.items()}
+                params = [v for v in sdc.values() if v.requires_grad]
+                optc = torch.optim.Adam(params, lr=1e-3)
+                c0 = time.perf_counter()
+                o = torch_ref.mvsnet_forward(imgs_c, pc, dvals.cpu()[:, :planes].contiguous(), sdc, train=True)
+                ls = torch_ref.masked_smooth_l1(o["depth"], gt_c, mc)
+                ls.backward()
+                optc.step()
+                return time.perf_counter() - c0, float(ls)
+
+            cpu_step(16)
+            cpu_s, cpu_loss = cpu_step(D)
+            line["cpu_baseline"] = {"value": round(1.0 / cpu_s, 5), "unit": "ref-views/s", "cores": threads, "kind": "port",
+                                    "seconds": round(cpu_s, 2), "loss": round(cpu_loss, 4),
+                                    "sample": "ONE training step (forward(train) + loss + backward + Adam) of the same workload on "
+                                              f"{threads} host threads after a warm-up step on 16 depth planes; ATen CPU restatement "
+                                              "of the reference step (oracle/torch_ref.py, MVSNet/train.py:204-248)"}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

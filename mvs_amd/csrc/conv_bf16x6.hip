@@ -374,6 +374,345 @@ __global__ __launch_bounds__(kSplitKernelThreads) void conv3d_c8_bf16x6_kernel(C
 #undef MVS_LAP
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same layer with a Z-SLIDING WINDOW (round 3).  A work unit is a GROUP of four z-neighbouring (4,4,32)-voxel tiles:
+// 16 output planes of one (y, x) tile.  Per 8-channel chunk the group's 18 halo planes enter LDS ONCE: step (j, chunk)
+// brings planes 16 zg + 4j + 1 ... + 4 (four planes = 24 rows; step 0 the six planes -1 ... 4) instead of a tile's six,
+// and the bf16 parts live in a ring of six plane slots, slot(z) = (z + 1 - 16 zg) mod 6 -- a step overwrites the four
+// slots its predecessor no longer needs.  25 % fewer copied and split bytes per output (27 rows per step on average
+// instead of 36): in the per-tile form the copies of a step (39 KiB at the ~11 bytes/cycle a CU sustains) did not
+// land inside the 3240-cycle MFMA phase they were meant to hide under -- the barrier in front of the split pass
+// waited for them -- and the split pass is bound by its LDS writes.  Results are bit-identical to the per-tile
+// kernel: same fragments, same MFMA order per output.
+// Group order: ty fastest, then tx, then z group, then batch; XCD x owns a contiguous range of the list and its
+// 32 workgroups walk 32 consecutive groups at a time -- y-neighbours, which share two of six halo rows in the XCD's L2.
+template <int CIN, int ABL = 0>
+__global__ __launch_bounds__(kSplitKernelThreads) void conv3d_c8_bf16x6_zs_kernel(ConvArgs a, int ngroups) {
+    constexpr int NCHUNK = CIN / 8, YT = 6, PLANE = kHaloPlane, T = kGroup;
+    constexpr int NC = kCopyWaves, NT = kSplitKernelThreads;
+    constexpr int ROWP = 68;                                        // 16-byte pieces per (z, y) row: 34 voxels x 2 halves
+    constexpr int NPIECE0 = 36 * ROWP, NPIECE1 = 24 * ROWP;         // step 0: six planes; later steps: four
+    constexpr int NCOPY0 = (NPIECE0 + 63) / 64, NCOPY1 = (NPIECE1 + 63) / 64, IPW = (NCOPY0 + NC - 1) / NC;
+    constexpr int WBYTES = kSplitChunkBytes, FBYTES = 2 * PLANE * 16, SPART = PLANE * 16, SBYTES = 3 * SPART;
+    constexpr int F_OFF = 2 * WBYTES, S_OFF = F_OFF + FBYTES;
+    constexpr int SLOT = YT * kRowVox * 16;                         // bytes of one plane slot inside a part
+    static_assert(NPIECE0 * 16 <= FBYTES && S_OFF + SBYTES <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[S_OFF + SBYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kq = lane >> 4;
+    const unsigned lds_base = (unsigned)(uintptr_t)lds;
+    const bool copier = wv >= 8;
+    const int cw = wv - 8;       // copy wave index
+
+    // this workgroup's groups: g0 + k * g_step, k < ngw
+    int g0, g_step, ngw;
+    {
+        const int nb = gridDim.x;
+        if ((nb & 7) == 0) {
+            const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3, per = nb >> 3;
+            const int lo = (int)((int64_t)ngroups * xcd / 8), hi = (int)((int64_t)ngroups * (xcd + 1) / 8);
+            g0 = lo + jb; g_step = per; ngw = (hi - g0 + per - 1) / per;
+        } else {
+            g0 = blockIdx.x; g_step = nb; ngw = (ngroups - g0 + nb - 1) / nb;
+        }
+        if (ngw < 0) ngw = 0;
+    }
+    const int ngz = (a.tiles_z + T - 1) / T;
+    struct Grp { int tx, ty, zg, b; };
+    auto decode = [&](int g) {
+        Grp r;
+        r.ty = g % a.tiles_y; g /= a.tiles_y;
+        r.tx = g % a.tiles_x; g /= a.tiles_x;
+        r.zg = g % ngz; r.b = g / ngz;
+        return r;
+    };
+
+    // the split pass: staging piece P (row = P / 68 = zl * 6 + y, q = P % 68 -> voxel x = q / 2, channel half q & 1)
+    // -> 8 bytes of each part at slot((zl + first slot of the step) mod 6) + ((y * 17 + x / 2 (+ kOddBase for odd x)) * 16
+    // + half * 8.  Thread order rotated so that the copy waves -- idle between the two barriers -- own the ragged tail.
+    const int tidr = tid < 512 ? tid + 256 : tid - 512;
+    constexpr int NPS = (NPIECE0 + NT - 1) / NT;
+    unsigned spos[NPS];          // in-slot byte position | zl << 16
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {
+        const int P = ps * NT + tidr;
+        const int Pc = P < NPIECE0 ? P : 0;
+        const int row = Pc / ROWP, q = Pc % ROWP, x = q >> 1;
+        spos[ps] = (unsigned)(((row % YT) * kRowVox + (x >> 1) + (x & 1) * kOddBase) * 16 + (q & 1) * 8) | ((unsigned)(row / YT) << 16);
+    }
+    auto split_pass = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int NP = j == 0 ? NPIECE0 : NPIECE1, NPSJ = (NP + NT - 1) / NT;
+        constexpr int ZF = j == 0 ? 0 : (4 * j + 2) % 6;             // ring slot of the first staged plane
+        f32x4 x[NPSJ];
+        const unsigned fp = lds_base + (unsigned)(F_OFF + tidr * 16);
+        const int wbase = tidr & ~63;                                 // wave-uniform
+        static_for<0, NPSJ>([&](auto pc) {
+            constexpr int ps = decltype(pc)::value;
+            if (ps * NT + wbase < NP) x[ps] = lds_read_b128<ps * NT * 16>(fp);
+        });
+        lds_wait_n<0>();
+        static_for<0, (NPSJ + 1) / 2>([&](auto pc) {
+            constexpr int p0 = 2 * decltype(pc)::value, p1 = (p0 + 1 < NPSJ) ? p0 + 1 : p0;
+            if (p0 * NT + wbase >= NP) return;                        // the whole wave has nothing here
+            asm volatile("" : "+v"(x[p0]), "+v"(x[p1]));
+            bf16x8 h, m, l;
+            split3_block(x[p0], x[p1], h, m, l);
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 hu = __builtin_bit_cast(u32x4, h), mu = __builtin_bit_cast(u32x4, m), lu = __builtin_bit_cast(u32x4, l);
+            auto dest = [&](unsigned sp) {
+                unsigned s = (sp >> 16) + ZF;
+                s = min(s, s - 6u);                                   // mod 6 (s < 12)
+                return lds_base + (unsigned)S_OFF + (sp & 0xffffu) + s * (unsigned)SLOT;
+            };
+            if (p0 * NT + tidr < NP) {
+                const unsigned sp = dest(spos[p0]);
+                lds_write_b64<0>(sp, hu[0], hu[1]);
+                lds_write_b64<SPART>(sp, mu[0], mu[1]);
+                lds_write_b64<2 * SPART>(sp, lu[0], lu[1]);
+            }
+            if (p1 != p0 && p1 * NT + tidr < NP) {
+                const unsigned sp = dest(spos[p1]);
+                lds_write_b64<0>(sp, hu[2], hu[3]);
+                lds_write_b64<SPART>(sp, mu[2], mu[3]);
+                lds_write_b64<2 * SPART>(sp, lu[2], lu[3]);
+            }
+        });
+        lds_wait_n<0>();
+    };
+
+    if (copier) {
+        // ================================================================ copy waves
+        // staging piece P = (i * NC + cw) * 64 + lane: the rows as they lie in memory, neighbouring lanes =
+        // neighbouring pieces (a 64-byte line is requested once)
+        int loc[IPW];
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const int P = (i * NC + cw) * 64 + lane;
+            const int Pc = P < NPIECE0 ? P : 0;
+            const int row = Pc / ROWP, q = Pc % ROWP;
+            loc[i] = (q >> 1) | ((row % YT) << 8) | ((row / YT) << 16) | ((q & 1) << 24);
+        }
+        const int64_t plane_in = (int64_t)a.H * a.W * CIN;
+        const int row_in = a.W * CIN;
+        const unsigned window_bytes = (unsigned)min((int64_t)6 * plane_in * 4, (int64_t)0xffffff00u);
+        unsigned voff[IPW];       // byte offset from the first staged plane; 0xffffff00 = outside the image in x or y
+        Grp cg{0, 0, 0, 0};
+        auto geometry = [&](int g) {
+            cg = decode(g);
+            const int ix0 = cg.tx * 32 - 1, iy0 = cg.ty * 4 - 1;
+#pragma unroll
+            for (int i = 0; i < IPW; ++i) {
+                const int gx = ix0 + (loc[i] & 255), gy = iy0 + ((loc[i] >> 8) & 255);
+                const int lz = (loc[i] >> 16) & 255, h = (loc[i] >> 24) & 1;
+                const bool ok = (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H;
+                voff[i] = ok ? (unsigned)(((int64_t)lz * plane_in + (int64_t)gy * row_in + gx * 8 + h * 4) * 4) : 0xffffff00u;
+            }
+        };
+        auto issue_halo = [&](auto jc, int ch) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int NP = j == 0 ? NPIECE0 : NPIECE1, NCP = j == 0 ? NCOPY0 : NCOPY1;
+            const int zs = cg.zg * 16 + (j == 0 ? -1 : 4 * j + 1);   // first staged plane
+            const mvs_srd_t srd = make_srd(a.in + ((int64_t)cg.b * a.D + zs) * plane_in, window_bytes);
+            const unsigned soff = (unsigned)(ch * a.W * 32);
+#pragma unroll
+            for (int i = 0; i < IPW; ++i) {
+                if (i * NC + cw >= NCP) continue;   // wave-uniform
+                const int P = (i * NC + cw) * 64 + lane, lz = (loc[i] >> 16) & 255;
+                const bool ok = P < NP && (unsigned)(zs + lz) < (unsigned)a.D;
+                glds16_buf(ok ? voff[i] : 0xffffff00u, srd, soff, lds_base + (unsigned)(F_OFF + (i * NC + cw) * 1024));
+            }
+        };
+        const unsigned char *wsrc = reinterpret_cast<const unsigned char *>(a.wpk);
+        auto issue_weights = [&](int ch, int sel) {   // 27 KiB = 27 wave-copies over the copy waves
+#pragma unroll
+            for (int i = 0; i < (27 + NC - 1) / NC; ++i) {
+                const int g = i * NC + cw;
+                if (g < 27) glds16(wsrc + (size_t)ch * WBYTES + (size_t)g * 1024 + lane * 16,
+                                   lds_base + (unsigned)(sel * WBYTES + g * 1024));
+            }
+        };
+        int wsel = 0;
+        if (ngw > 0) {
+            geometry(g0);
+            issue_halo(std::integral_constant<int, 0>{}, 0);
+            issue_weights(0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        for (int k = 0; k < ngw; ++k) {
+            const int nvalid = min(T, a.tiles_z - cg.zg * T);
+#pragma unroll 1
+            for (int ch = 0; ch < NCHUNK; ++ch) {
+                static_for<0, T>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    if (j >= nvalid) return;   // wave-uniform
+                    __syncthreads();           // the rows of this step are in the staging buffer (this wave has waited for them)
+                    split_pass(jc);
+                    __syncthreads();           // ... and have been split: the staging buffer is free
+                    if (j + 1 < nvalid) {
+                        issue_halo(std::integral_constant<int, (j + 1) % T>{}, ch);
+                    } else if (ch + 1 < NCHUNK) {
+                        issue_halo(std::integral_constant<int, 0>{}, ch + 1);
+                        issue_weights(ch + 1, wsel ^ 1);
+                    } else if (k + 1 < ngw) {
+                        geometry(g0 + (k + 1) * g_step);
+                        issue_halo(std::integral_constant<int, 0>{}, 0);
+                        issue_weights(0, wsel ^ 1);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                });
+                wsel ^= 1;
+            }
+        }
+        return;
+    }
+
+    float4 sc, sh;
+    {
+        const int c0 = (kq & 1) * 4;
+        sc = a.scale ? *reinterpret_cast<const float4 *>(a.scale + c0) : make_float4(1.f, 1.f, 1.f, 1.f);
+        sh = a.shift ? *reinterpret_cast<const float4 *>(a.shift + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    const int z0 = wv >> 1, y0 = (wv & 1) * 2;          // the wave's output rows: (z0, y0) and (z0, y0 + 1)
+    const int ex = 2 * n + (kq >> 1);
+    const int eoff = ((z0 * a.Ho + y0) * a.Wo + ex) * 8 + (kq & 1) * 4;
+    // this lane's B voxel of row y0 inside a plane slot: x = 2n + kq
+    const unsigned aB = lds_base + (unsigned)(S_OFF + (y0 * kRowVox + n + (kq >> 1) + (kq & 1) * kOddBase) * 16);
+
+    f32x4 acc[T][2];
+#pragma unroll
+    for (int j = 0; j < T; ++j) acc[j][0] = acc[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int wsel = 0;
+    long long tsum[7] = {0, 0, 0, 0, 0, 0, 0};
+    long long tprev = 0;
+    if constexpr (ABL & 128) tprev = clock64();
+#define MVS_LAP(k) do { if constexpr (ABL & 128) { const long long tn = clock64(); tsum[k] += tn - tprev; tprev = tn; } } while (0)
+    for (int k = 0; k < ngw; ++k) {
+        const Grp cur = decode(__builtin_amdgcn_readfirstlane(g0 + k * g_step));
+        const int nvalid = min(T, a.tiles_z - cur.zg * T);
+#pragma unroll 1
+        for (int ch = 0; ch < NCHUNK; ++ch) {
+            static_for<0, T>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if (j >= nvalid) return;   // wave-uniform
+                MVS_LAP(6);
+                __syncthreads();
+                MVS_LAP(1);
+                split_pass(jc);
+                MVS_LAP(2);
+                __syncthreads();
+                MVS_LAP(3);
+                // ---- MFMA phase: 12 input-row fragments f = (kz, iy) into row 0 (ky = iy) and row 1 (ky = iy - 1);
+                // plane z0 + kz of the tile sits in ring slot (4j + z0 + kz) mod 6
+                unsigned aBz[3];
+#pragma unroll
+                for (int kz = 0; kz < 3; ++kz) {
+                    int s = (4 * j) % 6 + z0 + kz;
+                    s = s >= 6 ? s - 6 : s;
+                    aBz[kz] = aB + (unsigned)(s * SLOT);
+                }
+                const unsigned aA = lds_base + (unsigned)(wsel * WBYTES + lane * 16);
+                // Nine blocks c = (kz, ky) of twelve MFMAs: the weight triple A(kz, ky) against input row (kz, ky) into
+                // output row 0 and against input row (kz, ky + 1) into output row 1, ALTERNATING between the two
+                // accumulators (each accumulator sees its products in the same order as before: bit-identical).  Back-to-
+                // back MFMAs on ONE accumulator wait for each other; the fragment-by-fragment form had two such runs of
+                // six per kz and issued its six reads as a block in front of each fragment -- fine while the partner wave
+                // of the SIMD fills the gaps, but the older wave wins the arbitration, finishes its 108 MFMAs in ~2400
+                // cycles and leaves the younger one alone at 62 % of the pipe's rate (phase laps).  Here
+                // the reads of block c + 1 ride in the issue shadow of block c's MFMAs 4 ... 11, ordered as block c + 1
+                // consumes them (mid, mid | lo, hi | hi, lo) with counted waits.
+                bf16x8 bsr[4][3], Aw[2][3];        // input rows g = kz * 4 + iy in slot g % 4; weight triples c in slot c % 2
+                auto rd = [&](auto ic, auto cc) {   // i-th read of the set that block c needs
+                    constexpr int i = decltype(ic)::value, c = decltype(cc)::value, kz = c / 3, ky = c % 3;
+                    constexpr bool two = ky == 0;                     // both rows are new at a kz change
+                    constexpr int per = two ? 3 : 2, what = i % per, lvl = i / per;   // what: 0 = A, 1.. = B rows
+                    constexpr int spA = lvl == 0 ? 1 : (lvl == 1 ? 2 : 0), spB = lvl == 0 ? 1 : (lvl == 1 ? 0 : 2);
+                    if constexpr (what == 0) {
+                        Aw[c & 1][spA] = __builtin_bit_cast(bf16x8, lds_read_b128<(c * 3 + spA) * 1024>(aA));
+                    } else {
+                        constexpr int iy = two ? ky + what - 1 : ky + 1, g = kz * 4 + iy;
+                        bsr[g & 3][spB] = __builtin_bit_cast(bf16x8, lds_read_b128<iy * kRowVox * 16 + spB * SPART>(aBz[kz]));
+                    }
+                };
+                static_for<0, 9>([&](auto ic) { rd(ic, std::integral_constant<int, 0>{}); });
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, 9>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value, kz = c / 3, ky = c % 3, g0 = kz * 4 + ky, g1 = g0 + 1;
+                    constexpr int nin = ky == 0 ? 9 : 6;                               // reads this block waits for
+                    constexpr int nout = c == 8 ? 0 : ((c + 1) % 3 == 0 ? 9 : 6);      // reads it issues for block c + 1
+                    static_for<0, 12>([&](auto mc) {
+                        constexpr int m = decltype(mc)::value, t = m / 2, r = m % 2;
+                        constexpr int as = (t == 0 || t == 3) ? 1 : (t == 1 ? 2 : 0);   // am al ah am ah ah
+                        constexpr int bp = (t == 0 || t == 4) ? 1 : (t == 2 ? 2 : 0);   // bm bh bl bh bm bh
+                        if constexpr (m == 0 || m == 2 || m == 4) {
+                            lds_wait_n<(m == 0 ? nin - nin / 3 : (m == 2 ? nin / 3 : 0))>();
+                            asm volatile("" : "+v"(Aw[c & 1][as]), "+v"(bsr[g0 & 3][bp]), "+v"(bsr[g1 & 3][bp]));
+                        }
+                        const bf16x8 &bb = bsr[(r == 0 ? g0 : g1) & 3][bp];
+                        f32x4 &cc2 = acc[j][r];
+                        cc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Aw[c & 1][as], bb, cc2, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (m >= 4 && m - 4 < nout) {
+                            rd(std::integral_constant<int, m - 4>{}, std::integral_constant<int, (c + 1) % 9>{});
+                            if constexpr (m == 11 && nout == 9) rd(std::integral_constant<int, 8>{}, std::integral_constant<int, (c + 1) % 9>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    });
+                });
+                if constexpr (ABL & 128) {
+                    f32x4 &c0 = acc[j][0], &c1 = acc[j][1];
+                    asm volatile("" : "+v"(c0), "+v"(c1));
+                    asm volatile("s_nop 0" ::: "memory");
+                }
+                MVS_LAP(5);
+            });
+            wsel ^= 1;
+        }
+        // ---- epilogue of the group: BN affine, ReLU, one 16-byte store per lane and row
+        const int tb = __builtin_amdgcn_readfirstlane(cur.b), oy0 = __builtin_amdgcn_readfirstlane(cur.ty) * 4;
+        const int ox0 = __builtin_amdgcn_readfirstlane(cur.tx) * 32, ozg = __builtin_amdgcn_readfirstlane(cur.zg) * 16;
+        static_for<0, T>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if (j >= nvalid) return;
+            const int oz0 = ozg + 4 * j;
+            const int64_t base = ((((int64_t)tb * a.Do + oz0) * a.Ho + oy0) * a.Wo + ox0) * 8;
+            float *const ob = a.out + base;
+            const float *const rp = (a.residual && !(ABL & 128)) ? a.residual + base : nullptr;
+            const bool xz_in = oz0 + z0 < a.Do && ox0 + ex < a.Wo;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                f32x4 v = acc[j][r];
+                acc[j][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (!xz_in || oy0 + y0 + r >= a.Ho) continue;
+                v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
+                v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+                if (a.relu == 1) {
+                    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+                    v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                }
+                const int o = eoff + r * a.Wo * 8;
+                if (rp) {
+                    const float4 rs = *reinterpret_cast<const float4 *>(rp + o);
+                    v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
+                }
+                *reinterpret_cast<float4 *>(ob + o) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        });
+    }
+    if constexpr (ABL & 128) {
+        MVS_LAP(6);
+        if (lane == 0) {
+            long long *dbg = reinterpret_cast<long long *>(const_cast<float *>(a.residual)) + ((int64_t)blockIdx.x * 8 + wv) * 8;
+            for (int k = 0; k < 7; ++k) dbg[k] = tsum[k];
+        }
+    }
+#undef MVS_LAP
+}
+
 // PyTorch-layout weight (8, Cin, 3, 3, 3) -> [chunk][kz*3+ky][split][lane][8 bf16]; lane (m, kq): row m =
 // (cout = m & 7, x-shift = m >> 3), k = kq * 8 + c: x-tap kx' = kq of the 4-tap window, channel c of the
 // chunk; the weight is w[cout][chunk*8 + c][kz][ky][kx' - shift] (zero outside the 3 real taps).
@@ -438,8 +777,25 @@ extern "C" int mvs_conv3d_c8_bf16x6_f32(const float *in, const void *packed, con
     const int64_t nt = (int64_t)B * a.tiles_x * a.tiles_y * a.tiles_z;
     if (nt <= 0 || nt > 0x7fffffffLL) return bare_error(MVS_EINVAL, __func__, __LINE__);
     const int n_cu = device_cu_count();
-    const dim3 grid((unsigned)(nt < n_cu ? nt : n_cu)), blk(kSplitKernelThreads);
     hipStream_t st = as_stream(stream);
+    // MVS_CONV0_ZSLIDE=0: the per-tile kernel of round 2 (A/B; bit-identical results)
+    static const bool zslide = [] { const char *e = getenv("MVS_CONV0_ZSLIDE"); return !(e && e[0] == '0'); }();
+    if (zslide && !(abl & (128 | 24 | 7))) {
+        const int64_t ng = (int64_t)B * a.tiles_x * a.tiles_y * ((a.tiles_z + kGroup - 1) / kGroup);
+        const dim3 gridz((unsigned)(ng < n_cu ? ng : n_cu)), blkz(kSplitKernelThreads);
+        if (Cin == 32) hipLaunchKernelGGL((conv3d_c8_bf16x6_zs_kernel<32>), gridz, blkz, 0, st, a, (int)ng);
+        else if (Cin == 16) hipLaunchKernelGGL((conv3d_c8_bf16x6_zs_kernel<16>), gridz, blkz, 0, st, a, (int)ng);
+        else hipLaunchKernelGGL((conv3d_c8_bf16x6_zs_kernel<8>), gridz, blkz, 0, st, a, (int)ng);
+        return check_launch("mvs_conv3d_c8_bf16x6_f32");
+    }
+    if (zslide && (abl & 128) && Cin == 32 && (abl & 64)) {   // tuning build of the z-sliding kernel: phase cycles into `residual`
+        if (!residual) return bare_error(MVS_EINVAL, __func__, __LINE__);
+        const int64_t ng = (int64_t)B * a.tiles_x * a.tiles_y * ((a.tiles_z + kGroup - 1) / kGroup);
+        const dim3 gridz((unsigned)(ng < n_cu ? ng : n_cu)), blkz(kSplitKernelThreads);
+        hipLaunchKernelGGL((conv3d_c8_bf16x6_zs_kernel<32, 128>), gridz, blkz, 0, st, a, (int)ng);
+        return check_launch("mvs_conv3d_c8_bf16x6_f32");
+    }
+    const dim3 grid((unsigned)(nt < n_cu ? nt : n_cu)), blk(kSplitKernelThreads);
     // MVS_CONV_SPLIT_DOT2=0: the split written with plain conversions and subtractions (same operands bit for
     // bit; kept to cross-check the v_dot2c form)
     static const bool dot2 = [] { const char *e = getenv("MVS_CONV_SPLIT_DOT2"); return !(e && e[0] == '0'); }();

@@ -480,7 +480,7 @@ static int launch_split(const SplitArgs &a0, hipStream_t st) {
     a.tiles_x = (a.Wo + C::TX - 1) / C::TX; a.tiles_y = (a.Ho + C::TY - 1) / C::TY; a.tiles_z = (a.Do + C::TZ - 1) / C::TZ;
     a.ystrip = C::KD == 3 ? 4 : 2;
     const int64_t nt = (int64_t)a.B * a.tiles_x * a.tiles_y * a.tiles_z;
-    if (nt <= 0 || nt >= (1 << 23)) return bare_error(MVS_EINVAL, __func__, __LINE__);   // the kernel's float tile decode
+    if (nt <= 0 || nt >= (1 << 23)) return bare_error(MVS_EUNSUPPORTED, __func__, __LINE__);   // the kernel's float tile decode: callers fall back to mvs_conv3d_f32 / mvs_conv2d_f32
     const int n_cu = device_cu_count();
     static const bool laps = [] { const char *e = getenv("MVS_CONV_SPLIT_LAPS"); return e && e[0] == '1'; }();
     if (laps && a.residual && (C::CIN == 64 || C::CIN == 16) && C::COUT == 16 * (C::CIN == 64 ? 2 : 1))   // tuning builds: 64 -> 32 and 16 -> 16
@@ -540,7 +540,7 @@ extern "C" int mvs_conv_split_f32(const float *in, const void *packed, const flo
         set_error("mvs_conv_split_f32: invalid argument (kd in {1, 3}; Cin, Cout in {16, 32, 64}, stride 1; or kd 3, stride 2, Cin in {8, 16, 32}; or kd 1, stride 2 = the 5x5 layers 8 -> 16, 16 -> 32; channels-last)");
         return MVS_EINVAL;
     }
-    if ((int64_t)(kd + 3) * H * W * Cin * 4 >= 0xffffff00LL) return bare_error(MVS_EINVAL, __func__, __LINE__);   // 32-bit halo offsets
+    if ((int64_t)(kd + 3) * H * W * Cin * 4 >= 0xffffff00LL) return bare_error(MVS_EUNSUPPORTED, __func__, __LINE__);   // 32-bit halo offsets: callers fall back to the fp32 kernels
     const int step = split_cout_step(kd, Cout, stride), cps = split_cps(kd, Cin, stride), G = (split_ntap(kd, stride) * cps + 3) / 4;
     const size_t per_launch = (size_t)(Cin / (8 * cps)) * G * (step / 16) * 3 * 1024;
     hipStream_t st = as_stream(stream);

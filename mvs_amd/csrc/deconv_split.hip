@@ -407,7 +407,7 @@ static int launch_deconv_split(const DeconvArgs &a0, hipStream_t st) {
     a.tiles_x = (a.W + 15) / 16; a.tiles_y = (a.H + C::TY - 1) / C::TY; a.tiles_z = (a.D + C::TZ - 1) / C::TZ;
     a.ystrip = 4;
     const int64_t nt = (int64_t)a.B * a.tiles_x * a.tiles_y * a.tiles_z;
-    if (nt <= 0 || nt >= (1 << 23)) return bare_error(MVS_EINVAL, __func__, __LINE__);   // the kernel's float tile decode
+    if (nt <= 0 || nt >= (1 << 23)) return bare_error(MVS_EUNSUPPORTED, __func__, __LINE__);   // the kernel's float tile decode: callers fall back to mvs_conv3d_f32 / mvs_conv2d_f32
     const int n_cu = device_cu_count();
     hipLaunchKernelGGL((deconv_split_kernel<C>), dim3((unsigned)(nt < n_cu ? nt : n_cu)), dim3(kDeconvThreads), 0, st, a, (int)nt);
     return check_launch("mvs_deconv_split_f32");
@@ -454,7 +454,7 @@ extern "C" int mvs_deconv_split_f32(const float *in, const void *packed, const f
         set_error("mvs_deconv_split_f32: invalid argument (Cin in {16, 32, 64}; Cout in {8, 16, 32}; stride 2; channels-last)");
         return MVS_EINVAL;
     }
-    if ((int64_t)5 * H * W * Cin * 4 >= 0xffffff00LL) return bare_error(MVS_EINVAL, __func__, __LINE__);   // 32-bit halo offsets
+    if ((int64_t)5 * H * W * Cin * 4 >= 0xffffff00LL) return bare_error(MVS_EUNSUPPORTED, __func__, __LINE__);   // 32-bit halo offsets: callers fall back to the fp32 kernels
     const int nk = deconv_nk(Cout), step = Cout == 8 ? 8 : 16;
     const size_t per_launch = (size_t)(Cin / 16) * nk * 3 * 1024;
     hipStream_t st = as_stream(stream);

@@ -175,11 +175,11 @@ class CostRegNet(nn.Module):
 
         def blk(name, t, stride=1):
             m = getattr(self, name)
-            return conv_bn_relu_cl(t, m.conv, m.bn, False, stride)
+            return conv_bn_relu_cl(t, m.conv, m.bn, False, stride, tag=name)
 
         def up(name, t, skip):
             m = getattr(self, name)
-            return conv_bn_relu_cl(t, m[0], m[1], True, 2, skip=skip)
+            return conv_bn_relu_cl(t, m[0], m[1], True, 2, skip=skip, tag=name)
 
         c0 = blk("conv0", x_cl)
         c2 = blk("conv2", blk("conv1", c0, 2))
@@ -188,7 +188,7 @@ class CostRegNet(nn.Module):
         t = up("conv7", t, c4)     # c4 + relu(bn(deconv))
         t = up("conv9", t, c2)
         t = up("conv11", t, c0)
-        return (conv3d_cl(t, self.prob.weight) + self.prob.bias).squeeze(-1)
+        return (conv3d_cl(t, self.prob.weight, tag="prob") + self.prob.bias).squeeze(-1)
 
     # -- inference path: HIP kernels, BN folded to a per-channel affine
     def _layers(self):

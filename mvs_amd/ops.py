@@ -55,12 +55,21 @@ _tls = threading.local()   # the timer belongs to the thread that installed it: 
                            # one forward per device on worker threads, which must not share event lists
 
 
+_process_timer = None      # set_timer(t, all_threads=True): also seen by autograd's backward thread
+
+
 def _get_timer():
-    return getattr(_tls, "timer", None)
+    return getattr(_tls, "timer", None) or _process_timer
 
 
-def set_timer(t):
+def set_timer(t, all_threads=False):
+    """Install (or with None remove) the stage timer of the calling thread; all_threads: of every thread that has none
+    of its own -- autograd runs backward() on its own thread, so a training step is timed with all_threads=True (one
+    model per process; nn.DataParallel's per-device worker threads must not share one)."""
+    global _process_timer
     _tls.timer = t
+    if all_threads or t is None:
+        _process_timer = t
 
 
 def timing_enabled():
@@ -391,7 +400,8 @@ class _CostVolVarianceC16(torch.autograd.Function):
         ref16, srcs16, depth_values = _f32c(ref16), _f32c(srcs16), _f32c(depth_values)
         if _depth_mode(depth_values) != 0:
             raise MvsHipError("the differentiable channels-last variance takes [B,D] depth planes")
-        out = costvol_variance_c16(ref16, srcs16, rts, depth_values, align_corners)
+        with stage("train.variance.fwd"):
+            out = costvol_variance_c16(ref16, srcs16, rts, depth_values, align_corners)
         ctx.save_for_backward(ref16, srcs16, rts, depth_values)
         ctx.ac = int(align_corners)
         return out
@@ -403,10 +413,11 @@ class _CostVolVarianceC16(torch.autograd.Function):
         V, D = srcs16.shape[0] + 1, depth_values.shape[1]
         grad_var = _f32c(grad_var)
         g_ref, g_src = torch.empty_like(ref16), torch.empty_like(srcs16)
-        check(_lib.load().mvs_costvol_variance_bwd_f32(
-            ptr(grad_var), ptr(ref16), ptr(srcs16), ptr(rts), ptr(depth_values), 0, B, V, G * 16, D, H, W,
-            ctx.ac, MVS_LAYOUT_C16, MVS_LAYOUT_NHWC, ptr(g_ref), ptr(g_src), stream()),
-            "mvs_costvol_variance_bwd_f32")
+        with stage("train.variance.bwd"):
+            check(_lib.load().mvs_costvol_variance_bwd_f32(
+                ptr(grad_var), ptr(ref16), ptr(srcs16), ptr(rts), ptr(depth_values), 0, B, V, G * 16, D, H, W,
+                ctx.ac, MVS_LAYOUT_C16, MVS_LAYOUT_NHWC, ptr(g_ref), ptr(g_src), stream()),
+                "mvs_costvol_variance_bwd_f32")
         return g_ref, g_src, None, None, None
 
 
@@ -664,10 +675,16 @@ def pack_conv_weight_split(weight, stride=1):
     return packed
 
 
-def conv_split(x_cl, packed_split, cout, scale=None, shift=None, residual=None, relu=1, kd=3, out_c4=False, stride=1):
+MVS_EUNSUPPORTED = -2     # include/mvs_hip.h
+split_stage_names = set()  # stage names whose kernel ran on the split-operand bf16 pipe (bench.py prices them against that ceiling)
+
+
+def conv_split(x_cl, packed_split, cout, scale=None, shift=None, residual=None, relu=1, kd=3, out_c4=False, stride=1, soft=False):
     """3x3(x3) layer (kd = 1 with stride 2: 5x5) on the bf16 matrix pipe with exactly split fp32 operands
     (mvs_conv_split_f32).  kd = 3: x_cl [B,D,H,W,Cin] -> [B,D,H,W,cout]; kd = 1: images x_cl [N,H,W,Cin] -> [N,H,W,cout].
-    relu: 0 none, 1 ReLU, 2 LeakyReLU(0.1)."""
+    relu: 0 none, 1 ReLU, 2 LeakyReLU(0.1).  soft: return None instead of raising when the launcher answers
+    MVS_EUNSUPPORTED (a volume beyond its 32-bit halo offsets / tile count) -- conv3d() / conv2d() then run the layer on the
+    fp32 MFMA kernels, whose limits are 4x wider."""
     x_cl = _f32c(x_cl)
     if kd == 3:
         B, D, H, W, cin = x_cl.shape
@@ -679,11 +696,14 @@ def conv_split(x_cl, packed_split, cout, scale=None, shift=None, residual=None, 
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
         out = torch.empty((D, cout // 4, Ho, Wo, 4) if out_c4 else (D, Ho, Wo, cout), device=x_cl.device, dtype=torch.float32)
     with stage("conv_split"):
-        check(_lib.load().mvs_conv_split_f32(
+        rc = _lib.load().mvs_conv_split_f32(
             ptr(x_cl), ptr(packed_split), ptr(_f32c(scale)) if scale is not None else None,
             ptr(_f32c(shift)) if shift is not None else None,
             ptr(_f32c(residual)) if residual is not None else None, int(relu), kd, stride, B, cin, cout, D, H, W,
-            int(bool(out_c4)), ptr(out), stream()), "mvs_conv_split_f32")
+            int(bool(out_c4)), ptr(out), stream())
+    if soft and rc == MVS_EUNSUPPORTED:
+        return None
+    check(rc, "mvs_conv_split_f32")
     return out
 
 
@@ -702,18 +722,22 @@ def pack_deconv_weight_split(weight):
     return packed
 
 
-def deconv_split(x_cl, packed_split, cout, scale=None, shift=None, residual=None, relu=True):
+def deconv_split(x_cl, packed_split, cout, scale=None, shift=None, residual=None, relu=True, soft=False):
     """Transposed 3x3x3 stride-2 layer on the bf16 matrix pipe with exactly split fp32 operands
-    (mvs_deconv_split_f32): x_cl [B,D,H,W,Cin] -> [B,2D,2H,2W,cout]; residual is added after the ReLU."""
+    (mvs_deconv_split_f32): x_cl [B,D,H,W,Cin] -> [B,2D,2H,2W,cout]; residual is added after the ReLU.
+    soft: None instead of an exception on MVS_EUNSUPPORTED (see conv_split)."""
     x_cl = _f32c(x_cl)
     B, D, H, W, cin = x_cl.shape
     out = torch.empty(B, 2 * D, 2 * H, 2 * W, cout, device=x_cl.device, dtype=torch.float32)
     with stage("deconv_split"):
-        check(_lib.load().mvs_deconv_split_f32(
+        rc = _lib.load().mvs_deconv_split_f32(
             ptr(x_cl), ptr(packed_split), ptr(_f32c(scale)) if scale is not None else None,
             ptr(_f32c(shift)) if shift is not None else None,
             ptr(_f32c(residual)) if residual is not None else None, int(bool(relu)), B, cin, cout, D, H, W,
-            ptr(out), stream()), "mvs_deconv_split_f32")
+            ptr(out), stream())
+    if soft and rc == MVS_EUNSUPPORTED:
+        return None
+    check(rc, "mvs_deconv_split_f32")
     return out
 
 
@@ -746,12 +770,18 @@ def conv3d(x, weight, scale=None, shift=None, residual=None, relu=False, transpo
         residual = _f32c(residual)
         if tuple(residual.shape) != shape:
             raise MvsHipError(f"residual shape {tuple(residual.shape)} != output shape {shape}")
-    sp = split_companion(packed)
-    if sp is not None and channels_last and not in_c8 and not transposed and impl != IMPL_DIRECT:
-        # the layer's split-operand pack was registered with its fp32 pack: bf16 matrix pipe, fp32 accuracy
-        return conv_split(x, sp, cout, scale, shift, residual, 1 if relu else 0, kd=3, stride=stride)
-    if sp is not None and channels_last and not in_c8 and transposed and stride == 2 and impl != IMPL_DIRECT:
-        return deconv_split(x, sp, cout, scale, shift, residual, relu)
+    # the layer's split-operand pack was registered with its fp32 pack: bf16 matrix pipe, fp32 accuracy.  Only on
+    # IMPL_AUTO (an explicit IMPL_MFMA / IMPL_DIRECT measures the kernel it names), and a volume beyond the split
+    # launcher's limits falls through to the fp32 kernels below.
+    sp = split_companion(packed) if impl == IMPL_AUTO else None
+    if sp is not None and channels_last and not in_c8 and not transposed:
+        out = conv_split(x, sp, cout, scale, shift, residual, 1 if relu else 0, kd=3, stride=stride, soft=True)
+        if out is not None:
+            return out
+    if sp is not None and channels_last and not in_c8 and transposed and stride == 2:
+        out = deconv_split(x, sp, cout, scale, shift, residual, relu, soft=True)
+        if out is not None:
+            return out
     out = torch.empty(shape, device=x.device, dtype=torch.float32)
     check(_lib.load().mvs_conv3d_f32(
         ptr(x), ptr(weight), ptr(packed), ptr(_f32c(scale)) if scale is not None else None,
@@ -1119,7 +1149,9 @@ def conv2d(x, packed, cin, cout, ksize, stride, scale=None, shift=None, relu=Fal
     Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
     sp = split_companion(packed)
     if sp is not None and (ksize, stride) in ((3, 1), (5, 2)) and not planar and coarse is None:
-        return conv_split(x, sp, cout, scale, shift, None, int(relu), kd=1, out_c4=out_c4, stride=stride)
+        out = conv_split(x, sp, cout, scale, shift, None, int(relu), kd=1, out_c4=out_c4, stride=stride, soft=True)
+        if out is not None:       # else: beyond the split launcher's 32-bit halo offsets -> the fp32 MFMA kernel
+            return out
     out = torch.empty((B, cout // 4, Ho, Wo, 4) if out_c4 else (B, Ho, Wo, cout), device=x.device, dtype=torch.float32)
     if coarse is not None:
         coarse = _f32c(coarse)

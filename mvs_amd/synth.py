@@ -25,6 +25,13 @@ DTU_TARGET_Z = 680.0
 
 _THETA_DEG = (0.0, -8.0, 8.0, -4.0, 4.0, -12.0, 12.0)
 _PHI_DEG = (0.0, 3.0, -3.0, -6.0, 6.0, 2.0, -2.0)
+# rig 1 (second parity scene): wider baselines, camera roll and unequal distances to the
+# target, so that footprints are longer and more oblique and more taps leave the source images
+_RIGS = {
+    0: dict(theta=_THETA_DEG, phi=_PHI_DEG, psi=(0.0,) * 7, dist=(1.0,) * 7),
+    1: dict(theta=(0.0, -13.0, 11.0, -6.5, 7.5, -17.0, 16.0), phi=(0.0, 5.0, -4.5, -8.0, 9.0, 3.0, -3.5),
+            psi=(0.0, 2.0, -3.0, 1.5, -1.0, 4.0, -2.5), dist=(1.0, 0.96, 1.05, 1.02, 0.93, 1.08, 0.9)),
+}
 
 
 def _rot_y(a):
@@ -37,6 +44,11 @@ def _rot_x(a):
     return np.array([[1, 0, 0], [0, c, -s], [0, s, c]], dtype=np.float64)
 
 
+def _rot_z(a):
+    c, s = math.cos(a), math.sin(a)
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]], dtype=np.float64)
+
+
 def feature_intrinsics(feat_h, feat_w):
     """DTU intrinsics divided by 4 (dtu_yao_eval.py:54), rescaled so the same
     field of view covers a feat_h x feat_w feature map (296x400 is native)."""
@@ -47,15 +59,17 @@ def feature_intrinsics(feat_h, feat_w):
     return K
 
 
-def arc_extrinsics(nviews):
+def arc_extrinsics(nviews, rig=0):
     """World->camera [R|t] 4x4 for `nviews` cameras on an arc around the
-    target point (0, 0, 680); view 0 is the reference (identity)."""
-    assert 1 <= nviews <= len(_THETA_DEG)
+    target point (0, 0, 680); view 0 is the reference (identity).  rig 0 = SURVEY 8(d)'s recipe,
+    rig 1 = the second parity scene (wider baselines, roll, unequal distances)."""
+    g = _RIGS[rig]
+    assert 1 <= nviews <= len(g["theta"])
     target = np.array([0.0, 0.0, DTU_TARGET_Z])
     out = []
     for i in range(nviews):
-        R = _rot_y(math.radians(_THETA_DEG[i])) @ _rot_x(math.radians(_PHI_DEG[i]))
-        C = target - R.T @ np.array([0.0, 0.0, DTU_TARGET_Z])
+        R = _rot_z(math.radians(g["psi"][i])) @ _rot_y(math.radians(g["theta"][i])) @ _rot_x(math.radians(g["phi"][i]))
+        C = target - R.T @ np.array([0.0, 0.0, DTU_TARGET_Z * g["dist"][i]])
         t = -R @ C
         E = np.eye(4)
         E[:3, :3] = R
@@ -64,11 +78,11 @@ def arc_extrinsics(nviews):
     return np.stack(out)
 
 
-def proj_matrices(nviews, feat_h, feat_w, batch=1):
+def proj_matrices(nviews, feat_h, feat_w, batch=1, rig=0):
     """[B, V, 4, 4] float32 projection matrices in the reference loader's
     convention (top 3x4 = K @ E[:3,:4])."""
     K = feature_intrinsics(feat_h, feat_w)
-    E = arc_extrinsics(nviews)
+    E = arc_extrinsics(nviews, rig)
     P = E.copy()
     for i in range(nviews):
         P[i, :3, :4] = K @ E[i, :3, :4]
@@ -76,11 +90,11 @@ def proj_matrices(nviews, feat_h, feat_w, batch=1):
     return np.broadcast_to(P, (batch,) + P.shape).copy()
 
 
-def cas_proj_matrices(nviews, feat_h, feat_w, batch=1):
+def cas_proj_matrices(nviews, feat_h, feat_w, batch=1, rig=0):
     """[B, V, 2, 4, 4] CasMVSNet convention: [.,.,0] extrinsic, [.,.,1,:3,:3]
     intrinsic (CasMVSNet/datasets/general_eval.py:158-180)."""
     K = feature_intrinsics(feat_h, feat_w)
-    E = arc_extrinsics(nviews)
+    E = arc_extrinsics(nviews, rig)
     P = np.zeros((nviews, 2, 4, 4), dtype=np.float32)
     for i in range(nviews):
         P[i, 0] = E[i]
@@ -177,12 +191,12 @@ def cas_random_state_dict(seed=0, peaked=100.0):
     return {k: v.clone() for k, v in sd.items()}
 
 
-def cvp_cameras(nsrc, img_h, img_w, batch=1):
+def cvp_cameras(nsrc, img_h, img_w, batch=1, rig=0):
     """CVP-MVSNet convention (CVP-MVSNet/models/net.py:106): full-image intrinsics
     ref_in [B,3,3], src_in [B,nsrc,3,3], extrinsics ref_ex [B,4,4], src_ex [B,nsrc,4,4]
     (float32), depth range [B] each."""
     K = feature_intrinsics(img_h, img_w).astype(np.float32)
-    E = arc_extrinsics(nsrc + 1).astype(np.float32)
+    E = arc_extrinsics(nsrc + 1, rig).astype(np.float32)
     rep = lambda a: np.broadcast_to(a, (batch,) + a.shape).copy()
     return {"ref_in": rep(K), "src_in": rep(np.stack([K] * nsrc)), "ref_ex": rep(E[0]), "src_ex": rep(E[1:]),
             "depth_min": np.full((batch,), DTU_DEPTH_MIN, dtype=np.float32),

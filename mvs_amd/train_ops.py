@@ -23,40 +23,52 @@ class _Conv3dCL(torch.autograd.Function):
     """x [B,D,H,W,Ci] -> raw convolution output [B,Do,Ho,Wo,Co] (no bias, no affine)."""
 
     @staticmethod
-    def forward(ctx, x, weight, transposed, stride):
+    def forward(ctx, x, weight, transposed, stride, tag):
         x = x.contiguous()
         w = weight.detach().contiguous()
         packed = ops.pack_conv3d_weight(w, transposed, stride, split=True)   # (split-operand bf16 kernels where the shape has one)
-        out = ops.conv3d(x, w, None, None, None, False, transposed, stride, channels_last=True,
-                         packed=packed)
+        if ops.split_companion(packed) is not None:
+            ops.split_stage_names.add(f"train.{tag}.fwd")
+        with ops.stage(f"train.{tag}.fwd"):
+            out = ops.conv3d(x, w, None, None, None, False, transposed, stride, channels_last=True,
+                             packed=packed)
         ctx.save_for_backward(x, weight)
-        ctx.cfg = (transposed, stride)
+        ctx.cfg = (transposed, stride, tag)
         return out
 
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
-        transposed, stride = ctx.cfg
+        transposed, stride, tag = ctx.cfg
         g = g.contiguous()
         w = weight.detach()
         gx = gw = None
         if ctx.needs_input_grad[0]:
             if not transposed and stride == 1:
                 wt = w.flip(2, 3, 4).permute(1, 0, 2, 3, 4).contiguous()      # (Ci,Co,k) as a conv weight
-                gx = ops.conv3d(g, wt, channels_last=True, packed=ops.pack_conv3d_weight(wt, False, 1, split=True))
+                pk = ops.pack_conv3d_weight(wt, False, 1, split=True)
+                if ops.split_companion(pk) is not None:
+                    ops.split_stage_names.add(f"train.{tag}.dgrad")
+                with ops.stage(f"train.{tag}.dgrad"):
+                    gx = ops.conv3d(g, wt, channels_last=True, packed=pk)
             elif not transposed:
                 if any(s % 2 for s in x.shape[1:4]):
                     raise ops.MvsHipError("stride-2 conv backward needs even D, H, W")
                 wc = w.contiguous()                                            # (Co,Ci,k) as a deconv weight
-                gx = ops.conv3d(g, wc, transposed=True, stride=2, channels_last=True,
-                                packed=ops.pack_conv3d_weight(wc, True, 2, split=True))
+                pk = ops.pack_conv3d_weight(wc, True, 2, split=True)
+                if ops.split_companion(pk) is not None:
+                    ops.split_stage_names.add(f"train.{tag}.dgrad")
+                with ops.stage(f"train.{tag}.dgrad"):
+                    gx = ops.conv3d(g, wc, transposed=True, stride=2, channels_last=True, packed=pk)
             else:
                 wc = w.contiguous()                                            # (Ci,Co,k) as a conv weight
-                gx = ops.conv3d(g, wc, stride=stride, channels_last=True,
-                                packed=ops.pack_conv3d_weight(wc, False, stride))
+                pk = ops.pack_conv3d_weight(wc, False, stride)
+                with ops.stage(f"train.{tag}.dgrad"):
+                    gx = ops.conv3d(g, wc, stride=stride, channels_last=True, packed=pk)
         if ctx.needs_input_grad[1]:
-            gw = _wgrad(x, g, transposed, stride, weight.shape)
-        return gx, gw, None, None
+            with ops.stage(f"train.{tag}.wgrad"):
+                gw = _wgrad(x, g, transposed, stride, weight.shape)
+        return gx, gw, None, None, None
 
 
 _SPLIT = 16384   # voxels per split-K slice
@@ -105,16 +117,16 @@ def _wgrad(x, g, transposed, stride, wshape):
     return gw
 
 
-def conv3d_cl(x, weight, transposed=False, stride=1):
-    return _Conv3dCL.apply(x, weight, transposed, stride)
+def conv3d_cl(x, weight, transposed=False, stride=1, tag="conv3d"):
+    return _Conv3dCL.apply(x, weight, transposed, stride, tag)
 
 
-def conv_bn_relu_cl(x, conv, bn, transposed=False, stride=1, skip=None):
+def conv_bn_relu_cl(x, conv, bn, transposed=False, stride=1, skip=None, tag="conv3d"):
     """ConvBnReLU3D / deconv block of the reference (module.py:26-33, mvsnet.py:66-79) in
     channels-last with batch statistics when bn.training (running stats are updated); `skip`
     is added after the ReLU (mvsnet.py:89-91).  BatchNorm + ReLU + skip are one fused HIP op
     when the channel count has a kernel, torch ops otherwise."""
-    y = conv3d_cl(x, conv.weight, transposed, stride)
+    y = conv3d_cl(x, conv.weight, transposed, stride, tag)
     C = y.shape[-1]
     if bn.training and C in (8, 16, 32, 64) and bn.momentum is not None and bn.weight is not None:
         return ops.bn_relu_cl(y, bn, True, skip)

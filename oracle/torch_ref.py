@@ -52,9 +52,11 @@ def sweep_grid(src_proj, ref_proj, depth, H, W):
     dev = depth.device
     M = src_proj @ torch.inverse(ref_proj)
     R, t = M[:, :3, :3], M[:, :3, 3:4]
-    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32, device=dev),
-                            torch.arange(W, dtype=torch.float32, device=dev), indexing="ij")
-    pix = torch.stack((xs.reshape(-1), ys.reshape(-1), torch.ones(H * W, device=dev)))
+    # the reference hard-codes float32 here (module.py:67-68); the working dtype is taken from `depth` so that the
+    # same composition can be evaluated in float64 as the "true" answer of the error-budget checks
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=depth.dtype, device=dev),
+                            torch.arange(W, dtype=depth.dtype, device=dev), indexing="ij")
+    pix = torch.stack((xs.reshape(-1), ys.reshape(-1), torch.ones(H * W, dtype=depth.dtype, device=dev)))
     ray = R @ pix.unsqueeze(0).expand(B, 3, H * W)
     pts = ray.unsqueeze(2) * depth.reshape(B, 1, D, -1) + t.reshape(B, 3, 1, 1)
     uv = pts[:, :2] / pts[:, 2:3]
@@ -82,11 +84,53 @@ def variance_volume(features, projs, depth, align_corners=False, alias_quirk=Fal
     ref = features[0].unsqueeze(2).expand(-1, -1, D, -1, -1)
     q = ref * ref
     s = q.clone() if alias_quirk else ref.clone()
+    inplace = not torch.is_grad_enabled()     # the reference's eval branch (mvsnet.py:163-165, 170): same values
     for fea, proj in zip(features[1:], projs[1:]):
         w = warp(fea, proj, projs[0], depth, align_corners)
-        s = s + w
-        q = q + w * w
+        if inplace:
+            s += w
+            q += w.pow_(2)
+        else:
+            s = s + w
+            q = q + w * w
+        del w
+    if inplace:
+        return q.div_(V).sub_(s.div_(V).pow_(2))
     return q / V - (s / V) ** 2
+
+
+_COLUMN_BYTES = 3 << 30   # float64 only: bound on ATen's vol2col buffer per call
+
+
+def conv3d_k3p1(x, w, bias, stride):
+    """F.conv3d(x, w, bias, stride, padding=1) for 3x3x3 kernels.  float32 goes straight to ATen (the
+    reference's call, module.py:29 / mvsnet.py:81).  float64 -- the "true answer" of the error-budget checks --
+    has no oneDNN path: ATen's slow_conv3d materialises a [Cin*27, D*H*W] column buffer (157 GB for conv0 at
+    1600x1184, D=192), so the output depth range is walked in slabs (same sums, plane by plane)."""
+    B, Cin, D, H, W = x.shape
+    if x.dtype != torch.float64 or Cin * 27 * D * H * W * 8 // (stride ** 3) <= _COLUMN_BYTES:
+        return F.conv3d(x, w, bias, stride, 1)
+    Do = (D - 1) // stride + 1
+    per_plane = Cin * 27 * ((H - 1) // stride + 1) * ((W - 1) // stride + 1) * 8
+    ch = max(1, _COLUMN_BYTES // per_plane)
+    xp = F.pad(x, (0, 0, 0, 0, 1, 1))
+    return torch.cat([F.conv3d(xp[:, :, z * stride:(min(Do, z + ch) - 1) * stride + 3], w, bias, stride, (0, 1, 1))
+                      for z in range(0, Do, ch)], 2)
+
+
+def deconv3d_k3s2(x, w):
+    """F.conv_transpose3d(x, w, None, stride=2, padding=1, output_padding=1); float64 in slabs of input
+    planes with overlap-add along depth (see conv3d_k3p1)."""
+    B, Cin, D, H, W = x.shape
+    Cout = w.shape[1]
+    if x.dtype != torch.float64 or Cout * 27 * D * H * W * 8 <= _COLUMN_BYTES:
+        return F.conv_transpose3d(x, w, None, 2, 1, 1)
+    ch = max(1, _COLUMN_BYTES // (Cout * 27 * H * W * 8))
+    full = x.new_zeros(B, Cout, 2 * D + 1, 2 * H, 2 * W)       # un-cropped along depth: p = 2 i + k
+    for a in range(0, D, ch):
+        b = min(D, a + ch)
+        full[:, :, 2 * a:2 * b + 1] += F.conv_transpose3d(x[:, :, a:b], w, None, 2, (0, 1, 1), (0, 1, 1))
+    return full[:, :, 1:2 * D + 1]
 
 
 def cost_reg_net(x, sd, prefix="cost_regularization.", train=False):
@@ -94,11 +138,11 @@ def cost_reg_net(x, sd, prefix="cost_regularization.", train=False):
     bn = _bn_train if train else _bn_eval
 
     def conv(name, t, stride):
-        t = F.conv3d(t, sd[f"{prefix}{name}.conv.weight"], None, stride, 1)
+        t = conv3d_k3p1(t, sd[f"{prefix}{name}.conv.weight"], None, stride)
         return F.relu(bn(t, sd, f"{prefix}{name}.bn"))
 
     def up(name, t):
-        t = F.conv_transpose3d(t, sd[f"{prefix}{name}.0.weight"], None, 2, 1, 1)
+        t = deconv3d_k3s2(t, sd[f"{prefix}{name}.0.weight"])
         return F.relu(bn(t, sd, f"{prefix}{name}.1"))
 
     c0 = conv("conv0", x, 1)
@@ -108,7 +152,7 @@ def cost_reg_net(x, sd, prefix="cost_regularization.", train=False):
     t = c4 + up("conv7", t)
     t = c2 + up("conv9", t)
     t = c0 + up("conv11", t)
-    return F.conv3d(t, sd[prefix + "prob.weight"], sd[prefix + "prob.bias"], 1, 1)
+    return conv3d_k3p1(t, sd[prefix + "prob.weight"], sd[prefix + "prob.bias"], 1)
 
 
 def regress(cost, depth, clamp_idx=False):
@@ -121,7 +165,7 @@ def regress(cost, depth, clamp_idx=False):
     with torch.no_grad():
         padded = F.pad(prob.unsqueeze(1), (0, 0, 0, 0, 1, 2))
         s4 = 4 * F.avg_pool3d(padded, (4, 1, 1), stride=1, padding=0).squeeze(1)
-        ramp = torch.arange(D, dtype=torch.float32, device=cost.device).reshape(1, D, 1, 1)
+        ramp = torch.arange(D, dtype=cost.dtype, device=cost.device).reshape(1, D, 1, 1)
         idx = (prob * ramp).sum(1).long()
         if clamp_idx:
             idx = idx.clamp(0, D - 1)
@@ -175,7 +219,7 @@ def cas_cost_reg_net(x, sd, prefix):
     """[B,Cin,D,H,W] -> [B,1,D,H,W]  (CasMVSNet/models/module.py:407-438; prob has no bias)."""
     def layer(name, t, stride, up=False):
         w = sd[f"{prefix}{name}.conv.weight"]
-        t = F.conv_transpose3d(t, w, None, 2, 1, 1) if up else F.conv3d(t, w, None, stride, 1)
+        t = deconv3d_k3s2(t, w) if up else conv3d_k3p1(t, w, None, stride)
         return F.relu(_bn_eval(t, sd, f"{prefix}{name}.bn"))
 
     c0 = layer("conv0", x, 1)
@@ -185,7 +229,7 @@ def cas_cost_reg_net(x, sd, prefix):
     t = c4 + layer("conv7", t, 2, True)
     t = c2 + layer("conv9", t, 2, True)
     t = c0 + layer("conv11", t, 2, True)
-    return F.conv3d(t, sd[prefix + "prob.weight"], None, 1, 1)
+    return conv3d_k3p1(t, sd[prefix + "prob.weight"], None, 1)
 
 
 def cas_hypotheses(cur, ndepth, interval, H, W):
@@ -255,11 +299,17 @@ def cvp_feature_pyramid(img, sd, nscale, prefix="featurePyramid."):
 def cvp_cost_reg_net(x, sd, prefix="cost_reg_refine."):
     """[B,16,D,H,W] -> [B,D,H,W]  (net.py:53-97)."""
     def cbr(name, t, stride=1):
-        t = F.conv3d(t, sd[f"{prefix}{name}.conv.weight"], None, stride, 1)
+        t = conv3d_k3p1(t, sd[f"{prefix}{name}.conv.weight"], None, stride)
         return F.relu(_bn_eval(t, sd, f"{prefix}{name}.bn"))
 
     def up(name, t, stride, outpad):
-        t = F.conv_transpose3d(t, sd[f"{prefix}{name}.0.weight"], None, stride, 1, outpad)
+        w = sd[f"{prefix}{name}.0.weight"]
+        if t.dtype == torch.float64 and stride == 1:      # = a convolution with the flipped, transposed kernel (slab-wise)
+            t = conv3d_k3p1(t, w.flip(2, 3, 4).transpose(0, 1).contiguous(), None, 1)
+        elif t.dtype == torch.float64:
+            t = deconv3d_k3s2(t, w)
+        else:
+            t = F.conv_transpose3d(t, w, None, stride, 1, outpad)
         return F.relu(_bn_eval(t, sd, f"{prefix}{name}.1"))
 
     c0 = cbr("conv0a", cbr("conv0", x))
@@ -267,7 +317,7 @@ def cvp_cost_reg_net(x, sd, prefix="cost_reg_refine."):
     c4 = cbr("conv4a", cbr("conv4", cbr("conv3", c2)))
     c5 = c2 + up("conv5", c4, 1, 0)
     c6 = c0 + up("conv6", c5, 2, 1)
-    return F.conv3d(c6, sd[prefix + "prob0.weight"], sd[prefix + "prob0.bias"], 1, 1).squeeze(1)
+    return conv3d_k3p1(c6, sd[prefix + "prob0.weight"], sd[prefix + "prob0.bias"], 1).squeeze(1)
 
 
 def _cvp_proj(K, E):
@@ -300,10 +350,10 @@ def cvp_refine_hypotheses(depth_up, Kr, Ks, Er, Es, d=4):
         A = (kr @ er[:3, :3]) @ torch.inverse(ks @ es[:3, :3])
         t1, t2 = z1 * (A @ x1), A @ x3
         M = torch.stack((pix.t()[:, 1:], t2.t()[:, 1:]), 2)
-        step = (torch.inverse(M) @ t1.t()[:, 1:].unsqueeze(2))[:, 0, 0].abs().mean().float()
+        step = (torch.inverse(M) @ t1.t()[:, 1:].unsqueeze(2))[:, 0, 0].abs().mean().to(depth_up.dtype)
         for k in range(-d, d):
             out[b, k + d] += k * step
-    return out.float()
+    return out.to(depth_up.dtype)
 
 
 def cvp_forward(ref_img, src_imgs, ref_in, src_in, ref_ex, src_ex, depth_min, depth_max, sd, nscale):
@@ -328,7 +378,8 @@ def cvp_forward(ref_img, src_imgs, ref_in, src_in, ref_ex, src_ex, depth_min, de
     step = (depth_max[0] - depth_min[0]) / 47
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        hyp = torch.range(float(depth_min[0]), float(depth_max[0]), float(step)).unsqueeze(0).repeat(ref_img.shape[0], 1)
+        hyp = torch.range(float(depth_min[0]), float(depth_max[0]), float(step),
+                          dtype=ref_img.dtype).unsqueeze(0).repeat(ref_img.shape[0], 1)
     depth, conf, _ = regress(level_cost(nscale - 1, hyp), hyp)
     depths = [depth]
     for level in range(nscale - 2, -1, -1):

@@ -59,77 +59,137 @@ def conf_report(prob, clamp, conf, conf_ref, tol=2e-4, sub=1):
     return out
 
 
-def depth_report(d, ref):
+def depth_report(d, ref, truth=None):
+    """max |d - ref| (the gate); with `truth` (the float64 evaluation of the same composition, fixtures *64 keys)
+    also the error budget: how far the HIP result and the reference's float32 result each are from it."""
     e = (d - ref).abs()
-    return {"maxabs_mm": float(e.max()), "p999_mm": float(e.flatten().kthvalue(max(1, int(e.numel() * 0.999))).values)}
+    out = {"maxabs_mm": float(e.max()), "p999_mm": float(e.flatten().kthvalue(max(1, int(e.numel() * 0.999))).values)}
+    if truth is not None:
+        eh, er = (d.double() - truth).abs(), (ref.double() - truth).abs()
+        out.update(hip_vs_f64_mm=float(eh.max()), ref_vs_f64_mm=float(er.max()),
+                   hip_vs_f64_rms=float(eh.pow(2).mean().sqrt()), ref_vs_f64_rms=float(er.pow(2).mean().sqrt()))
+    return out
 
 
-def run_mvsnet(fast):
-    from mvs_amd import ops, synth
+def _dev(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def run_mvsnet_case(case, gold, fast, truth_file=None):
+    """One MVSNet eval forward on a config_cases recipe against fixture `gold` (depth / confidence from the
+    reference; depth64 from the float64 evaluation, possibly in a separate fixture)."""
+    from mvs_amd import ops
     from mvs_amd.models import MVSNet
     dev = torch.device("cuda:0")
-    g = dict(np.load(os.path.join(GOLDEN, "g12_mvsnet_fullsize.npz")))
-    H, W, V, D = (int(x) for x in g["shape"])
-    imgs = torch.from_numpy(synth.images(np.random.default_rng(0), 1, V, H, W)).to(dev)
-    proj = torch.from_numpy(synth.proj_matrices(V, H // 4, W // 4)).to(dev)
-    dv = torch.from_numpy(synth.depth_values(D)).to(dev)
+    g = dict(np.load(os.path.join(GOLDEN, gold + ".npz")))
+    t = dict(np.load(os.path.join(GOLDEN, truth_file + ".npz"))) if truth_file else g
     model = MVSNet(refine=False)
-    model.load_state_dict(synth.random_state_dict(0))
+    model.load_state_dict(case["sd"])
     model = model.to(dev).eval()
     model.variance_fast = fast
     with ProbCapture(ops) as cap:
-        out = model(imgs, proj, dv)
-    res = depth_report(out["depth"], torch.from_numpy(g["depth"]).to(dev))
-    res["conf"] = conf_report(cap.calls[-1][0], cap.calls[-1][1], out["photometric_confidence"],
-                              torch.from_numpy(g["confidence"]).to(dev))
+        out = model(_dev(case["imgs"], dev), _dev(case["proj"], dev), _dev(case["depth_values"], dev))
+    res = depth_report(out["depth"], _dev(g["depth"], dev), _dev(t["depth64"], dev) if "depth64" in t else None)
+    res["conf"] = conf_report(cap.calls[-1][0], cap.calls[-1][1], out["photometric_confidence"], _dev(g["confidence"], dev))
     return res
 
 
-def run_cas():
-    from mvs_amd import ops, synth
+def run_mvsnet(fast, scene=0):
+    import config_cases as cc
+    if scene == 0:
+        return run_mvsnet_case(cc.mvsnet_fullsize_case(0), "g12_mvsnet_fullsize", fast, "g20_mvsnet_fullsize_fp64")
+    return run_mvsnet_case(cc.mvsnet_fullsize_case(scene), f"g19_mvsnet_fullsize_scene{scene}", fast)
+
+
+def run_eval_small(fast):
+    """BASELINE configs[0]: 640x512, N=3, D=48."""
+    import config_cases as cc
+    return run_mvsnet_case(cc.eval_small_case(), "g18_eval_640x512_v3_d48", fast)
+
+
+def run_train_step():
+    """BASELINE configs[4], one GPU's share of a step (640x512, V=3, D=192, B=1): forward(train) -> mvsnet_loss ->
+    backward on the HIP training path against the reference's own step (g17: depth, loss, every parameter gradient,
+    BatchNorm running statistics) and against the float64 evaluation of the same step."""
+    import config_cases as cc
+    from mvs_amd.models import MVSNet, mvsnet_loss
+    dev = torch.device("cuda:0")
+    c = cc.train_case()
+    g = dict(np.load(os.path.join(GOLDEN, "g17_train_640x512_v3_d192.npz")))
+    model = MVSNet(refine=False)
+    model.load_state_dict(c["sd"])
+    model = model.to(dev).train()
+    out = model(_dev(c["imgs"], dev), _dev(c["proj"], dev), _dev(c["depth_values"], dev))
+    loss = mvsnet_loss(out["depth"], _dev(c["gt"], dev), _dev(c["mask"], dev))
+    loss.backward()
+    params = dict(model.named_parameters())
+    names = [str(k) for k in g["grad_names"]]
+    got = torch.cat([params[k].grad.reshape(-1) for k in names]).double().cpu()
+    ref, truth = torch.from_numpy(g["grads"]).double(), torch.from_numpy(g["grads64"])
+    res = {"depth": depth_report(out["depth"].detach(), _dev(g["depth"], dev), _dev(g["depth64"], dev)),
+           "loss": float(loss), "loss_ref": float(g["loss"]), "loss64": float(g["loss64"]), "grads": {}, "stats": {}}
+    off = 0
+    gmax = float(truth.abs().max())
+    res["grads_all"] = {"hip_vs_f64_rms": float((got - truth).pow(2).mean().sqrt()), "ref_vs_f64_rms": float((ref - truth).pow(2).mean().sqrt()),
+                        "hip_vs_ref_rms": float((got - ref).pow(2).mean().sqrt()), "truth_rms": float(truth.pow(2).mean().sqrt())}
+    for k, nel in zip(names, g["grad_sizes"]):
+        a, r, t = got[off:off + nel], ref[off:off + nel], truth[off:off + nel]
+        off += int(nel)
+        # relative to the tensor's largest true gradient (prob.bias: the softmax is shift-invariant, its true
+        # gradient is ~0 -- measured against the largest gradient of the network instead)
+        scale = max(float(t.abs().max()), 1e-6 * gmax)
+        res["grads"][k] = {"hip_vs_f64": float((a - t).abs().max()) / scale, "ref_vs_f64": float((r - t).abs().max()) / scale,
+                           "hip_vs_ref": float((a - r).abs().max()) / scale}
+    sd = model.state_dict()
+    for k in g:
+        if k.startswith("stat__"):
+            res["stats"][k[6:]] = float((sd[k[6:]].cpu() - torch.from_numpy(g[k])).abs().max())
+    return res
+
+
+def run_cas(scene=0):
+    import config_cases as cc
+    from mvs_amd import ops
     from mvs_amd.models.cas_mvsnet import CascadeMVSNet
     dev = torch.device("cuda:0")
-    g = dict(np.load(os.path.join(GOLDEN, "g13_cas_fullsize.npz")))
-    H, W, V = (int(x) for x in g["shape"])
-    imgs = torch.from_numpy(synth.images(np.random.default_rng(0), 1, V, H, W)).to(dev)
-    projs = {f"stage{s + 1}": torch.from_numpy(synth.cas_proj_matrices(V, H // sc, W // sc)).to(dev)
-             for s, sc in enumerate((4, 2, 1))}
-    dv = torch.from_numpy(synth.depth_values(192)).to(dev)
+    g = dict(np.load(os.path.join(GOLDEN, "g13_cas_fullsize.npz" if scene == 0 else f"g21_cas_fullsize_scene{scene}.npz")))
+    c = cc.cas_fullsize_case(scene)
     net = CascadeMVSNet()
-    net.load_state_dict(synth.cas_random_state_dict(0))
+    net.load_state_dict(c["sd"])
     net.eval().to(dev)
     with ProbCapture(ops) as cap:
-        out = net(imgs, projs, dv)
+        out = net(_dev(c["imgs"], dev), {k: _dev(v, dev) for k, v in c["proj"].items()}, _dev(c["depth_values"], dev))
     res = {}
     for i, s in enumerate(("stage1", "stage2", "stage3")):
         sub = 2 if s == "stage3" else 1
-        d, c = out[s]["depth"][:, ::sub, ::sub], out[s]["photometric_confidence"][:, ::sub, ::sub]
-        res[s] = depth_report(d, torch.from_numpy(g[s + "_depth"]).to(dev))
-        res[s]["conf"] = conf_report(cap.calls[i][0], cap.calls[i][1], c, torch.from_numpy(g[s + "_conf"]).to(dev), sub=sub)
+        d, cf = out[s]["depth"][:, ::sub, ::sub], out[s]["photometric_confidence"][:, ::sub, ::sub]
+        res[s] = depth_report(d, _dev(g[s + "_depth"], dev))
+        res[s]["conf"] = conf_report(cap.calls[i][0], cap.calls[i][1], cf, _dev(g[s + "_conf"], dev), sub=sub)
     return res
 
 
-def run_cvp():
-    from mvs_amd import ops, synth
+def run_cvp(scene=0):
+    import config_cases as cc
+    from mvs_amd import ops
     from mvs_amd.models.cvp_mvsnet import network
     dev = torch.device("cuda:0")
-    g = dict(np.load(os.path.join(GOLDEN, "g14_cvp_fullsize.npz")))
-    H, W, nsrc, nscale = (int(x) for x in g["shape"])
-    imgs = torch.from_numpy(synth.images(np.random.default_rng(0), 1, nsrc + 1, H, W)).to(dev)
-    cams = {k: torch.from_numpy(v).to(dev) for k, v in synth.cvp_cameras(nsrc, H, W).items()}
-    net = network(types.SimpleNamespace(nscale=nscale, nsrc=nsrc, mode="test"))
-    net.load_state_dict(synth.cvp_random_state_dict(0))
+    g = dict(np.load(os.path.join(GOLDEN, "g14_cvp_fullsize.npz" if scene == 0 else f"g22_cvp_fullsize_scene{scene}.npz")))
+    c = cc.cvp_fullsize_case(scene)
+    net = network(types.SimpleNamespace(nscale=c["nscale"], nsrc=c["nsrc"], mode="test"))
+    net.load_state_dict(c["sd"])
     net.eval().to(dev)
+    imgs = _dev(c["imgs"], dev)
+    cams = {k: _dev(v, dev) for k, v in c["cams"].items()}
     with ProbCapture(ops) as cap:
         out = net(imgs[:, 0], imgs[:, 1:], cams["ref_in"], cams["src_in"], cams["ref_ex"], cams["src_ex"],
                   cams["depth_min"], cams["depth_max"])
     res = {}
     for i, d in enumerate(out["depth_est_list"]):
-        ref = torch.from_numpy(g[f"depth_level{i}"]).to(dev)
+        ref = _dev(g[f"depth_level{i}"], dev)
         sub = 2 if d.shape[-1] > 1000 else 1
         res[f"level{i}"] = depth_report(d[:, ::sub, ::sub], ref)
-    c = out["prob_confidence"]
-    sub = 2 if c.shape[-1] > 1000 else 1
-    cref = torch.from_numpy(g["prob_confidence"]).to(dev).reshape(c[..., ::sub, ::sub].shape)
-    res["conf"] = conf_report(cap.calls[-1][0], cap.calls[-1][1], c[..., ::sub, ::sub], cref, sub=sub)
+    cf = out["prob_confidence"]
+    sub = 2 if cf.shape[-1] > 1000 else 1
+    cref = _dev(g["prob_confidence"], dev).reshape(cf[..., ::sub, ::sub].shape)
+    res["conf"] = conf_report(cap.calls[-1][0], cap.calls[-1][1], cf[..., ::sub, ::sub], cref, sub=sub)
     return res

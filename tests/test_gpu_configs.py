@@ -1,0 +1,53 @@
+"""BASELINE configs[0] and configs[4] at their own workloads, single GPU (VERDICT r02 items 1 and `configs_untested`).
+
+Fixtures (tests/golden/make_golden_configs.py, build container): the imported reference's float32 outputs AND the same
+composition evaluated in float64 (oracle/torch_ref.py in double) -- the "true" answer both float32 evaluations
+approximate.  Two statements per case:
+  * the north-star gate, |HIP - reference| < 1e-3 mm, for the eval forward;
+  * the error budget: HIP is no farther from the float64 answer than the reference itself is.
+For the train() step (batch-statistics BatchNorm, a softmax sharpened x30: the reference's own float32 step is 0.23 mm and
+1-3 % of the largest gradient away from the float64 step) the second statement IS the gate -- it replaces the hand-set
+atol=5e-2 / 2e-3 * max of round 2's small-fixture test with bounds measured against the truth."""
+import pytest
+import torch
+
+from fullsize_cases import run_eval_small, run_train_step
+
+pytestmark = pytest.mark.gpu
+GATE_MM = 1e-3
+
+
+@pytest.mark.parametrize("fast", [False, True], ids=["exact_coordinates", "fast_coordinates"])
+def test_mvsnet_config0_eval_640x512_v3_d48(fast):
+    """configs[0]: MVSNet/eval.py's forward at 640x512, N=3, D=48 (eval.py:96-131) against g18."""
+    with torch.no_grad():
+        r = run_eval_small(fast)
+    assert r["maxabs_mm"] < GATE_MM, r
+    assert r["hip_vs_f64_mm"] < GATE_MM and r["hip_vs_f64_mm"] <= 1.1 * r["ref_vs_f64_mm"], r
+    assert r["hip_vs_f64_rms"] <= 1.1 * r["ref_vs_f64_rms"], r
+    c = r["conf"]
+    assert c["unexplained"] == 0 and c.get("maxabs_without_flips", c["maxabs"]) < 2e-4, c
+
+
+def test_mvsnet_config4_train_step_640x512_v3_d192():
+    """configs[4], one GPU's share of a step (MVSNet/train.py:204-248 up to loss.backward()): 640x512, V=3, D=192, B=1
+    on the HIP training path against the reference's own step (g17: depth, loss, all 338,129 gradient elements, BatchNorm
+    running statistics) and against the float64 step."""
+    r = run_train_step()
+    d = r["depth"]
+    # forward: as close to the float64 depth as the reference's train() forward is (max and rms)
+    assert d["hip_vs_f64_mm"] <= 1.25 * d["ref_vs_f64_mm"], d
+    assert d["hip_vs_f64_rms"] <= 1.1 * d["ref_vs_f64_rms"], d
+    assert d["maxabs_mm"] <= d["hip_vs_f64_mm"] + d["ref_vs_f64_mm"], d
+    # loss
+    assert abs(r["loss"] - r["loss64"]) <= 2.0 * abs(r["loss_ref"] - r["loss64"]) + 1e-6 * abs(r["loss64"]), r
+    assert abs(r["loss"] - r["loss_ref"]) <= 1e-5 * abs(r["loss_ref"]), r
+    # gradients: over all elements no worse (rms) than the reference's float32 backward; per tensor within 2x of it
+    ga = r["grads_all"]
+    assert ga["hip_vs_f64_rms"] <= 1.1 * ga["ref_vs_f64_rms"], ga
+    assert ga["hip_vs_ref_rms"] <= 0.5 * ga["ref_vs_f64_rms"] + 1e-3 * ga["truth_rms"], ga
+    for k, v in r["grads"].items():
+        assert v["hip_vs_f64"] <= 2.0 * v["ref_vs_f64"] + 1e-4, (k, v)
+    # BatchNorm running statistics after the step (momentum 0.1, unbiased variance)
+    for k, v in r["stats"].items():
+        assert v < 5e-6, (k, v)
