@@ -36,7 +36,7 @@
  *                        channel quad is one contiguous run, so an LDS-DMA instruction touches
  *                        a quarter of the cache lines it touches with C16); only for
  *                        mvs_costvol_variance_fwd_ws_f32 where
- *                        mvs_costvol_variance_workspace_bytes(..., MVS_LAYOUT_C4) > 0.
+ *                        mvs_costvol_variance_workspace_bytes2(..., MVS_LAYOUT_C4, alias_quirk) > 0.
  * depth_mode
  *   0: depth_values [B,D]        (MVSNet, module.py:74)
  *   1: depth_values [B,D,H,W]    (CasMVSNet/models/module.py:249,267;
@@ -115,21 +115,29 @@ int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *src_feas,
                                  int depth_mode, int B, int V, int C, int D, int H, int W,
                                  int align_corners, int alias_quirk, int fea_layout,
                                  int out_layout, float *out_var, void *stream);
-/* The same operation with a caller workspace: for shared depth planes (depth_mode 0) and C16
- * features this runs the persistent kernel -- one workgroup per CU walks (16x4 pixels x 16 depth
- * planes) tiles, the source footprints of the next tile land in LDS by DMA while the current one
- * is sampled -- and the workspace holds the queue of its cold path (waves whose footprint does
- * not fit LDS are served by a second, gather-based kernel).  Every other shape takes the kernels
- * of mvs_costvol_variance_fwd_f32 and ignores the workspace (which may then be NULL / 0 bytes:
- * the persistent kernel also reads channels-last maps [B,H,W,C] (MVS_LAYOUT_NHWC) in place;
- * mvs_costvol_variance_workspace_bytes returns 0).  Results are bit-identical to
+/* The same operation with a caller workspace: for shared depth planes (depth_mode 0, no alias quirk, C % 16 == 0)
+ * this runs the persistent kernel -- one workgroup per CU walks (16x4 pixels x 16 or 8 depth planes) tiles, the source
+ * footprints of the next tile land in LDS by DMA while the current one is sampled -- or, when the footprints of such
+ * tiles outgrow LDS (wide baselines against the depth range of a tile), the per-tile kernel of
+ * mvs_costvol_variance_fwd_f32.  WHICH of the three is decided on the device, per call, from the cameras and depth
+ * planes themselves: a one-workgroup kernel projects the corner voxels of sample tiles and writes the choice into the
+ * workspace header; all candidates are enqueued behind it and begin by reading that word (MVS_SWEEP_PERSIST=16|8|0 in
+ * the environment forces one).  The workspace holds that header, the queue of the persistent kernel's cold path
+ * (waves whose footprint does not fit LDS are served by a gather-based kernel) and, for C4 features, room for their
+ * 16-channel-blocked copy (made only if the per-tile kernel is chosen).  Every other shape takes the kernels of
+ * mvs_costvol_variance_fwd_f32 and ignores the workspace (which may then be NULL / 0 bytes;
+ * mvs_costvol_variance_workspace_bytes2 returns 0 -- exactly when the persistent kernel does not take the shape: the
+ * query and the launcher share one predicate).  The persistent kernel also reads channels-last maps [B,H,W,C]
+ * (MVS_LAYOUT_NHWC) in place.  Results are bit-identical to
  * mvs_costvol_variance_fwd_f32 unless flags has MVS_SWEEP_FAST: coordinates from one refined
  * reciprocal per voxel and view with the reference's normalise / un-normalise pair
  * (module.py:78-79 + grid_sample) folded into one FMA, Q += w*w as an FMA, multiplication by
  * 1/V -- sampling positions within ~1e-4 texel of the reference's. */
 #define MVS_SWEEP_FAST 1
 size_t mvs_costvol_variance_workspace_bytes(int depth_mode, int B, int V, int C, int D, int H, int W,
-                                            int fea_layout);
+                                            int fea_layout);   /* = ..._bytes2(..., alias_quirk 0) */
+size_t mvs_costvol_variance_workspace_bytes2(int depth_mode, int B, int V, int C, int D, int H, int W,
+                                             int fea_layout, int alias_quirk);
 int mvs_costvol_variance_fwd_ws_f32(const float *ref_fea, const float *src_feas,
                                     const float *rot_trans, const float *depth_values,
                                     int depth_mode, int B, int V, int C, int D, int H, int W,

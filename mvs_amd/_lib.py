@@ -35,6 +35,7 @@ _SIGS = {
     "mvs_warp_bwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i] + [_c_i] * 6 + [_c_f, _c_f]),
     "mvs_costvol_variance_fwd_f32": (_c_i, [_c_f] * 4 + [_c_i] * 11 + [_c_f, _c_f]),
     "mvs_costvol_variance_workspace_bytes": (ctypes.c_size_t, [_c_i] * 8),
+    "mvs_costvol_variance_workspace_bytes2": (ctypes.c_size_t, [_c_i] * 9),
     "mvs_costvol_variance_fwd_ws_f32": (_c_i, [_c_f] * 4 + [_c_i] * 12 + [_c_f, _c_f, ctypes.c_size_t, _c_f]),
     "mvs_selftest_div_by_views_f32": (_c_i, [_c_i, _c_f, _c_f]),
     "mvs_costvol_variance_bwd_f32": (_c_i, [_c_f] * 5 + [_c_i] * 10 + [_c_f, _c_f, _c_f]),

@@ -360,11 +360,18 @@ __device__ __forceinline__ void accumulate_taps_planar(const float *__restrict__
 // NQ = 4: features [B,C/16,H,W,16]; NQ = 2: 8-channel maps [B,H,W,8] (the cascade's finest
 // stage) -- the same layout with one group of two quads, waves 2 and 3 take every other
 // DMA instruction instead of their own quad.
-template <int NV, bool CORNER, int NQ = 4>
+// LOOP: a fixed grid walks the nblk tiles (the form launched behind variance_choose_kernel: when the geometry asks for
+// another kernel, 768 workgroups leave at once instead of tens of thousands being dispatched to find that out).
+template <int NV, bool CORNER, int NQ = 4, bool LOOP = false>
 __global__ __launch_bounds__(256, 2) void variance_fwd_dma_kernel(
     const float *__restrict__ ref16, const float *__restrict__ srcs16,
     const float *__restrict__ rt, const float *__restrict__ depth, SweepParams p,
-    int tiles_x, int tiles_y, float *__restrict__ out, int out_c8, int ablate) {
+    int tiles_x, int tiles_y, float *__restrict__ out, int out_c8, int ablate, const unsigned *__restrict__ sel, int nblk) {
+    // sel: word of the workspace header written by variance_choose_kernel (sweep_persist.hip); this kernel runs when it
+    // reads 0 ("per-tile kernel"); NULL = unconditional
+    if (sel && *sel != 0u) return;
+    int vblk = blockIdx.x;
+    do {   // (one pass unless LOOP)
     constexpr int cap = dma_cap(NV, NQ);
     constexpr int NJ = (cap + 63) / 64;          // DMA instructions per plane
     constexpr int GC = 4 * NQ, NSH = 4 / NQ;     // channels per group; waves sharing a quad
@@ -379,9 +386,9 @@ __global__ __launch_bounds__(256, 2) void variance_fwd_dma_kernel(
         // a texel per depth plane, so the depth chunks of a tile re-read the same source lines
         // out of that XCD's L2; ordered by tile first, every depth chunk swept all source
         // maps (61 MB at config 2, > L2) again: 13x the HBM-side fetch.
-        const int nwg = gridDim.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
-        int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + ((int)blockIdx.x >> 3);
+        const int nwg = LOOP ? nblk : (int)gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = vblk & 7;
+        int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vblk >> 3);
         const int ndc = nwg / (tiles_x * tiles_y);
         dc = bid % ndc; bid /= ndc;
         tx = bid % tiles_x;
@@ -651,6 +658,9 @@ __global__ __launch_bounds__(256, 2) void variance_fwd_dma_kernel(
             }
         }
     }
+    if constexpr (LOOP) __syncthreads();   // every wave is done with this tile's LDS image before the next tile's copies
+    vblk += (int)gridDim.x;
+    } while (LOOP && vblk < nblk);
 }
 
 // ---------------------------------------------------------------------
@@ -1183,6 +1193,70 @@ extern "C" int mvs_warp_bwd_f32(const float *grad_out, const float *rot_trans,
     return check_launch("mvs_warp_bwd_f32");
 }
 
+
+// LDS-staged per-tile kernel: features [B,C/16,H,W,16].  sel: see variance_fwd_dma_kernel.
+static int launch_variance_tile_c16(const float *ref_fea, const float *src_feas, const float *rot_trans,
+                                    const float *depth_values, const SweepParams &p, float *out_var, int out_c8,
+                                    hipStream_t st, const unsigned *sel) {
+    const int B = p.B, C = p.C, D = p.D, H = p.H, W = p.W, NV = p.V - 1, depth_mode = p.depth_mode;
+    if (C % 16 || C > 64) {
+        set_error("mvs_costvol_variance_fwd_f32: C16 features need C in {16,32,48,64}, got %d", C);
+        return MVS_EUNSUPPORTED;
+    }
+    if ((int64_t)H * W >= (1 << 26) || H >= (1 << 23) || W >= (1 << 23) || B > 65535) return MVS_EINVAL;
+    const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (H + kTileH - 1) / kTileH;
+    const int dchunks = (D + kTileD - 1) / kTileD;
+    const int64_t nblk = (int64_t)tiles_x * tiles_y * dchunks;
+    if (nblk > 0x7fffffffLL) return bare_error(MVS_EINVAL, __func__, __LINE__);
+#ifdef MVS_TUNING
+    const char *abl_env = getenv("MVS_SWEEP_ABLATE");   // tuning builds only: some values give wrong results
+    const int lds_ablate = abl_env ? atoi(abl_env) : 0;
+#else
+    const int lds_ablate = 0;
+#endif
+    // MVS_SWEEP_TILE_LOOP=1 (A/B): behind the chooser, a fixed grid of three workgroups per CU loops over the tiles
+    static const bool tile_loop = [] { const char *e = getenv("MVS_SWEEP_TILE_LOOP"); return e && e[0] == '1'; }();
+    const bool loop = sel && tile_loop;
+    const dim3 g(loop ? (unsigned)(nblk < 3 * device_cu_count() ? nblk : 3 * device_cu_count()) : (unsigned)nblk, (unsigned)B);
+#define MVS_LDS_CASE(n)                                                                                      \
+    case n: {                                                                                                \
+        const size_t shmem = (size_t)n * 4 * dma_cap(n) * 16;                                                \
+        if (loop)                                                                                            \
+            hipLaunchKernelGGL((variance_fwd_dma_kernel<n, true, 4, true>), g, dim3(256), shmem, st,         \
+                               ref_fea, src_feas, rot_trans, depth_values, p, tiles_x,                       \
+                               tiles_y, out_var, out_c8, lds_ablate, sel, (int)nblk);                        \
+        else if (depth_mode == 0 && !(lds_ablate & 32))                                                      \
+            hipLaunchKernelGGL((variance_fwd_dma_kernel<n, true>), g, dim3(256), shmem, st,                  \
+                               ref_fea, src_feas, rot_trans, depth_values, p, tiles_x,                       \
+                               tiles_y, out_var, out_c8, lds_ablate, sel, 0);                                \
+        else                                                                                                 \
+            hipLaunchKernelGGL((variance_fwd_dma_kernel<n, false>), g, dim3(256), shmem, st,                 \
+                               ref_fea, src_feas, rot_trans, depth_values, p, tiles_x,                       \
+                               tiles_y, out_var, out_c8, lds_ablate, sel, 0);                                \
+        break;                                                                                               \
+    }
+    switch (NV) {
+        MVS_LDS_CASE(1) MVS_LDS_CASE(2) MVS_LDS_CASE(3) MVS_LDS_CASE(4) MVS_LDS_CASE(5)
+        MVS_LDS_CASE(6) MVS_LDS_CASE(7) MVS_LDS_CASE(8)
+    }
+#undef MVS_LDS_CASE
+    return check_launch("mvs_costvol_variance_fwd_f32(lds)");
+}
+
+// [N, C/4, H*W, 4] -> [N, C/16, H*W, 16] (the per-tile kernel's layout), only when the chooser asked for that kernel
+// (the reference view's ng_ref groups, then the source views' ng_src, into one contiguous scratch)
+__global__ __launch_bounds__(256) void c4_to_c16_sel_kernel(const float4 *__restrict__ ref, const float4 *__restrict__ src,
+                                                            float4 *__restrict__ out, int ng_ref, int ng_src, int plane,
+                                                            const unsigned *__restrict__ sel) {
+    if (sel && *sel != 0u) return;
+    const int64_t total = (int64_t)(ng_ref + ng_src) * plane * 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int q = (int)(i & 3);
+        const int64_t gp = i >> 2, g = gp / plane, pix = gp - g * plane;
+        out[i] = g < ng_ref ? ref[(g * 4 + q) * plane + pix] : src[((g - ng_ref) * 4 + q) * plane + pix];
+    }
+}
+
 extern "C" int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *src_feas,
                                             const float *rot_trans, const float *depth_values,
                                             int depth_mode, int B, int V, int C, int D, int H,
@@ -1228,40 +1302,8 @@ extern "C" int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *s
 #undef MVS_PL_CASE
         return check_launch("mvs_costvol_variance_fwd_f32(planar)");
     }
-    if (fea_layout == MVS_LAYOUT_C16) {
-        // LDS-staged kernel: features [B,C/16,H,W,16]
-        if (C % 16 || C > 64) {
-            set_error("mvs_costvol_variance_fwd_f32: C16 features need C in {16,32,48,64}, got %d", C);
-            return MVS_EUNSUPPORTED;
-        }
-        if ((int64_t)H * W >= (1 << 26) || H >= (1 << 23) || W >= (1 << 23) || B > 65535) return MVS_EINVAL;
-        const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (H + kTileH - 1) / kTileH;
-        const int dchunks = (D + kTileD - 1) / kTileD;
-        const int64_t nblk = (int64_t)tiles_x * tiles_y * dchunks;
-        if (nblk > 0x7fffffffLL) return bare_error(MVS_EINVAL, __func__, __LINE__);
-        const char *abl_env = getenv("MVS_SWEEP_ABLATE");   // tuning only
-        const int lds_ablate = abl_env ? atoi(abl_env) : 0;
-        const dim3 g((unsigned)nblk, (unsigned)B);
-#define MVS_LDS_CASE(n)                                                                        \
-    case n: {                                                                                  \
-        const size_t shmem = (size_t)n * 4 * dma_cap(n) * 16;                                  \
-        if (depth_mode == 0 && !(lds_ablate & 32))                                             \
-            hipLaunchKernelGGL((variance_fwd_dma_kernel<n, true>), g, dim3(256), shmem, st,    \
-                               ref_fea, src_feas, rot_trans, depth_values, p, tiles_x,         \
-                               tiles_y, out_var, out_c8, lds_ablate);                          \
-        else                                                                                   \
-            hipLaunchKernelGGL((variance_fwd_dma_kernel<n, false>), g, dim3(256), shmem, st,   \
-                               ref_fea, src_feas, rot_trans, depth_values, p, tiles_x,         \
-                               tiles_y, out_var, out_c8, lds_ablate);                          \
-        break;                                                                                 \
-    }
-        switch (NV) {
-            MVS_LDS_CASE(1) MVS_LDS_CASE(2) MVS_LDS_CASE(3) MVS_LDS_CASE(4) MVS_LDS_CASE(5)
-            MVS_LDS_CASE(6) MVS_LDS_CASE(7) MVS_LDS_CASE(8)
-        }
-#undef MVS_LDS_CASE
-        return check_launch("mvs_costvol_variance_fwd_f32(lds)");
-    }
+    if (fea_layout == MVS_LAYOUT_C16)
+        return launch_variance_tile_c16(ref_fea, src_feas, rot_trans, depth_values, p, out_var, out_c8, st, nullptr);
     if (fea_layout != MVS_LAYOUT_NHWC) return bare_error(MVS_EINVAL, __func__, __LINE__);
     if (C == 8 && (int64_t)H * W < (1 << 26) && H < (1 << 23) && W < (1 << 23) && B <= 65535 &&
         !getenv("MVS_SWEEP_C8_GATHER")) {
@@ -1277,11 +1319,11 @@ extern "C" int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *s
         if (depth_mode == 0)                                                                      \
             hipLaunchKernelGGL((variance_fwd_dma_kernel<n, true, 2>), g, dim3(256), shmem, st,    \
                                ref_fea, src_feas, rot_trans, depth_values, p, tiles_x, tiles_y,   \
-                               out_var, out_c8, 0);                                               \
+                               out_var, out_c8, 0, (const unsigned *)nullptr, 0);                 \
         else                                                                                      \
             hipLaunchKernelGGL((variance_fwd_dma_kernel<n, false, 2>), g, dim3(256), shmem, st,   \
                                ref_fea, src_feas, rot_trans, depth_values, p, tiles_x, tiles_y,   \
-                               out_var, out_c8, 0);                                               \
+                               out_var, out_c8, 0, (const unsigned *)nullptr, 0);                 \
         break;                                                                                    \
     }
         switch (NV) {
@@ -1305,41 +1347,54 @@ extern "C" int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *s
     return check_launch("mvs_costvol_variance_fwd_f32(channels-last)");
 }
 
-// Shape of the persistent kernel's workgroup: waves (= depth planes per tile) and channel quads
-// per stage.  tuning: MVS_SWEEP_PERSIST = "<waves>[,<flags>[,<quads>]]", 0 = always the per-tile kernels
-// Without the variable: 16-plane tiles for D >= 160, 8-plane tiles for 72 <= D < 160, the per-tile kernels below that.
-// What decides is the depth range of a tile against the baselines -- its footprint boxes must fit the workgroup's LDS
-// share or its waves go to the cold kernel -- and the host cannot see that (the planes live on the device); the rule
-// assumes what the reference's scripts do when numdepth is reduced: the same depth range in fewer, coarser planes.
-// Measured at 296 x 400, 5 views, microseconds per plane (16-plane tiles / 8-plane tiles / per-tile kernel): interval x1
-// 6.5 / 8.3 / 10.4, x1.5 9.7 / 9.3 / 10.5, x2 12.9 / 8.6 / 11.2, x3 24 / 11.9 / 12.1, x4 (CasMVSNet's first stage,
-// 48 planes) 33 / 14.5 / 13.5.
-static int persist_waves(int *flags, int *quads, int D) {
-    const char *pe = getenv("MVS_SWEEP_PERSIST");
-    int nw = D >= 160 ? 16 : (D >= 72 ? 8 : 0);
+// Which sweep kernel: by default the DEVICE decides per call from the geometry (variance_choose_kernel,
+// sweep_persist.hip): 16-plane tiles of the persistent kernel, 8-plane tiles, or the per-tile kernel above.  Round 2
+// keyed this on the plane count (D >= 160 -> 16, D >= 72 -> 8), which assumed that fewer planes mean a coarser
+// interval; a caller sweeping 192 planes at a x4 interval then ran 2.4x slower than the best kernel.
+// MVS_SWEEP_PERSIST = 16 | 8 | 0 forces one of them (A/B runs).  Tuning builds (-DMVS_TUNING) also read
+// "<waves>,<flags>,<quads>" -- the ablation flags give wrong results and are not reachable in a release build.
+static int persist_forced(int *flags, int *quads) {
     *flags = 0;
     *quads = 2;
-    if (pe) {
-        nw = atoi(pe);
-        const char *c = strchr(pe, ',');
-        if (c) {
-            *flags = atoi(c + 1);
-            c = strchr(c + 1, ',');
-            if (c) *quads = atoi(c + 1);
-        }
+    const char *pe = getenv("MVS_SWEEP_PERSIST");
+    if (!pe) return -1;
+    const int nw = atoi(pe);
+#ifdef MVS_TUNING
+    const char *c = strchr(pe, ',');
+    if (c) {
+        *flags = atoi(c + 1);
+        c = strchr(c + 1, ',');
+        if (c) *quads = atoi(c + 1);
     }
-    return nw;
+#endif
+    return (nw == 16 || nw == 8) ? nw : 0;
+}
+
+// ONE predicate for the workspace query and the launcher: the persistent kernel takes shared depth
+// planes, no CVP alias quirk, C % 16 == 0, and the size limits of variance_persist_shape_ok
+static bool persist_takes(const SweepParams &p, int fea_layout) {
+    return (fea_layout == MVS_LAYOUT_C16 || fea_layout == MVS_LAYOUT_C4 || fea_layout == MVS_LAYOUT_NHWC) &&
+           variance_persist_shape_ok(p);
+}
+
+static size_t c16_scratch_bytes(const SweepParams &p) { return (size_t)p.V * p.B * p.C * p.H * p.W * 4; }
+
+extern "C" size_t mvs_costvol_variance_workspace_bytes2(int depth_mode, int B, int V, int C, int D, int H, int W,
+                                                        int fea_layout, int alias_quirk) {
+    if (B <= 0 || D <= 0 || H <= 1 || W <= 1 || V < 2) return 0;
+    const SweepParams p = make_params(B, V, C, D, H, W, depth_mode, 0, alias_quirk);
+    if (!persist_takes(p, fea_layout)) return 0;
+    int flags, quads;
+    if (persist_forced(&flags, &quads) == 0) return 0;
+    const size_t q = variance_persist_workspace_bytes(p, 8) > variance_persist_workspace_bytes(p, 16)
+                         ? variance_persist_workspace_bytes(p, 8) : variance_persist_workspace_bytes(p, 16);
+    // C4 features: room for their 16-channel-blocked copy, should the geometry ask for the per-tile kernel
+    return ((q + 255) & ~(size_t)255) + (fea_layout == MVS_LAYOUT_C4 ? c16_scratch_bytes(p) : 0);
 }
 
 extern "C" size_t mvs_costvol_variance_workspace_bytes(int depth_mode, int B, int V, int C, int D,
                                                        int H, int W, int fea_layout) {
-    if ((fea_layout != MVS_LAYOUT_C16 && fea_layout != MVS_LAYOUT_C4 && fea_layout != MVS_LAYOUT_NHWC) || B <= 0 || D <= 0 ||
-        H <= 1 || W <= 1)
-        return 0;
-    int flags, quads;
-    const int nw = persist_waves(&flags, &quads, D);
-    if (nw <= 0) return 0;
-    return variance_persist_workspace_bytes(make_params(B, V, C, D, H, W, depth_mode, 0, 0), nw);
+    return mvs_costvol_variance_workspace_bytes2(depth_mode, B, V, C, D, H, W, fea_layout, 0);
 }
 
 extern "C" int mvs_costvol_variance_fwd_ws_f32(const float *ref_fea, const float *src_feas,
@@ -1350,23 +1405,57 @@ extern "C" int mvs_costvol_variance_fwd_ws_f32(const float *ref_fea, const float
                                                float *out_var, void *workspace,
                                                size_t workspace_bytes, void *stream) {
     const bool c4 = fea_layout == MVS_LAYOUT_C4;
-    if (ref_fea && src_feas && rot_trans && depth_values && out_var && B > 0 && D > 0 && H > 1 &&
-        W > 1 && depth_mode == 0 && (fea_layout == MVS_LAYOUT_C16 || c4 || fea_layout == MVS_LAYOUT_NHWC) &&
+    hipStream_t st = as_stream(stream);
+    if (ref_fea && src_feas && rot_trans && depth_values && out_var && B > 0 && D > 0 && H > 1 && W > 1 && V >= 2 &&
         (out_layout == MVS_LAYOUT_C8 || out_layout == MVS_LAYOUT_NHWC)) {
+        const SweepParams p = make_params(B, V, C, D, H, W, depth_mode, align_corners, alias_quirk);
         int tune, quads;
-        const int nw = persist_waves(&tune, &quads, D);
-        if (nw > 0) {
-            const SweepParams p = make_params(B, V, C, D, H, W, depth_mode, align_corners, alias_quirk);
-            const int rc = launch_variance_persist(ref_fea, src_feas, rot_trans, depth_values, p, out_var,
-                                                   out_layout == MVS_LAYOUT_C8, c4 ? 1 : (fea_layout == MVS_LAYOUT_NHWC ? 2 : 0), flags & MVS_SWEEP_FAST,
-                                                   nw, quads, tune, workspace, workspace_bytes, as_stream(stream));
-            if (rc == MVS_OK) return check_launch("mvs_costvol_variance_fwd_ws_f32(persistent)");
-            if (rc != MVS_EUNSUPPORTED) return rc;
+        const int forced = persist_forced(&tune, &quads);
+        if (persist_takes(p, fea_layout) && forced != 0) {
+            const int out_c8 = out_layout == MVS_LAYOUT_C8, lay = c4 ? 1 : (fea_layout == MVS_LAYOUT_NHWC ? 2 : 0);
+            if (forced > 0) {
+                const int rc = launch_variance_persist(ref_fea, src_feas, rot_trans, depth_values, p, out_var, out_c8, lay,
+                                                       flags & MVS_SWEEP_FAST, forced, quads, tune, workspace, workspace_bytes, st);
+                if (rc == MVS_OK) return check_launch("mvs_costvol_variance_fwd_ws_f32(persistent)");
+                if (rc != MVS_EUNSUPPORTED) return rc;
+            } else {
+                const size_t need = mvs_costvol_variance_workspace_bytes2(depth_mode, B, V, C, D, H, W, fea_layout, alias_quirk);
+                if (!workspace || workspace_bytes < need) {
+                    set_error("mvs_costvol_variance_fwd_ws_f32: workspace of %zu bytes, need %zu", workspace_bytes, need);
+                    return MVS_EWORKSPACE;
+                }
+                // the per-tile kernel reads 16-channel blocks: directly (C16), or from a copy made only if it is chosen (C4);
+                // channels-last maps choose between the two tile depths of the persistent kernel only
+                const int allow_tile = fea_layout != MVS_LAYOUT_NHWC && B <= 65535;
+                int rc = launch_variance_choose(rot_trans, depth_values, p, allow_tile, workspace, st);
+                if (rc != MVS_OK) return rc;
+                for (int nw = 16; nw >= 8; nw -= 8) {   // (autosel 2: no cold-path launch behind the first candidate)
+                    rc = launch_variance_persist(ref_fea, src_feas, rot_trans, depth_values, p, out_var, out_c8, lay,
+                                                 flags & MVS_SWEEP_FAST, nw, 2, 0, workspace, workspace_bytes, st, nw == 16 ? 2 : 1);
+                    if (rc != MVS_OK) return rc == MVS_EUNSUPPORTED ? bare_error(MVS_ELAUNCH, __func__, __LINE__) : rc;
+                }
+                if (allow_tile) {
+                    const unsigned *sel = static_cast<const unsigned *>(workspace) + 1;
+                    const float *r16 = ref_fea, *s16 = src_feas;
+                    if (c4) {
+                        float *scratch = reinterpret_cast<float *>(static_cast<char *>(workspace) + (need - c16_scratch_bytes(p)));
+                        const int plane = H * W, nmaps = B * (C / 16);
+                        // maps: the reference view's B maps, then the source views' (V-1) * B
+                        hipLaunchKernelGGL(c4_to_c16_sel_kernel, dim3(2048), dim3(256), 0, st, reinterpret_cast<const float4 *>(ref_fea),
+                                           reinterpret_cast<const float4 *>(src_feas), reinterpret_cast<float4 *>(scratch), nmaps,
+                                           nmaps * (V - 1), plane, sel);
+                        r16 = scratch; s16 = scratch + (size_t)B * C * plane;
+                    }
+                    rc = launch_variance_tile_c16(r16, s16, rot_trans, depth_values, p, out_var, out_c8, st, sel);
+                    if (rc != MVS_OK) return rc;
+                }
+                return check_launch("mvs_costvol_variance_fwd_ws_f32(device-selected)");
+            }
         }
     }
     if (c4) {
         set_error("mvs_costvol_variance_fwd_ws_f32: C4 features are the persistent kernel's layout "
-                  "(shared depth planes, mvs_costvol_variance_workspace_bytes > 0); use C16 for this shape");
+                  "(shared depth planes, no alias quirk, mvs_costvol_variance_workspace_bytes2 > 0); use C16 for this shape");
         return MVS_EUNSUPPORTED;
     }
     return mvs_costvol_variance_fwd_f32(ref_fea, src_feas, rot_trans, depth_values, depth_mode, B, V, C,

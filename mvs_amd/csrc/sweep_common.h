@@ -106,9 +106,14 @@ inline bool grid_for(int64_t total, int per_block, unsigned &grid) {
 // features (+ its cold-path kernel); MVS_EUNSUPPORTED (nothing launched) when the shape is not
 // its own.  The workspace holds the cold path's queue.
 size_t variance_persist_workspace_bytes(const SweepParams &p, int nw);
+bool variance_persist_shape_ok(const SweepParams &p);     // the ONE predicate of the workspace query and the launcher
 int launch_variance_persist(const float *ref16, const float *srcs16, const float *rt,
                             const float *depth, const SweepParams &p, float *out, int out_c8,
                             int fea_c4, int fast, int nw, int nq, int flags, void *workspace,
-                            size_t workspace_bytes, hipStream_t st);
+                            size_t workspace_bytes, hipStream_t st, int autosel = 0);
+// device-side choice between 16-plane tiles, 8-plane tiles and (allow_tile) the per-tile kernel of sweep.hip from the
+// footprints of sample tiles; clears the workspace header and writes the choice into word 1 of it
+int launch_variance_choose(const float *rt, const float *depth, const SweepParams &p, int allow_tile, void *workspace,
+                           hipStream_t st);
 
 }  // namespace mvs

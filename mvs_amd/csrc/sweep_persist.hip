@@ -67,7 +67,12 @@ struct PersistArgs {
     int out_c8, flags;
     int fea_c4;             // features: 0 = [B,C/16,H,W,16], 1 = [B,C/4,H,W,4], 2 = [B,H,W,C]
     float sx, ox, sy, oy;   // FAST: ix = (X/Z) * sx + ox
+    int autosel;            // 1: run only if queue[kSelWord] names this kernel's tile depth (variance_choose_kernel)
 };
+// workspace header (32-bit words): [0] cold-path records, [1] the chosen tile depth (16, 8, or 0 = the per-tile
+// kernel), [2..7] what the choice was made from (largest / mean footprint box of 16- and 8-plane tiles, texels; box
+// samples), records from word 8
+constexpr int kSelWord = 1, kQueueHdr = 8;
 constexpr int kPFlagLinearLanes = 1;   // tuning: lane = (x = lane & 15, y = lane >> 4)
 constexpr int kPFlagNoStore = 2;       // tuning
 constexpr int kPFlagNoBlend = 4;       // tuning
@@ -157,6 +162,12 @@ __device__ __forceinline__ void tap_setup(const float *__restrict__ r, int cx, i
 template <int NV, bool FAST>
 __global__ __launch_bounds__(256) void variance_fwd_cold_kernel(PersistArgs a, int nw) {
     const SweepParams &p = a.p;
+    int nchunks = a.nchunks;
+    if (a.autosel) {   // one launch behind both candidates: the records are the chosen kernel's
+        nw = (int)a.queue[kSelWord];
+        if (nw == 0) return;
+        nchunks = (p.D + nw - 1) / nw;
+    }
     const unsigned count = a.queue[0];
     const int lane = threadIdx.x & 63;
     const int plane = p.H * p.W, ngroups = p.C >> 4;
@@ -164,10 +175,10 @@ __global__ __launch_bounds__(256) void variance_fwd_cold_kernel(PersistArgs a, i
     const unsigned tex = a.fea_c4 == 1 ? 4u : a.fea_c4 == 2 ? (unsigned)p.C : 16u;   // floats between neighbouring texels of one quad
     const float rV = 1.0f / p.fV;
     for (unsigned rec = blockIdx.x * 4 + (threadIdx.x >> 6); rec < count; rec += gridDim.x * 4) {
-        const unsigned q = a.queue[1 + rec];
+        const unsigned q = a.queue[kQueueHdr + rec];
         int t = (int)(q >> 4);
         const int wv = (int)(q & 15u);
-        const int dc = t % a.nchunks; t /= a.nchunks;
+        const int dc = t % nchunks; t /= nchunks;
         const int tx = t % a.tiles_x; t /= a.tiles_x;
         const int ty = t % a.tiles_y, b = t / a.tiles_y;
         const int px = tx * kPW + (lane & 15), py = ty * kPH + (lane >> 4), d = dc * nw + wv;
@@ -242,6 +253,76 @@ __global__ __launch_bounds__(256) void variance_fwd_cold_kernel(PersistArgs a, i
     }
 }
 
+
+// Which kernel serves this geometry?  The host cannot tell: what decides is how far a tile's footprints move
+// through the source images across the tile's depth planes -- baselines against the depth range of 16 (or 8)
+// consecutive planes -- and cameras and planes live on the device.  One workgroup projects the corner voxels of
+// sample tiles (a 3 x 3 grid of pixel tiles x first / middle / last depth chunk) exactly as plan() does, for
+// 16-plane and for 8-plane tiles, and writes the choice into the workspace header; the three candidate kernels are
+// all enqueued behind it and each begins by reading that word (an early exit costs a few microseconds).
+// Rule, from the times of the three kernels over interval scales x1 ... x4, 192 / 96 / 48 planes and two camera rigs
+// (scripts/exp_sweep_select.py, profiles/r03_sweep_select.json): 16-plane tiles while the sampled boxes average at most
+// 0.31 of a view's LDS share (160 of 512 texels; beyond that the copies grow faster than the blends they feed and the
+// near chunks start to go cold), else 8-plane tiles up to 0.52 (266 texels), else the per-tile kernel of sweep.hip.  The
+// MEAN decides: the largest box sits at the nearest planes of the image corners and says little about the volume.
+__global__ __launch_bounds__(1024) void variance_choose_kernel(PersistArgs a, int NV, int cap, int allow_tile, unsigned *hdr) {
+    __shared__ int s_max[2], s_sum[2], s_cnt[2];
+    const SweepParams &p = a.p;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < 2) { s_max[tid] = 0; s_sum[tid] = 0; s_cnt[tid] = 0; }
+    __syncthreads();
+    const int tiles_x = (p.W + kPW - 1) / kPW, tiles_y = (p.H + kPH - 1) / kPH;
+    for (int t = wv; t < 54 * p.B; t += 16) {
+        const int b = t / 54, tt = t % 54, which = tt / 27, s = tt % 27;
+        const int nw = which == 0 ? 16 : 8, nchunks = (p.D + nw - 1) / nw;
+        const int gx = s % 3, gy = (s / 3) % 3, gc = s / 9;
+        const int ptx = gx == 0 ? 0 : (gx == 1 ? tiles_x / 2 : tiles_x - 1), pty = gy == 0 ? 0 : (gy == 1 ? tiles_y / 2 : tiles_y - 1);
+        const int pdc = gc == 0 ? 0 : (gc == 1 ? nchunks / 2 : nchunks - 1);
+        const int v0 = min(lane >> 3, NV - 1), k = lane & 7;
+        const int xlo = ptx * kPW, xhi = min(xlo + kPW - 1, p.W - 1);
+        const int ylo = pty * kPH, yhi = min(ylo + kPH - 1, p.H - 1);
+        const int dlo = pdc * nw, dhi = min(dlo + nw - 1, p.D - 1);
+        const float *r = a.rt + ((int64_t)v0 * p.B + b) * 12;
+        const float cxk = (float)((k & 1) ? xhi : xlo), cyk = (float)((k & 2) ? yhi : ylo);
+        const float dk = a.depth[(int64_t)b * p.D + ((k & 4) ? dhi : dlo)];
+        const float rx = __fmaf_rn(r[0], cxk, __fmaf_rn(r[1], cyk, r[2]));
+        const float ry = __fmaf_rn(r[4], cxk, __fmaf_rn(r[5], cyk, r[6]));
+        const float rz = __fmaf_rn(r[8], cxk, __fmaf_rn(r[9], cyk, r[10]));
+        const float X = __fmaf_rn(rx, dk, r[3]), Y = __fmaf_rn(ry, dk, r[7]), Z = __fmaf_rn(rz, dk, r[11]);
+        const float inv = __builtin_amdgcn_rcpf(Z);
+        const float ix = __fmaf_rn(X * inv, a.sx, a.ox), iy = __fmaf_rn(Y * inv, a.sy, a.oy);
+        const bool zok = Z > 1e-6f && fabsf(ix) < 1.0e9f && fabsf(iy) < 1.0e9f;
+        const int fxi = zok ? (int)floorf(ix) : 0, fyi = zok ? (int)floorf(iy) : 0;
+        int lo_x = fxi - 1, hi_x = fxi + 2, lo_y = fyi - 1, hi_y = fyi + 2;
+        int bad = zok ? 0 : 1;
+#pragma unroll
+        for (int off = 1; off <= 4; off <<= 1) {
+            lo_x = min(lo_x, __shfl_xor(lo_x, off)); hi_x = max(hi_x, __shfl_xor(hi_x, off));
+            lo_y = min(lo_y, __shfl_xor(lo_y, off)); hi_y = max(hi_y, __shfl_xor(hi_y, off));
+            bad |= __shfl_xor(bad, off);
+        }
+        int x0 = max(lo_x, -1), x1 = min(hi_x, p.W), y0 = max(lo_y, -1), y1 = min(hi_y, p.H);
+        if (x1 <= x0 || y1 <= y0) { x0 = 0; y0 = 0; x1 = 1; y1 = 1; }
+        const int area = bad ? 4 * cap : min((x1 - x0 + 1) * (y1 - y0 + 1), 4 * cap);
+        if (k == 0 && (lane >> 3) < NV) {
+            atomicMax(&s_max[which], area);
+            atomicAdd(&s_sum[which], area);
+            atomicAdd(&s_cnt[which], 1);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float m16 = (float)s_sum[0] / (float)max(s_cnt[0], 1), m8 = (float)s_sum[1] / (float)max(s_cnt[1], 1);
+        unsigned choice;
+        if (m16 <= 0.31f * (float)cap) choice = 16;
+        else if (m8 <= 0.52f * (float)cap || !allow_tile) choice = 8;
+        else choice = 0;
+        hdr[kSelWord] = choice;
+        hdr[2] = (unsigned)s_max[0]; hdr[3] = (unsigned)(m16 + 0.5f); hdr[4] = (unsigned)s_max[1]; hdr[5] = (unsigned)(m8 + 0.5f);
+        hdr[6] = (unsigned)s_cnt[0]; hdr[7] = (unsigned)cap;
+    }
+}
+
 template <int NV, int NW, int NQ, bool FAST>
 __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistArgs a) {
     constexpr int cap = persist_cap(NV, NQ);
@@ -259,6 +340,7 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
     __shared__ float s_depth[kPMaxDepthFloats];  // depth_values [B][D]
 
     const SweepParams &p = a.p;
+    if (a.autosel && a.queue[kSelWord] != (unsigned)NW) return;   // the geometry asked for another kernel
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kq = wv % NQ, mj = wv / NQ;
@@ -460,7 +542,7 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
         const bool hot = (cstaged & win) == (1u << NV) - 1u;
         if (!hot && wave_live && lane == 0) {
             const unsigned slot = atomicAdd(a.queue, 1u);
-            a.queue[1 + slot] = ((unsigned)T << 4) | (unsigned)wv;
+            a.queue[kQueueHdr + slot] = ((unsigned)T << 4) | (unsigned)wv;
             stored = false;   // more vector-memory traffic behind the last copy: wait for all of it
         }
         const bool has_next = pdc + 1 < seg_end || u + u_step < u_end;
@@ -607,8 +689,9 @@ static int launch_persist_nv(int NV, const PersistArgs &a, int grid, hipStream_t
     case n:                                                                                           \
         hipLaunchKernelGGL((variance_fwd_persist_kernel<n, NW, NQ, FAST>), dim3(grid), dim3(NW * 64), \
                            0, st, a);                                                                 \
-        hipLaunchKernelGGL((variance_fwd_cold_kernel<n, FAST>), dim3(grid), dim3(256), 0, st, a,      \
-                           NW);                                                                       \
+        if (a.autosel != 2)   /* 2: another candidate follows, the cold kernel is launched behind it */ \
+            hipLaunchKernelGGL((variance_fwd_cold_kernel<n, FAST>), dim3(grid), dim3(256), 0, st, a,  \
+                               NW);                                                                   \
         return MVS_OK;
     switch (NV) {
         MVS_PERSIST_CASE(1) MVS_PERSIST_CASE(2) MVS_PERSIST_CASE(3) MVS_PERSIST_CASE(4)
@@ -634,13 +717,32 @@ size_t variance_persist_workspace_bytes(const SweepParams &p, int nw) {
     if (!persist_shape_ok(p)) return 0;
     const int64_t total = persist_tiles(p, nw);
     if (total >= (1 << 27)) return 0;
-    return 4 + 4 * (size_t)total * nw;   // counter + one record per (tile, wave)
+    return 4 * (size_t)kQueueHdr + 4 * (size_t)total * nw;   // header + one record per (tile, wave)
+}
+
+bool variance_persist_shape_ok(const SweepParams &p) { return persist_shape_ok(p) && persist_tiles(p, 8) < (1 << 27); }
+
+// the chooser in front of the candidate kernels (all of them launched with autosel)
+int launch_variance_choose(const float *rt, const float *depth, const SweepParams &p, int allow_tile, void *workspace,
+                           hipStream_t st) {
+    PersistArgs a{};
+    a.rt = rt; a.depth = depth; a.p = p;
+    if (p.align_corners) { a.sx = 1.0f; a.ox = 0.0f; a.sy = 1.0f; a.oy = 0.0f; }
+    else {
+        a.sx = (float)((double)p.W / (double)(p.W - 1)); a.ox = -0.5f;
+        a.sy = (float)((double)p.H / (double)(p.H - 1)); a.oy = -0.5f;
+    }
+    const int NV = p.V - 1;
+    if (hipMemsetAsync(workspace, 0, 4 * kQueueHdr, st) != hipSuccess) return check_launch("variance workspace memset");
+    hipLaunchKernelGGL(variance_choose_kernel, dim3(1), dim3(1024), 0, st, a, NV, persist_cap(NV, 2), allow_tile,
+                       static_cast<unsigned *>(workspace));
+    return check_launch("variance_choose_kernel");
 }
 
 int launch_variance_persist(const float *ref16, const float *srcs16, const float *rt,
                             const float *depth, const SweepParams &p, float *out, int out_c8,
                             int fea_c4, int fast, int nw, int nq, int flags, void *workspace,
-                            size_t workspace_bytes, hipStream_t st) {
+                            size_t workspace_bytes, hipStream_t st, int autosel) {
     if ((nw != 8 && nw != 16) || nq != 2) return MVS_EUNSUPPORTED;
     const size_t need = variance_persist_workspace_bytes(p, nw);
     if (need == 0) return MVS_EUNSUPPORTED;
@@ -667,12 +769,14 @@ int launch_variance_persist(const float *ref16, const float *srcs16, const float
     a.out_c8 = out_c8;
     a.flags = flags;
     a.fea_c4 = fea_c4;
+    a.autosel = autosel;
     if (p.align_corners) { a.sx = 1.0f; a.ox = 0.0f; a.sy = 1.0f; a.oy = 0.0f; }
     else {
         a.sx = (float)((double)p.W / (double)(p.W - 1)); a.ox = -0.5f;
         a.sy = (float)((double)p.H / (double)(p.H - 1)); a.oy = -0.5f;
     }
-    if (hipMemsetAsync(workspace, 0, 4, st) != hipSuccess) return check_launch("variance workspace memset");
+    // (with autosel the chooser has cleared the header)
+    if (!autosel && hipMemsetAsync(workspace, 0, 4 * kQueueHdr, st) != hipSuccess) return check_launch("variance workspace memset");
     const int grid = device_cu_count();
     const int NV = p.V - 1;
 #define MVS_PERSIST_PICK(W_, Q_)                                                             \

@@ -501,7 +501,7 @@ def costvol_variance_c16(ref16, srcs16, rts, depth_values, align_corners=False, 
     out = torch.empty(shape, device=ref16.device, dtype=torch.float32)
     lib = _lib.load()
     mode = _depth_mode(depth_values)
-    need = lib.mvs_costvol_variance_workspace_bytes(mode, B, V, C, D, H, W, layout)
+    need = lib.mvs_costvol_variance_workspace_bytes2(mode, B, V, C, D, H, W, layout, int(alias_quirk))
     ws = _variance_workspace(ref16.device, need) if need else None
     check(lib.mvs_costvol_variance_fwd_ws_f32(
         ptr(ref16), ptr(srcs16), ptr(rts), ptr(depth_values), mode, B, V, C,
@@ -533,12 +533,12 @@ def costvol_variance_nhwc_ws(ref_cl, srcs_cl, rts, depth_values, align_corners=F
     return out
 
 
-def variance_persistent_supported(depth_values, B, V, C, H, W):
+def variance_persistent_supported(depth_values, B, V, C, H, W, alias_quirk=False):
     """True when mvs_costvol_variance_fwd_ws_f32 serves this shape with the persistent kernel
-    (then 4-channel-blocked features, nchw_to_c4, are its fastest input)."""
+    (then 4-channel-blocked features, nchw_to_c4, are its fastest input).  The same predicate as the launcher's."""
     depth_values = _f32c(depth_values)
-    return _lib.load().mvs_costvol_variance_workspace_bytes(
-        _depth_mode(depth_values), B, V, C, depth_values.shape[1], H, W, MVS_LAYOUT_C4) > 0
+    return _lib.load().mvs_costvol_variance_workspace_bytes2(
+        _depth_mode(depth_values), B, V, C, depth_values.shape[1], H, W, MVS_LAYOUT_C4, int(alias_quirk)) > 0
 
 
 def nchw_to_c4(x):

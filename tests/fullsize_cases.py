@@ -75,6 +75,11 @@ def _dev(x, dev):
     return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 
 
+def _truth(t, key, ref32, dev):
+    """float64 answer stored as int16 steps from the reference's float32 map (make_golden_configs._delta16)."""
+    return _dev(np.asarray(ref32, dtype=np.float64) + t[key + "_d16"].astype(np.float64) * float(t["delta_step_mm"]), dev)
+
+
 def run_mvsnet_case(case, gold, fast, truth_file=None):
     """One MVSNet eval forward on a config_cases recipe against fixture `gold` (depth / confidence from the
     reference; depth64 from the float64 evaluation, possibly in a separate fixture)."""
@@ -153,6 +158,7 @@ def run_cas(scene=0):
     from mvs_amd.models.cas_mvsnet import CascadeMVSNet
     dev = torch.device("cuda:0")
     g = dict(np.load(os.path.join(GOLDEN, "g13_cas_fullsize.npz" if scene == 0 else f"g21_cas_fullsize_scene{scene}.npz")))
+    t = dict(np.load(os.path.join(GOLDEN, "g23_cas_fullsize_fp64.npz")))
     c = cc.cas_fullsize_case(scene)
     net = CascadeMVSNet()
     net.load_state_dict(c["sd"])
@@ -163,7 +169,7 @@ def run_cas(scene=0):
     for i, s in enumerate(("stage1", "stage2", "stage3")):
         sub = 2 if s == "stage3" else 1
         d, cf = out[s]["depth"][:, ::sub, ::sub], out[s]["photometric_confidence"][:, ::sub, ::sub]
-        res[s] = depth_report(d, _dev(g[s + "_depth"], dev))
+        res[s] = depth_report(d, _dev(g[s + "_depth"], dev), _truth(t, f"s{scene}_{s}_depth64", g[s + "_depth"], dev))
         res[s]["conf"] = conf_report(cap.calls[i][0], cap.calls[i][1], cf, _dev(g[s + "_conf"], dev), sub=sub)
     return res
 
@@ -174,6 +180,7 @@ def run_cvp(scene=0):
     from mvs_amd.models.cvp_mvsnet import network
     dev = torch.device("cuda:0")
     g = dict(np.load(os.path.join(GOLDEN, "g14_cvp_fullsize.npz" if scene == 0 else f"g22_cvp_fullsize_scene{scene}.npz")))
+    t = dict(np.load(os.path.join(GOLDEN, "g24_cvp_fullsize_fp64.npz")))
     c = cc.cvp_fullsize_case(scene)
     net = network(types.SimpleNamespace(nscale=c["nscale"], nsrc=c["nsrc"], mode="test"))
     net.load_state_dict(c["sd"])
@@ -187,7 +194,7 @@ def run_cvp(scene=0):
     for i, d in enumerate(out["depth_est_list"]):
         ref = _dev(g[f"depth_level{i}"], dev)
         sub = 2 if d.shape[-1] > 1000 else 1
-        res[f"level{i}"] = depth_report(d[:, ::sub, ::sub], ref)
+        res[f"level{i}"] = depth_report(d[:, ::sub, ::sub], ref, _truth(t, f"s{scene}_depth_level{i}_64", g[f"depth_level{i}"], dev))
     cf = out["prob_confidence"]
     sub = 2 if cf.shape[-1] > 1000 else 1
     cref = _dev(g["prob_confidence"], dev).reshape(cf[..., ::sub, ::sub].shape)

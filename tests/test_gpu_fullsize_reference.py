@@ -46,20 +46,29 @@ def test_mvsnet_config2_matches_reference_forward(fast, scene):
     _check_conf(r["conf"])
 
 
-def test_cascade_config3_matches_reference_forward():
-    """configs[2]: CascadeMVSNet 1600x1184, N=5, 48/32/8 hypotheses; every stage."""
+@pytest.mark.parametrize("scene", [0, 1], ids=["scene0", "scene1"])
+def test_cascade_config3_matches_reference_forward(scene):
+    """configs[2]: CascadeMVSNet 1600x1184, N=5, 48/32/8 hypotheses; every stage, both scenes (g13 / g21, truths g23)."""
     with torch.no_grad():
-        r = run_cas()
+        r = run_cas(scene)
     for s in ("stage1", "stage2", "stage3"):
         assert r[s]["maxabs_mm"] < GATE_MM, (s, r[s])
+        _check_budget(r[s])
         _check_conf(r[s]["conf"])
 
 
-def test_cvp_config4_matches_reference_forward():
-    """configs[3]: CVP-MVSNet 1920x1056, 7 views, 5 pyramid levels; every level."""
+@pytest.mark.parametrize("scene", [0, 1], ids=["scene0", "scene1"])
+def test_cvp_config4_matches_reference_forward(scene):
+    """configs[3]: CVP-MVSNet 1920x1056, 7 views, 5 pyramid levels; every level, both scenes (g14 / g22, truths g24).
+    Gate against the reference: 1e-3 mm -- or, where the reference's own float32 forward is farther than 0.9e-3 mm from
+    the float64 answer (scene 1, levels 0-2: 0.95e-3 ... 1.14e-3 mm), the reference's distance plus the HIP result's;
+    the error budget (HIP within the gate of the float64 answer and no farther from it than the reference) holds
+    without exception."""
     with torch.no_grad():
-        r = run_cvp()
+        r = run_cvp(scene)
     for k, v in r.items():
         if k.startswith("level"):
-            assert v["maxabs_mm"] < GATE_MM, (k, v)
+            gate = GATE_MM if v["ref_vs_f64_mm"] < 0.9 * GATE_MM else v["ref_vs_f64_mm"] + v["hip_vs_f64_mm"]
+            assert v["maxabs_mm"] < gate, (k, v)
+            _check_budget(v)
     _check_conf(r["conf"])
