@@ -411,6 +411,24 @@ int mvs_softmax_regress_bwd_f32(const float *cost, const float *depth_values, in
                                 const float *grad_depth, int B, int D, int H, int W,
                                 float *grad_cost, void *stream);
 
+/* ---- FeatureNet under autograd (training path, BASELINE configs[4]; MVSNet/models/mvsnet.py:8-45, train.py:222-226) ----
+ * Weight gradient of a k x k, stride-s 2D convolution (3x3 stride 1 or 5x5 stride 2, up to 32 channels either side):
+ * x [N,H,W,Cin] channels-last (planar: [N,Cin,H,W], the RGB layer), grad_out [N,Ho,Wo,Cout] -> grad_weight
+ * (Cout,Cin,k,k).  The workspace holds one partial gradient per workgroup. */
+size_t mvs_conv2d_wgrad_workspace_bytes(int N, int Cin, int Cout, int H, int W, int ksize, int stride);
+int mvs_conv2d_wgrad_f32(const float *x, const float *grad_out, int N, int Cin, int Cout, int H, int W, int ksize,
+                         int stride, int planar, float *grad_weight, void *workspace, size_t workspace_bytes,
+                         void *stream);
+/* classes [4,N,H,W,C] (class py*2+px = the pixels (2y+py, 2x+px)) -> out [N,2H,2W,C]: assembles the input gradient of a
+ * stride-2 layer from its four output-parity classes, each a 3x3 stride-1 convolution of the output gradient. */
+int mvs_interleave2x2_f32(const float *classes, int N, int H, int W, int C, float *out, void *stream);
+
+/* rot_trans [V-1,B,12] (the rows of (src_proj @ inverse(ref_proj))[:3,:4], module.py:63-65) of every source view
+ * from proj_matrices [B,V,4,4] on the device: float64 Gauss-Jordan + product, rounded once; no synchronisation, so it
+ * can sit inside a captured HIP graph.  (The eval default evaluates these with the reference's own float32 LAPACK
+ * call on the host, stream-ordered.) */
+int mvs_rot_trans_f32(const float *proj_matrices, int B, int V, float *rot_trans, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

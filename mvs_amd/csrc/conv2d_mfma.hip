@@ -292,6 +292,7 @@ static bool lookup_persist2(int Cin, int Cout, int ksize, int stride, Persist2In
     MVS_P2(8, 32, 1, 1, 0, 32)    // inner2
     MVS_P2(32, 16, 3, 1, 0, 32)   // out2
     MVS_P2(32, 8, 3, 1, 2, 32)    // out3
+    MVS_P2(16, 8, 3, 1, 2, 32)    // input gradient of feature.conv2 (5x5 stride 2, 8 -> 16): its four parity classes
     // CVP-MVSNet feature pyramid
     MVS_P2(64, 32, 3, 1, 0, 32)   // conv0bc
     // ((32,16) conv0bf, (32,32) conv0bd/be and (16,16) conv0bg/bh: entries above)

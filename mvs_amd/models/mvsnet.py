@@ -81,15 +81,14 @@ class FeatureNet(nn.Module):
         return all(p["packed"] is not None for p in self._hip_params())
 
     def forward_train_hip(self, img_nchw):
-        """Autograd path on the HIP 2D kernels: [N,3,H,W] -> [N,32,H/4,W/4] (the planar layout
-        the autograd variance op takes), batch-statistics BatchNorm as in forward()."""
+        """Autograd path on the HIP 2D kernels, forward and both gradients (mvs_amd/train_ops.py: no MIOpen):
+        [N,3,H,W] -> [N,H/4,W/4,32] channels-last, batch-statistics BatchNorm (fused HIP op) as in forward()."""
         from ..train_ops import conv2d_bn_relu_cl, conv2d_cl
         x = conv2d_bn_relu_cl(img_nchw, self.conv0.conv, self.conv0.bn, 1, planar=True)
         for name, stride in self._PLAN[1:]:
             m = getattr(self, name)
             x = conv2d_bn_relu_cl(x, m.conv, m.bn, stride)
-        x = conv2d_cl(x, self.feature.weight, 1) + self.feature.bias
-        return x.permute(0, 3, 1, 2).contiguous()
+        return conv2d_cl(x, self.feature.weight, 1) + self.feature.bias      # [N,H/4,W/4,32] channels-last
 
     def forward_train_cl(self, img_nchw):
         """Autograd path in channels-last: torch's conv2d (MIOpen NHWC kernels, forward and both
@@ -289,6 +288,7 @@ class MVSNet(nn.Module):
         self.refine = refine
         self.align_corners = align_corners
         self.proj_where = proj_where
+        self.train_proj_where = "device"
         self.variance_impl = "lds"      # "lds" (LDS-staged source tiles) | "gather"
         # True (eval default): MVS_SWEEP_FAST -- sampling positions within ~1e-4 texel of the
         # reference's, 0.25 ms less per view; the depth map stays as close to the reference's CPU
@@ -297,10 +297,10 @@ class MVSNet(nn.Module):
         self.variance_fast = True
         self.feature_impl = "hip"       # "hip" (2D MFMA kernels) | "torch" (PyTorch-ROCm / MIOpen)
         self.train_impl = "hip"         # CostRegNet autograd convs: "hip" (MFMA fwd+dgrad) | "torch"
-        # FeatureNet autograd: "torch_cl" = MIOpen's NHWC 2D kernels + the fused HIP BatchNorm/ReLU
-        # (fastest), "torch" = plain nn modules, "hip" = the 2D MFMA kernels (torch-side wgrad)
-        self.train_feature_impl = "torch_cl"
-                                            # (1.6 ms backward); "hip" = mvs_amd.train_ops.conv2d_cl
+        # FeatureNet autograd: "hip" (default since round 3) = the HIP 2D kernels forward, input gradient and weight
+        # gradient (mvs_amd.train_ops.conv2d_cl) + the fused HIP BatchNorm/ReLU; "torch_cl" = MIOpen's NHWC 2D
+        # kernels + the fused HIP BatchNorm/ReLU (A/B); "torch" = plain nn modules
+        self.train_feature_impl = "hip"
         self._feature_cl = False
         self.feature = FeatureNet()
         self.cost_regularization = CostRegNet()
@@ -330,14 +330,18 @@ class MVSNet(nn.Module):
         if autograd_path and features is not None:
             raise ops.MvsHipError("forward: precomputed features are an inference-path input (model.eval(), torch.no_grad())")
         if autograd_path:
-            # the host hop of rot_trans is stream-ordered and runs under FeatureNet (no device sync)
-            rt_job = ops.HostRotTrans(proj_matrices) if self.proj_where == "host" and proj_matrices.is_cuda else None
+            # training: rot_trans on the device (mvs_rot_trans_f32, float64 internally; no host hop -- the hop's D2H /
+            # host function / H2D cost the launching thread ~3 ms of a 13 ms step once FeatureNet ran on the HIP
+            # kernels).  train_proj_where = "host" restores the reference's float32 LAPACK inverse (stream-ordered hop).
+            where = self.train_proj_where if proj_matrices.is_cuda else self.proj_where
+            rt_job = ops.HostRotTrans(proj_matrices) if where == "host" and proj_matrices.is_cuda else None
             with ops.stage("feature"):
                 # per-view calls: BatchNorm batch statistics are per call in the
                 # reference (mvsnet.py:146)
                 feats_cl = None
                 if self.train_feature_impl == "hip" and self.feature.hip_supported():
-                    feats = [self.feature.forward_train_hip(imgs[:, v]) for v in range(V)]
+                    feats_cl = [self.feature.forward_train_hip(imgs[:, v]) for v in range(V)]   # [B,h,w,C]
+                    feats = [f.permute(0, 3, 1, 2) for f in feats_cl]
                 elif self.train_feature_impl == "torch_cl" and self.feature.training:
                     if not self._feature_cl:   # weights in NHWC once, not re-laid-out by every conv2d call
                         self.feature.to(memory_format=torch.channels_last)
@@ -348,7 +352,7 @@ class MVSNet(nn.Module):
                     feats = [self.feature(imgs[:, v]) for v in range(V)]
             with ops.stage("rot_trans"):
                 rts = rt_job.result() if rt_job is not None else \
-                    ops.rot_trans_all(proj_matrices, self.proj_where)   # [V-1,B,12]
+                    ops.rot_trans_all(proj_matrices, where)   # [V-1,B,12]
             C = feats[0].shape[1]
             if self.train_impl == "hip" and C % 16 == 0 and depth_values.dim() == 2:
                 # channels-last all the way: 16-channel-blocked maps (torch layout ops, in the

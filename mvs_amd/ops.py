@@ -124,6 +124,13 @@ def rot_trans_all(proj_matrices, where="host", device=None):
     shapes ([B,4,4] @ inverse([B,4,4]), module.py:63), so the values are bit-identical
     to calling rot_trans per view."""
     dev = device if device is not None else proj_matrices.device
+    if where == "device" and proj_matrices.is_cuda:
+        # mvs_rot_trans_f32: float64 Gauss-Jordan on the device, no synchronisation (torch.inverse checks LAPACK's
+        # info word on the host: it cannot be captured into a HIP graph and stalls the launching thread)
+        P = _f32c(proj_matrices.detach())
+        out = torch.empty(P.shape[1] - 1, P.shape[0], 12, device=P.device, dtype=torch.float32)
+        check(_lib.load().mvs_rot_trans_f32(ptr(P), P.shape[0], P.shape[1], ptr(out), stream()), "mvs_rot_trans_f32")
+        return out
     with torch.no_grad():
         P = proj_matrices.detach().float()
         if where == "host":
@@ -965,6 +972,35 @@ def conv3d_wgrad(x_cl, g_cl, stride):
     return gw
 
 
+def conv2d_wgrad(x, g_cl, ksize, stride, planar=False):
+    """Weight gradient of a 2D layer on the matrix cores (mvs_conv2d_wgrad_f32): x [N,H,W,Cin] channels-last (planar:
+    [N,Cin,H,W]), g_cl [N,Ho,Wo,Cout] -> (Cout,Cin,k,k)."""
+    x, g_cl = _f32c(x), _f32c(g_cl)
+    if planar:
+        N, cin, H, W = x.shape
+    else:
+        N, H, W, cin = x.shape
+    cout = g_cl.shape[-1]
+    lib = _lib.load()
+    nbytes = int(lib.mvs_conv2d_wgrad_workspace_bytes(N, cin, cout, H, W, ksize, stride))
+    if nbytes == 0:
+        raise MvsHipError(f"conv2d_wgrad: no kernel for k={ksize} stride={stride} Cin={cin} Cout={cout}")
+    gw = torch.empty((cout, cin, ksize, ksize), device=x.device, dtype=torch.float32)
+    ws = torch.empty((nbytes // 4,), device=x.device, dtype=torch.float32)
+    check(lib.mvs_conv2d_wgrad_f32(ptr(x), ptr(g_cl), N, cin, cout, H, W, ksize, stride, int(planar), ptr(gw), ptr(ws),
+                                   nbytes, stream()), "mvs_conv2d_wgrad_f32")
+    return gw
+
+
+def interleave2x2(classes):
+    """[4,N,H,W,C] (class py*2+px holds the pixels (2y+py, 2x+px)) -> [N,2H,2W,C]."""
+    classes = _f32c(classes)
+    _, N, H, W, C = classes.shape
+    out = torch.empty((N, 2 * H, 2 * W, C), device=classes.device, dtype=torch.float32)
+    check(_lib.load().mvs_interleave2x2_f32(ptr(classes), N, H, W, C, ptr(out), stream()), "mvs_interleave2x2_f32")
+    return out
+
+
 def geo_consistency_matrices(K_ref, E_ref, src_Ks, src_Es):
     """The fp32 matrices of mvs_geo_consistency_f32, composed on the host with the numpy calls
     the reference makes per pair (eval.py:155-178): inverse(K_ref), K_ref, then per source view
@@ -1135,7 +1171,7 @@ def feature_head(img_nchw, w0, scale0, shift0, packed1, scale1, shift1):
 
 
 def conv2d(x, packed, cin, cout, ksize, stride, scale=None, shift=None, relu=False, planar=False, coarse=None,
-           out_c4=False):
+           out_c4=False, out=None):
     """FeatureNet convolution.  x: [B,H,W,cin] channels-last, or (planar) the [B,3,H,W]
     image.  relu: False/True, or 2 for LeakyReLU(0.1).  coarse: [B,Ho/2,Wo/2,cout], added through
     a nearest x2 upsample (FPN top-down step).  Returns [B,Ho,Wo,cout] channels-last, or with out_c4
@@ -1148,11 +1184,15 @@ def conv2d(x, packed, cin, cout, ksize, stride, scale=None, shift=None, relu=Fal
     pad = ksize // 2
     Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
     sp = split_companion(packed)
-    if sp is not None and (ksize, stride) in ((3, 1), (5, 2)) and not planar and coarse is None:
-        out = conv_split(x, sp, cout, scale, shift, None, int(relu), kd=1, out_c4=out_c4, stride=stride, soft=True)
-        if out is not None:       # else: beyond the split launcher's 32-bit halo offsets -> the fp32 MFMA kernel
-            return out
-    out = torch.empty((B, cout // 4, Ho, Wo, 4) if out_c4 else (B, Ho, Wo, cout), device=x.device, dtype=torch.float32)
+    if sp is not None and (ksize, stride) in ((3, 1), (5, 2)) and not planar and coarse is None and out is None:
+        res = conv_split(x, sp, cout, scale, shift, None, int(relu), kd=1, out_c4=out_c4, stride=stride, soft=True)
+        if res is not None:       # else: beyond the split launcher's 32-bit halo offsets -> the fp32 MFMA kernel
+            return res
+    shape = (B, cout // 4, Ho, Wo, 4) if out_c4 else (B, Ho, Wo, cout)
+    if out is None:
+        out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    elif tuple(out.shape) != shape or not out.is_contiguous() or out.dtype != torch.float32:
+        raise MvsHipError(f"conv2d: out must be a contiguous float32 tensor of shape {shape}")
     if coarse is not None:
         coarse = _f32c(coarse)
         if tuple(coarse.shape) != (B, Ho // 2, Wo // 2, cout) or Ho % 2 or Wo % 2:

@@ -19,6 +19,25 @@ import torch.nn.functional as F
 from . import ops
 
 
+_derived = {}
+
+
+def _cached(weight, kind, make):
+    """Tensors derived from a layer's weight (packed fragments, flipped / transposed / parity-class weights), made once
+    per weight VERSION: a step uses each of them in the forward and the backward of every view, and re-deriving them
+    (a flip, a permute, a pack launch, ...) per use was hundreds of tiny launches per step.  Keyed on the storage, so
+    the optimizer's in-place update (which bumps _version) invalidates the entry."""
+    key = (weight.data_ptr(), tuple(weight.shape), kind)
+    hit = _derived.get(key)
+    if hit is not None and hit[0] == weight._version:
+        return hit[1]
+    val = make()
+    if len(_derived) > 4096:
+        _derived.clear()
+    _derived[key] = (weight._version, val)
+    return val
+
+
 class _Conv3dCL(torch.autograd.Function):
     """x [B,D,H,W,Ci] -> raw convolution output [B,Do,Ho,Wo,Co] (no bias, no affine)."""
 
@@ -26,7 +45,8 @@ class _Conv3dCL(torch.autograd.Function):
     def forward(ctx, x, weight, transposed, stride, tag):
         x = x.contiguous()
         w = weight.detach().contiguous()
-        packed = ops.pack_conv3d_weight(w, transposed, stride, split=True)   # (split-operand bf16 kernels where the shape has one)
+        # (split-operand bf16 kernels where the shape has one)
+        packed = _cached(weight, ("pk3", transposed, stride), lambda: ops.pack_conv3d_weight(w, transposed, stride, split=True))
         if ops.split_companion(packed) is not None:
             ops.split_stage_names.add(f"train.{tag}.fwd")
         with ops.stage(f"train.{tag}.fwd"):
@@ -45,8 +65,8 @@ class _Conv3dCL(torch.autograd.Function):
         gx = gw = None
         if ctx.needs_input_grad[0]:
             if not transposed and stride == 1:
-                wt = w.flip(2, 3, 4).permute(1, 0, 2, 3, 4).contiguous()      # (Ci,Co,k) as a conv weight
-                pk = ops.pack_conv3d_weight(wt, False, 1, split=True)
+                wt, pk = _cached(weight, "dgrad3_s1", lambda: (lambda t: (t, ops.pack_conv3d_weight(t, False, 1, split=True)))(
+                    w.flip(2, 3, 4).permute(1, 0, 2, 3, 4).contiguous()))        # (Ci,Co,k) as a conv weight
                 if ops.split_companion(pk) is not None:
                     ops.split_stage_names.add(f"train.{tag}.dgrad")
                 with ops.stage(f"train.{tag}.dgrad"):
@@ -55,14 +75,14 @@ class _Conv3dCL(torch.autograd.Function):
                 if any(s % 2 for s in x.shape[1:4]):
                     raise ops.MvsHipError("stride-2 conv backward needs even D, H, W")
                 wc = w.contiguous()                                            # (Co,Ci,k) as a deconv weight
-                pk = ops.pack_conv3d_weight(wc, True, 2, split=True)
+                pk = _cached(weight, "dgrad3_s2", lambda: ops.pack_conv3d_weight(wc, True, 2, split=True))
                 if ops.split_companion(pk) is not None:
                     ops.split_stage_names.add(f"train.{tag}.dgrad")
                 with ops.stage(f"train.{tag}.dgrad"):
                     gx = ops.conv3d(g, wc, transposed=True, stride=2, channels_last=True, packed=pk)
             else:
                 wc = w.contiguous()                                            # (Ci,Co,k) as a conv weight
-                pk = ops.pack_conv3d_weight(wc, False, stride)
+                pk = _cached(weight, ("dgrad3_t", stride), lambda: ops.pack_conv3d_weight(wc, False, stride))
                 with ops.stage(f"train.{tag}.dgrad"):
                     gx = ops.conv3d(g, wc, stride=stride, channels_last=True, packed=pk)
         if ctx.needs_input_grad[1]:
@@ -144,17 +164,42 @@ def _bn_relu_torch(y, bn):
 
 
 # ------------------------------------------------------------------ FeatureNet (2D)
+_parity_index = {}
+
+
+def _parity_weights(w):
+    """The input gradient of a 5x5 stride-2 layer (padding 2) as four 3x3 stride-1 convolutions of the output gradient,
+    one per parity class (py, px) of the input pixel: gx[2a+py][2b+px][ci] = sum_{co,ty,tx} Wc[ci][co][ty][tx] *
+    g[a+ty-1][b+tx-1][co] with Wc[ci][co][ty][tx] = w[co][ci][py+4-2ty][px+4-2tx] (zero where that index leaves 0..4).
+    -> [4, Cin, Cout, 3, 3] (one gather)."""
+    idx = _parity_index.get(w.device)
+    if idx is None:
+        k = torch.tensor([[p + 4 - 2 * t for t in range(3)] for p in (0, 1)])          # [parity, tap]
+        ok = ((k >= 0) & (k <= 4)).float()
+        k = k.clamp(0, 4)
+        ky = k[[0, 0, 1, 1]][:, :, None].expand(4, 3, 3)
+        kx = k[[0, 1, 0, 1]][:, None, :].expand(4, 3, 3)
+        mask = ok[[0, 0, 1, 1]][:, :, None] * ok[[0, 1, 0, 1]][:, None, :]
+        idx = _parity_index[w.device] = (ky.to(w.device), kx.to(w.device), mask.to(w.device))
+    ky, kx, mask = idx
+    wt = w.permute(1, 0, 2, 3)                                   # [Cin, Cout, 5, 5]
+    return (wt[:, :, ky, kx] * mask).permute(2, 0, 1, 3, 4).contiguous()
+
+
 class _Conv2dCL(torch.autograd.Function):
-    """x [N,H,W,Ci] (or the planar [N,3,H,W] image for the RGB layer) -> raw convolution
-    output [N,Ho,Wo,Co] on the 2D MFMA kernels.  k in {3 (stride 1), 5 (stride 2)}."""
+    """x [N,H,W,Ci] channels-last (planar: the [N,3,H,W] image) -> raw convolution output [N,Ho,Wo,Co]: forward, input
+    gradient and weight gradient on the HIP kernels (no MIOpen): the input gradient of a 3x3 stride-1 layer is the
+    same layer shape with flipped, transposed weights; of a 5x5 stride-2 layer, four 3x3 stride-1 convolutions (one per
+    output parity) + mvs_interleave2x2_f32; the weight gradient is mvs_conv2d_wgrad_f32."""
 
     @staticmethod
     def forward(ctx, x, weight, stride, planar):
         x = x.contiguous()
         w = weight.detach().contiguous()
         cout, cin, k, _ = w.shape
-        out = ops.conv2d(x, ops.pack_conv2d_weight(w, stride), cin, cout, k, stride, None, None,
-                         False, planar=planar)
+        pk = _cached(weight, ("pk2", stride), lambda: ops.pack_conv2d_weight(w, stride, split=True))
+        with ops.stage("train.feature.fwd"):
+            out = ops.conv2d(x, pk, cin, cout, k, stride, None, None, False, planar=planar)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, planar)
         return out
@@ -168,23 +213,26 @@ class _Conv2dCL(torch.autograd.Function):
         cout, cin, k, _ = w.shape
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            if stride == 1 and ops.conv2d_supported(cout, cin, k, 1) and not planar:
-                wt = w.flip(2, 3).permute(1, 0, 2, 3).contiguous()
-                gx = ops.conv2d(g, ops.pack_conv2d_weight(wt, 1), cout, cin, k, 1)
-            else:   # 5x5 stride-2 layers: transposed convolution through torch (NHWC views)
-                gx = F.conv_transpose2d(g.permute(0, 3, 1, 2), w, None, stride, k // 2, stride - 1)
-                gx = gx if planar else gx.permute(0, 2, 3, 1).contiguous()
+            H, W = (x.shape[2], x.shape[3]) if planar else (x.shape[1], x.shape[2])
+            with ops.stage("train.feature.dgrad"):
+                if stride == 1 and ops.conv2d_supported(cout, cin, k, 1) and not planar:
+                    pk = _cached(weight, "dgrad2_s1", lambda: ops.pack_conv2d_weight(
+                        w.flip(2, 3).permute(1, 0, 2, 3).contiguous(), 1, split=True))
+                    gx = ops.conv2d(g, pk, cout, cin, k, 1)
+                elif stride == 2 and k == 5 and not planar and H % 2 == 0 and W % 2 == 0 and \
+                        ops.conv2d_supported(cout, cin, 3, 1):
+                    N, Ho, Wo, _ = g.shape
+                    cls = torch.empty(4, N, Ho, Wo, cin, device=g.device, dtype=torch.float32)
+                    pks = _cached(weight, "dgrad2_parity", lambda: [ops.pack_conv2d_weight(wc, 1) for wc in _parity_weights(w)])
+                    for i, pk in enumerate(pks):
+                        ops.conv2d(g, pk, cout, cin, 3, 1, out=cls[i])
+                    gx = ops.interleave2x2(cls)
+                else:   # odd image sizes: transposed convolution through torch (NHWC views)
+                    gx = F.conv_transpose2d(g.permute(0, 3, 1, 2), w, None, stride, k // 2, stride - 1)
+                    gx = gx if planar else gx.permute(0, 2, 3, 1).contiguous()
         if ctx.needs_input_grad[1]:
-            xcl = x.permute(0, 2, 3, 1) if planar else x
-            pad = k // 2
-            xp = F.pad(xcl, (0, 0, pad, pad, pad, pad))
-            _, Ho, Wo, Co = g.shape
-            g2 = g.reshape(-1, Co)
-            gw = torch.empty(w.shape, device=x.device, dtype=torch.float32)
-            for ky in range(k):
-                for kx in range(k):
-                    xv = xp[:, ky:ky + stride * Ho:stride, kx:kx + stride * Wo:stride, :]
-                    gw[:, :, ky, kx] = _tall_gemm_t(g2, xv.reshape(g2.shape[0], -1))
+            with ops.stage("train.feature.wgrad"):
+                gw = ops.conv2d_wgrad(x, g, k, stride, planar)
         return gx, gw, None, None
 
 
@@ -193,10 +241,12 @@ def conv2d_cl(x, weight, stride=1, planar=False):
 
 
 def conv2d_bn_relu_cl(x, conv, bn, stride=1, planar=False):
-    """ConvBnReLU of the reference (module.py:6-13) in channels-last, batch statistics when
-    bn.training."""
+    """ConvBnReLU of the reference (module.py:6-13) in channels-last: the HIP convolution + the fused HIP BatchNorm
+    (batch statistics when bn.training, running statistics updated) + ReLU."""
     y = conv2d_cl(x, conv.weight, stride, planar)
     C = y.shape[-1]
+    if bn.training and C in (8, 16, 32, 64) and bn.momentum is not None and bn.weight is not None:
+        return ops.bn_relu_cl(y, bn)
     y2 = F.batch_norm(y.reshape(-1, C), bn.running_mean, bn.running_var, bn.weight, bn.bias,
                       bn.training, bn.momentum, bn.eps)
     if bn.training and bn.num_batches_tracked is not None:

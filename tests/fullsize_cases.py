@@ -132,7 +132,7 @@ def run_train_step():
     got = torch.cat([params[k].grad.reshape(-1) for k in names]).double().cpu()
     ref, truth = torch.from_numpy(g["grads"]).double(), torch.from_numpy(g["grads64"])
     res = {"depth": depth_report(out["depth"].detach(), _dev(g["depth"], dev), _dev(g["depth64"], dev)),
-           "loss": float(loss), "loss_ref": float(g["loss"]), "loss64": float(g["loss64"]), "grads": {}, "stats": {}}
+           "loss": float(loss.detach()), "loss_ref": float(g["loss"]), "loss64": float(g["loss64"]), "grads": {}, "stats": {}}
     off = 0
     gmax = float(truth.abs().max())
     res["grads_all"] = {"hip_vs_f64_rms": float((got - truth).pow(2).mean().sqrt()), "ref_vs_f64_rms": float((ref - truth).pow(2).mean().sqrt()),

@@ -45,7 +45,10 @@ def test_mvsnet_config4_train_step_640x512_v3_d192():
     # gradients: over all elements no worse (rms) than the reference's float32 backward; per tensor within 2x of it
     ga = r["grads_all"]
     assert ga["hip_vs_f64_rms"] <= 1.1 * ga["ref_vs_f64_rms"], ga
-    assert ga["hip_vs_ref_rms"] <= 0.5 * ga["ref_vs_f64_rms"] + 1e-3 * ga["truth_rms"], ga
+    # (the training path takes rot_trans from mvs_rot_trans_f32 -- float64 internally -- not from the reference's float32
+    # LAPACK inverse, whose rounding is most of the reference's own distance from the float64 step: the two float32
+    # results are therefore about as far from each other as the reference is from the truth)
+    assert ga["hip_vs_ref_rms"] <= 1.5 * ga["ref_vs_f64_rms"], ga
     for k, v in r["grads"].items():
         assert v["hip_vs_f64"] <= 2.0 * v["ref_vs_f64"] + 1e-4, (k, v)
     # BatchNorm running statistics after the step (momentum 0.1, unbiased variance)
