@@ -93,6 +93,9 @@ def pmc_traffic():
 def roofline_entry(name, kind, amount, ms, traffic=None):
     e = _roofline_entry(name, kind, amount, ms)
     e["traffic"] = traffic
+    if traffic is not None:   # (not a measurement of THIS run -- the counters need their own rocprofv3 --pmc passes)
+        e["traffic_source"] = "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command " \
+                              "(scripts/profile_round.sh), per launch; 2 x FETCH_SIZE + WRITE_SIZE"
     return e
 
 

@@ -133,8 +133,9 @@ def deconv3d_k3s2(x, w):
     return full[:, :, 1:2 * D + 1]
 
 
-def cost_reg_net(x, sd, prefix="cost_regularization.", train=False):
-    """[B,32,D,H,W] -> [B,1,D,H,W]  (mvsnet.py:48-93)"""
+def cost_reg_net(x, sd, prefix="cost_regularization.", train=False, capture=None):
+    """[B,32,D,H,W] -> [B,1,D,H,W]  (mvsnet.py:48-93).  capture: dict that receives the conv0 activation (error-budget
+    diagnostics)."""
     bn = _bn_train if train else _bn_eval
 
     def conv(name, t, stride):
@@ -146,6 +147,8 @@ def cost_reg_net(x, sd, prefix="cost_regularization.", train=False):
         return F.relu(bn(t, sd, f"{prefix}{name}.1"))
 
     c0 = conv("conv0", x, 1)
+    if capture is not None:
+        capture["conv0"] = c0
     c2 = conv("conv2", conv("conv1", c0, 2), 1)
     c4 = conv("conv4", conv("conv3", c2, 2), 1)
     t = conv("conv6", conv("conv5", c4, 2), 1)
