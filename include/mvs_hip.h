@@ -264,6 +264,11 @@ int mvs_costreg_fwd_f32(const float *in, int in_layout, const mvs_conv_layer *la
 int mvs_conv3d_wgrad_f32(const float *in, const float *grad_out, int B, int Cin, int Cout, int D,
                          int H, int W, int stride, float *grad_weight, void *workspace,
                          size_t workspace_bytes, void *stream);
+/* The same for the conv0-class layers (Cout = 8, stride 1, Cin in {8, 16, 32}) whose input is the 8-channel-blocked
+ * volume [B,D,H,Cin/8,W,8] (MVS_LAYOUT_C8) that mvs_conv3d_c8_bf16x6_f32 reads: the training step runs conv0 on the
+ * split-operand bf16 kernel and takes its weight gradient from the same tensor. */
+int mvs_conv3d_wgrad_c8_f32(const float *in_c8, const float *grad_out, int B, int Cin, int D, int H, int W,
+                            float *grad_weight, void *workspace, size_t workspace_bytes, void *stream);
 size_t mvs_conv3d_wgrad_workspace_bytes(int B, int Cin, int Cout, int D, int H, int W, int stride);
 int mvs_conv3d_wgrad_supported(int Cin, int Cout, int stride);
 

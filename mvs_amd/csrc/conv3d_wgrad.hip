@@ -37,6 +37,7 @@ struct WgradArgs {
     int D, H, W;          // input (x) grid
     int Do, Ho, Wo;       // output (g) grid
     int tiles_x, tiles_y, tiles_z;
+    int x_c8 = 0;         // x is [B,D,H,Cin/8,W,8] (8-channel blocked: the variance volume as conv0's bf16 kernel reads it)
 };
 
 template <int COUT_T, int CK, int S>
@@ -303,8 +304,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_xanchor_kernel(WgradArgs 
                 const int v = s / Q, q = (s % Q) ^ (CIN == 32 ? ((v >> 1) & 1) * 4 : 0);
                 const int x = v & 15, row = v >> 4, rz = row / C::TY, ry = row % C::TY;
                 const bool ok = z0 + rz < a.D && y0 + ry < a.H && x0 + x < a.W;
-                const unsigned off = ok ? (unsigned)(((rz * plane + (int64_t)(y0 + ry) * a.W + x0 + x) * CIN + q * 4) * 4)
-                                        : 0xffffff00u;
+                const unsigned off = !ok ? 0xffffff00u
+                    : a.x_c8 ? (unsigned)(((((int64_t)rz * a.H + (y0 + ry)) * (CIN / 8) + (q >> 1)) * a.W + x0 + x) * 32 + (q & 1) * 16)
+                             : (unsigned)(((rz * plane + (int64_t)(y0 + ry) * a.W + x0 + x) * CIN + q * 4) * 4);
                 glds16_buf(off, srd, 0u, lds_base + (unsigned)((it * 4 + wv) * 1024));
             }
         }
@@ -424,9 +426,27 @@ extern "C" size_t mvs_conv3d_wgrad_workspace_bytes(int B, int Cin, int Cout, int
     return (size_t)wgrad_streams((int)nt, ncc) * ncc * (4 * 7 * mt * 256) * sizeof(float);
 }
 
+static int conv3d_wgrad_impl(const float *in, const float *grad_out, int B, int Cin, int Cout, int D, int H, int W, int stride,
+                             int in_c8, float *grad_weight, void *workspace, size_t workspace_bytes, void *stream);
+
 extern "C" int mvs_conv3d_wgrad_f32(const float *in, const float *grad_out, int B, int Cin, int Cout,
                                     int D, int H, int W, int stride, float *grad_weight, void *workspace,
                                     size_t workspace_bytes, void *stream) {
+    return conv3d_wgrad_impl(in, grad_out, B, Cin, Cout, D, H, W, stride, 0, grad_weight, workspace, workspace_bytes, stream);
+}
+
+// the conv0-class layers (Cout 8, stride 1) with the 8-channel-blocked input [B,D,H,Cin/8,W,8] their forward kernel reads
+extern "C" int mvs_conv3d_wgrad_c8_f32(const float *in_c8, const float *grad_out, int B, int Cin, int D, int H, int W,
+                                       float *grad_weight, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!(Cin == 8 || Cin == 16 || Cin == 32) || !workspace) {
+        set_error("mvs_conv3d_wgrad_c8_f32: Cin in {8, 16, 32} (Cout = 8, stride 1) and a workspace of mvs_conv3d_wgrad_workspace_bytes");
+        return MVS_EUNSUPPORTED;
+    }
+    return conv3d_wgrad_impl(in_c8, grad_out, B, Cin, 8, D, H, W, 1, 1, grad_weight, workspace, workspace_bytes, stream);
+}
+
+static int conv3d_wgrad_impl(const float *in, const float *grad_out, int B, int Cin, int Cout, int D, int H, int W, int stride,
+                             int in_c8, float *grad_weight, void *workspace, size_t workspace_bytes, void *stream) {
     if (!in || !grad_out || !grad_weight || B <= 0 || D <= 0 || H <= 0 || W <= 0) {
         set_error("mvs_conv3d_wgrad_f32: bad argument");
         return MVS_EINVAL;
@@ -438,8 +458,12 @@ extern "C" int mvs_conv3d_wgrad_f32(const float *in, const float *grad_out, int 
     WgradArgs a;
     int64_t nt;
     if (!wgrad_geometry(B, Cin, Cout, D, H, W, stride, a, nt)) return bare_error(MVS_EINVAL, __func__, __LINE__);
-    a.x = in; a.g = grad_out; a.gw = grad_weight; a.partial = nullptr;
+    a.x = in; a.g = grad_out; a.gw = grad_weight; a.partial = nullptr; a.x_c8 = in_c8;
     hipStream_t st = as_stream(stream);
+    if (in_c8 && !(wgrad_xanchor_shape(Cin, Cout, stride) && workspace && workspace_bytes >= wgrad_xanchor_bytes(Cout, (int)nt))) {
+        set_error("mvs_conv3d_wgrad_c8_f32: workspace of %zu bytes too small", workspace_bytes);
+        return MVS_EWORKSPACE;
+    }
     if (wgrad_xanchor_shape(Cin, Cout, stride) && workspace && workspace_bytes >= wgrad_xanchor_bytes(Cout, (int)nt)) {
 #define MVS_WX(ci, co) if (Cin == ci && Cout == co) return launch_wgrad_xanchor<ci, co>(a, (int)nt, workspace, st);
         MVS_WX(32, 8) MVS_WX(16, 8) MVS_WX(8, 8) MVS_WX(32, 1) MVS_WX(16, 1) MVS_WX(8, 1)

@@ -168,8 +168,9 @@ class CostRegNet(nn.Module):
         return self.prob(x)
 
     # -- autograd path on the HIP conv kernels (forward + input gradients), channels-last
-    def forward_train_hip(self, x_cl):
-        """x_cl [B,D,H,W,32] -> cost [B,D,H,W]; same graph as forward() (mvsnet.py:83-93)."""
+    def forward_train_hip(self, x_cl, conv0_raw=None):
+        """x_cl [B,D,H,W,32] -> cost [B,D,H,W]; same graph as forward() (mvsnet.py:83-93).  conv0_raw: conv0's output
+        before BatchNorm from ops.variance_conv0_autograd (then x_cl is not used)."""
         from ..train_ops import conv3d_cl, conv_bn_relu_cl
 
         def blk(name, t, stride=1):
@@ -180,7 +181,10 @@ class CostRegNet(nn.Module):
             m = getattr(self, name)
             return conv_bn_relu_cl(t, m[0], m[1], True, 2, skip=skip, tag=name)
 
-        c0 = blk("conv0", x_cl)
+        if conv0_raw is not None and self.conv0.bn.training and self.conv0.bn.momentum is not None:
+            c0 = ops.bn_relu_cl(conv0_raw, self.conv0.bn)
+        else:
+            c0 = blk("conv0", x_cl)
         c2 = blk("conv2", blk("conv1", c0, 2))
         c4 = blk("conv4", blk("conv3", c2, 2))
         t = blk("conv6", blk("conv5", c4, 2))
@@ -289,6 +293,7 @@ class MVSNet(nn.Module):
         self.align_corners = align_corners
         self.proj_where = proj_where
         self.train_proj_where = "device"
+        self.train_conv0_fused = True   # training: variance -> conv0 as one autograd node on the bf16 split-operand kernel
         self.variance_impl = "lds"      # "lds" (LDS-staged source tiles) | "gather"
         # True (eval default): MVS_SWEEP_FAST -- sampling positions within ~1e-4 texel of the
         # reference's, 0.25 ms less per view; the depth map stays as close to the reference's CPU
@@ -364,8 +369,14 @@ class MVSNet(nn.Module):
                 else:
                     f16 = torch.stack(feats)                            # [V,B,C,h,w]
                     f16 = f16.reshape(V, f16.shape[1], C // 16, 16, *f16.shape[3:]).permute(0, 1, 2, 4, 5, 3).contiguous()
-                var = ops.costvol_variance_c16_autograd(f16[0], f16[1:], rts, depth_values, self.align_corners)
-                cost = self.cost_regularization.forward_train_hip(var)
+                if C == 32 and self.training and self.train_conv0_fused and ops.conv_split_enabled():
+                    # warp + variance -> conv0 as one autograd node: the volume stays 8-channel blocked for the bf16 kernel
+                    c0 = ops.variance_conv0_autograd(f16[0], f16[1:], rts, depth_values,
+                                                     self.cost_regularization.conv0.conv.weight, self.align_corners)
+                    cost = self.cost_regularization.forward_train_hip(None, conv0_raw=c0)
+                else:
+                    var = ops.costvol_variance_c16_autograd(f16[0], f16[1:], rts, depth_values, self.align_corners)
+                    cost = self.cost_regularization.forward_train_hip(var)
             else:
                 var = ops.costvol_variance(feats[0], torch.stack(feats[1:]), rts, depth_values,
                                            self.align_corners)          # [B,32,D,h,w]

@@ -972,6 +972,76 @@ def conv3d_wgrad(x_cl, g_cl, stride):
     return gw
 
 
+def conv3d_wgrad_c8(x_c8, g_cl):
+    """Weight gradient of a conv0-class layer (Cout 8, stride 1) from its 8-channel-blocked input [B,D,H,Cin/8,W,8] and
+    the output gradient [B,D,H,W,8] -> (8,Cin,3,3,3)."""
+    x_c8, g_cl = _f32c(x_c8), _f32c(g_cl)
+    B, D, H, G, W, _ = x_c8.shape
+    cin = G * 8
+    lib = _lib.load()
+    gw = torch.zeros((8, cin, 3, 3, 3), device=x_c8.device, dtype=torch.float32)   # (the reduction adds into it)
+    nbytes = int(lib.mvs_conv3d_wgrad_workspace_bytes(B, cin, 8, D, H, W, 1))
+    ws = torch.empty((max(nbytes, 4) // 4,), device=x_c8.device, dtype=torch.float32)
+    check(lib.mvs_conv3d_wgrad_c8_f32(ptr(x_c8), ptr(g_cl), B, cin, D, H, W, ptr(gw), ptr(ws), nbytes, stream()),
+          "mvs_conv3d_wgrad_c8_f32")
+    return gw
+
+
+class _VarianceConv0(torch.autograd.Function):
+    """Training path: fused warp + variance -> conv0 (raw output, before BatchNorm) as ONE autograd node, so that the
+    variance volume can live in the 8-channel-blocked layout conv0's split-operand bf16 kernel reads (0.87 -> 0.4 ms at
+    640x512, D=192) without a mislabelled tensor leaving the node: backward = conv0's weight gradient from the blocked
+    volume (mvs_conv3d_wgrad_c8_f32), its input gradient as an 8 -> 32 convolution (channels-last), and the variance
+    kernel's backward on that."""
+
+    @staticmethod
+    def forward(ctx, ref16, srcs16, rts, depth_values, weight, align_corners):
+        ref16, srcs16, depth_values = _f32c(ref16), _f32c(srcs16), _f32c(depth_values)
+        if _depth_mode(depth_values) != 0:
+            raise MvsHipError("the fused variance -> conv0 training op takes [B,D] depth planes")
+        with stage("train.variance.fwd"):
+            var = costvol_variance_c16(ref16, srcs16, rts, depth_values, align_corners, out_c8=True)
+        w = weight.detach().contiguous()
+        pks = pack_conv3d_weight_split(w)
+        if pks is None:
+            raise MvsHipError(f"no split-operand conv0 kernel for a {tuple(w.shape)} weight")
+        split_stage_names.add("train.conv0.fwd")
+        with stage("train.conv0.fwd"):
+            out = conv3d_c8_split(var, pks, None, None, None, False)
+        ctx.save_for_backward(ref16, srcs16, rts, depth_values, var, weight)
+        ctx.ac = int(align_corners)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ref16, srcs16, rts, depth_values, var, weight = ctx.saved_tensors
+        g = _f32c(g)
+        w = weight.detach()
+        gw = g_ref = g_src = None
+        if ctx.needs_input_grad[4]:
+            with stage("train.conv0.wgrad"):
+                gw = conv3d_wgrad_c8(var, g)
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            wt = w.flip(2, 3, 4).permute(1, 0, 2, 3, 4).contiguous()      # (32, 8, k) as a conv weight
+            pk = pack_conv3d_weight(wt, False, 1, split=True)
+            with stage("train.conv0.dgrad"):
+                gvar = conv3d(g, wt, channels_last=True, packed=pk)        # [B,D,H,W,32]
+            B, G, H, W, _ = ref16.shape
+            V, D = srcs16.shape[0] + 1, depth_values.shape[1]
+            g_ref, g_src = torch.empty_like(ref16), torch.empty_like(srcs16)
+            with stage("train.variance.bwd"):
+                check(_lib.load().mvs_costvol_variance_bwd_f32(
+                    ptr(gvar), ptr(ref16), ptr(srcs16), ptr(rts), ptr(depth_values), 0, B, V, G * 16, D, H, W,
+                    ctx.ac, MVS_LAYOUT_C16, MVS_LAYOUT_NHWC, ptr(g_ref), ptr(g_src), stream()),
+                    "mvs_costvol_variance_bwd_f32")
+        return g_ref, g_src, None, None, gw, None
+
+
+def variance_conv0_autograd(ref16, srcs16, rts, depth_values, conv0_weight, align_corners=False):
+    """ref16 [B,C/16,H,W,16]; srcs16 [V-1,B,C/16,H,W,16]; conv0_weight (8,C,3,3,3) -> conv0's raw output [B,D,H,W,8]."""
+    return _VarianceConv0.apply(ref16, srcs16, rts, depth_values, conv0_weight, align_corners)
+
+
 def conv2d_wgrad(x, g_cl, ksize, stride, planar=False):
     """Weight gradient of a 2D layer on the matrix cores (mvs_conv2d_wgrad_f32): x [N,H,W,Cin] channels-last (planar:
     [N,Cin,H,W]), g_cl [N,Ho,Wo,Cout] -> (Cout,Cin,k,k)."""
