@@ -26,6 +26,24 @@ from .. import ops
 from .dtu_eval import read_cam_file, read_pair_file
 
 
+class _Sample(dict):
+    """A sample of DeviceScanPipeline: like the reference loader's dict, with the [1,V,3,H,W] image tensor gathered from the
+    scan's resident images the first time it is asked for."""
+
+    def __missing__(self, key):
+        if key != "imgs":
+            raise KeyError(key)
+        v = self["scan_imgs"].index_select(0, self["view_slots"]).unsqueeze(0)
+        self[key] = v
+        return v
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+
 class DeviceScanPipeline:
     def __init__(self, datapath, listfile, nviews, ndepths=192, interval_scale=1.06, device="cuda:0",
                  decode_workers=None, image_hw=(1200, 1600), crop_bottom=16, intrinsics_div=4.0):
@@ -122,8 +140,9 @@ class DeviceScanPipeline:
                             self.dev, non_blocking=True)
                 # "scan_imgs" / "view_slots": the scan's resident images and this sample's rows of them, for a
                 # driver that runs FeatureNet once per image (MVSNet.extract_features)
-                yield {"scan_imgs": cur["imgs"], "view_slots": idx,
-                       "imgs": cur["imgs"].index_select(0, idx).unsqueeze(0),
+                # "imgs" is gathered on first access (a driver that hands forward() cached feature maps never
+                # reads it -- 113 MB of index_select per depth map otherwise)
+                yield _Sample({"scan_imgs": cur["imgs"], "view_slots": idx,
                        "proj_matrices": cur["proj"].index_select(0, idx).unsqueeze(0),
                        "depth_values": dv_cache[(dmin, dint)].unsqueeze(0),
-                       "filename": [scan + "/{}/" + f"{ref:0>8}" + "{}"]}
+                       "filename": [scan + "/{}/" + f"{ref:0>8}" + "{}"]})

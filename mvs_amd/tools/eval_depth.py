@@ -68,7 +68,10 @@ def save_depth(args):
                         scan_feats = model.extract_features(scan_imgs)
                     if scan_feats is not None:
                         feats = scan_feats.index_select(0, sample["view_slots"]).unsqueeze(0)
-                out = model(sample["imgs"], sample["proj_matrices"], sample["depth_values"], features=feats)
+                # with cached features forward() only needs the SHAPE of the images: a stride-0 view of one resident image
+                imgs = sample["imgs"] if feats is None else \
+                    sample["scan_imgs"][:1].unsqueeze(0).expand(1, sample["view_slots"].numel(), -1, -1, -1)
+                out = model(imgs, sample["proj_matrices"], sample["depth_values"], features=feats)
                 # results leave through a ring of pinned buffers: the launching thread never waits
                 # for the GPU, it runs whole reference views ahead of it
                 if len(ring) < RING:
