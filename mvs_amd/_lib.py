@@ -110,11 +110,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = LIB_PATH
+    if os.environ.get("MVS_HIP_TUNING") == "1":   # kernel-tuning scripts: the -DMVS_TUNING build (python -m mvs_amd.build --tuning)
+        path = LIB_PATH.replace(".so", "_tuning.so")
+    if not os.path.exists(path):
         raise MvsHipError(
-            f"{LIB_PATH} not found: build it with `python -m mvs_amd.build` (hipcc, gfx950). "
+            f"{path} not found: build it with `python -m mvs_amd.build` (hipcc, gfx950). "
             "mvs_amd has no CPU or PyTorch fallback for the cost-volume path.")
-    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_LOCAL)
+    lib = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)  # AttributeError here = ABI drift, fail loudly
         fn.restype = res

@@ -42,15 +42,21 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    os.makedirs(OBJ, exist_ok=True)
+def build(force=False, verbose=False, tuning=False):
+    """tuning: libmvs_hip_tuning.so with -DMVS_TUNING -- the ablation / phase-stamp switches (MVS_CONV_SPLIT_ABL,
+    MVS_CONV_SPLIT_LAPS, MVS_PROB_ABL, MVS_HEAD_ABL, MVS_SWEEP_ABLATE, the flag fields of MVS_SWEEP_PERSIST) exist only
+    there: several of them give wrong results by design and write cycle counters through a caller's tensor, so the
+    release library does not read them.  MVS_HIP_TUNING=1 makes mvs_amd._lib load that build."""
+    obj_dir = OBJ + ("_tuning" if tuning else "")
+    lib = LIB.replace(".so", "_tuning.so") if tuning else LIB
+    os.makedirs(obj_dir, exist_ok=True)
     cc = hipcc()
     jobs = []
     for name in SOURCES:
         src = os.path.join(CSRC, name + ".hip")
-        obj = os.path.join(OBJ, name + ".o")
+        obj = os.path.join(obj_dir, name + ".o")
         if force or _stale(obj, (src,) + HEADERS):
-            jobs.append([cc] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([cc] + FLAGS + (["-DMVS_TUNING"] if tuning else []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -64,10 +70,10 @@ def build(force=False, verbose=False):
         for warn in ex.map(run, jobs):
             if verbose and warn.strip():
                 print(warn)
-    objs = [os.path.join(OBJ, n + ".o") for n in SOURCES]
-    if force or jobs or _stale(LIB, objs):
-        run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    return LIB
+    objs = [os.path.join(obj_dir, n + ".o") for n in SOURCES]
+    if force or jobs or _stale(lib, objs):
+        run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
 
 
 ABI_TEST_SRC = os.path.join(os.path.dirname(HERE), "tests", "cpp", "abi_chain.cpp")
@@ -89,5 +95,5 @@ def build_abi_test(force=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, tuning="--tuning" in sys.argv))
     print(build_abi_test(force="--force" in sys.argv))

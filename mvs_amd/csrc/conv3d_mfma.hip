@@ -1021,7 +1021,11 @@ int conv3d_mfma_launch(const float *in, const float *packed, const float *scale,
             m.sps = (a.tiles_z + nseg - 1) / nseg;
             m.nseg = (a.tiles_z + m.sps - 1) / m.sps;
             m.nunits = m.ncols * m.nseg;
+#ifdef MVS_TUNING
             static const int abl = getenv("MVS_PROB_ABL") ? atoi(getenv("MVS_PROB_ABL")) : 0;
+#else
+            constexpr int abl = 0;
+#endif
             m.abl = abl;
             hipLaunchKernelGGL(conv3d_cout1_march_kernel, dim3((unsigned)(m.nunits < n_cu ? m.nunits : n_cu)), dim3(768), 0, st,
                                m, packed);

@@ -772,7 +772,11 @@ extern "C" int mvs_conv3d_c8_bf16x6_f32(const float *in, const void *packed, con
     a.Do = D; a.Ho = H; a.Wo = W;
     a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 3) / 4; a.tiles_z = (D + 3) / 4;
     a.relu = relu; a.in_c8 = 1; a.ystrip = 8;
+#ifdef MVS_TUNING   // ablation / phase-stamp builds: wrong results by design, cycle counters written through `residual`
     static const int abl = [] { const char *e = getenv("MVS_CONV_SPLIT_ABL"); return e ? atoi(e) : 0; }();
+#else
+    constexpr int abl = 0;
+#endif
     a.res_up2 = abl & 7;
     const int64_t nt = (int64_t)B * a.tiles_x * a.tiles_y * a.tiles_z;
     if (nt <= 0 || nt > 0x7fffffffLL) return bare_error(MVS_EINVAL, __func__, __LINE__);

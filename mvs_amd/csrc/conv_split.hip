@@ -482,7 +482,11 @@ static int launch_split(const SplitArgs &a0, hipStream_t st) {
     const int64_t nt = (int64_t)a.B * a.tiles_x * a.tiles_y * a.tiles_z;
     if (nt <= 0 || nt >= (1 << 23)) return bare_error(MVS_EUNSUPPORTED, __func__, __LINE__);   // the kernel's float tile decode: callers fall back to mvs_conv3d_f32 / mvs_conv2d_f32
     const int n_cu = device_cu_count();
+#ifdef MVS_TUNING   // phase-stamp build: int64 cycle counters written through `residual`
     static const bool laps = [] { const char *e = getenv("MVS_CONV_SPLIT_LAPS"); return e && e[0] == '1'; }();
+#else
+    constexpr bool laps = false;
+#endif
     if (laps && a.residual && (C::CIN == 64 || C::CIN == 16) && C::COUT == 16 * (C::CIN == 64 ? 2 : 1))   // tuning builds: 64 -> 32 and 16 -> 16
         hipLaunchKernelGGL((conv_split_kernel<C, true>), dim3((unsigned)(nt < n_cu ? nt : n_cu)), dim3(C::NTHREADS), 0, st, a, (int)nt);
     else

@@ -340,7 +340,11 @@ extern "C" int mvs_feature_head_f32(const float *img, const float *w0, const flo
     a.wpk1 = static_cast<const unsigned char *>(packed1); a.scale1 = scale1; a.shift1 = shift1; a.out = out;
     a.N = N; a.H = H; a.W = W;
     a.tiles_x = (W + 31) / 32; a.tiles_y = (H + kTH - 1) / kTH; a.ystrip = 8;
+#ifdef MVS_TUNING
     static const int abl = getenv("MVS_HEAD_ABL") ? atoi(getenv("MVS_HEAD_ABL")) : 0;
+#else
+    constexpr int abl = 0;
+#endif
     a.abl = abl;
     const int64_t nt = (int64_t)a.tiles_x * a.tiles_y * N;
     if (nt > 0x7fffffffLL) return bare_error(MVS_EINVAL, __func__, __LINE__);

@@ -1136,7 +1136,11 @@ static int launch_variance_cl(int NV, const float *ref, const float *srcs, const
     }
     const dim3 grid((unsigned)((per_item + 255) / 256), (unsigned)p.B);
     const FastDiv fdp = make_fastdiv((uint32_t)(p.H * p.W)), fdw = make_fastdiv((uint32_t)p.W);
-    const char *abl_env = getenv("MVS_SWEEP_ABLATE");   // tuning only
+#ifdef MVS_TUNING
+    const char *abl_env = getenv("MVS_SWEEP_ABLATE");   // tuning builds only
+#else
+    const char *abl_env = nullptr;
+#endif
     const int ablate = abl_env ? atoi(abl_env) : 0;
 #define MVS_CL_CASE(n)                                                                         \
     case n:                                                                                    \

@@ -1,5 +1,6 @@
 """Per-phase cycle counts of the conv_split kernel (tuning build, MVS_CONV_SPLIT_LAPS=1).
   python scripts/exp_conv_split_laps.py kd cin cout  N|B,D H W"""
+import os as _os; _os.environ.setdefault("MVS_HIP_TUNING", "1")   # needs python -m mvs_amd.build --tuning
 import json, os, sys, torch
 os.environ["MVS_CONV_SPLIT_LAPS"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

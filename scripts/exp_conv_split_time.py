@@ -1,4 +1,5 @@
 """time of the split-operand conv0 kernel at one shape (tuning: MVS_CONV_SPLIT_ABL, MVS_CONV_SPLIT_DOT2)"""
+import os as _os; _os.environ.setdefault("MVS_HIP_TUNING", "1")   # needs python -m mvs_amd.build --tuning
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mvs_amd import ops

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Persistent variance kernel vs the per-tile kernel: bit-equality (exact mode), distance of the
 fast mode, timing of the tuning variants at BASELINE configs[1].  python scripts/exp_persist.py [reps]"""
+import os as _os; _os.environ.setdefault("MVS_HIP_TUNING", "1")   # needs python -m mvs_amd.build --tuning
 import json
 import os
 import sys
