@@ -1613,3 +1613,95 @@ def test_sweep_kernel_choice_follows_geometry(dev, D, scale, rig):
     assert r["bit_equal_exact"], r
     assert r["auto_over_best"] <= 1.15, r
     assert r["choice"] in (0, 8, 16), r
+
+
+# ---------------------------------------------------------------- round 3: training-path kernels
+@pytest.mark.parametrize("cfg", [(3, 8, 3, 1, True, (2, 24, 32)), (8, 8, 3, 1, False, (1, 17, 35)), (8, 16, 5, 2, False, (2, 24, 32)),
+                                 (16, 16, 3, 1, False, (3, 9, 20)), (16, 32, 5, 2, False, (1, 30, 46)), (32, 32, 3, 1, False, (2, 13, 16))])
+def test_conv2d_wgrad_vs_float64(dev, cfg):
+    """mvs_conv2d_wgrad_f32 (FeatureNet's weight gradients, MVSNet/models/mvsnet.py:8-45 under train.py:222-226) against a
+    float64 autograd convolution: every layer shape of FeatureNet incl. the planar RGB layer, ragged tiles, batch > 1."""
+    import torch.nn.functional as F
+    from mvs_amd import ops
+    cin, cout, k, stride, planar, (N, H, W) = cfg
+    g = torch.Generator().manual_seed(cin * 31 + cout + H)
+    x = torch.randn(N, cin, H, W, generator=g)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    go = torch.randn(N, Ho, Wo, cout, generator=g)
+    w = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w, None, stride, k // 2).backward(go.permute(0, 3, 1, 2).double())
+    xd = x.to(dev) if planar else x.permute(0, 2, 3, 1).contiguous().to(dev)
+    got = ops.conv2d_wgrad(xd, go.to(dev), k, stride, planar).cpu().double()
+    assert (got - w.grad).abs().max().item() < 2e-5 * max(1.0, w.grad.abs().max().item())
+
+
+def test_conv2d_stride2_input_gradient_as_parity_classes(dev):
+    """The input gradient of a 5x5 stride-2 layer = four 3x3 stride-1 convolutions of the output gradient (one per parity
+    class of the input pixel) + mvs_interleave2x2_f32, against torch's transposed convolution; both 5x5 layers of FeatureNet."""
+    import torch.nn.functional as F
+    from mvs_amd.train_ops import conv2d_cl
+    for cin, cout, (N, H, W) in ((8, 16, (2, 24, 32)), (16, 32, (1, 20, 44))):
+        g = torch.Generator(device=dev).manual_seed(cin)
+        x = torch.randn(N, H, W, cin, device=dev, generator=g).requires_grad_(True)
+        w = (torch.randn(cout, cin, 5, 5, device=dev, generator=g) / (25 * cin) ** 0.5).requires_grad_(True)
+        y = conv2d_cl(x, w, 2)
+        go = torch.randn(y.shape, device=dev, generator=g)
+        y.backward(go)
+        ref = F.conv_transpose2d(go.permute(0, 3, 1, 2).double().cpu(), w.detach().double().cpu(), None, 2, 2, 1)
+        np.testing.assert_allclose(x.grad.permute(0, 3, 1, 2).cpu().numpy(), ref.numpy(), atol=3e-5, rtol=1e-4)
+
+
+def test_rot_trans_device_kernel_vs_float64(dev):
+    """mvs_rot_trans_f32 (module.py:63-65 for every source view, float64 Gauss-Jordan on the device) against numpy float64:
+    within one float32 rounding of the exact rows; the float32 LAPACK route of the reference is itself 1e-6 relative off."""
+    from mvs_amd import ops, synth
+    for rig in (0, 1):
+        P = synth.proj_matrices(5, 296, 400, batch=2, rig=rig)
+        P[1, :, :3, 3] += 7.0
+        got = ops.rot_trans_all(torch.from_numpy(P).to(dev), "device").cpu().numpy()        # [V-1,B,12]
+        P64 = P.astype(np.float64)
+        for b in range(2):
+            inv = np.linalg.inv(P64[b, 0])
+            for v in range(1, 5):
+                want = (P64[b, v] @ inv)[:3, :4].reshape(12)
+                np.testing.assert_allclose(got[v - 1, b], want, rtol=2e-7, atol=1e-7 * np.abs(want).max())
+
+
+def test_conv0_weight_gradient_from_blocked_volume(dev):
+    """mvs_conv3d_wgrad_c8_f32 (conv0's weight gradient from the 8-channel-blocked variance volume its bf16 kernel reads)
+    equals the channels-last kernel's result and a float64 autograd convolution, on ragged shapes and batch 2."""
+    import torch.nn.functional as F
+    from mvs_amd import ops
+    for B, D, H, W in ((1, 4, 8, 16), (2, 8, 16, 24), (1, 6, 9, 21)):
+        g = torch.Generator().manual_seed(D * 100 + W)
+        x = torch.randn(B, 32, D, H, W, generator=g)
+        go = torch.randn(B, D, H, W, 8, generator=g)
+        w = torch.zeros(8, 32, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+        F.conv3d(x.double(), w, padding=1).backward(go.permute(0, 4, 1, 2, 3).double())
+        a = ops.conv3d_wgrad(x.permute(0, 2, 3, 4, 1).contiguous().to(dev), go.to(dev), 1).cpu().double()
+        b = ops.conv3d_wgrad_c8(ops.nchw_to_c8(x.to(dev)), go.to(dev)).cpu().double()
+        scale = w.grad.abs().max().item()
+        assert (a - b).abs().max().item() < 1e-5 * scale and (b - w.grad).abs().max().item() < 2e-5 * scale
+
+
+def test_fused_variance_conv0_node_matches_separate_ops(dev):
+    """ops.variance_conv0_autograd (warp + variance -> conv0 as one autograd node on the bf16 kernel) against the two separate
+    autograd ops of the unfused training path: conv0's raw output, the gradients of all feature maps and of the weight."""
+    from mvs_amd import ops, synth, train_ops
+    V, h, w, D = 3, 32, 40, 16
+    g = torch.Generator(device=dev).manual_seed(3)
+    f1 = (torch.randn(V, 1, 2, h, w, 16, device=dev, generator=g) * 0.5).requires_grad_(True)
+    f2 = f1.detach().clone().requires_grad_(True)
+    w1 = (torch.randn(8, 32, 3, 3, 3, device=dev, generator=g) / 30).requires_grad_(True)
+    w2 = w1.detach().clone().requires_grad_(True)
+    rts = ops.rot_trans_all(torch.from_numpy(synth.proj_matrices(V, h, w)).to(dev), "device")
+    dv = torch.from_numpy(synth.depth_values(D, interval=synth.sweep_interval(D))).to(dev)
+    y1 = ops.variance_conv0_autograd(f1[0], f1[1:], rts, dv, w1)
+    y2 = train_ops.conv3d_cl(ops.costvol_variance_c16_autograd(f2[0], f2[1:], rts, dv), w2)
+    go = torch.randn(y1.shape, device=dev, generator=g)
+    y1.backward(go)
+    y2.backward(go)
+    tol = lambda t: 2e-5 * max(1.0, t.abs().max().item())
+    assert (y1 - y2).abs().max().item() < tol(y2)
+    assert (f1.grad - f2.grad).abs().max().item() < 5 * tol(f2.grad)
+    assert (w1.grad - w2.grad).abs().max().item() < 5 * tol(w2.grad)
