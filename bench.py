@@ -43,6 +43,9 @@ BF16_MFMA_PEAK_TF = 2500.0   # v_mfma_f32_16x16x32_bf16, dense
 # conv0 computes every fp32 product as six bf16 products (operands split exactly in three,
 # mvs_amd/csrc/conv_bf16x6.hip): its matrix-pipe ceiling in ALGORITHMIC (fp32) flops
 SPLIT_BF16X6_PEAK_TF = BF16_MFMA_PEAK_TF / 6.0
+# ... and since the end of round 3 as THREE fp16 products (operands scaled and split in two, mvs_amd/csrc/conv_f16x3.hip;
+# v_mfma_f32_16x16x32_f16 has the bf16 instruction's rate)
+SPLIT_F16X3_PEAK_TF = BF16_MFMA_PEAK_TF / 3.0
 # the stages that run on the split-operand kernels (conv_bf16x6.hip: conv0; conv_split.hip: the stride-1 3x3(x3) layers
 # with 16 / 32 / 64 channels; deconv_split.hip: the transposed layers)
 SPLIT_STAGES = {"costreg.conv0", "costreg.conv1", "costreg.conv2", "costreg.conv4", "costreg.conv6", "costreg.conv7", "costreg.conv9",
@@ -106,6 +109,13 @@ def _roofline_entry(name, kind, amount, ms):
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                 "algorithmic_bytes": amount, "ms": round(ms, 4)}
     ach = amount / (ms * 1e-3) / 1e12
+    if name == "costreg.conv0" and ops.conv0_f16_enabled():
+        return {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": round(SPLIT_F16X3_PEAK_TF, 1),
+                "unit": "TFLOP/s", "frac": round(ach / SPLIT_F16X3_PEAK_TF, 4), "traffic": None,
+                "algorithmic_flops": amount, "issued_f16_flops": 3.0 * amount, "ms": round(ms, 4),
+                "peak_note": "fp16 dense MFMA peak 2500 TFLOP/s / 3 fp16 products per fp32 product (two-piece operands, "
+                             "conv_f16x3.hip); against the six-product bf16 form's ceiling, 416.7, the same time is "
+                             f"{round(ach / SPLIT_BF16X6_PEAK_TF, 3)}; the fp32 MFMA peak is 157.3"}
     if (name in SPLIT_STAGES or name in ops.split_stage_names) and ops.conv_split_enabled():
         return {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": round(SPLIT_BF16X6_PEAK_TF, 1),
                 "unit": "TFLOP/s", "frac": round(ach / SPLIT_BF16X6_PEAK_TF, 4), "traffic": None,

@@ -144,6 +144,16 @@ int mvs_costvol_variance_fwd_ws_f32(const float *ref_fea, const float *src_feas,
                                     int align_corners, int alias_quirk, int fea_layout,
                                     int out_layout, int flags, float *out_var, void *workspace,
                                     size_t workspace_bytes, void *stream);
+/* The same, and the largest magnitude of the volume as a by-product: absmax_bits = NULL, or a device word that
+ * receives the bit pattern of max |out_var| -- the operand scale mvs_conv3d_c8_f16x3_f32 / mvs_costreg_fwd2_f32 need.
+ * The LDS-staged kernels collect it as they store (one atomic max per wave); behind the gather kernels it costs one more
+ * pass over the volume (mvs_absmax_f32). */
+int mvs_costvol_variance_fwd_ws2_f32(const float *ref_fea, const float *src_feas,
+                                     const float *rot_trans, const float *depth_values,
+                                     int depth_mode, int B, int V, int C, int D, int H, int W,
+                                     int align_corners, int alias_quirk, int fea_layout,
+                                     int out_layout, int flags, float *out_var, void *workspace,
+                                     size_t workspace_bytes, void *absmax_bits, void *stream);
 /* Self-test: the variance kernel divides by the view count V with a 3-op
  * multiply/FMA sequence instead of an IEEE division; this checks it against
  * x / V for EVERY float bit pattern on the device and writes the number of
@@ -192,6 +202,24 @@ int mvs_conv3d_pack_weights_bf16x6_f32(const float *weight, int Cin, void *packe
 int mvs_conv3d_c8_bf16x6_f32(const float *in, const void *packed, const float *scale, const float *shift,
                              const float *residual, int relu, int B, int Cin, int D, int H, int W,
                              float *out, void *stream);
+
+/* The same layers on the FP16 matrix pipe with TWO-piece operands and three products per fp32 product (half the
+ * matrix work of the bf16 form; mvs_amd/csrc/conv_f16x3.hip): x * 2^k = hi + lo + e, hi and lo fp16, |e| <= 2^-23 |x 2^k|;
+ * a b ~ ah bh + ah bl + al bh, each product exact in the fp32 accumulator.  Against a float64 convolution the result is
+ * as close as the bf16 form's and ATen's fp32 convolution (the fp32 accumulation, common to all three, is what sets the
+ * distance; tests/test_gpu_parity.py::test_conv3d_f16x3_*).  fp16 has 5 exponent bits, so the kernel scales its input
+ * by 2^(14 - exponent(max |in|)): in_absmax = device word holding the bit pattern of the largest magnitude of `in`,
+ * written by the producer of the volume (mvs_costvol_variance_fwd_ws2_f32) or by mvs_absmax_f32 (one pass over the
+ * array: resets the word, then collects; n floats, 16-byte aligned).  An element below 2^-18 of the maximum keeps an
+ * absolute error below 2^-40 of the maximum.  The weights are scaled the same way when packed:
+ * mvs_conv3d_f16x3_packed_bytes(Cin) bytes (0 = unsupported Cin; supported: 8, 16, 32).  Other arguments as
+ * mvs_conv3d_c8_bf16x6_f32. */
+size_t mvs_conv3d_f16x3_packed_bytes(int Cin);
+int mvs_conv3d_pack_weights_f16x3_f32(const float *weight, int Cin, void *packed, void *stream);
+int mvs_absmax_f32(const float *x, int64_t n, void *absmax_bits, void *stream);
+int mvs_conv3d_c8_f16x3_f32(const float *in, const void *in_absmax, const void *packed, const float *scale,
+                            const float *shift, const float *residual, int relu, int B, int Cin, int D, int H, int W,
+                            float *out, void *stream);
 
 /* The same split-operand arithmetic for the 3x3(x3), stride-1, pad-1 layers with 16 / 32 / 64 input and output
  * channels (CostRegNet conv2 / conv4 / conv6, mvsnet.py:68-72; FeatureNet's 16 -> 16 and 32 -> 32 layers,
@@ -247,6 +275,13 @@ size_t mvs_costreg_workspace_bytes(int B, int base, int D, int H, int W);
 int mvs_costreg_fwd_f32(const float *in, int in_layout, const mvs_conv_layer *layers, int B, int Cin,
                         int base, int D, int H, int W, int impl, void *workspace,
                         size_t workspace_bytes, float *out_cost, void *stream);
+/* The same with conv0 on the two-piece fp16 kernel: conv0_f16x3 = mvs_conv3d_pack_weights_f16x3_f32 of conv0's weight
+ * (NULL: as mvs_costreg_fwd_f32), taken for an MVS_LAYOUT_C8 input; in_absmax = the device word the producer of `in`
+ * filled (mvs_costvol_variance_fwd_ws2_f32), or NULL: the largest magnitude is then collected here by one more pass
+ * over `in` (mvs_absmax_f32 into the workspace). */
+int mvs_costreg_fwd2_f32(const float *in, int in_layout, const mvs_conv_layer *layers, int B, int Cin,
+                         int base, int D, int H, int W, int impl, void *workspace, size_t workspace_bytes,
+                         const void *conv0_f16x3, const void *in_absmax, float *out_cost, void *stream);
 
 /* Weight gradient of one 3x3x3 layer (training, BASELINE config 5; the reference gets it from
  * autograd through nn.Conv3d / nn.ConvTranspose3d, module.py:26-33, mvsnet.py:66-79):

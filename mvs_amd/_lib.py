@@ -37,17 +37,23 @@ _SIGS = {
     "mvs_costvol_variance_workspace_bytes": (ctypes.c_size_t, [_c_i] * 8),
     "mvs_costvol_variance_workspace_bytes2": (ctypes.c_size_t, [_c_i] * 9),
     "mvs_costvol_variance_fwd_ws_f32": (_c_i, [_c_f] * 4 + [_c_i] * 12 + [_c_f, _c_f, ctypes.c_size_t, _c_f]),
+    "mvs_costvol_variance_fwd_ws2_f32": (_c_i, [_c_f] * 4 + [_c_i] * 12 + [_c_f, _c_f, ctypes.c_size_t, _c_f, _c_f]),
     "mvs_selftest_div_by_views_f32": (_c_i, [_c_i, _c_f, _c_f]),
     "mvs_costvol_variance_bwd_f32": (_c_i, [_c_f] * 5 + [_c_i] * 10 + [_c_f, _c_f, _c_f]),
     "mvs_conv3d_f32": (_c_i, [_c_f] * 6 + [_c_i] * 11 + [_c_f, _c_f]),
     "mvs_costreg_workspace_bytes": (ctypes.c_size_t, [_c_i] * 5),
     "mvs_costreg_fwd_f32": (_c_i, [_c_f, _c_i, _c_f] + [_c_i] * 7 + [_c_f, ctypes.c_size_t, _c_f, _c_f]),
+    "mvs_costreg_fwd2_f32": (_c_i, [_c_f, _c_i, _c_f] + [_c_i] * 7 + [_c_f, ctypes.c_size_t, _c_f, _c_f, _c_f, _c_f]),
     "mvs_conv3d_packed_weight_floats": (_c_l, [_c_i] * 4),
     "mvs_conv3d_pack_weights_f32": (_c_i, [_c_f] + [_c_i] * 4 + [_c_f, _c_f]),
     "mvs_conv3d_mfma_supported": (_c_i, [_c_i] * 4),
     "mvs_conv3d_bf16x6_packed_bytes": (ctypes.c_size_t, [_c_i]),
     "mvs_conv3d_pack_weights_bf16x6_f32": (_c_i, [_c_f, _c_i, _c_f, _c_f]),
     "mvs_conv3d_c8_bf16x6_f32": (_c_i, [_c_f] * 5 + [_c_i] * 6 + [_c_f, _c_f]),
+    "mvs_conv3d_f16x3_packed_bytes": (ctypes.c_size_t, [_c_i]),
+    "mvs_conv3d_pack_weights_f16x3_f32": (_c_i, [_c_f, _c_i, _c_f, _c_f]),
+    "mvs_absmax_f32": (_c_i, [_c_f, _c_l, _c_f, _c_f]),
+    "mvs_conv3d_c8_f16x3_f32": (_c_i, [_c_f] * 6 + [_c_i] * 6 + [_c_f, _c_f]),
     "mvs_conv_split_supported": (_c_i, [_c_i] * 4),
     "mvs_conv_split_packed_bytes": (ctypes.c_size_t, [_c_i] * 4),
     "mvs_conv_split_pack_weights_f32": (_c_i, [_c_f] + [_c_i] * 4 + [_c_f, _c_f]),

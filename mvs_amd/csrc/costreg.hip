@@ -23,7 +23,7 @@ static bool costreg_plan(int B, int base, int D, int H, int W, CostRegPlan &p) {
         p.off[i] = o;
         o += ((size_t)sz[i] + 63) & ~(size_t)63;   // 256-byte aligned slices
     }
-    p.total = o;
+    p.total = o + 64;   // + the word mvs_costreg_fwd2_f32 collects the input's largest magnitude in when the caller has none
     return true;
 }
 
@@ -39,6 +39,14 @@ extern "C" size_t mvs_costreg_workspace_bytes(int B, int base, int D, int H, int
 extern "C" int mvs_costreg_fwd_f32(const float *in, int in_layout, const mvs_conv_layer *layers, int B,
                                    int Cin, int base, int D, int H, int W, int impl, void *workspace,
                                    size_t workspace_bytes, float *out_cost, void *stream) {
+    return mvs_costreg_fwd2_f32(in, in_layout, layers, B, Cin, base, D, H, W, impl, workspace, workspace_bytes, nullptr,
+                                nullptr, out_cost, stream);
+}
+
+extern "C" int mvs_costreg_fwd2_f32(const float *in, int in_layout, const mvs_conv_layer *layers, int B,
+                                    int Cin, int base, int D, int H, int W, int impl, void *workspace,
+                                    size_t workspace_bytes, const void *conv0_f16x3, const void *in_absmax,
+                                    float *out_cost, void *stream) {
     if (!in || !layers || !out_cost || (in_layout != MVS_LAYOUT_NHWC && in_layout != MVS_LAYOUT_C8)) {
         set_error("mvs_costreg_fwd_f32: invalid argument");
         return MVS_EINVAL;
@@ -84,6 +92,22 @@ extern "C" int mvs_costreg_fwd_f32(const float *in, int in_layout, const mvs_con
     };
     for (const Step &s : steps) {
         const mvs_conv_layer &L = layers[s.layer];
+        if (s.layer == 0 && conv0_f16x3 && in_layout == MVS_LAYOUT_C8 && b == 8 && impl != 1 &&
+            mvs_conv3d_f16x3_packed_bytes(Cin) != 0) {
+            // conv0 on the fp16 matrix pipe with two-piece operands (conv_f16x3.hip); the operand scale comes from the
+            // producer of the volume, or from one more pass over it
+            const void *mx = in_absmax;
+            if (!mx) {
+                void *w = ws + p.total - 64;
+                const int rc = mvs_absmax_f32(in, (int64_t)B * D * H * W * Cin, w, stream);
+                if (rc != MVS_OK) return rc;
+                mx = w;
+            }
+            const int rc = mvs_conv3d_c8_f16x3_f32(s.src, mx, conv0_f16x3, L.scale, L.shift, nullptr, s.relu, B, Cin,
+                                                   D, H, W, s.dst, stream);
+            if (rc != MVS_OK) return rc;
+            continue;
+        }
         if (s.layer == 0 && L.packed_split && in_layout == MVS_LAYOUT_C8 && b == 8 && impl != 1 &&
             mvs_conv3d_bf16x6_packed_bytes(Cin) != 0) {
             // conv0 on the bf16 matrix pipe with exactly split fp32 operands (conv_bf16x6.hip)

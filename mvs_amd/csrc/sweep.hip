@@ -366,11 +366,13 @@ template <int NV, bool CORNER, int NQ = 4, bool LOOP = false>
 __global__ __launch_bounds__(256, 2) void variance_fwd_dma_kernel(
     const float *__restrict__ ref16, const float *__restrict__ srcs16,
     const float *__restrict__ rt, const float *__restrict__ depth, SweepParams p,
-    int tiles_x, int tiles_y, float *__restrict__ out, int out_c8, int ablate, const unsigned *__restrict__ sel, int nblk) {
+    int tiles_x, int tiles_y, float *__restrict__ out, int out_c8, int ablate, const unsigned *__restrict__ sel, int nblk,
+    unsigned *__restrict__ absmax) {
     // sel: word of the workspace header written by variance_choose_kernel (sweep_persist.hip); this kernel runs when it
-    // reads 0 ("per-tile kernel"); NULL = unconditional
+    // reads 0 ("per-tile kernel"); NULL = unconditional.  absmax: NULL, or the word that collects the largest |variance|
     if (sel && *sel != 0u) return;
     int vblk = blockIdx.x;
+    float vmax = 0.0f;
     do {   // (one pass unless LOOP)
     constexpr int cap = dma_cap(NV, NQ);
     constexpr int NJ = (cap + 63) / 64;          // DMA instructions per plane
@@ -656,11 +658,14 @@ __global__ __launch_bounds__(256, 2) void variance_fwd_dma_kernel(
                 for (int k = 0; k < NQ; ++k)
                     o[k] = make_float4(var[k * 4], var[k * 4 + 1], var[k * 4 + 2], var[k * 4 + 3]);
             }
+#pragma unroll
+            for (int c = 0; c < GC; c += 2) vmax = fmaxf(vmax, fmaxf(fabsf(var[c]), fabsf(var[c + 1])));
         }
     }
     if constexpr (LOOP) __syncthreads();   // every wave is done with this tile's LDS image before the next tile's copies
     vblk += (int)gridDim.x;
     } while (LOOP && vblk < nblk);
+    publish_absmax(absmax, vmax);
 }
 
 // ---------------------------------------------------------------------
@@ -1201,7 +1206,7 @@ extern "C" int mvs_warp_bwd_f32(const float *grad_out, const float *rot_trans,
 // LDS-staged per-tile kernel: features [B,C/16,H,W,16].  sel: see variance_fwd_dma_kernel.
 static int launch_variance_tile_c16(const float *ref_fea, const float *src_feas, const float *rot_trans,
                                     const float *depth_values, const SweepParams &p, float *out_var, int out_c8,
-                                    hipStream_t st, const unsigned *sel) {
+                                    hipStream_t st, const unsigned *sel, unsigned *absmax) {
     const int B = p.B, C = p.C, D = p.D, H = p.H, W = p.W, NV = p.V - 1, depth_mode = p.depth_mode;
     if (C % 16 || C > 64) {
         set_error("mvs_costvol_variance_fwd_f32: C16 features need C in {16,32,48,64}, got %d", C);
@@ -1221,6 +1226,8 @@ static int launch_variance_tile_c16(const float *ref_fea, const float *src_feas,
     // MVS_SWEEP_TILE_LOOP=1 (A/B): behind the chooser, a fixed grid of three workgroups per CU loops over the tiles
     static const bool tile_loop = [] { const char *e = getenv("MVS_SWEEP_TILE_LOOP"); return e && e[0] == '1'; }();
     const bool loop = sel && tile_loop;
+    // (behind the chooser, sel != NULL, the chooser has cleared the word)
+    if (!sel && absmax && hipMemsetAsync(absmax, 0, 4, st) != hipSuccess) return check_launch("variance absmax memset");
     const dim3 g(loop ? (unsigned)(nblk < 3 * device_cu_count() ? nblk : 3 * device_cu_count()) : (unsigned)nblk, (unsigned)B);
 #define MVS_LDS_CASE(n)                                                                                      \
     case n: {                                                                                                \
@@ -1228,15 +1235,15 @@ static int launch_variance_tile_c16(const float *ref_fea, const float *src_feas,
         if (loop)                                                                                            \
             hipLaunchKernelGGL((variance_fwd_dma_kernel<n, true, 4, true>), g, dim3(256), shmem, st,         \
                                ref_fea, src_feas, rot_trans, depth_values, p, tiles_x,                       \
-                               tiles_y, out_var, out_c8, lds_ablate, sel, (int)nblk);                        \
+                               tiles_y, out_var, out_c8, lds_ablate, sel, (int)nblk, absmax);                        \
         else if (depth_mode == 0 && !(lds_ablate & 32))                                                      \
             hipLaunchKernelGGL((variance_fwd_dma_kernel<n, true>), g, dim3(256), shmem, st,                  \
                                ref_fea, src_feas, rot_trans, depth_values, p, tiles_x,                       \
-                               tiles_y, out_var, out_c8, lds_ablate, sel, 0);                                \
+                               tiles_y, out_var, out_c8, lds_ablate, sel, 0, absmax);                         \
         else                                                                                                 \
             hipLaunchKernelGGL((variance_fwd_dma_kernel<n, false>), g, dim3(256), shmem, st,                 \
                                ref_fea, src_feas, rot_trans, depth_values, p, tiles_x,                       \
-                               tiles_y, out_var, out_c8, lds_ablate, sel, 0);                                \
+                               tiles_y, out_var, out_c8, lds_ablate, sel, 0, absmax);                         \
         break;                                                                                               \
     }
     switch (NV) {
@@ -1261,13 +1268,18 @@ __global__ __launch_bounds__(256) void c4_to_c16_sel_kernel(const float4 *__rest
     }
 }
 
-extern "C" int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *src_feas,
-                                            const float *rot_trans, const float *depth_values,
-                                            int depth_mode, int B, int V, int C, int D, int H,
-                                            int W, int align_corners, int alias_quirk,
-                                            int fea_layout, int out_layout, float *out_var,
-                                            void *stream) {
+extern "C" int mvs_absmax_f32(const float *x, int64_t n, void *absmax_bits, void *stream);   // conv_f16x3.hip
+
+// absmax: NULL, or the device word that receives the bit pattern of the largest |variance| (collected by the LDS-staged
+// kernels as they store; one more pass over the volume behind the gather kernels)
+static int variance_fwd_impl(const float *ref_fea, const float *src_feas,
+                             const float *rot_trans, const float *depth_values,
+                             int depth_mode, int B, int V, int C, int D, int H,
+                             int W, int align_corners, int alias_quirk,
+                             int fea_layout, int out_layout, float *out_var, unsigned *absmax,
+                             void *stream) {
     const int NV = V - 1;
+    const int64_t nvol = (int64_t)B * D * H * W * C;
     if (!ref_fea || !src_feas || !rot_trans || !depth_values || !out_var || B <= 0 || D <= 0 ||
         H <= 1 || W <= 1 || depth_mode < 0 || depth_mode > 1) {
         set_error("mvs_costvol_variance_fwd_f32: invalid argument");
@@ -1304,10 +1316,11 @@ extern "C" int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *s
             MVS_PL_CASE(6) MVS_PL_CASE(7) MVS_PL_CASE(8)
         }
 #undef MVS_PL_CASE
+        if (absmax) return mvs_absmax_f32(out_var, nvol, absmax, stream);
         return check_launch("mvs_costvol_variance_fwd_f32(planar)");
     }
     if (fea_layout == MVS_LAYOUT_C16)
-        return launch_variance_tile_c16(ref_fea, src_feas, rot_trans, depth_values, p, out_var, out_c8, st, nullptr);
+        return launch_variance_tile_c16(ref_fea, src_feas, rot_trans, depth_values, p, out_var, out_c8, st, nullptr, absmax);
     if (fea_layout != MVS_LAYOUT_NHWC) return bare_error(MVS_EINVAL, __func__, __LINE__);
     if (C == 8 && (int64_t)H * W < (1 << 26) && H < (1 << 23) && W < (1 << 23) && B <= 65535 &&
         !getenv("MVS_SWEEP_C8_GATHER")) {
@@ -1316,6 +1329,7 @@ extern "C" int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *s
         const int dchunks = (D + kTileD - 1) / kTileD;
         const int64_t nblk = (int64_t)tiles_x * tiles_y * dchunks;
         if (nblk > 0x7fffffffLL) return bare_error(MVS_EINVAL, __func__, __LINE__);
+        if (absmax && hipMemsetAsync(absmax, 0, 4, st) != hipSuccess) return check_launch("variance absmax memset");
         const dim3 g((unsigned)nblk, (unsigned)B);
 #define MVS_LDS8_CASE(n)                                                                          \
     case n: {                                                                                     \
@@ -1323,11 +1337,11 @@ extern "C" int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *s
         if (depth_mode == 0)                                                                      \
             hipLaunchKernelGGL((variance_fwd_dma_kernel<n, true, 2>), g, dim3(256), shmem, st,    \
                                ref_fea, src_feas, rot_trans, depth_values, p, tiles_x, tiles_y,   \
-                               out_var, out_c8, 0, (const unsigned *)nullptr, 0);                 \
+                               out_var, out_c8, 0, (const unsigned *)nullptr, 0, absmax);                 \
         else                                                                                      \
             hipLaunchKernelGGL((variance_fwd_dma_kernel<n, false, 2>), g, dim3(256), shmem, st,   \
                                ref_fea, src_feas, rot_trans, depth_values, p, tiles_x, tiles_y,   \
-                               out_var, out_c8, 0, (const unsigned *)nullptr, 0);                 \
+                               out_var, out_c8, 0, (const unsigned *)nullptr, 0, absmax);                 \
         break;                                                                                    \
     }
         switch (NV) {
@@ -1348,7 +1362,18 @@ extern "C" int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *s
             return MVS_EUNSUPPORTED;
     }
     if (rc != MVS_OK) return rc;
+    if (absmax) return mvs_absmax_f32(out_var, nvol, absmax, stream);
     return check_launch("mvs_costvol_variance_fwd_f32(channels-last)");
+}
+
+extern "C" int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *src_feas,
+                                            const float *rot_trans, const float *depth_values,
+                                            int depth_mode, int B, int V, int C, int D, int H,
+                                            int W, int align_corners, int alias_quirk,
+                                            int fea_layout, int out_layout, float *out_var,
+                                            void *stream) {
+    return variance_fwd_impl(ref_fea, src_feas, rot_trans, depth_values, depth_mode, B, V, C, D, H, W, align_corners,
+                             alias_quirk, fea_layout, out_layout, out_var, nullptr, stream);
 }
 
 // Which sweep kernel: by default the DEVICE decides per call from the geometry (variance_choose_kernel,
@@ -1401,14 +1426,15 @@ extern "C" size_t mvs_costvol_variance_workspace_bytes(int depth_mode, int B, in
     return mvs_costvol_variance_workspace_bytes2(depth_mode, B, V, C, D, H, W, fea_layout, 0);
 }
 
-extern "C" int mvs_costvol_variance_fwd_ws_f32(const float *ref_fea, const float *src_feas,
-                                               const float *rot_trans, const float *depth_values,
-                                               int depth_mode, int B, int V, int C, int D, int H,
-                                               int W, int align_corners, int alias_quirk,
-                                               int fea_layout, int out_layout, int flags,
-                                               float *out_var, void *workspace,
-                                               size_t workspace_bytes, void *stream) {
+extern "C" int mvs_costvol_variance_fwd_ws2_f32(const float *ref_fea, const float *src_feas,
+                                                const float *rot_trans, const float *depth_values,
+                                                int depth_mode, int B, int V, int C, int D, int H,
+                                                int W, int align_corners, int alias_quirk,
+                                                int fea_layout, int out_layout, int flags,
+                                                float *out_var, void *workspace,
+                                                size_t workspace_bytes, void *absmax_bits, void *stream) {
     const bool c4 = fea_layout == MVS_LAYOUT_C4;
+    unsigned *const absmax = static_cast<unsigned *>(absmax_bits);
     hipStream_t st = as_stream(stream);
     if (ref_fea && src_feas && rot_trans && depth_values && out_var && B > 0 && D > 0 && H > 1 && W > 1 && V >= 2 &&
         (out_layout == MVS_LAYOUT_C8 || out_layout == MVS_LAYOUT_NHWC)) {
@@ -1419,7 +1445,7 @@ extern "C" int mvs_costvol_variance_fwd_ws_f32(const float *ref_fea, const float
             const int out_c8 = out_layout == MVS_LAYOUT_C8, lay = c4 ? 1 : (fea_layout == MVS_LAYOUT_NHWC ? 2 : 0);
             if (forced > 0) {
                 const int rc = launch_variance_persist(ref_fea, src_feas, rot_trans, depth_values, p, out_var, out_c8, lay,
-                                                       flags & MVS_SWEEP_FAST, forced, quads, tune, workspace, workspace_bytes, st);
+                                                       flags & MVS_SWEEP_FAST, forced, quads, tune, workspace, workspace_bytes, st, 0, absmax);
                 if (rc == MVS_OK) return check_launch("mvs_costvol_variance_fwd_ws_f32(persistent)");
                 if (rc != MVS_EUNSUPPORTED) return rc;
             } else {
@@ -1431,11 +1457,11 @@ extern "C" int mvs_costvol_variance_fwd_ws_f32(const float *ref_fea, const float
                 // the per-tile kernel reads 16-channel blocks: directly (C16), or from a copy made only if it is chosen (C4);
                 // channels-last maps choose between the two tile depths of the persistent kernel only
                 const int allow_tile = fea_layout != MVS_LAYOUT_NHWC && B <= 65535;
-                int rc = launch_variance_choose(rot_trans, depth_values, p, allow_tile, workspace, st);
+                int rc = launch_variance_choose(rot_trans, depth_values, p, allow_tile, absmax, workspace, st);
                 if (rc != MVS_OK) return rc;
                 for (int nw = 16; nw >= 8; nw -= 8) {   // (autosel 2: no cold-path launch behind the first candidate)
                     rc = launch_variance_persist(ref_fea, src_feas, rot_trans, depth_values, p, out_var, out_c8, lay,
-                                                 flags & MVS_SWEEP_FAST, nw, 2, 0, workspace, workspace_bytes, st, nw == 16 ? 2 : 1);
+                                                 flags & MVS_SWEEP_FAST, nw, 2, 0, workspace, workspace_bytes, st, nw == 16 ? 2 : 1, absmax);
                     if (rc != MVS_OK) return rc == MVS_EUNSUPPORTED ? bare_error(MVS_ELAUNCH, __func__, __LINE__) : rc;
                 }
                 if (allow_tile) {
@@ -1450,7 +1476,7 @@ extern "C" int mvs_costvol_variance_fwd_ws_f32(const float *ref_fea, const float
                                            nmaps * (V - 1), plane, sel);
                         r16 = scratch; s16 = scratch + (size_t)B * C * plane;
                     }
-                    rc = launch_variance_tile_c16(r16, s16, rot_trans, depth_values, p, out_var, out_c8, st, sel);
+                    rc = launch_variance_tile_c16(r16, s16, rot_trans, depth_values, p, out_var, out_c8, st, sel, absmax);
                     if (rc != MVS_OK) return rc;
                 }
                 return check_launch("mvs_costvol_variance_fwd_ws_f32(device-selected)");
@@ -1462,9 +1488,21 @@ extern "C" int mvs_costvol_variance_fwd_ws_f32(const float *ref_fea, const float
                   "(shared depth planes, no alias quirk, mvs_costvol_variance_workspace_bytes2 > 0); use C16 for this shape");
         return MVS_EUNSUPPORTED;
     }
-    return mvs_costvol_variance_fwd_f32(ref_fea, src_feas, rot_trans, depth_values, depth_mode, B, V, C,
-                                        D, H, W, align_corners, alias_quirk, fea_layout, out_layout,
-                                        out_var, stream);
+    return variance_fwd_impl(ref_fea, src_feas, rot_trans, depth_values, depth_mode, B, V, C,
+                             D, H, W, align_corners, alias_quirk, fea_layout, out_layout,
+                             out_var, absmax, stream);
+}
+
+extern "C" int mvs_costvol_variance_fwd_ws_f32(const float *ref_fea, const float *src_feas,
+                                               const float *rot_trans, const float *depth_values,
+                                               int depth_mode, int B, int V, int C, int D, int H,
+                                               int W, int align_corners, int alias_quirk,
+                                               int fea_layout, int out_layout, int flags,
+                                               float *out_var, void *workspace,
+                                               size_t workspace_bytes, void *stream) {
+    return mvs_costvol_variance_fwd_ws2_f32(ref_fea, src_feas, rot_trans, depth_values, depth_mode, B, V, C, D, H, W,
+                                            align_corners, alias_quirk, fea_layout, out_layout, flags, out_var, workspace,
+                                            workspace_bytes, nullptr, stream);
 }
 
 extern "C" int mvs_selftest_div_by_views_f32(int V, unsigned long long *mismatch_count,

@@ -68,6 +68,8 @@ struct PersistArgs {
     int fea_c4;             // features: 0 = [B,C/16,H,W,16], 1 = [B,C/4,H,W,4], 2 = [B,H,W,C]
     float sx, ox, sy, oy;   // FAST: ix = (X/Z) * sx + ox
     int autosel;            // 1: run only if queue[kSelWord] names this kernel's tile depth (variance_choose_kernel)
+    unsigned *absmax;       // NULL, or a device word that collects the bit pattern of the largest |variance| written
+                            // (atomic max; the operand scale of mvs_conv3d_c8_f16x3_f32)
 };
 // workspace header (32-bit words): [0] cold-path records, [1] the chosen tile depth (16, 8, or 0 = the per-tile
 // kernel), [2..7] what the choice was made from (largest / mean footprint box of 16- and 8-plane tiles, texels; box
@@ -174,6 +176,7 @@ __global__ __launch_bounds__(256) void variance_fwd_cold_kernel(PersistArgs a, i
     const size_t grp_floats = (size_t)plane * 16, map_floats = (size_t)plane * p.C;
     const unsigned tex = a.fea_c4 == 1 ? 4u : a.fea_c4 == 2 ? (unsigned)p.C : 16u;   // floats between neighbouring texels of one quad
     const float rV = 1.0f / p.fV;
+    float vmax = 0.0f;
     for (unsigned rec = blockIdx.x * 4 + (threadIdx.x >> 6); rec < count; rec += gridDim.x * 4) {
         const unsigned q = a.queue[kQueueHdr + rec];
         int t = (int)(q >> 4);
@@ -248,9 +251,11 @@ __global__ __launch_bounds__(256) void variance_fwd_cold_kernel(PersistArgs a, i
                     ? pl + ((unsigned)(py * (p.C >> 3) + (g * 2 + (k >> 1))) * (unsigned)p.W + (unsigned)px) * 8u + (k & 1) * 4
                     : pl + (unsigned)pix * (unsigned)p.C + (unsigned)(g * 16 + k * 4);
                 *reinterpret_cast<float4 *>(o) = make_float4(var[0], var[1], var[2], var[3]);
+                vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(var[0]), fabsf(var[1]))), fmaxf(fabsf(var[2]), fabsf(var[3])));
             }
         }
     }
+    publish_absmax(a.absmax, vmax);
 }
 
 
@@ -270,6 +275,7 @@ __global__ __launch_bounds__(1024) void variance_choose_kernel(PersistArgs a, in
     const SweepParams &p = a.p;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid < 2) { s_max[tid] = 0; s_sum[tid] = 0; s_cnt[tid] = 0; }
+    if (tid == 0 && a.absmax) *a.absmax = 0u;
     __syncthreads();
     const int tiles_x = (p.W + kPW - 1) / kPW, tiles_y = (p.H + kPH - 1) / kPH;
     for (int t = wv; t < 54 * p.B; t += 16) {
@@ -496,6 +502,7 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
     unsigned buf_off = 0;
     const float rV = 1.0f / p.fV;
     bool stored = false;   // did this wave issue its NST stores after the last copy it issued?
+    float vmax = 0.0f;     // largest |variance| this lane has stored
 
 #pragma unroll 1
     for (;;) {
@@ -672,6 +679,8 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
                             reinterpret_cast<float4 *>(o + h * step)[0] = make_float4(var[h * 8 + 0], var[h * 8 + 1], var[h * 8 + 2], var[h * 8 + 3]);
                             reinterpret_cast<float4 *>(o + h * step)[1] = make_float4(var[h * 8 + 4], var[h * 8 + 5], var[h * 8 + 6], var[h * 8 + 7]);
                         }
+#pragma unroll
+                        for (int c = 0; c < GC; c += 2) vmax = fmaxf(vmax, fmaxf(fabsf(var[c]), fabsf(var[c + 1])));
                     }
                     stored = true;
                 }
@@ -680,6 +689,7 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
         }
         if (!has_next) break;
     }
+    publish_absmax(a.absmax, vmax);
 }
 
 // Launch table.  MVS_EUNSUPPORTED (nothing launched) when the shape is not this kernel's.
@@ -723,10 +733,10 @@ size_t variance_persist_workspace_bytes(const SweepParams &p, int nw) {
 bool variance_persist_shape_ok(const SweepParams &p) { return persist_shape_ok(p) && persist_tiles(p, 8) < (1 << 27); }
 
 // the chooser in front of the candidate kernels (all of them launched with autosel)
-int launch_variance_choose(const float *rt, const float *depth, const SweepParams &p, int allow_tile, void *workspace,
+int launch_variance_choose(const float *rt, const float *depth, const SweepParams &p, int allow_tile, unsigned *absmax, void *workspace,
                            hipStream_t st) {
     PersistArgs a{};
-    a.rt = rt; a.depth = depth; a.p = p;
+    a.rt = rt; a.depth = depth; a.p = p; a.absmax = absmax;
     if (p.align_corners) { a.sx = 1.0f; a.ox = 0.0f; a.sy = 1.0f; a.oy = 0.0f; }
     else {
         a.sx = (float)((double)p.W / (double)(p.W - 1)); a.ox = -0.5f;
@@ -742,7 +752,7 @@ int launch_variance_choose(const float *rt, const float *depth, const SweepParam
 int launch_variance_persist(const float *ref16, const float *srcs16, const float *rt,
                             const float *depth, const SweepParams &p, float *out, int out_c8,
                             int fea_c4, int fast, int nw, int nq, int flags, void *workspace,
-                            size_t workspace_bytes, hipStream_t st, int autosel) {
+                            size_t workspace_bytes, hipStream_t st, int autosel, unsigned *absmax) {
     if ((nw != 8 && nw != 16) || nq != 2) return MVS_EUNSUPPORTED;
     const size_t need = variance_persist_workspace_bytes(p, nw);
     if (need == 0) return MVS_EUNSUPPORTED;
@@ -770,6 +780,7 @@ int launch_variance_persist(const float *ref16, const float *srcs16, const float
     a.flags = flags;
     a.fea_c4 = fea_c4;
     a.autosel = autosel;
+    a.absmax = absmax;
     if (p.align_corners) { a.sx = 1.0f; a.ox = 0.0f; a.sy = 1.0f; a.oy = 0.0f; }
     else {
         a.sx = (float)((double)p.W / (double)(p.W - 1)); a.ox = -0.5f;
@@ -777,6 +788,7 @@ int launch_variance_persist(const float *ref16, const float *srcs16, const float
     }
     // (with autosel the chooser has cleared the header)
     if (!autosel && hipMemsetAsync(workspace, 0, 4 * kQueueHdr, st) != hipSuccess) return check_launch("variance workspace memset");
+    if (!autosel && absmax && hipMemsetAsync(absmax, 0, 4, st) != hipSuccess) return check_launch("variance absmax memset");
     const int grid = device_cu_count();
     const int NV = p.V - 1;
 #define MVS_PERSIST_PICK(W_, Q_)                                                             \

@@ -40,6 +40,8 @@ def pack_costreg(sd, prefix=""):
                            stride=stride, transposed=tr, packed=ops.pack_conv3d_weight(w, tr, stride, split=True))
         if ops.conv_split_enabled():
             P["conv0"]["packed_split"] = ops.pack_conv3d_weight_split(P["conv0"]["weight"])
+        if ops.conv0_f16_enabled():
+            P["conv0"]["packed_f16x3"] = ops.pack_conv3d_weight_f16x3(P["conv0"]["weight"])
         w = sd[f"{prefix}prob.weight"].float().contiguous()
         bias = sd.get(f"{prefix}prob.bias")
         P["prob"] = dict(weight=w, scale=None, shift=None if bias is None else bias.float().contiguous(),
@@ -47,15 +49,17 @@ def pack_costreg(sd, prefix=""):
     return P
 
 
-def costreg_forward(x_cl, P, impl=ops.IMPL_AUTO, in_c8=False):
+def costreg_forward(x_cl, P, impl=ops.IMPL_AUTO, in_c8=False, x_absmax=None):
     """x_cl [B,D,H,W,Cin] channels-last (in_c8: [B,D,H,Cin/8,W,8]) -> cost [B,D,H,W]
     (module.py:429-438)."""
     D, H, W = x_cl.shape[1], x_cl.shape[2], x_cl.shape[4 if in_c8 else 3]
     if D % 8 == 0 and H % 8 == 0 and W % 8 == 0:
-        return ops.costreg_forward(x_cl, P, in_c8=in_c8, impl=impl)   # one C call: mvs_costreg_fwd_f32
+        return ops.costreg_forward(x_cl, P, in_c8=in_c8, impl=impl, x_absmax=x_absmax)   # one C call: mvs_costreg_fwd2_f32
 
     def run(name, t, skip=None, relu=True, c8=False):
         p = P[name]
+        if c8 and p.get("packed_f16x3") is not None and impl != ops.IMPL_DIRECT:
+            return ops.conv3d_c8_f16x3(t, p["packed_f16x3"], x_absmax, p["scale"], p["shift"], skip, relu)
         if c8 and p.get("packed_split") is not None and impl != ops.IMPL_DIRECT:
             return ops.conv3d_c8_split(t, p["packed_split"], p["scale"], p["shift"], skip, relu)
         return ops.conv3d(t, p["weight"], p["scale"], p["shift"], skip, relu, p["transposed"],
@@ -96,13 +100,16 @@ def depthnet_forward(features, cas_proj, depth_values, costreg_params, prob_volu
             blk = 4 if ops.variance_persistent_supported(depth_values, fcl.shape[1], fcl.shape[0], C,
                                                          fcl.shape[2], fcl.shape[3]) else 16
             f16 = fcl.reshape(*fcl.shape[:4], C // blk, blk).permute(0, 1, 4, 2, 3, 5).contiguous()
+    amax = None
     with ops.stage(tag + "costvol_variance"):
         if use_dma:
-            var = ops.costvol_variance_c16(f16[0], f16[1:], rts, depth_values, out_c8=True)
+            if costreg_params["conv0"].get("packed_f16x3") is not None:   # conv0's operand scale, collected by the sweep kernel
+                amax = torch.empty(1, device=fcl.device, dtype=torch.int32)
+            var = ops.costvol_variance_c16(f16[0], f16[1:], rts, depth_values, out_c8=True, absmax_out=amax)
         else:
             var = ops.costvol_variance_cl(fcl[0], fcl[1:], rts, depth_values, out_c8=True)
     with ops.stage(tag + "costreg"):
-        cost = costreg_forward(var, costreg_params, in_c8=True)
+        cost = costreg_forward(var, costreg_params, in_c8=True, x_absmax=amax)
         if prob_volume_init is not None:
             cost = cost + prob_volume_init
     with ops.stage(tag + "softmax_regress_conf"):

@@ -224,6 +224,8 @@ class CostRegNet(nn.Module):
                                     packed=ops.pack_conv3d_weight(w, kind == "deconv", stride, split=True))
             if ops.conv_split_enabled():
                 params["conv0"]["packed_split"] = ops.pack_conv3d_weight_split(params["conv0"]["weight"])
+            if ops.conv0_f16_enabled():     # default: conv0 on the two-piece fp16 kernel (MVS_CONV0_F16=0: the bf16 one)
+                params["conv0"]["packed_f16x3"] = ops.pack_conv3d_weight_f16x3(params["conv0"]["weight"])
             w = self.prob.weight.detach().float().contiguous()
             params["prob"] = dict(weight=w, scale=None,
                                   shift=self.prob.bias.detach().float().contiguous(), stride=1,
@@ -236,15 +238,16 @@ class CostRegNet(nn.Module):
         volume as [B,D,H,C/8,W,8] (see include/mvs_hip.h, MVS_LAYOUT_C8)."""
         return self.conv_impl != ops.IMPL_DIRECT and self._hip_params()["conv0"]["packed"] is not None
 
-    def forward_hip(self, x_cl, in_c8=False):
+    def forward_hip(self, x_cl, in_c8=False, x_absmax=None):
         """x_cl: variance volume, channels-last [B,D,H,W,32] (or 8-channel blocked
-        [B,D,H,4,W,8] with in_c8) -> cost [B,D,H,W]."""
+        [B,D,H,4,W,8] with in_c8) -> cost [B,D,H,W].  x_absmax: the word the variance op filled with the volume's
+        largest magnitude (conv0's operand scale on the fp16 kernel; None: collected by one more pass)."""
         P = self._hip_params()
         D, H, W = (x_cl.shape[1], x_cl.shape[2], x_cl.shape[4 if in_c8 else 3])
         if not ops.timing_enabled() and D % 8 == 0 and H % 8 == 0 and W % 8 == 0:
             # one C call for the eleven layers (mvs_costreg_fwd_f32); the per-layer calls below
             # remain for stage timing and for sizes the whole-net entry does not take
-            return ops.costreg_forward(x_cl, P, in_c8=in_c8, impl=self.conv_impl)
+            return ops.costreg_forward(x_cl, P, in_c8=in_c8, impl=self.conv_impl, x_absmax=x_absmax)
 
         def run(name, t, skip=None, relu=True):
             p = P[name]
@@ -252,6 +255,8 @@ class CostRegNet(nn.Module):
                 return _conv(p, t, skip, relu)
 
         def _conv(p, t, skip, relu, c8=False):
+            if c8 and p.get("packed_f16x3") is not None and self.conv_impl != ops.IMPL_DIRECT:
+                return ops.conv3d_c8_f16x3(t, p["packed_f16x3"], x_absmax, p["scale"], p["shift"], skip, relu)
             if c8 and p.get("packed_split") is not None and self.conv_impl != ops.IMPL_DIRECT:
                 return ops.conv3d_c8_split(t, p["packed_split"], p["scale"], p["shift"], skip, relu)
             return ops.conv3d(t, p["weight"], p["scale"], p["shift"], skip, relu, p["transposed"],
@@ -436,14 +441,17 @@ class MVSNet(nn.Module):
                     f16 = f.reshape(B, V, h, w, C // blk, blk).permute(1, 0, 4, 2, 3, 5).contiguous()
                 else:
                     fcl = f.reshape(B, V, h, w, C).transpose(0, 1).contiguous()   # [V,B,h,w,C]
+            amax = None
             with ops.stage("costvol_variance"):
                 if use_lds:
+                    if c8 and ops.conv0_f16_enabled():   # the sweep kernels collect conv0's operand scale as they store
+                        amax = torch.empty(1, device=f16.device, dtype=torch.int32)
                     var = ops.costvol_variance_c16(f16[0], f16[1:], rts, depth_values,
-                                                   self.align_corners, out_c8=c8, fast=self.variance_fast)
+                                                   self.align_corners, out_c8=c8, fast=self.variance_fast, absmax_out=amax)
                 else:
                     var = ops.costvol_variance_cl(fcl[0], fcl[1:], rts, depth_values,
                                                   self.align_corners, out_c8=c8)
-            cost = self.cost_regularization.forward_hip(var, in_c8=c8)  # [B,D,h,w]
+            cost = self.cost_regularization.forward_hip(var, in_c8=c8, x_absmax=amax)  # [B,D,h,w]
         with ops.stage("softmax_regress_conf"):
             depth, conf, _ = ops.softmax_regress_conf(cost, depth_values)
         out = {"depth": depth, "photometric_confidence": conf}

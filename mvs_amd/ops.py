@@ -491,11 +491,13 @@ def _variance_workspace(dev, nbytes):
 
 
 def costvol_variance_c16(ref16, srcs16, rts, depth_values, align_corners=False, alias_quirk=False,
-                         out_c8=False, fast=False):
+                         out_c8=False, fast=False, absmax_out=None):
     """LDS-staged fused warp+variance.  ref16 [B,C/16,H,W,16]; srcs16 [V-1,B,C/16,H,W,16]
     -> [B,D,H,W,C] or (out_c8) [B,D,H,C/8,W,8].  Shared depth planes run the persistent
     kernel (mvs_costvol_variance_fwd_ws_f32); `fast` selects its fast-coordinate mode
-    (MVS_SWEEP_FAST), otherwise the result is bit-identical to the reference's arithmetic."""
+    (MVS_SWEEP_FAST), otherwise the result is bit-identical to the reference's arithmetic.
+    absmax_out: one-word int32 device tensor that receives the bit pattern of the volume's largest magnitude
+    (mvs_costvol_variance_fwd_ws2_f32; what conv3d_c8_f16x3 / costreg_forward scale conv0's operands by)."""
     ref16, srcs16, depth_values = _f32c(ref16), _f32c(srcs16), _f32c(depth_values)
     B, G, H, W, blk = ref16.shape
     if blk not in (4, 16):
@@ -510,16 +512,18 @@ def costvol_variance_c16(ref16, srcs16, rts, depth_values, align_corners=False, 
     mode = _depth_mode(depth_values)
     need = lib.mvs_costvol_variance_workspace_bytes2(mode, B, V, C, D, H, W, layout, int(alias_quirk))
     ws = _variance_workspace(ref16.device, need) if need else None
-    check(lib.mvs_costvol_variance_fwd_ws_f32(
+    check(lib.mvs_costvol_variance_fwd_ws2_f32(
         ptr(ref16), ptr(srcs16), ptr(rts), ptr(depth_values), mode, B, V, C,
         D, H, W, int(align_corners), int(alias_quirk), layout,
         MVS_LAYOUT_C8 if out_c8 else MVS_LAYOUT_NHWC, 1 if fast else 0, ptr(out),
         ctypes.c_void_p(ws.data_ptr()) if ws is not None else None, ws.numel() if ws is not None else 0,
-        stream()), "mvs_costvol_variance_fwd_ws_f32")
+        ctypes.c_void_p(absmax_out.data_ptr()) if absmax_out is not None else None,
+        stream()), "mvs_costvol_variance_fwd_ws2_f32")
     return out
 
 
-def costvol_variance_nhwc_ws(ref_cl, srcs_cl, rts, depth_values, align_corners=False, out_c8=False, fast=False):
+def costvol_variance_nhwc_ws(ref_cl, srcs_cl, rts, depth_values, align_corners=False, out_c8=False, fast=False,
+                             absmax_out=None):
     """Channels-last maps [B,H,W,C] / [V-1,B,H,W,C] through the workspace entry: the persistent kernel
     reads them in place (no re-blocking copy) when the shape is its own, else the gather kernel runs."""
     ref_cl, srcs_cl, depth_values = _f32c(ref_cl), _f32c(srcs_cl), _f32c(depth_values)
@@ -532,11 +536,12 @@ def costvol_variance_nhwc_ws(ref_cl, srcs_cl, rts, depth_values, align_corners=F
     mode = _depth_mode(depth_values)
     need = lib.mvs_costvol_variance_workspace_bytes(mode, B, V, C, D, H, W, MVS_LAYOUT_NHWC)
     ws = _variance_workspace(ref_cl.device, need) if need else None
-    check(lib.mvs_costvol_variance_fwd_ws_f32(
+    check(lib.mvs_costvol_variance_fwd_ws2_f32(
         ptr(ref_cl), ptr(srcs_cl), ptr(rts), ptr(depth_values), mode, B, V, C, D, H, W, int(align_corners), 0,
         MVS_LAYOUT_NHWC, MVS_LAYOUT_C8 if out_c8 else MVS_LAYOUT_NHWC, 1 if fast else 0, ptr(out),
         ctypes.c_void_p(ws.data_ptr()) if ws is not None else None, ws.numel() if ws is not None else 0,
-        stream()), "mvs_costvol_variance_fwd_ws_f32")
+        ctypes.c_void_p(absmax_out.data_ptr()) if absmax_out is not None else None,
+        stream()), "mvs_costvol_variance_fwd_ws2_f32")
     return out
 
 
@@ -661,6 +666,49 @@ def conv3d_c8_split(x_c8, packed_split, scale=None, shift=None, residual=None, r
             ptr(_f32c(shift)) if shift is not None else None,
             ptr(_f32c(residual)) if residual is not None else None, int(bool(relu)), B, G * 8, D, H, W,
             ptr(out), stream()), "mvs_conv3d_c8_bf16x6_f32")
+    return out
+
+
+def pack_conv3d_weight_f16x3(weight):
+    """(8, Cin, 3, 3, 3) weight -> the scaled fp16 hi/lo A fragments of conv3d_c8_f16x3 + the trailer that undoes the
+    scale (None if the shape has no such kernel)."""
+    weight = _f32c(weight)
+    if weight.dim() != 5 or weight.shape[0] != 8 or tuple(weight.shape[2:]) != (3, 3, 3):
+        return None
+    n = _lib.load().mvs_conv3d_f16x3_packed_bytes(int(weight.shape[1]))
+    if n == 0:
+        return None
+    packed = torch.empty(n // 4, device=weight.device, dtype=torch.float32)   # opaque bytes
+    check(_lib.load().mvs_conv3d_pack_weights_f16x3_f32(ptr(weight), int(weight.shape[1]), ptr(packed), stream()),
+          "mvs_conv3d_pack_weights_f16x3_f32")
+    return packed
+
+
+def absmax(x, out=None):
+    """Largest magnitude of a device array as the bit pattern of |x| in a one-word int32 tensor (mvs_absmax_f32)."""
+    x = _f32c(x)
+    if out is None:
+        out = torch.empty(1, device=x.device, dtype=torch.int32)
+    with stage("absmax"):
+        check(_lib.load().mvs_absmax_f32(ptr(x), x.numel(), ctypes.c_void_p(out.data_ptr()), stream()), "mvs_absmax_f32")
+    return out
+
+
+def conv3d_c8_f16x3(x_c8, packed, x_absmax=None, scale=None, shift=None, residual=None, relu=False):
+    """conv0-class layer (3x3x3, Cout 8, stride 1) on the fp16 matrix pipe with two-piece operands, three products
+    (mvs_conv3d_c8_f16x3_f32): x_c8 [B,D,H,Cin/8,W,8] -> [B,D,H,W,8].  x_absmax: the one-word tensor the producer of
+    x_c8 filled (None: computed here by one more pass over x_c8)."""
+    x_c8 = _f32c(x_c8)
+    B, D, H, G, W, _ = x_c8.shape
+    if x_absmax is None:
+        x_absmax = absmax(x_c8)
+    out = torch.empty(B, D, H, W, 8, device=x_c8.device, dtype=torch.float32)
+    with stage("conv3d_split"):
+        check(_lib.load().mvs_conv3d_c8_f16x3_f32(
+            ptr(x_c8), ctypes.c_void_p(x_absmax.data_ptr()), ptr(packed), ptr(_f32c(scale)) if scale is not None else None,
+            ptr(_f32c(shift)) if shift is not None else None,
+            ptr(_f32c(residual)) if residual is not None else None, int(bool(relu)), B, G * 8, D, H, W,
+            ptr(out), stream()), "mvs_conv3d_c8_f16x3_f32")
     return out
 
 
@@ -882,7 +930,14 @@ COSTREG_ORDER = ("conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6", 
 _costreg_ws = {}
 
 
-def costreg_forward(x, params, in_c8=False, impl=IMPL_AUTO):
+def conv0_f16_enabled():
+    """False when MVS_CONV0_F16=0 keeps conv0 on the three-piece bf16 kernel (six products; A/B switch).  Default: the
+    two-piece fp16 kernel (three products, mvs_conv3d_c8_f16x3_f32)."""
+    import os
+    return conv_split_enabled() and os.environ.get("MVS_CONV0_F16", "1") != "0"
+
+
+def costreg_forward(x, params, in_c8=False, impl=IMPL_AUTO, x_absmax=None):
     """The whole 3D U-Net in one C call (mvs_costreg_fwd_f32; mvsnet.py:83-93).  x: variance
     volume [B,D,H,W,Cin] or (in_c8) [B,D,H,Cin/8,W,8]; params: name -> dict(weight, packed, scale,
     shift) for the eleven layers of COSTREG_ORDER.  -> cost [B,D,H,W].  The activations live in a
@@ -917,10 +972,13 @@ def costreg_forward(x, params, in_c8=False, impl=IMPL_AUTO):
                     raise MvsHipError("costreg_forward needs device tensors")
                 setattr(layers[i], field, t.data_ptr())
     out = torch.empty((B, D, H, W), device=x.device, dtype=torch.float32)
-    check(lib.mvs_costreg_fwd_f32(ptr(x), MVS_LAYOUT_C8 if in_c8 else MVS_LAYOUT_NHWC,
-                                  ctypes.cast(layers, ctypes.c_void_p), B, cin, base, D, H, W, impl,
-                                  ctypes.c_void_p(ws.data_ptr()), ws.numel(), ptr(out), stream()),
-          "mvs_costreg_fwd_f32")
+    f16 = params["conv0"].get("packed_f16x3") if in_c8 else None    # conv0 on the two-piece fp16 kernel; x_absmax from
+    check(lib.mvs_costreg_fwd2_f32(ptr(x), MVS_LAYOUT_C8 if in_c8 else MVS_LAYOUT_NHWC,   # the variance op, or collected in the call
+                                   ctypes.cast(layers, ctypes.c_void_p), B, cin, base, D, H, W, impl,
+                                   ctypes.c_void_p(ws.data_ptr()), ws.numel(), ptr(f16) if f16 is not None else None,
+                                   ctypes.c_void_p(x_absmax.data_ptr()) if (x_absmax is not None and f16 is not None) else None,
+                                   ptr(out), stream()),
+          "mvs_costreg_fwd2_f32")
     return out
 
 
