@@ -144,16 +144,20 @@ int mvs_costvol_variance_fwd_ws_f32(const float *ref_fea, const float *src_feas,
                                     int align_corners, int alias_quirk, int fea_layout,
                                     int out_layout, int flags, float *out_var, void *workspace,
                                     size_t workspace_bytes, void *stream);
-/* The same, and the largest magnitude of the volume as a by-product: absmax_bits = NULL, or a device word that
- * receives the bit pattern of max |out_var| -- the operand scale mvs_conv3d_c8_f16x3_f32 / mvs_costreg_fwd2_f32 need.
- * The LDS-staged kernels collect it as they store (one atomic max per wave); behind the gather kernels it costs one more
- * pass over the volume (mvs_absmax_f32). */
+/* The same, and the largest magnitude of the volume as a by-product: absmax = NULL, or an ABSMAX BLOCK -- MVS_ABSMAX_WORDS
+ * 32-bit device words, 16-byte aligned, that together hold max |x| of an array as the bit pattern of a non-negative float:
+ * word i collects the workgroups with index i mod MVS_ABSMAX_WORDS (one shared word made the atomics of thousands of waves
+ * queue up at the end of a kernel), the reader takes the maximum of all words.  It is the operand scale
+ * mvs_conv3d_c8_f16x3_f32 / mvs_costreg_fwd2_f32 / mvs_conv_split_f16_f32 need.  This call RESETS the block; the LDS-staged
+ * kernels then collect as they store (one atomic max per wave); behind the gather kernels it costs one more pass over the
+ * volume (mvs_absmax_f32). */
+#define MVS_ABSMAX_WORDS 256
 int mvs_costvol_variance_fwd_ws2_f32(const float *ref_fea, const float *src_feas,
                                      const float *rot_trans, const float *depth_values,
                                      int depth_mode, int B, int V, int C, int D, int H, int W,
                                      int align_corners, int alias_quirk, int fea_layout,
                                      int out_layout, int flags, float *out_var, void *workspace,
-                                     size_t workspace_bytes, void *absmax_bits, void *stream);
+                                     size_t workspace_bytes, void *absmax, void *stream);
 /* Self-test: the variance kernel divides by the view count V with a 3-op
  * multiply/FMA sequence instead of an IEEE division; this checks it against
  * x / V for EVERY float bit pattern on the device and writes the number of
@@ -182,6 +186,14 @@ int mvs_conv3d_f32(const float *in, const float *weight, const float *packed_wei
                    const float *scale, const float *shift, const float *residual, int relu,
                    int transposed, int B, int Cin, int Cout, int D, int H, int W, int stride,
                    int layout, int impl, float *out, void *stream);
+/* The same, and the largest magnitude of `out` into the absmax block out_absmax (MVS_ABSMAX_WORDS words, see
+ * mvs_costvol_variance_fwd_ws2_f32; NULL = none): the MFMA convolutions collect it in their epilogue (max-ed INTO the block:
+ * the caller clears it); behind the other kernels it costs one more pass over `out` (mvs_absmax_f32).  For a layer whose
+ * output feeds a two-piece fp16 layer (mvs_conv_split_f16_f32 ...). */
+int mvs_conv3d_absmax_f32(const float *in, const float *weight, const float *packed_weight,
+                          const float *scale, const float *shift, const float *residual, int relu,
+                          int transposed, int B, int Cin, int Cout, int D, int H, int W, int stride,
+                          int layout, int impl, float *out, void *out_absmax, void *stream);
 /* Number of floats mvs_conv3d_pack_weights_f32 writes for this layer. */
 int64_t mvs_conv3d_packed_weight_floats(int transposed, int Cin, int Cout, int stride);
 /* Re-order a PyTorch-layout weight tensor into MFMA A-fragment order. */
@@ -208,18 +220,19 @@ int mvs_conv3d_c8_bf16x6_f32(const float *in, const void *packed, const float *s
  * a b ~ ah bh + ah bl + al bh, each product exact in the fp32 accumulator.  Against a float64 convolution the result is
  * as close as the bf16 form's and ATen's fp32 convolution (the fp32 accumulation, common to all three, is what sets the
  * distance; tests/test_gpu_parity.py::test_conv3d_f16x3_*).  fp16 has 5 exponent bits, so the kernel scales its input
- * by 2^(14 - exponent(max |in|)): in_absmax = device word holding the bit pattern of the largest magnitude of `in`,
- * written by the producer of the volume (mvs_costvol_variance_fwd_ws2_f32) or by mvs_absmax_f32 (one pass over the
- * array: resets the word, then collects; n floats, 16-byte aligned).  An element below 2^-18 of the maximum keeps an
+ * by 2^(14 - exponent(max |in|)): in_absmax = the absmax block (MVS_ABSMAX_WORDS words, see
+ * mvs_costvol_variance_fwd_ws2_f32) of `in`, filled by the producer of the volume or by mvs_absmax_f32 (one pass over the
+ * array: resets the block, then collects; n floats, 16-byte aligned).  An element below 2^-18 of the maximum keeps an
  * absolute error below 2^-40 of the maximum.  The weights are scaled the same way when packed:
- * mvs_conv3d_f16x3_packed_bytes(Cin) bytes (0 = unsupported Cin; supported: 8, 16, 32).  Other arguments as
- * mvs_conv3d_c8_bf16x6_f32. */
+ * mvs_conv3d_f16x3_packed_bytes(Cin) bytes (0 = unsupported Cin; supported: 8, 16, 32).  out_absmax: NULL, or the
+ * absmax block the largest magnitude of `out` is atomically max-ed INTO as it is stored (the next layer's operand scale;
+ * the caller clears it -- one memset serves the blocks of a whole network).  Other arguments as mvs_conv3d_c8_bf16x6_f32. */
 size_t mvs_conv3d_f16x3_packed_bytes(int Cin);
 int mvs_conv3d_pack_weights_f16x3_f32(const float *weight, int Cin, void *packed, void *stream);
-int mvs_absmax_f32(const float *x, int64_t n, void *absmax_bits, void *stream);
+int mvs_absmax_f32(const float *x, int64_t n, void *absmax, void *stream);
 int mvs_conv3d_c8_f16x3_f32(const float *in, const void *in_absmax, const void *packed, const float *scale,
                             const float *shift, const float *residual, int relu, int B, int Cin, int D, int H, int W,
-                            float *out, void *stream);
+                            float *out, void *out_absmax, void *stream);
 
 /* The same split-operand arithmetic for the 3x3(x3), stride-1, pad-1 layers with 16 / 32 / 64 input and output
  * channels (CostRegNet conv2 / conv4 / conv6, mvsnet.py:68-72; FeatureNet's 16 -> 16 and 32 -> 32 layers,
@@ -250,6 +263,21 @@ int mvs_deconv_split_f32(const float *in, const void *packed, const float *scale
                          const float *residual, int relu, int B, int Cin, int Cout, int D, int H, int W,
                          float *out, void *stream);
 
+/* The two-piece fp16 form of both (mvs_conv3d_c8_f16x3_f32 has the arithmetic and the error bound; same shapes, same
+ * supported-predicates): weights scaled and packed by the *_pack_weights_f16_f32 functions (packed_bytes includes a 16-byte
+ * trailer); in_absmax = the absmax block of `in` (required); out_absmax = NULL, or the absmax block the largest magnitude
+ * of `out` is max-ed INTO in the epilogue (the caller clears it; the next two-piece layer's in_absmax). */
+size_t mvs_conv_split_f16_packed_bytes(int kd, int Cin, int Cout, int stride);
+int mvs_conv_split_pack_weights_f16_f32(const float *weight, int kd, int Cin, int Cout, int stride, void *packed, void *stream);
+int mvs_conv_split_f16_f32(const float *in, const void *in_absmax, const void *packed, const float *scale,
+                           const float *shift, const float *residual, int relu, int kd, int stride, int B, int Cin,
+                           int Cout, int D, int H, int W, int out_c4, float *out, void *out_absmax, void *stream);
+size_t mvs_deconv_split_f16_packed_bytes(int Cin, int Cout);
+int mvs_deconv_split_pack_weights_f16_f32(const float *weight, int Cin, int Cout, void *packed, void *stream);
+int mvs_deconv_split_f16_f32(const float *in, const void *in_absmax, const void *packed, const float *scale,
+                             const float *shift, const float *residual, int relu, int B, int Cin, int Cout, int D,
+                             int H, int W, float *out, void *out_absmax, void *stream);
+
 /* The whole 3D U-Net in one call -- CostRegNet.forward, mvsnet.py:83-93 (also the cascade's
  * CostRegNet, CasMVSNet/models/module.py:407-438): conv0 .. conv6 (3x3x3 + folded BN + ReLU, strides
  * 1 2 1 2 1 2 1), conv7 / conv9 / conv11 (transposed, stride 2, + BN + ReLU, skip-add of conv4 /
@@ -275,13 +303,16 @@ size_t mvs_costreg_workspace_bytes(int B, int base, int D, int H, int W);
 int mvs_costreg_fwd_f32(const float *in, int in_layout, const mvs_conv_layer *layers, int B, int Cin,
                         int base, int D, int H, int W, int impl, void *workspace,
                         size_t workspace_bytes, float *out_cost, void *stream);
-/* The same with conv0 on the two-piece fp16 kernel: conv0_f16x3 = mvs_conv3d_pack_weights_f16x3_f32 of conv0's weight
- * (NULL: as mvs_costreg_fwd_f32), taken for an MVS_LAYOUT_C8 input; in_absmax = the device word the producer of `in`
- * filled (mvs_costvol_variance_fwd_ws2_f32), or NULL: the largest magnitude is then collected here by one more pass
- * over `in` (mvs_absmax_f32 into the workspace). */
-int mvs_costreg_fwd2_f32(const float *in, int in_layout, const mvs_conv_layer *layers, int B, int Cin,
-                         int base, int D, int H, int W, int impl, void *workspace, size_t workspace_bytes,
-                         const void *conv0_f16x3, const void *in_absmax, float *out_cost, void *stream);
+/* The same with layers on the two-piece fp16 kernels (three products per fp32 product instead of six): packed_f16[11] =
+ * per layer, in the order of `layers`, its two-piece pack or NULL -- conv0: mvs_conv3d_pack_weights_f16x3_f32 (taken for an
+ * MVS_LAYOUT_C8 input); conv1 .. conv6: mvs_conv_split_pack_weights_f16_f32; conv7 / conv9 / conv11:
+ * mvs_deconv_split_pack_weights_f16_f32; a NULL entry (and prob) runs as in mvs_costreg_fwd_f32.  The operand scale of such
+ * a layer is the absmax block of its input, which the layer in front of it collects in its epilogue into the workspace
+ * (behind conv3 / conv5 on the fp32 kernels: one more pass over their small outputs).  in_absmax = the absmax block the
+ * producer of `in` filled (mvs_costvol_variance_fwd_ws2_f32), or NULL: collected here by one more pass over `in`. */
+int mvs_costreg_fwd2_f32(const float *in, int in_layout, const mvs_conv_layer *layers, const void *const *packed_f16,
+                         int B, int Cin, int base, int D, int H, int W, int impl, void *workspace, size_t workspace_bytes,
+                         const void *in_absmax, float *out_cost, void *stream);
 
 /* Weight gradient of one 3x3x3 layer (training, BASELINE config 5; the reference gets it from
  * autograd through nn.Conv3d / nn.ConvTranspose3d, module.py:26-33, mvsnet.py:66-79):
@@ -420,6 +451,11 @@ int mvs_feature_head_pack_weights_f32(const float *weight1, void *packed, void *
 int mvs_feature_head_f32(const float *img, const float *weight0, const float *scale0, const float *shift0,
                          const void *packed1, const float *scale1, const float *shift1, int N, int H, int W,
                          float *out, void *stream);
+/* The same, and the largest magnitude of `out` max-ed INTO the absmax block out_absmax (the caller clears it; NULL = none):
+ * the operand scale of the two-piece fp16 layer that reads `out` (mvs_conv_split_f16_f32). */
+int mvs_feature_head_absmax_f32(const float *img, const float *w0, const float *scale0, const float *shift0,
+                                const void *packed1, const float *scale1, const float *shift1, int N, int H, int W,
+                                float *out, void *out_absmax, void *stream);
 /* The full-resolution end of CasMVSNet's FPN in one kernel (CasMVSNet/models/module.py:396-398,
  * `intra_feat = F.interpolate(intra_feat, scale_factor=2, mode="nearest") + self.inner2(conv0)` followed by
  * `out = self.out3(intra_feat)`, final_chs = 32, base_channels = 8): the 32-channel full-resolution map stays in LDS

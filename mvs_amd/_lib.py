@@ -41,9 +41,10 @@ _SIGS = {
     "mvs_selftest_div_by_views_f32": (_c_i, [_c_i, _c_f, _c_f]),
     "mvs_costvol_variance_bwd_f32": (_c_i, [_c_f] * 5 + [_c_i] * 10 + [_c_f, _c_f, _c_f]),
     "mvs_conv3d_f32": (_c_i, [_c_f] * 6 + [_c_i] * 11 + [_c_f, _c_f]),
+    "mvs_conv3d_absmax_f32": (_c_i, [_c_f] * 6 + [_c_i] * 11 + [_c_f, _c_f, _c_f]),
     "mvs_costreg_workspace_bytes": (ctypes.c_size_t, [_c_i] * 5),
     "mvs_costreg_fwd_f32": (_c_i, [_c_f, _c_i, _c_f] + [_c_i] * 7 + [_c_f, ctypes.c_size_t, _c_f, _c_f]),
-    "mvs_costreg_fwd2_f32": (_c_i, [_c_f, _c_i, _c_f] + [_c_i] * 7 + [_c_f, ctypes.c_size_t, _c_f, _c_f, _c_f, _c_f]),
+    "mvs_costreg_fwd2_f32": (_c_i, [_c_f, _c_i, _c_f, _c_f] + [_c_i] * 7 + [_c_f, ctypes.c_size_t, _c_f, _c_f, _c_f]),
     "mvs_conv3d_packed_weight_floats": (_c_l, [_c_i] * 4),
     "mvs_conv3d_pack_weights_f32": (_c_i, [_c_f] + [_c_i] * 4 + [_c_f, _c_f]),
     "mvs_conv3d_mfma_supported": (_c_i, [_c_i] * 4),
@@ -53,14 +54,20 @@ _SIGS = {
     "mvs_conv3d_f16x3_packed_bytes": (ctypes.c_size_t, [_c_i]),
     "mvs_conv3d_pack_weights_f16x3_f32": (_c_i, [_c_f, _c_i, _c_f, _c_f]),
     "mvs_absmax_f32": (_c_i, [_c_f, _c_l, _c_f, _c_f]),
-    "mvs_conv3d_c8_f16x3_f32": (_c_i, [_c_f] * 6 + [_c_i] * 6 + [_c_f, _c_f]),
+    "mvs_conv3d_c8_f16x3_f32": (_c_i, [_c_f] * 6 + [_c_i] * 6 + [_c_f, _c_f, _c_f]),
     "mvs_conv_split_supported": (_c_i, [_c_i] * 4),
     "mvs_conv_split_packed_bytes": (ctypes.c_size_t, [_c_i] * 4),
     "mvs_conv_split_pack_weights_f32": (_c_i, [_c_f] + [_c_i] * 4 + [_c_f, _c_f]),
     "mvs_conv_split_f32": (_c_i, [_c_f] * 5 + [_c_i] * 10 + [_c_f, _c_f]),
+    "mvs_conv_split_f16_packed_bytes": (ctypes.c_size_t, [_c_i] * 4),
+    "mvs_conv_split_pack_weights_f16_f32": (_c_i, [_c_f] + [_c_i] * 4 + [_c_f, _c_f]),
+    "mvs_conv_split_f16_f32": (_c_i, [_c_f] * 6 + [_c_i] * 10 + [_c_f, _c_f, _c_f]),
     "mvs_deconv_split_supported": (_c_i, [_c_i] * 2),
     "mvs_deconv_split_packed_bytes": (ctypes.c_size_t, [_c_i] * 2),
     "mvs_deconv_split_pack_weights_f32": (_c_i, [_c_f] + [_c_i] * 2 + [_c_f, _c_f]),
+    "mvs_deconv_split_f16_packed_bytes": (ctypes.c_size_t, [_c_i] * 2),
+    "mvs_deconv_split_pack_weights_f16_f32": (_c_i, [_c_f] + [_c_i] * 2 + [_c_f, _c_f]),
+    "mvs_deconv_split_f16_f32": (_c_i, [_c_f] * 6 + [_c_i] * 7 + [_c_f, _c_f, _c_f]),
     "mvs_deconv_split_f32": (_c_i, [_c_f] * 5 + [_c_i] * 7 + [_c_f, _c_f]),
     "mvs_conv3d_wgrad_f32": (_c_i, [_c_f, _c_f] + [_c_i] * 7 + [_c_f, _c_f, ctypes.c_size_t, _c_f]),
     "mvs_conv3d_wgrad_workspace_bytes": (ctypes.c_size_t, [_c_i] * 7),
@@ -91,6 +98,7 @@ _SIGS = {
     "mvs_feature_head_packed_bytes": (ctypes.c_size_t, []),
     "mvs_feature_head_pack_weights_f32": (_c_i, [_c_f, _c_f, _c_f]),
     "mvs_feature_head_f32": (_c_i, [_c_f] * 7 + [_c_i] * 3 + [_c_f, _c_f]),
+    "mvs_feature_head_absmax_f32": (_c_i, [_c_f] * 7 + [_c_i] * 3 + [_c_f, _c_f, _c_f]),
     "mvs_conv2d_packed_weight_floats": (_c_l, [_c_i] * 4),
     "mvs_conv2d_pack_weights_f32": (_c_i, [_c_f] + [_c_i] * 4 + [_c_f, _c_f]),
     "mvs_conv2d_supported": (_c_i, [_c_i] * 4),

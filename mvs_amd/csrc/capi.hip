@@ -18,7 +18,7 @@ void set_error(const char *fmt, ...) {
 int conv3d_direct_launch(const float *, const float *, const float *, const float *, const float *,
                          int, int, int, int, int, int, int, int, int, int, float *, hipStream_t);
 int conv3d_mfma_launch(const float *, const float *, const float *, const float *, const float *,
-                       int, int, int, int, int, int, int, int, int, int, float *, hipStream_t);
+                       int, int, int, int, int, int, int, int, int, int, float *, hipStream_t, unsigned *, bool *);
 int conv3d_pack_launch(const float *, int, int, int, int, float *, hipStream_t);
 int64_t conv3d_packed_floats(int, int, int, int);
 int conv3d_mfma_supported(int, int, int, int);
@@ -137,10 +137,20 @@ extern "C" int mvs_conv3d_pack_weights_f32(const float *weight, int transposed, 
     return conv3d_pack_launch(weight, transposed, Cin, Cout, stride, packed, as_stream(stream));
 }
 
+extern "C" int mvs_absmax_f32(const float *x, int64_t n, void *absmax, void *stream);   // conv_f16x3.hip
+
 extern "C" int mvs_conv3d_f32(const float *in, const float *weight, const float *packed_weight,
                               const float *scale, const float *shift, const float *residual,
                               int relu, int transposed, int B, int Cin, int Cout, int D, int H,
                               int W, int stride, int layout, int impl, float *out, void *stream) {
+    return mvs_conv3d_absmax_f32(in, weight, packed_weight, scale, shift, residual, relu, transposed, B, Cin, Cout, D, H, W,
+                                 stride, layout, impl, out, nullptr, stream);
+}
+
+extern "C" int mvs_conv3d_absmax_f32(const float *in, const float *weight, const float *packed_weight,
+                                     const float *scale, const float *shift, const float *residual,
+                                     int relu, int transposed, int B, int Cin, int Cout, int D, int H,
+                                     int W, int stride, int layout, int impl, float *out, void *out_absmax, void *stream) {
     if (!in || !out || B <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0 ||
         (stride != 1 && stride != 2) ||
         (layout != MVS_LAYOUT_NCHW && layout != MVS_LAYOUT_NHWC && layout != MVS_LAYOUT_C8) ||
@@ -160,9 +170,17 @@ extern "C" int mvs_conv3d_f32(const float *in, const float *weight, const float 
                   transposed ? "deconv" : "conv", Cin, Cout, stride);
         return MVS_EUNSUPPORTED;
     }
-    if (impl == 2 || (impl == 0 && mfma_ok))
-        return conv3d_mfma_launch(in, packed_weight, scale, shift, residual, relu, transposed, B,
-                                  Cin, Cout, D, H, W, stride, layout == MVS_LAYOUT_C8, out, st);
+    // out_absmax: the MFMA convolutions collect it in their epilogue; behind every other kernel, one more pass over `out`
+    const int64_t nout = transposed ? (int64_t)B * Cout * (2 * D) * (2 * H) * (2 * W)
+                                    : (int64_t)B * Cout * ((D - 1) / stride + 1) * ((H - 1) / stride + 1) * ((W - 1) / stride + 1);
+    if (impl == 2 || (impl == 0 && mfma_ok)) {
+        bool collected = false;
+        const int rc = conv3d_mfma_launch(in, packed_weight, scale, shift, residual, relu, transposed, B,
+                                          Cin, Cout, D, H, W, stride, layout == MVS_LAYOUT_C8, out, st,
+                                          static_cast<unsigned *>(out_absmax), &collected);
+        if (rc != MVS_OK || !out_absmax || collected) return rc;
+        return mvs_absmax_f32(out, nout, out_absmax, stream);
+    }
     if (layout == MVS_LAYOUT_C8) {
         set_error("mvs_conv3d_f32: the 8-channel-blocked layout is input-only for the MFMA path");
         return MVS_EUNSUPPORTED;
@@ -171,6 +189,8 @@ extern "C" int mvs_conv3d_f32(const float *in, const float *weight, const float 
         set_error("mvs_conv3d_f32: direct path needs the PyTorch-layout weight");
         return MVS_EINVAL;
     }
-    return conv3d_direct_launch(in, weight, scale, shift, residual, relu, transposed, B, Cin, Cout,
-                                D, H, W, stride, layout, out, st);
+    const int rc = conv3d_direct_launch(in, weight, scale, shift, residual, relu, transposed, B, Cin, Cout,
+                                        D, H, W, stride, layout, out, st);
+    if (rc != MVS_OK || !out_absmax) return rc;
+    return mvs_absmax_f32(out, nout, out_absmax, stream);
 }

@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
         }
     }
     // ---- epilogue: BN affine, ReLU, skip add, one 16-byte store per lane
+    float vmax = 0.0f;      // largest magnitude this lane stores (-> a.out_absmax)
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const int row = wv * RPW + r;
@@ -267,8 +268,10 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
                 v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
             }
             *reinterpret_cast<float4 *>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         }
     }
+    publish_absmax(a.out_absmax, vmax);
 }
 
 // ---------------------------------------------------------------------
@@ -983,11 +986,16 @@ int conv3d_pack_launch(const float *weight, int transposed, int Cin, int Cout, i
     return check_launch("mvs_conv3d_pack_weights_f32");
 }
 
+// out_absmax: NULL, or the absmax block the output's largest magnitude is max-ed into by the kernels that collect it in their
+// epilogue (the convolutions with Cout > 1); *collected tells the caller whether the launched kernel was one of them
 int conv3d_mfma_launch(const float *in, const float *packed, const float *scale,
                        const float *shift, const float *residual, int relu, int transposed, int B,
                        int Cin, int Cout, int D, int H, int W, int stride, int in_c8, float *out,
-                       hipStream_t st) {
+                       hipStream_t st, unsigned *out_absmax, bool *collected) {
     ConvArgs a;
+    const bool collects = !transposed && !is_cout1(transposed, Cin, Cout, stride);
+    a.out_absmax = collects ? out_absmax : nullptr;
+    if (collected) *collected = collects && out_absmax;
     a.in = in; a.wpk = packed; a.scale = scale; a.shift = shift; a.residual = residual;
     a.out = out;
     a.B = B; a.D = D; a.H = H; a.W = W;

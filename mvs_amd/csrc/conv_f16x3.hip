@@ -27,50 +27,14 @@
 
 namespace mvs {
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
 constexpr int kF16ChunkBytes = 9 * 2 * 1024;   // A fragments of one 8-channel chunk: (kz,ky) x (hi,lo) x 1 KiB
 constexpr int kFRowVox = 17, kFOddBase = 624, kFHaloPlane = 1280;
 constexpr int kFGroup = 4, kFCopyWaves = 4, kFThreads = 512 + 64 * kFCopyWaves;
 
-// scale = 2^(14 - e), e = exponent of the largest magnitude (clamped: an all-zero or non-finite input keeps the
-// arithmetic defined)
-__device__ __host__ __forceinline__ int absmax_exponent(unsigned bits) {
-    int e = (int)((bits >> 23) & 255u) - 127;
-    return e < -100 ? -100 : (e > 100 ? 100 : e);
-}
-__device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float, (unsigned)(e + 127) << 23); }
-
-// 8 fp32 values -> hi, lo (fp16 pairs) of x * s
-__device__ __forceinline__ void split2_block(f32x4 &a, f32x4 &b, float s, u32x4 &h, u32x4 &l) {
-    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-    float x0 = a[0], x1 = a[1], x2 = a[2], x3 = a[3], x4 = b[0], x5 = b[1], x6 = b[2], x7 = b[3];
-    asm volatile(
-        "v_fma_mixlo_f16 %8, %0, %16, 0\n\tv_fma_mixlo_f16 %9, %2, %16, 0\n\t"
-        "v_fma_mixlo_f16 %10, %4, %16, 0\n\tv_fma_mixlo_f16 %11, %6, %16, 0\n\t"
-        "v_fma_mixhi_f16 %8, %1, %16, 0\n\tv_fma_mixhi_f16 %9, %3, %16, 0\n\t"
-        "v_fma_mixhi_f16 %10, %5, %16, 0\n\tv_fma_mixhi_f16 %11, %7, %16, 0\n\t"
-        "v_fma_mix_f32 %0, %0, %16, -%8 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mix_f32 %1, %1, %16, -%8 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mix_f32 %2, %2, %16, -%9 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mix_f32 %3, %3, %16, -%9 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mix_f32 %4, %4, %16, -%10 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mix_f32 %5, %5, %16, -%10 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mix_f32 %6, %6, %16, -%11 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mix_f32 %7, %7, %16, -%11 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "v_cvt_pk_f16_f32 %12, %0, %1\n\tv_cvt_pk_f16_f32 %13, %2, %3\n\t"
-        "v_cvt_pk_f16_f32 %14, %4, %5\n\tv_cvt_pk_f16_f32 %15, %6, %7"
-        : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7),
-          "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3), "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
-        : "s"(s));
-    h = (u32x4){h0, h1, h2, h3};
-    l = (u32x4){l0, l1, l2, l3};
-}
-
 template <int CIN, int ABL = 0>
 __global__ __launch_bounds__(kFThreads) void conv3d_c8_f16x3_zs_kernel(ConvArgs a, int ngroups,
-                                                                       const unsigned *__restrict__ in_absmax) {
+                                                                       const unsigned *__restrict__ in_absmax,
+                                                                       unsigned *__restrict__ out_absmax) {
     constexpr int NCHUNK = CIN / 8, YT = 6, PLANE = kFHaloPlane, T = kFGroup;
     constexpr int NC = kFCopyWaves, NT = kFThreads;
     constexpr int ROWP = 68;                                        // 16-byte pieces per (z, y) row: 34 voxels x 2 halves
@@ -91,7 +55,7 @@ __global__ __launch_bounds__(kFThreads) void conv3d_c8_f16x3_zs_kernel(ConvArgs 
     const int cw = wv - 8;       // copy wave index
 
     // operand scale of the input and what undoes it and the weights' scale (the trailer of the packed weights)
-    const int xe = absmax_exponent(__builtin_amdgcn_readfirstlane((int)*in_absmax));
+    const int xe = absmax_exponent(load_absmax(in_absmax));
     const float sx = pow2f(14 - xe), isx = pow2f(xe - 14);
     const float isw = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(
         __builtin_bit_cast(int, a.wpk[(size_t)NCHUNK * (WBYTES / 4)])));
@@ -144,6 +108,7 @@ __global__ __launch_bounds__(kFThreads) void conv3d_c8_f16x3_zs_kernel(ConvArgs 
             if (ps * NT + wbase < NP) x[ps] = lds_read_b128<ps * NT * 16>(fp);
         });
         lds_wait_n<0>();
+        if constexpr (ABL & 1) { lds_wait_n<0>(); return; }          // tuning: barriers and copies only
         static_for<0, (NPSJ + 1) / 2>([&](auto pc) {
             constexpr int p0 = 2 * decltype(pc)::value, p1 = (p0 + 1 < NPSJ) ? p0 + 1 : p0;
             if (p0 * NT + wbase >= NP) return;                        // the whole wave has nothing here
@@ -297,6 +262,7 @@ __global__ __launch_bounds__(kFThreads) void conv3d_c8_f16x3_zs_kernel(ConvArgs 
     for (int j = 0; j < T; ++j) acc[j][0] = acc[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     int wsel = 0, par = 0;
+    float vmax = 0.0f;       // largest magnitude this lane has stored (-> out_absmax, the next layer's operand scale)
     long long tsum[7] = {0, 0, 0, 0, 0, 0, 0};
     long long tprev = 0;
     if constexpr (ABL & 128) tprev = clock64();
@@ -344,6 +310,7 @@ __global__ __launch_bounds__(kFThreads) void conv3d_c8_f16x3_zs_kernel(ConvArgs 
                         bsr[g & 3][sp] = __builtin_bit_cast(f16x8, lds_read_b128<iy * kFRowVox * 16 + sp * SPART>(aBz[kz]));
                     }
                 };
+                if constexpr (!(ABL & 2)) {
                 static_for<0, 6>([&](auto ic) { rd(ic, std::integral_constant<int, 0>{}); });
                 __builtin_amdgcn_sched_barrier(0);
                 static_for<0, 9>([&](auto cc) {
@@ -369,6 +336,7 @@ __global__ __launch_bounds__(kFThreads) void conv3d_c8_f16x3_zs_kernel(ConvArgs 
                         }
                     });
                 });
+                }
                 if constexpr (ABL & 128) {
                     f32x4 &c0 = acc[j][0], &c1 = acc[j][1];
                     asm volatile("" : "+v"(c0), "+v"(c1));
@@ -408,9 +376,11 @@ __global__ __launch_bounds__(kFThreads) void conv3d_c8_f16x3_zs_kernel(ConvArgs 
                     v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
                 }
                 *reinterpret_cast<float4 *>(ob + o) = make_float4(v[0], v[1], v[2], v[3]);
+                vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
             }
         });
     }
+    publish_absmax(out_absmax, vmax);
     if constexpr (ABL & 128) {
         MVS_LAP(6);
         if (lane == 0) {
@@ -421,7 +391,7 @@ __global__ __launch_bounds__(kFThreads) void conv3d_c8_f16x3_zs_kernel(ConvArgs 
 #undef MVS_LAP
 }
 
-// largest magnitude of n floats as the bit pattern of |x| (non-negative floats order like their bits; a NaN wins)
+// largest magnitude of n floats into an absmax block (a NaN wins: its bit pattern is above every number's)
 __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, int64_t n, unsigned *__restrict__ out) {
     unsigned m = 0;
     const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * 256;
@@ -433,7 +403,22 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = max(m, __float_as_uint(x[n4 * 4 + threadIdx.x]) & 0x7fffffffu);
 #pragma unroll
     for (int o = 32; o; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out + (blockIdx.x & (kAbsmaxWords - 1)), m);
+}
+
+// ... of a small array (a layer's weights) into ONE word, by one workgroup
+__global__ __launch_bounds__(1024) void absmax_word_kernel(const float *__restrict__ x, int n, unsigned *__restrict__ out) {
+    __shared__ unsigned s_m[16];
+    unsigned m = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) m = max(m, s_m[i]);
+        *out = m;
+    }
 }
 
 // PyTorch-layout weight (8, Cin, 3, 3, 3) -> [chunk][kz*3+ky][hi,lo][lane][8 fp16] of w * 2^(14 - exponent(max |w|)),
@@ -467,13 +452,22 @@ extern "C" size_t mvs_conv3d_f16x3_packed_bytes(int Cin) {
     return f16x3_shape_ok(Cin) ? (size_t)(Cin / 8) * kF16ChunkBytes + 16 : 0;
 }
 
-extern "C" int mvs_absmax_f32(const float *x, int64_t n, void *absmax_bits, void *stream) {
-    if (!x || !absmax_bits || n <= 0 || (reinterpret_cast<uintptr_t>(x) & 15)) {
-        set_error("mvs_absmax_f32: needs a 16-byte aligned device array and a device word for the result");
+namespace mvs {
+// (weights) one word; n below 2^31
+int launch_absmax_word(const float *x, int64_t n, unsigned *word, hipStream_t st) {
+    hipLaunchKernelGGL(absmax_word_kernel, dim3(1), dim3(1024), 0, st, x, (int)n, word);
+    return check_launch("absmax_word_kernel");
+}
+}  // namespace mvs
+
+extern "C" int mvs_absmax_f32(const float *x, int64_t n, void *absmax, void *stream) {
+    void *const absmax_bits = absmax;
+    if (!x || !absmax_bits || n <= 0 || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(absmax) & 15)) {
+        set_error("mvs_absmax_f32: needs 16-byte aligned device arrays: the data and the MVS_ABSMAX_WORDS-word block of the result");
         return MVS_EINVAL;
     }
     hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(absmax_bits, 0, 4, st) != hipSuccess) return bare_error(MVS_ELAUNCH, __func__, __LINE__);
+    if (hipMemsetAsync(absmax_bits, 0, 4 * kAbsmaxWords, st) != hipSuccess) return bare_error(MVS_ELAUNCH, __func__, __LINE__);
     const int64_t blocks = (n / 4 + 255) / 256;
     const int nb = (int)(blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks));
     hipLaunchKernelGGL(absmax_kernel, dim3(nb), dim3(256), 0, st, x, n, static_cast<unsigned *>(absmax_bits));
@@ -487,7 +481,7 @@ extern "C" int mvs_conv3d_pack_weights_f16x3_f32(const float *weight, int Cin, v
     }
     // the weights' largest magnitude goes through the last word of the trailer, which the pack kernel does not write
     unsigned *wmax = reinterpret_cast<unsigned *>(static_cast<unsigned char *>(packed) + (size_t)(Cin / 8) * kF16ChunkBytes + 12);
-    const int rc = mvs_absmax_f32(weight, (int64_t)8 * Cin * 27, wmax, stream);
+    const int rc = launch_absmax_word(weight, (int64_t)8 * Cin * 27, wmax, as_stream(stream));
     if (rc != MVS_OK) return rc;
     const int total = (Cin / 8) * 9 * 512;
     hipLaunchKernelGGL(pack_f16x3_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), weight, Cin,
@@ -497,10 +491,10 @@ extern "C" int mvs_conv3d_pack_weights_f16x3_f32(const float *weight, int Cin, v
 
 extern "C" int mvs_conv3d_c8_f16x3_f32(const float *in, const void *in_absmax, const void *packed, const float *scale,
                                        const float *shift, const float *residual, int relu, int B, int Cin,
-                                       int D, int H, int W, float *out, void *stream) {
+                                       int D, int H, int W, float *out, void *out_absmax, void *stream) {
     if (!in || !in_absmax || !packed || !out || B <= 0 || D <= 0 || H <= 0 || W <= 0 || !f16x3_shape_ok(Cin)) {
         set_error("mvs_conv3d_c8_f16x3_f32: invalid argument (Cin in {8, 16, 32}, Cout = 8, stride 1, 8-channel-blocked input, "
-                  "in_absmax = device word holding the input's largest magnitude)");
+                  "in_absmax = the absmax block of the input)");
         return MVS_EINVAL;
     }
     if ((int64_t)9 * H * W * Cin * 4 >= 0xffffff00LL) return bare_error(MVS_EINVAL, __func__, __LINE__);
@@ -517,16 +511,23 @@ extern "C" int mvs_conv3d_c8_f16x3_f32(const float *in, const void *in_absmax, c
     hipStream_t st = as_stream(stream);
     const dim3 grid((unsigned)(ng < n_cu ? ng : n_cu)), blk(kFThreads);
     const unsigned *mx = static_cast<const unsigned *>(in_absmax);
+    unsigned *omx = static_cast<unsigned *>(out_absmax);
 #ifdef MVS_TUNING   // phase-stamp build: cycle counters written through `residual` (scripts/exp_conv0_f16.py)
     static const int abl = [] { const char *e = getenv("MVS_CONV_SPLIT_ABL"); return e ? atoi(e) : 0; }();
     if ((abl & 128) && Cin == 32) {
         if (!residual) return bare_error(MVS_EINVAL, __func__, __LINE__);
-        hipLaunchKernelGGL((conv3d_c8_f16x3_zs_kernel<32, 128>), grid, blk, 0, st, a, (int)ng, mx);
+        hipLaunchKernelGGL((conv3d_c8_f16x3_zs_kernel<32, 128>), grid, blk, 0, st, a, (int)ng, mx, omx);
+        return check_launch("mvs_conv3d_c8_f16x3_f32");
+    }
+    if ((abl & 3) && Cin == 32) {   // wrong results by design: 1 = no split work, 2 = no MFMA phase, 3 = copies and barriers only
+        if ((abl & 3) == 1) hipLaunchKernelGGL((conv3d_c8_f16x3_zs_kernel<32, 1>), grid, blk, 0, st, a, (int)ng, mx, omx);
+        else if ((abl & 3) == 2) hipLaunchKernelGGL((conv3d_c8_f16x3_zs_kernel<32, 2>), grid, blk, 0, st, a, (int)ng, mx, omx);
+        else hipLaunchKernelGGL((conv3d_c8_f16x3_zs_kernel<32, 3>), grid, blk, 0, st, a, (int)ng, mx, omx);
         return check_launch("mvs_conv3d_c8_f16x3_f32");
     }
 #endif
-    if (Cin == 32) hipLaunchKernelGGL((conv3d_c8_f16x3_zs_kernel<32>), grid, blk, 0, st, a, (int)ng, mx);
-    else if (Cin == 16) hipLaunchKernelGGL((conv3d_c8_f16x3_zs_kernel<16>), grid, blk, 0, st, a, (int)ng, mx);
-    else hipLaunchKernelGGL((conv3d_c8_f16x3_zs_kernel<8>), grid, blk, 0, st, a, (int)ng, mx);
+    if (Cin == 32) hipLaunchKernelGGL((conv3d_c8_f16x3_zs_kernel<32>), grid, blk, 0, st, a, (int)ng, mx, omx);
+    else if (Cin == 16) hipLaunchKernelGGL((conv3d_c8_f16x3_zs_kernel<16>), grid, blk, 0, st, a, (int)ng, mx, omx);
+    else hipLaunchKernelGGL((conv3d_c8_f16x3_zs_kernel<8>), grid, blk, 0, st, a, (int)ng, mx, omx);
     return check_launch("mvs_conv3d_c8_f16x3_f32");
 }

@@ -26,6 +26,7 @@ struct ConvArgs {
     int ystrip;  // tile order: 0 = x, y, z; n > 0 = y within strips of n tile rows, then z, then x
     int res_up2; // residual is [B,Do,Ho/2,Wo/2,C]: added through a nearest x2 upsample in y and x (FPN top-down path)
     int out_c4 = 0;   // 2D layers: write [image,C/4,Ho,Wo,4] (4-channel blocked, the sweep kernel's fastest input) instead of [image,Ho,Wo,C]
+    unsigned *out_absmax = nullptr;   // the absmax block (mvs_common.h) the largest magnitude stored is max-ed into, or NULL
 };
 
 // XCD-aware bijective remap: consecutive tiles land on the same XCD (same L2)
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(512) void conv3d_c8_persistent_kernel(ConvArgs a, i
     // ordered tile list, its workgroups take that range round-robin, so the tiles in
     // flight on one XCD are neighbours and share halo lines in that XCD's L2
     int t_cur, t_end, t_step;
+    float vmax = 0.0f;      // largest magnitude this lane has stored (-> a.out_absmax)
     {
         const int nb = gridDim.x;
         if ((nb & 7) == 0) {
@@ -388,11 +390,13 @@ __global__ __launch_bounds__(512) void conv3d_c8_persistent_kernel(ConvArgs a, i
                         v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
                     }
                     *reinterpret_cast<float4 *>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+                    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
                 }
             }
         }
         t_cur = t_next;
     }
+    publish_absmax(a.out_absmax, vmax);
     if constexpr (ABL & 16) {
         MVS_LAP(4);
         if (tid == 0) {

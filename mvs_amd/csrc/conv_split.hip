@@ -32,10 +32,18 @@ struct SplitArgs {
     int relu;                 // 0 none, 1 ReLU, 2 LeakyReLU(0.1)
     int nco;                  // output channels of this launch that exist (8 for an 8-channel layer on the 16-row tile)
     int co0, out_c4;          // out_c4: the WHOLE output tensor is [B*D, ldc/4, H, W, 4] (4-channel blocks), co0 = first channel of the launch
+    // two-piece fp16 form (NP = 2): the input's absmax block (mvs_common.h), what undoes the weights' scale
+    // (device float, the trailer of the packed weights)
+    const unsigned *in_absmax;
+    const float *w_iscale;
+    unsigned *out_absmax;     // NULL, or the absmax block that collects the largest magnitude this launch stores (any form)
 };
 
-template <int CIN_, int COUT_, int KD_, int S_ = 1, int KH_ = 3>
+// NP: operand pieces -- 3 = bf16 hi/mid/lo, six products (exact split); 2 = scaled fp16 hi/lo, three products (conv_f16x3.hip
+// has the arithmetic and its error bound)
+template <int CIN_, int COUT_, int KD_, int S_ = 1, int KH_ = 3, int NP_ = 3>
 struct SplitCfg {
+    static constexpr int NP = NP_;
     // S: stride (2: the 3D down-sampling layers, and FeatureNet's 5x5 layers = KD 1, KH 5)
     static constexpr int CIN = CIN_, COUT = COUT_, KD = KD_, S = S_, KH = KH_;
     // 8-channel chunks per step: two for the 2D layers (a K = 32 step is then 2 taps x 16 channels: 9 taps fill 18 of
@@ -56,8 +64,8 @@ struct SplitCfg {
     // service group (same tap, chunk 0 / chunk 1) then read voxels n .. and 16 k + n ..: complementary 16-byte slots
     static constexpr int NVP = CPS == 1 ? NVOX : (NVOX + 15) / 16 * 16;
     static constexpr int NPIECE = 2 * NVP * CPS, NCOPY = (NPIECE + 63) / 64;   // 16-byte pieces (chunk, voxel, channel half)
-    static constexpr int FBYTES = NCOPY * 1024, SPART = NVP * 16 * CPS, SBYTES = 3 * SPART;
-    static constexpr int WBYTES = G * MT * 3 * 1024;                      // A fragments of one chunk
+    static constexpr int FBYTES = NCOPY * 1024, SPART = NVP * 16 * CPS, SBYTES = NP * SPART;
+    static constexpr int WBYTES = G * MT * NP * 1024;                     // A fragments of one chunk
     // tiles per group (they share a chunk's weights and hold their accumulators, RPW x MT x 4 registers each, over the
     // chunk loop): bounded by the 168 registers of a 12-wave workgroup
     static constexpr int T = 48 / (RPW * MT * 4) >= 2 ? 2 : 1;
@@ -101,10 +109,18 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_split_kernel(SplitArgs a, in
     const unsigned lds_base = (unsigned)(uintptr_t)lds;
     const bool copier = wv >= 8;
     const int cw = wv - 8;
+    constexpr int NP = C::NP;
+    // NP = 2: operand scale of the input; what undoes it and the weights' scale goes into the epilogue's per-channel scale
+    float sx = 1.0f, unscale = 1.0f;
+    if constexpr (NP == 2) {
+        const int xe = absmax_exponent(load_absmax(a.in_absmax));
+        sx = pow2f(14 - xe);
+        unscale = pow2f(xe - 14) * __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *a.w_iscale)));
+    }
     // the per-channel affine of the epilogue waits in LDS (a global load there would put its latency into every tile)
     if (tid < 2 * C::COUT) {
         const int c = tid % C::COUT;
-        const float v = c >= a.nco ? 0.0f : tid < C::COUT ? (a.scale ? a.scale[c] : 1.0f) : (a.shift ? a.shift[c] : 0.0f);
+        const float v = c >= a.nco ? 0.0f : tid < C::COUT ? (a.scale ? a.scale[c] : 1.0f) * unscale : (a.shift ? a.shift[c] : 0.0f);
         *reinterpret_cast<float *>(lds + C::AFF_OFF + tid * 4) = v;
     }
 
@@ -138,19 +154,24 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_split_kernel(SplitArgs a, in
             constexpr int p0 = 2 * decltype(pc)::value, p1 = (p0 + 1 < NPS) ? p0 + 1 : p0;
             f32x4 &x0 = x[p0], &x1 = x[p1];
             asm volatile("" : "+v"(x0), "+v"(x1));
-            bf16x8 h, m, l;
-            split3_block(x0, x1, h, m, l);
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 hu = __builtin_bit_cast(u32x4, h), mu = __builtin_bit_cast(u32x4, m), lu = __builtin_bit_cast(u32x4, l);
+            u32x4 hu, mu, lu;
+            if constexpr (NP == 2) {
+                split2_block(x0, x1, sx, hu, mu);
+            } else {
+                bf16x8 h, m, l;
+                split3_block(x0, x1, h, m, l);
+                hu = __builtin_bit_cast(u32x4, h); mu = __builtin_bit_cast(u32x4, m); lu = __builtin_bit_cast(u32x4, l);
+            }
             if (p0 * NT + tid < NPIECE) {
                 lds_write_b64<p0 * NT * 8>(sp, hu[0], hu[1]);
                 lds_write_b64<p0 * NT * 8>(sp1, mu[0], mu[1]);
-                lds_write_b64<p0 * NT * 8>(sp2, lu[0], lu[1]);
+                if constexpr (NP == 3) lds_write_b64<p0 * NT * 8>(sp2, lu[0], lu[1]);
             }
             if (p1 != p0 && p1 * NT + tid < NPIECE) {
                 lds_write_b64<p1 * NT * 8>(sp, hu[2], hu[3]);
                 lds_write_b64<p1 * NT * 8>(sp1, mu[2], mu[3]);
-                lds_write_b64<p1 * NT * 8>(sp2, lu[2], lu[3]);
+                if constexpr (NP == 3) lds_write_b64<p1 * NT * 8>(sp2, lu[2], lu[3]);
             }
         });
         lds_wait_n<0>();
@@ -306,6 +327,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_split_kernel(SplitArgs a, in
         loff[r] = a.out_c4 ? (int)(zr * (a.ldc >> 2) * hw4 + (yr * a.Wo + xr) * 4 + kq * hw4)
                            : ((zr * a.Ho + yr) * a.Wo + xr) * a.ldc + kq * 4;
     }
+    float vmax = 0.0f;          // largest magnitude this lane has stored (-> a.out_absmax)
     long long tsum[5] = {0, 0, 0, 0, 0};
     long long tprev = 0;
     if constexpr (LAPS) tprev = clock64();
@@ -329,18 +351,18 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_split_kernel(SplitArgs a, in
                 // MFMAs of the current one
                 const unsigned aA = lds_base + (unsigned)(wsel * WBYTES + lane * 16);
                 const unsigned aS = lds_base + (unsigned)S_OFF;
-                bf16x8 A[2][MT][3], Bf[2][3];
+                bf16x8 A[2][MT][NP], Bf[2][NP];     // (NP = 2: the same registers hold fp16 pairs)
                 auto read_a = [&](auto gc) {
                     constexpr int g = decltype(gc)::value;
-                    static_for<0, MT * 3>([&](auto ic) {
+                    static_for<0, MT * NP>([&](auto ic) {
                         constexpr int i = decltype(ic)::value;
-                        A[g & 1][i / 3][i % 3] = __builtin_bit_cast(bf16x8, lds_read_b128<(g * MT * 3 + i) * 1024>(aA));
+                        A[g & 1][i / NP][i % NP] = __builtin_bit_cast(bf16x8, lds_read_b128<(g * MT * NP + i) * 1024>(aA));
                     });
                 };
                 auto read_b = [&](auto ic) {
                     constexpr int it = decltype(ic)::value, g = it / RPW, r = it % RPW;
                     const unsigned ad = aS + rbo[r] + tapo[g];
-                    static_for<0, 3>([&](auto pc) {
+                    static_for<0, NP>([&](auto pc) {
                         constexpr int sp = decltype(pc)::value;
                         Bf[it & 1][sp] = __builtin_bit_cast(bf16x8, lds_read_b128<sp * SPART>(ad));
                     });
@@ -350,13 +372,13 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_split_kernel(SplitArgs a, in
                 static_for<0, G * RPW>([&](auto ic) {
                     constexpr int it = decltype(ic)::value, g = it / RPW, r = it % RPW;
                     lds_wait_n<0>();
-                    {
-                        bf16x8 &b0 = Bf[it & 1][0], &b1 = Bf[it & 1][1], &b2 = Bf[it & 1][2];
-                        asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2));
-                    }
+                    static_for<0, NP>([&](auto pc) {
+                        bf16x8 &b0 = Bf[it & 1][decltype(pc)::value];
+                        asm volatile("" : "+v"(b0));
+                    });
                     if constexpr (r == 0) {
-                        static_for<0, MT * 3>([&](auto qc) {
-                            bf16x8 &aa = A[g & 1][decltype(qc)::value / 3][decltype(qc)::value % 3];
+                        static_for<0, MT * NP>([&](auto qc) {
+                            bf16x8 &aa = A[g & 1][decltype(qc)::value / NP][decltype(qc)::value % NP];
                             asm volatile("" : "+v"(aa));
                         });
                     }
@@ -365,7 +387,20 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_split_kernel(SplitArgs a, in
                         read_b(std::integral_constant<int, it + 1>{});
                     }
                     __builtin_amdgcn_sched_barrier(0);   // the reads go out BEFORE this item's MFMAs
-                    const bf16x8 bh = Bf[it & 1][0], bm = Bf[it & 1][1], bl = Bf[it & 1][2];
+                    if constexpr (NP == 2) {
+                        // three partial products per 16 output channels, small terms first: al bh, ah bl, ah bh
+                        static_for<0, 3>([&](auto tc) {
+                            constexpr int t = decltype(tc)::value;
+                            static_for<0, MT>([&](auto mc) {
+                                constexpr int m = decltype(mc)::value;
+                                const f16x8 bb = __builtin_bit_cast(f16x8, Bf[it & 1][t == 1 ? 1 : 0]);
+                                const f16x8 aa = __builtin_bit_cast(f16x8, A[g & 1][m][t == 0 ? 1 : 0]);
+                                f32x4 &cc = acc[j][r][m];
+                                cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(aa, bb, cc, 0, 0, 0);
+                            });
+                        });
+                    } else {
+                    const bf16x8 bh = Bf[it & 1][0], bm = Bf[it & 1][1], bl = Bf[it & 1][NP - 1];
                     // six partial products per 16 output channels, small terms first; M tiles interleaved
                     static_for<0, 6>([&](auto tc) {
                         constexpr int t = decltype(tc)::value;
@@ -373,11 +408,12 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_split_kernel(SplitArgs a, in
                         static_for<0, MT>([&](auto mc) {
                             constexpr int m = decltype(mc)::value;
                             const bf16x8 &bb = (t == 0 || t == 4) ? bm : (t == 2 ? bl : bh);   // bm bh bl bh bm bh
-                            const bf16x8 &aa = A[g & 1][m][as];
+                            const bf16x8 &aa = A[g & 1][m][as < NP ? as : 0];
                             f32x4 &cc = acc[j][r][m];
                             cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aa, bb, cc, 0, 0, 0);
                         });
                     });
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 });
                 if constexpr (LAPS) {
@@ -434,10 +470,12 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_split_kernel(SplitArgs a, in
                         v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
                     }
                     *reinterpret_cast<float4 *>(ob + o) = make_float4(v[0], v[1], v[2], v[3]);
+                    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
                 }
             }
         });
     }
+    publish_absmax(a.out_absmax, vmax);
     if constexpr (LAPS) {
         MVS_LAP(4);
         if (lane == 0) {
@@ -473,6 +511,30 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const float *__restrict
     o[1024] = __builtin_bit_cast(unsigned short, l);
 }
 
+// the two-piece fp16 form of the same fragments: [step][group][m-tile][hi,lo][lane][8 fp16] of w * 2^(14 - exponent(max |w|))
+// (the layer's largest weight, *wmax); block 0 also writes what undoes the scale into *iscale
+__global__ __launch_bounds__(256) void pack_split_f16_kernel(const float *__restrict__ w, int Cin, int Cout, int ntap, int cps, int G, int MT,
+                                                             int co0, unsigned short *__restrict__ out, int total,
+                                                             const unsigned *__restrict__ wmax, float *__restrict__ iscale) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int e = absmax_exponent(*wmax);
+    if (i == 0) *iscale = pow2f(e - 14);
+    if (i >= total) return;
+    const int j = i & 7, lane = (i >> 3) & 63;
+    int rest = i >> 9;
+    const int m = rest % MT; rest /= MT;
+    const int g = rest % G, ch = rest / G;
+    const int mrow = lane & 15, kq = lane >> 4, sl = 4 * g + kq, t = sl / cps, c = sl % cps;   // ch = step of the tile
+    float x = 0.0f;
+    if (t < ntap && co0 + m * 16 + mrow < Cout)
+        x = w[((int64_t)(co0 + m * 16 + mrow) * Cin + (ch * cps + c) * 8 + j) * ntap + t] * pow2f(14 - e);
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)(x - (float)h);
+    unsigned short *o = out + ((size_t)((ch * G + g) * MT + m) * 2) * 512 + lane * 8 + j;
+    o[0] = __builtin_bit_cast(unsigned short, h);
+    o[512] = __builtin_bit_cast(unsigned short, l);
+}
+
 template <class C>
 static int launch_split(const SplitArgs &a0, hipStream_t st) {
     SplitArgs a = a0;
@@ -487,7 +549,7 @@ static int launch_split(const SplitArgs &a0, hipStream_t st) {
 #else
     constexpr bool laps = false;
 #endif
-    if (laps && a.residual && (C::CIN == 64 || C::CIN == 16) && C::COUT == 16 * (C::CIN == 64 ? 2 : 1))   // tuning builds: 64 -> 32 and 16 -> 16
+    if (laps && C::NP == 3 && a.residual && (C::CIN == 64 || C::CIN == 16) && C::COUT == 16 * (C::CIN == 64 ? 2 : 1))   // tuning builds: 64 -> 32 and 16 -> 16
         hipLaunchKernelGGL((conv_split_kernel<C, true>), dim3((unsigned)(nt < n_cu ? nt : n_cu)), dim3(C::NTHREADS), 0, st, a, (int)nt);
     else
         hipLaunchKernelGGL((conv_split_kernel<C>), dim3((unsigned)(nt < n_cu ? nt : n_cu)), dim3(C::NTHREADS), 0, st, a, (int)nt);
@@ -512,10 +574,44 @@ extern "C" int mvs_conv_split_supported(int kd, int Cin, int Cout, int stride) {
     return stride == 1 && (kd == 1 || kd == 3) && (Cin == 16 || Cin == 32 || Cin == 64) && cout_ok;
 }
 
-extern "C" size_t mvs_conv_split_packed_bytes(int kd, int Cin, int Cout, int stride) {
+static size_t split_packed_bytes(int kd, int Cin, int Cout, int stride, int np) {
     if (!mvs_conv_split_supported(kd, Cin, Cout, stride)) return 0;
     const int cps = split_cps(kd, Cin, stride), G = (split_ntap(kd, stride) * cps + 3) / 4;
-    return (size_t)(Cin / (8 * cps)) * G * ((Cout + 15) / 16) * 3 * 1024;
+    return (size_t)(Cin / (8 * cps)) * G * ((Cout + 15) / 16) * np * 1024;
+}
+
+extern "C" size_t mvs_conv_split_packed_bytes(int kd, int Cin, int Cout, int stride) {
+    return split_packed_bytes(kd, Cin, Cout, stride, 3);
+}
+
+// two-piece fp16 form: the fragments + a 16-byte trailer (what undoes the weights' scale; the weights' largest magnitude)
+extern "C" size_t mvs_conv_split_f16_packed_bytes(int kd, int Cin, int Cout, int stride) {
+    const size_t n = split_packed_bytes(kd, Cin, Cout, stride, 2);
+    return n ? n + 16 : 0;
+}
+
+namespace mvs { int launch_absmax_word(const float *x, int64_t n, unsigned *word, hipStream_t st); }   // conv_f16x3.hip
+
+extern "C" int mvs_conv_split_pack_weights_f16_f32(const float *weight, int kd, int Cin, int Cout, int stride, void *packed,
+                                                   void *stream) {
+    if (!weight || !packed || !mvs_conv_split_supported(kd, Cin, Cout, stride)) {
+        set_error("mvs_conv_split_pack_weights_f16_f32: unsupported layer shape (see mvs_conv_split_supported)");
+        return MVS_EINVAL;
+    }
+    const int ntap = split_ntap(kd, stride);
+    const int step = split_cout_step(kd, Cout, stride), cps = split_cps(kd, Cin, stride), G = (ntap * cps + 3) / 4, MT = step / 16;
+    const size_t per_launch = (size_t)(Cin / (8 * cps)) * G * MT * 2 * 1024, body = split_packed_bytes(kd, Cin, Cout, stride, 2);
+    unsigned char *pk = static_cast<unsigned char *>(packed);
+    unsigned *wmax = reinterpret_cast<unsigned *>(pk + body + 4);
+    const int rc = launch_absmax_word(weight, (int64_t)Cout * Cin * ntap, wmax, as_stream(stream));
+    if (rc != MVS_OK) return rc;
+    for (int co0 = 0; co0 < Cout; co0 += step) {
+        const int total = (Cin / (8 * cps)) * G * MT * 512;
+        hipLaunchKernelGGL(pack_split_f16_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), weight, Cin, Cout, ntap, cps, G, MT,
+                           co0, reinterpret_cast<unsigned short *>(pk + (co0 / step) * per_launch), total, wmax,
+                           reinterpret_cast<float *>(pk + body));
+    }
+    return check_launch("mvs_conv_split_pack_weights_f16_f32");
 }
 
 extern "C" int mvs_conv_split_pack_weights_f32(const float *weight, int kd, int Cin, int Cout, int stride, void *packed,
@@ -536,20 +632,25 @@ extern "C" int mvs_conv_split_pack_weights_f32(const float *weight, int kd, int 
     return check_launch("mvs_conv_split_pack_weights_f32");
 }
 
-extern "C" int mvs_conv_split_f32(const float *in, const void *packed, const float *scale, const float *shift,
-                                  const float *residual, int relu, int kd, int stride, int B, int Cin, int Cout, int D, int H,
-                                  int W, int out_c4, float *out, void *stream) {
-    if (!in || !packed || !out || B <= 0 || D <= 0 || H <= 0 || W <= 0 || relu < 0 || relu > 2 ||
+// np = 3: the bf16 form; np = 2: the fp16 form (in_absmax required).  out_absmax: NULL, or the absmax block the largest
+// magnitude of `out` is atomically max-ed INTO (the caller clears it: one memset serves the blocks of a whole network)
+static int conv_split_impl(const float *in, const void *in_absmax, const void *packed, const float *scale, const float *shift,
+                           const float *residual, int relu, int kd, int stride, int B, int Cin, int Cout, int D, int H,
+                           int W, int out_c4, float *out, void *out_absmax, int np, void *stream) {
+    if (!in || (np == 2 && !in_absmax) || !packed || !out || B <= 0 || D <= 0 || H <= 0 || W <= 0 || relu < 0 || relu > 2 ||
         !mvs_conv_split_supported(kd, Cin, Cout, stride) || (out_c4 && residual)) {
         set_error("mvs_conv_split_f32: invalid argument (kd in {1, 3}; Cin, Cout in {16, 32, 64}, stride 1; or kd 3, stride 2, Cin in {8, 16, 32}; or kd 1, stride 2 = the 5x5 layers 8 -> 16, 16 -> 32; channels-last)");
         return MVS_EINVAL;
     }
     if ((int64_t)(kd + 3) * H * W * Cin * 4 >= 0xffffff00LL) return bare_error(MVS_EUNSUPPORTED, __func__, __LINE__);   // 32-bit halo offsets: callers fall back to the fp32 kernels
     const int step = split_cout_step(kd, Cout, stride), cps = split_cps(kd, Cin, stride), G = (split_ntap(kd, stride) * cps + 3) / 4;
-    const size_t per_launch = (size_t)(Cin / (8 * cps)) * G * (step / 16) * 3 * 1024;
+    const size_t per_launch = (size_t)(Cin / (8 * cps)) * G * (step / 16) * np * 1024;
     hipStream_t st = as_stream(stream);
     for (int co0 = 0; co0 < Cout; co0 += step) {
         SplitArgs a;
+        a.in_absmax = static_cast<const unsigned *>(in_absmax);
+        a.w_iscale = reinterpret_cast<const float *>(static_cast<const unsigned char *>(packed) + split_packed_bytes(kd, Cin, Cout, stride, 2));
+        a.out_absmax = static_cast<unsigned *>(out_absmax);
         a.in = in; a.wpk = static_cast<const unsigned char *>(packed) + (co0 / step) * per_launch;
         a.scale = scale ? scale + co0 : nullptr; a.shift = shift ? shift + co0 : nullptr;
         a.residual = residual ? residual + co0 : nullptr; a.out = out + co0;
@@ -557,18 +658,33 @@ extern "C" int mvs_conv_split_f32(const float *in, const void *packed, const flo
         a.nco = Cout - co0 < step ? Cout - co0 : step; a.co0 = co0; a.out_c4 = out_c4;
         if (out_c4) a.out = out;      // (the block index carries the channel offset)
         int rc = MVS_EUNSUPPORTED;
-#define MVS_SPLIT_CASE(CI, CO, KD) if (stride == 1 && Cin == CI && step == CO && kd == KD) rc = launch_split<SplitCfg<CI, CO, KD>>(a, st);
+#define MVS_SPLIT_CASE(CI, CO, KD) if (stride == 1 && Cin == CI && step == CO && kd == KD) \
+        rc = np == 2 ? launch_split<SplitCfg<CI, CO, KD, 1, 3, 2>>(a, st) : launch_split<SplitCfg<CI, CO, KD>>(a, st);
         MVS_SPLIT_CASE(16, 16, 3) MVS_SPLIT_CASE(32, 16, 3) MVS_SPLIT_CASE(64, 16, 3)
         MVS_SPLIT_CASE(16, 32, 3) MVS_SPLIT_CASE(32, 32, 3) MVS_SPLIT_CASE(64, 32, 3)
         MVS_SPLIT_CASE(16, 16, 1) MVS_SPLIT_CASE(32, 16, 1) MVS_SPLIT_CASE(64, 16, 1)
         MVS_SPLIT_CASE(16, 32, 1) MVS_SPLIT_CASE(32, 32, 1) MVS_SPLIT_CASE(64, 32, 1)
 #undef MVS_SPLIT_CASE
-        if (stride == 2 && kd == 3 && Cin == 8) rc = launch_split<SplitCfg<8, 16, 3, 2>>(a, st);
-        if (stride == 2 && kd == 3 && Cin == 16) rc = launch_split<SplitCfg<16, 16, 3, 2>>(a, st);
-        if (stride == 2 && kd == 3 && Cin == 32) rc = launch_split<SplitCfg<32, 16, 3, 2>>(a, st);
-        if (stride == 2 && kd == 1 && Cin == 8) rc = launch_split<SplitCfg<8, 16, 1, 2, 5>>(a, st);
-        if (stride == 2 && kd == 1 && Cin == 16) rc = launch_split<SplitCfg<16, 32, 1, 2, 5>>(a, st);
+#define MVS_SPLIT_S2(CI, CO, KD, KH) if (stride == 2 && kd == KD && Cin == CI) \
+        rc = np == 2 ? launch_split<SplitCfg<CI, CO, KD, 2, KH, 2>>(a, st) : launch_split<SplitCfg<CI, CO, KD, 2, KH>>(a, st);
+        MVS_SPLIT_S2(8, 16, 3, 3) MVS_SPLIT_S2(16, 16, 3, 3) MVS_SPLIT_S2(32, 16, 3, 3)
+        MVS_SPLIT_S2(8, 16, 1, 5) MVS_SPLIT_S2(16, 32, 1, 5)
+#undef MVS_SPLIT_S2
         if (rc != MVS_OK) return rc;
     }
     return MVS_OK;
+}
+
+extern "C" int mvs_conv_split_f32(const float *in, const void *packed, const float *scale, const float *shift,
+                                  const float *residual, int relu, int kd, int stride, int B, int Cin, int Cout, int D, int H,
+                                  int W, int out_c4, float *out, void *stream) {
+    return conv_split_impl(in, nullptr, packed, scale, shift, residual, relu, kd, stride, B, Cin, Cout, D, H, W, out_c4, out,
+                           nullptr, 3, stream);
+}
+
+extern "C" int mvs_conv_split_f16_f32(const float *in, const void *in_absmax, const void *packed, const float *scale,
+                                      const float *shift, const float *residual, int relu, int kd, int stride, int B, int Cin,
+                                      int Cout, int D, int H, int W, int out_c4, float *out, void *out_absmax, void *stream) {
+    return conv_split_impl(in, in_absmax, packed, scale, shift, residual, relu, kd, stride, B, Cin, Cout, D, H, W, out_c4, out,
+                           out_absmax, 2, stream);
 }

@@ -23,7 +23,7 @@ static bool costreg_plan(int B, int base, int D, int H, int W, CostRegPlan &p) {
         p.off[i] = o;
         o += ((size_t)sz[i] + 63) & ~(size_t)63;   // 256-byte aligned slices
     }
-    p.total = o + 64;   // + the word mvs_costreg_fwd2_f32 collects the input's largest magnitude in when the caller has none
+    p.total = o + 10 * kAbsmaxWords;   // + the absmax blocks of mvs_costreg_fwd2_f32: the input's (when the caller has none), nine activations'
     return true;
 }
 
@@ -36,105 +36,132 @@ extern "C" size_t mvs_costreg_workspace_bytes(int B, int base, int D, int H, int
     return costreg_plan(B, base, D, H, W, p) ? p.total * sizeof(float) : 0;
 }
 
-extern "C" int mvs_costreg_fwd_f32(const float *in, int in_layout, const mvs_conv_layer *layers, int B,
-                                   int Cin, int base, int D, int H, int W, int impl, void *workspace,
-                                   size_t workspace_bytes, float *out_cost, void *stream) {
-    return mvs_costreg_fwd2_f32(in, in_layout, layers, B, Cin, base, D, H, W, impl, workspace, workspace_bytes, nullptr,
-                                nullptr, out_cost, stream);
-}
-
-extern "C" int mvs_costreg_fwd2_f32(const float *in, int in_layout, const mvs_conv_layer *layers, int B,
-                                    int Cin, int base, int D, int H, int W, int impl, void *workspace,
-                                    size_t workspace_bytes, const void *conv0_f16x3, const void *in_absmax,
-                                    float *out_cost, void *stream) {
+// layers: the eleven layers; f16 = their two-piece fp16 packs or NULL (the entry of before those existed)
+static int costreg_impl(const float *in, int in_layout, const mvs_conv_layer *layers, const void *const *f16, int B,
+                        int Cin, int base, int D, int H, int W, int impl, void *workspace,
+                        size_t workspace_bytes, const void *in_absmax, float *out_cost, void *stream, const char *who) {
     if (!in || !layers || !out_cost || (in_layout != MVS_LAYOUT_NHWC && in_layout != MVS_LAYOUT_C8)) {
-        set_error("mvs_costreg_fwd_f32: invalid argument");
+        set_error("%s: invalid argument", who);
         return MVS_EINVAL;
     }
     CostRegPlan p;
     if (!costreg_plan(B, base, D, H, W, p)) {
-        set_error("mvs_costreg_fwd_f32: D, H, W = %d, %d, %d must be positive multiples of 8 (three "
-                  "stride-2 levels whose transposed layers return exactly 2x)", D, H, W);
+        set_error("%s: D, H, W = %d, %d, %d must be positive multiples of 8 (three "
+                  "stride-2 levels whose transposed layers return exactly 2x)", who, D, H, W);
         return MVS_EINVAL;
     }
     if (!workspace || workspace_bytes < p.total * sizeof(float)) {
-        set_error("mvs_costreg_fwd_f32: workspace of %zu bytes, need %zu", workspace_bytes,
-                  p.total * sizeof(float));
+        set_error("%s: workspace of %zu bytes, need %zu", who, workspace_bytes, p.total * sizeof(float));
         return MVS_EWORKSPACE;
     }
     for (int i = 0; i < 11; ++i)
         if (!layers[i].weight) {
-            set_error("mvs_costreg_fwd_f32: layer %d has no weight", i);
+            set_error("%s: layer %d has no weight", who, i);
             return MVS_EINVAL;
         }
     float *ws = static_cast<float *>(workspace);
     float *c0 = ws + p.off[0], *t1 = ws + p.off[1], *c2 = ws + p.off[2], *t3 = ws + p.off[3],
           *c4 = ws + p.off[4], *t5 = ws + p.off[5], *t6 = ws + p.off[6], *d7 = ws + p.off[7],
           *d9 = ws + p.off[8], *d11 = ws + p.off[9];
+    // absmax blocks (mvs_common.h): [0] the input's when the caller has none, [1 + i] activation i's -- what a layer on the
+    // two-piece fp16 kernels scales its input by, collected in the epilogue of the layer that wrote it
+    unsigned *const amax = reinterpret_cast<unsigned *>(ws + p.total - 10 * kAbsmaxWords);
+    auto block = [&](int i) { return static_cast<void *>(amax + (size_t)i * kAbsmaxWords); };
+    const bool two_piece = f16 && impl != 1;
+    if (two_piece && hipMemsetAsync(amax, 0, 10 * kAbsmaxWords * sizeof(unsigned), as_stream(stream)) != hipSuccess)
+        return bare_error(MVS_ELAUNCH, __func__, __LINE__);
     const int b = base;
     struct Step {
         int layer; const float *src; const float *skip; float *dst; int cin, cout, lvl, stride, transposed, relu, layout;
+        int src_act, dst_act;   // activation index of src / dst (-1: the network's input / none)
     };
     // mvsnet.py:83-93: conv0 .. conv6, then x = conv4 + conv7(x); x = conv2 + conv9(x);
     // x = conv0 + conv11(x); prob (bias, no BN, no ReLU)
     const Step steps[11] = {
-        {0, in, nullptr, c0, Cin, b, 0, 1, 0, 1, in_layout},
-        {1, c0, nullptr, t1, b, 2 * b, 0, 2, 0, 1, MVS_LAYOUT_NHWC},
-        {2, t1, nullptr, c2, 2 * b, 2 * b, 1, 1, 0, 1, MVS_LAYOUT_NHWC},
-        {3, c2, nullptr, t3, 2 * b, 4 * b, 1, 2, 0, 1, MVS_LAYOUT_NHWC},
-        {4, t3, nullptr, c4, 4 * b, 4 * b, 2, 1, 0, 1, MVS_LAYOUT_NHWC},
-        {5, c4, nullptr, t5, 4 * b, 8 * b, 2, 2, 0, 1, MVS_LAYOUT_NHWC},
-        {6, t5, nullptr, t6, 8 * b, 8 * b, 3, 1, 0, 1, MVS_LAYOUT_NHWC},
-        {7, t6, c4, d7, 8 * b, 4 * b, 3, 2, 1, 1, MVS_LAYOUT_NHWC},
-        {8, d7, c2, d9, 4 * b, 2 * b, 2, 2, 1, 1, MVS_LAYOUT_NHWC},
-        {9, d9, c0, d11, 2 * b, b, 1, 2, 1, 1, MVS_LAYOUT_NHWC},
-        {10, d11, nullptr, out_cost, b, 1, 0, 1, 0, 0, MVS_LAYOUT_NHWC},
+        {0, in, nullptr, c0, Cin, b, 0, 1, 0, 1, in_layout, -1, 0},
+        {1, c0, nullptr, t1, b, 2 * b, 0, 2, 0, 1, MVS_LAYOUT_NHWC, 0, 1},
+        {2, t1, nullptr, c2, 2 * b, 2 * b, 1, 1, 0, 1, MVS_LAYOUT_NHWC, 1, 2},
+        {3, c2, nullptr, t3, 2 * b, 4 * b, 1, 2, 0, 1, MVS_LAYOUT_NHWC, 2, 3},
+        {4, t3, nullptr, c4, 4 * b, 4 * b, 2, 1, 0, 1, MVS_LAYOUT_NHWC, 3, 4},
+        {5, c4, nullptr, t5, 4 * b, 8 * b, 2, 2, 0, 1, MVS_LAYOUT_NHWC, 4, 5},
+        {6, t5, nullptr, t6, 8 * b, 8 * b, 3, 1, 0, 1, MVS_LAYOUT_NHWC, 5, 6},
+        {7, t6, c4, d7, 8 * b, 4 * b, 3, 2, 1, 1, MVS_LAYOUT_NHWC, 6, 7},
+        {8, d7, c2, d9, 4 * b, 2 * b, 2, 2, 1, 1, MVS_LAYOUT_NHWC, 7, 8},
+        {9, d9, c0, d11, 2 * b, b, 1, 2, 1, 1, MVS_LAYOUT_NHWC, 8, -1},
+        {10, d11, nullptr, out_cost, b, 1, 0, 1, 0, 0, MVS_LAYOUT_NHWC, -1, -1},
     };
+    // does the layer that reads activation i run on a two-piece kernel (its producer then collects the absmax block)?
+    auto two_piece_layer = [&](const Step &s) {
+        if (!two_piece || !f16[s.layer]) return false;
+        if (s.layer == 0) return in_layout == MVS_LAYOUT_C8 && b == 8 && mvs_conv3d_f16x3_packed_bytes(Cin) != 0;
+        if (s.transposed) return s.stride == 2 && mvs_deconv_split_supported(s.cin, s.cout) != 0;
+        return s.layout == MVS_LAYOUT_NHWC && mvs_conv_split_supported(3, s.cin, s.cout, s.stride) != 0;
+    };
+    bool wanted[10] = {false};     // activation i's absmax block has a reader
+    for (const Step &s : steps)
+        if (s.src_act >= 0 && two_piece_layer(s)) wanted[s.src_act] = true;
     for (const Step &s : steps) {
         const mvs_conv_layer &L = layers[s.layer];
-        if (s.layer == 0 && conv0_f16x3 && in_layout == MVS_LAYOUT_C8 && b == 8 && impl != 1 &&
-            mvs_conv3d_f16x3_packed_bytes(Cin) != 0) {
-            // conv0 on the fp16 matrix pipe with two-piece operands (conv_f16x3.hip); the operand scale comes from the
-            // producer of the volume, or from one more pass over it
-            const void *mx = in_absmax;
-            if (!mx) {
-                void *w = ws + p.total - 64;
-                const int rc = mvs_absmax_f32(in, (int64_t)B * D * H * W * Cin, w, stream);
+        const int d = D >> s.lvl, h = H >> s.lvl, w = W >> s.lvl;
+        void *const out_mx = (s.dst_act >= 0 && wanted[s.dst_act]) ? block(1 + s.dst_act) : nullptr;
+        bool collected = false;     // did the kernel collect out_mx in its epilogue?
+        int rc;
+        if (two_piece_layer(s)) {
+            const void *mx = s.src_act >= 0 ? block(1 + s.src_act) : in_absmax;
+            if (!mx) {    // the network's input without a block from its producer: one more pass over it
+                rc = mvs_absmax_f32(in, (int64_t)B * D * H * W * Cin, block(0), stream);
                 if (rc != MVS_OK) return rc;
-                mx = w;
+                mx = block(0);
             }
-            const int rc = mvs_conv3d_c8_f16x3_f32(s.src, mx, conv0_f16x3, L.scale, L.shift, nullptr, s.relu, B, Cin,
-                                                   D, H, W, s.dst, stream);
-            if (rc != MVS_OK) return rc;
-            continue;
-        }
-        if (s.layer == 0 && L.packed_split && in_layout == MVS_LAYOUT_C8 && b == 8 && impl != 1 &&
-            mvs_conv3d_bf16x6_packed_bytes(Cin) != 0) {
+            if (s.layer == 0)            // conv0 on the fp16 matrix pipe with two-piece operands (conv_f16x3.hip)
+                rc = mvs_conv3d_c8_f16x3_f32(s.src, mx, f16[0], L.scale, L.shift, nullptr, s.relu, B, Cin, D, H, W, s.dst, out_mx, stream);
+            else if (s.transposed)       // conv7 / conv9 / conv11 (deconv_split.hip); s.lvl is the INPUT level
+                rc = mvs_deconv_split_f16_f32(s.src, mx, f16[s.layer], L.scale, L.shift, s.skip, s.relu, B, s.cin, s.cout, d, h, w,
+                                              s.dst, out_mx, stream);
+            else                         // conv1 .. conv6 (conv_split.hip)
+                rc = mvs_conv_split_f16_f32(s.src, mx, f16[s.layer], L.scale, L.shift, s.skip, s.relu, 3, s.stride, B, s.cin, s.cout,
+                                            d, h, w, 0, s.dst, out_mx, stream);
+            collected = true;
+        } else if (s.layer == 0 && L.packed_split && in_layout == MVS_LAYOUT_C8 && b == 8 && impl != 1 &&
+                   mvs_conv3d_bf16x6_packed_bytes(Cin) != 0) {
             // conv0 on the bf16 matrix pipe with exactly split fp32 operands (conv_bf16x6.hip)
-            const int rc = mvs_conv3d_c8_bf16x6_f32(s.src, L.packed_split, L.scale, L.shift, nullptr, s.relu, B, Cin,
-                                                    D, H, W, s.dst, stream);
-            if (rc != MVS_OK) return rc;
-            continue;
+            rc = mvs_conv3d_c8_bf16x6_f32(s.src, L.packed_split, L.scale, L.shift, nullptr, s.relu, B, Cin, D, H, W, s.dst, stream);
+        } else if (L.packed_split && s.transposed && s.stride == 2 && impl != 1 && mvs_deconv_split_supported(s.cin, s.cout)) {
+            rc = mvs_deconv_split_f32(s.src, L.packed_split, L.scale, L.shift, s.skip, s.relu, B, s.cin, s.cout, d, h, w, s.dst, stream);
+        } else if (L.packed_split && !s.transposed && s.layout == MVS_LAYOUT_NHWC && impl != 1 &&
+                   mvs_conv_split_supported(3, s.cin, s.cout, s.stride)) {
+            rc = mvs_conv_split_f32(s.src, L.packed_split, L.scale, L.shift, s.skip, s.relu, 3, s.stride, B, s.cin, s.cout,
+                                    d, h, w, 0, s.dst, stream);
+        } else {      // (conv3, conv5 on the fp32 MFMA kernels: they collect out_mx in their epilogue too)
+            rc = mvs_conv3d_absmax_f32(s.src, L.weight, L.packed, L.scale, L.shift, s.skip, s.relu,
+                                       s.transposed, B, s.cin, s.cout, d, h, w, s.stride, s.layout, impl, s.dst, out_mx, stream);
+            collected = true;
         }
-        if (L.packed_split && s.transposed && s.stride == 2 && impl != 1 && mvs_deconv_split_supported(s.cin, s.cout)) {
-            // conv7 / conv9 / conv11 (deconv_split.hip); s.lvl is the INPUT level
-            const int rc = mvs_deconv_split_f32(s.src, L.packed_split, L.scale, L.shift, s.skip, s.relu, B, s.cin, s.cout,
-                                                D >> s.lvl, H >> s.lvl, W >> s.lvl, s.dst, stream);
-            if (rc != MVS_OK) return rc;
-            continue;
-        }
-        if (L.packed_split && !s.transposed && s.layout == MVS_LAYOUT_NHWC && impl != 1 &&
-            mvs_conv_split_supported(3, s.cin, s.cout, s.stride)) {
-            // conv1 .. conv6: the split-operand kernel (conv_split.hip)
-            const int rc = mvs_conv_split_f32(s.src, L.packed_split, L.scale, L.shift, s.skip, s.relu, 3, s.stride, B, s.cin, s.cout,
-                                              D >> s.lvl, H >> s.lvl, W >> s.lvl, 0, s.dst, stream);
-            if (rc != MVS_OK) return rc;
-            continue;
-        }
-        const int rc = mvs_conv3d_f32(s.src, L.weight, L.packed, L.scale, L.shift, s.skip, s.relu,
-                                      s.transposed, B, s.cin, s.cout, D >> s.lvl, H >> s.lvl, W >> s.lvl,
-                                      s.stride, s.layout, impl, s.dst, stream);
         if (rc != MVS_OK) return rc;   // the layer call has set the error text
+        if (out_mx && !collected) {    // a layer on the other kernels (conv3, conv5) in front of a two-piece one: one pass over its output
+            const int so = s.transposed ? 1 : -1, q = s.stride == 2 ? 1 : 0;
+            const int lo = s.lvl + (so < 0 ? q : -q);
+            rc = mvs_absmax_f32(s.dst, (int64_t)B * (D >> lo) * (H >> lo) * (W >> lo) * s.cout, out_mx, stream);
+            if (rc != MVS_OK) return rc;
+        }
     }
     return MVS_OK;
+}
+
+extern "C" int mvs_costreg_fwd_f32(const float *in, int in_layout, const mvs_conv_layer *layers, int B,
+                                   int Cin, int base, int D, int H, int W, int impl, void *workspace,
+                                   size_t workspace_bytes, float *out_cost, void *stream) {
+    return costreg_impl(in, in_layout, layers, nullptr, B, Cin, base, D, H, W, impl, workspace, workspace_bytes, nullptr, out_cost,
+                        stream, "mvs_costreg_fwd_f32");
+}
+
+extern "C" int mvs_costreg_fwd2_f32(const float *in, int in_layout, const mvs_conv_layer *layers, const void *const *packed_f16,
+                                    int B, int Cin, int base, int D, int H, int W, int impl, void *workspace,
+                                    size_t workspace_bytes, const void *in_absmax, float *out_cost, void *stream) {
+    if (!packed_f16) {
+        set_error("mvs_costreg_fwd2_f32: packed_f16 = the eleven layers' two-piece packs (NULL entries allowed)");
+        return MVS_EINVAL;
+    }
+    return costreg_impl(in, in_layout, layers, packed_f16, B, Cin, base, D, H, W, impl, workspace, workspace_bytes, in_absmax,
+                        out_cost, stream, "mvs_costreg_fwd2_f32");
 }

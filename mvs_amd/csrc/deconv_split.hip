@@ -26,22 +26,27 @@ struct DeconvArgs {
     int B, D, H, W, ldc;
     int tiles_x, tiles_y, tiles_z, ystrip;
     int relu;
+    // two-piece fp16 form (NP = 2): the input's absmax block (mvs_common.h), what undoes the weights' scale (device float)
+    const unsigned *in_absmax;
+    const float *w_iscale;
+    unsigned *out_absmax;     // NULL, or the absmax block that collects the largest magnitude this launch stores (any form)
 };
 
 // per-dimension tap t of parity p -> (kernel index, input offset)
 __host__ __device__ constexpr int dsp_k(int p, int t) { return p == 0 ? 1 : (t == 0 ? 2 : 0); }
 __host__ __device__ constexpr int dsp_d(int p, int t) { return (p == 1 && t == 1) ? 1 : 0; }
 
-template <int CIN_, bool PXM_>
+// NP: operand pieces -- 3 = bf16 hi/mid/lo, six products; 2 = scaled fp16 hi/lo, three products (conv_f16x3.hip)
+template <int CIN_, bool PXM_, int NP_ = 3>
 struct DeconvSplitCfg {
-    static constexpr int CIN = CIN_;
+    static constexpr int CIN = CIN_, NP = NP_;
     static constexpr bool PXM = PXM_;
     static constexpr int COUT = PXM ? 8 : 16, NCLS = PXM ? 4 : 8, CPS = 2, NSTEP = CIN / 16;
     static constexpr int TZ = PXM ? 4 : 2, TY = 4, ZT = TZ + 1, YT = TY + 1, XP = 17, NVOX = ZT * YT * XP;
     static constexpr int NVP = (NVOX + 15) / 16 * 16;
     static constexpr int RB = TZ * TY, RPW = RB / 8;
     static constexpr int NPIECE = 2 * NVP * CPS, NCOPY = (NPIECE + 63) / 64;
-    static constexpr int FBYTES = NCOPY * 1024, SPART = NVP * 16 * CPS, SBYTES = 3 * SPART;
+    static constexpr int FBYTES = NCOPY * 1024, SPART = NVP * 16 * CPS, SBYTES = NP * SPART;
     // class c = (pz, py [, px]); taps (tz, ty, tx) with tx fastest; slots = taps x chunks, 4 slots per K-step
     static constexpr int pz(int c) { return PXM ? c >> 1 : c >> 2; }
     static constexpr int py(int c) { return PXM ? c & 1 : (c >> 1) & 1; }
@@ -52,7 +57,7 @@ struct DeconvSplitCfg {
     static constexpr int kbase(int c) { int s = 0; for (int i = 0; i < c; ++i) s += nk(i); return s; }
     static constexpr int NK = kbase(NCLS);
     static constexpr int cls_of(int g) { int c = 0; while (g >= kbase(c + 1)) ++c; return c; }
-    static constexpr int WBYTES = NK * 3 * 1024;
+    static constexpr int WBYTES = NK * NP * 1024;
     static constexpr int F_OFF = 2 * WBYTES, S_OFF = F_OFF + FBYTES, AFF_OFF = S_OFF + SBYTES, LDS_BYTES = AFF_OFF + 2 * COUT * 4;
     static_assert(RB % 8 == 0 && LDS_BYTES <= 160 * 1024 && SPART * 2 + 16 * 1024 < 65536, "tile / LDS budget");
 };
@@ -75,9 +80,16 @@ __global__ __launch_bounds__(kDeconvThreads) void deconv_split_kernel(DeconvArgs
     const unsigned lds_base = (unsigned)(uintptr_t)lds;
     const bool copier = wv >= 8;
     const int cw = wv - 8;
+    constexpr int NP = C::NP;
+    float sx = 1.0f, unscale = 1.0f;     // NP = 2: operand scale of the input; what undoes it and the weights' scale
+    if constexpr (NP == 2) {
+        const int xe = absmax_exponent(load_absmax(a.in_absmax));
+        sx = pow2f(14 - xe);
+        unscale = pow2f(xe - 14) * __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *a.w_iscale)));
+    }
     if (tid < 2 * C::COUT) {
         const int c = tid % C::COUT;
-        const float v = tid < C::COUT ? (a.scale ? a.scale[c] : 1.0f) : (a.shift ? a.shift[c] : 0.0f);
+        const float v = tid < C::COUT ? (a.scale ? a.scale[c] : 1.0f) * unscale : (a.shift ? a.shift[c] : 0.0f);
         *reinterpret_cast<float *>(lds + C::AFF_OFF + tid * 4) = v;
     }
 
@@ -131,19 +143,23 @@ __global__ __launch_bounds__(kDeconvThreads) void deconv_split_kernel(DeconvArgs
             constexpr int p0 = 2 * decltype(pc)::value, p1 = (p0 + 1 < NPS) ? p0 + 1 : p0;
             f32x4 &x0 = x[p0], &x1 = x[p1];
             asm volatile("" : "+v"(x0), "+v"(x1));
-            bf16x8 h, m, l;
-            split3_block(x0, x1, h, m, l);
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 hu = __builtin_bit_cast(u32x4, h), mu = __builtin_bit_cast(u32x4, m), lu = __builtin_bit_cast(u32x4, l);
+            u32x4 hu, mu, lu;
+            if constexpr (NP == 2) {
+                split2_block(x0, x1, sx, hu, mu);
+            } else {
+                bf16x8 h, m, l;
+                split3_block(x0, x1, h, m, l);
+                hu = __builtin_bit_cast(u32x4, h); mu = __builtin_bit_cast(u32x4, m); lu = __builtin_bit_cast(u32x4, l);
+            }
             if (p0 * NT + tid < NPIECE) {
                 lds_write_b64<p0 * NT * 8>(sp, hu[0], hu[1]);
                 lds_write_b64<p0 * NT * 8 + SPART>(sp, mu[0], mu[1]);
-                lds_write_b64<p0 * NT * 8 + 2 * SPART>(sp, lu[0], lu[1]);
+                if constexpr (NP == 3) lds_write_b64<p0 * NT * 8 + 2 * SPART>(sp, lu[0], lu[1]);
             }
             if (p1 != p0 && p1 * NT + tid < NPIECE) {
                 lds_write_b64<p1 * NT * 8>(sp, hu[2], hu[3]);
                 lds_write_b64<p1 * NT * 8 + SPART>(sp, mu[2], mu[3]);
-                lds_write_b64<p1 * NT * 8 + 2 * SPART>(sp, lu[2], lu[3]);
+                if constexpr (NP == 3) lds_write_b64<p1 * NT * 8 + 2 * SPART>(sp, lu[2], lu[3]);
             }
         });
         lds_wait_n<0>();
@@ -262,6 +278,7 @@ __global__ __launch_bounds__(kDeconvThreads) void deconv_split_kernel(DeconvArgs
         return ((((int64_t)cur.b * Do + oz) * Ho + oy) * Wo + ox) * a.ldc + c0;
     };
     int wsel = 0;
+    float vmax = 0.0f;       // largest magnitude this lane has stored (-> a.out_absmax)
     for (int k = 0; k < ntw; ++k) {
         const TileIdx cur = decode(t0 + k * t_step);
 #pragma unroll 1
@@ -282,18 +299,18 @@ __global__ __launch_bounds__(kDeconvThreads) void deconv_split_kernel(DeconvArgs
             // ---- MFMA phase: items (K-step g, row block r); the reads of the next item go out before the MFMAs of this one
             const unsigned aA = lds_base + (unsigned)(wsel * WBYTES + lane * 16);
             const unsigned aS = lds_base + (unsigned)S_OFF;
-            bf16x8 A[2][3], Bf[2][3];
+            bf16x8 A[2][NP], Bf[2][NP];      // (NP = 2: the same registers hold fp16 pairs)
             auto read_a = [&](auto gc) {
                 constexpr int g = decltype(gc)::value;
-                static_for<0, 3>([&](auto ic) {
+                static_for<0, NP>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
-                    A[g & 1][i] = __builtin_bit_cast(bf16x8, lds_read_b128<(g * 3 + i) * 1024>(aA));
+                    A[g & 1][i] = __builtin_bit_cast(bf16x8, lds_read_b128<(g * NP + i) * 1024>(aA));
                 });
             };
             auto read_b = [&](auto ic) {
                 constexpr int it = decltype(ic)::value, g = it / RPW, r = it % RPW;
                 const unsigned ad = aS + rbo[r] + tapo[g];
-                static_for<0, 3>([&](auto pc) {
+                static_for<0, NP>([&](auto pc) {
                     constexpr int sp = decltype(pc)::value;
                     Bf[it & 1][sp] = __builtin_bit_cast(bf16x8, lds_read_b128<sp * SPART>(ad));
                 });
@@ -303,28 +320,39 @@ __global__ __launch_bounds__(kDeconvThreads) void deconv_split_kernel(DeconvArgs
             static_for<0, NK * RPW>([&](auto ic) {
                 constexpr int it = decltype(ic)::value, g = it / RPW, r = it % RPW, c = C::cls_of(g);
                 lds_wait_n<0>();
-                {
-                    bf16x8 &b0 = Bf[it & 1][0], &b1 = Bf[it & 1][1], &b2 = Bf[it & 1][2];
-                    asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2));
-                }
+                static_for<0, NP>([&](auto pc) {
+                    bf16x8 &b0 = Bf[it & 1][decltype(pc)::value];
+                    asm volatile("" : "+v"(b0));
+                });
                 if constexpr (r == 0) {
-                    bf16x8 &a0 = A[g & 1][0], &a1 = A[g & 1][1], &a2 = A[g & 1][2];
-                    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2));
+                    static_for<0, NP>([&](auto pc) {
+                        bf16x8 &a0 = A[g & 1][decltype(pc)::value];
+                        asm volatile("" : "+v"(a0));
+                    });
                 }
                 if constexpr (it + 1 < NK * RPW) {
                     if constexpr (r == RPW - 1) read_a(std::integral_constant<int, g + 1>{});
                     read_b(std::integral_constant<int, it + 1>{});
                 }
                 __builtin_amdgcn_sched_barrier(0);   // the reads go out BEFORE this item's MFMAs
-                const bf16x8 bh = Bf[it & 1][0], bm = Bf[it & 1][1], bl = Bf[it & 1][2];
                 f32x4 &cc = acc[c][r];
+                if constexpr (NP == 2) {
+                    // three partial products, small terms first: al bh, ah bl, ah bh
+                    const f16x8 ah = __builtin_bit_cast(f16x8, A[g & 1][0]), al = __builtin_bit_cast(f16x8, A[g & 1][1]);
+                    const f16x8 fh = __builtin_bit_cast(f16x8, Bf[it & 1][0]), fl = __builtin_bit_cast(f16x8, Bf[it & 1][1]);
+                    cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, fh, cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, fl, cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, fh, cc, 0, 0, 0);
+                } else {
+                const bf16x8 bh = Bf[it & 1][0], bm = Bf[it & 1][1], bl = Bf[it & 1][NP - 1];
                 // six partial products, small terms first
                 cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[g & 1][1], bm, cc, 0, 0, 0);
-                cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[g & 1][2], bh, cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[g & 1][NP - 1], bh, cc, 0, 0, 0);
                 cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[g & 1][0], bl, cc, 0, 0, 0);
                 cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[g & 1][1], bh, cc, 0, 0, 0);
                 cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[g & 1][0], bm, cc, 0, 0, 0);
                 cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[g & 1][0], bh, cc, 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             });
             if (NSTEP > 1) wsel ^= 1;
@@ -352,20 +380,29 @@ __global__ __launch_bounds__(kDeconvThreads) void deconv_split_kernel(DeconvArgs
                         v[0] += res[c][r].x; v[1] += res[c][r].y; v[2] += res[c][r].z; v[3] += res[c][r].w;
                     }
                     *reinterpret_cast<float4 *>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+                    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
                 }
             }
         }
     }
+    publish_absmax(a.out_absmax, vmax);
 }
 
 // PyTorch ConvTranspose3d weight (Cin, Cout_total, 3, 3, 3), output channels [co0, co0 + 8 or 16) ->
 // [step][K-step g][part][lane][8 bf16]; lane (mrow, kq): slot 4 ks + kq of g's class = (tap (tz, ty, tx), chunk cc),
 // input channel (step*2 + cc)*8 + j; row mrow = output channel (pxm: (px', channel))
-template <bool PXM>
+// F16: [..][hi,lo][lane][8 fp16] of w * 2^(14 - exponent(*wmax)); thread 0 writes what undoes the scale into *iscale
+template <bool PXM, bool F16 = false>
 __global__ __launch_bounds__(256) void pack_deconv_split_kernel(const float *__restrict__ w, int Cin, int Cout, int co0,
-                                                                unsigned short *__restrict__ out, int total) {
+                                                                unsigned short *__restrict__ out, int total,
+                                                                const unsigned *__restrict__ wmax = nullptr, float *__restrict__ iscale = nullptr) {
     using C = DeconvSplitCfg<16, PXM>;      // (the class tables do not depend on Cin)
     const int i = blockIdx.x * 256 + threadIdx.x;
+    int we = 0;
+    if constexpr (F16) {
+        we = absmax_exponent(*wmax);
+        if (i == 0) *iscale = pow2f(we - 14);
+    }
     if (i >= total) return;
     const int j = i & 7, lane = (i >> 3) & 63;
     const int g = (i >> 9) % C::NK, st = (i >> 9) / C::NK;
@@ -389,6 +426,15 @@ __global__ __launch_bounds__(256) void pack_deconv_split_kernel(const float *__r
         }
         const int ci = (st * 2 + cc) * 8 + j;
         if (live) x = w[(((int64_t)ci * Cout + co) * 3 + kz) * 9 + ky * 3 + kx];
+    }
+    if constexpr (F16) {
+        x *= pow2f(14 - we);
+        const _Float16 h = (_Float16)x;
+        const _Float16 l = (_Float16)(x - (float)h);
+        unsigned short *o = out + ((size_t)(st * C::NK + g) * 2) * 512 + lane * 8 + j;
+        o[0] = __builtin_bit_cast(unsigned short, h);
+        o[512] = __builtin_bit_cast(unsigned short, l);
+        return;
     }
     const __bf16 h = (__bf16)x;
     const float r1 = x - (float)h;
@@ -423,10 +469,43 @@ extern "C" int mvs_deconv_split_supported(int Cin, int Cout) {
 
 static int deconv_nk(int Cout) { return Cout == 8 ? DeconvSplitCfg<16, true>::NK : DeconvSplitCfg<16, false>::NK; }
 
-extern "C" size_t mvs_deconv_split_packed_bytes(int Cin, int Cout) {
+static size_t deconv_packed_bytes(int Cin, int Cout, int np) {
     if (!mvs_deconv_split_supported(Cin, Cout)) return 0;
     const int launches = Cout == 8 ? 1 : Cout / 16;
-    return (size_t)launches * (Cin / 16) * deconv_nk(Cout) * 3 * 1024;
+    return (size_t)launches * (Cin / 16) * deconv_nk(Cout) * np * 1024;
+}
+
+extern "C" size_t mvs_deconv_split_packed_bytes(int Cin, int Cout) { return deconv_packed_bytes(Cin, Cout, 3); }
+
+// two-piece fp16 form: the fragments + a 16-byte trailer (what undoes the weights' scale; the weights' largest magnitude)
+extern "C" size_t mvs_deconv_split_f16_packed_bytes(int Cin, int Cout) {
+    const size_t n = deconv_packed_bytes(Cin, Cout, 2);
+    return n ? n + 16 : 0;
+}
+
+namespace mvs { int launch_absmax_word(const float *x, int64_t n, unsigned *word, hipStream_t st); }   // conv_f16x3.hip
+
+extern "C" int mvs_deconv_split_pack_weights_f16_f32(const float *weight, int Cin, int Cout, void *packed, void *stream) {
+    if (!weight || !packed || !mvs_deconv_split_supported(Cin, Cout)) {
+        set_error("mvs_deconv_split_pack_weights_f16_f32: needs a (Cin, Cout, 3, 3, 3) weight with Cin in {16, 32, 64}, Cout in {8, 16, 32}");
+        return MVS_EINVAL;
+    }
+    const int nk = deconv_nk(Cout), step = Cout == 8 ? 8 : 16;
+    const size_t per_launch = (size_t)(Cin / 16) * nk * 2 * 1024, body = deconv_packed_bytes(Cin, Cout, 2);
+    unsigned char *pk = static_cast<unsigned char *>(packed);
+    unsigned *wmax = reinterpret_cast<unsigned *>(pk + body + 4);
+    float *iscale = reinterpret_cast<float *>(pk + body);
+    const int rc = launch_absmax_word(weight, (int64_t)Cin * Cout * 27, wmax, as_stream(stream));
+    if (rc != MVS_OK) return rc;
+    const int total = (Cin / 16) * nk * 512;
+    for (int co0 = 0; co0 < Cout; co0 += step) {
+        unsigned short *dst = reinterpret_cast<unsigned short *>(pk + (co0 / step) * per_launch);
+        if (Cout == 8)
+            hipLaunchKernelGGL((pack_deconv_split_kernel<true, true>), dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), weight, Cin, Cout, co0, dst, total, wmax, iscale);
+        else
+            hipLaunchKernelGGL((pack_deconv_split_kernel<false, true>), dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), weight, Cin, Cout, co0, dst, total, wmax, iscale);
+    }
+    return check_launch("mvs_deconv_split_pack_weights_f16_f32");
 }
 
 extern "C" int mvs_deconv_split_pack_weights_f32(const float *weight, int Cin, int Cout, void *packed, void *stream) {
@@ -440,41 +519,54 @@ extern "C" int mvs_deconv_split_pack_weights_f32(const float *weight, int Cin, i
     for (int co0 = 0; co0 < Cout; co0 += step) {
         unsigned short *dst = reinterpret_cast<unsigned short *>(static_cast<unsigned char *>(packed) + (co0 / step) * per_launch);
         if (Cout == 8)
-            hipLaunchKernelGGL(pack_deconv_split_kernel<true>, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), weight, Cin, Cout, co0, dst, total);
+            hipLaunchKernelGGL((pack_deconv_split_kernel<true, false>), dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), weight, Cin, Cout, co0, dst, total, nullptr, nullptr);
         else
-            hipLaunchKernelGGL(pack_deconv_split_kernel<false>, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), weight, Cin, Cout, co0, dst, total);
+            hipLaunchKernelGGL((pack_deconv_split_kernel<false, false>), dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), weight, Cin, Cout, co0, dst, total, nullptr, nullptr);
     }
     return check_launch("mvs_deconv_split_pack_weights_f32");
 }
 
-extern "C" int mvs_deconv_split_f32(const float *in, const void *packed, const float *scale, const float *shift,
-                                    const float *residual, int relu, int B, int Cin, int Cout, int D, int H, int W,
-                                    float *out, void *stream) {
-    if (!in || !packed || !out || B <= 0 || D <= 0 || H <= 0 || W <= 0 || !mvs_deconv_split_supported(Cin, Cout)) {
+// np = 3: the bf16 form; np = 2: the fp16 form (in_absmax required); out_absmax: NULL, or the absmax block the largest magnitude
+// of `out` is max-ed INTO (the caller clears it)
+static int deconv_split_impl(const float *in, const void *in_absmax, const void *packed, const float *scale, const float *shift,
+                             const float *residual, int relu, int B, int Cin, int Cout, int D, int H, int W,
+                             float *out, void *out_absmax, int np, void *stream) {
+    if (!in || (np == 2 && !in_absmax) || !packed || !out || B <= 0 || D <= 0 || H <= 0 || W <= 0 || !mvs_deconv_split_supported(Cin, Cout)) {
         set_error("mvs_deconv_split_f32: invalid argument (Cin in {16, 32, 64}; Cout in {8, 16, 32}; stride 2; channels-last)");
         return MVS_EINVAL;
     }
     if ((int64_t)5 * H * W * Cin * 4 >= 0xffffff00LL) return bare_error(MVS_EUNSUPPORTED, __func__, __LINE__);   // 32-bit halo offsets: callers fall back to the fp32 kernels
     const int nk = deconv_nk(Cout), step = Cout == 8 ? 8 : 16;
-    const size_t per_launch = (size_t)(Cin / 16) * nk * 3 * 1024;
+    const size_t per_launch = (size_t)(Cin / 16) * nk * np * 1024;
     hipStream_t st = as_stream(stream);
     for (int co0 = 0; co0 < Cout; co0 += step) {
         DeconvArgs a;
+        a.in_absmax = static_cast<const unsigned *>(in_absmax);
+        a.w_iscale = reinterpret_cast<const float *>(static_cast<const unsigned char *>(packed) + deconv_packed_bytes(Cin, Cout, 2));
+        a.out_absmax = static_cast<unsigned *>(out_absmax);
         a.in = in; a.wpk = static_cast<const unsigned char *>(packed) + (co0 / step) * per_launch;
         a.scale = scale ? scale + co0 : nullptr; a.shift = shift ? shift + co0 : nullptr;
         a.residual = residual ? residual + co0 : nullptr; a.out = out + co0;
         a.B = B; a.D = D; a.H = H; a.W = W; a.ldc = Cout; a.relu = relu;
         int rc = MVS_EUNSUPPORTED;
-        if (Cout == 8) {
-            if (Cin == 16) rc = launch_deconv_split<DeconvSplitCfg<16, true>>(a, st);
-            else if (Cin == 32) rc = launch_deconv_split<DeconvSplitCfg<32, true>>(a, st);
-            else rc = launch_deconv_split<DeconvSplitCfg<64, true>>(a, st);
-        } else {
-            if (Cin == 16) rc = launch_deconv_split<DeconvSplitCfg<16, false>>(a, st);
-            else if (Cin == 32) rc = launch_deconv_split<DeconvSplitCfg<32, false>>(a, st);
-            else rc = launch_deconv_split<DeconvSplitCfg<64, false>>(a, st);
-        }
+#define MVS_DECONV_CASE(CI, PX) if (Cin == CI && (Cout == 8) == PX) \
+        rc = np == 2 ? launch_deconv_split<DeconvSplitCfg<CI, PX, 2>>(a, st) : launch_deconv_split<DeconvSplitCfg<CI, PX>>(a, st);
+        MVS_DECONV_CASE(16, true) MVS_DECONV_CASE(32, true) MVS_DECONV_CASE(64, true)
+        MVS_DECONV_CASE(16, false) MVS_DECONV_CASE(32, false) MVS_DECONV_CASE(64, false)
+#undef MVS_DECONV_CASE
         if (rc != MVS_OK) return rc;
     }
     return MVS_OK;
+}
+
+extern "C" int mvs_deconv_split_f32(const float *in, const void *packed, const float *scale, const float *shift,
+                                    const float *residual, int relu, int B, int Cin, int Cout, int D, int H, int W,
+                                    float *out, void *stream) {
+    return deconv_split_impl(in, nullptr, packed, scale, shift, residual, relu, B, Cin, Cout, D, H, W, out, nullptr, 3, stream);
+}
+
+extern "C" int mvs_deconv_split_f16_f32(const float *in, const void *in_absmax, const void *packed, const float *scale,
+                                        const float *shift, const float *residual, int relu, int B, int Cin, int Cout, int D,
+                                        int H, int W, float *out, void *out_absmax, void *stream) {
+    return deconv_split_impl(in, in_absmax, packed, scale, shift, residual, relu, B, Cin, Cout, D, H, W, out, out_absmax, 2, stream);
 }

@@ -50,6 +50,7 @@ struct HeadArgs {
     float *out;            // [N,H,W,8]
     int N, H, W, tiles_x, tiles_y, ystrip;
     int abl;               // tuning: 1 no conv0, 2 no conv1, 4 no stores, 8 no copies (results are garbage)
+    unsigned *out_absmax;  // NULL, or the absmax block (mvs_common.h) the largest magnitude stored is max-ed into
 };
 
 __global__ __launch_bounds__(kHeadThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void feature_head_kernel(HeadArgs a, int ntiles) {
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(kHeadThreads) __attribute__((amdgpu_waves_per_eu(2,
     int parity = 0;
     bool full_stores = false;   // did this wave issue exactly kRPW stores after its last copies?
     if (t_cur < t_end) issue(t_cur, 0);
+    float vmax = 0.0f;
     while (t_cur < t_end) {
         const Tile cur = nxt;
         const int t_next = t_cur + t_step;
@@ -283,12 +285,14 @@ __global__ __launch_bounds__(kHeadThreads) __attribute__((amdgpu_waves_per_eu(2,
                 v[2] = fmaxf(v[2] * sc1.z + sh1.z, 0.f); v[3] = fmaxf(v[3] * sc1.w + sh1.w, 0.f);
                 const int64_t o = (((int64_t)cur.b * a.H + oy) * a.W + ox) * 8 + c0;
                 *reinterpret_cast<float4 *>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+                vmax = fmaxf(fmaxf(vmax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));       // (after the ReLU: non-negative)
             }
         }
         full_stores = !(a.abl & 4) && cur.ty * kTH + wv * kRPW + kRPW <= a.H;
         parity ^= 1;
         t_cur = t_next;
     }
+    publish_absmax(a.out_absmax, vmax);
 }
 
 // conv1's weight (8, 8, 3, 3) -> [kernel row ky][part][lane][8 bf16]: lane (m, kq) = MFMA row m = (x-shift m >> 3, channel
@@ -330,6 +334,12 @@ extern "C" int mvs_feature_head_pack_weights_f32(const float *weight1, void *pac
 extern "C" int mvs_feature_head_f32(const float *img, const float *w0, const float *scale0, const float *shift0,
                                     const void *packed1, const float *scale1, const float *shift1, int N, int H,
                                     int W, float *out, void *stream) {
+    return mvs_feature_head_absmax_f32(img, w0, scale0, shift0, packed1, scale1, shift1, N, H, W, out, nullptr, stream);
+}
+
+extern "C" int mvs_feature_head_absmax_f32(const float *img, const float *w0, const float *scale0, const float *shift0,
+                                           const void *packed1, const float *scale1, const float *shift1, int N, int H,
+                                           int W, float *out, void *out_absmax, void *stream) {
     if (!img || !w0 || !packed1 || !out || N <= 0) return bare_error(MVS_EINVAL, __func__, __LINE__);
     if (!mvs_feature_head_supported(H, W)) {
         set_error("mvs_feature_head_f32: needs W %% 4 == 0 and an image below 4 GiB (H=%d W=%d)", H, W);
@@ -338,6 +348,7 @@ extern "C" int mvs_feature_head_f32(const float *img, const float *w0, const flo
     HeadArgs a;
     a.img = img; a.w0 = w0; a.scale0 = scale0; a.shift0 = shift0;
     a.wpk1 = static_cast<const unsigned char *>(packed1); a.scale1 = scale1; a.shift1 = shift1; a.out = out;
+    a.out_absmax = static_cast<unsigned *>(out_absmax);
     a.N = N; a.H = H; a.W = W;
     a.tiles_x = (W + 31) / 32; a.tiles_y = (H + kTH - 1) / kTH; a.ystrip = 8;
 #ifdef MVS_TUNING

@@ -150,6 +150,27 @@ __device__ __forceinline__ void glds16_buf(unsigned voffset, mvs_srd_t srd, unsi
                  : "v"(voffset), "s"(srd), "s"(soffset), "s"(lds_byte_addr)
                  : "memory");
 }
+
+// "absmax block": kAbsmaxWords 32-bit words that together hold the largest magnitude of an array as the bit pattern of |x|
+// (non-negative floats order like their bit patterns) -- word i collects the workgroups with blockIdx.x % 256 == i, the
+// reader takes the maximum of all words.  One word for everybody made every wave's atomic queue up behind 2000-4000 others at
+// the end of a kernel (+6 us per launch on the small layers, +50 us on the sweep).  The consumer is the operand scale of the
+// two-piece fp16 convolutions (conv_f16x3.hip).
+constexpr int kAbsmaxWords = 256;
+__device__ __forceinline__ void publish_absmax(unsigned *absmax, float vmax) {
+    if (!absmax) return;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    if ((threadIdx.x & 63) == 0 && vmax > 0.0f) atomicMax(absmax + (blockIdx.x & (kAbsmaxWords - 1)), __float_as_uint(vmax));
+}
+// wave-uniform maximum of an absmax block
+__device__ __forceinline__ unsigned load_absmax(const unsigned *absmax) {
+    const uint4 v = reinterpret_cast<const uint4 *>(absmax)[threadIdx.x & 63];
+    unsigned m = max(max(v.x, v.y), max(v.z, v.w));
+#pragma unroll
+    for (int o = 32; o; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+}
 #endif
 
 }  // namespace mvs

@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void variance_fwd_dma_kernel(
     int tiles_x, int tiles_y, float *__restrict__ out, int out_c8, int ablate, const unsigned *__restrict__ sel, int nblk,
     unsigned *__restrict__ absmax) {
     // sel: word of the workspace header written by variance_choose_kernel (sweep_persist.hip); this kernel runs when it
-    // reads 0 ("per-tile kernel"); NULL = unconditional.  absmax: NULL, or the word that collects the largest |variance|
+    // reads 0 ("per-tile kernel"); NULL = unconditional.  absmax: NULL, or the absmax block that collects the largest |variance|
     if (sel && *sel != 0u) return;
     int vblk = blockIdx.x;
     float vmax = 0.0f;
@@ -1227,7 +1227,7 @@ static int launch_variance_tile_c16(const float *ref_fea, const float *src_feas,
     static const bool tile_loop = [] { const char *e = getenv("MVS_SWEEP_TILE_LOOP"); return e && e[0] == '1'; }();
     const bool loop = sel && tile_loop;
     // (behind the chooser, sel != NULL, the chooser has cleared the word)
-    if (!sel && absmax && hipMemsetAsync(absmax, 0, 4, st) != hipSuccess) return check_launch("variance absmax memset");
+    if (!sel && absmax && hipMemsetAsync(absmax, 0, 4 * kAbsmaxWords, st) != hipSuccess) return check_launch("variance absmax memset");
     const dim3 g(loop ? (unsigned)(nblk < 3 * device_cu_count() ? nblk : 3 * device_cu_count()) : (unsigned)nblk, (unsigned)B);
 #define MVS_LDS_CASE(n)                                                                                      \
     case n: {                                                                                                \
@@ -1270,7 +1270,7 @@ __global__ __launch_bounds__(256) void c4_to_c16_sel_kernel(const float4 *__rest
 
 extern "C" int mvs_absmax_f32(const float *x, int64_t n, void *absmax_bits, void *stream);   // conv_f16x3.hip
 
-// absmax: NULL, or the device word that receives the bit pattern of the largest |variance| (collected by the LDS-staged
+// absmax: NULL, or the absmax block that receives the largest |variance| (collected by the LDS-staged
 // kernels as they store; one more pass over the volume behind the gather kernels)
 static int variance_fwd_impl(const float *ref_fea, const float *src_feas,
                              const float *rot_trans, const float *depth_values,
@@ -1329,7 +1329,7 @@ static int variance_fwd_impl(const float *ref_fea, const float *src_feas,
         const int dchunks = (D + kTileD - 1) / kTileD;
         const int64_t nblk = (int64_t)tiles_x * tiles_y * dchunks;
         if (nblk > 0x7fffffffLL) return bare_error(MVS_EINVAL, __func__, __LINE__);
-        if (absmax && hipMemsetAsync(absmax, 0, 4, st) != hipSuccess) return check_launch("variance absmax memset");
+        if (absmax && hipMemsetAsync(absmax, 0, 4 * kAbsmaxWords, st) != hipSuccess) return check_launch("variance absmax memset");
         const dim3 g((unsigned)nblk, (unsigned)B);
 #define MVS_LDS8_CASE(n)                                                                          \
     case n: {                                                                                     \

@@ -102,14 +102,6 @@ inline bool grid_for(int64_t total, int per_block, unsigned &grid) {
 }
 
 
-// largest |variance| a wave has written -> the caller's word (non-negative floats order like their bit patterns)
-__device__ __forceinline__ void publish_absmax(unsigned *absmax, float vmax) {
-    if (!absmax) return;
-#pragma unroll
-    for (int o = 32; o; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-    if ((threadIdx.x & 63) == 0 && vmax > 0.0f) atomicMax(absmax, __float_as_uint(vmax));
-}
-
 // sweep_persist.hip: the persistent kernel for shared depth planes and 16-channel-blocked
 // features (+ its cold-path kernel); MVS_EUNSUPPORTED (nothing launched) when the shape is not
 // its own.  The workspace holds the cold path's queue.
@@ -120,7 +112,7 @@ int launch_variance_persist(const float *ref16, const float *srcs16, const float
                             int fea_c4, int fast, int nw, int nq, int flags, void *workspace,
                             size_t workspace_bytes, hipStream_t st, int autosel = 0, unsigned *absmax = nullptr);
 // device-side choice between 16-plane tiles, 8-plane tiles and (allow_tile) the per-tile kernel of sweep.hip from the
-// footprints of sample tiles; clears the workspace header (and *absmax, the word the candidates collect the largest
+// footprints of sample tiles; clears the workspace header (and the absmax block the candidates collect the largest
 // |variance| in, if given) and writes the choice into word 1 of the header
 int launch_variance_choose(const float *rt, const float *depth, const SweepParams &p, int allow_tile, unsigned *absmax,
                            void *workspace, hipStream_t st);

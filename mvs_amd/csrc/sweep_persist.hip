@@ -68,7 +68,7 @@ struct PersistArgs {
     int fea_c4;             // features: 0 = [B,C/16,H,W,16], 1 = [B,C/4,H,W,4], 2 = [B,H,W,C]
     float sx, ox, sy, oy;   // FAST: ix = (X/Z) * sx + ox
     int autosel;            // 1: run only if queue[kSelWord] names this kernel's tile depth (variance_choose_kernel)
-    unsigned *absmax;       // NULL, or a device word that collects the bit pattern of the largest |variance| written
+    unsigned *absmax;       // NULL, or the absmax block (mvs_common.h) that collects the largest |variance| written
                             // (atomic max; the operand scale of mvs_conv3d_c8_f16x3_f32)
 };
 // workspace header (32-bit words): [0] cold-path records, [1] the chosen tile depth (16, 8, or 0 = the per-tile
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(1024) void variance_choose_kernel(PersistArgs a, in
     const SweepParams &p = a.p;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid < 2) { s_max[tid] = 0; s_sum[tid] = 0; s_cnt[tid] = 0; }
-    if (tid == 0 && a.absmax) *a.absmax = 0u;
+    if (tid < kAbsmaxWords && a.absmax) a.absmax[tid] = 0u;
     __syncthreads();
     const int tiles_x = (p.W + kPW - 1) / kPW, tiles_y = (p.H + kPH - 1) / kPH;
     for (int t = wv; t < 54 * p.B; t += 16) {
@@ -788,7 +788,7 @@ int launch_variance_persist(const float *ref16, const float *srcs16, const float
     }
     // (with autosel the chooser has cleared the header)
     if (!autosel && hipMemsetAsync(workspace, 0, 4 * kQueueHdr, st) != hipSuccess) return check_launch("variance workspace memset");
-    if (!autosel && absmax && hipMemsetAsync(absmax, 0, 4, st) != hipSuccess) return check_launch("variance absmax memset");
+    if (!autosel && absmax && hipMemsetAsync(absmax, 0, 4 * kAbsmaxWords, st) != hipSuccess) return check_launch("variance absmax memset");
     const int grid = device_cu_count();
     const int NV = p.V - 1;
 #define MVS_PERSIST_PICK(W_, Q_)                                                             \

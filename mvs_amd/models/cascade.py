@@ -104,7 +104,7 @@ def depthnet_forward(features, cas_proj, depth_values, costreg_params, prob_volu
     with ops.stage(tag + "costvol_variance"):
         if use_dma:
             if costreg_params["conv0"].get("packed_f16x3") is not None:   # conv0's operand scale, collected by the sweep kernel
-                amax = torch.empty(1, device=fcl.device, dtype=torch.int32)
+                amax = ops.absmax_block(fcl.device)
             var = ops.costvol_variance_c16(f16[0], f16[1:], rts, depth_values, out_c8=True, absmax_out=amax)
         else:
             var = ops.costvol_variance_cl(fcl[0], fcl[1:], rts, depth_values, out_c8=True)

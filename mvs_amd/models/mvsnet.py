@@ -109,17 +109,24 @@ class FeatureNet(nn.Module):
         x = imgs_nchw
         P = self._hip_params()
         first = 0
-        if ops.feature_head_enabled() and ops.feature_head_supported(x.shape[2], x.shape[3]):
+        # a layer on a two-piece fp16 kernel scales its input by the absmax block the layer in front of it collected in its
+        # epilogue (ops.conv2d: x_absmax / out_absmax); the chain starts at the fused head
+        head = ops.feature_head_enabled() and ops.feature_head_supported(x.shape[2], x.shape[3])
+        blocks = ops.absmax_block(x.device, zero=True, n=len(P)) if (head and ops.split_f16_enabled()) else None
+        if head:
             with ops.stage("feature.head"):   # conv0 + conv1 in one kernel
                 x = ops.feature_head(x, P[0]["weight"], P[0]["scale"], P[0]["shift"], P[1]["head"], P[1]["scale"],
-                                     P[1]["shift"])
+                                     P[1]["shift"], out_absmax=blocks[1] if blocks is not None else None)
             first = 2
         for i, p in enumerate(P):
             if i < first:
                 continue
+            last = i == len(P) - 1
             with ops.stage("feature." + p["name"]):
                 x = ops.conv2d(x, p["packed"], p["cin"], p["cout"], p["k"], p["stride"], p["scale"],
-                               p["shift"], p["relu"], planar=(i == 0), out_c4=(out_c4 and i == len(P) - 1))
+                               p["shift"], p["relu"], planar=(i == 0), out_c4=(out_c4 and last),
+                               x_absmax=blocks[i - 1] if blocks is not None else None,
+                               out_absmax=blocks[i] if (blocks is not None and not last) else None)
         return x
 
 
@@ -249,28 +256,37 @@ class CostRegNet(nn.Module):
             # remain for stage timing and for sizes the whole-net entry does not take
             return ops.costreg_forward(x_cl, P, in_c8=in_c8, impl=self.conv_impl, x_absmax=x_absmax)
 
-        def run(name, t, skip=None, relu=True):
+        # the per-layer chain of mvs_costreg_fwd2_f32: a layer on a two-piece fp16 kernel scales its input by the absmax block the
+        # layer in front of it collected (blocks of activations nobody reads that way stay None)
+        f16 = ops.split_f16_enabled() and self.conv_impl == ops.IMPL_AUTO
+        blocks = ops.absmax_block(x_cl.device, zero=True, n=7) if f16 else None
+        blk = (lambda i: blocks[i]) if f16 else (lambda i: None)
+
+        def run(name, t, skip=None, relu=True, x_abs=None, out_abs=None):
             p = P[name]
             with ops.stage("costreg." + name):
-                return _conv(p, t, skip, relu)
+                return ops.conv3d(t, p["weight"], p["scale"], p["shift"], skip, relu, p["transposed"],
+                                  p["stride"], channels_last=True, packed=p["packed"],
+                                  impl=self.conv_impl, x_absmax=x_abs, out_absmax=out_abs)
 
-        def _conv(p, t, skip, relu, c8=False):
-            if c8 and p.get("packed_f16x3") is not None and self.conv_impl != ops.IMPL_DIRECT:
-                return ops.conv3d_c8_f16x3(t, p["packed_f16x3"], x_absmax, p["scale"], p["shift"], skip, relu)
-            if c8 and p.get("packed_split") is not None and self.conv_impl != ops.IMPL_DIRECT:
-                return ops.conv3d_c8_split(t, p["packed_split"], p["scale"], p["shift"], skip, relu)
-            return ops.conv3d(t, p["weight"], p["scale"], p["shift"], skip, relu, p["transposed"],
-                              p["stride"], channels_last=True, packed=p["packed"],
-                              impl=self.conv_impl, in_c8=c8)
-
+        p0 = P["conv0"]
         with ops.stage("costreg.conv0"):
-            c0 = _conv(P["conv0"], x_cl, None, True, in_c8)
-        c2 = run("conv2", run("conv1", c0))
-        c4 = run("conv4", run("conv3", c2))
-        t = run("conv6", run("conv5", c4))
-        t = run("conv7", t, c4)
-        t = run("conv9", t, c2)
-        t = run("conv11", t, c0)
+            if in_c8 and p0.get("packed_f16x3") is not None and self.conv_impl != ops.IMPL_DIRECT:
+                c0 = ops.conv3d_c8_f16x3(x_cl, p0["packed_f16x3"], x_absmax, p0["scale"], p0["shift"], None, True, out_absmax=blk(0))
+            elif in_c8 and p0.get("packed_split") is not None and self.conv_impl != ops.IMPL_DIRECT:
+                c0 = ops._with_absmax(ops.conv3d_c8_split(x_cl, p0["packed_split"], p0["scale"], p0["shift"], None, True), blk(0))
+            else:
+                c0 = ops.conv3d(x_cl, p0["weight"], p0["scale"], p0["shift"], None, True, False, 1, channels_last=True,
+                                packed=p0["packed"], impl=self.conv_impl, in_c8=in_c8, out_absmax=blk(0))
+        t1 = run("conv1", c0, x_abs=blk(0), out_abs=blk(1))
+        c2 = run("conv2", t1, x_abs=blk(1))
+        t3 = run("conv3", c2, out_abs=blk(2))
+        c4 = run("conv4", t3, x_abs=blk(2))
+        t5 = run("conv5", c4, out_abs=blk(3))
+        t = run("conv6", t5, x_abs=blk(3), out_abs=blk(4))
+        t = run("conv7", t, c4, x_abs=blk(4), out_abs=blk(5))
+        t = run("conv9", t, c2, x_abs=blk(5), out_abs=blk(6))
+        t = run("conv11", t, c0, x_abs=blk(6))
         cost = run("prob", t, None, relu=False)     # [B,D,H,W,1]
         return cost.squeeze(-1)
 
@@ -445,7 +461,7 @@ class MVSNet(nn.Module):
             with ops.stage("costvol_variance"):
                 if use_lds:
                     if c8 and ops.conv0_f16_enabled():   # the sweep kernels collect conv0's operand scale as they store
-                        amax = torch.empty(1, device=f16.device, dtype=torch.int32)
+                        amax = ops.absmax_block(f16.device)
                     var = ops.costvol_variance_c16(f16[0], f16[1:], rts, depth_values,
                                                    self.align_corners, out_c8=c8, fast=self.variance_fast, absmax_out=amax)
                 else:

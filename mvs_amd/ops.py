@@ -496,7 +496,7 @@ def costvol_variance_c16(ref16, srcs16, rts, depth_values, align_corners=False, 
     -> [B,D,H,W,C] or (out_c8) [B,D,H,C/8,W,8].  Shared depth planes run the persistent
     kernel (mvs_costvol_variance_fwd_ws_f32); `fast` selects its fast-coordinate mode
     (MVS_SWEEP_FAST), otherwise the result is bit-identical to the reference's arithmetic.
-    absmax_out: one-word int32 device tensor that receives the bit pattern of the volume's largest magnitude
+    absmax_out: absmax block (absmax_block()) that receives the volume's largest magnitude
     (mvs_costvol_variance_fwd_ws2_f32; what conv3d_c8_f16x3 / costreg_forward scale conv0's operands by)."""
     ref16, srcs16, depth_values = _f32c(ref16), _f32c(srcs16), _f32c(depth_values)
     B, G, H, W, blk = ref16.shape
@@ -591,16 +591,30 @@ def conv3d_mfma_supported(transposed, cin, cout, stride):
 _split_registry = {}   # id(packed fp32 weights) -> (weakref to them, their split-operand companion)
 
 
-def _register_split(packed, split):
+def _register_split(packed, split, f16=None):
     import weakref
     key = id(packed)
-    _split_registry[key] = (weakref.ref(packed, lambda _r, k=key: _split_registry.pop(k, None)), split)
+    _split_registry[key] = (weakref.ref(packed, lambda _r, k=key: _split_registry.pop(k, None)), split, f16)
 
 
 def split_companion(packed):
     """The bf16 hi/mid/lo pack registered for this packed weight tensor (pack_conv*_weight(..., split=True)), or None."""
     hit = _split_registry.get(id(packed)) if packed is not None else None
     return hit[1] if hit is not None and hit[0]() is packed else None
+
+
+def f16_companion(packed):
+    """The scaled fp16 hi/lo pack registered beside it (two-piece form: the layer runs there when its caller hands the
+    input's absmax block to conv3d / conv2d), or None."""
+    hit = _split_registry.get(id(packed)) if packed is not None else None
+    return hit[2] if hit is not None and hit[0]() is packed else None
+
+
+def split_f16_enabled():
+    """False when MVS_SPLIT_F16=0 keeps the split-operand layers on the three-piece bf16 kernels (six products; A/B).
+    Default: the two-piece fp16 kernels (three products) wherever the caller chains the absmax blocks."""
+    import os
+    return conv_split_enabled() and os.environ.get("MVS_SPLIT_F16", "1") != "0"
 
 
 def pack_conv3d_weight(weight, transposed, stride, split=False):
@@ -624,11 +638,13 @@ def pack_conv3d_weight(weight, transposed, stride, split=False):
     if split and not transposed and conv_split_enabled() and want:
         sp = pack_conv_weight_split(weight, stride)
         if sp is not None:
-            _register_split(packed, sp)
+            _register_split(packed, sp, pack_conv_weight_split_f16(weight, stride) if split_f16_enabled() else None)
     if split and transposed and stride == 2 and conv_split_enabled():
         sp = pack_deconv_weight_split(weight)
         if sp is not None:
-            _register_split(packed, sp)
+            import os
+            f16d = split_f16_enabled() and os.environ.get("MVS_DECONV_F16", "1") != "0"      # (A/B switch)
+            _register_split(packed, sp, pack_deconv_weight_split_f16(weight) if f16d else None)
     return packed
 
 
@@ -684,17 +700,39 @@ def pack_conv3d_weight_f16x3(weight):
     return packed
 
 
+ABSMAX_WORDS = 256      # MVS_ABSMAX_WORDS of include/mvs_hip.h
+
+
+def absmax_block(device, zero=False, n=None):
+    """An absmax block: the int32 words a producer kernel collects the largest magnitude of its output in (bit patterns of
+    |x|; the maximum over the block is the value) and a two-piece fp16 convolution scales its input by.  n: that many
+    blocks as rows of one tensor (one fill for a whole network's blocks)."""
+    shape = ABSMAX_WORDS if n is None else (n, ABSMAX_WORDS)
+    return (torch.zeros if zero else torch.empty)(shape, device=device, dtype=torch.int32)
+
+
+def absmax_value(block):
+    """The float an absmax block holds."""
+    return block.max().view(1).view(torch.float32).item()
+
+
+def _with_absmax(out, block):
+    if block is not None:
+        absmax(out, block)
+    return out
+
+
 def absmax(x, out=None):
-    """Largest magnitude of a device array as the bit pattern of |x| in a one-word int32 tensor (mvs_absmax_f32)."""
+    """Largest magnitude of a device array into an absmax block (mvs_absmax_f32: resets the block, then one pass over x)."""
     x = _f32c(x)
     if out is None:
-        out = torch.empty(1, device=x.device, dtype=torch.int32)
+        out = absmax_block(x.device)
     with stage("absmax"):
         check(_lib.load().mvs_absmax_f32(ptr(x), x.numel(), ctypes.c_void_p(out.data_ptr()), stream()), "mvs_absmax_f32")
     return out
 
 
-def conv3d_c8_f16x3(x_c8, packed, x_absmax=None, scale=None, shift=None, residual=None, relu=False):
+def conv3d_c8_f16x3(x_c8, packed, x_absmax=None, scale=None, shift=None, residual=None, relu=False, out_absmax=None):
     """conv0-class layer (3x3x3, Cout 8, stride 1) on the fp16 matrix pipe with two-piece operands, three products
     (mvs_conv3d_c8_f16x3_f32): x_c8 [B,D,H,Cin/8,W,8] -> [B,D,H,W,8].  x_absmax: the one-word tensor the producer of
     x_c8 filled (None: computed here by one more pass over x_c8)."""
@@ -708,7 +746,8 @@ def conv3d_c8_f16x3(x_c8, packed, x_absmax=None, scale=None, shift=None, residua
             ptr(x_c8), ctypes.c_void_p(x_absmax.data_ptr()), ptr(packed), ptr(_f32c(scale)) if scale is not None else None,
             ptr(_f32c(shift)) if shift is not None else None,
             ptr(_f32c(residual)) if residual is not None else None, int(bool(relu)), B, G * 8, D, H, W,
-            ptr(out), stream()), "mvs_conv3d_c8_f16x3_f32")
+            ptr(out), ctypes.c_void_p(out_absmax.data_ptr()) if out_absmax is not None else None, stream()),
+            "mvs_conv3d_c8_f16x3_f32")
     return out
 
 
@@ -728,6 +767,51 @@ def pack_conv_weight_split(weight, stride=1):
     check(_lib.load().mvs_conv_split_pack_weights_f32(ptr(weight), kd, int(weight.shape[1]), int(weight.shape[0]), stride,
                                                       ptr(packed), stream()), "mvs_conv_split_pack_weights_f32")
     return packed
+
+
+def pack_conv_weight_split_f16(weight, stride=1):
+    """The same layers' weights as scaled fp16 hi/lo A fragments + trailer (two-piece form, mvs_conv_split_f16_f32)."""
+    weight = _f32c(weight)
+    kd = 3 if weight.dim() == 5 else 1
+    k55 = kd == 1 and stride == 2
+    if tuple(weight.shape[-2:]) != ((5, 5) if k55 else (3, 3)) or (kd == 3 and weight.shape[2] != 3):
+        return None
+    n = _lib.load().mvs_conv_split_f16_packed_bytes(kd, int(weight.shape[1]), int(weight.shape[0]), stride)
+    if n == 0:
+        return None
+    packed = torch.empty(n // 4, device=weight.device, dtype=torch.float32)   # opaque bytes
+    check(_lib.load().mvs_conv_split_pack_weights_f16_f32(ptr(weight), kd, int(weight.shape[1]), int(weight.shape[0]), stride,
+                                                          ptr(packed), stream()), "mvs_conv_split_pack_weights_f16_f32")
+    return packed
+
+
+def conv_split_f16(x_cl, packed_f16, cout, x_absmax=None, scale=None, shift=None, residual=None, relu=1, kd=3, out_c4=False,
+                   stride=1, out_absmax=None, soft=False):
+    """conv_split on the fp16 matrix pipe with two-piece operands (three products; mvs_conv_split_f16_f32).  x_absmax: the
+    one-word tensor the producer of x_cl filled (None: one more pass over x_cl); out_absmax: one-word tensor that receives
+    the largest magnitude of the result (for the next two-piece layer)."""
+    x_cl = _f32c(x_cl)
+    if x_absmax is None:
+        x_absmax = absmax(x_cl)
+    if kd == 3:
+        B, D, H, W, cin = x_cl.shape
+        out = torch.empty(B, (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1, cout, device=x_cl.device,
+                          dtype=torch.float32)
+    else:
+        D, H, W, cin = x_cl.shape
+        B = 1
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        out = torch.empty((D, cout // 4, Ho, Wo, 4) if out_c4 else (D, Ho, Wo, cout), device=x_cl.device, dtype=torch.float32)
+    with stage("conv_split"):
+        rc = _lib.load().mvs_conv_split_f16_f32(
+            ptr(x_cl), ctypes.c_void_p(x_absmax.data_ptr()), ptr(packed_f16), ptr(_f32c(scale)) if scale is not None else None,
+            ptr(_f32c(shift)) if shift is not None else None,
+            ptr(_f32c(residual)) if residual is not None else None, int(relu), kd, stride, B, cin, cout, D, H, W,
+            int(bool(out_c4)), ptr(out), ctypes.c_void_p(out_absmax.data_ptr()) if out_absmax is not None else None, stream())
+    if soft and rc == MVS_EUNSUPPORTED:
+        return None
+    check(rc, "mvs_conv_split_f16_f32")
+    return out
 
 
 MVS_EUNSUPPORTED = -2     # include/mvs_hip.h
@@ -777,6 +861,41 @@ def pack_deconv_weight_split(weight):
     return packed
 
 
+def pack_deconv_weight_split_f16(weight):
+    """The same layers' weights as scaled fp16 hi/lo A fragments + trailer (two-piece form, mvs_deconv_split_f16_f32)."""
+    weight = _f32c(weight)
+    if weight.dim() != 5 or tuple(weight.shape[2:]) != (3, 3, 3):
+        return None
+    n = _lib.load().mvs_deconv_split_f16_packed_bytes(int(weight.shape[0]), int(weight.shape[1]))
+    if n == 0:
+        return None
+    packed = torch.empty(n // 4, device=weight.device, dtype=torch.float32)   # opaque bytes
+    check(_lib.load().mvs_deconv_split_pack_weights_f16_f32(ptr(weight), int(weight.shape[0]), int(weight.shape[1]),
+                                                            ptr(packed), stream()), "mvs_deconv_split_pack_weights_f16_f32")
+    return packed
+
+
+def deconv_split_f16(x_cl, packed_f16, cout, x_absmax=None, scale=None, shift=None, residual=None, relu=True, out_absmax=None,
+                     soft=False):
+    """deconv_split on the fp16 matrix pipe with two-piece operands (mvs_deconv_split_f16_f32); x_absmax / out_absmax as
+    conv_split_f16."""
+    x_cl = _f32c(x_cl)
+    if x_absmax is None:
+        x_absmax = absmax(x_cl)
+    B, D, H, W, cin = x_cl.shape
+    out = torch.empty(B, 2 * D, 2 * H, 2 * W, cout, device=x_cl.device, dtype=torch.float32)
+    with stage("deconv_split"):
+        rc = _lib.load().mvs_deconv_split_f16_f32(
+            ptr(x_cl), ctypes.c_void_p(x_absmax.data_ptr()), ptr(packed_f16), ptr(_f32c(scale)) if scale is not None else None,
+            ptr(_f32c(shift)) if shift is not None else None,
+            ptr(_f32c(residual)) if residual is not None else None, int(bool(relu)), B, cin, cout, D, H, W,
+            ptr(out), ctypes.c_void_p(out_absmax.data_ptr()) if out_absmax is not None else None, stream())
+    if soft and rc == MVS_EUNSUPPORTED:
+        return None
+    check(rc, "mvs_deconv_split_f16_f32")
+    return out
+
+
 def deconv_split(x_cl, packed_split, cout, scale=None, shift=None, residual=None, relu=True, soft=False):
     """Transposed 3x3x3 stride-2 layer on the bf16 matrix pipe with exactly split fp32 operands
     (mvs_deconv_split_f32): x_cl [B,D,H,W,Cin] -> [B,2D,2H,2W,cout]; residual is added after the ReLU.
@@ -797,11 +916,15 @@ def deconv_split(x_cl, packed_split, cout, scale=None, shift=None, residual=None
 
 
 def conv3d(x, weight, scale=None, shift=None, residual=None, relu=False, transposed=False,
-           stride=1, channels_last=False, packed=None, impl=IMPL_AUTO, in_c8=False):
+           stride=1, channels_last=False, packed=None, impl=IMPL_AUTO, in_c8=False, x_absmax=None, out_absmax=None):
     """3x3x3 (transposed) convolution + per-channel affine + ReLU + skip add.
     x: [B,Cin,D,H,W] or, with channels_last, [B,D,H,W,Cin]; with in_c8 the input
     is the 8-channel-blocked [B,D,H,Cin/8,W,8] (MFMA conv path only; the output
-    is channels-last)."""
+    is channels-last).
+    x_absmax: the absmax block of x (filled by the layer that produced x) -- a layer with a two-piece fp16 pack then runs on
+    those kernels (three products instead of six).  out_absmax: a ZEROED absmax block that receives the largest magnitude of
+    the result for the next layer (collected in the epilogue of the split-operand kernels, by one more pass behind the
+    others)."""
     x = _f32c(x)
     weight = _f32c(weight) if weight is not None else None
     if in_c8:
@@ -829,21 +952,32 @@ def conv3d(x, weight, scale=None, shift=None, residual=None, relu=False, transpo
     # IMPL_AUTO (an explicit IMPL_MFMA / IMPL_DIRECT measures the kernel it names), and a volume beyond the split
     # launcher's limits falls through to the fp32 kernels below.
     sp = split_companion(packed) if impl == IMPL_AUTO else None
+    f16 = f16_companion(packed) if (sp is not None and x_absmax is not None) else None
     if sp is not None and channels_last and not in_c8 and not transposed:
+        if f16 is not None:
+            out = conv_split_f16(x, f16, cout, x_absmax, scale, shift, residual, 1 if relu else 0, kd=3, stride=stride,
+                                 out_absmax=out_absmax, soft=True)
+            if out is not None:
+                return out
         out = conv_split(x, sp, cout, scale, shift, residual, 1 if relu else 0, kd=3, stride=stride, soft=True)
         if out is not None:
-            return out
+            return _with_absmax(out, out_absmax)
     if sp is not None and channels_last and not in_c8 and transposed and stride == 2:
+        if f16 is not None:
+            out = deconv_split_f16(x, f16, cout, x_absmax, scale, shift, residual, relu, out_absmax=out_absmax, soft=True)
+            if out is not None:
+                return out
         out = deconv_split(x, sp, cout, scale, shift, residual, relu, soft=True)
         if out is not None:
-            return out
+            return _with_absmax(out, out_absmax)
     out = torch.empty(shape, device=x.device, dtype=torch.float32)
-    check(_lib.load().mvs_conv3d_f32(
+    check(_lib.load().mvs_conv3d_absmax_f32(
         ptr(x), ptr(weight), ptr(packed), ptr(_f32c(scale)) if scale is not None else None,
         ptr(_f32c(shift)) if shift is not None else None, ptr(residual), int(relu), int(transposed),
         B, cin, cout, D, H, W, stride,
         MVS_LAYOUT_C8 if in_c8 else (MVS_LAYOUT_NHWC if channels_last else MVS_LAYOUT_NCHW),
-        impl, ptr(out), stream()), "mvs_conv3d_f32")
+        impl, ptr(out), ctypes.c_void_p(out_absmax.data_ptr()) if out_absmax is not None else None, stream()),
+        "mvs_conv3d_absmax_f32")
     return out
 
 
@@ -972,13 +1106,26 @@ def costreg_forward(x, params, in_c8=False, impl=IMPL_AUTO, x_absmax=None):
                     raise MvsHipError("costreg_forward needs device tensors")
                 setattr(layers[i], field, t.data_ptr())
     out = torch.empty((B, D, H, W), device=x.device, dtype=torch.float32)
-    f16 = params["conv0"].get("packed_f16x3") if in_c8 else None    # conv0 on the two-piece fp16 kernel; x_absmax from
-    check(lib.mvs_costreg_fwd2_f32(ptr(x), MVS_LAYOUT_C8 if in_c8 else MVS_LAYOUT_NHWC,   # the variance op, or collected in the call
-                                   ctypes.cast(layers, ctypes.c_void_p), B, cin, base, D, H, W, impl,
-                                   ctypes.c_void_p(ws.data_ptr()), ws.numel(), ptr(f16) if f16 is not None else None,
-                                   ctypes.c_void_p(x_absmax.data_ptr()) if (x_absmax is not None and f16 is not None) else None,
-                                   ptr(out), stream()),
-          "mvs_costreg_fwd2_f32")
+    # two-piece fp16 packs (conv0: packed_f16x3, taken for a blocked input; the other layers: the companion registered with
+    # their fp32 pack); x_absmax: the block the variance op filled, else collected inside the call
+    f16 = (ctypes.c_void_p * 11)()
+    any_f16 = False
+    for i, name in enumerate(COSTREG_ORDER):
+        t = (params[name].get("packed_f16x3") if in_c8 else None) if i == 0 else f16_companion(params[name].get("packed"))
+        if t is not None and split_f16_enabled():
+            keep.append(t)
+            f16[i] = t.data_ptr()
+            any_f16 = True
+    if any_f16:
+        check(lib.mvs_costreg_fwd2_f32(ptr(x), MVS_LAYOUT_C8 if in_c8 else MVS_LAYOUT_NHWC,
+                                       ctypes.cast(layers, ctypes.c_void_p), ctypes.cast(f16, ctypes.c_void_p),
+                                       B, cin, base, D, H, W, impl, ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                                       ctypes.c_void_p(x_absmax.data_ptr()) if x_absmax is not None else None,
+                                       ptr(out), stream()), "mvs_costreg_fwd2_f32")
+    else:
+        check(lib.mvs_costreg_fwd_f32(ptr(x), MVS_LAYOUT_C8 if in_c8 else MVS_LAYOUT_NHWC,
+                                      ctypes.cast(layers, ctypes.c_void_p), B, cin, base, D, H, W, impl,
+                                      ctypes.c_void_p(ws.data_ptr()), ws.numel(), ptr(out), stream()), "mvs_costreg_fwd_f32")
     return out
 
 
@@ -1008,7 +1155,7 @@ def pack_conv2d_weight(weight, stride, split=False):
     if split and ((stride == 1 and k == 3) or k55) and conv_split_enabled():
         sp = pack_conv_weight_split(weight, stride)
         if sp is not None:
-            _register_split(packed, sp)
+            _register_split(packed, sp, pack_conv_weight_split_f16(weight, stride) if split_f16_enabled() else None)
     return packed
 
 
@@ -1284,7 +1431,7 @@ def pack_feature_head_weight(w1):
     return packed
 
 
-def feature_head(img_nchw, w0, scale0, shift0, packed1, scale1, shift1):
+def feature_head(img_nchw, w0, scale0, shift0, packed1, scale1, shift1, out_absmax=None):
     """FeatureNet's conv0 + BN + ReLU + conv1 + BN + ReLU (mvsnet.py:11-12) in one kernel: the [N,3,H,W] image batch ->
     [N,H,W,8] channels-last.  w0: conv0's weight in PyTorch layout (8,3,3,3); packed1: pack_feature_head_weight(w1);
     scale / shift: the folded BatchNorm affines."""
@@ -1293,13 +1440,14 @@ def feature_head(img_nchw, w0, scale0, shift0, packed1, scale1, shift1):
     if C != 3 or tuple(w0.shape) != (8, 3, 3, 3):
         raise MvsHipError(f"feature_head: image {tuple(x.shape)} / conv0 weight {tuple(w0.shape)} are not the 3 -> 8 head")
     out = torch.empty((N, H, W, 8), device=x.device, dtype=torch.float32)
-    check(_lib.load().mvs_feature_head_f32(ptr(x), ptr(_f32c(w0)), ptr(scale0), ptr(shift0), ptr(packed1), ptr(scale1),
-                                           ptr(shift1), N, H, W, ptr(out), stream()), "mvs_feature_head_f32")
+    check(_lib.load().mvs_feature_head_absmax_f32(
+        ptr(x), ptr(_f32c(w0)), ptr(scale0), ptr(shift0), ptr(packed1), ptr(scale1), ptr(shift1), N, H, W, ptr(out),
+        ctypes.c_void_p(out_absmax.data_ptr()) if out_absmax is not None else None, stream()), "mvs_feature_head_absmax_f32")
     return out
 
 
 def conv2d(x, packed, cin, cout, ksize, stride, scale=None, shift=None, relu=False, planar=False, coarse=None,
-           out_c4=False, out=None):
+           out_c4=False, out=None, x_absmax=None, out_absmax=None):
     """FeatureNet convolution.  x: [B,H,W,cin] channels-last, or (planar) the [B,3,H,W]
     image.  relu: False/True, or 2 for LeakyReLU(0.1).  coarse: [B,Ho/2,Wo/2,cout], added through
     a nearest x2 upsample (FPN top-down step).  Returns [B,Ho,Wo,cout] channels-last, or with out_c4
@@ -1313,8 +1461,16 @@ def conv2d(x, packed, cin, cout, ksize, stride, scale=None, shift=None, relu=Fal
     Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
     sp = split_companion(packed)
     if sp is not None and (ksize, stride) in ((3, 1), (5, 2)) and not planar and coarse is None and out is None:
+        f16 = f16_companion(packed) if x_absmax is not None else None      # x_absmax / out_absmax: as conv3d
+        if f16 is not None:
+            res = conv_split_f16(x, f16, cout, x_absmax, scale, shift, None, int(relu), kd=1, out_c4=out_c4, stride=stride,
+                                 out_absmax=out_absmax, soft=True)
+            if res is not None:
+                return res
         res = conv_split(x, sp, cout, scale, shift, None, int(relu), kd=1, out_c4=out_c4, stride=stride, soft=True)
         if res is not None:       # else: beyond the split launcher's 32-bit halo offsets -> the fp32 MFMA kernel
+            if out_absmax is not None:
+                absmax(res, out_absmax)
             return res
     shape = (B, cout // 4, Ho, Wo, 4) if out_c4 else (B, Ho, Wo, cout)
     if out is None:
@@ -1328,6 +1484,8 @@ def conv2d(x, packed, cin, cout, ksize, stride, scale=None, shift=None, relu=Fal
     check(_lib.load().mvs_conv2d_f32(ptr(x), ptr(packed), ptr(scale), ptr(shift), ptr(coarse), int(relu), B, cin,
                                      cout, H, W, ksize, stride, int(planar) | (2 if out_c4 else 0), ptr(out), stream()),
           "mvs_conv2d_f32")
+    if out_absmax is not None:
+        absmax(out, out_absmax)
     return out
 
 
