@@ -109,7 +109,11 @@ def _roofline_entry(name, kind, amount, ms):
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                 "algorithmic_bytes": amount, "ms": round(ms, 4)}
     ach = amount / (ms * 1e-3) / 1e12
-    if name == "costreg.conv0" and ops.conv0_f16_enabled():
+    # the inference layers on the two-piece fp16 kernels: conv0 (conv_f16x3.hip) and, chained through the absmax blocks, the
+    # split-operand layers of CostRegNet and FeatureNet (conv_split.hip / deconv_split.hip with NP = 2)
+    f16 = (name == "costreg.conv0" and ops.conv0_f16_enabled()) or \
+          (name in SPLIT_STAGES and name != "costreg.conv0" and not name.startswith("train.") and ops.split_f16_enabled())
+    if f16:
         return {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": round(SPLIT_F16X3_PEAK_TF, 1),
                 "unit": "TFLOP/s", "frac": round(ach / SPLIT_F16X3_PEAK_TF, 4), "traffic": None,
                 "algorithmic_flops": amount, "issued_f16_flops": 3.0 * amount, "ms": round(ms, 4),

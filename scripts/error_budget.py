@@ -49,7 +49,7 @@ def hip_stages(c, fast):
     model = model.to(dev).eval()
     model.variance_fast = fast
     cap = {}
-    o_var, o_c0, o_reg = ops.costvol_variance_c16, ops.conv3d_c8_split, ops.softmax_regress_conf
+    o_var, o_c0, o_reg = ops.costvol_variance_c16, ops.conv3d_c8_f16x3, ops.softmax_regress_conf
 
     def w_var(*a, **k):
         r = o_var(*a, **k); cap["variance"] = r; return r
@@ -60,7 +60,7 @@ def hip_stages(c, fast):
     def w_reg(cost, *a, **k):
         cap["cost"] = cost; return o_reg(cost, *a, **k)
 
-    ops.costvol_variance_c16, ops.conv3d_c8_split, ops.softmax_regress_conf = w_var, w_c0, w_reg
+    ops.costvol_variance_c16, ops.conv3d_c8_f16x3, ops.softmax_regress_conf = w_var, w_c0, w_reg      # (conv0: the two-piece fp16 kernel)
     try:
         with torch.no_grad():
             imgs = d(c["imgs"])
@@ -70,7 +70,7 @@ def hip_stages(c, fast):
             out = model(imgs, d(c["proj"]), d(c["depth_values"]))
     finally:
         ops.set_timer(None)
-        ops.costvol_variance_c16, ops.conv3d_c8_split, ops.softmax_regress_conf = o_var, o_c0, o_reg
+        ops.costvol_variance_c16, ops.conv3d_c8_f16x3, ops.softmax_regress_conf = o_var, o_c0, o_reg
     n, q, h, w, _ = f4.shape
     res = {"feature": f4.permute(0, 1, 4, 2, 3).reshape(B, V, q * 4, h, w).double().cpu(),
            "variance": ops.c8_to_nchw(cap["variance"]).double().cpu(),
