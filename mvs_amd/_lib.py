@@ -18,6 +18,7 @@ MVS_LAYOUT_NHWC = 1
 MVS_LAYOUT_C8 = 2
 MVS_LAYOUT_C16 = 3
 MVS_LAYOUT_C4 = 4
+MVS_LAYOUT_C8H = 5
 
 _c_f = ctypes.c_void_p   # device pointers travel as integers
 _c_i = ctypes.c_int
@@ -55,6 +56,9 @@ _SIGS = {
     "mvs_conv3d_pack_weights_f16x3_f32": (_c_i, [_c_f, _c_i, _c_f, _c_f]),
     "mvs_absmax_f32": (_c_i, [_c_f, _c_l, _c_f, _c_f]),
     "mvs_conv3d_c8_f16x3_f32": (_c_i, [_c_f] * 6 + [_c_i] * 6 + [_c_f, _c_f, _c_f]),
+    "mvs_c8h_bytes": (ctypes.c_size_t, [_c_i] * 5),
+    "mvs_c8_to_c8h_f32": (_c_i, [_c_f, _c_f] + [_c_i] * 5 + [_c_f, _c_f]),
+    "mvs_conv3d_c8h_f16x3_f32": (_c_i, [_c_f] * 6 + [_c_i] * 6 + [_c_f, _c_f, _c_f]),
     "mvs_conv_split_supported": (_c_i, [_c_i] * 4),
     "mvs_conv_split_packed_bytes": (ctypes.c_size_t, [_c_i] * 4),
     "mvs_conv_split_pack_weights_f32": (_c_i, [_c_f] + [_c_i] * 4 + [_c_f, _c_f]),

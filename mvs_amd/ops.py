@@ -751,6 +751,32 @@ def conv3d_c8_f16x3(x_c8, packed, x_absmax=None, scale=None, shift=None, residua
     return out
 
 
+def c8_to_c8h(x_c8, block):
+    """fp32 blocked volume [B,D,H,C/8,W,8] -> the fp16 pairs of MVS_LAYOUT_C8H (opaque int16 tensor) under the scale of an
+    absmax block that bounds it (mvs_c8_to_c8h_f32)."""
+    x_c8 = _f32c(x_c8)
+    B, D, H, G, W, _ = x_c8.shape
+    out = torch.empty(_lib.load().mvs_c8h_bytes(B, G * 8, D, H, W) // 2, device=x_c8.device, dtype=torch.int16)
+    check(_lib.load().mvs_c8_to_c8h_f32(ptr(x_c8), ctypes.c_void_p(block.data_ptr()), B, G * 8, D, H, W,
+                                        ctypes.c_void_p(out.data_ptr()), stream()), "mvs_c8_to_c8h_f32")
+    return out
+
+
+def conv3d_c8h_f16x3(x_pairs, shape, packed, x_absmax, scale=None, shift=None, residual=None, relu=False, out_absmax=None):
+    """conv0-class layer on a volume that arrives as fp16 pairs (MVS_LAYOUT_C8H; mvs_conv3d_c8h_f16x3_f32).  shape = (B, Cin, D, H, W);
+    x_absmax = the block the producer scaled by."""
+    B, cin, D, H, W = shape
+    out = torch.empty(B, D, H, W, 8, device=x_pairs.device, dtype=torch.float32)
+    with stage("conv3d_split"):
+        check(_lib.load().mvs_conv3d_c8h_f16x3_f32(
+            ctypes.c_void_p(x_pairs.data_ptr()), ctypes.c_void_p(x_absmax.data_ptr()), ptr(packed),
+            ptr(_f32c(scale)) if scale is not None else None, ptr(_f32c(shift)) if shift is not None else None,
+            ptr(_f32c(residual)) if residual is not None else None, int(bool(relu)), B, cin, D, H, W,
+            ptr(out), ctypes.c_void_p(out_absmax.data_ptr()) if out_absmax is not None else None, stream()),
+            "mvs_conv3d_c8h_f16x3_f32")
+    return out
+
+
 def pack_conv_weight_split(weight, stride=1):
     """(Cout, Cin, [3,] 3, 3) weight -> the bf16 hi/mid/lo A fragments of conv_split (None if the shape has no
     such kernel: stride 1 with Cin, Cout in {16, 32, 64}; 3D stride 2 with Cin in {8, 16, 32}; 2D stride 2 = the

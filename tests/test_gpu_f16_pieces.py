@@ -208,3 +208,25 @@ def test_costreg_one_call_equals_the_layer_chain(dev):
         ref = net(x).squeeze(1)
     assert torch.equal(one, one_blk) and torch.equal(one, chain)
     assert (one - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("shape,cin", [((1, 12, 20, 70), 32), ((2, 7, 9, 37), 16), ((1, 5, 30, 33), 8), ((1, 17, 6, 64), 32), ((1, 4, 4, 32), 32),
+                                       ((1, 40, 12, 31), 32)])
+def test_conv0_on_presplit_pairs_is_bit_identical(dev, shape, cin):
+    """mvs_conv3d_c8h_f16x3_f32 (the volume arrives as scaled fp16 pairs, MVS_LAYOUT_C8H: no staging buffer, no split pass) returns
+    the bits of mvs_conv3d_c8_f16x3_f32 on the fp32 volume under the same absmax block: odd and even widths, single-tile groups
+    (the 18-slot ring's worst case), batch 2, all channel counts, affine + ReLU + skip add."""
+    from mvs_amd import ops
+    B, D, H, W = shape
+    g = torch.Generator().manual_seed(D * 7 + W)
+    x = ((torch.randn(B, D, H, cin // 8, W, 8, generator=g) * torch.rand(B, D, H, cin // 8, W, 8, generator=g) ** 4).square()).to(dev)
+    w = (torch.randn(8, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5).to(dev)
+    sc, sh = (torch.rand(8, generator=g) + 0.5).to(dev), (torch.randn(8, generator=g) * 0.1).to(dev)
+    r = torch.randn(B, D, H, W, 8, generator=g).to(dev)
+    pf = ops.pack_conv3d_weight_f16x3(w)
+    blk = ops.absmax(x)
+    a = ops.conv3d_c8_f16x3(x, pf, blk, sc, sh, r, True)
+    om = ops.absmax_block(dev, zero=True)
+    b = ops.conv3d_c8h_f16x3(ops.c8_to_c8h(x, blk), (B, cin, D, H, W), pf, blk, sc, sh, r, True, out_absmax=om)
+    assert torch.equal(a, b)
+    assert ops.absmax_value(om) == b.abs().max().item()
