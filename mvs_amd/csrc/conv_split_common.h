@@ -88,11 +88,11 @@ __device__ __forceinline__ void split3_block(f32x4 &a, f32x4 &b, bf16x8 &h, bf16
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// scale = 2^(14 - e), e = exponent of the largest magnitude (clamped: an all-zero or non-finite input keeps the
-// arithmetic defined)
+// scale = 2^(14 - e), e = exponent of the largest magnitude (clamped below: an all-zero input keeps the arithmetic defined;
+// every finite fp32 maximum is covered: 2^127 * 2^(14 - 127) < 2^15)
 __device__ __host__ __forceinline__ int absmax_exponent(unsigned bits) {
     int e = (int)((bits >> 23) & 255u) - 127;
-    return e < -100 ? -100 : (e > 100 ? 100 : e);
+    return e < -100 ? -100 : (e > 127 ? 127 : e);
 }
 __device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float, (unsigned)(e + 127) << 23); }
 

@@ -117,9 +117,14 @@ class FeatureNet(nn.Module):
         channels-last (module.py:343-405; the nearest x2 upsample + lateral add ride in the 1x1 kernels)."""
         P = self._hip_params()
 
-        def run(x, p, planar=False, coarse=None):
+        # the 3x3 / 5x5 layers between the head and the top of the pyramid chain their absmax blocks (ops.conv2d): a layer on a
+        # two-piece fp16 kernel scales its input by what the layer in front of it left
+        nchain = 1 + len(P["conv1"]) + len(P["conv2"])
+        blocks = ops.absmax_block(imgs_nchw.device, zero=True, n=nchain) if ops.split_f16_enabled() else None
+
+        def run(x, p, planar=False, coarse=None, xa=None, oa=None):
             return ops.conv2d(x, p["packed"], p["cin"], p["cout"], p["k"], p["stride"], p["scale"], p["shift"],
-                              p["relu"], planar=planar, coarse=coarse)
+                              p["relu"], planar=planar, coarse=coarse, x_absmax=xa, out_absmax=oa)
 
         def lateral(top, x, p):   # F.interpolate(top, x2, nearest) + inner(x)  (module.py:392,396)
             if top.shape[1] * 2 == x.shape[1] and top.shape[2] * 2 == x.shape[2]:
@@ -133,15 +138,17 @@ class FeatureNet(nn.Module):
             if "head" not in h1:
                 h1["head"] = ops.pack_feature_head_weight(h1["weight"])
             c0 = ops.feature_head(imgs_nchw, h0["weight"], h0["scale"], h0["shift"], h1["head"], h1["scale"],
-                                  h1["shift"])      # the two 3x3 layers of conv0 in one kernel
+                                  h1["shift"], out_absmax=blocks[0] if blocks is not None else None)      # the two 3x3 layers of conv0 in one kernel
         else:
-            c0 = run(run(imgs_nchw, h0, planar=True), h1)
-        c1 = c0
+            c0 = run(run(imgs_nchw, h0, planar=True), h1, oa=blocks[0] if blocks is not None else None)
+        c1, bi = c0, 0
         for p in P["conv1"]:
-            c1 = run(c1, p)
+            c1 = run(c1, p, xa=blocks[bi] if blocks is not None else None, oa=blocks[bi + 1] if blocks is not None else None)
+            bi += 1
         top = c1
         for p in P["conv2"]:
-            top = run(top, p)
+            top = run(top, p, xa=blocks[bi] if blocks is not None else None, oa=blocks[bi + 1] if blocks is not None else None)
+            bi += 1
         out = {"stage1": run(top, P["out1"])}
         top = lateral(top, c1, P["inner1"])
         out["stage2"] = run(top, P["out2"])

@@ -75,8 +75,12 @@ class FeaturePyramid(nn.Module):
         P = self._hip_params()
 
         def cnn(x):
+            # a layer on a two-piece fp16 kernel scales its input by the absmax block the layer in front of it left (ops.conv2d)
+            blocks = ops.absmax_block(x.device, zero=True, n=len(P)) if ops.split_f16_enabled() else None
             for i, p in enumerate(P):
-                x = ops.conv2d(x, p["packed"], p["cin"], p["cout"], 3, 1, None, p["shift"], 2, planar=(i == 0))
+                x = ops.conv2d(x, p["packed"], p["cin"], p["cout"], 3, 1, None, p["shift"], 2, planar=(i == 0),
+                               x_absmax=blocks[i - 1] if (blocks is not None and i > 0) else None,
+                               out_absmax=blocks[i] if (blocks is not None and i + 1 < len(P)) else None)
             return x
 
         out = [cnn(img)]
@@ -153,20 +157,24 @@ class CostRegNet(nn.Module):
         self._hip_cache = (key, P)
         return P
 
-    def forward_hip(self, x_cl):
-        """x_cl [B,D,H,W,16] channels-last -> cost [B,D,H,W]."""
+    def forward_hip(self, x_cl, x_absmax=None):
+        """x_cl [B,D,H,W,16] channels-last -> cost [B,D,H,W].  x_absmax: the absmax block of x_cl from the variance op -- the
+        layers then run on the two-piece fp16 kernels, each scaling its input by the block the layer in front of it left."""
         P = self._hip_params()
+        f16 = x_absmax is not None and ops.split_f16_enabled()
+        blocks = ops.absmax_block(x_cl.device, zero=True, n=9) if f16 else None
+        blk = (lambda i: blocks[i]) if f16 else (lambda i: None)
 
-        def run(name, t, skip=None, relu=True):
+        def run(name, t, skip=None, relu=True, xa=None, oa=None):
             p = P[name]
             return ops.conv3d(t, p["weight"], p["scale"], p["shift"], skip, relu, p["transposed"], p["stride"],
-                              channels_last=True, packed=p["packed"])
+                              channels_last=True, packed=p["packed"], x_absmax=xa, out_absmax=oa)
 
-        c0 = run("conv0a", run("conv0", x_cl))
-        c2 = run("conv2a", run("conv2", run("conv1", c0)))
-        c4 = run("conv4a", run("conv4", run("conv3", c2)))
-        c5 = run("conv5", c4, c2)
-        c6 = run("conv6", c5, c0)
+        c0 = run("conv0a", run("conv0", x_cl, xa=x_absmax if f16 else None, oa=blk(0)), xa=blk(0), oa=blk(1))
+        c2 = run("conv2a", run("conv2", run("conv1", c0, xa=blk(1), oa=blk(2)), xa=blk(2), oa=blk(3)), xa=blk(3), oa=blk(4))
+        c4 = run("conv4a", run("conv4", run("conv3", c2, xa=blk(4), oa=blk(5)), xa=blk(5), oa=blk(6)), xa=blk(6), oa=blk(7))
+        c5 = run("conv5", c4, c2, xa=blk(7), oa=blk(8))
+        c6 = run("conv6", c5, c0, xa=blk(8))
         return run("prob0", c6, None, relu=False).squeeze(-1)
 
 
@@ -285,8 +293,9 @@ class CVPMVSNet(nn.Module):
         rts = ops.rot_trans_all(proj, where, device=dev)
         f = torch.stack(feats_cl)                                   # [V,B,H,W,16] = [V,B,1,H,W,16] blocked
         f16 = f.reshape(f.shape[0], B, 1, f.shape[2], f.shape[3], 16).contiguous()
-        var = ops.costvol_variance_c16(f16[0], f16[1:], rts, hypos, alias_quirk=True)   # [B,D,H,W,16]
-        return self.cost_reg_refine.forward_hip(var)
+        amax = ops.absmax_block(dev) if ops.split_f16_enabled() else None                # the regulariser's first operand scale
+        var = ops.costvol_variance_c16(f16[0], f16[1:], rts, hypos, alias_quirk=True, absmax_out=amax)   # [B,D,H,W,16]
+        return self.cost_reg_refine.forward_hip(var, amax)
 
     def forward(self, ref_img, src_imgs, ref_in, src_in, ref_ex, src_ex, depth_min, depth_max):
         if self.training:
