@@ -256,6 +256,7 @@ int mvs_conv3d_c8h_f16x3_f32(const void *in_pairs, const void *in_absmax, const 
  * [B,D,H,W,Cin] convolved plane by plane (pass D = number of images, B = 1).  weight: PyTorch layout
  * (Cout, Cin, [kd,] 3, 3); relu: 0 none, 1 ReLU, 2 LeakyReLU(0.1); scale / shift / residual as mvs_conv3d_f32;
  * out_c4 = 1: the output is written as 4-channel blocks [B*D, Cout/4, H, W, 4] (MVS_LAYOUT_C4; no residual).
+ * Also kd = 3, stride 1, (Cin, Cout) = (8, 32): the input gradient of a 32 -> 8 layer (conv0) in training.
  * stride = 2 with kd = 3 (Cin in {8, 16, 32}: CostRegNet conv1 / conv3 / conv5, mvsnet.py:67-71): output
  * [B, (D-1)/2+1, (H-1)/2+1, (W-1)/2+1, Cout].  stride = 2 with kd = 1 is FeatureNet's 5x5, pad-2 form
  * (mvsnet.py:13,16 `ConvBnReLU(8, 16, 5, 2, 2)`, `ConvBnReLU(16, 32, 5, 2, 2)`; CasMVSNet/models/module.py:323,329):

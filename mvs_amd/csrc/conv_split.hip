@@ -571,6 +571,7 @@ extern "C" int mvs_conv_split_supported(int kd, int Cin, int Cout, int stride) {
     const bool cout_ok = Cout == 16 || Cout == 32 || Cout == 64;
     if (stride == 2 && kd == 1) return (Cin == 8 && Cout == 16) || (Cin == 16 && Cout == 32);   // FeatureNet's 5x5 layers
     if (stride == 2) return kd == 3 && cout_ok && (Cin == 8 || Cin == 16 || Cin == 32);     // conv1, conv3, conv5
+    if (stride == 1 && kd == 3 && Cin == 8) return Cout == 32;      // the input gradient of a 32 -> 8 layer (conv0) in training
     return stride == 1 && (kd == 1 || kd == 3) && (Cin == 16 || Cin == 32 || Cin == 64) && cout_ok;
 }
 
@@ -660,6 +661,7 @@ static int conv_split_impl(const float *in, const void *in_absmax, const void *p
         int rc = MVS_EUNSUPPORTED;
 #define MVS_SPLIT_CASE(CI, CO, KD) if (stride == 1 && Cin == CI && step == CO && kd == KD) \
         rc = np == 2 ? launch_split<SplitCfg<CI, CO, KD, 1, 3, 2>>(a, st) : launch_split<SplitCfg<CI, CO, KD>>(a, st);
+        MVS_SPLIT_CASE(8, 32, 3)
         MVS_SPLIT_CASE(16, 16, 3) MVS_SPLIT_CASE(32, 16, 3) MVS_SPLIT_CASE(64, 16, 3)
         MVS_SPLIT_CASE(16, 32, 3) MVS_SPLIT_CASE(32, 32, 3) MVS_SPLIT_CASE(64, 32, 3)
         MVS_SPLIT_CASE(16, 16, 1) MVS_SPLIT_CASE(32, 16, 1) MVS_SPLIT_CASE(64, 16, 1)

@@ -1230,15 +1230,17 @@ class _VarianceConv0(torch.autograd.Function):
         ref16, srcs16, depth_values = _f32c(ref16), _f32c(srcs16), _f32c(depth_values)
         if _depth_mode(depth_values) != 0:
             raise MvsHipError("the fused variance -> conv0 training op takes [B,D] depth planes")
+        f16 = conv0_f16_enabled()      # conv0 on the two-piece fp16 kernel: its operand scale rides out of the sweep kernel
+        amax = absmax_block(ref16.device) if f16 else None
         with stage("train.variance.fwd"):
-            var = costvol_variance_c16(ref16, srcs16, rts, depth_values, align_corners, out_c8=True)
+            var = costvol_variance_c16(ref16, srcs16, rts, depth_values, align_corners, out_c8=True, absmax_out=amax)
         w = weight.detach().contiguous()
-        pks = pack_conv3d_weight_split(w)
+        pks = pack_conv3d_weight_f16x3(w) if f16 else pack_conv3d_weight_split(w)
         if pks is None:
             raise MvsHipError(f"no split-operand conv0 kernel for a {tuple(w.shape)} weight")
         split_stage_names.add("train.conv0.fwd")
         with stage("train.conv0.fwd"):
-            out = conv3d_c8_split(var, pks, None, None, None, False)
+            out = conv3d_c8_f16x3(var, pks, amax) if f16 else conv3d_c8_split(var, pks, None, None, None, False)
         ctx.save_for_backward(ref16, srcs16, rts, depth_values, var, weight)
         ctx.ac = int(align_corners)
         return out
@@ -1255,8 +1257,10 @@ class _VarianceConv0(torch.autograd.Function):
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             wt = w.flip(2, 3, 4).permute(1, 0, 2, 3, 4).contiguous()      # (32, 8, k) as a conv weight
             pk = pack_conv3d_weight(wt, False, 1, split=True)
-            with stage("train.conv0.dgrad"):
-                gvar = conv3d(g, wt, channels_last=True, packed=pk)        # [B,D,H,W,32]
+            with stage("train.conv0.dgrad"):     # (8 -> 32 on the split-operand kernel: two pieces when the pack has them, scale = max |g|)
+                gvar = conv3d(g, wt, channels_last=True, packed=pk, x_absmax=absmax(g) if f16_companion(pk) is not None else None)   # [B,D,H,W,32]
+            if split_companion(pk) is not None:
+                split_stage_names.add("train.conv0.dgrad")
             B, G, H, W, _ = ref16.shape
             V, D = srcs16.shape[0] + 1, depth_values.shape[1]
             g_ref, g_src = torch.empty_like(ref16), torch.empty_like(srcs16)

@@ -79,6 +79,7 @@ def test_conv3d_f16x3_scale_follows_the_producer_block(dev):
 @pytest.mark.parametrize("kd,cin,cout,shape,k,stride,relu", [
     (3, 16, 16, (1, 5, 9, 21), 3, 1, 1), (3, 32, 32, (2, 6, 7, 33), 3, 1, 1), (3, 64, 64, (1, 4, 10, 18), 3, 1, 0),
     (3, 16, 32, (1, 9, 17, 40), 3, 1, 1), (3, 64, 32, (1, 3, 5, 16), 3, 1, 0), (3, 8, 16, (1, 9, 20, 37), 3, 2, 1),
+    (3, 8, 32, (2, 6, 9, 35), 3, 1, 0),
     (3, 16, 32, (1, 8, 11, 35), 3, 2, 1), (3, 32, 64, (1, 6, 9, 18), 3, 2, 1),
     (1, 16, 16, (3, 21, 45), 3, 1, 2), (1, 32, 32, (2, 40, 70), 3, 1, 1), (1, 64, 64, (1, 18, 50), 3, 1, 2),
     (1, 8, 16, (2, 37, 70), 5, 2, 1), (1, 16, 32, (2, 37, 70), 5, 2, 1)])
