@@ -617,10 +617,12 @@ def split_f16_enabled():
     return conv_split_enabled() and os.environ.get("MVS_SPLIT_F16", "1") != "0"
 
 
-def pack_conv3d_weight(weight, transposed, stride, split=False):
+def pack_conv3d_weight(weight, transposed, stride, split=False, f16=True):
     """PyTorch-layout weight -> MFMA A-fragment order (None if the shape has no
     MFMA configuration).  split: also pack the layer for the split-operand bf16 kernel (mvs_conv_split_f32) where
-    its shape has one and MVS_CONV_SPLIT is not 0; conv3d() then runs the layer there (inference paths opt in)."""
+    its shape has one and MVS_CONV_SPLIT is not 0; conv3d() then runs the layer there (inference paths opt in).  f16: with
+    split, also the two-piece fp16 pack (taken when the caller hands conv3d the input's absmax block); the training layers,
+    whose weights are packed every step and whose inputs carry no block, pass False."""
     weight = _f32c(weight)
     cin, cout = (weight.shape[0], weight.shape[1]) if transposed else (weight.shape[1], weight.shape[0])
     n = _lib.load().mvs_conv3d_packed_weight_floats(int(transposed), cin, cout, stride)
@@ -638,12 +640,12 @@ def pack_conv3d_weight(weight, transposed, stride, split=False):
     if split and not transposed and conv_split_enabled() and want:
         sp = pack_conv_weight_split(weight, stride)
         if sp is not None:
-            _register_split(packed, sp, pack_conv_weight_split_f16(weight, stride) if split_f16_enabled() else None)
+            _register_split(packed, sp, pack_conv_weight_split_f16(weight, stride) if (f16 and split_f16_enabled()) else None)
     if split and transposed and stride == 2 and conv_split_enabled():
         sp = pack_deconv_weight_split(weight)
         if sp is not None:
             import os
-            f16d = split_f16_enabled() and os.environ.get("MVS_DECONV_F16", "1") != "0"      # (A/B switch)
+            f16d = f16 and split_f16_enabled() and os.environ.get("MVS_DECONV_F16", "1") != "0"      # (A/B switch)
             _register_split(packed, sp, pack_deconv_weight_split_f16(weight) if f16d else None)
     return packed
 
@@ -1166,7 +1168,7 @@ def conv2d_supported(cin, cout, ksize, stride):
     return bool(_lib.load().mvs_conv2d_supported(cin, cout, ksize, stride))
 
 
-def pack_conv2d_weight(weight, stride, split=False):
+def pack_conv2d_weight(weight, stride, split=False, f16=True):
     """(Cout,Cin,k,k) -> MFMA A-fragment order, or None if the layer shape has no kernel.  split: as pack_conv3d_weight."""
     weight = _f32c(weight)
     cout, cin, k, _ = weight.shape
@@ -1181,7 +1183,7 @@ def pack_conv2d_weight(weight, stride, split=False):
     if split and ((stride == 1 and k == 3) or k55) and conv_split_enabled():
         sp = pack_conv_weight_split(weight, stride)
         if sp is not None:
-            _register_split(packed, sp, pack_conv_weight_split_f16(weight, stride) if split_f16_enabled() else None)
+            _register_split(packed, sp, pack_conv_weight_split_f16(weight, stride) if (f16 and split_f16_enabled()) else None)
     return packed
 
 
