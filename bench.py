@@ -458,7 +458,10 @@ def main():
         "config": {"workload": f"MVSNet DTU {W}x{H}, N={V} views, D={D} inference (BASELINE "
                                "configs[1]); 1 reference view per step per GPU",
                    "feature_res": [h, w], "sharding": f"ref-views x{world}, no collective",
-                   "conv_impl": args.conv_impl, "proj_inverse": model.proj_where},
+                   "conv_impl": args.conv_impl, "proj_inverse": model.proj_where,
+                   "arithmetic": ("fp32 data, fp32 accumulation; convolution products on the 16-bit matrix pipe from fp32 operands split into "
+                                  + ("two scaled fp16 pieces (three exact products)" if ops.split_f16_enabled() else "three bf16 pieces (six exact products)")
+                                  + ", no operand is rounded away (DESIGN section 4)") if ops.conv_split_enabled() else "fp32 MFMA / VALU"},
         "roofline": roof,
         "stages_ms": {k: round(v, 4) for k, v in sorted(stages.items())},
         "rooflines": rooflines,
