@@ -156,6 +156,32 @@ int main(int argc, char **argv) {
     float *cost = dev_alloc((size_t)B * vol);
     MVS_OK_(mvs_costreg_fwd_f32(var8, MVS_LAYOUT_C8, layers, B, C, 8, D, H, W, 0, cr_ws, cws, cost, st));
 
+    // (3b) the same network on the two-piece fp16 kernels, as the Python host runs it by default: the sweep entry hands over the
+    // absmax block of the volume (conv0's operand scale), the layers chain theirs through the workspace
+    const void *packed_f16[11];
+    for (int i = 0; i < 11; ++i) {
+        void *pf = nullptr;
+        if (i == 0) {
+            HIP_OK(hipMalloc(&pf, mvs_conv3d_f16x3_packed_bytes(cin[0])));
+            MVS_OK_(mvs_conv3d_pack_weights_f16x3_f32(layers[0].weight, cin[0], pf, st));
+        } else if (!transposed[i] && mvs_conv_split_supported(3, cin[i], cout[i], stride[i]) && (stride[i] == 1 || cin[i] == 8)) {
+            HIP_OK(hipMalloc(&pf, mvs_conv_split_f16_packed_bytes(3, cin[i], cout[i], stride[i])));
+            MVS_OK_(mvs_conv_split_pack_weights_f16_f32(layers[i].weight, 3, cin[i], cout[i], stride[i], pf, st));
+        } else if (transposed[i] && mvs_deconv_split_supported(cin[i], cout[i])) {
+            HIP_OK(hipMalloc(&pf, mvs_deconv_split_f16_packed_bytes(cin[i], cout[i])));
+            MVS_OK_(mvs_deconv_split_pack_weights_f16_f32(layers[i].weight, cin[i], cout[i], pf, st));
+        }
+        packed_f16[i] = pf;
+    }
+    void *amax;
+    HIP_OK(hipMalloc(&amax, MVS_ABSMAX_WORDS * 4));
+    float *var8b = dev_alloc((size_t)B * C * vol), *cost2 = dev_alloc((size_t)B * vol);
+    MVS_OK_(mvs_costvol_variance_fwd_ws2_f32(f16, f16 + fmap, rt, dv, 0, B, V, C, D, H, W, 0, 0, MVS_LAYOUT_C16,
+                                             MVS_LAYOUT_C8, 0, var8b, var_ws, vws, amax, st));
+    MVS_OK_(mvs_costreg_fwd2_f32(var8b, MVS_LAYOUT_C8, layers, packed_f16, B, C, 8, D, H, W, 0, cr_ws, cws, amax, cost2, st));
+    float *depth2 = dev_alloc((size_t)B * plane), *conf2 = dev_alloc((size_t)B * plane);
+    MVS_OK_(mvs_softmax_regress_conf_f32(cost2, dv, 0, 0, B, D, H, W, depth2, conf2, nullptr, st));
+
     // (4) softmax + depth regression + photometric confidence
     float *depth = dev_alloc((size_t)B * plane), *conf = dev_alloc((size_t)B * plane);
     MVS_OK_(mvs_softmax_regress_conf_f32(cost, dv, 0, 0, B, D, H, W, depth, conf, nullptr, st));
@@ -166,10 +192,15 @@ int main(int argc, char **argv) {
     const double e_cost = maxabs(to_host(cost, (size_t)B * vol), d.get("cost"));
     const double e_depth = maxabs(to_host(depth, (size_t)B * plane), d.get("depth"));
     const double e_conf = maxabs(to_host(conf, (size_t)B * plane), d.get("confidence"));
-    const bool ok = e_warp < 1e-6 && e_var < 1e-6 && e_depth < 1e-3 && e_conf < 1e-3;
+    const double e_cost2 = maxabs(to_host(cost2, (size_t)B * vol), d.get("cost"));
+    const double e_depth2 = maxabs(to_host(depth2, (size_t)B * plane), d.get("depth"));
+    const double e_conf2 = maxabs(to_host(conf2, (size_t)B * plane), d.get("confidence"));
+    const bool ok = e_warp < 1e-6 && e_var < 1e-6 && e_depth < 1e-3 && e_conf < 1e-3 && e_depth2 < 1e-3 && e_conf2 < 1e-3;
     std::printf("{\"version\": %d, \"arch\": \"%s\", \"warp_maxabs\": %.3g, \"variance_maxabs\": %.3g, \"cost_maxabs\": %.3g, "
-                "\"depth_maxabs_mm\": %.3g, \"confidence_maxabs\": %.3g, \"variance_workspace_bytes\": %zu, "
+                "\"depth_maxabs_mm\": %.3g, \"confidence_maxabs\": %.3g, \"two_piece_cost_maxabs\": %.3g, "
+                "\"two_piece_depth_maxabs_mm\": %.3g, \"two_piece_confidence_maxabs\": %.3g, \"variance_workspace_bytes\": %zu, "
                 "\"costreg_workspace_bytes\": %zu, \"ok\": %s}\n",
-                mvs_version(), mvs_arch(), e_warp, e_var, e_cost, e_depth, e_conf, vws, cws, ok ? "true" : "false");
+                mvs_version(), mvs_arch(), e_warp, e_var, e_cost, e_depth, e_conf, e_cost2, e_depth2, e_conf2, vws, cws,
+                ok ? "true" : "false");
     return ok ? 0 : 1;
 }

@@ -67,4 +67,6 @@ def test_cpp_caller_matches_reference_outputs(tmp_path, weights):
     assert res["ok"] and res["arch"] == "gfx950"
     assert res["warp_maxabs"] < 1e-6 and res["variance_maxabs"] < 1e-6
     assert res["depth_maxabs_mm"] < 1e-3 and res["confidence_maxabs"] < 2e-4
+    # the two-piece fp16 chain through mvs_costvol_variance_fwd_ws2_f32 -> mvs_costreg_fwd2_f32 (absmax blocks), same gate
+    assert res["two_piece_depth_maxabs_mm"] < 1e-3 and res["two_piece_confidence_maxabs"] < 2e-4
     assert res["variance_workspace_bytes"] > 0 and res["costreg_workspace_bytes"] > 0
