@@ -453,6 +453,11 @@ int mvs_fusibile_fuse_f32(const float *normals_depths, const float *colors, cons
 int mvs_conv2d_f32(const float *in, const float *packed_weight, const float *scale,
                    const float *shift, const float *coarse, int relu, int B, int Cin, int Cout, int H,
                    int W, int ksize, int stride, int layout_flags, float *out, void *stream);
+/* The same, and the largest magnitude of `out` max-ed INTO the absmax block out_absmax in the kernels' epilogues (the caller
+ * clears it; NULL = none): for a layer whose output feeds a two-piece fp16 layer (mvs_conv_split_f16_f32). */
+int mvs_conv2d_absmax_f32(const float *in, const float *packed_weight, const float *scale, const float *shift,
+                          const float *coarse, int relu, int B, int Cin, int Cout, int H, int W, int ksize, int stride,
+                          int layout_flags, float *out, void *out_absmax, void *stream);
 /* FeatureNet's first two layers in one kernel: conv0 (3 -> 8, 3x3) + BN + ReLU + conv1 (8 -> 8, 3x3) + BN + ReLU
  * (MVSNet/models/mvsnet.py:11-12,33-34 `self.conv0 = ConvBnReLU(3, 8, 3, 1, 1)`, `self.conv1 = ConvBnReLU(8, 8, 3, 1, 1)`;
  * CasMVSNet/models/module.py:318-321 opens with the same pair).  conv0's 8-channel full-resolution output never

@@ -94,6 +94,7 @@ _SIGS = {
     "mvs_cvp_hypotheses_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "mvs_fusibile_fuse_f32": (_c_i, [_c_f] * 3 + [_c_i] * 4 + [ctypes.c_float, ctypes.c_float, _c_i] + [_c_f] * 4),
     "mvs_conv2d_f32": (_c_i, [_c_f] * 5 + [_c_i] * 9 + [_c_f, _c_f]),
+    "mvs_conv2d_absmax_f32": (_c_i, [_c_f] * 5 + [_c_i] * 9 + [_c_f, _c_f, _c_f]),
     "mvs_feature_head_supported": (_c_i, [_c_i] * 2),
     "mvs_fpn_tail_supported": (_c_i, [_c_i] * 2),
     "mvs_fpn_tail_packed_bytes": (ctypes.c_size_t, []),

@@ -51,6 +51,7 @@ struct Conv2Args {
     int in_planar;      // input is [B,cin_real,H,W] instead of [B,H,W,CIN]
     int tiles_x, tiles_y;
     int relu;
+    unsigned *out_absmax;   // NULL, or the absmax block (mvs_common.h) the largest magnitude stored is max-ed into
 };
 
 template <class Cfg>
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(Conv2Args a) {
         }
     }
 
+    float vmax = 0.0f;
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const int oy = oy0 + wv * RPW + r, ox = ox0 + n;
@@ -208,8 +210,10 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(Conv2Args a) {
             }
             *reinterpret_cast<float4 *>(a.out + (((int64_t)b * a.Ho + oy) * a.Wo + ox) * COUT + c0) =
                 make_float4(v[0], v[1], v[2], v[3]);
+            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         }
     }
+    publish_absmax(a.out_absmax, vmax);
 }
 
 // PyTorch (Cout,Cin,KH,KW) -> packed[ch][tap][mt][lane][s]; input channel =
@@ -375,7 +379,7 @@ int conv2d_pack_launch(const float *weight, int Cin, int Cout, int ksize, int st
 
 int conv2d_launch(const float *in, const float *packed, const float *scale, const float *shift,
                   const float *coarse, int relu, int B, int Cin, int Cout, int H, int W, int ksize, int stride,
-                  int layout_flags, float *out, hipStream_t st) {
+                  int layout_flags, float *out, hipStream_t st, unsigned *out_absmax) {
     const int in_planar = layout_flags & 1, out_c4 = (layout_flags >> 1) & 1;
     Persist2Info pi;
     const bool persistent = !in_planar && lookup_persist2(Cin, Cout, ksize, stride, pi);
@@ -402,7 +406,7 @@ int conv2d_launch(const float *in, const float *packed, const float *scale, cons
         a.tiles_x = (a.Wo + pi.xout - 1) / pi.xout;
         a.tiles_y = (a.Ho + pi.ty - 1) / pi.ty;
         a.tiles_z = B;
-        a.relu = relu; a.in_c8 = 0; a.ystrip = 4; a.out_c4 = out_c4;
+        a.relu = relu; a.in_c8 = 0; a.ystrip = 4; a.out_c4 = out_c4; a.out_absmax = out_absmax;
         const int64_t nt = (int64_t)a.tiles_x * a.tiles_y * a.tiles_z;
         if (nt <= 0 || nt > 0x7fffffffLL) return bare_error(MVS_EINVAL, __func__, __LINE__);
         const int n_cu = device_cu_count();
@@ -436,7 +440,7 @@ int conv2d_launch(const float *in, const float *packed, const float *scale, cons
     a.cin_real = Cin; a.in_planar = in_planar;
     a.tiles_x = (a.Wo + 15) / 16;
     a.tiles_y = (a.Ho + ci.ty - 1) / ci.ty;
-    a.relu = relu;
+    a.relu = relu; a.out_absmax = out_absmax;
     const int64_t nblk = (int64_t)B * a.tiles_x * a.tiles_y;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return bare_error(MVS_EINVAL, __func__, __LINE__);
     hipLaunchKernelGGL(ci.kernel, dim3((unsigned)nblk), dim3(256), 0, st, a);
@@ -467,10 +471,19 @@ extern "C" int mvs_conv2d_pack_weights_f32(const float *weight, int Cin, int Cou
 extern "C" int mvs_conv2d_f32(const float *in, const float *packed_weight, const float *scale,
                               const float *shift, const float *coarse, int relu, int B, int Cin, int Cout,
                               int H, int W, int ksize, int stride, int layout_flags, float *out, void *stream) {
+    return mvs_conv2d_absmax_f32(in, packed_weight, scale, shift, coarse, relu, B, Cin, Cout, H, W, ksize, stride, layout_flags,
+                                 out, nullptr, stream);
+}
+
+// out_absmax: NULL, or the absmax block the largest magnitude of `out` is max-ed INTO in the kernels' epilogues (the caller clears it)
+extern "C" int mvs_conv2d_absmax_f32(const float *in, const float *packed_weight, const float *scale,
+                                     const float *shift, const float *coarse, int relu, int B, int Cin, int Cout,
+                                     int H, int W, int ksize, int stride, int layout_flags, float *out, void *out_absmax,
+                                     void *stream) {
     if (!in || !packed_weight || !out || B <= 0 || H <= 0 || W <= 0) {
         set_error("mvs_conv2d_f32: invalid argument");
         return MVS_EINVAL;
     }
     return conv2d_launch(in, packed_weight, scale, shift, coarse, relu, B, Cin, Cout, H, W, ksize, stride,
-                         layout_flags, out, as_stream(stream));
+                         layout_flags, out, as_stream(stream), static_cast<unsigned *>(out_absmax));
 }

@@ -1513,11 +1513,10 @@ def conv2d(x, packed, cin, cout, ksize, stride, scale=None, shift=None, relu=Fal
         coarse = _f32c(coarse)
         if tuple(coarse.shape) != (B, Ho // 2, Wo // 2, cout) or Ho % 2 or Wo % 2:
             raise MvsHipError(f"conv2d: coarse {tuple(coarse.shape)} is not half of {(B, Ho, Wo, cout)}")
-    check(_lib.load().mvs_conv2d_f32(ptr(x), ptr(packed), ptr(scale), ptr(shift), ptr(coarse), int(relu), B, cin,
-                                     cout, H, W, ksize, stride, int(planar) | (2 if out_c4 else 0), ptr(out), stream()),
-          "mvs_conv2d_f32")
-    if out_absmax is not None:
-        absmax(out, out_absmax)
+    check(_lib.load().mvs_conv2d_absmax_f32(ptr(x), ptr(packed), ptr(scale), ptr(shift), ptr(coarse), int(relu), B, cin,
+                                            cout, H, W, ksize, stride, int(planar) | (2 if out_c4 else 0), ptr(out),
+                                            ctypes.c_void_p(out_absmax.data_ptr()) if out_absmax is not None else None, stream()),
+          "mvs_conv2d_absmax_f32")
     return out
 
 
