@@ -71,7 +71,12 @@ struct SplitCfg {
     static constexpr int T = 48 / (RPW * MT * 4) >= 2 ? 2 : 1;
     // copy waves: a stride-2 step carries 47 copies for 42 MFMAs per wave -- eight copy waves (16 waves, 128 registers)
     static constexpr int NCW = S == 2 ? 8 : 4, NTHREADS = 512 + 64 * NCW;
-    static constexpr int F_OFF = 2 * WBYTES, S_OFF = F_OFF + FBYTES, AFF_OFF = S_OFF + SBYTES;   // + scale, shift of the launch
+    // DB2: a tile is ONE step (one chunk: the weights never change, one weight buffer) and LDS has room for a second staging
+    // buffer -- the copies then run two tiles ahead and have a whole step to land.  Behind the second barrier of a step with a
+    // single buffer they had only the MFMA phase, which the two-piece form halved: the stride-2 layer conv1 (47 KiB of halo
+    // per step) waited for them every step (0.28 ms for 1.0 GB)
+    static constexpr bool DB2 = NCHUNK == 1 && NP_ == 2 && WBYTES + 2 * FBYTES + SBYTES + 2 * COUT * 4 <= 160 * 1024;
+    static constexpr int F_OFF = DB2 ? WBYTES : 2 * WBYTES, S_OFF = F_OFF + (DB2 ? 2 : 1) * FBYTES, AFF_OFF = S_OFF + SBYTES;   // + scale, shift of the launch
     static constexpr int LDS_BYTES = AFF_OFF + 2 * COUT * 4;
     static_assert(RB % 8 == 0 && LDS_BYTES <= 160 * 1024 && SPART * 2 + 16 * 1024 < 65536 && (S == 1 || KD == 1 || MT == 1) &&
                   (KH == 3 || (KH == 5 && KD == 1 && S == 2)), "tile / LDS budget");
@@ -141,9 +146,9 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_split_kernel(SplitArgs a, in
     // split pass (all waves): piece P = ps*NT + tid = (voxel P >> 1, channel half P & 1): 16 bytes of the fp32 buffer
     // -> 8 bytes of each bf16 part at the same position
     constexpr int NPS = (NPIECE + NT - 1) / NT;
-    auto split_pass = [&]() {
+    auto split_pass = [&](int par = 0) {     // par: the staging buffer of this step (DB2)
         f32x4 x[NPS];
-        const unsigned fp = lds_base + (unsigned)(F_OFF + tid * 16), sp = lds_base + (unsigned)(S_OFF + tid * 8);
+        const unsigned fp = lds_base + (unsigned)(F_OFF + par * C::FBYTES + tid * 16), sp = lds_base + (unsigned)(S_OFF + tid * 8);
         const unsigned sp1 = sp + (unsigned)SPART, sp2 = sp + (unsigned)(2 * SPART);     // (offset field: 16 bits)
         static_for<0, NPS>([&](auto pc) {
             constexpr int ps = decltype(pc)::value;
@@ -228,6 +233,34 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_split_kernel(SplitArgs a, in
                                               lds_base + (unsigned)(sel * WBYTES + g * 1024));
             }
         };
+        if constexpr (C::DB2) {
+            // tile i of this workgroup -> staging buffer i & 1; behind the second barrier of tile i: wait for the copies of tile
+            // i + 1 (issued a step ago), request tile i + 2
+            auto issue_tile = [&](int i) {
+                if (i >= ntw) return;
+                geometry(std::integral_constant<int, 0>{}, t0 + i * t_step);
+#pragma unroll
+                for (int q = 0; q < IPW; ++q) {
+                    if (q * NC + cw >= NCOPY) continue;   // wave-uniform
+                    glds16_buf(voff[0][q], srd[0], 0u, lds_base + (unsigned)(F_OFF + (i & 1) * C::FBYTES + (q * NC + cw) * 1024));
+                }
+            };
+            if (ntw > 0) {
+                issue_weights(0, 0);
+                issue_tile(0);
+                issue_tile(1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            for (int i = 0; i < ntw; ++i) {
+                __syncthreads();
+                split_pass(i & 1);
+                __syncthreads();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                issue_tile(i + 2);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
         int wsel = 0;
         if (ntw > 0) {
             geometry(std::integral_constant<int, 0>{}, t0);
@@ -343,7 +376,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_split_kernel(SplitArgs a, in
                 MVS_LAP(4);
                 __syncthreads();
                 MVS_LAP(0);
-                split_pass();
+                split_pass(C::DB2 ? ((k0 + j) & 1) : 0);
                 MVS_LAP(1);
                 __syncthreads();
                 MVS_LAP(2);
