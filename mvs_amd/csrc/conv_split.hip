@@ -71,12 +71,15 @@ struct SplitCfg {
     static constexpr int T = 48 / (RPW * MT * 4) >= 2 ? 2 : 1;
     // copy waves: a stride-2 step carries 47 copies for 42 MFMAs per wave -- eight copy waves (16 waves, 128 registers)
     static constexpr int NCW = S == 2 ? 8 : 4, NTHREADS = 512 + 64 * NCW;
-    // DB2: a tile is ONE step (one chunk: the weights never change, one weight buffer) and LDS has room for a second staging
-    // buffer -- the copies then run two tiles ahead and have a whole step to land.  Behind the second barrier of a step with a
+    // DB2 (two-piece form, where LDS has room for a second staging buffer): the copies run two STEPS ahead and have a whole step
+    // to land.  Behind the second barrier of a step with a
     // single buffer they had only the MFMA phase, which the two-piece form halved: the stride-2 layer conv1 (47 KiB of halo
     // per step) waited for them every step (0.28 ms for 1.0 GB)
-    static constexpr bool DB2 = NCHUNK == 1 && NP_ == 2 && WBYTES + 2 * FBYTES + SBYTES + 2 * COUT * 4 <= 160 * 1024;
-    static constexpr int F_OFF = DB2 ? WBYTES : 2 * WBYTES, S_OFF = F_OFF + (DB2 ? 2 : 1) * FBYTES, AFF_OFF = S_OFF + SBYTES;   // + scale, shift of the launch
+    static constexpr int NWBUF = NCHUNK == 1 ? 1 : 2;      // (one chunk per tile: the weights never change)
+    // (measured, profiles/r03_split_f16.json: conv1 0.268 -> 0.230 ms, conv4 0.081 -> 0.076, FeatureNet's 5x5 8 -> 16 layer 0.135 -> 0.120;
+    // the multi-chunk 2D layers lose 5 %: they keep the single buffer)
+    static constexpr bool DB2 = NP_ == 2 && (NCHUNK == 1 || KD_ == 3) && NWBUF * WBYTES + 2 * FBYTES + SBYTES + 2 * COUT * 4 <= 160 * 1024;
+    static constexpr int F_OFF = (DB2 ? NWBUF : 2) * WBYTES, S_OFF = F_OFF + (DB2 ? 2 : 1) * FBYTES, AFF_OFF = S_OFF + SBYTES;   // + scale, shift of the launch
     static constexpr int LDS_BYTES = AFF_OFF + 2 * COUT * 4;
     static_assert(RB % 8 == 0 && LDS_BYTES <= 160 * 1024 && SPART * 2 + 16 * 1024 < 65536 && (S == 1 || KD == 1 || MT == 1) &&
                   (KH == 3 || (KH == 5 && KD == 1 && S == 2)), "tile / LDS budget");
@@ -234,29 +237,62 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_split_kernel(SplitArgs a, in
             }
         };
         if constexpr (C::DB2) {
-            // tile i of this workgroup -> staging buffer i & 1; behind the second barrier of tile i: wait for the copies of tile
-            // i + 1 (issued a step ago), request tile i + 2
-            auto issue_tile = [&](int i) {
-                if (i >= ntw) return;
-                geometry(std::integral_constant<int, 0>{}, t0 + i * t_step);
+            // step s of this workgroup -> staging buffer s & 1; behind the second barrier of step s: wait for the copies of step
+            // s + 1 (issued a step ago), request step s + 2.  The issue iterator walks (group, chunk, tile) like the consumers.
+            int it_k0 = 0, it_ch = 0, it_j = 0, it_par = 0;
+            bool it_done = ntw <= 0;
+            auto it_issue = [&]() {
+                if (it_done) return;
+                // (a tile's offsets are computed with its first chunk and kept for the others: slot = tile of the group)
+                static_for<0, T>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    if (it_j != j) return;   // wave-uniform
+                    if (it_ch == 0) geometry(jc, t0 + (it_k0 + j) * t_step);
+                    const unsigned soff = (unsigned)(it_ch * 32 * C::CPS);
 #pragma unroll
-                for (int q = 0; q < IPW; ++q) {
-                    if (q * NC + cw >= NCOPY) continue;   // wave-uniform
-                    glds16_buf(voff[0][q], srd[0], 0u, lds_base + (unsigned)(F_OFF + (i & 1) * C::FBYTES + (q * NC + cw) * 1024));
+                    for (int q = 0; q < IPW; ++q) {
+                        if (q * NC + cw >= NCOPY) continue;   // wave-uniform
+                        glds16_buf(voff[j][q], srd[j], soff, lds_base + (unsigned)(F_OFF + it_par * C::FBYTES + (q * NC + cw) * 1024));
+                    }
+                });
+                it_par ^= 1;
+                if (++it_j >= min(T, ntw - it_k0)) {
+                    it_j = 0;
+                    if (++it_ch >= NCHUNK) {
+                        it_ch = 0;
+                        it_k0 += T;
+                        if (it_k0 >= ntw) it_done = true;
+                    }
                 }
             };
+            int wsel = 0, par = 0;
             if (ntw > 0) {
                 issue_weights(0, 0);
-                issue_tile(0);
-                issue_tile(1);
+                it_issue();
+                it_issue();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            for (int i = 0; i < ntw; ++i) {
-                __syncthreads();
-                split_pass(i & 1);
-                __syncthreads();
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                issue_tile(i + 2);
+            for (int k0 = 0; k0 < ntw; k0 += T) {
+                const int nvalid = min(T, ntw - k0);
+#pragma unroll 1
+                for (int ch = 0; ch < NCHUNK; ++ch) {
+                    // the weights of the next chunk (of this group, or chunk 0 of the next) go out behind this chunk's first step, when
+                    // the buffer of the previous chunk is free; a single-tile group needs them by its very next step
+                    const bool more = NCHUNK > 1 && (ch + 1 < NCHUNK || k0 + T < ntw);
+                    const int nch = ch + 1 < NCHUNK ? ch + 1 : 0;
+#pragma unroll 1
+                    for (int j = 0; j < nvalid; ++j) {
+                        __syncthreads();
+                        split_pass(par);
+                        __syncthreads();
+                        par ^= 1;
+                        if (more && j == 0 && nvalid == 1) issue_weights(nch, wsel ^ 1);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (more && j == 0 && nvalid > 1) issue_weights(nch, wsel ^ 1);
+                        it_issue();
+                    }
+                    if (NCHUNK > 1) wsel ^= 1;
+                }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             return;
@@ -365,7 +401,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_split_kernel(SplitArgs a, in
     long long tprev = 0;
     if constexpr (LAPS) tprev = clock64();
 #define MVS_LAP(k) do { if constexpr (LAPS) { const long long tn = clock64(); tsum[k] += tn - tprev; tprev = tn; } } while (0)
-    int wsel = 0;
+    int wsel = 0, spar = 0;     // spar: staging buffer of the step (DB2)
     for (int k0 = 0; k0 < ntw; k0 += T) {
         const int nvalid = min(T, ntw - k0);
 #pragma unroll 1
@@ -376,7 +412,8 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_split_kernel(SplitArgs a, in
                 MVS_LAP(4);
                 __syncthreads();
                 MVS_LAP(0);
-                split_pass(C::DB2 ? ((k0 + j) & 1) : 0);
+                split_pass(C::DB2 ? spar : 0);
+                spar ^= 1;
                 MVS_LAP(1);
                 __syncthreads();
                 MVS_LAP(2);
