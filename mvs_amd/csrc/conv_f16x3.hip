@@ -85,8 +85,10 @@ __global__ __launch_bounds__(kFThreads) void conv3d_c8_f16x3_zs_kernel(ConvArgs 
 
     // the split pass: staging piece P (row = P / 68 = zl * 6 + y, q = P % 68 -> voxel x = q / 2, channel half q & 1)
     // -> 8 bytes of each part at slot((zl + first slot of the step) mod 6) + (y * 17 + x / 2 (+ kFOddBase for odd x)) * 16
-    // + half * 8.  Thread order rotated so that the copy waves -- idle between the two barriers -- own the ragged tail.
-    const int tidr = tid < 512 ? tid + 256 : tid - 512;
+    // + half * 8.  The ragged tail (96 of 1632 pieces: a third round for two waves) goes to the two OLDEST waves: they win the issue
+    // arbitration during the pass, so the round costs the workgroup least there (given to the copy waves -- the youngest -- as in
+    // the bf16 kernel, every other wave waited ~400 cycles for them at the second barrier: 3493 -> 3391 cycles per step).
+    const int tidr = tid;
     constexpr int NPS = (NPIECE0 + NT - 1) / NT;
     unsigned spos[NPS];          // in-slot byte position | zl << 16
 #pragma unroll
