@@ -10,7 +10,7 @@
 // its own accumulation (1.26e-7) -- the fp32 accumulation of the matrix pipe, the same in both split forms, is what
 // sets this kernel's distance from the float64 answer, not the operands (tests: test_conv3d_f16x3_*; full-size error
 // budget in DESIGN section 2).  What the two-piece form needs and the three-piece bf16 form does not is RANGE: fp16
-// has 5 exponent bits.  The caller passes the largest magnitude of the input (a device word, written by the kernel
+// has 5 exponent bits.  The caller passes the largest magnitude of the input (an absmax block, mvs_common.h, filled by the kernel
 // that produced the volume: mvs_costvol_variance_fwd_ws_f32, or by mvs_absmax_f32) and the kernel scales by
 // s = 2^(14 - exponent(max)); the weights are scaled the same way when they are packed.  An element below 2^-18 of
 // the maximum has its lo piece in fp16's subnormals: its absolute error stays below 2^-40 of the maximum.

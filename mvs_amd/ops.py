@@ -736,7 +736,7 @@ def absmax(x, out=None):
 
 def conv3d_c8_f16x3(x_c8, packed, x_absmax=None, scale=None, shift=None, residual=None, relu=False, out_absmax=None):
     """conv0-class layer (3x3x3, Cout 8, stride 1) on the fp16 matrix pipe with two-piece operands, three products
-    (mvs_conv3d_c8_f16x3_f32): x_c8 [B,D,H,Cin/8,W,8] -> [B,D,H,W,8].  x_absmax: the one-word tensor the producer of
+    (mvs_conv3d_c8_f16x3_f32): x_c8 [B,D,H,Cin/8,W,8] -> [B,D,H,W,8].  x_absmax: the absmax block (absmax_block()) the producer of
     x_c8 filled (None: computed here by one more pass over x_c8)."""
     x_c8 = _f32c(x_c8)
     B, D, H, G, W, _ = x_c8.shape
@@ -816,7 +816,7 @@ def pack_conv_weight_split_f16(weight, stride=1):
 def conv_split_f16(x_cl, packed_f16, cout, x_absmax=None, scale=None, shift=None, residual=None, relu=1, kd=3, out_c4=False,
                    stride=1, out_absmax=None, soft=False):
     """conv_split on the fp16 matrix pipe with two-piece operands (three products; mvs_conv_split_f16_f32).  x_absmax: the
-    one-word tensor the producer of x_cl filled (None: one more pass over x_cl); out_absmax: one-word tensor that receives
+    absmax block the producer of x_cl filled (None: one more pass over x_cl); out_absmax: ZEROED absmax block that receives
     the largest magnitude of the result (for the next two-piece layer)."""
     x_cl = _f32c(x_cl)
     if x_absmax is None:
