@@ -231,3 +231,36 @@ def test_conv0_on_presplit_pairs_is_bit_identical(dev, shape, cin):
     b = ops.conv3d_c8h_f16x3(ops.c8_to_c8h(x, blk), (B, cin, D, H, W), pf, blk, sc, sh, r, True, out_absmax=om)
     assert torch.equal(a, b)
     assert ops.absmax_value(om) == b.abs().max().item()
+
+
+@pytest.mark.parametrize("env", [{"MVS_CONV0_F16": "0"}, {"MVS_SPLIT_F16": "0"}, {"MVS_CONV_SPLIT": "0"}])
+def test_arithmetic_switches_stay_within_the_gate(env):
+    """The A/B switches of the convolution arithmetic (three-piece bf16 conv0; three-piece bf16 everywhere; fp32 MFMA kernels)
+    run the same network: an MVSNet eval forward under each differs from the default build's by far less than the 1e-3 mm gate
+    (own process: the switches are read when the weights are packed)."""
+    import os, subprocess, sys
+    code = r'''
+import sys, numpy as np, torch
+from mvs_amd import synth
+from mvs_amd.models import MVSNet
+dev = torch.device("cuda:0")
+H, W, V, D = 128, 160, 3, 16
+rng = np.random.default_rng(3)
+model = MVSNet(refine=False); model.load_state_dict(synth.random_state_dict(2)); model = model.to(dev).eval()
+g = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+with torch.no_grad():
+    out = model(g(synth.images(rng, 1, V, H, W)), g(synth.proj_matrices(V, H // 4, W // 4)),
+                g(synth.depth_values(D, interval=synth.sweep_interval(D))))
+np.save(sys.argv[1], out["depth"].cpu().numpy())
+'''
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        outs = []
+        for e in ({}, env):
+            f = os.path.join(tmp, "d%d.npy" % len(outs))
+            r = subprocess.run([sys.executable, "-c", code, f], env={**os.environ, **e}, capture_output=True, text=True, cwd=root)
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+            outs.append(np.load(f))
+    assert np.isfinite(outs[1]).all()
+    assert np.abs(outs[0] - outs[1]).max() < 5e-4, np.abs(outs[0] - outs[1]).max()
