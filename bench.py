@@ -83,6 +83,47 @@ def algorithmic_work(V, C, D, h, w):
     return work
 
 
+def arithmetic_note():
+    """What the convolution layers multiply with (the A/B switches MVS_CONV_SPLIT / MVS_CONV0_F16 / MVS_SPLIT_F16 are read by
+    mvs_amd.ops).  The two-piece form is NOT exact: its bound is the one mvs_amd/csrc/conv_f16x3.hip states."""
+    if not ops.conv_split_enabled():
+        return "fp32 data, fp32 accumulation, fp32 MFMA / VALU products"
+    three = "three bf16 pieces per fp32 operand, six products: every operand exact (8+8+8 significand bits), products exact in the fp32 accumulator"
+    two = ("two fp16 pieces of the operand scaled by one power of two per tensor, three products: the operand is carried to 2^-23 "
+           "relative (one unit in fp32's last place; NOT exact) and al*bl is dropped, so a product is within 2^-22 relative of the fp32 "
+           "product for operands within 2^-18 of their tensor's largest magnitude and within 2^-40 of that magnitude absolute below; a "
+           "device-side guard sends a launch whose input is non-finite or outlier-dominated to plain fp32 (mvs_amd/csrc/conv_guard.h)")
+    c0, rest = ops.conv0_f16_enabled(), ops.split_f16_enabled()
+    if c0 and rest:
+        body = two
+    elif not c0 and not rest:
+        body = three
+    else:
+        body = f"conv0: {'two-piece fp16' if c0 else 'three-piece bf16'}, the other split-operand layers: {'two-piece fp16' if rest else 'three-piece bf16'} ({two}; {three})"
+    return "fp32 data in HBM, fp32 accumulation; convolution products on the 16-bit matrix pipe: " + body
+
+
+def child_bench(extra_args, env_overrides, timeout=900):
+    """Run this script once more in a child process (its own env switches) and return its JSON line, or {'error': ...}."""
+    import subprocess
+    env = dict(os.environ)
+    env.update(env_overrides)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-extras"] + extra_args
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": f"timeout after {timeout} s"}
+    for ln in reversed(r.stdout.strip().splitlines()):
+        if ln.startswith("{"):
+            try:
+                return json.loads(ln)
+            except ValueError:
+                break
+    return {"error": f"rc {r.returncode}: {(r.stderr or r.stdout)[-400:]}"}
+
+
 def pmc_traffic():
     """HBM-side bytes per launch measured with rocprofv3 PMC passes of this same
     command (profiles/pmc_traffic.json, written from scripts/profile_round.sh)."""
@@ -327,6 +368,10 @@ def main():
     ap.add_argument("--views", type=int, default=5)
     ap.add_argument("--ndepth", type=int, default=192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="infer mode, one GPU: skip the two child runs the default line carries -- `value_exact_operands` (the same "
+                         "forward with every split-operand layer on the exact three-piece bf16 kernels, MVS_CONV0_F16=0 "
+                         "MVS_SPLIT_F16=0) and `train` (BASELINE configs[4], one HIP graph replay per step)")
     ap.add_argument("--cpu-protocol", action="store_true",
                     help="cpu_baseline by BASELINE.md section 4 in full: 1 warm-up + 3 timed forwards on all host "
                          "cores plus one 1-thread forward (minutes of CPU time; default: a bounded sample)")
@@ -459,9 +504,7 @@ def main():
                                "configs[1]); 1 reference view per step per GPU",
                    "feature_res": [h, w], "sharding": f"ref-views x{world}, no collective",
                    "conv_impl": args.conv_impl, "proj_inverse": model.proj_where,
-                   "arithmetic": ("fp32 data, fp32 accumulation; convolution products on the 16-bit matrix pipe from fp32 operands split into "
-                                  + ("two scaled fp16 pieces (three exact products)" if ops.split_f16_enabled() else "three bf16 pieces (six exact products)")
-                                  + ", no operand is rounded away (DESIGN section 4)") if ops.conv_split_enabled() else "fp32 MFMA / VALU"},
+                   "arithmetic": arithmetic_note()},
         "roofline": roof,
         "stages_ms": {k: round(v, 4) for k, v in sorted(stages.items())},
         "rooflines": rooflines,
@@ -518,6 +561,21 @@ def main():
             "stages_s": {k: round(v, 3) for k, v in st.items()},
             "max_abs_depth_diff_vs_gpu_mm": err, **extra,
         }
+    line["guard_fallbacks"] = ops.guard_fallback_count()   # launches whose two-piece layer fell back to fp32 (conv_guard.h): 0 on a sane volume
+    if world == 1 and not args.no_extras:
+        #  the same forward with EXACT operands -- every split-operand layer on the three-piece bf16 kernels --
+        # timed by the same protocol in a child process (the switches are read when the weights are packed), 5 steps
+        shape = ["--height", str(H), "--width", str(W), "--views", str(V), "--ndepth", str(D)]
+        ex = child_bench(["--steps", "5", "--warmup", "3", "--no-cpu-baseline"] + shape, {"MVS_CONV0_F16": "0", "MVS_SPLIT_F16": "0"})
+        line["value_exact_operands"] = ex.get("value")
+        line["exact_operands"] = ({"value": ex.get("value"), "unit": ex.get("unit"), "ms_per_step": ex.get("ms_per_step"), "steps": ex.get("steps"),
+                                   "warmup": ex.get("warmup"), "arithmetic": ex.get("config", {}).get("arithmetic"),
+                                   "dominant": {k: ex.get("roofline", {}).get(k) for k in ("kernel", "ms", "achieved", "peak", "frac")},
+                                   "env": "MVS_CONV0_F16=0 MVS_SPLIT_F16=0"} if "error" not in ex else ex)
+        #  BASELINE configs[4] on this GPU: the training step as one HIP graph replay, 5 steps
+        tr = child_bench(["--mode", "train", "--graph", "--steps", "5", "--warmup", "3"] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []), {})
+        line["train"] = ({k: tr.get(k) for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "launch", "loss", "config",
+                                                 "roofline", "cpu_baseline", "peak_mem_GB")} if "error" not in tr else tr)
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -227,7 +227,19 @@ int mvs_conv3d_c8_bf16x6_f32(const float *in, const void *packed, const float *s
  * absolute error below 2^-40 of the maximum.  The weights are scaled the same way when packed:
  * mvs_conv3d_f16x3_packed_bytes(Cin) bytes (0 = unsupported Cin; supported: 8, 16, 32).  out_absmax: NULL, or the
  * absmax block the largest magnitude of `out` is atomically max-ed INTO as it is stored (the next layer's operand scale;
- * the caller clears it -- one memset serves the blocks of a whole network).  Other arguments as mvs_conv3d_c8_bf16x6_f32. */
+ * the caller clears it -- one memset serves the blocks of a whole network).  Other arguments as mvs_conv3d_c8_bf16x6_f32.
+ *
+ * RANGE GUARD (mvs_amd/csrc/conv_guard.h; the same in mvs_conv_split_f16_f32 / mvs_deconv_split_f16_f32 and, through them,
+ * mvs_costreg_fwd2_f32).  One scale per tensor cannot serve every input: an Inf or NaN voxel (the reference keeps its damage
+ * inside the receptive field, module.py:83-84 -> mvsnet.py:83-93) or a few outliers far above the rest would push everything
+ * else out of fp16's range.  Every launch therefore first judges in_absmax ON THE DEVICE: maximum not finite, or fewer than one
+ * in eight of the block's non-zero words within 2^-16 of it (the maximum is carried by outliers), or weights not finite -> the
+ * launch computes the layer in plain fp32 from the ORIGINAL weights (kept behind the packed fragments: packed_bytes includes
+ * them), real taps only, IEEE Inf / NaN semantics and torch's NaN-propagating ReLU -- the reference's arithmetic, at the speed
+ * of a direct convolution.  Otherwise the bound above holds: per product 2^-22 relative for operands within 2^-18 of their
+ * tensor's maximum, 2^-40 of the maximum absolute for smaller ones.  mvs_guard_fallback_count reports how many launches of the
+ * current device took the fp32 path since the library was loaded (it synchronises: a diagnostic, not a data-path call). */
+int mvs_guard_fallback_count(unsigned long long *count);
 size_t mvs_conv3d_f16x3_packed_bytes(int Cin);
 int mvs_conv3d_pack_weights_f16x3_f32(const float *weight, int Cin, void *packed, void *stream);
 int mvs_absmax_f32(const float *x, int64_t n, void *absmax, void *stream);

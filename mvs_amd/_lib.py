@@ -55,6 +55,7 @@ _SIGS = {
     "mvs_conv3d_f16x3_packed_bytes": (ctypes.c_size_t, [_c_i]),
     "mvs_conv3d_pack_weights_f16x3_f32": (_c_i, [_c_f, _c_i, _c_f, _c_f]),
     "mvs_absmax_f32": (_c_i, [_c_f, _c_l, _c_f, _c_f]),
+    "mvs_guard_fallback_count": (_c_i, [ctypes.POINTER(ctypes.c_ulonglong)]),
     "mvs_conv3d_c8_f16x3_f32": (_c_i, [_c_f] * 6 + [_c_i] * 6 + [_c_f, _c_f, _c_f]),
     "mvs_c8h_bytes": (ctypes.c_size_t, [_c_i] * 5),
     "mvs_c8_to_c8h_f32": (_c_i, [_c_f, _c_f] + [_c_i] * 5 + [_c_f, _c_f]),

@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(CSRC, "libmvs_hip.so")
 SOURCES = ("capi", "sweep", "sweep_persist", "regress", "conv3d_direct", "conv3d_mfma", "costreg", "conv_bf16x6", "conv_f16x3", "conv_f16x3_pairs", "conv_split", "deconv_split", "conv2d_mfma", "feature_head", "fpn_tail", "conv3d_wgrad", "conv2d_wgrad", "bnorm", "cas_hypo", "geo_filter", "cvp_hypo", "cvp_glue", "imgprep", "fusibile", "camera")
-HEADERS = (os.path.join(CSRC, "mvs_common.h"), os.path.join(CSRC, "sweep_common.h"), os.path.join(CSRC, "conv_persistent.h"), os.path.join(CSRC, "conv_split_common.h"),
+HEADERS = (os.path.join(CSRC, "mvs_common.h"), os.path.join(CSRC, "sweep_common.h"), os.path.join(CSRC, "conv_persistent.h"), os.path.join(CSRC, "conv_split_common.h"), os.path.join(CSRC, "conv_guard.h"),
            os.path.join(os.path.dirname(HERE), "include", "mvs_hip.h"))
 # -ffp-contract=off: the plane-sweep coordinate arithmetic places its FMAs by
 # hand to match the reference bit for bit; everything else uses fmaf/MFMA.

@@ -15,6 +15,20 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+// launches that took the range guard's fallback (conv_guard.h), per device
+__device__ unsigned long long g_guard_fallbacks;
+unsigned long long *guard_counter() {
+    static unsigned long long *ptr[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!ptr[dev]) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_guard_fallbacks)) != hipSuccess) return nullptr;
+        ptr[dev] = static_cast<unsigned long long *>(p);
+    }
+    return ptr[dev];
+}
+
 int conv3d_direct_launch(const float *, const float *, const float *, const float *, const float *,
                          int, int, int, int, int, int, int, int, int, int, float *, hipStream_t);
 int conv3d_mfma_launch(const float *, const float *, const float *, const float *, const float *,
@@ -103,6 +117,19 @@ using namespace mvs;
 extern "C" int mvs_version(void) { return 100; /* 0.1.0 */ }
 extern "C" const char *mvs_last_error_string(void) { return g_err; }
 extern "C" const char *mvs_arch(void) { return "gfx950"; }
+
+// Launches of the current device that took the range guard's fallback (conv_guard.h) since the library was loaded.
+// Synchronises with the device (a diagnostic: call it after the work, not between the layers).
+extern "C" int mvs_guard_fallback_count(unsigned long long *count) {
+    unsigned long long *p = guard_counter();
+    if (!count || !p) {
+        set_error("mvs_guard_fallback_count: no counter on this device");
+        return MVS_EINVAL;
+    }
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(count, p, sizeof(*count), hipMemcpyDeviceToHost) != hipSuccess)
+        return bare_error(MVS_ELAUNCH, __func__, __LINE__);
+    return MVS_OK;
+}
 
 extern "C" int mvs_nchw_to_nhwc_f32(const float *in, float *out, int B, int C, int64_t S,
                                     void *stream) {

@@ -202,15 +202,15 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(Conv2Args a) {
                 v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w;
             }
             if (a.relu == 1) {
-                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
-                v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                v[0] = relu_nan(v[0]); v[1] = relu_nan(v[1]);
+                v[2] = relu_nan(v[2]); v[3] = relu_nan(v[3]);
             } else if (a.relu == 2) {   // LeakyReLU(0.1)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * 0.1f;
             }
             *reinterpret_cast<float4 *>(a.out + (((int64_t)b * a.Ho + oy) * a.Wo + ox) * COUT + c0) =
                 make_float4(v[0], v[1], v[2], v[3]);
-            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+            vmax = amax4_nan(vmax, v[0], v[1], v[2], v[3]);
         }
     }
     publish_absmax(a.out_absmax, vmax);

@@ -40,7 +40,7 @@ __device__ __forceinline__ float epilogue(float acc, int co, int64_t o, const fl
     float v = acc;
     if (scale) v = v * scale[co];
     if (shift) v = v + shift[co];
-    if (relu) v = fmaxf(v, 0.0f);
+    if (relu) v = relu_nan(v);
     if (residual) v = residual[o] + v;
     return v;
 }

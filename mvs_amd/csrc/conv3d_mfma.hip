@@ -259,8 +259,8 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
                 v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w;
             }
             if (a.relu) {
-                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
-                v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                v[0] = relu_nan(v[0]); v[1] = relu_nan(v[1]);
+                v[2] = relu_nan(v[2]); v[3] = relu_nan(v[3]);
             }
             const int64_t o = ((((int64_t)b * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * COUT + c0;
             if (a.residual) {
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
                 v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
             }
             *reinterpret_cast<float4 *>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
-            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+            vmax = amax4_nan(vmax, v[0], v[1], v[2], v[3]);
         }
     }
     publish_absmax(a.out_absmax, vmax);
@@ -489,8 +489,8 @@ __global__ __launch_bounds__(256) void deconv3d_mfma_kernel(ConvArgs a) {
                             v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w;
                         }
                         if (a.relu) {
-                            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
-                            v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                            v[0] = relu_nan(v[0]); v[1] = relu_nan(v[1]);
+                            v[2] = relu_nan(v[2]); v[3] = relu_nan(v[3]);
                         }
                         const int64_t o =
                             ((((int64_t)b * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * COUT + c0;
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(NWV * 64) void conv3d_cout1_kernel(ConvArgs a, cons
         float v = acc[z];
         if (a.scale) v *= a.scale[0];
         if (a.shift) v += a.shift[0];
-        if (a.relu) v = fmaxf(v, 0.f);
+        if (a.relu) v = relu_nan(v);
         const int64_t o = (((int64_t)b * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
         if (a.residual) v += a.residual[o];
         a.out[o] = v;
@@ -803,7 +803,7 @@ __global__ __launch_bounds__(768) void conv3d_cout1_march_kernel(MarchArgs m, co
                 const int oz = s * TZ + cq * 2 + zz;
                 if (oz >= a.Do) continue;
                 float v = (cq ? acc[2 + zz] : acc[zz]) * sc + sh;
-                if (a.relu) v = fmaxf(v, 0.f);
+                if (a.relu) v = relu_nan(v);
                 const int64_t o = (((int64_t)b * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
                 if (a.residual) v += a.residual[o];
                 a.out[o] = v;

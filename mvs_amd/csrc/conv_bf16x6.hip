@@ -352,8 +352,8 @@ __global__ __launch_bounds__(kSplitKernelThreads) void conv3d_c8_bf16x6_kernel(C
                 v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
                 v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
                 if (a.relu == 1) {
-                    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
-                    v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                    v[0] = relu_nan(v[0]); v[1] = relu_nan(v[1]);
+                    v[2] = relu_nan(v[2]); v[3] = relu_nan(v[3]);
                 }
                 const int o = eoff + r * a.Wo * 8;
                 if (rp) {
@@ -691,8 +691,8 @@ __global__ __launch_bounds__(kSplitKernelThreads) void conv3d_c8_bf16x6_zs_kerne
                 v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
                 v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
                 if (a.relu == 1) {
-                    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
-                    v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                    v[0] = relu_nan(v[0]); v[1] = relu_nan(v[1]);
+                    v[2] = relu_nan(v[2]); v[3] = relu_nan(v[3]);
                 }
                 const int o = eoff + r * a.Wo * 8;
                 if (rp) {

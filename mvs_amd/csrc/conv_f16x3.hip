@@ -22,6 +22,7 @@
 //   * 54 MFMAs (v_mfma_f32_16x16x32_f16) and 42 ds_read_b128 per wave and step instead of 108 and 63;
 //   * LDS 2 x 18 KiB weights + 2 x 40 KiB fp32 staging (copies run two steps ahead) + 40 KiB fp16 parts = 156 KiB.
 #include "conv_split_common.h"
+#include "conv_guard.h"
 
 #include <cstdlib>
 
@@ -34,7 +35,8 @@ constexpr int kFGroup = 4, kFCopyWaves = 4, kFThreads = 512 + 64 * kFCopyWaves;
 template <int CIN, int ABL = 0>
 __global__ __launch_bounds__(kFThreads) void conv3d_c8_f16x3_zs_kernel(ConvArgs a, int ngroups,
                                                                        const unsigned *__restrict__ in_absmax,
-                                                                       unsigned *__restrict__ out_absmax) {
+                                                                       unsigned *__restrict__ out_absmax,
+                                                                       unsigned long long *guard_cnt) {
     constexpr int NCHUNK = CIN / 8, YT = 6, PLANE = kFHaloPlane, T = kFGroup;
     constexpr int NC = kFCopyWaves, NT = kFThreads;
     constexpr int ROWP = 68;                                        // 16-byte pieces per (z, y) row: 34 voxels x 2 halves
@@ -55,10 +57,22 @@ __global__ __launch_bounds__(kFThreads) void conv3d_c8_f16x3_zs_kernel(ConvArgs 
     const int cw = wv - 8;       // copy wave index
 
     // operand scale of the input and what undoes it and the weights' scale (the trailer of the packed weights)
-    const int xe = absmax_exponent(load_absmax(in_absmax));
+    const AbsmaxVerdict verdict = absmax_verdict(in_absmax);
+    const int xe = absmax_exponent(verdict.bits);
     const float sx = pow2f(14 - xe), isx = pow2f(xe - 14);
     const float isw = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(
         __builtin_bit_cast(int, a.wpk[(size_t)NCHUNK * (WBYTES / 4)])));
+    // the range guard (conv_guard.h): a non-finite or outlier-dominated input, or non-finite weights (the pack kernel then
+    // left a NaN where the scale goes) -- the layer in plain fp32 on the original weights, which lie behind the trailer
+    if (verdict.code != 0 || isw != isw) {
+        GuardConv g;
+        g.in = a.in; g.w = a.wpk + (size_t)NCHUNK * (WBYTES / 4) + 4; g.scale = a.scale; g.shift = a.shift; g.residual = a.residual;
+        g.out = a.out; g.out_absmax = out_absmax; g.counter = guard_cnt;
+        g.B = a.B; g.D = a.D; g.H = a.H; g.W = a.W; g.Cin = CIN; g.Do = a.Do; g.Ho = a.Ho; g.Wo = a.Wo;
+        g.ldc = 8; g.co0 = 0; g.nco = 8; g.kd = 3; g.kh = 3; g.stride = 1; g.transposed = 0; g.relu = a.relu; g.in_c8 = 1; g.out_c4 = 0;
+        guard_direct_conv(g);
+        return;
+    }
 
     // this workgroup's groups: g0 + k * g_step, k < ngw
     int g0, g_step, ngw;
@@ -369,8 +383,8 @@ __global__ __launch_bounds__(kFThreads) void conv3d_c8_f16x3_zs_kernel(ConvArgs 
                 v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
                 v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
                 if (a.relu == 1) {
-                    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
-                    v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                    v[0] = relu_nan(v[0]); v[1] = relu_nan(v[1]);
+                    v[2] = relu_nan(v[2]); v[3] = relu_nan(v[3]);
                 }
                 const int o = eoff + r * a.Wo * 8;
                 if (rp) {
@@ -378,7 +392,7 @@ __global__ __launch_bounds__(kFThreads) void conv3d_c8_f16x3_zs_kernel(ConvArgs 
                     v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
                 }
                 *reinterpret_cast<float4 *>(ob + o) = make_float4(v[0], v[1], v[2], v[3]);
-                vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                vmax = amax4_nan(vmax, v[0], v[1], v[2], v[3]);
             }
         });
     }
@@ -430,7 +444,10 @@ __global__ __launch_bounds__(256) void pack_f16x3_kernel(const float *__restrict
                                                          int total, const unsigned *__restrict__ wmax) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int e = absmax_exponent(*wmax);
-    if (i == 0) *reinterpret_cast<float *>(out + (size_t)total * 2) = pow2f(e - 14);
+    // what undoes the scale; NaN = "the weights are not finite", which sends every launch to the guard's fp32 path
+    if (i == 0) *reinterpret_cast<float *>(out + (size_t)total * 2) = *wmax >= 0x7f800000u ? __builtin_nanf("") : pow2f(e - 14);
+    // the original fp32 weights behind the 16-byte trailer (conv_guard.h)
+    if (i < 8 * Cin * 27) reinterpret_cast<float *>(out + (size_t)total * 2)[4 + i] = w[i];
     if (i >= total) return;
     const int j = i & 7, lane = (i >> 3) & 63, t = (i >> 9) % 9, ch = i / (9 * 512);
     const int m = lane & 15, kq = lane >> 4, co = m & 7, sft = m >> 3, kx = kq - sft;
@@ -451,7 +468,8 @@ using namespace mvs;
 static bool f16x3_shape_ok(int Cin) { return Cin == 8 || Cin == 16 || Cin == 32; }
 
 extern "C" size_t mvs_conv3d_f16x3_packed_bytes(int Cin) {
-    return f16x3_shape_ok(Cin) ? (size_t)(Cin / 8) * kF16ChunkBytes + 16 : 0;
+    // fragments + 16-byte trailer (scale, -, -, largest weight) + the original (8, Cin, 27) fp32 weights for the range guard
+    return f16x3_shape_ok(Cin) ? (size_t)(Cin / 8) * kF16ChunkBytes + 16 + (size_t)8 * Cin * 27 * 4 : 0;
 }
 
 namespace mvs {
@@ -514,22 +532,23 @@ extern "C" int mvs_conv3d_c8_f16x3_f32(const float *in, const void *in_absmax, c
     const dim3 grid((unsigned)(ng < n_cu ? ng : n_cu)), blk(kFThreads);
     const unsigned *mx = static_cast<const unsigned *>(in_absmax);
     unsigned *omx = static_cast<unsigned *>(out_absmax);
+    unsigned long long *const gc = guard_counter();
 #ifdef MVS_TUNING   // phase-stamp build: cycle counters written through `residual` (scripts/exp_conv0_f16.py)
     static const int abl = [] { const char *e = getenv("MVS_CONV_SPLIT_ABL"); return e ? atoi(e) : 0; }();
     if ((abl & 128) && Cin == 32) {
         if (!residual) return bare_error(MVS_EINVAL, __func__, __LINE__);
-        hipLaunchKernelGGL((conv3d_c8_f16x3_zs_kernel<32, 128>), grid, blk, 0, st, a, (int)ng, mx, omx);
+        hipLaunchKernelGGL((conv3d_c8_f16x3_zs_kernel<32, 128>), grid, blk, 0, st, a, (int)ng, mx, omx, gc);
         return check_launch("mvs_conv3d_c8_f16x3_f32");
     }
     if ((abl & 3) && Cin == 32) {   // wrong results by design: 1 = no split work, 2 = no MFMA phase, 3 = copies and barriers only
-        if ((abl & 3) == 1) hipLaunchKernelGGL((conv3d_c8_f16x3_zs_kernel<32, 1>), grid, blk, 0, st, a, (int)ng, mx, omx);
-        else if ((abl & 3) == 2) hipLaunchKernelGGL((conv3d_c8_f16x3_zs_kernel<32, 2>), grid, blk, 0, st, a, (int)ng, mx, omx);
-        else hipLaunchKernelGGL((conv3d_c8_f16x3_zs_kernel<32, 3>), grid, blk, 0, st, a, (int)ng, mx, omx);
+        if ((abl & 3) == 1) hipLaunchKernelGGL((conv3d_c8_f16x3_zs_kernel<32, 1>), grid, blk, 0, st, a, (int)ng, mx, omx, gc);
+        else if ((abl & 3) == 2) hipLaunchKernelGGL((conv3d_c8_f16x3_zs_kernel<32, 2>), grid, blk, 0, st, a, (int)ng, mx, omx, gc);
+        else hipLaunchKernelGGL((conv3d_c8_f16x3_zs_kernel<32, 3>), grid, blk, 0, st, a, (int)ng, mx, omx, gc);
         return check_launch("mvs_conv3d_c8_f16x3_f32");
     }
 #endif
-    if (Cin == 32) hipLaunchKernelGGL((conv3d_c8_f16x3_zs_kernel<32>), grid, blk, 0, st, a, (int)ng, mx, omx);
-    else if (Cin == 16) hipLaunchKernelGGL((conv3d_c8_f16x3_zs_kernel<16>), grid, blk, 0, st, a, (int)ng, mx, omx);
-    else hipLaunchKernelGGL((conv3d_c8_f16x3_zs_kernel<8>), grid, blk, 0, st, a, (int)ng, mx, omx);
+    if (Cin == 32) hipLaunchKernelGGL((conv3d_c8_f16x3_zs_kernel<32>), grid, blk, 0, st, a, (int)ng, mx, omx, gc);
+    else if (Cin == 16) hipLaunchKernelGGL((conv3d_c8_f16x3_zs_kernel<16>), grid, blk, 0, st, a, (int)ng, mx, omx, gc);
+    else hipLaunchKernelGGL((conv3d_c8_f16x3_zs_kernel<8>), grid, blk, 0, st, a, (int)ng, mx, omx, gc);
     return check_launch("mvs_conv3d_c8_f16x3_f32");
 }

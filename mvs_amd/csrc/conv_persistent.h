@@ -372,8 +372,8 @@ __global__ __launch_bounds__(512) void conv3d_c8_persistent_kernel(ConvArgs a, i
                     v[0] = v[0] * sc[m].x + sh[m].x; v[1] = v[1] * sc[m].y + sh[m].y;
                     v[2] = v[2] * sc[m].z + sh[m].z; v[3] = v[3] * sc[m].w + sh[m].w;
                     if (a.relu == 1) {
-                        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
-                        v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                        v[0] = relu_nan(v[0]); v[1] = relu_nan(v[1]);
+                        v[2] = relu_nan(v[2]); v[3] = relu_nan(v[3]);
                     } else if (a.relu == 2) {   // LeakyReLU(0.1): CVP-MVSNet's feature pyramid
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * 0.1f;
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(512) void conv3d_c8_persistent_kernel(ConvArgs a, i
                         v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
                     }
                     *reinterpret_cast<float4 *>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
-                    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                    vmax = amax4_nan(vmax, v[0], v[1], v[2], v[3]);
                 }
             }
         }

@@ -16,6 +16,7 @@
 //                (tap group, 16 output channels) the A fragment three more; six MFMAs per pair
 // Tiles of a group share the chunk's weights in LDS and keep their accumulators in registers over the chunk loop.
 #include "conv_split_common.h"
+#include "conv_guard.h"
 
 #include <cstdlib>
 
@@ -37,6 +38,10 @@ struct SplitArgs {
     const unsigned *in_absmax;
     const float *w_iscale;
     unsigned *out_absmax;     // NULL, or the absmax block that collects the largest magnitude this launch stores (any form)
+    // NP = 2, the range guard (conv_guard.h): the layer's original fp32 weights (PyTorch layout, behind the trailer of the
+    // packed weights) and the device counter of launches that fell back to them
+    const float *w_f32;
+    unsigned long long *guard_cnt;
 };
 
 // NP: operand pieces -- 3 = bf16 hi/mid/lo, six products (exact split); 2 = scaled fp16 hi/lo, three products (conv_f16x3.hip
@@ -119,11 +124,29 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_split_kernel(SplitArgs a, in
     const int cw = wv - 8;
     constexpr int NP = C::NP;
     // NP = 2: operand scale of the input; what undoes it and the weights' scale goes into the epilogue's per-channel scale
-    float sx = 1.0f, unscale = 1.0f;
+    float sx = 1.0f, unscale = 1.0f, unscale2 = 1.0f;
     if constexpr (NP == 2) {
-        const int xe = absmax_exponent(load_absmax(a.in_absmax));
+        const AbsmaxVerdict verdict = absmax_verdict(a.in_absmax);
+        const int xe = absmax_exponent(verdict.bits);
+        const float isw = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *a.w_iscale)));
         sx = pow2f(14 - xe);
-        unscale = pow2f(xe - 14) * __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *a.w_iscale)));
+        // what undoes both operand scales is 2^E: the part within +-60 rides in the per-channel scale of the epilogue, the rest
+        // (inputs or weights beyond 1e+-18: folded into one float it would underflow) is a second multiply there
+        const int E = xe - 14 + (int)((__builtin_bit_cast(unsigned, isw) >> 23) & 255u) - 127;
+        const int e1 = E < -60 ? -60 : (E > 60 ? 60 : E), e2 = E - e1 < -126 ? -126 : (E - e1 > 127 ? 127 : E - e1);
+        unscale = pow2f(e1);
+        unscale2 = pow2f(e2);
+        // the range guard (conv_guard.h): a non-finite or outlier-dominated input, or non-finite weights -> plain fp32
+        if (verdict.code != 0 || isw != isw) {
+            GuardConv g;
+            g.in = a.in; g.w = a.w_f32; g.scale = a.scale; g.shift = a.shift; g.residual = a.residual; g.out = a.out;
+            g.out_absmax = a.out_absmax; g.counter = a.guard_cnt;
+            g.B = a.B; g.D = a.D; g.H = a.H; g.W = a.W; g.Cin = CIN; g.Do = a.Do; g.Ho = a.Ho; g.Wo = a.Wo;
+            g.ldc = a.ldc; g.co0 = a.co0; g.nco = a.nco; g.kd = C::KD; g.kh = C::KH; g.stride = C::S; g.transposed = 0;
+            g.relu = a.relu; g.in_c8 = 0; g.out_c4 = a.out_c4;
+            guard_direct_conv(g);
+            return;
+        }
     }
     // the per-channel affine of the epilogue waits in LDS (a global load there would put its latency into every tile)
     if (tid < 2 * C::COUT) {
@@ -525,11 +548,12 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_split_kernel(SplitArgs a, in
                     f32x4 v = acc[j][r][m];
                     acc[j][r][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     if (!inside || m * 16 + kq * 4 >= a.nco) continue;
+                    if (unscale2 != 1.0f) { v[0] *= unscale2; v[1] *= unscale2; v[2] *= unscale2; v[3] *= unscale2; }   // (wave-uniform; extreme magnitudes only)
                     v[0] = v[0] * sc[m].x + sh[m].x; v[1] = v[1] * sc[m].y + sh[m].y;
                     v[2] = v[2] * sc[m].z + sh[m].z; v[3] = v[3] * sc[m].w + sh[m].w;
                     if (a.relu == 1) {
-                        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
-                        v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                        v[0] = relu_nan(v[0]); v[1] = relu_nan(v[1]);
+                        v[2] = relu_nan(v[2]); v[3] = relu_nan(v[3]);
                     } else if (a.relu == 2) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : v[q] * 0.1f;
@@ -540,7 +564,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_split_kernel(SplitArgs a, in
                         v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
                     }
                     *reinterpret_cast<float4 *>(ob + o) = make_float4(v[0], v[1], v[2], v[3]);
-                    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                    vmax = amax4_nan(vmax, v[0], v[1], v[2], v[3]);
                 }
             }
         });
@@ -588,7 +612,8 @@ __global__ __launch_bounds__(256) void pack_split_f16_kernel(const float *__rest
                                                              const unsigned *__restrict__ wmax, float *__restrict__ iscale) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int e = absmax_exponent(*wmax);
-    if (i == 0) *iscale = pow2f(e - 14);
+    // what undoes the scale; NaN = "the weights are not finite", which sends every launch to the guard's fp32 path
+    if (i == 0) *iscale = *wmax >= 0x7f800000u ? __builtin_nanf("") : pow2f(e - 14);
     if (i >= total) return;
     const int j = i & 7, lane = (i >> 3) & 63;
     int rest = i >> 9;
@@ -656,9 +681,10 @@ extern "C" size_t mvs_conv_split_packed_bytes(int kd, int Cin, int Cout, int str
 }
 
 // two-piece fp16 form: the fragments + a 16-byte trailer (what undoes the weights' scale; the weights' largest magnitude)
+// + the original fp32 weights (the range guard's, conv_guard.h)
 extern "C" size_t mvs_conv_split_f16_packed_bytes(int kd, int Cin, int Cout, int stride) {
     const size_t n = split_packed_bytes(kd, Cin, Cout, stride, 2);
-    return n ? n + 16 : 0;
+    return n ? n + 16 + (size_t)Cout * Cin * split_ntap(kd, stride) * 4 : 0;
 }
 
 namespace mvs { int launch_absmax_word(const float *x, int64_t n, unsigned *word, hipStream_t st); }   // conv_f16x3.hip
@@ -682,6 +708,8 @@ extern "C" int mvs_conv_split_pack_weights_f16_f32(const float *weight, int kd, 
                            co0, reinterpret_cast<unsigned short *>(pk + (co0 / step) * per_launch), total, wmax,
                            reinterpret_cast<float *>(pk + body));
     }
+    if (hipMemcpyAsync(pk + body + 16, weight, (size_t)Cout * Cin * ntap * 4, hipMemcpyDeviceToDevice, as_stream(stream)) != hipSuccess)
+        return bare_error(MVS_ELAUNCH, __func__, __LINE__);
     return check_launch("mvs_conv_split_pack_weights_f16_f32");
 }
 
@@ -722,6 +750,8 @@ static int conv_split_impl(const float *in, const void *in_absmax, const void *p
         a.in_absmax = static_cast<const unsigned *>(in_absmax);
         a.w_iscale = reinterpret_cast<const float *>(static_cast<const unsigned char *>(packed) + split_packed_bytes(kd, Cin, Cout, stride, 2));
         a.out_absmax = static_cast<unsigned *>(out_absmax);
+        a.w_f32 = a.w_iscale + 4;
+        a.guard_cnt = np == 2 ? guard_counter() : nullptr;
         a.in = in; a.wpk = static_cast<const unsigned char *>(packed) + (co0 / step) * per_launch;
         a.scale = scale ? scale + co0 : nullptr; a.shift = shift ? shift + co0 : nullptr;
         a.residual = residual ? residual + co0 : nullptr; a.out = out + co0;

@@ -13,6 +13,7 @@
 //   Cout = 16 per launch (conv9; conv7 as two launches): 8 classes of 1, 1, 1, 2, 1, 2, 2, 4 K-steps.
 // BatchNorm affine, ReLU and the skip add (AFTER the ReLU, mvsnet.py:89-91) in the epilogue.
 #include "conv_split_common.h"
+#include "conv_guard.h"
 
 #include <cstdlib>
 
@@ -30,6 +31,11 @@ struct DeconvArgs {
     const unsigned *in_absmax;
     const float *w_iscale;
     unsigned *out_absmax;     // NULL, or the absmax block that collects the largest magnitude this launch stores (any form)
+    // NP = 2, the range guard (conv_guard.h): the original fp32 weights (behind the trailer of the packed weights), the first
+    // output channel of this launch, the device counter of launches that fell back
+    const float *w_f32;
+    int co0;
+    unsigned long long *guard_cnt;
 };
 
 // per-dimension tap t of parity p -> (kernel index, input offset)
@@ -81,11 +87,29 @@ __global__ __launch_bounds__(kDeconvThreads) void deconv_split_kernel(DeconvArgs
     const bool copier = wv >= 8;
     const int cw = wv - 8;
     constexpr int NP = C::NP;
-    float sx = 1.0f, unscale = 1.0f;     // NP = 2: operand scale of the input; what undoes it and the weights' scale
+    float sx = 1.0f, unscale = 1.0f, unscale2 = 1.0f;     // NP = 2: operand scale of the input; what undoes it and the weights' scale
     if constexpr (NP == 2) {
-        const int xe = absmax_exponent(load_absmax(a.in_absmax));
+        const AbsmaxVerdict verdict = absmax_verdict(a.in_absmax);
+        const int xe = absmax_exponent(verdict.bits);
+        const float isw = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *a.w_iscale)));
         sx = pow2f(14 - xe);
-        unscale = pow2f(xe - 14) * __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *a.w_iscale)));
+        // what undoes both operand scales is 2^E: the part within +-60 rides in the per-channel scale of the epilogue, the rest
+        // (inputs or weights beyond 1e+-18: folded into one float it would underflow) is a second multiply there
+        const int E = xe - 14 + (int)((__builtin_bit_cast(unsigned, isw) >> 23) & 255u) - 127;
+        const int e1 = E < -60 ? -60 : (E > 60 ? 60 : E), e2 = E - e1 < -126 ? -126 : (E - e1 > 127 ? 127 : E - e1);
+        unscale = pow2f(e1);
+        unscale2 = pow2f(e2);
+        // the range guard (conv_guard.h): a non-finite or outlier-dominated input, or non-finite weights -> plain fp32
+        if (verdict.code != 0 || isw != isw) {
+            GuardConv g;
+            g.in = a.in; g.w = a.w_f32; g.scale = a.scale; g.shift = a.shift; g.residual = a.residual; g.out = a.out;
+            g.out_absmax = a.out_absmax; g.counter = a.guard_cnt;
+            g.B = a.B; g.D = a.D; g.H = a.H; g.W = a.W; g.Cin = CIN; g.Do = 2 * a.D; g.Ho = 2 * a.H; g.Wo = 2 * a.W;
+            g.ldc = a.ldc; g.co0 = a.co0; g.nco = C::COUT; g.kd = 3; g.kh = 3; g.stride = 2; g.transposed = 1;
+            g.relu = a.relu ? 1 : 0; g.in_c8 = 0; g.out_c4 = 0;
+            guard_direct_conv(g);
+            return;
+        }
     }
     if (tid < 2 * C::COUT) {
         const int c = tid % C::COUT;
@@ -370,17 +394,18 @@ __global__ __launch_bounds__(kDeconvThreads) void deconv_split_kernel(DeconvArgs
                     bool inside;
                     const int64_t o = out_offset(cur, c, r, inside);
                     if (!inside) continue;
+                    if (unscale2 != 1.0f) { v[0] *= unscale2; v[1] *= unscale2; v[2] *= unscale2; v[3] *= unscale2; }   // (wave-uniform; extreme magnitudes only)
                     v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
                     v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
                     if (a.relu) {
-                        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
-                        v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                        v[0] = relu_nan(v[0]); v[1] = relu_nan(v[1]);
+                        v[2] = relu_nan(v[2]); v[3] = relu_nan(v[3]);
                     }
                     if (a.residual) {
                         v[0] += res[c][r].x; v[1] += res[c][r].y; v[2] += res[c][r].z; v[3] += res[c][r].w;
                     }
                     *reinterpret_cast<float4 *>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
-                    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                    vmax = amax4_nan(vmax, v[0], v[1], v[2], v[3]);
                 }
             }
         }
@@ -401,7 +426,8 @@ __global__ __launch_bounds__(256) void pack_deconv_split_kernel(const float *__r
     int we = 0;
     if constexpr (F16) {
         we = absmax_exponent(*wmax);
-        if (i == 0) *iscale = pow2f(we - 14);
+        // what undoes the scale; NaN = "the weights are not finite", which sends every launch to the guard's fp32 path
+        if (i == 0) *iscale = *wmax >= 0x7f800000u ? __builtin_nanf("") : pow2f(we - 14);
     }
     if (i >= total) return;
     const int j = i & 7, lane = (i >> 3) & 63;
@@ -478,9 +504,10 @@ static size_t deconv_packed_bytes(int Cin, int Cout, int np) {
 extern "C" size_t mvs_deconv_split_packed_bytes(int Cin, int Cout) { return deconv_packed_bytes(Cin, Cout, 3); }
 
 // two-piece fp16 form: the fragments + a 16-byte trailer (what undoes the weights' scale; the weights' largest magnitude)
+// + the original fp32 weights (the range guard's, conv_guard.h)
 extern "C" size_t mvs_deconv_split_f16_packed_bytes(int Cin, int Cout) {
     const size_t n = deconv_packed_bytes(Cin, Cout, 2);
-    return n ? n + 16 : 0;
+    return n ? n + 16 + (size_t)Cin * Cout * 27 * 4 : 0;
 }
 
 namespace mvs { int launch_absmax_word(const float *x, int64_t n, unsigned *word, hipStream_t st); }   // conv_f16x3.hip
@@ -505,6 +532,8 @@ extern "C" int mvs_deconv_split_pack_weights_f16_f32(const float *weight, int Ci
         else
             hipLaunchKernelGGL((pack_deconv_split_kernel<false, true>), dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), weight, Cin, Cout, co0, dst, total, wmax, iscale);
     }
+    if (hipMemcpyAsync(pk + body + 16, weight, (size_t)Cin * Cout * 27 * 4, hipMemcpyDeviceToDevice, as_stream(stream)) != hipSuccess)
+        return bare_error(MVS_ELAUNCH, __func__, __LINE__);
     return check_launch("mvs_deconv_split_pack_weights_f16_f32");
 }
 
@@ -544,6 +573,8 @@ static int deconv_split_impl(const float *in, const void *in_absmax, const void 
         a.in_absmax = static_cast<const unsigned *>(in_absmax);
         a.w_iscale = reinterpret_cast<const float *>(static_cast<const unsigned char *>(packed) + deconv_packed_bytes(Cin, Cout, 2));
         a.out_absmax = static_cast<unsigned *>(out_absmax);
+        a.w_f32 = a.w_iscale + 4; a.co0 = co0;
+        a.guard_cnt = np == 2 ? guard_counter() : nullptr;
         a.in = in; a.wpk = static_cast<const unsigned char *>(packed) + (co0 / step) * per_launch;
         a.scale = scale ? scale + co0 : nullptr; a.shift = shift ? shift + co0 : nullptr;
         a.residual = residual ? residual + co0 : nullptr; a.out = out + co0;

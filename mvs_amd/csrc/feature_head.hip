@@ -206,10 +206,10 @@ __global__ __launch_bounds__(kHeadThreads) __attribute__((amdgpu_waves_per_eu(2,
                 const int gy = cur.ty * kTH - 1 + hrow0 + r;
                 const bool in_img = xin && (unsigned)gy < (unsigned)a.H;
                 f32x4 lo, hi;
-                lo[0] = fmaxf(fmaf(acc[r][0], s0a.x, h0a.x), 0.f); lo[1] = fmaxf(fmaf(acc[r][1], s0a.y, h0a.y), 0.f);
-                lo[2] = fmaxf(fmaf(acc[r][2], s0a.z, h0a.z), 0.f); lo[3] = fmaxf(fmaf(acc[r][3], s0a.w, h0a.w), 0.f);
-                hi[0] = fmaxf(fmaf(acc[r][4], s0b.x, h0b.x), 0.f); hi[1] = fmaxf(fmaf(acc[r][5], s0b.y, h0b.y), 0.f);
-                hi[2] = fmaxf(fmaf(acc[r][6], s0b.z, h0b.z), 0.f); hi[3] = fmaxf(fmaf(acc[r][7], s0b.w, h0b.w), 0.f);
+                lo[0] = relu_nan(fmaf(acc[r][0], s0a.x, h0a.x)); lo[1] = relu_nan(fmaf(acc[r][1], s0a.y, h0a.y));
+                lo[2] = relu_nan(fmaf(acc[r][2], s0a.z, h0a.z)); lo[3] = relu_nan(fmaf(acc[r][3], s0a.w, h0a.w));
+                hi[0] = relu_nan(fmaf(acc[r][4], s0b.x, h0b.x)); hi[1] = relu_nan(fmaf(acc[r][5], s0b.y, h0b.y));
+                hi[2] = relu_nan(fmaf(acc[r][6], s0b.z, h0b.z)); hi[3] = relu_nan(fmaf(acc[r][7], s0b.w, h0b.w));
                 if (!in_img) lo = hi = (f32x4){0.f, 0.f, 0.f, 0.f};
                 bf16x8 ph, pm, pl;
                 split3_block(lo, hi, ph, pm, pl);
@@ -281,11 +281,11 @@ __global__ __launch_bounds__(kHeadThreads) __attribute__((amdgpu_waves_per_eu(2,
                 const int oy = cur.ty * kTH + wv * kRPW + r;
                 if (oy >= a.H || ox >= a.W || (a.abl & 4)) continue;
                 f32x4 v = acc1[r];
-                v[0] = fmaxf(v[0] * sc1.x + sh1.x, 0.f); v[1] = fmaxf(v[1] * sc1.y + sh1.y, 0.f);
-                v[2] = fmaxf(v[2] * sc1.z + sh1.z, 0.f); v[3] = fmaxf(v[3] * sc1.w + sh1.w, 0.f);
+                v[0] = relu_nan(v[0] * sc1.x + sh1.x); v[1] = relu_nan(v[1] * sc1.y + sh1.y);
+                v[2] = relu_nan(v[2] * sc1.z + sh1.z); v[3] = relu_nan(v[3] * sc1.w + sh1.w);
                 const int64_t o = (((int64_t)cur.b * a.H + oy) * a.W + ox) * 8 + c0;
                 *reinterpret_cast<float4 *>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
-                vmax = fmaxf(fmaxf(vmax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));       // (after the ReLU: non-negative)
+                vmax = max_nan(max_nan(max_nan(vmax, v[0]), v[1]), max_nan(v[2], v[3]));       // (after the ReLU: non-negative)
             }
         }
         full_stores = !(a.abl & 4) && cur.ty * kTH + wv * kRPW + kRPW <= a.H;

@@ -157,11 +157,22 @@ __device__ __forceinline__ void glds16_buf(unsigned voffset, mvs_srd_t srd, unsi
 // the end of a kernel (+6 us per launch on the small layers, +50 us on the sweep).  The consumer is the operand scale of the
 // two-piece fp16 convolutions (conv_f16x3.hip).
 constexpr int kAbsmaxWords = 256;
+// NaN-propagating maximum (IEEE 754-2019 `maximum`: v_maximum3_f32 on gfx950, one instruction like v_max_f32).  The reference's
+// ReLU is torch's: relu(NaN) = NaN, relu(-Inf) = 0 -- fmaxf(NaN, 0) = 0 would hide a poisoned voxel; and an absmax block must SEE
+// a NaN (its bit pattern is above every number's), because the two-piece layers decide on it whether their arithmetic holds
+// (conv_guard.h).
+__device__ __forceinline__ float max_nan(float a, float b) { return __builtin_elementwise_maximum(a, b); }
+__device__ __forceinline__ float relu_nan(float v) { return __builtin_elementwise_maximum(v, 0.0f); }
+// running largest magnitude of a lane's stored values: vmax = max(vmax, |a|, |b|, |c|, |d|), a NaN sticks
+__device__ __forceinline__ float amax4_nan(float vmax, float a, float b, float c, float d) {
+    return max_nan(max_nan(max_nan(vmax, __builtin_fabsf(a)), __builtin_fabsf(b)), max_nan(__builtin_fabsf(c), __builtin_fabsf(d)));
+}
 __device__ __forceinline__ void publish_absmax(unsigned *absmax, float vmax) {
     if (!absmax) return;
 #pragma unroll
-    for (int o = 32; o; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-    if ((threadIdx.x & 63) == 0 && vmax > 0.0f) atomicMax(absmax + (blockIdx.x & (kAbsmaxWords - 1)), __float_as_uint(vmax));
+    for (int o = 32; o; o >>= 1) vmax = max_nan(vmax, __shfl_xor(vmax, o));
+    if ((threadIdx.x & 63) == 0 && !(vmax <= 0.0f))
+        atomicMax(absmax + (blockIdx.x & (kAbsmaxWords - 1)), __float_as_uint(vmax) & 0x7fffffffu);
 }
 // wave-uniform maximum of an absmax block
 __device__ __forceinline__ unsigned load_absmax(const unsigned *absmax) {

@@ -659,7 +659,7 @@ __global__ __launch_bounds__(256, 2) void variance_fwd_dma_kernel(
                     o[k] = make_float4(var[k * 4], var[k * 4 + 1], var[k * 4 + 2], var[k * 4 + 3]);
             }
 #pragma unroll
-            for (int c = 0; c < GC; c += 2) vmax = fmaxf(vmax, fmaxf(fabsf(var[c]), fabsf(var[c + 1])));
+            for (int c = 0; c < GC; c += 2) vmax = max_nan(max_nan(vmax, __builtin_fabsf(var[c])), __builtin_fabsf(var[c + 1]));
         }
     }
     if constexpr (LOOP) __syncthreads();   // every wave is done with this tile's LDS image before the next tile's copies

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void variance_fwd_cold_kernel(PersistArgs a, i
                     ? pl + ((unsigned)(py * (p.C >> 3) + (g * 2 + (k >> 1))) * (unsigned)p.W + (unsigned)px) * 8u + (k & 1) * 4
                     : pl + (unsigned)pix * (unsigned)p.C + (unsigned)(g * 16 + k * 4);
                 *reinterpret_cast<float4 *>(o) = make_float4(var[0], var[1], var[2], var[3]);
-                vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(var[0]), fabsf(var[1]))), fmaxf(fabsf(var[2]), fabsf(var[3])));
+                vmax = amax4_nan(vmax, var[0], var[1], var[2], var[3]);
             }
         }
     }
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
                             reinterpret_cast<float4 *>(o + h * step)[1] = make_float4(var[h * 8 + 4], var[h * 8 + 5], var[h * 8 + 6], var[h * 8 + 7]);
                         }
 #pragma unroll
-                        for (int c = 0; c < GC; c += 2) vmax = fmaxf(vmax, fmaxf(fabsf(var[c]), fabsf(var[c + 1])));
+                        for (int c = 0; c < GC; c += 2) vmax = max_nan(max_nan(vmax, __builtin_fabsf(var[c])), __builtin_fabsf(var[c + 1]));
                     }
                     stored = true;
                 }

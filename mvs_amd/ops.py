@@ -713,6 +713,14 @@ def absmax_block(device, zero=False, n=None):
     return (torch.zeros if zero else torch.empty)(shape, device=device, dtype=torch.int32)
 
 
+def guard_fallback_count():
+    """Launches of the current device whose two-piece fp16 layer judged its input unfit for one scale per tensor (non-finite,
+    or outlier-dominated) and ran in plain fp32 instead (mvs_guard_fallback_count; synchronises the device: a diagnostic)."""
+    n = ctypes.c_ulonglong(0)
+    check(_lib.load().mvs_guard_fallback_count(ctypes.byref(n)), "mvs_guard_fallback_count")
+    return int(n.value)
+
+
 def absmax_value(block):
     """The float an absmax block holds."""
     return block.max().view(1).view(torch.float32).item()
@@ -1140,7 +1148,8 @@ def costreg_forward(x, params, in_c8=False, impl=IMPL_AUTO, x_absmax=None):
     any_f16 = False
     for i, name in enumerate(COSTREG_ORDER):
         t = (params[name].get("packed_f16x3") if in_c8 else None) if i == 0 else f16_companion(params[name].get("packed"))
-        if t is not None and split_f16_enabled():
+        # (each switch on its own: MVS_CONV0_F16 decides conv0, MVS_SPLIT_F16 the other layers -- as the per-layer path does)
+        if t is not None and (conv0_f16_enabled() if i == 0 else split_f16_enabled()):
             keep.append(t)
             f16[i] = t.data_ptr()
             any_f16 = True
