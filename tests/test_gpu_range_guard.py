@@ -49,18 +49,24 @@ def _poison(x, case, pos):
     return x
 
 
-def _check(got, ref32, ref64, bound, what):
-    """got (device), ref32 = the reference's float32 result, ref64 = float64 with the non-finite inputs' reach masked by ref32."""
+def _check(got, ref32, ref64, bound, what, reach=None):
+    """got (device) against ref32 = the reference's float32 result and ref64 = float64 of the input with its non-finite
+    elements zeroed.  reach: the outputs a non-finite input element contributes to -- there the reference's value (NaN, +-Inf,
+    or the finite relu(-Inf) = 0 [+ skip]) must be reproduced exactly; everywhere else the float32 bound holds.  Returns the
+    number of non-finite outputs."""
     got = got.detach().cpu()
     nan_r, inf_r = torch.isnan(ref32), torch.isinf(ref32)
     assert torch.equal(torch.isnan(got), nan_r), f"{what}: NaN pattern differs ({int(torch.isnan(got).sum())} vs {int(nan_r.sum())})"
     assert torch.equal(torch.isinf(got), inf_r) and torch.equal(got[inf_r], ref32[inf_r]), f"{what}: Inf pattern / signs differ"
-    fin = ~(nan_r | inf_r)
-    err = (got.double() - ref64)[fin].abs()
-    tol = bound[fin]
-    worst = (err / tol).max().item() if err.numel() else 0.0
-    assert worst <= 1.0, f"{what}: error {worst:.2f} x the float32 bound at the worst finite element"
-    return int((~fin).sum())
+    if reach is None:       # (no poisoned input element: whatever the reference makes non-finite)
+        reach = nan_r | inf_r
+    assert not (nan_r | inf_r)[~reach].any(), f"{what}: the reference is non-finite outside the poisoned element's receptive field?"
+    inside = reach & ~nan_r
+    assert torch.equal(got[inside], ref32[inside]), f"{what}: differs from the reference inside the poisoned receptive field"
+    err = (got.double() - ref64)[~reach].abs()
+    worst = (err / bound[~reach]).max().item() if err.numel() else 0.0
+    assert worst <= 1.0, f"{what}: error {worst:.2f} x the float32 bound at the worst element outside the poisoned receptive field"
+    return int((nan_r | inf_r).sum())
 
 
 def _fallbacks():
@@ -77,12 +83,13 @@ def _layer_reference(x, w, scale, shift, res, relu, conv, **kw):
     xf = torch.where(torch.isfinite(x), x, torch.zeros_like(x))
     y64 = act(conv(xf.double(), w.double(), **kw) * scale.double().view(v) + shift.double().view(v))
     mag = conv(xf.double().abs(), w.double().abs(), **kw) * scale.double().abs().view(v)
+    reach = conv((~torch.isfinite(x)).double(), torch.ones_like(w).double(), **kw) > 0     # outputs with a non-finite term
     perm = (0,) + tuple(range(2, x.dim())) + (1,)
-    y32, y64, mag = y32.permute(perm), y64.permute(perm), mag.permute(perm)
+    y32, y64, mag, reach = y32.permute(perm), y64.permute(perm), mag.permute(perm), reach.permute(perm)
     if res is not None:
         y32, y64 = y32 + res, y64 + res.double()
     bound = 2e-6 * mag + 3e-7 * (y64.abs() + (res.double().abs() if res is not None else 0)) + 1e-30
-    return y32.contiguous(), y64.contiguous(), bound.contiguous()
+    return y32.contiguous(), y64.contiguous(), bound.contiguous(), reach.contiguous()
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -96,12 +103,12 @@ def test_conv0_two_piece_keeps_damage_local(dev, case):
     w = torch.randn(8, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5
     scale, shift = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.1
     res = torch.randn(B, D, H, W, 8, generator=g)
-    y32, y64, bound = _layer_reference(x, w, scale, shift, res, 1, F.conv3d, padding=1)
+    y32, y64, bound, reach = _layer_reference(x, w, scale, shift, res, 1, F.conv3d, padding=1)
     n0 = _fallbacks()
     om = ops.absmax_block(dev, zero=True)
     got = ops.conv3d_c8_f16x3(ops.nchw_to_c8(x.to(dev)), ops.pack_conv3d_weight_f16x3(w.to(dev)), None, scale.to(dev), shift.to(dev),
                               res.to(dev), True, out_absmax=om)
-    nbad = _check(got, y32, y64, bound, f"conv0 / {case}")
+    nbad = _check(got, y32, y64, bound, f"conv0 / {case}", reach)
     assert (_fallbacks() - n0 > 0) == TAKES_FALLBACK[case], (case, _fallbacks() - n0)
     if case in ("inf", "neg_inf", "nan"):
         assert 0 < nbad <= 27 * 8           # inside the 3x3x3 receptive field only
@@ -125,7 +132,7 @@ def test_conv_split_two_piece_keeps_damage_local(dev, case, kd, cin, cout, shape
     w = torch.randn(cout, cin, *([3] * (kd == 3)), k, k, generator=g) / (k * k * (3 if kd == 3 else 1) * cin) ** 0.5
     scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
     conv = F.conv3d if kd == 3 else F.conv2d
-    y32, y64, bound = _layer_reference(x, w, scale, shift, None, relu, conv, stride=stride, padding=k // 2)
+    y32, y64, bound, reach = _layer_reference(x, w, scale, shift, None, relu, conv, stride=stride, padding=k // 2)
     res = torch.randn(y32.shape, generator=g) if relu != 2 else None
     if res is not None:
         y32, y64 = y32 + res, y64 + res.double()
@@ -135,7 +142,7 @@ def test_conv_split_two_piece_keeps_damage_local(dev, case, kd, cin, cout, shape
     om = ops.absmax_block(dev, zero=True)
     got = ops.conv_split_f16(x.permute(pin).contiguous().to(dev), ops.pack_conv_weight_split_f16(w.to(dev), stride), cout, None,
                              scale.to(dev), shift.to(dev), res.to(dev) if res is not None else None, relu, kd=kd, stride=stride, out_absmax=om)
-    _check(got, y32, y64, bound, f"conv_split {kd}D {cin}->{cout} s{stride} / {case}")
+    _check(got, y32, y64, bound, f"conv_split {kd}D {cin}->{cout} s{stride} / {case}", reach)
     assert (_fallbacks() - n0 > 0) == TAKES_FALLBACK[case]
 
 
@@ -150,11 +157,11 @@ def test_deconv_split_two_piece_keeps_damage_local(dev, case, cin, cout, shape):
     w = torch.randn(cin, cout, 3, 3, 3, generator=g) / (27 * cin / 8) ** 0.5
     scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
     res = torch.randn(B, 2 * D, 2 * H, 2 * W, cout, generator=g)
-    y32, y64, bound = _layer_reference(x, w, scale, shift, res, 1, F.conv_transpose3d, stride=2, padding=1, output_padding=1)
+    y32, y64, bound, reach = _layer_reference(x, w, scale, shift, res, 1, F.conv_transpose3d, stride=2, padding=1, output_padding=1)
     n0 = _fallbacks()
     got = ops.deconv_split_f16(x.permute(0, 2, 3, 4, 1).contiguous().to(dev), ops.pack_deconv_weight_split_f16(w.to(dev)), cout, None,
                                scale.to(dev), shift.to(dev), res.to(dev), True)
-    _check(got, y32, y64, bound, f"deconv {cin}->{cout} / {case}")
+    _check(got, y32, y64, bound, f"deconv {cin}->{cout} / {case}", reach)
     assert _fallbacks() - n0 > 0
 
 
@@ -167,11 +174,11 @@ def test_non_finite_weights_take_the_fp32_path(dev):
     w = torch.randn(16, 16, 3, 3, 3, generator=g) / 20
     w[5, 2, 1, 1, 1] = float("nan")
     one, zero = torch.ones(16), torch.zeros(16)
-    y32, y64, bound = _layer_reference(x, w, one, zero, None, 1, F.conv3d, padding=1)
+    y32, y64, bound, reach = _layer_reference(x, w, one, zero, None, 1, F.conv3d, padding=1)
     n0 = _fallbacks()
     got = ops.conv_split_f16(x.permute(0, 2, 3, 4, 1).contiguous().to(dev), ops.pack_conv_weight_split_f16(w.to(dev), 1), 16, None,
                              one.to(dev), zero.to(dev), None, 1)
-    assert _check(got, y32, y64, bound, "NaN weight") == x[0, 0].numel()       # the whole channel 5
+    assert _check(got, y32, y64, bound, "NaN weight") == x[0, 0].numel()       # the whole channel 5 (no input is non-finite: reach is empty)
     assert _fallbacks() - n0 > 0
 
 
