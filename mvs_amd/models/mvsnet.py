@@ -9,13 +9,15 @@ Module / parameter names equal the reference's, so `load_state_dict` accepts
 its checkpoints (including `module.`-prefixed DataParallel ones via
 `load_reference_checkpoint`).
 
-eval():  FeatureNet (PyTorch-ROCm) -> fused warp+variance (HIP, channels-last,
-         per-view volumes never materialised) -> CostRegNet as MFMA implicit-GEMM
-         3D convolutions with folded BatchNorm (HIP) -> fused softmax /
-         expectation / confidence (HIP).
-train(): same kernels for warp+variance and softmax-regression with their
-         hand-written backward kernels; CostRegNet runs through PyTorch-ROCm
-         autograd (batch-statistics BatchNorm), as does FeatureNet.
+eval():  FeatureNet on the HIP 2D kernels (fused head + split-operand MFMA layers, BatchNorm folded)
+         -> fused warp+variance (persistent LDS-DMA sweep kernel, per-view volumes never
+         materialised) -> CostRegNet as split-operand MFMA 3D convolutions with folded BatchNorm
+         (one C call, mvs_costreg_fwd2_f32) -> fused softmax / expectation / confidence.
+train(): every layer of FeatureNet and CostRegNet runs on the HIP kernels in both directions under
+         autograd (mvs_amd/train_ops.py: forward, input gradient, weight gradient; batch-statistics
+         BatchNorm + ReLU as one fused HIP op), warp+variance and softmax-regression with their
+         hand-written backward kernels; no MIOpen kernel is in a step.  PyTorch-ROCm layers remain as
+         A/B switches (feature_impl / train_feature_impl / train_impl = "torch").
 """
 import torch
 import torch.nn as nn
@@ -390,7 +392,10 @@ class MVSNet(nn.Module):
                 else:
                     f16 = torch.stack(feats)                            # [V,B,C,h,w]
                     f16 = f16.reshape(V, f16.shape[1], C // 16, 16, *f16.shape[3:]).permute(0, 1, 2, 4, 5, 3).contiguous()
-                if C == 32 and self.training and self.train_conv0_fused and ops.conv_split_enabled():
+                bn0 = self.cost_regularization.conv0.bn
+                # (the fused node hands over conv0's RAW output, which only the batch-statistics BatchNorm op consumes: a frozen
+                # conv0.bn -- model.train() followed by bn.eval(), or momentum=None -- takes the unfused layers)
+                if C == 32 and self.training and self.train_conv0_fused and ops.conv_split_enabled() and bn0.training and bn0.momentum is not None:
                     # warp + variance -> conv0 as one autograd node: the volume stays 8-channel blocked for the bf16 kernel
                     c0 = ops.variance_conv0_autograd(f16[0], f16[1:], rts, depth_values,
                                                      self.cost_regularization.conv0.conv.weight, self.align_corners)

@@ -19,23 +19,47 @@ import torch.nn.functional as F
 from . import ops
 
 
-_derived = {}
+import weakref
+
+_derived = {}           # eager use
+_derived_capture = {}   # while a HIP graph is being captured (see _cached)
+_capture_state = {"on": False}
 
 
 def _cached(weight, kind, make):
     """Tensors derived from a layer's weight (packed fragments, flipped / transposed / parity-class weights), made once
     per weight VERSION: a step uses each of them in the forward and the backward of every view, and re-deriving them
-    (a flip, a permute, a pack launch, ...) per use was hundreds of tiny launches per step.  Keyed on the storage, so
-    the optimizer's in-place update (which bumps _version) invalidates the entry."""
-    key = (weight.data_ptr(), tuple(weight.shape), kind)
-    hit = _derived.get(key)
-    if hit is not None and hit[0] == weight._version:
-        return hit[1]
+    (a flip, a permute, a pack launch, ...) per use was hundreds of tiny launches per step.
+
+    An entry belongs to ONE tensor object: it holds a weak reference to the weight and a hit needs `ref() is weight` and
+    the same `_version` (the storage address alone is recycled by the caching allocator when a model is freed
+    and another one built, with the same version count after the same init sequence); the entry goes when the weight does.
+    What bumps `_version` is an in-place op on the parameter itself (every torch optimizer's step).  Updates written
+    through `p.data` (`p.data.copy_()`, `p.data.add_()`: hand-made EMA / clipping code) do NOT -- call `invalidate_derived()`
+    after them.
+    While the stream is capturing a HIP graph the eager entries are not used: the graph must CONTAIN the kernels that
+    derive the packs from the weights it updates, or its replays would run with the packs of capture time.  Entries made
+    during a capture live in their own table (the forward and the backward of the captured step still share them) that is
+    dropped when the next capture begins."""
+    capturing = weight.is_cuda and torch.cuda.is_current_stream_capturing()
+    if capturing and not _capture_state["on"]:
+        _derived_capture.clear()
+    _capture_state["on"] = capturing
+    table = _derived_capture if capturing else _derived
+    key = (id(weight), kind)
+    hit = table.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version:
+        return hit[2]
     val = make()
-    if len(_derived) > 4096:
-        _derived.clear()
-    _derived[key] = (weight._version, val)
+    ref = weakref.ref(weight, lambda _r, k=key, t=table: t.pop(k, None))
+    table[key] = (ref, weight._version, val)
     return val
+
+
+def invalidate_derived():
+    """Drop every cached derived tensor (after weight updates that bypass autograd's version counter, e.g. `p.data.copy_()`)."""
+    _derived.clear()
+    _derived_capture.clear()
 
 
 class _Conv3dCL(torch.autograd.Function):

@@ -195,3 +195,30 @@ def test_flat_gradient_allreduce_gloo_world2():
     nb = net.feature.bias.numel()            # the last parameter: rank 1 contributed zeros for it
     grads[1][-nb:] = 0
     np.testing.assert_allclose(g0, (grads[0] + grads[1]) / 2, atol=1e-6)
+
+
+def test_derived_weight_cache_is_tied_to_the_tensor_object():
+    """mvs_amd.train_ops._cached: an entry is hit only by the SAME tensor object at the same version -- not by
+    another tensor that shares its storage address and shape (what the caching allocator hands a second model), not after
+    an in-place update; it disappears with the weight."""
+    import gc
+    import torch
+    from mvs_amd import train_ops
+    train_ops.invalidate_derived()
+    w = torch.nn.Parameter(torch.randn(4, 3))
+    calls = []
+    make = lambda: calls.append(1) or torch.zeros(1)
+    a = train_ops._cached(w, "k", make)
+    assert train_ops._cached(w, "k", make) is a and len(calls) == 1
+    alias = w.detach()                       # same data_ptr, same shape, same _version counter -- a different object
+    assert alias.data_ptr() == w.data_ptr()
+    train_ops._cached(alias, "k", make)
+    assert len(calls) == 2
+    with torch.no_grad():
+        w.add_(1.0)                          # what an optimizer step does: bumps _version
+    train_ops._cached(w, "k", make)
+    assert len(calls) == 3
+    n = len(train_ops._derived)
+    del w, alias, a
+    gc.collect()
+    assert len(train_ops._derived) < n       # the weakref callbacks evicted the entries
