@@ -79,7 +79,6 @@ constexpr int kPFlagLinearLanes = 1;   // tuning: lane = (x = lane & 15, y = lan
 constexpr int kPFlagNoStore = 2;       // tuning
 constexpr int kPFlagNoBlend = 4;       // tuning
 constexpr int kPFlagNoDma = 8;         // tuning (results are garbage)
-constexpr int kPFlagNoPlan = 16;       // tuning: every tile reuses the first tile's plan (garbage)
 constexpr int kPFlagNoTaps = 32;       // tuning: constant tap set (garbage)
 constexpr int kPFlagContiguous = 64;   // tuning: one contiguous, pixel-tile-major unit range per CU (round 2's first schedule)
 
@@ -117,6 +116,9 @@ __device__ __forceinline__ void tap_setup(const float *__restrict__ r, int cx, i
                                           int &tx0, int &ty0, bool &has) {
     float ix, iy, nw, ne, sw, se;
     bool x0ok, x1ok, y0ok, y1ok, fin;
+    // Branch-free on purpose (round 4): the clamp alone decides tx0 / ty0.  fmaxf drops a NaN (-> -4) and clamps +-Inf to an
+    // index outside the image, so a non-finite coordinate ends up with no tap in the image and NaN weights exactly as with the
+    // earlier `fin ? ... : -4` select -- whose exec-mask branch per view cost ~20 scalar instructions on every voxel.
     if constexpr (FAST) {
         const float fx = (float)cx, fy = (float)cy;
         const float rx = __fmaf_rn(r[0], fx, __fmaf_rn(r[1], fy, r[2]));
@@ -128,12 +130,12 @@ __device__ __forceinline__ void tap_setup(const float *__restrict__ r, int cx, i
         inv = __fmaf_rn(__fmaf_rn(-Z, inv, 1.0f), inv, inv);
         ix = __fmaf_rn(X * inv, sx, ox);
         iy = __fmaf_rn(Y * inv, sy, oy);
-        fin = (fabsf(ix) <= 3.0e38f) && (fabsf(iy) <= 3.0e38f);
+        fin = (fabsf(ix) <= 3.0e38f) & (fabsf(iy) <= 3.0e38f);
         const float x0f = floorf(ix), y0f = floorf(iy);
         const float wx = ix - x0f, wy = iy - y0f, ex = 1.0f - wx, ey = 1.0f - wy;
         nw = ey * ex; ne = ey * wx; sw = wy * ex; se = wy * wx;
-        tx0 = fin ? (int)fminf(fmaxf(x0f, -4.0f), (float)p.W + 4.0f) : -4;
-        ty0 = fin ? (int)fminf(fmaxf(y0f, -4.0f), (float)p.H + 4.0f) : -4;
+        tx0 = (int)fminf(fmaxf(x0f, -4.0f), (float)p.W + 4.0f);
+        ty0 = (int)fminf(fmaxf(y0f, -4.0f), (float)p.H + 4.0f);
         x0ok = (unsigned)tx0 < (unsigned)p.W; x1ok = (unsigned)(tx0 + 1) < (unsigned)p.W;
         y0ok = (unsigned)ty0 < (unsigned)p.H; y1ok = (unsigned)(ty0 + 1) < (unsigned)p.H;
     } else {
@@ -141,18 +143,16 @@ __device__ __forceinline__ void tap_setup(const float *__restrict__ r, int cx, i
         sweep_ray(r, (float)cx, (float)cy, rx, ry, rz);
         sweep_coord(r, rx, ry, rz, dv, p.half_w, p.half_h, p.unn_w, p.unn_h, p.align_corners, ix, iy);
         const Taps t = make_taps(ix, iy, p.H, p.W);
-        fin = (fabsf(ix) <= 3.0e38f) && (fabsf(iy) <= 3.0e38f);
+        fin = (fabsf(ix) <= 3.0e38f) & (fabsf(iy) <= 3.0e38f);
         nw = t.nw; ne = t.ne; sw = t.sw; se = t.se;
         x0ok = t.x0ok; x1ok = t.x1ok; y0ok = t.y0ok; y1ok = t.y1ok;
-        const float x0f = fminf(fmaxf(floorf(ix), -4.0f), (float)p.W + 4.0f);
-        const float y0f = fminf(fmaxf(floorf(iy), -4.0f), (float)p.H + 4.0f);
-        tx0 = fin ? (int)x0f : -4;
-        ty0 = fin ? (int)y0f : -4;
+        tx0 = (int)fminf(fmaxf(floorf(ix), -4.0f), (float)p.W + 4.0f);
+        ty0 = (int)fminf(fmaxf(floorf(iy), -4.0f), (float)p.H + 4.0f);
     }
     const float dead = fin ? 0.0f : __int_as_float(0x7fc00000);
-    wnw = (x0ok && y0ok) ? nw : dead; wne = (x1ok && y0ok) ? ne : dead;
-    wsw = (x0ok && y1ok) ? sw : dead; wse = (x1ok && y1ok) ? se : dead;
-    has = (x0ok || x1ok) && (y0ok || y1ok);
+    wnw = (x0ok & y0ok) ? nw : dead; wne = (x1ok & y0ok) ? ne : dead;
+    wsw = (x0ok & y1ok) ? sw : dead; wse = (x1ok & y1ok) ? se : dead;
+    has = (x0ok | x1ok) & (y0ok | y1ok);
 }
 
 // Cold path of the persistent kernel.  A wave of it that cannot serve its voxels from LDS -- a
@@ -398,28 +398,50 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
 
     // ---- the planned tile: the one whose copies are issued next
     int pdc, ptx, pty, pb, seg_end;
-    auto open_unit = [&]() {   // unit u -> its pixel tile and first chunk
-        const int sg = contiguous ? u % a.nseg : u / ptiles;
-        int qq = contiguous ? u / a.nseg : u - sg * ptiles;
-        ptx = qq % a.tiles_x; qq /= a.tiles_x;
-        pty = qq % a.tiles_y; pb = qq / a.tiles_y;
-        pdc = sg * a.cps;
-        seg_end = min(pdc + a.cps, a.nchunks);
+    struct TileIt { int u, dc, seg_end, tx, ty, b; };
+    auto it_open = [&](TileIt &t) {   // unit t.u -> its pixel tile and first chunk
+        const int sg = contiguous ? t.u % a.nseg : t.u / ptiles;
+        int qq = contiguous ? t.u / a.nseg : t.u - sg * ptiles;
+        t.tx = qq % a.tiles_x; qq /= a.tiles_x;
+        t.ty = qq % a.tiles_y; t.b = qq / a.tiles_y;
+        t.dc = sg * a.cps;
+        t.seg_end = min(t.dc + a.cps, a.nchunks);
+    };
+    auto it_advance = [&](TileIt &t) {   // -> false behind this workgroup's last tile
+        if (++t.dc < t.seg_end) return true;
+        t.u += u_step;
+        if (t.u >= u_end) return false;
+        it_open(t);
+        return true;
+    };
+    auto open_unit = [&]() {
+        TileIt t; t.u = u; it_open(t);
+        pdc = t.dc; ptx = t.tx; pty = t.ty; pb = t.b; seg_end = t.seg_end;
     };
     open_unit();
     int pbx0[NV], pby0[NV], pbw[NV], pbh[NV];
     unsigned pstaged = 0;
     unsigned soff[NV][NP];
     unsigned roff = 0;
+    int tcount = 0;     // index of the planned tile in this workgroup's sequence
 
-    auto plan = [&]() {
+    // The footprint boxes of a tile are the same for all its waves, so they are PLANNED ONCE PER WORKGROUP (round 4; every wave
+    // used to re-derive them for every tile: ~250 of a wave's ~2960 instructions per tile): in a round, wave w plans the w-th
+    // tile from `first` on and leaves (x0, y0, bw, bh | staged << 30) per view in slot (first_index + w) mod 2 NW of s_plan;
+    // load_plan() below picks a tile's entry up.  A round is written while the previous round's last tile is still being
+    // loaded, hence two rounds of slots; a barrier always lies between a slot's write and its first read.
+    __shared__ __attribute__((aligned(16))) int s_plan[2 * NW][NV][4];
+    auto plan_round = [&](TileIt t, int first_index) {
+        bool ok = true;
+        for (int i = 0; i < wv && ok; ++i) ok = it_advance(t);
+        if (!ok) return;
         const int v0 = min(lane >> 3, NV - 1), k = lane & 7;
-        const int xlo = ptx * kPW, xhi = min(xlo + kPW - 1, p.W - 1);
-        const int ylo = pty * kPH, yhi = min(ylo + kPH - 1, p.H - 1);
-        const int dlo = pdc * NW, dhi = min(dlo + NW - 1, p.D - 1);
-        const float *r = s_cam + (v0 * p.B + pb) * 12;
+        const int xlo = t.tx * kPW, xhi = min(xlo + kPW - 1, p.W - 1);
+        const int ylo = t.ty * kPH, yhi = min(ylo + kPH - 1, p.H - 1);
+        const int dlo = t.dc * NW, dhi = min(dlo + NW - 1, p.D - 1);
+        const float *r = s_cam + (v0 * p.B + t.b) * 12;
         const float cxk = (float)((k & 1) ? xhi : xlo), cyk = (float)((k & 2) ? yhi : ylo);
-        const float dk = s_depth[pb * p.D + ((k & 4) ? dhi : dlo)];
+        const float dk = s_depth[t.b * p.D + ((k & 4) ? dhi : dlo)];
         // Per depth plane pixel -> source is a homography, so (all Z > 0) the tile's image is
         // the convex hull of its corner images; along depth each coordinate is a Moebius
         // function of d, monotone between the extreme planes.  Approximate arithmetic is
@@ -440,25 +462,31 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
             lo_y = min(lo_y, __shfl_xor(lo_y, off)); hi_y = max(hi_y, __shfl_xor(hi_y, off));
             bad |= __shfl_xor(bad, off);
         }
+        // one texel beyond the image on every side stays in the box, so a tap pair that
+        // straddles the border is addressed like any other
+        int x0 = max(lo_x, -1), x1 = min(hi_x, p.W), y0 = max(lo_y, -1), y1 = min(hi_y, p.H);
+        if (x1 <= x0 || y1 <= y0) { x0 = 0; y0 = 0; x1 = 1; y1 = 1; }   // nothing of this view in sight
+        const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
+        const int staged = (!bad && bw * bh <= cap) ? 1 : 0;
+        if (k == 0 && (lane >> 3) < NV)
+            *reinterpret_cast<int4 *>(&s_plan[(first_index + wv) & (2 * NW - 1)][lane >> 3][0]) = make_int4(x0, y0, bw, bh | (staged << 30));
+    };
+    // the planned tile's entry -> the box scalars, the staged-view mask and this wave's per-lane source offsets
+    auto load_plan = [&]() {
         pstaged = 0;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            // one texel beyond the image on every side stays in the box, so a tap pair that
-            // straddles the border is addressed like any other
-            int x0 = max(__builtin_amdgcn_readlane(lo_x, v * 8), -1);
-            int x1 = min(__builtin_amdgcn_readlane(hi_x, v * 8), p.W);
-            int y0 = max(__builtin_amdgcn_readlane(lo_y, v * 8), -1);
-            int y1 = min(__builtin_amdgcn_readlane(hi_y, v * 8), p.H);
-            const int vbad = __builtin_amdgcn_readlane(bad, v * 8);
-            if (x1 <= x0 || y1 <= y0) { x0 = 0; y0 = 0; x1 = 1; y1 = 1; }   // nothing of this view in sight
-            pbx0[v] = x0; pby0[v] = y0; pbw[v] = x1 - x0 + 1; pbh[v] = y1 - y0 + 1;
-            if (!vbad && pbw[v] * pbh[v] <= cap) pstaged |= 1u << v;
-            const float rb = __builtin_amdgcn_rcpf((float)pbw[v]);
+            const int4 e = *reinterpret_cast<const int4 *>(&s_plan[tcount & (2 * NW - 1)][v][0]);
+            const int x0 = __builtin_amdgcn_readfirstlane(e.x), y0 = __builtin_amdgcn_readfirstlane(e.y);
+            const int bw = __builtin_amdgcn_readfirstlane(e.z), bhs = __builtin_amdgcn_readfirstlane(e.w);
+            pbx0[v] = x0; pby0[v] = y0; pbw[v] = bw; pbh[v] = bhs & 0xffff;
+            pstaged |= (unsigned)(bhs >> 30) << v;
+            const float rb = __builtin_amdgcn_rcpf((float)bw);
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 const int t = (mj + i * WQ) * 64 + lane;
                 const int tyy = (int)(((float)t + 0.5f) * rb);      // t / bw (t < 2^10: exact)
-                const int txx = t - __mul24(tyy, pbw[v]);
+                const int txx = t - __mul24(tyy, bw);
                 const int sxx = min(max(x0 + txx, 0), p.W - 1), syy = min(max(y0 + tyy, 0), p.H - 1);
                 soff[v][i] = (unsigned)(__mul24(syy, p.W) + sxx) * tstride;
             }
@@ -497,7 +525,12 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
             glds16_buf(roff, srd_ref, boff, lds_base + buf_off + kRefOff + (unsigned)kq * 1024u);
     };
 
-    plan();
+    {
+        TileIt t0; t0.u = u; it_open(t0);
+        plan_round(t0, 0);
+    }
+    __syncthreads();
+    load_plan();
     issue_dma(0, 0u);
     unsigned buf_off = 0;
     const float rV = 1.0f / p.fV;
@@ -536,7 +569,7 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
                 tap_setup<FAST>(s_cam + (v * p.B + cb) * 12, cx, cy, dv, p, a.sx, a.ox, a.sy, a.oy,
                                 wnw[v], wne[v], wsw[v], wse[v], tx0, ty0, has);
                 const int bx0 = pbx0[v], by0 = pby0[v], bw = pbw[v], bh = pbh[v];
-                const bool inbox = !has || (tx0 >= bx0 && tx0 + 1 < bx0 + bw && ty0 >= by0 && ty0 + 1 < by0 + bh);
+                const bool inbox = !has | ((tx0 >= bx0) & (tx0 + 1 < bx0 + bw) & (ty0 >= by0) & (ty0 + 1 < by0 + bh));
                 if (__all(inbox)) win |= 1u << v;
                 const int ccx = min(max(tx0, bx0), bx0 + bw - 2) - bx0;
                 const int ccy = min(max(ty0, by0), by0 + bh - 2) - by0;
@@ -563,12 +596,17 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
             // this loop and held in registers
 #pragma unroll
             for (int v = 0; v < NV; ++v) asm volatile("" : "+v"(aoff[v]));
-            if (last && has_next) {   // plan the next tile before the barrier: off the critical path
+            if (last && has_next) {   // the next tile's plan before the barrier: off the critical path
                 if (++pdc == seg_end) {
                     u += u_step;
                     open_unit();
                 }
-                if (!(a.flags & kPFlagNoPlan)) plan();
+                ++tcount;
+                load_plan();
+                if ((tcount & (NW - 1)) == NW - 1) {   // the last tile of a round is planned: now the next round's (a barrier before their first use)
+                    TileIt t; t.u = u; t.dc = pdc; t.seg_end = seg_end; t.tx = ptx; t.ty = pty; t.b = pb;
+                    if (it_advance(t)) plan_round(t, tcount + 1);
+                }
             }
             // This stage's copies have landed (vector memory retires in order: at most the NST
             // stores issued behind them are still in flight -- waiting for those too would put a
