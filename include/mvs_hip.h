@@ -386,6 +386,19 @@ int mvs_bn_train_bwd_f32(const float *grad_y, const float *x, const float *weigh
                          const float *save_mean, const float *save_invstd, int64_t N, int C, int relu,
                          float *grad_x, float *grad_weight, float *grad_bias, void *workspace,
                          size_t workspace_bytes, void *stream);
+/* The same with GROUPS: x is G consecutive blocks of N rows, each normalised with its OWN batch statistics (save_mean /
+ * save_invstd: [G][C]) -- the reference calls FeatureNet once per view (mvsnet.py:146 `[self.feature(img) for img in imgs]`),
+ * so a batch of views [V*B, h, w, C] in one launch is V groups.  The running statistics take the groups in order, one
+ * momentum update each, and num_batches_tracked grows by G: exactly what G separate calls leave behind.  grad_weight /
+ * grad_bias are the sums over the groups.  1 <= G <= 16; the workspace is that of mvs_bn_train_workspace_bytes. */
+int mvs_bn_train_fwd_groups_f32(const float *x, const float *weight, const float *bias, const float *skip, int G,
+                                int64_t N, int C, float eps, float momentum, int relu, float *running_mean,
+                                float *running_var, long long *num_batches_tracked, float *save_mean,
+                                float *save_invstd, float *y, void *workspace, size_t workspace_bytes, void *stream);
+int mvs_bn_train_bwd_groups_f32(const float *grad_y, const float *x, const float *weight, const float *bias,
+                                const float *save_mean, const float *save_invstd, int G, int64_t N, int C, int relu,
+                                float *grad_x, float *grad_weight, float *grad_bias, void *workspace,
+                                size_t workspace_bytes, void *stream);
 
 /* Per-pixel depth hypotheses of a cascade stage after the first (CasMVSNet/models/cas_mvsnet.py:129-152
  * + get_cur_depth_range_samples, module.py:485-502): prev_depth [B,hp,wp] (the previous stage's depth

@@ -86,6 +86,9 @@ _SIGS = {
     "mvs_bn_train_fwd_f32": (_c_i, [_c_f] * 4 + [_c_l, _c_i, ctypes.c_float, ctypes.c_float, _c_i] + [_c_f] * 7
                              + [ctypes.c_size_t, _c_f]),
     "mvs_bn_train_bwd_f32": (_c_i, [_c_f] * 6 + [_c_l, _c_i, _c_i] + [_c_f] * 4 + [ctypes.c_size_t, _c_f]),
+    "mvs_bn_train_fwd_groups_f32": (_c_i, [_c_f] * 4 + [_c_i, _c_l, _c_i, ctypes.c_float, ctypes.c_float, _c_i] + [_c_f] * 7
+                                    + [ctypes.c_size_t, _c_f]),
+    "mvs_bn_train_bwd_groups_f32": (_c_i, [_c_f] * 6 + [_c_i, _c_l, _c_i, _c_i] + [_c_f] * 4 + [ctypes.c_size_t, _c_f]),
     "mvs_cas_depth_hypotheses_f32": (_c_i, [_c_f] + [_c_i] * 8 + [ctypes.c_float, _c_f, _c_f]),
     "mvs_geo_consistency_f32": (_c_i, [_c_f] * 3 + [_c_i] * 3 + [_c_f] * 6),
     "mvs_cvp_interval_sum_f64": (_c_i, [_c_f, _c_f, _c_i, _c_i, ctypes.c_double, _c_f, _c_f]),

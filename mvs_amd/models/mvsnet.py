@@ -82,14 +82,17 @@ class FeatureNet(nn.Module):
     def hip_supported(self):
         return all(p["packed"] is not None for p in self._hip_params())
 
-    def forward_train_hip(self, img_nchw):
+    def forward_train_hip(self, img_nchw, groups=1):
         """Autograd path on the HIP 2D kernels, forward and both gradients (mvs_amd/train_ops.py: no MIOpen):
-        [N,3,H,W] -> [N,H/4,W/4,32] channels-last, batch-statistics BatchNorm (fused HIP op) as in forward()."""
+        [N,3,H,W] -> [N,H/4,W/4,32] channels-last, batch-statistics BatchNorm (fused HIP op) as in forward().
+        groups: the N images are that many consecutive blocks (the V views of a sample batch, view-major), each normalised
+        with its own batch statistics and counted as one update of the running statistics -- the reference's V calls
+        `self.feature(imgs[:, v])` (mvsnet.py:146) as ONE launch per layer (round 4: a third of the launches of a step)."""
         from ..train_ops import conv2d_bn_relu_cl, conv2d_cl
-        x = conv2d_bn_relu_cl(img_nchw, self.conv0.conv, self.conv0.bn, 1, planar=True)
+        x = conv2d_bn_relu_cl(img_nchw, self.conv0.conv, self.conv0.bn, 1, planar=True, groups=groups)
         for name, stride in self._PLAN[1:]:
             m = getattr(self, name)
-            x = conv2d_bn_relu_cl(x, m.conv, m.bn, stride)
+            x = conv2d_bn_relu_cl(x, m.conv, m.bn, stride, groups=groups)
         return conv2d_cl(x, self.feature.weight, 1) + self.feature.bias      # [N,H/4,W/4,32] channels-last
 
     def forward_train_cl(self, img_nchw):
@@ -329,6 +332,9 @@ class MVSNet(nn.Module):
         # gradient (mvs_amd.train_ops.conv2d_cl) + the fused HIP BatchNorm/ReLU; "torch_cl" = MIOpen's NHWC 2D
         # kernels + the fused HIP BatchNorm/ReLU (A/B); "torch" = plain nn modules
         self.train_feature_impl = "hip"
+        # True: the V per-view FeatureNet calls of a training step run as ONE batch with per-view BatchNorm statistics
+        # (FeatureNet.forward_train_hip(groups=V)); False: V calls, as the reference's loop (A/B)
+        self.train_feature_batched = True
         self._feature_cl = False
         self.feature = FeatureNet()
         self.cost_regularization = CostRegNet()
@@ -366,9 +372,16 @@ class MVSNet(nn.Module):
             with ops.stage("feature"):
                 # per-view calls: BatchNorm batch statistics are per call in the
                 # reference (mvsnet.py:146)
-                feats_cl = None
+                feats_cl = feats_stacked = None
                 if self.train_feature_impl == "hip" and self.feature.hip_supported():
-                    feats_cl = [self.feature.forward_train_hip(imgs[:, v]) for v in range(V)]   # [B,h,w,C]
+                    if self.train_feature_batched:
+                        # the V per-view calls as one batch of V groups (view-major): per-view BatchNorm statistics, one launch per layer
+                        Bn = imgs.shape[0]
+                        fall = self.feature.forward_train_hip(imgs.transpose(0, 1).reshape(V * Bn, *imgs.shape[2:]), groups=V)
+                        feats_stacked = fall.reshape(V, Bn, *fall.shape[1:])                           # [V,B,h,w,C]
+                        feats_cl = list(feats_stacked.unbind(0))
+                    else:
+                        feats_cl = [self.feature.forward_train_hip(imgs[:, v]) for v in range(V)]   # [B,h,w,C]
                     feats = [f.permute(0, 3, 1, 2) for f in feats_cl]
                 elif self.train_feature_impl == "torch_cl" and self.feature.training:
                     if not self._feature_cl:   # weights in NHWC once, not re-laid-out by every conv2d call
@@ -387,7 +400,7 @@ class MVSNet(nn.Module):
                 # autograd graph) -> DMA sweep kernel -> [B,D,h,w,C] for the conv kernels;
                 # backward on the LDS-accumulating kernel
                 if feats_cl is not None:
-                    f16 = torch.stack(feats_cl)                         # [V,B,h,w,C]
+                    f16 = feats_stacked if feats_stacked is not None else torch.stack(feats_cl)   # [V,B,h,w,C]
                     f16 = f16.reshape(*f16.shape[:4], C // 16, 16).permute(0, 1, 4, 2, 3, 5).contiguous()
                 else:
                     f16 = torch.stack(feats)                            # [V,B,C,h,w]

@@ -1375,10 +1375,12 @@ class _BnReluCL(torch.autograd.Function):
     (mvs_bn_train_fwd_f32 / mvs_bn_train_bwd_f32); running statistics are updated in place."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, skip, running_mean, running_var, nbt, momentum, eps, relu):
+    def forward(ctx, x, weight, bias, skip, running_mean, running_var, nbt, momentum, eps, relu, groups=1):
         x = _f32c(x)
         C = x.shape[-1]
-        N = x.numel() // C
+        if x.shape[0] % groups:
+            raise MvsHipError(f"bn_relu_cl: leading dimension {x.shape[0]} is not a multiple of groups={groups}")
+        N = x.numel() // C // groups        # rows of one group
         lib = _lib.load()
         nbytes = int(lib.mvs_bn_train_workspace_bytes(C))
         if nbytes == 0:
@@ -1386,16 +1388,16 @@ class _BnReluCL(torch.autograd.Function):
         ws = torch.empty((nbytes // 4,), device=x.device, dtype=torch.float32)
         w, b = _f32c(weight.detach()), _f32c(bias.detach())
         sk = _f32c(skip) if skip is not None else None
-        mean = torch.empty((C,), device=x.device, dtype=torch.float32)
+        mean = torch.empty((groups, C), device=x.device, dtype=torch.float32)
         invstd = torch.empty_like(mean)
         y = torch.empty_like(x)
-        check(lib.mvs_bn_train_fwd_f32(ptr(x), ptr(w), ptr(b), ptr(sk), N, C, float(eps), float(momentum), int(relu),
-                                       ptr(running_mean), ptr(running_var),
-                                       ctypes.c_void_p(nbt.data_ptr()) if nbt is not None else None,
-                                       ptr(mean), ptr(invstd), ptr(y),
-                                       ptr(ws), nbytes, stream()), "mvs_bn_train_fwd_f32")
+        check(lib.mvs_bn_train_fwd_groups_f32(ptr(x), ptr(w), ptr(b), ptr(sk), int(groups), N, C, float(eps), float(momentum),
+                                              int(relu), ptr(running_mean), ptr(running_var),
+                                              ctypes.c_void_p(nbt.data_ptr()) if nbt is not None else None,
+                                              ptr(mean), ptr(invstd), ptr(y),
+                                              ptr(ws), nbytes, stream()), "mvs_bn_train_fwd_groups_f32")
         ctx.save_for_backward(x, w, b, mean, invstd)
-        ctx.relu, ctx.has_skip = int(relu), skip is not None
+        ctx.relu, ctx.has_skip, ctx.groups = int(relu), skip is not None, int(groups)
         ctx.mark_non_differentiable(*[t for t in (running_mean, running_var, nbt) if t is not None])
         return y
 
@@ -1404,24 +1406,27 @@ class _BnReluCL(torch.autograd.Function):
         x, w, b, mean, invstd = ctx.saved_tensors
         gy = _f32c(gy)
         C = x.shape[-1]
-        N = x.numel() // C
+        N = x.numel() // C // ctx.groups
         lib = _lib.load()
         nbytes = int(lib.mvs_bn_train_workspace_bytes(C))
         ws = torch.empty((nbytes // 4,), device=x.device, dtype=torch.float32)
         gx = torch.empty_like(x)
         gw, gb = torch.empty_like(w), torch.empty_like(b)
-        check(lib.mvs_bn_train_bwd_f32(ptr(gy), ptr(x), ptr(w), ptr(b), ptr(mean), ptr(invstd), N, C, ctx.relu,
-                                       ptr(gx), ptr(gw), ptr(gb), ptr(ws), nbytes, stream()), "mvs_bn_train_bwd_f32")
-        return gx, gw, gb, (gy if ctx.has_skip else None), None, None, None, None, None, None
+        check(lib.mvs_bn_train_bwd_groups_f32(ptr(gy), ptr(x), ptr(w), ptr(b), ptr(mean), ptr(invstd), ctx.groups, N, C, ctx.relu,
+                                              ptr(gx), ptr(gw), ptr(gb), ptr(ws), nbytes, stream()), "mvs_bn_train_bwd_groups_f32")
+        return gx, gw, gb, (gy if ctx.has_skip else None), None, None, None, None, None, None, None
 
 
-def bn_relu_cl(x, bn, relu=True, skip=None):
+def bn_relu_cl(x, bn, relu=True, skip=None, groups=1):
     """relu(bn(x)) [+ skip] with batch statistics for a channels-last tensor [..., C] and an
-    nn.BatchNorm module in training mode (momentum must be a number, affine + running stats)."""
+    nn.BatchNorm module in training mode (momentum must be a number, affine + running stats).
+    groups: x[0] splits into that many consecutive blocks, each normalised with its OWN statistics; the running statistics are
+    updated once per block, in order -- what `groups` separate calls of the module would do (the reference's per-view FeatureNet
+    calls, mvsnet.py:146, as one batch)."""
     if bn.momentum is None or bn.weight is None:
         raise MvsHipError("bn_relu_cl: needs an affine BatchNorm with a numeric momentum")
     return _BnReluCL.apply(x, bn.weight, bn.bias, skip, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                           bn.momentum, bn.eps, relu)
+                           bn.momentum, bn.eps, relu, groups)
 
 
 def fpn_tail_supported(H, W):

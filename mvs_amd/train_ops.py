@@ -264,15 +264,19 @@ def conv2d_cl(x, weight, stride=1, planar=False):
     return _Conv2dCL.apply(x, weight, stride, planar)
 
 
-def conv2d_bn_relu_cl(x, conv, bn, stride=1, planar=False):
+def conv2d_bn_relu_cl(x, conv, bn, stride=1, planar=False, groups=1):
     """ConvBnReLU of the reference (module.py:6-13) in channels-last: the HIP convolution + the fused HIP BatchNorm
-    (batch statistics when bn.training, running statistics updated) + ReLU."""
+    (batch statistics when bn.training, running statistics updated) + ReLU.  groups: the images of x are that many
+    consecutive blocks (views), each with its own batch statistics -- `groups` calls of the reference's module as one."""
     y = conv2d_cl(x, conv.weight, stride, planar)
     C = y.shape[-1]
     if bn.training and C in (8, 16, 32, 64) and bn.momentum is not None and bn.weight is not None:
-        return ops.bn_relu_cl(y, bn)
-    y2 = F.batch_norm(y.reshape(-1, C), bn.running_mean, bn.running_var, bn.weight, bn.bias,
-                      bn.training, bn.momentum, bn.eps)
-    if bn.training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
-    return F.relu(y2).reshape(y.shape)
+        return ops.bn_relu_cl(y, bn, groups=groups)
+    outs = []
+    for yg in y.chunk(groups, 0):       # torch ops: one module call per group, as the reference
+        y2 = F.batch_norm(yg.reshape(-1, C), bn.running_mean, bn.running_var, bn.weight, bn.bias,
+                          bn.training, bn.momentum, bn.eps)
+        if bn.training and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+        outs.append(F.relu(y2).reshape(yg.shape))
+    return outs[0] if groups == 1 else torch.cat(outs, 0)

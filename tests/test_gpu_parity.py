@@ -1236,6 +1236,60 @@ def test_bn_relu_fused_vs_torch(dev, C, shape, with_skip):
     assert int(bn.num_batches_tracked) == int(bn_ref.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("C,groups,shape", [(8, 3, (3, 9, 21)), (16, 3, (6, 5, 10)), (32, 5, (5, 4, 7)), (8, 2, (4, 64, 80))])
+def test_bn_relu_groups_equal_separate_calls(dev, C, groups, shape):
+    """The grouped form of the fused BatchNorm (a batch of views in one launch, per-view statistics: the reference's
+    `[self.feature(img) for img in imgs]`, mvsnet.py:146) against `groups` separate calls of nn.BatchNorm2d under autograd:
+    output, all gradients (the weight / bias gradients are the sums over the calls), running statistics after the calls IN
+    ORDER, num_batches_tracked."""
+    import copy
+    import torch.nn.functional as F
+    from mvs_amd import ops
+    g = torch.Generator(device=dev).manual_seed(C * 10 + groups)
+    x = (torch.randn(*shape, C, device=dev, generator=g) * torch.linspace(0.5, 3.0, shape[0], device=dev).view(-1, 1, 1, 1) + 1.5).requires_grad_(True)
+    go = torch.randn(*shape, C, device=dev, generator=g)
+    bn = torch.nn.BatchNorm2d(C).to(dev).train()
+    with torch.no_grad():
+        bn.weight.copy_(0.5 + torch.rand(C, device=dev, generator=g))
+        bn.bias.copy_(torch.randn(C, device=dev, generator=g) * 0.3)
+    bn_ref = copy.deepcopy(bn)
+    y = ops.bn_relu_cl(x, bn, True, None, groups=groups)
+    y.backward(go)
+    xr = x.detach().clone().requires_grad_(True)
+    yr = torch.cat([F.relu(bn_ref(c.permute(0, 3, 1, 2))).permute(0, 2, 3, 1) for c in xr.chunk(groups, 0)], 0)
+    yr.backward(go)
+    for a, b in zip([y.detach(), x.grad, bn.weight.grad, bn.bias.grad], [yr.detach(), xr.grad, bn_ref.weight.grad, bn_ref.bias.grad]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-5 * float(b.abs().max()) + 1e-6, rtol=1e-4)
+    np.testing.assert_allclose(bn.running_mean.cpu().numpy(), bn_ref.running_mean.cpu().numpy(), atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), bn_ref.running_var.cpu().numpy(), atol=1e-6, rtol=1e-5)
+    assert int(bn.num_batches_tracked) == int(bn_ref.num_batches_tracked) == groups
+
+
+def test_featurenet_train_batched_views_equal_per_view_calls(dev, weights):
+    """FeatureNet.forward_train_hip(groups=V) -- the V views of a training sample as one batch per layer -- against V per-view
+    calls of the same path: features, the gradients of every parameter, running statistics."""
+    import copy
+    from mvs_amd.models import MVSNet
+    sd = {k: torch.from_numpy(v) for k, v in weights.items()}
+    net = MVSNet(refine=False)
+    net.load_state_dict(sd)
+    fa = net.feature.to(dev).train()
+    fb = copy.deepcopy(fa)
+    g = torch.Generator(device=dev).manual_seed(4)
+    V, B, H, W = 3, 2, 64, 96
+    imgs = torch.rand(B, V, 3, H, W, device=dev, generator=g)
+    go = torch.randn(V * B, H // 4, W // 4, 32, device=dev, generator=g)
+    ya = fa.forward_train_hip(imgs.transpose(0, 1).reshape(V * B, 3, H, W), groups=V)
+    ya.backward(go)
+    yb = torch.cat([fb.forward_train_hip(imgs[:, v].contiguous()) for v in range(V)], 0)
+    yb.backward(go)
+    np.testing.assert_allclose(ya.detach().cpu().numpy(), yb.detach().cpu().numpy(), atol=1e-5, rtol=1e-5)
+    for (n, pa), (_, pb) in zip(fa.named_parameters(), fb.named_parameters()):
+        np.testing.assert_allclose(pa.grad.cpu().numpy(), pb.grad.cpu().numpy(), atol=2e-4 * float(pb.grad.abs().max()) + 1e-7, rtol=1e-3, err_msg=n)
+    for (n, ba), (_, bb) in zip(fa.named_buffers(), fb.named_buffers()):
+        np.testing.assert_allclose(ba.float().cpu().numpy(), bb.float().cpu().numpy(), atol=1e-6, rtol=1e-5, err_msg=n)
+
+
 @pytest.mark.parametrize("cin,shape", [(16, (2, 18, 26)), (8, (1, 40, 72))])
 def test_conv2d_fused_upsample_add(dev, cin, shape):
     """FPN top-down step fused into the lateral 1x1 convolution: conv(x) + nearest_x2(coarse)
