@@ -63,7 +63,7 @@ extern "C" {
 #define MVS_LAYOUT_C8 2
 #define MVS_LAYOUT_C16 3
 #define MVS_LAYOUT_C4 4
-#define MVS_LAYOUT_C8H 5 /* fp16 pairs of an 8-channel-blocked volume: see mvs_conv3d_c8h_f16x3_f32 */
+#define MVS_LAYOUT_C8H 5 /* fp16 pairs of an 8-channel-blocked volume: tuning builds only, include/mvs_hip_tuning.h */
 
 /* Library version: major*10000 + minor*100 + patch. */
 int mvs_version(void);
@@ -246,20 +246,6 @@ int mvs_absmax_f32(const float *x, int64_t n, void *absmax, void *stream);
 int mvs_conv3d_c8_f16x3_f32(const float *in, const void *in_absmax, const void *packed, const float *scale,
                             const float *shift, const float *residual, int relu, int B, int Cin, int D, int H, int W,
                             float *out, void *out_absmax, void *stream);
-
-/* ... and on a volume that ARRIVES as fp16 pairs (MVS_LAYOUT_C8H: [B,D,H,C/8, part (hi, lo), parity (x & 1), ceil(W/2), 8 fp16],
- * mvs_c8h_bytes(B, C, D, H, W) bytes -- 4 per element like the fp32 volume): the producer has scaled every value by
- * 2^(14 - exponent(max of the absmax block)) and split it, so the kernel has no fp32 staging buffer, no split pass and one
- * barrier per step instead of two (mvs_amd/csrc/conv_f16x3_pairs.hip); results are bit-identical to mvs_conv3d_c8_f16x3_f32 on
- * the fp32 volume with the same block.  in_absmax = the block the producer scaled by -- it must BOUND the data (a larger bound
- * costs range in the lo piece only: an element below 2^-18 of the bound keeps an absolute error below 2^-40 of the bound).
- * Producers: mvs_costvol_variance_fwd_ws2_f32 with out_layout MVS_LAYOUT_C8H (the block is then an INPUT: the bound of the
- * variance, e.g. the square of the feature maps' largest magnitude), or mvs_c8_to_c8h_f32 from an fp32 MVS_LAYOUT_C8 volume. */
-size_t mvs_c8h_bytes(int B, int C, int D, int H, int W);
-int mvs_c8_to_c8h_f32(const float *in_c8, const void *absmax, int B, int C, int D, int H, int W, void *out_pairs, void *stream);
-int mvs_conv3d_c8h_f16x3_f32(const void *in_pairs, const void *in_absmax, const void *packed, const float *scale,
-                             const float *shift, const float *residual, int relu, int B, int Cin, int D, int H, int W,
-                             float *out, void *out_absmax, void *stream);
 
 /* The same split-operand arithmetic for the 3x3(x3), stride-1, pad-1 layers with 16 / 32 / 64 input and output
  * channels (CostRegNet conv2 / conv4 / conv6, mvsnet.py:68-72; FeatureNet's 16 -> 16 and 32 -> 32 layers,

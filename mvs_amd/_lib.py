@@ -57,9 +57,6 @@ _SIGS = {
     "mvs_absmax_f32": (_c_i, [_c_f, _c_l, _c_f, _c_f]),
     "mvs_guard_fallback_count": (_c_i, [ctypes.POINTER(ctypes.c_ulonglong)]),
     "mvs_conv3d_c8_f16x3_f32": (_c_i, [_c_f] * 6 + [_c_i] * 6 + [_c_f, _c_f, _c_f]),
-    "mvs_c8h_bytes": (ctypes.c_size_t, [_c_i] * 5),
-    "mvs_c8_to_c8h_f32": (_c_i, [_c_f, _c_f] + [_c_i] * 5 + [_c_f, _c_f]),
-    "mvs_conv3d_c8h_f16x3_f32": (_c_i, [_c_f] * 6 + [_c_i] * 6 + [_c_f, _c_f, _c_f]),
     "mvs_conv_split_supported": (_c_i, [_c_i] * 4),
     "mvs_conv_split_packed_bytes": (ctypes.c_size_t, [_c_i] * 4),
     "mvs_conv_split_pack_weights_f32": (_c_i, [_c_f] + [_c_i] * 4 + [_c_f, _c_f]),
@@ -115,6 +112,14 @@ _SIGS = {
     "mvs_softmax_regress_bwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_f] + [_c_i] * 4 + [_c_f, _c_f]),
 }
 
+# only in the tuning build (include/mvs_hip_tuning.h; MVS_HIP_TUNING=1 loads libmvs_hip_tuning.so)
+_TUNING_SIGS = {
+    "mvs_c8h_bytes": (ctypes.c_size_t, [_c_i] * 5),
+    "mvs_c8_to_c8h_f32": (_c_i, [_c_f, _c_f] + [_c_i] * 5 + [_c_f, _c_f]),
+    "mvs_conv3d_c8h_f16x3_f32": (_c_i, [_c_f] * 6 + [_c_i] * 6 + [_c_f, _c_f, _c_f]),
+}
+
+
 class ConvLayer(ctypes.Structure):
     """mvs_conv_layer of include/mvs_hip.h"""
     _fields_ = [("weight", ctypes.c_void_p), ("packed", ctypes.c_void_p),
@@ -141,7 +146,10 @@ def load():
             f"{path} not found: build it with `python -m mvs_amd.build` (hipcc, gfx950). "
             "mvs_amd has no CPU or PyTorch fallback for the cost-volume path.")
     lib = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
-    for name, (res, args) in _SIGS.items():
+    sigs = dict(_SIGS)
+    if path != LIB_PATH:
+        sigs.update(_TUNING_SIGS)
+    for name, (res, args) in sigs.items():
         fn = getattr(lib, name)  # AttributeError here = ABI drift, fail loudly
         fn.restype = res
         fn.argtypes = args
@@ -151,6 +159,11 @@ def load():
 
 def exported_symbols():
     return sorted(_SIGS)
+
+
+def tuning_build_loaded():
+    """True when the library in this process is the -DMVS_TUNING build (it also exports include/mvs_hip_tuning.h)."""
+    return os.environ.get("MVS_HIP_TUNING") == "1"
 
 
 def check(rc, what):

@@ -16,9 +16,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(CSRC, "libmvs_hip.so")
-SOURCES = ("capi", "sweep", "sweep_persist", "regress", "conv3d_direct", "conv3d_mfma", "costreg", "conv_bf16x6", "conv_f16x3", "conv_f16x3_pairs", "conv_split", "deconv_split", "conv2d_mfma", "feature_head", "fpn_tail", "conv3d_wgrad", "conv2d_wgrad", "bnorm", "cas_hypo", "geo_filter", "cvp_hypo", "cvp_glue", "imgprep", "fusibile", "camera")
+SOURCES = ("capi", "sweep", "sweep_persist", "regress", "conv3d_direct", "conv3d_mfma", "costreg", "conv_bf16x6", "conv_f16x3", "conv_split", "deconv_split", "conv2d_mfma", "feature_head", "fpn_tail", "conv3d_wgrad", "conv2d_wgrad", "bnorm", "cas_hypo", "geo_filter", "cvp_hypo", "cvp_glue", "imgprep", "fusibile", "camera")
+# experiments kept with their tests, compiled into the tuning build only (dead weight in the release .so)
+TUNING_SOURCES = ("conv_f16x3_pairs",)
 HEADERS = (os.path.join(CSRC, "mvs_common.h"), os.path.join(CSRC, "sweep_common.h"), os.path.join(CSRC, "conv_persistent.h"), os.path.join(CSRC, "conv_split_common.h"), os.path.join(CSRC, "conv_guard.h"),
-           os.path.join(os.path.dirname(HERE), "include", "mvs_hip.h"))
+           os.path.join(os.path.dirname(HERE), "include", "mvs_hip_tuning.h"), os.path.join(os.path.dirname(HERE), "include", "mvs_hip.h"))
 # -ffp-contract=off: the plane-sweep coordinate arithmetic places its FMAs by
 # hand to match the reference bit for bit; everything else uses fmaf/MFMA.
 # -fno-slp-vectorize: v_pk_fma_f32 retires two results in 5-7 cycles (scripts/micro/pk_fma.hip), no
@@ -52,7 +54,8 @@ def build(force=False, verbose=False, tuning=False):
     os.makedirs(obj_dir, exist_ok=True)
     cc = hipcc()
     jobs = []
-    for name in SOURCES:
+    sources = SOURCES + (TUNING_SOURCES if tuning else ())
+    for name in sources:
         src = os.path.join(CSRC, name + ".hip")
         obj = os.path.join(obj_dir, name + ".o")
         if force or _stale(obj, (src,) + HEADERS):
@@ -70,7 +73,7 @@ def build(force=False, verbose=False, tuning=False):
         for warn in ex.map(run, jobs):
             if verbose and warn.strip():
                 print(warn)
-    objs = [os.path.join(obj_dir, n + ".o") for n in SOURCES]
+    objs = [os.path.join(obj_dir, n + ".o") for n in sources]
     if force or jobs or _stale(lib, objs):
         run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
     return lib

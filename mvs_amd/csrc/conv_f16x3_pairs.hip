@@ -14,6 +14,7 @@
 // reads, what step s + 1 adds and what step s + 2 adds (6 + 6 + 6 in the worst case, single-tile groups).
 // LDS: 2 x 18 KiB weights + 2 parts x 2 parities x 18 slots x (6 rows x 17 voxels x 16 B) = 151 KiB.
 #include "conv_split_common.h"
+#include "../../include/mvs_hip_tuning.h"
 
 #include <cstdlib>
 

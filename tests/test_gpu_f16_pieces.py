@@ -213,6 +213,8 @@ def test_costreg_one_call_equals_the_layer_chain(dev):
 
 @pytest.mark.parametrize("shape,cin", [((1, 12, 20, 70), 32), ((2, 7, 9, 37), 16), ((1, 5, 30, 33), 8), ((1, 17, 6, 64), 32), ((1, 4, 4, 32), 32),
                                        ((1, 40, 12, 31), 32)])
+@pytest.mark.skipif(__import__("os").environ.get("MVS_HIP_TUNING") != "1", reason="the pre-split conv0 experiment lives in the tuning build "
+                    "(python -m mvs_amd.build --tuning; MVS_HIP_TUNING=1 python -m pytest ...)")
 def test_conv0_on_presplit_pairs_is_bit_identical(dev, shape, cin):
     """mvs_conv3d_c8h_f16x3_f32 (the volume arrives as scaled fp16 pairs, MVS_LAYOUT_C8H: no staging buffer, no split pass) returns
     the bits of mvs_conv3d_c8_f16x3_f32 on the fp32 volume under the same absmax block: odd and even widths, single-tile groups
