@@ -2,10 +2,10 @@
 # Round profile on the GPU box: rocprofv3 kernel trace + stats of the bench command,
 # then HBM-traffic counters in their own passes (no tracing mixed in).
 # Usage: bash scripts/profile_round.sh r01     (writes gpurun_out/prof_<tag>/...)
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd "$(dirname "$0")/.." ; mkdir -p gpurun_out/prof_$TAG
 export TMPDIR=/tmp
-CMD="python bench.py --steps 10 --warmup 3 --no-cpu-baseline"
+CMD="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$TAG/trace -o trace --output-format csv -- $CMD > gpurun_out/prof_$TAG/bench_under_trace.json 2> gpurun_out/prof_$TAG/trace.log
 # HBM traffic: FETCH_SIZE and WRITE_SIZE need separate passes (TCC slots)
 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/prof_$TAG/pmc_fetch -o pmc --output-format csv -- $CMD > /dev/null 2> gpurun_out/prof_$TAG/pmc_fetch.log
