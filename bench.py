@@ -53,6 +53,10 @@ SPLIT_STAGES = {"costreg.conv0", "costreg.conv1", "costreg.conv2", "costreg.conv
                 "feature.feature"}
 
 
+# (round 4) conv3 / conv5: on the two-piece fp16 kernel with 32 output channels per launch; no bf16 form (MVS_SPLIT_F16=0: the fp32 MFMA kernels)
+F16_ONLY_STAGES = {"costreg.conv3", "costreg.conv5"}
+
+
 def algorithmic_work(V, C, D, h, w):
     """SURVEY.md 8(d) / BASELINE.md 3: algorithmic bytes (HBM-bound kernels) and
     flops (MFMA-bound kernels) per reference view at feature resolution h x w."""
@@ -153,7 +157,7 @@ def _roofline_entry(name, kind, amount, ms):
     # the inference layers on the two-piece fp16 kernels: conv0 (conv_f16x3.hip) and, chained through the absmax blocks, the
     # split-operand layers of CostRegNet and FeatureNet (conv_split.hip / deconv_split.hip with NP = 2)
     f16 = (name == "costreg.conv0" and ops.conv0_f16_enabled()) or \
-          (name in SPLIT_STAGES and name != "costreg.conv0" and not name.startswith("train.") and ops.split_f16_enabled())
+          ((name in SPLIT_STAGES or name in F16_ONLY_STAGES) and name != "costreg.conv0" and not name.startswith("train.") and ops.split_f16_enabled())
     if f16:
         return {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": round(SPLIT_F16X3_PEAK_TF, 1),
                 "unit": "TFLOP/s", "frac": round(ach / SPLIT_F16X3_PEAK_TF, 4), "traffic": None,

@@ -86,7 +86,9 @@ struct SplitCfg {
     static constexpr bool DB2 = NP_ == 2 && (NCHUNK == 1 || KD_ == 3) && NWBUF * WBYTES + 2 * FBYTES + SBYTES + 2 * COUT * 4 <= 160 * 1024;
     static constexpr int F_OFF = (DB2 ? NWBUF : 2) * WBYTES, S_OFF = F_OFF + (DB2 ? 2 : 1) * FBYTES, AFF_OFF = S_OFF + SBYTES;   // + scale, shift of the launch
     static constexpr int LDS_BYTES = AFF_OFF + 2 * COUT * 4;
-    static_assert(RB % 8 == 0 && LDS_BYTES <= 160 * 1024 && SPART * 2 + 16 * 1024 < 65536 && (S == 1 || KD == 1 || MT == 1) &&
+    // (3D stride 2: 16 output channels per launch in the bf16 form -- its three part planes leave no room for a second M tile;
+    // 32 in the two-piece form, round 4: conv3 / conv5 then read and split their input once per 32 output channels)
+    static_assert(RB % 8 == 0 && LDS_BYTES <= 160 * 1024 && SPART * 2 + 16 * 1024 < 65536 && (S == 1 || KD == 1 || MT == 1 || (MT == 2 && NP_ == 2)) &&
                   (KH == 3 || (KH == 5 && KD == 1 && S == 2)), "tile / LDS budget");
 };
 
@@ -657,7 +659,9 @@ using namespace mvs;
 
 // output channels of ONE launch: 32 where the layer has a multiple of 32, else 16; stride 2: always 16 (its halo fills LDS)
 // (kd = 1 with stride 2 is FeatureNet's 5x5 form: the whole layer, 16 or 32 output channels, in one launch)
-static int split_cout_step(int kd, int Cout, int stride) { return (stride == 1 || kd == 1) && Cout % 32 == 0 ? 32 : 16; }
+static int split_cout_step(int kd, int Cout, int stride, int np) {
+    return (stride == 1 || kd == 1 || np == 2) && Cout % 32 == 0 ? 32 : 16;
+}
 static int split_cps(int kd, int Cin, int stride) { return kd == 1 && stride == 1 && Cin >= 16 ? 2 : 1; }
 static int split_ntap(int kd, int stride) { return kd == 1 && stride == 2 ? 25 : kd * 9; }
 
@@ -696,7 +700,7 @@ extern "C" int mvs_conv_split_pack_weights_f16_f32(const float *weight, int kd, 
         return MVS_EINVAL;
     }
     const int ntap = split_ntap(kd, stride);
-    const int step = split_cout_step(kd, Cout, stride), cps = split_cps(kd, Cin, stride), G = (ntap * cps + 3) / 4, MT = step / 16;
+    const int step = split_cout_step(kd, Cout, stride, 2), cps = split_cps(kd, Cin, stride), G = (ntap * cps + 3) / 4, MT = step / 16;
     const size_t per_launch = (size_t)(Cin / (8 * cps)) * G * MT * 2 * 1024, body = split_packed_bytes(kd, Cin, Cout, stride, 2);
     unsigned char *pk = static_cast<unsigned char *>(packed);
     unsigned *wmax = reinterpret_cast<unsigned *>(pk + body + 4);
@@ -721,7 +725,7 @@ extern "C" int mvs_conv_split_pack_weights_f32(const float *weight, int kd, int 
     }
     // one block of the packed buffer per launch of the layer (Cout / step launches, each `step` output channels)
     const int ntap = split_ntap(kd, stride);
-    const int step = split_cout_step(kd, Cout, stride), cps = split_cps(kd, Cin, stride), G = (ntap * cps + 3) / 4, MT = step / 16;
+    const int step = split_cout_step(kd, Cout, stride, 3), cps = split_cps(kd, Cin, stride), G = (ntap * cps + 3) / 4, MT = step / 16;
     const size_t per_launch = (size_t)(Cin / (8 * cps)) * G * MT * 3 * 1024;
     for (int co0 = 0; co0 < Cout; co0 += step) {
         const int total = (Cin / (8 * cps)) * G * MT * 512;
@@ -742,7 +746,7 @@ static int conv_split_impl(const float *in, const void *in_absmax, const void *p
         return MVS_EINVAL;
     }
     if ((int64_t)(kd + 3) * H * W * Cin * 4 >= 0xffffff00LL) return bare_error(MVS_EUNSUPPORTED, __func__, __LINE__);   // 32-bit halo offsets: callers fall back to the fp32 kernels
-    const int step = split_cout_step(kd, Cout, stride), cps = split_cps(kd, Cin, stride), G = (split_ntap(kd, stride) * cps + 3) / 4;
+    const int step = split_cout_step(kd, Cout, stride, np), cps = split_cps(kd, Cin, stride), G = (split_ntap(kd, stride) * cps + 3) / 4;
     const size_t per_launch = (size_t)(Cin / (8 * cps)) * G * (step / 16) * np * 1024;
     hipStream_t st = as_stream(stream);
     for (int co0 = 0; co0 < Cout; co0 += step) {
@@ -767,11 +771,17 @@ static int conv_split_impl(const float *in, const void *in_absmax, const void *p
         MVS_SPLIT_CASE(16, 16, 1) MVS_SPLIT_CASE(32, 16, 1) MVS_SPLIT_CASE(64, 16, 1)
         MVS_SPLIT_CASE(16, 32, 1) MVS_SPLIT_CASE(32, 32, 1) MVS_SPLIT_CASE(64, 32, 1)
 #undef MVS_SPLIT_CASE
-#define MVS_SPLIT_S2(CI, CO, KD, KH) if (stride == 2 && kd == KD && Cin == CI) \
+#define MVS_SPLIT_S2(CI, CO, KD, KH) if (stride == 2 && kd == KD && Cin == CI && step == CO) \
         rc = np == 2 ? launch_split<SplitCfg<CI, CO, KD, 2, KH, 2>>(a, st) : launch_split<SplitCfg<CI, CO, KD, 2, KH>>(a, st);
         MVS_SPLIT_S2(8, 16, 3, 3) MVS_SPLIT_S2(16, 16, 3, 3) MVS_SPLIT_S2(32, 16, 3, 3)
         MVS_SPLIT_S2(8, 16, 1, 5) MVS_SPLIT_S2(16, 32, 1, 5)
 #undef MVS_SPLIT_S2
+        // two-piece form, 32 output channels per launch (conv3: 16 -> 32, conv5: 32 -> 64 as two launches; 8 -> 32 for completeness)
+        if (np == 2 && stride == 2 && kd == 3 && step == 32) {
+            if (Cin == 8) rc = launch_split<SplitCfg<8, 32, 3, 2, 3, 2>>(a, st);
+            else if (Cin == 16) rc = launch_split<SplitCfg<16, 32, 3, 2, 3, 2>>(a, st);
+            else if (Cin == 32) rc = launch_split<SplitCfg<32, 32, 3, 2, 3, 2>>(a, st);
+        }
         if (rc != MVS_OK) return rc;
     }
     return MVS_OK;

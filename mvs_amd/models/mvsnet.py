@@ -264,7 +264,7 @@ class CostRegNet(nn.Module):
         # the per-layer chain of mvs_costreg_fwd2_f32: a layer on a two-piece fp16 kernel scales its input by the absmax block the
         # layer in front of it collected (blocks of activations nobody reads that way stay None)
         f16 = ops.split_f16_enabled() and self.conv_impl == ops.IMPL_AUTO
-        blocks = ops.absmax_block(x_cl.device, zero=True, n=7) if f16 else None
+        blocks = ops.absmax_block(x_cl.device, zero=True, n=9) if f16 else None
         blk = (lambda i: blocks[i]) if f16 else (lambda i: None)
 
         def run(name, t, skip=None, relu=True, x_abs=None, out_abs=None):
@@ -284,10 +284,10 @@ class CostRegNet(nn.Module):
                 c0 = ops.conv3d(x_cl, p0["weight"], p0["scale"], p0["shift"], None, True, False, 1, channels_last=True,
                                 packed=p0["packed"], impl=self.conv_impl, in_c8=in_c8, out_absmax=blk(0))
         t1 = run("conv1", c0, x_abs=blk(0), out_abs=blk(1))
-        c2 = run("conv2", t1, x_abs=blk(1))
-        t3 = run("conv3", c2, out_abs=blk(2))
-        c4 = run("conv4", t3, x_abs=blk(2))
-        t5 = run("conv5", c4, out_abs=blk(3))
+        c2 = run("conv2", t1, x_abs=blk(1), out_abs=blk(7))
+        t3 = run("conv3", c2, x_abs=blk(7), out_abs=blk(2))
+        c4 = run("conv4", t3, x_abs=blk(2), out_abs=blk(8))
+        t5 = run("conv5", c4, x_abs=blk(8), out_abs=blk(3))
         t = run("conv6", t5, x_abs=blk(3), out_abs=blk(4))
         t = run("conv7", t, c4, x_abs=blk(4), out_abs=blk(5))
         t = run("conv9", t, c2, x_abs=blk(5), out_abs=blk(6))

@@ -641,6 +641,12 @@ def pack_conv3d_weight(weight, transposed, stride, split=False, f16=True):
         sp = pack_conv_weight_split(weight, stride)
         if sp is not None:
             _register_split(packed, sp, pack_conv_weight_split_f16(weight, stride) if (f16 and split_f16_enabled()) else None)
+    elif split and not transposed and stride == 2 and f16 and split_f16_enabled():
+        # (round 4) conv3 / conv5: no bf16 companion (it loses to the fp32 kernel), but the TWO-piece form takes 32 output channels
+        # per launch and wins: registered alone, taken when the caller hands over the input's absmax block
+        pf = pack_conv_weight_split_f16(weight, stride)
+        if pf is not None:
+            _register_split(packed, None, pf)
     if split and transposed and stride == 2 and conv_split_enabled():
         sp = pack_deconv_weight_split(weight)
         if sp is not None:
@@ -988,14 +994,14 @@ def conv3d(x, weight, scale=None, shift=None, residual=None, relu=False, transpo
     # IMPL_AUTO (an explicit IMPL_MFMA / IMPL_DIRECT measures the kernel it names), and a volume beyond the split
     # launcher's limits falls through to the fp32 kernels below.
     sp = split_companion(packed) if impl == IMPL_AUTO else None
-    f16 = f16_companion(packed) if (sp is not None and x_absmax is not None) else None
-    if sp is not None and channels_last and not in_c8 and not transposed:
+    f16 = f16_companion(packed) if (impl == IMPL_AUTO and x_absmax is not None) else None
+    if (sp is not None or f16 is not None) and channels_last and not in_c8 and not transposed:
         if f16 is not None:
             out = conv_split_f16(x, f16, cout, x_absmax, scale, shift, residual, 1 if relu else 0, kd=3, stride=stride,
                                  out_absmax=out_absmax, soft=True)
             if out is not None:
                 return out
-        out = conv_split(x, sp, cout, scale, shift, residual, 1 if relu else 0, kd=3, stride=stride, soft=True)
+        out = conv_split(x, sp, cout, scale, shift, residual, 1 if relu else 0, kd=3, stride=stride, soft=True) if sp is not None else None
         if out is not None:
             return _with_absmax(out, out_absmax)
     if sp is not None and channels_last and not in_c8 and transposed and stride == 2:

@@ -31,6 +31,10 @@ _RIGS = {
     0: dict(theta=_THETA_DEG, phi=_PHI_DEG, psi=(0.0,) * 7, dist=(1.0,) * 7),
     1: dict(theta=(0.0, -13.0, 11.0, -6.5, 7.5, -17.0, 16.0), phi=(0.0, 5.0, -4.5, -8.0, 9.0, 3.0, -3.5),
             psi=(0.0, 2.0, -3.0, 1.5, -1.0, 4.0, -2.5), dist=(1.0, 0.96, 1.05, 1.02, 0.93, 1.08, 0.9)),
+    # rig 2 (third CVP parity scene): narrow baselines on one side, wide on the other, mostly vertical
+    # disparity for two views, stronger roll, cameras closer to and farther from the target
+    2: dict(theta=(0.0, -3.0, 15.0, 2.0, -10.0, 6.0, -19.0), phi=(0.0, 9.0, 1.5, -11.0, -2.0, 6.5, 4.0),
+            psi=(0.0, -5.0, 3.5, 6.0, -2.0, -7.0, 1.0), dist=(1.0, 1.1, 0.88, 0.97, 1.12, 0.92, 1.04)),
 }
 
 

@@ -15,6 +15,7 @@ Run in the build container (needs /root/reference):
   g22_cvp_fullsize_scene1     configs[3] on scene 1
   g23_cas_fullsize_fp64       float64 depths of configs[2], scenes 0 and 1 (all three stages)
   g24_cvp_fullsize_fp64       float64 depths of configs[3], scenes 0 and 1 (all five levels)
+  g25_cvp_fullsize_scene2     configs[3] on a third scene (image / weight seed 2, rig 2): reference float32 + float64
 
 Every fixture holds the REFERENCE's float32 outputs (imported from /root/reference, as in
 make_golden_fullsize.py) and, under *64 keys, the same composition evaluated in float64 by
@@ -232,6 +233,53 @@ def g24():
         del o
         gc.collect()
     save("g24_cvp_fullsize_fp64", delta_step_mm=np.float64(DELTA_STEP_MM), **arrs)
+
+
+def g25():
+    """configs[3] on a THIRD scene (image seed 2, weight seed 2, camera rig 2: VERDICT r03 item 6): the reference's float32
+    outputs and, in the same file, the float64 evaluation of the composition (delta-coded like g24)."""
+    import pdb
+    warnings.filterwarnings("ignore")
+    c = cc.cvp_fullsize_case(scene=2)
+    for s in ("torchvision", "torchvision.utils", "cv2"):
+        sys.modules.setdefault(s, types.ModuleType(s))
+    for k in [k for k in sys.modules if k in ("models", "utils") or k.startswith("models.")]:
+        del sys.modules[k]
+    torch.Tensor.cuda = lambda self, *a, **k: self      # the reference hard-codes .cuda()
+    pdb.set_trace = lambda *a, **k: None                # ... and a breakpoint in its forward
+    sys.path.insert(0, "/root/reference/CVP-MVSNet")
+    from models import net as refnet
+    sys.path.pop(0)
+    net = refnet.network(types.SimpleNamespace(nscale=c["nscale"], nsrc=c["nsrc"], mode="test"))
+    net.load_state_dict(c["sd"])
+    net.eval()
+    cams, imgs = c["cams"], c["imgs"]
+    t0 = time.time()
+    with torch.no_grad():
+        out = net(T(imgs[:, 0]), T(imgs[:, 1:]), T(cams["ref_in"]), T(cams["src_in"]), T(cams["ref_ex"]),
+                  T(cams["src_ex"]), T(cams["depth_min"]), T(cams["depth_max"]))
+        port = torch_ref.cvp_forward(T(imgs[:, 0]), T(imgs[:, 1:]), T(cams["ref_in"]), T(cams["src_in"]), T(cams["ref_ex"]),
+                                     T(cams["src_ex"]), T(cams["depth_min"]), T(cams["depth_max"]), c["sd"], c["nscale"])
+    print("g25 cvp reference forward (+ port)", round(time.time() - t0, 1), "s; port_vs_reference =",
+          max(float((a - b).abs().max()) for a, b in zip(out["depth_est_list"], port["depth_est_list"])))
+    arrs = {}
+    for i, d in enumerate(out["depth_est_list"]):
+        arrs[f"depth_level{i}"] = (d[:, ::2, ::2] if d.shape[-1] > 1000 else d).contiguous()
+    cf = out["prob_confidence"]
+    arrs["prob_confidence"] = (cf[..., ::2, ::2] if cf.shape[-1] > 1000 else cf).contiguous()
+    del out, port
+    gc.collect()
+    cams64, imgs64 = {k: T(v).double() for k, v in c["cams"].items()}, T(c["imgs"]).double()
+    t0 = time.time()
+    with torch.no_grad():
+        o = torch_ref.cvp_forward(imgs64[:, 0], imgs64[:, 1:], cams64["ref_in"], cams64["src_in"], cams64["ref_ex"], cams64["src_ex"],
+                                  cams64["depth_min"], cams64["depth_max"], _dbl(c["sd"]), c["nscale"])
+    print("g25 cvp float64", round(time.time() - t0, 1), "s")
+    for i, d in enumerate(o["depth_est_list"]):
+        d = (d[:, ::2, ::2] if d.shape[-1] > 1000 else d).contiguous()
+        arrs[f"s2_depth_level{i}_64_d16"] = _delta16(d, arrs[f"depth_level{i}"].numpy())
+        print("    level", i, "max|ref32 - f64| =", float(np.abs(arrs[f"depth_level{i}"].numpy().astype(np.float64) - d.numpy()).max()), "mm")
+    save("g25_cvp_fullsize_scene2", delta_step_mm=np.float64(DELTA_STEP_MM), **arrs)
 
 
 if __name__ == "__main__":
