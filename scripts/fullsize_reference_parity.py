@@ -17,11 +17,11 @@ from fullsize_cases import run_cas, run_cvp, run_eval_small, run_mvsnet, run_tra
 def main():
     res = {}
     which = sys.argv[1:] or ["mvsnet", "mvsnet_fast", "mvsnet_s1", "mvsnet_fast_s1", "eval_small", "eval_small_fast",
-                             "cas", "cas_s1", "cvp", "cvp_s1", "train"]
+                             "cas", "cas_s1", "cvp", "cvp_s1", "cvp_s2", "train"]
     table = {"mvsnet": lambda: run_mvsnet(False), "mvsnet_fast": lambda: run_mvsnet(True),
              "mvsnet_s1": lambda: run_mvsnet(False, 1), "mvsnet_fast_s1": lambda: run_mvsnet(True, 1),
              "eval_small": lambda: run_eval_small(False), "eval_small_fast": lambda: run_eval_small(True),
-             "cas": run_cas, "cvp": run_cvp, "cas_s1": lambda: run_cas(1), "cvp_s1": lambda: run_cvp(1)}
+             "cas": run_cas, "cvp": run_cvp, "cas_s1": lambda: run_cas(1), "cvp_s1": lambda: run_cvp(1), "cvp_s2": lambda: run_cvp(2)}
     for w in which:
         if w == "train":
             res[w] = run_train_step()

@@ -179,8 +179,9 @@ def run_cvp(scene=0):
     from mvs_amd import ops
     from mvs_amd.models.cvp_mvsnet import network
     dev = torch.device("cuda:0")
-    g = dict(np.load(os.path.join(GOLDEN, "g14_cvp_fullsize.npz" if scene == 0 else f"g22_cvp_fullsize_scene{scene}.npz")))
-    t = dict(np.load(os.path.join(GOLDEN, "g24_cvp_fullsize_fp64.npz")))
+    # scene 2 (round 4): reference outputs and float64 answers in one file
+    g = dict(np.load(os.path.join(GOLDEN, {0: "g14_cvp_fullsize.npz", 1: "g22_cvp_fullsize_scene1.npz", 2: "g25_cvp_fullsize_scene2.npz"}[scene])))
+    t = g if scene == 2 else dict(np.load(os.path.join(GOLDEN, "g24_cvp_fullsize_fp64.npz")))
     c = cc.cvp_fullsize_case(scene)
     net = network(types.SimpleNamespace(nscale=c["nscale"], nsrc=c["nsrc"], mode="test"))
     net.load_state_dict(c["sd"])

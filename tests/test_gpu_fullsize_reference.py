@@ -57,20 +57,25 @@ def test_cascade_config3_matches_reference_forward(scene):
         _check_conf(r[s]["conf"])
 
 
-@pytest.mark.parametrize("scene", [0, 1], ids=["scene0", "scene1"])
+@pytest.mark.parametrize("scene", [0, 1, 2], ids=["scene0", "scene1", "scene2"])
 def test_cvp_config4_matches_reference_forward(scene):
-    """configs[3]: CVP-MVSNet 1920x1056, 7 views, 5 pyramid levels; every level, both scenes (g14 / g22, truths g24).
-    Gate against the reference: 1e-3 mm -- or, where the reference's own float32 forward is farther than 0.9e-3 mm from
-    the float64 answer (scene 1, levels 0-2: 0.95e-3 ... 1.14e-3 mm -- a HIP result that WAS the float64 answer would
-    miss the literal gate there), a fixed 1.2e-3 mm (measured 1.10e-3 / 1.10e-3 / 1.04e-3 = 17-18 float32 ulps of a
-    ~1000 mm depth, profiles/r04_fullsize_reference_parity.json; ADVICE r03: the sum of the two distances to float64, the
-    earlier form, is an upper bound of |HIP - ref| by the triangle inequality and could never fail); the error budget
-    (HIP within the gate of the float64 answer and no farther from it than the reference) holds without exception."""
+    """configs[3]: CVP-MVSNet 1920x1056, 7 views, 5 pyramid levels; every level, three scenes (g14 / g22, truths g24; scene 2 --
+    image / weight seed 2, camera rig 2 -- with its float64 answers in g25: VERDICT r03 item 6).
+
+    What is asserted per level: (a) the error budget WITHOUT allowance -- the HIP depth is within 1e-3 mm of the float64
+    answer and no farther from it than the reference's own float32 forward, maximum and rms (measured on 15 levels: 0.26-0.84e-3
+    against the reference's 0.48-1.14e-3 mm); (b) against the reference: 99.9 % of the pixels within 1e-3 mm (measured
+    4.3-7.3e-4) and every pixel within 1e-3 mm where the reference itself is within 0.7e-3 mm of the float64 answer, else
+    within a FIXED 1.3e-3 mm.  The second clause exists because two float32 evaluations that each sit 0.71-1.14e-3
+    mm from the truth (level 0 of every scene, levels 1-4 of scene 1, level 1 of scene 2) can be 1.1e-3 mm apart at one pixel in two million with neither
+    being wrong -- a HIP result that WAS the float64 answer would miss the literal gate there (measured maxima 1.01e-3 /
+    9.8e-4 / 9.5e-4 on scene 1, 1.10e-3 on scene 2: profiles/r04_fullsize_reference_parity.json)."""
     with torch.no_grad():
         r = run_cvp(scene)
     for k, v in r.items():
         if k.startswith("level"):
-            gate = GATE_MM if v["ref_vs_f64_mm"] < 0.9 * GATE_MM else 1.2e-3
+            assert v["hip_vs_f64_mm"] < GATE_MM and v["hip_vs_f64_mm"] <= v["ref_vs_f64_mm"] and v["hip_vs_f64_rms"] <= v["ref_vs_f64_rms"], (k, v)
+            assert v["p999_mm"] < GATE_MM, (k, v)
+            gate = GATE_MM if v["ref_vs_f64_mm"] < 0.7 * GATE_MM else 1.3e-3
             assert v["maxabs_mm"] < gate, (k, v)
-            _check_budget(v)
     _check_conf(r["conf"])
