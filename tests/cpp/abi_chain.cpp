@@ -195,12 +195,15 @@ int main(int argc, char **argv) {
     const double e_cost2 = maxabs(to_host(cost2, (size_t)B * vol), d.get("cost"));
     const double e_depth2 = maxabs(to_host(depth2, (size_t)B * plane), d.get("depth"));
     const double e_conf2 = maxabs(to_host(conf2, (size_t)B * plane), d.get("confidence"));
-    const bool ok = e_warp < 1e-6 && e_var < 1e-6 && e_depth < 1e-3 && e_conf < 1e-3 && e_depth2 < 1e-3 && e_conf2 < 1e-3;
+    // the range guard of the two-piece layers (conv_guard.h) must have stayed silent on this volume
+    unsigned long long guard = ~0ull;
+    MVS_OK_(mvs_guard_fallback_count(&guard));
+    const bool ok = e_warp < 1e-6 && e_var < 1e-6 && e_depth < 1e-3 && e_conf < 1e-3 && e_depth2 < 1e-3 && e_conf2 < 1e-3 && guard == 0;
     std::printf("{\"version\": %d, \"arch\": \"%s\", \"warp_maxabs\": %.3g, \"variance_maxabs\": %.3g, \"cost_maxabs\": %.3g, "
                 "\"depth_maxabs_mm\": %.3g, \"confidence_maxabs\": %.3g, \"two_piece_cost_maxabs\": %.3g, "
                 "\"two_piece_depth_maxabs_mm\": %.3g, \"two_piece_confidence_maxabs\": %.3g, \"variance_workspace_bytes\": %zu, "
-                "\"costreg_workspace_bytes\": %zu, \"ok\": %s}\n",
-                mvs_version(), mvs_arch(), e_warp, e_var, e_cost, e_depth, e_conf, e_cost2, e_depth2, e_conf2, vws, cws,
+                "\"costreg_workspace_bytes\": %zu, \"guard_fallbacks\": %llu, \"ok\": %s}\n",
+                mvs_version(), mvs_arch(), e_warp, e_var, e_cost, e_depth, e_conf, e_cost2, e_depth2, e_conf2, vws, cws, guard,
                 ok ? "true" : "false");
     return ok ? 0 : 1;
 }
