@@ -238,7 +238,8 @@ int mvs_conv3d_c8_bf16x6_f32(const float *in, const void *packed, const float *s
  * them), real taps only, IEEE Inf / NaN semantics and torch's NaN-propagating ReLU -- the reference's arithmetic, at the speed
  * of a direct convolution.  Otherwise the bound above holds: per product 2^-22 relative for operands within 2^-18 of their
  * tensor's maximum, 2^-40 of the maximum absolute for smaller ones.  mvs_guard_fallback_count reports how many launches of the
- * current device took the fp32 path since the library was loaded (it synchronises: a diagnostic, not a data-path call). */
+ * current device took the fp32 path since the library was loaded (it synchronises: a diagnostic, not a data-path call; call it
+ * once before capturing HIP graphs of these layers -- the first call resolves the counter's device address). */
 int mvs_guard_fallback_count(unsigned long long *count);
 size_t mvs_conv3d_f16x3_packed_bytes(int Cin);
 int mvs_conv3d_pack_weights_f16x3_f32(const float *weight, int Cin, void *packed, void *stream);

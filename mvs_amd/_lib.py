@@ -154,6 +154,11 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    # resolve the range guard's device counter now (hipGetSymbolAddress on first use may load the code object: not something to
+    # meet for the first time inside a HIP-graph capture)
+    if torch.cuda.is_available():
+        n = ctypes.c_ulonglong(0)
+        lib.mvs_guard_fallback_count(ctypes.byref(n))
     return lib
 
 

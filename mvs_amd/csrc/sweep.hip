@@ -1224,11 +1224,12 @@ static int launch_variance_tile_c16(const float *ref_fea, const float *src_feas,
     const int lds_ablate = 0;
 #endif
     // MVS_SWEEP_TILE_LOOP=1 (A/B): behind the chooser, a fixed grid of three workgroups per CU loops over the tiles
-    static const bool tile_loop = [] { const char *e = getenv("MVS_SWEEP_TILE_LOOP"); return e && e[0] == '1'; }();
-    const bool loop = sel && tile_loop;
+    static const int tile_loop = [] { const char *e = getenv("MVS_SWEEP_TILE_LOOP"); return e ? atoi(e) : 0; }();   // workgroups per CU (0: one block per tile)
+    const bool loop = sel && tile_loop > 0;
+    const int loop_wgs = (tile_loop == 1 ? 3 : tile_loop) * device_cu_count();
     // (behind the chooser, sel != NULL, the chooser has cleared the word)
     if (!sel && absmax && hipMemsetAsync(absmax, 0, 4 * kAbsmaxWords, st) != hipSuccess) return check_launch("variance absmax memset");
-    const dim3 g(loop ? (unsigned)(nblk < 3 * device_cu_count() ? nblk : 3 * device_cu_count()) : (unsigned)nblk, (unsigned)B);
+    const dim3 g(loop ? (unsigned)(nblk < loop_wgs ? nblk : loop_wgs) : (unsigned)nblk, (unsigned)B);
 #define MVS_LDS_CASE(n)                                                                                      \
     case n: {                                                                                                \
         const size_t shmem = (size_t)n * 4 * dma_cap(n) * 16;                                                \
