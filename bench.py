@@ -325,6 +325,7 @@ def train_main(args, rank, world, dev, dist):
                 "launch": "one HIP graph replay per step" if graph is not None else "eager (~450 launches per step)",
                 "loss": round(float(loss.item()), 4),
                 "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+                "guard_fallbacks": ops.guard_fallback_count(),   # two-piece launches that fell back to fp32 (conv_guard.h): 0 expected
                 "roofline": roof,
                 "stages_ms": {k: round(v, 4) for k, v in sorted(stages.items())},
                 "rooflines": [entry(k, stages[k]) for k in sorted(stages) if k in work],
@@ -579,7 +580,7 @@ def main():
         #  BASELINE configs[4] on this GPU: the training step as one HIP graph replay, 5 steps
         tr = child_bench(["--mode", "train", "--graph", "--steps", "5", "--warmup", "3"] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []), {})
         line["train"] = ({k: tr.get(k) for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "launch", "loss", "config",
-                                                 "roofline", "cpu_baseline", "peak_mem_GB")} if "error" not in tr else tr)
+                                                 "roofline", "cpu_baseline", "peak_mem_GB", "guard_fallbacks")} if "error" not in tr else tr)
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
