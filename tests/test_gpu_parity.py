@@ -1195,6 +1195,40 @@ def test_mvsnet_train_step_golden(dev, weights):
                                        err_msg=k)
 
 
+def test_mvsnet_train_with_frozen_batchnorm_and_per_view_featurenet(dev, weights):
+    """Fine-tuning with frozen BatchNorm (model.train() followed by bn.eval(), ADVICE r03: the fused variance -> conv0 node handed
+    a raw conv0 output to a layer that wanted the volume and crashed), and the A/B switch that runs FeatureNet per view as the
+    reference's loop does: both give the loss and gradients of the same step through torch's own modules."""
+    import copy
+    from mvs_amd.models import MVSNet, mvsnet_loss
+    g = load_golden("g7_train_step")
+    base = MVSNet(refine=False)
+    base.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    base = base.to(dev).train()
+    for m in base.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.eval()
+    args = (G(g["imgs"], dev), G(g["proj"], dev), G(g["depth_values"], dev))
+
+    def step(model):
+        out = model(*args)
+        loss = mvsnet_loss(out["depth"], G(g["gt"], dev), G(g["mask"], dev))
+        loss.backward()
+        return loss.item(), {k: p.grad.detach().cpu().numpy() for k, p in model.named_parameters() if p.grad is not None}
+
+    ref = copy.deepcopy(base)
+    ref.train_impl, ref.train_feature_impl = "torch", "torch"      # PyTorch-ROCm modules + the planar variance op
+    l_ref, g_ref = step(ref)
+    for batched in (True, False):
+        m = copy.deepcopy(base)
+        m.train_feature_batched = batched
+        l, gr = step(m)
+        np.testing.assert_allclose(l, l_ref, rtol=2e-4)
+        assert set(gr) == set(g_ref)
+        for k in g_ref:
+            np.testing.assert_allclose(gr[k], g_ref[k], atol=3e-3 * max(1e-3, np.abs(g_ref[k]).max()), err_msg=f"{k} batched={batched}")
+
+
 def test_cpu_tensors_rejected():
     from mvs_amd import ops
     from mvs_amd._lib import MvsHipError
