@@ -130,7 +130,7 @@ __device__ __forceinline__ void tap_setup(const float *__restrict__ r, int cx, i
         inv = __fmaf_rn(__fmaf_rn(-Z, inv, 1.0f), inv, inv);
         ix = __fmaf_rn(X * inv, sx, ox);
         iy = __fmaf_rn(Y * inv, sy, oy);
-        fin = (fabsf(ix) <= 3.0e38f) & (fabsf(iy) <= 3.0e38f);
+        fin = (int)(fabsf(ix) <= 3.0e38f) & (int)(fabsf(iy) <= 3.0e38f);   // (bitwise on purpose: no branch)
         const float x0f = floorf(ix), y0f = floorf(iy);
         const float wx = ix - x0f, wy = iy - y0f, ex = 1.0f - wx, ey = 1.0f - wy;
         nw = ey * ex; ne = ey * wx; sw = wy * ex; se = wy * wx;
@@ -143,7 +143,7 @@ __device__ __forceinline__ void tap_setup(const float *__restrict__ r, int cx, i
         sweep_ray(r, (float)cx, (float)cy, rx, ry, rz);
         sweep_coord(r, rx, ry, rz, dv, p.half_w, p.half_h, p.unn_w, p.unn_h, p.align_corners, ix, iy);
         const Taps t = make_taps(ix, iy, p.H, p.W);
-        fin = (fabsf(ix) <= 3.0e38f) & (fabsf(iy) <= 3.0e38f);
+        fin = (int)(fabsf(ix) <= 3.0e38f) & (int)(fabsf(iy) <= 3.0e38f);   // (bitwise on purpose: no branch)
         nw = t.nw; ne = t.ne; sw = t.sw; se = t.se;
         x0ok = t.x0ok; x1ok = t.x1ok; y0ok = t.y0ok; y1ok = t.y1ok;
         tx0 = (int)fminf(fmaxf(floorf(ix), -4.0f), (float)p.W + 4.0f);
