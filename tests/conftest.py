@@ -31,6 +31,24 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _range_guard_stays_silent(request):
+    """Every -m gpu test outside tests/test_gpu_range_guard.py runs on ordinary data: no launch of a two-piece fp16 layer may take
+    the range guard's fp32 path (mvs_amd/csrc/conv_guard.h) -- a false positive would be correct but ~35x slower, silently."""
+    if "gpu" not in request.keywords or request.module.__name__.endswith("test_gpu_range_guard"):
+        yield
+        return
+    import torch
+    if not torch.cuda.is_available():
+        yield
+        return
+    from mvs_amd import ops
+    before = ops.guard_fallback_count()
+    yield
+    taken = ops.guard_fallback_count() - before
+    assert taken == 0, f"{taken} two-piece launches fell back to fp32 on this test's data (range guard false positive?)"
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
 
