@@ -577,8 +577,8 @@ def main():
                                    "warmup": ex.get("warmup"), "arithmetic": ex.get("config", {}).get("arithmetic"),
                                    "dominant": {k: ex.get("roofline", {}).get(k) for k in ("kernel", "ms", "achieved", "peak", "frac")},
                                    "env": "MVS_CONV0_F16=0 MVS_SPLIT_F16=0"} if "error" not in ex else ex)
-        #  BASELINE configs[4] on this GPU: the training step as one HIP graph replay, 5 steps
-        tr = child_bench(["--mode", "train", "--graph", "--steps", "5", "--warmup", "3"] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []), {})
+        #  BASELINE configs[4] on this GPU: the training step as one HIP graph replay, 10 timed steps
+        tr = child_bench(["--mode", "train", "--graph", "--steps", "10", "--warmup", "5"] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []), {})
         line["train"] = ({k: tr.get(k) for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "launch", "loss", "config",
                                                  "roofline", "cpu_baseline", "peak_mem_GB", "guard_fallbacks")} if "error" not in tr else tr)
     print(json.dumps(line), flush=True)

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float z = (xs[j] - mean[j]) * istd[j] * w[j] + b[j];
-                o[j] = (a.relu && !(z > 0.0f)) ? 0.0f : z;
+                o[j] = (a.relu && z <= 0.0f) ? 0.0f : z;       // (a NaN stays: torch's relu)
             }
             if (a.skip) {
                 const float4 sv = ld4(a.skip, e);
