@@ -591,10 +591,30 @@ def conv3d_mfma_supported(transposed, cin, cout, stride):
 _split_registry = {}   # id(packed fp32 weights) -> (weakref to them, their split-operand companion)
 
 
+_lazy_fill = {}         # id(packed fp32 weights) -> (weakref to them, closure that fills them): fp32 fragments not packed yet
+
+
 def _register_split(packed, split, f16=None):
     import weakref
     key = id(packed)
     _split_registry[key] = (weakref.ref(packed, lambda _r, k=key: _split_registry.pop(k, None)), split, f16)
+
+
+def _register_lazy(packed, fill):
+    import weakref
+    key = id(packed)
+    _lazy_fill[key] = (weakref.ref(packed, lambda _r, k=key: _lazy_fill.pop(k, None)), fill)
+
+
+def materialize_packed(packed):
+    """pack_conv*_weight(..., lazy=True) skips the fp32 fragment pack of a layer whose split-operand companion will run it (the
+    training path packs every weight every step: ~35 tiny launches per step that nothing read).  A caller that does fall through to
+    the fp32 MFMA kernels -- a volume beyond the split launcher's limits, an explicit impl -- fills the fragments here first."""
+    hit = _lazy_fill.get(id(packed)) if packed is not None else None
+    if hit is not None and hit[0]() is packed:
+        _lazy_fill.pop(id(packed), None)
+        hit[1]()
+    return packed
 
 
 def split_companion(packed):
@@ -617,7 +637,7 @@ def split_f16_enabled():
     return conv_split_enabled() and os.environ.get("MVS_SPLIT_F16", "1") != "0"
 
 
-def pack_conv3d_weight(weight, transposed, stride, split=False, f16=True):
+def pack_conv3d_weight(weight, transposed, stride, split=False, f16=True, lazy=False):
     """PyTorch-layout weight -> MFMA A-fragment order (None if the shape has no
     MFMA configuration).  split: also pack the layer for the split-operand bf16 kernel (mvs_conv_split_f32) where
     its shape has one and MVS_CONV_SPLIT is not 0; conv3d() then runs the layer there (inference paths opt in).  f16: with
@@ -629,9 +649,11 @@ def pack_conv3d_weight(weight, transposed, stride, split=False, f16=True):
     if n <= 0:
         return None
     packed = torch.empty(n, device=weight.device, dtype=torch.float32)
-    check(_lib.load().mvs_conv3d_pack_weights_f32(ptr(weight), int(transposed), cin, cout, stride,
-                                                  ptr(packed), stream()),
-          "mvs_conv3d_pack_weights_f32")
+
+    def fill():
+        check(_lib.load().mvs_conv3d_pack_weights_f32(ptr(weight), int(transposed), cin, cout, stride,
+                                                      ptr(packed), stream()),
+              "mvs_conv3d_pack_weights_f32")
     # (the stride-2 layers have a split-operand kernel too; it wins only where one launch covers the layer -- conv1, 8 -> 16:
     # 0.28 vs 0.34 ms -- not where each 16 output channels re-read and re-split the input: conv3 0.17 vs 0.13, conv5
     # 0.15 vs 0.105: those are routed there only on request)
@@ -653,6 +675,11 @@ def pack_conv3d_weight(weight, transposed, stride, split=False, f16=True):
             import os
             f16d = f16 and split_f16_enabled() and os.environ.get("MVS_DECONV_F16", "1") != "0"      # (A/B switch)
             _register_split(packed, sp, pack_deconv_weight_split_f16(weight) if f16d else None)
+    # lazy: the fp32 fragments only if no split-operand companion will run the layer (materialize_packed() otherwise, on demand)
+    if lazy and split_companion(packed) is not None:
+        _register_lazy(packed, fill)
+    else:
+        fill()
     return packed
 
 
@@ -1013,6 +1040,7 @@ def conv3d(x, weight, scale=None, shift=None, residual=None, relu=False, transpo
         if out is not None:
             return _with_absmax(out, out_absmax)
     out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    materialize_packed(packed)
     check(_lib.load().mvs_conv3d_absmax_f32(
         ptr(x), ptr(weight), ptr(packed), ptr(_f32c(scale)) if scale is not None else None,
         ptr(_f32c(shift)) if shift is not None else None, ptr(residual), int(relu), int(transposed),
@@ -1183,22 +1211,28 @@ def conv2d_supported(cin, cout, ksize, stride):
     return bool(_lib.load().mvs_conv2d_supported(cin, cout, ksize, stride))
 
 
-def pack_conv2d_weight(weight, stride, split=False, f16=True):
-    """(Cout,Cin,k,k) -> MFMA A-fragment order, or None if the layer shape has no kernel.  split: as pack_conv3d_weight."""
+def pack_conv2d_weight(weight, stride, split=False, f16=True, lazy=False):
+    """(Cout,Cin,k,k) -> MFMA A-fragment order, or None if the layer shape has no kernel.  split, lazy: as pack_conv3d_weight."""
     weight = _f32c(weight)
     cout, cin, k, _ = weight.shape
     n = _lib.load().mvs_conv2d_packed_weight_floats(cin, cout, k, stride)
     if n <= 0:
         return None
     packed = torch.empty(n, device=weight.device, dtype=torch.float32)
-    check(_lib.load().mvs_conv2d_pack_weights_f32(ptr(weight), cin, cout, k, stride, ptr(packed),
-                                                  stream()), "mvs_conv2d_pack_weights_f32")
+
+    def fill():
+        check(_lib.load().mvs_conv2d_pack_weights_f32(ptr(weight), cin, cout, k, stride, ptr(packed),
+                                                      stream()), "mvs_conv2d_pack_weights_f32")
     import os
     k55 = stride == 2 and k == 5 and os.environ.get("MVS_CONV_SPLIT_55", "1") != "0"   # (A/B switch)
     if split and ((stride == 1 and k == 3) or k55) and conv_split_enabled():
         sp = pack_conv_weight_split(weight, stride)
         if sp is not None:
             _register_split(packed, sp, pack_conv_weight_split_f16(weight, stride) if (f16 and split_f16_enabled()) else None)
+    if lazy and split_companion(packed) is not None:
+        _register_lazy(packed, fill)
+    else:
+        fill()
     return packed
 
 
@@ -1533,6 +1567,7 @@ def conv2d(x, packed, cin, cout, ksize, stride, scale=None, shift=None, relu=Fal
         coarse = _f32c(coarse)
         if tuple(coarse.shape) != (B, Ho // 2, Wo // 2, cout) or Ho % 2 or Wo % 2:
             raise MvsHipError(f"conv2d: coarse {tuple(coarse.shape)} is not half of {(B, Ho, Wo, cout)}")
+    materialize_packed(packed)
     check(_lib.load().mvs_conv2d_absmax_f32(ptr(x), ptr(packed), ptr(scale), ptr(shift), ptr(coarse), int(relu), B, cin,
                                             cout, H, W, ksize, stride, int(planar) | (2 if out_c4 else 0), ptr(out),
                                             ctypes.c_void_p(out_absmax.data_ptr()) if out_absmax is not None else None, stream()),

@@ -70,7 +70,7 @@ class _Conv3dCL(torch.autograd.Function):
         x = x.contiguous()
         w = weight.detach().contiguous()
         # (split-operand bf16 kernels where the shape has one)
-        packed = _cached(weight, ("pk3", transposed, stride), lambda: ops.pack_conv3d_weight(w, transposed, stride, split=True, f16=False))
+        packed = _cached(weight, ("pk3", transposed, stride), lambda: ops.pack_conv3d_weight(w, transposed, stride, split=True, f16=False, lazy=True))
         if ops.split_companion(packed) is not None:
             ops.split_stage_names.add(f"train.{tag}.fwd")
         with ops.stage(f"train.{tag}.fwd"):
@@ -89,7 +89,7 @@ class _Conv3dCL(torch.autograd.Function):
         gx = gw = None
         if ctx.needs_input_grad[0]:
             if not transposed and stride == 1:
-                wt, pk = _cached(weight, "dgrad3_s1", lambda: (lambda t: (t, ops.pack_conv3d_weight(t, False, 1, split=True, f16=False)))(
+                wt, pk = _cached(weight, "dgrad3_s1", lambda: (lambda t: (t, ops.pack_conv3d_weight(t, False, 1, split=True, f16=False, lazy=True)))(
                     w.flip(2, 3, 4).permute(1, 0, 2, 3, 4).contiguous()))        # (Ci,Co,k) as a conv weight
                 if ops.split_companion(pk) is not None:
                     ops.split_stage_names.add(f"train.{tag}.dgrad")
@@ -99,7 +99,7 @@ class _Conv3dCL(torch.autograd.Function):
                 if any(s % 2 for s in x.shape[1:4]):
                     raise ops.MvsHipError("stride-2 conv backward needs even D, H, W")
                 wc = w.contiguous()                                            # (Co,Ci,k) as a deconv weight
-                pk = _cached(weight, "dgrad3_s2", lambda: ops.pack_conv3d_weight(wc, True, 2, split=True, f16=False))
+                pk = _cached(weight, "dgrad3_s2", lambda: ops.pack_conv3d_weight(wc, True, 2, split=True, f16=False, lazy=True))
                 if ops.split_companion(pk) is not None:
                     ops.split_stage_names.add(f"train.{tag}.dgrad")
                 with ops.stage(f"train.{tag}.dgrad"):
@@ -221,7 +221,7 @@ class _Conv2dCL(torch.autograd.Function):
         x = x.contiguous()
         w = weight.detach().contiguous()
         cout, cin, k, _ = w.shape
-        pk = _cached(weight, ("pk2", stride), lambda: ops.pack_conv2d_weight(w, stride, split=True, f16=False))
+        pk = _cached(weight, ("pk2", stride), lambda: ops.pack_conv2d_weight(w, stride, split=True, f16=False, lazy=True))
         with ops.stage("train.feature.fwd"):
             out = ops.conv2d(x, pk, cin, cout, k, stride, None, None, False, planar=planar)
         ctx.save_for_backward(x, weight)
@@ -241,7 +241,7 @@ class _Conv2dCL(torch.autograd.Function):
             with ops.stage("train.feature.dgrad"):
                 if stride == 1 and ops.conv2d_supported(cout, cin, k, 1) and not planar:
                     pk = _cached(weight, "dgrad2_s1", lambda: ops.pack_conv2d_weight(
-                        w.flip(2, 3).permute(1, 0, 2, 3).contiguous(), 1, split=True, f16=False))
+                        w.flip(2, 3).permute(1, 0, 2, 3).contiguous(), 1, split=True, f16=False, lazy=True))
                     gx = ops.conv2d(g, pk, cout, cin, k, 1)
                 elif stride == 2 and k == 5 and not planar and H % 2 == 0 and W % 2 == 0 and \
                         ops.conv2d_supported(cout, cin, 3, 1):
