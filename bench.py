@@ -266,7 +266,10 @@ def train_main(args, rank, world, dev, dist):
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             def gstep():
-                opt.zero_grad(set_to_none=False)
+                # (set_to_none inside the capture: backward then WRITES every gradient into graph-pool memory instead of accumulating
+                # into zero-filled tensors -- no fill and no add per parameter in the replayed step; torch's own whole-network
+                # capture recipe)
+                opt.zero_grad(set_to_none=True)
                 out = model(slot_imgs, proj, dvals)
                 ls = mvsnet_loss(out["depth"], slot_gt, mask)
                 ls.backward()

@@ -597,13 +597,13 @@ _lazy_fill = {}         # id(packed fp32 weights) -> (weakref to them, closure t
 def _register_split(packed, split, f16=None):
     import weakref
     key = id(packed)
-    _split_registry[key] = (weakref.ref(packed, lambda _r, k=key: _split_registry.pop(k, None)), split, f16)
+    _split_registry[key] = (weakref.ref(packed, lambda _r, k=key, d=_split_registry: d.pop(k, None)), split, f16)
 
 
 def _register_lazy(packed, fill):
     import weakref
     key = id(packed)
-    _lazy_fill[key] = (weakref.ref(packed, lambda _r, k=key: _lazy_fill.pop(k, None)), fill)
+    _lazy_fill[key] = (weakref.ref(packed, lambda _r, k=key, d=_lazy_fill: d.pop(k, None)), fill)   # (dict bound: alive at interpreter teardown)
 
 
 def materialize_packed(packed):
