@@ -213,6 +213,9 @@ def test_costregnet_keeps_damage_where_the_reference_does(dev, weights, case):
     from mvs_amd import ops
     from mvs_amd.models import MVSNet
     from oracle import torch_ref
+    if not (ops.split_f16_enabled() and ops.conv0_f16_enabled()):
+        pytest.skip("the guarded path is the DEFAULT arithmetic; MVS_CONV0_F16=0 / MVS_SPLIT_F16=0 select the unguarded exact kernels, "
+                    "which turn a non-finite voxel into NaN over a slightly wider field (DESIGN section 3)")
     sd = {k: torch.from_numpy(v) for k, v in weights.items()}
     model = MVSNet(refine=False)
     model.load_state_dict(sd)
