@@ -1229,6 +1229,30 @@ def test_mvsnet_train_with_frozen_batchnorm_and_per_view_featurenet(dev, weights
             np.testing.assert_allclose(gr[k], g_ref[k], atol=3e-3 * max(1e-3, np.abs(g_ref[k]).max()), err_msg=f"{k} batched={batched}")
 
 
+def test_lazy_fp32_pack_is_materialised_on_demand(dev):
+    """pack_conv*_weight(lazy=True) (the training path) skips the fp32 fragment pack of a layer its split-operand companion runs;
+    a call that does take the fp32 MFMA kernel -- an explicit impl -- must find the fragments filled."""
+    from mvs_amd import ops
+    g = torch.Generator(device=dev).manual_seed(2)
+    x = torch.randn(1, 6, 10, 20, 16, device=dev, generator=g)
+    w = torch.randn(16, 16, 3, 3, 3, device=dev, generator=g) / 20
+    eager = ops.pack_conv3d_weight(w, False, 1, split=True, f16=False)
+    lazy = ops.pack_conv3d_weight(w, False, 1, split=True, f16=False, lazy=True)
+    assert ops.split_companion(lazy) is not None
+    a = ops.conv3d(x, w, channels_last=True, packed=eager, impl=ops.IMPL_MFMA)
+    b = ops.conv3d(x, w, channels_last=True, packed=lazy, impl=ops.IMPL_MFMA)       # materialises
+    assert torch.equal(a, b) and torch.equal(eager, lazy)
+    assert torch.equal(ops.conv3d(x, w, channels_last=True, packed=lazy), ops.conv3d(x, w, channels_last=True, packed=eager))   # split path
+    x2 = torch.randn(2, 24, 40, 16, device=dev, generator=g)
+    w2 = torch.randn(16, 16, 3, 3, device=dev, generator=g) / 12
+    e2, l2 = ops.pack_conv2d_weight(w2, 1, split=True, f16=False), ops.pack_conv2d_weight(w2, 1, split=True, f16=False, lazy=True)
+    # conv2d(out=...) writes into a caller's tensor, which only the fp32 kernel does: the lazy pack must be filled first
+    oa, ob = torch.empty(2, 24, 40, 16, device=dev), torch.empty(2, 24, 40, 16, device=dev)
+    ops.conv2d(x2, e2, 16, 16, 3, 1, out=oa)
+    ops.conv2d(x2, l2, 16, 16, 3, 1, out=ob)
+    assert torch.equal(oa, ob) and torch.equal(e2, l2)
+
+
 def test_cpu_tensors_rejected():
     from mvs_amd import ops
     from mvs_amd._lib import MvsHipError
