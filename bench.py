@@ -107,25 +107,90 @@ def arithmetic_note():
     return "fp32 data in HBM, fp32 accumulation; convolution products on the 16-bit matrix pipe: " + body
 
 
-def child_bench(extra_args, env_overrides, timeout=900):
-    """Run this script once more in a child process (its own env switches) and return its JSON line, or {'error': ...}."""
-    import subprocess
-    env = dict(os.environ)
-    env.update(env_overrides)
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
-        env.pop(k, None)
-    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-extras"] + extra_args
-    try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
-    except subprocess.TimeoutExpired:
-        return {"error": f"timeout after {timeout} s"}
-    for ln in reversed(r.stdout.strip().splitlines()):
+# what torch.distributed.run exports into its workers: a child launch must not inherit its parent's rendezvous
+_LAUNCH_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_NAME",
+               "ROLE_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS",
+               "TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_ERROR_FILE", "TORCH_NCCL_ASYNC_ERROR_HANDLING")
+
+
+def clean_env(overrides=None):
+    env = {k: v for k, v in os.environ.items() if k not in _LAUNCH_ENV}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between processes needs it on this host driver
+    env.update(overrides or {})
+    return env
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_command(n_gpus, script_args, port):
+    """`python bench.py --gpus N ...` outside a launcher = this command: one process per GPU under torch.distributed.run, the
+    way the reference starts its own ranks (CasMVSNet/train.py:365-393: one process per GPU, env:// rendezvous)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_gpus)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + list(script_args)
+
+
+def last_json_line(text):
+    for ln in reversed((text or "").strip().splitlines()):
         if ln.startswith("{"):
             try:
                 return json.loads(ln)
             except ValueError:
-                break
+                return None
+    return None
+
+
+def self_launch(n_gpus, script_args, timeout=None):
+    """Run N ranks of this script and forward rank 0's JSON line.  Never falls back to fewer ranks: a box with fewer GPUs than
+    asked for is an error (a one-rank run labelled as the N-GPU line is worse than no line)."""
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n_gpus:
+        raise SystemExit(f"bench.py: --gpus {n_gpus} but this box has {have} GPU(s); refusing to run fewer ranks than asked")
+    cmd = launch_command(n_gpus, script_args, free_port())
+    try:
+        r = subprocess.run(cmd, env=clean_env(), stdout=subprocess.PIPE, text=True, timeout=timeout)   # stderr passes through
+    except subprocess.TimeoutExpired:
+        raise SystemExit(f"bench.py: {n_gpus}-rank launch timed out after {timeout} s")
+    line = last_json_line(r.stdout)
+    if r.returncode != 0 or line is None:
+        sys.stderr.write(r.stdout[-2000:])
+        raise SystemExit(f"bench.py: {n_gpus}-rank launch failed (rc {r.returncode})")
+    if line.get("n_gpus") != n_gpus:
+        raise SystemExit(f"bench.py: asked for {n_gpus} ranks, the line says {line.get('n_gpus')}")
+    print(json.dumps(line), flush=True)
+    return 0
+
+
+def child_bench(extra_args, env_overrides, timeout=900, gpus=1):
+    """Run this script once more in a child process (its own env switches; gpus > 1: it launches its own ranks) and return its
+    JSON line, or {'error': ...}."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(gpus), "--no-extras"] + extra_args
+    try:
+        r = subprocess.run(cmd, env=clean_env(env_overrides), capture_output=True, text=True, timeout=timeout, start_new_session=True)
+    except subprocess.TimeoutExpired:
+        return {"error": f"timeout after {timeout} s"}
+    line = last_json_line(r.stdout)
+    if line is not None:
+        return line
     return {"error": f"rc {r.returncode}: {(r.stderr or r.stdout)[-400:]}"}
+
+
+def child_script(rel_path, script_args, timeout=600):
+    """Run one of scripts/bench_*.py on this GPU in a child process and return its JSON line, or {'error': ...}."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(REPO, rel_path)] + list(script_args)
+    try:
+        r = subprocess.run(cmd, env=clean_env(), capture_output=True, text=True, timeout=timeout, start_new_session=True)
+    except subprocess.TimeoutExpired:
+        return {"error": f"timeout after {timeout} s"}
+    line = last_json_line(r.stdout)
+    return line if line is not None else {"error": f"rc {r.returncode}: {(r.stderr or r.stdout)[-400:]}"}
 
 
 def pmc_traffic():
@@ -211,7 +276,7 @@ def train_main(args, rank, world, dev, dist):
     model = MVSNet(refine=False).to(dev)
     parallel.broadcast_parameters(model, 0)
     sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}     # for the CPU baseline
-    use_graph = bool(getattr(args, "graph", False)) and world == 1
+    use_graph = bool(getattr(args, "graph", False))
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.0, capturable=use_graph)   # train.py:98
     reduce_grads = parallel.FlatGradAllReduce(model.parameters())
     rng = np.random.default_rng(100 + rank)
@@ -257,30 +322,19 @@ def train_main(args, rank, world, dev, dist):
     live = ops.StageTimer(only={dominant})
     graph = None
     if use_graph:
-        # the whole step as one graph launch; its input slot is refilled from the pool before every replay.  (The dominant
-        # kernel cannot carry HIP events inside a replay: its time in the roofline is then the instrumented passes'.)
+        # the whole step as HIP graph replays (parallel.GraphedTrainStep): ONE graph on one rank; on N ranks graph A (zero_grad ->
+        # forward -> loss -> backward -> flat pack), the RCCL all-reduce of the flat gradient, graph B (average -> Adam).  The
+        # input slot is refilled from the pool before every replay.  (The dominant kernel cannot carry HIP events inside a
+        # replay: its time in the roofline is then the instrumented passes'.)
         slot_imgs, slot_gt = pool[0][0].clone(), pool[0][1].clone()
         pool = [(a_.clone(), b_.clone()) for a_, b_ in pool]
-        graph = torch.cuda.CUDAGraph()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            def gstep():
-                # (set_to_none inside the capture: backward then WRITES every gradient into graph-pool memory instead of accumulating
-                # into zero-filled tensors -- no fill and no add per parameter in the replayed step; torch's own whole-network
-                # capture recipe)
-                opt.zero_grad(set_to_none=True)
-                out = model(slot_imgs, proj, dvals)
-                ls = mvsnet_loss(out["depth"], slot_gt, mask)
-                ls.backward()
-                opt.step()
-                return ls
-            for _ in range(2):
-                gstep()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        with torch.cuda.graph(graph, capture_error_mode="relaxed"):
-            graph_loss = gstep()
+
+        def forward_loss():
+            out = model(slot_imgs, proj, dvals)
+            return mvsnet_loss(out["depth"], slot_gt, mask)
+
+        graph = parallel.GraphedTrainStep(model.parameters(), opt, forward_loss,
+                                          split=True if (world > 1 or getattr(args, "graph_split", False)) else False)
     else:
         ops.set_timer(live, all_threads=True)
     if dist is not None:
@@ -291,8 +345,7 @@ def train_main(args, rank, world, dev, dist):
         if graph is not None:
             slot_imgs.copy_(pool[i % len(pool)][0], non_blocking=True)
             slot_gt.copy_(pool[i % len(pool)][1], non_blocking=True)
-            graph.replay()
-            loss = graph_loss
+            loss = graph.replay(events=ar_events)
         else:
             loss = step(i, True)
     torch.cuda.synchronize()
@@ -325,7 +378,7 @@ def train_main(args, rank, world, dev, dist):
                                        "gradient all-reduce per step (RCCL)", "grad_floats": reduce_grads.numel},
                 "allreduce_us": (round(1e3 * sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events), 1)
                                  if ar_events else None),
-                "launch": "one HIP graph replay per step" if graph is not None else "eager (~450 launches per step)",
+                "launch": graph.launch_note if graph is not None else "eager (~300 launches per step)",
                 "loss": round(float(loss.item()), 4),
                 "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
                 "guard_fallbacks": ops.guard_fallback_count(),   # two-piece launches that fell back to fp32 (conv_guard.h): 0 expected
@@ -388,21 +441,25 @@ def main():
                          "training 640x512 V=3 D=192, one reference view per GPU, RCCL all-reduce of the flat gradient")
     ap.add_argument("--conv-impl", choices=["auto", "direct", "mfma"], default="auto")
     ap.add_argument("--graph", action="store_true",
-                    help="train mode, one GPU: capture zero_grad -> forward -> loss -> backward -> Adam into ONE HIP graph and "
-                         "time its replays (about 450 launches per step otherwise: on a slow or busy host the eager step is bound "
-                         "by the launching thread, 12-16 ms against 9.4 ms of kernels)")
+                    help="train mode: time the step as HIP graph replays -- one rank: zero_grad -> forward -> loss -> backward -> "
+                         "Adam as ONE graph; N ranks: graph A (... backward, flat gradient pack), the RCCL all-reduce, graph B "
+                         "(average, Adam).  About 300 launches per step otherwise: the eager step is bound by the launching thread")
+    ap.add_argument("--graph-split", action="store_true",
+                    help="with --graph on one rank: take the two-graph form of the N-rank step anyway (its all-reduce is a no-op)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with "
-                  "torch.distributed.run --nproc-per-node N", file=sys.stderr)
-        args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves and forward rank 0's line
+        return self_launch(args.gpus, sys.argv[1:])
+    if world != args.gpus:
+        # a launcher started another number of ranks than the line would claim: an error, not a silent relabel
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with "
+                         f"torch.distributed.run --nproc-per-node {args.gpus}, or plain `python bench.py --gpus {args.gpus}`")
     # the reference's drivers set this (MVSNet/eval.py:23, train.py:25); on ROCm it lets
     # MIOpen pick its fastest FeatureNet convolution kernels during warm-up
     torch.backends.cudnn.benchmark = True
@@ -570,24 +627,46 @@ def main():
             "max_abs_depth_diff_vs_gpu_mm": err, **extra,
         }
     line["guard_fallbacks"] = ops.guard_fallback_count()   # launches whose two-piece layer fell back to fp32 (conv_guard.h): 0 on a sane volume
-    if world == 1 and not args.no_extras:
-        #  the same forward with EXACT operands -- every split-operand layer on the three-piece bf16 kernels --
-        # timed by the same protocol in a child process (the switches are read when the weights are packed), 5 steps
-        shape = ["--height", str(H), "--width", str(W), "--views", str(V), "--ndepth", str(D)]
-        ex = child_bench(["--steps", "5", "--warmup", "3", "--no-cpu-baseline"] + shape, {"MVS_CONV0_F16": "0", "MVS_SPLIT_F16": "0"})
-        line["value_exact_operands"] = ex.get("value")
-        line["exact_operands"] = ({"value": ex.get("value"), "unit": ex.get("unit"), "ms_per_step": ex.get("ms_per_step"), "steps": ex.get("steps"),
-                                   "warmup": ex.get("warmup"), "arithmetic": ex.get("config", {}).get("arithmetic"),
-                                   "dominant": {k: ex.get("roofline", {}).get(k) for k in ("kernel", "ms", "achieved", "peak", "frac")},
-                                   "env": "MVS_CONV0_F16=0 MVS_SPLIT_F16=0"} if "error" not in ex else ex)
-        #  BASELINE configs[4] on this GPU: the training step as one HIP graph replay, 10 timed steps
-        tr = child_bench(["--mode", "train", "--graph", "--steps", "10", "--warmup", "5"] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []), {})
-        line["train"] = ({k: tr.get(k) for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "launch", "loss", "config",
-                                                 "roofline", "cpu_baseline", "peak_mem_GB", "guard_fallbacks")} if "error" not in tr else tr)
-    print(json.dumps(line), flush=True)
     if dist is not None:
-        dist.destroy_process_group()
+        dist.destroy_process_group()      # the extras below are rank 0's alone (the other ranks have left)
+        dist = None
+    if not args.no_extras:
+        shape = ["--height", str(H), "--width", str(W), "--views", str(V), "--ndepth", str(D)]
+        nocpu = ["--no-cpu-baseline"] if (args.no_cpu_baseline or world > 1) else []
+        if world == 1:
+            #  the same forward with EXACT operands -- every split-operand layer on the three-piece bf16 kernels --
+            # timed by the same protocol in a child process (the switches are read when the weights are packed), 5 steps
+            ex = child_bench(["--steps", "5", "--warmup", "3", "--no-cpu-baseline"] + shape, {"MVS_CONV0_F16": "0", "MVS_SPLIT_F16": "0"})
+            line["value_exact_operands"] = ex.get("value")
+            line["exact_operands"] = ({"value": ex.get("value"), "unit": ex.get("unit"), "ms_per_step": ex.get("ms_per_step"), "steps": ex.get("steps"),
+                                       "warmup": ex.get("warmup"), "arithmetic": ex.get("config", {}).get("arithmetic"),
+                                       "dominant": {k: ex.get("roofline", {}).get(k) for k in ("kernel", "ms", "achieved", "peak", "frac")},
+                                       "env": "MVS_CONV0_F16=0 MVS_SPLIT_F16=0"} if "error" not in ex else ex)
+        # BASELINE configs[4] on the SAME number of GPUs: the training step as HIP graph replays, 10 timed steps -- one graph on one
+        # rank; on N ranks (a child launch of N processes, after this job's other ranks have left) two graphs around the RCCL
+        # all-reduce of the flat gradient (mvs_amd/parallel.py::GraphedTrainStep)
+        tr = child_bench(["--mode", "train", "--graph", "--steps", "10", "--warmup", "5"] + nocpu, {}, gpus=world, timeout=600)
+        line["train"] = ({k: tr.get(k) for k in ("metric", "value", "unit", "n_gpus", "ms_per_step", "steps", "warmup", "launch", "allreduce_us",
+                                                 "loss", "config", "roofline", "cpu_baseline", "peak_mem_GB", "guard_fallbacks")}
+                         if "error" not in tr else tr)
+        if world == 1:
+            #  BASELINE configs[2] and configs[3] timed by the same run: 5 steady-state forwards each, the dominant
+            # stage against its roofline, the depth against the REFERENCE's own CPU output on the same seeded inputs (committed
+            # fixtures g13 / g14 -- cheaper and stronger than re-running a CPU restatement here)
+            cas = child_script("scripts/bench_cascade.py", ["--steps", "5", "--golden"])
+            line["cascade"] = ({"workload": "CasMVSNet 3-stage cascade 48/32/8, DTU 1600x1184, N=5 (BASELINE configs[2])",
+                                "ms_per_step": cas.get("ms_per_ref_view"), "value": round(1e3 / cas["ms_per_ref_view"], 3), "unit": "depth-maps/s",
+                                "steps": 5, "roofline": cas.get("roofline"), "peak_mem_GB": cas.get("peak_mem_gb"),
+                                "depth_maxabs_vs_reference_mm": [cas.get(f"stage{i}_depth_maxabs_vs_reference_mm") for i in (1, 2, 3)],
+                                "checker": cas.get("golden")} if "error" not in cas else cas)
+            cvp = child_script("scripts/bench_cvp.py", ["--steps", "5", "--golden"])
+            line["cvp"] = ({"workload": "CVP-MVSNet coarse-to-fine pyramid, 1920x1056, N=7, 5 levels (BASELINE configs[3])",
+                            "ms_per_step": cvp.get("ms_per_ref_view"), "value": round(1e3 / cvp["ms_per_ref_view"], 3), "unit": "depth-maps/s",
+                            "steps": 5, "roofline": cvp.get("roofline"), "peak_mem_GB": cvp.get("peak_mem_gb"),
+                            "depth_maxabs_vs_reference_mm": cvp.get("depth_maxabs_vs_reference_mm_per_level"),
+                            "checker": cvp.get("golden")} if "error" not in cvp else cvp)
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -65,7 +65,8 @@ extern "C" {
 #define MVS_LAYOUT_C4 4
 #define MVS_LAYOUT_C8H 5 /* fp16 pairs of an 8-channel-blocked volume: tuning builds only, include/mvs_hip_tuning.h */
 
-/* Library version: major*10000 + minor*100 + patch. */
+/* Library version: major*10000 + minor*100 + patch.  101 (0.1.1): every *_f16*_packed_bytes size grew -- the fp32 weights
+ * ride behind the packed fragments for the range guard -- so buffers sized by 100 are too small: re-query the sizes. */
 int mvs_version(void);
 /* Text of the last error on the calling thread ("" if none). */
 const char *mvs_last_error_string(void);
@@ -239,8 +240,20 @@ int mvs_conv3d_c8_bf16x6_f32(const float *in, const void *packed, const float *s
  * of a direct convolution.  Otherwise the bound above holds: per product 2^-22 relative for operands within 2^-18 of their
  * tensor's maximum, 2^-40 of the maximum absolute for smaller ones.  mvs_guard_fallback_count reports how many launches of the
  * current device took the fp32 path since the library was loaded (it synchronises: a diagnostic, not a data-path call; call it
- * once before capturing HIP graphs of these layers -- the first call resolves the counter's device address). */
+ * once before capturing HIP graphs of these layers -- the first call resolves the counter's device address).
+ *
+ * LIMITS OF THE VERDICT (it reads only the 256 words of the block, each the maximum over a share of the producer's
+ * workgroups): a block with ONE non-zero word -- a producer that ran a single workgroup, or mvs_absmax_f32 over an array
+ * small enough for one -- has nothing to compare and always passes; outliers spread over an eighth or more of the words are
+ * the tensor's range as far as the verdict can tell.  In both cases elements more than 2^18 below the maximum keep the
+ * ABSOLUTE bound (2^-40 of the maximum), not the relative one.  A caller that cannot rule such inputs out runs the exact
+ * three-piece kernels (mvs_conv3d_c8_bf16x6_f32 / mvs_conv_split_f32 / mvs_deconv_split_f32), which need no scale.
+ * mvs_guard_resolve_all_devices(): resolve the counter on every visible device (call once, before any HIP-graph capture, in a
+ * multi-device process). */
 int mvs_guard_fallback_count(unsigned long long *count);
+int mvs_guard_resolve_all_devices(void);
+/* 0 when `stream` is not capturing a HIP graph, else an id that differs between captures (hipStreamGetCaptureInfo). */
+int mvs_stream_capture_id(void *stream, unsigned long long *id);
 size_t mvs_conv3d_f16x3_packed_bytes(int Cin);
 int mvs_conv3d_pack_weights_f16x3_f32(const float *weight, int Cin, void *packed, void *stream);
 int mvs_absmax_f32(const float *x, int64_t n, void *absmax, void *stream);

@@ -56,6 +56,8 @@ _SIGS = {
     "mvs_conv3d_pack_weights_f16x3_f32": (_c_i, [_c_f, _c_i, _c_f, _c_f]),
     "mvs_absmax_f32": (_c_i, [_c_f, _c_l, _c_f, _c_f]),
     "mvs_guard_fallback_count": (_c_i, [ctypes.POINTER(ctypes.c_ulonglong)]),
+    "mvs_guard_resolve_all_devices": (_c_i, []),
+    "mvs_stream_capture_id": (_c_i, [_c_f, ctypes.POINTER(ctypes.c_ulonglong)]),
     "mvs_conv3d_c8_f16x3_f32": (_c_i, [_c_f] * 6 + [_c_i] * 6 + [_c_f, _c_f, _c_f]),
     "mvs_conv_split_supported": (_c_i, [_c_i] * 4),
     "mvs_conv_split_packed_bytes": (ctypes.c_size_t, [_c_i] * 4),
@@ -156,9 +158,9 @@ def load():
     _lib = lib
     # resolve the range guard's device counter now (hipGetSymbolAddress on first use may load the code object: not something to
     # meet for the first time inside a HIP-graph capture)
+    # -- on every visible device (a DataParallel replica's first launch on another device would otherwise do it)
     if torch.cuda.is_available():
-        n = ctypes.c_ulonglong(0)
-        lib.mvs_guard_fallback_count(ctypes.byref(n))
+        lib.mvs_guard_resolve_all_devices()
     return lib
 
 

@@ -2,6 +2,7 @@
 // mvs_conv3d_f32 dispatcher (include/mvs_hip.h).
 #include "mvs_common.h"
 
+#include <atomic>
 #include <cstring>
 
 namespace mvs {
@@ -18,15 +19,19 @@ void set_error(const char *fmt, ...) {
 // launches that took the range guard's fallback (conv_guard.h), per device
 __device__ unsigned long long g_guard_fallbacks;
 unsigned long long *guard_counter() {
-    static unsigned long long *ptr[64] = {nullptr};
+    // one slot per device, published with release / acquire: concurrent host threads (nn.DataParallel replicas) may race to
+    // resolve the same slot, and both then store the same address
+    static std::atomic<unsigned long long *> ptr[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (!ptr[dev]) {
+    unsigned long long *q = ptr[dev].load(std::memory_order_acquire);
+    if (!q) {
         void *p = nullptr;
         if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_guard_fallbacks)) != hipSuccess) return nullptr;
-        ptr[dev] = static_cast<unsigned long long *>(p);
+        q = static_cast<unsigned long long *>(p);
+        ptr[dev].store(q, std::memory_order_release);
     }
-    return ptr[dev];
+    return q;
 }
 
 int conv3d_direct_launch(const float *, const float *, const float *, const float *, const float *,
@@ -114,7 +119,9 @@ static int launch_transpose(const float *in, float *out, int B, int R, int64_t S
 
 using namespace mvs;
 
-extern "C" int mvs_version(void) { return 100; /* 0.1.0 */ }
+// 0.1.1: the *_f16*_packed_bytes sizes grew (the fp32 weights ride behind the packed fragments for the range guard) and the
+// c8h entry points left the release library -- a client sized by 0.1.0 must re-query
+extern "C" int mvs_version(void) { return 101; /* 0.1.1 */ }
 extern "C" const char *mvs_last_error_string(void) { return g_err; }
 extern "C" const char *mvs_arch(void) { return "gfx950"; }
 
@@ -128,6 +135,33 @@ extern "C" int mvs_guard_fallback_count(unsigned long long *count) {
     }
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(count, p, sizeof(*count), hipMemcpyDeviceToHost) != hipSuccess)
         return bare_error(MVS_ELAUNCH, __func__, __LINE__);
+    return MVS_OK;
+}
+
+// Resolve the guard counter of EVERY visible device now (hipGetSymbolAddress on first use may load a code object: not something
+// a launch should meet for the first time inside a HIP-graph capture on a device that was not current at load time).
+extern "C" int mvs_guard_resolve_all_devices(void) {
+    int n = 0, cur = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || hipGetDevice(&cur) != hipSuccess) return bare_error(MVS_ELAUNCH, __func__, __LINE__);
+    int rc = MVS_OK;
+    for (int d = 0; d < n && d < 64; ++d) {
+        if (hipSetDevice(d) != hipSuccess || !guard_counter()) rc = MVS_ELAUNCH;
+    }
+    (void)hipSetDevice(cur);
+    if (rc != MVS_OK) set_error("mvs_guard_resolve_all_devices: a device has no counter");
+    return rc;
+}
+
+// The id of the HIP-graph capture `stream` is in (0 = not capturing): lets a host-side cache tell one capture from the next.
+extern "C" int mvs_stream_capture_id(void *stream, unsigned long long *id) {
+    if (!id) {
+        set_error("mvs_stream_capture_id: id is NULL");
+        return MVS_EINVAL;
+    }
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long cid = 0;
+    if (hipStreamGetCaptureInfo(as_stream(stream), &st, &cid) != hipSuccess) return bare_error(MVS_ELAUNCH, __func__, __LINE__);
+    *id = (st == hipStreamCaptureStatusActive) ? (cid ? cid : 1ull) : 0ull;
     return MVS_OK;
 }
 

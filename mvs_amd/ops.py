@@ -588,46 +588,42 @@ def conv3d_mfma_supported(transposed, cin, cout, stride):
     return bool(_lib.load().mvs_conv3d_mfma_supported(int(transposed), cin, cout, stride))
 
 
-_split_registry = {}   # id(packed fp32 weights) -> (weakref to them, their split-operand companion)
-
-
-_lazy_fill = {}         # id(packed fp32 weights) -> (weakref to them, closure that fills them): fp32 fragments not packed yet
-
-
+# A packed fp32 weight tensor carries its derived packs as attributes of the tensor OBJECT: `_mvs_split` = (bf16 three-piece
+# companion, fp16 two-piece companion), `_mvs_lazy_fill` = the callable that fills its fp32 fragments on demand.  Nothing
+# module-level owns them (an id-keyed registry whose entry held a closure over `packed` pinned every training
+# step's packs forever -- ~5 MB per eager step); they die with the tensor.
 def _register_split(packed, split, f16=None):
-    import weakref
-    key = id(packed)
-    _split_registry[key] = (weakref.ref(packed, lambda _r, k=key, d=_split_registry: d.pop(k, None)), split, f16)
+    packed._mvs_split = (split, f16)
 
 
 def _register_lazy(packed, fill):
-    import weakref
-    key = id(packed)
-    _lazy_fill[key] = (weakref.ref(packed, lambda _r, k=key, d=_lazy_fill: d.pop(k, None)), fill)   # (dict bound: alive at interpreter teardown)
+    """fill(packed) writes the fp32 fragments; it must not close over `packed` itself (a tensor -> closure -> tensor cycle
+    would leave the device memory to the cycle collector)."""
+    packed._mvs_lazy_fill = fill
 
 
 def materialize_packed(packed):
     """pack_conv*_weight(..., lazy=True) skips the fp32 fragment pack of a layer whose split-operand companion will run it (the
     training path packs every weight every step: ~35 tiny launches per step that nothing read).  A caller that does fall through to
     the fp32 MFMA kernels -- a volume beyond the split launcher's limits, an explicit impl -- fills the fragments here first."""
-    hit = _lazy_fill.get(id(packed)) if packed is not None else None
-    if hit is not None and hit[0]() is packed:
-        _lazy_fill.pop(id(packed), None)
-        hit[1]()
+    fill = getattr(packed, "_mvs_lazy_fill", None) if packed is not None else None
+    if fill is not None:
+        packed._mvs_lazy_fill = None
+        fill(packed)
     return packed
 
 
 def split_companion(packed):
     """The bf16 hi/mid/lo pack registered for this packed weight tensor (pack_conv*_weight(..., split=True)), or None."""
-    hit = _split_registry.get(id(packed)) if packed is not None else None
-    return hit[1] if hit is not None and hit[0]() is packed else None
+    hit = getattr(packed, "_mvs_split", None) if packed is not None else None
+    return hit[0] if hit is not None else None
 
 
 def f16_companion(packed):
     """The scaled fp16 hi/lo pack registered beside it (two-piece form: the layer runs there when its caller hands the
     input's absmax block to conv3d / conv2d), or None."""
-    hit = _split_registry.get(id(packed)) if packed is not None else None
-    return hit[2] if hit is not None and hit[0]() is packed else None
+    hit = getattr(packed, "_mvs_split", None) if packed is not None else None
+    return hit[1] if hit is not None else None
 
 
 def split_f16_enabled():
@@ -650,9 +646,9 @@ def pack_conv3d_weight(weight, transposed, stride, split=False, f16=True, lazy=F
         return None
     packed = torch.empty(n, device=weight.device, dtype=torch.float32)
 
-    def fill():
+    def fill(dst):
         check(_lib.load().mvs_conv3d_pack_weights_f32(ptr(weight), int(transposed), cin, cout, stride,
-                                                      ptr(packed), stream()),
+                                                      ptr(dst), stream()),
               "mvs_conv3d_pack_weights_f32")
     # (the stride-2 layers have a split-operand kernel too; it wins only where one launch covers the layer -- conv1, 8 -> 16:
     # 0.28 vs 0.34 ms -- not where each 16 output channels re-read and re-split the input: conv3 0.17 vs 0.13, conv5
@@ -679,7 +675,7 @@ def pack_conv3d_weight(weight, transposed, stride, split=False, f16=True, lazy=F
     if lazy and split_companion(packed) is not None:
         _register_lazy(packed, fill)
     else:
-        fill()
+        fill(packed)
     return packed
 
 
@@ -1220,8 +1216,8 @@ def pack_conv2d_weight(weight, stride, split=False, f16=True, lazy=False):
         return None
     packed = torch.empty(n, device=weight.device, dtype=torch.float32)
 
-    def fill():
-        check(_lib.load().mvs_conv2d_pack_weights_f32(ptr(weight), cin, cout, k, stride, ptr(packed),
+    def fill(dst):
+        check(_lib.load().mvs_conv2d_pack_weights_f32(ptr(weight), cin, cout, k, stride, ptr(dst),
                                                       stream()), "mvs_conv2d_pack_weights_f32")
     import os
     k55 = stride == 2 and k == 5 and os.environ.get("MVS_CONV_SPLIT_55", "1") != "0"   # (A/B switch)
@@ -1232,7 +1228,7 @@ def pack_conv2d_weight(weight, stride, split=False, f16=True, lazy=False):
     if lazy and split_companion(packed) is not None:
         _register_lazy(packed, fill)
     else:
-        fill()
+        fill(packed)
     return packed
 
 

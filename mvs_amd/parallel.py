@@ -69,6 +69,108 @@ class FlatGradAllReduce:
         torch._foreach_copy_([p.grad for p in self.params], views)
 
 
+class GraphedTrainStep:
+    """One data-parallel training step -- zero_grad -> forward -> loss -> backward -> gradient average -> optimizer step
+    (MVSNet/train.py:204-248 under CasMVSNet/train.py:365-393's one process per GPU) -- as HIP-graph replays, so that N ranks do
+    not each push ~300 kernel launches per step through their interpreters (the eager step is host-bound: DESIGN.md section 4).
+
+    split=False (one rank): the whole step is ONE graph.
+    split=True (any number of ranks; the default when the process group has more than one): graph A = zero_grad -> forward ->
+    loss -> backward -> pack every gradient into one flat fp32 buffer (one concatenation kernel); then ONE RCCL all-reduce of
+    that buffer, launched eagerly on the same stream between the two replays (1.35 MB for MVSNet: latency-bound on xGMI, one
+    bucket); graph B = scale by 1/world, one multi-tensor copy back into the gradient tensors, the optimizer step.  The
+    optimizer must be `capturable` (torch.optim.Adam(..., capturable=True)).
+
+    forward_loss() runs the model on STATIC input tensors the caller refills before each replay and returns the scalar loss."""
+
+    def __init__(self, params, opt, forward_loss, split=None, allreduce=True, warmup=2):
+        self.params = [p for p in params if p.requires_grad]
+        self.opt = opt
+        self.forward_loss = forward_loss
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.split = (self.world > 1) if split is None else bool(split)
+        if self.world > 1 and not self.split:
+            raise ValueError("more than one rank needs the split form (the all-reduce sits between the two graphs)")
+        self.allreduce = bool(allreduce) and self.world > 1
+        self.numel = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(self.numel, device=dev, dtype=torch.float32) if self.split else None
+        self.views = [v.view(p.shape) for v, p in zip(self.flat.split([p.numel() for p in self.params]), self.params)] \
+            if self.split else None
+        self.graphs = []
+        self.loss = None
+        self._capture(warmup)
+
+    # the two halves of a split step; eager and captured runs go through the same code
+    def _backward_and_pack(self):
+        self.opt.zero_grad(set_to_none=True)      # backward then WRITES each gradient (graph-pool memory under capture): no fill, no add
+        loss = self.forward_loss()
+        loss.backward()
+        if self.split:
+            dev = self.flat.device
+            torch.cat([p.grad.reshape(-1) if p.grad is not None else torch.zeros(p.numel(), device=dev, dtype=torch.float32)
+                       for p in self.params], out=self.flat)
+        return loss
+
+    def _average_and_step(self):
+        if self.split:
+            if self.world > 1:
+                self.flat.mul_(1.0 / self.world)
+            # back into the tensors backward wrote (one multi-tensor copy): the optimizer then runs the very kernels of the
+            # one-graph step on the very same operands -- with the gradients as VIEWS of the flat buffer torch's multi-tensor
+            # Adam took another code path (unaligned views) and the parameters drifted from the one-graph step's in the last bit
+            torch._foreach_copy_([p.grad for p in self.params], self.views)
+        self.opt.step()
+
+    def _reduce(self):
+        if self.allreduce:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+
+    def _capture(self, warmup):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):      # optimizer state, lazy packs, the RCCL communicator: all before the capture
+                self._backward_and_pack()
+                self._reduce()
+                self._average_and_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        ga = torch.cuda.CUDAGraph()
+        if not self.split:
+            with torch.cuda.graph(ga, capture_error_mode="relaxed"):
+                self.loss = self._backward_and_pack()
+                self._average_and_step()
+            self.graphs = [ga]
+            return
+        with torch.cuda.graph(ga, capture_error_mode="relaxed"):
+            self.loss = self._backward_and_pack()
+        gb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="relaxed"):
+            self._average_and_step()
+        self.graphs = [ga, gb]
+
+    def replay(self, events=None):
+        """One step.  events: a list that receives (start, stop) HIP events around the all-reduce."""
+        self.graphs[0].replay()
+        if self.split:
+            if events is not None and self.allreduce:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); self._reduce(); b.record()
+                events.append((a, b))
+            else:
+                self._reduce()
+            self.graphs[1].replay()
+        return self.loss
+
+    @property
+    def launch_note(self):
+        if not self.split:
+            return "one HIP graph replay per step"
+        return ("two HIP graph replays per step (backward + flat pack | average + optimizer) around "
+                + ("one eager RCCL all-reduce" if self.allreduce else "a no-op all-reduce"))
+
+
 def broadcast_parameters(model, src=0):
     """Make every rank start from rank `src`'s weights and buffers."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

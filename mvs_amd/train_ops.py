@@ -23,7 +23,18 @@ import weakref
 
 _derived = {}           # eager use
 _derived_capture = {}   # while a HIP graph is being captured (see _cached)
-_capture_state = {"on": False}
+_capture_state = {"id": 0}
+
+
+def _capture_id():
+    """0 when the current stream is not capturing, else the id of the capture it is in (hipStreamGetCaptureInfo through
+    mvs_stream_capture_id): two captures with no eager call between them are still two captures."""
+    import ctypes
+    if not torch.cuda.is_current_stream_capturing():
+        return 0
+    cid = ctypes.c_ulonglong(0)
+    ops.check(ops._lib.load().mvs_stream_capture_id(ops.stream(), ctypes.byref(cid)), "mvs_stream_capture_id")
+    return int(cid.value) or 1
 
 
 def _cached(weight, kind, make):
@@ -39,12 +50,13 @@ def _cached(weight, kind, make):
     after them.
     While the stream is capturing a HIP graph the eager entries are not used: the graph must CONTAIN the kernels that
     derive the packs from the weights it updates, or its replays would run with the packs of capture time.  Entries made
-    during a capture live in their own table (the forward and the backward of the captured step still share them) that is
-    dropped when the next capture begins."""
-    capturing = weight.is_cuda and torch.cuda.is_current_stream_capturing()
-    if capturing and not _capture_state["on"]:
+    during a capture live in their own table (the forward and the backward of the captured step still share them), which
+    belongs to ONE capture: it is dropped as soon as a call arrives under another capture id."""
+    cid = _capture_id() if weight.is_cuda else 0
+    capturing = cid != 0
+    if capturing and cid != _capture_state["id"]:
         _derived_capture.clear()
-    _capture_state["on"] = capturing
+        _capture_state["id"] = cid
     table = _derived_capture if capturing else _derived
     key = (id(weight), kind)
     hit = table.get(key)

@@ -19,7 +19,10 @@ from mvs_amd.models.cas_mvsnet import CascadeMVSNet  # noqa: E402
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    argv = list(sys.argv[1:])
+    if "--steps" in argv:          # its value is not a positional size
+        del argv[argv.index("--steps") + 1]
+    args = [a for a in argv if not a.startswith("--")]
     H, W, V = (int(x) for x in (args[:3] or (1184, 1600, 5)))
     steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 5
     dev = torch.device("cuda:0")
@@ -58,6 +61,38 @@ def main():
             print("total kernel ms", round(sum(e.device_time_total for e in rows) / 1e3, 2), file=sys.stderr)
             for e in rows[:36]:
                 print(f"{e.key[:120]:120s} n={e.count:4d} ms={e.device_time_total / 1e3:7.2f}", file=sys.stderr)
+        # the dominant sweep / regulariser stage against its roofline (HIP events around the stage, steady state)
+        feat = {"stage1": (H // 4, W // 4, 32), "stage2": (H // 2, W // 2, 16), "stage3": (H, W, 8)}
+        work = {}
+        for (st_name, (h, w, c)), nd in zip(feat.items(), net.ndepths):
+            n0 = nd * h * w
+            work[st_name + ".costvol_variance"] = ("hbm", (V * c * h * w + n0 + c * n0) * 4.0)   # per-pixel hypotheses: D*h*w depths
+            fl = 2.0 * 27 * n0 * (c * 8 + 8 * 16 / 8 + 16 * 16 / 8 + 16 * 32 / 64 + 32 * 32 / 64 + 32 * 64 / 512 + 64 * 64 / 512
+                                  + 64 * 32 / 512 + 32 * 16 / 64 + 16 * 8 / 8 + 8)
+            work[st_name + ".costreg"] = ("mfma", fl)
+        ms = {k: v[1] for k, v in res["stages_ms"].items() if k in work}
+        dom = max(ms, key=ms.get)
+        kind, amount = work[dom]
+        if kind == "hbm":
+            ach = amount / (ms[dom] * 1e-3) / 1e9
+            res["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
+                               "frac": round(ach / 8000.0, 4), "algorithmic_bytes": amount, "ms": ms[dom]}
+        else:
+            ach = amount / (ms[dom] * 1e-3) / 1e12
+            peak = 2500.0 / 3.0 if ops.split_f16_enabled() else 2500.0 / 6.0
+            res["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                               "frac": round(ach / peak, 4), "algorithmic_flops": amount, "ms": ms[dom],
+                               "peak_note": "the eleven layers of the stage's regulariser in one C call (mvs_costreg_fwd2_f32); fp16 dense "
+                                            "MFMA peak / products per fp32 product of the split-operand kernels"}
+        if "--golden" in sys.argv and (H, W, V) == (1184, 1600, 5):
+            # the reference's own CascadeMVSNet CPU forward on these inputs (tests/golden/make_golden_fullsize.py: g13; the
+            # 1184x1600 stage on the even-row, even-column grid)
+            g = dict(np.load(os.path.join(REPO, "tests", "golden", "g13_cas_fullsize.npz")))
+            res["golden"] = "tests/golden/g13_cas_fullsize.npz: the imported reference's CPU forward on the same seeded inputs"
+            for k in ("stage1", "stage2", "stage3"):
+                sub = 2 if k == "stage3" else 1
+                res[k + "_depth_maxabs_vs_reference_mm"] = float(
+                    (out[k]["depth"][:, ::sub, ::sub].cpu() - torch.from_numpy(g[k + "_depth"])).abs().max())
         if "--parity" in sys.argv:
             from oracle import torch_ref as tr
             torch.set_num_threads(os.cpu_count())

@@ -19,7 +19,10 @@ from mvs_amd.models.cvp_mvsnet import network  # noqa: E402
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    argv = list(sys.argv[1:])
+    if "--steps" in argv:          # its value is not a positional size
+        del argv[argv.index("--steps") + 1]
+    args = [a for a in argv if not a.startswith("--")]
     H, W, nsrc, nscale = (int(x) for x in (args[:4] or (1056, 1920, 6, 5)))
     steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 5
     dev = torch.device("cuda:0")
@@ -90,6 +93,24 @@ def main():
         res["kernel_ms_by_group"] = {k: round(v, 2) for k, v in groups.items()}
         res["group_TFLOPs"] = {"feature_pyramid": round(flops["feature_pyramid"] / groups["feature_pyramid_2d_convs"] / 1e9, 1),
                                "costreg": round(flops["costreg"] / groups["costreg_3d_convs"] / 1e9, 1)}
+    # whole-forward roofline: the pyramid CNN and the regularisers are matrix-pipe work on the two-piece fp16 kernels
+    from mvs_amd import ops
+    peak = 2500.0 / 3.0 if ops.split_f16_enabled() else 2500.0 / 6.0
+    res["roofline"] = {"kernel": "whole forward (9-layer pyramid CNN x views x levels + refinement U-Nets)", "bound": "mfma",
+                       "achieved": res["achieved_TFLOPs"], "peak": round(peak, 1), "unit": "TFLOP/s",
+                       "frac": round(res["achieved_TFLOPs"] / peak, 4), "algorithmic_flops": total, "ms": res["ms_per_ref_view"],
+                       "peak_note": "fp16 dense MFMA peak 2500 / 3 products per fp32 product; against the fp32 MFMA peak (157.3): "
+                                    f"{res['frac_fp32_mfma_peak']}"}
+    if "--golden" in sys.argv and (H, W, nsrc, nscale) == (1056, 1920, 6, 5):
+        # the reference's own CVP `network` CPU forward on these inputs (tests/golden/make_golden_fullsize.py: g14; maps wider
+        # than 1000 pixels on the even-row, even-column grid)
+        g = dict(np.load(os.path.join(REPO, "tests", "golden", "g14_cvp_fullsize.npz")))
+        res["golden"] = "tests/golden/g14_cvp_fullsize.npz: the imported reference's CPU forward on the same seeded inputs"
+        res["depth_maxabs_vs_reference_mm_per_level"] = []
+        for i, d in enumerate(out["depth_est_list"]):
+            sub = 2 if d.shape[-1] > 1000 else 1
+            res["depth_maxabs_vs_reference_mm_per_level"].append(
+                float((d[:, ::sub, ::sub].cpu() - torch.from_numpy(g[f"depth_level{i}"])).abs().max()))
     if "--parity" in sys.argv:   # the checker: ATen CPU restatement on the same inputs
         from oracle import torch_ref as tr
         torch.set_num_threads(os.cpu_count())

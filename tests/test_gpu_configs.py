@@ -38,7 +38,10 @@ def test_mvsnet_config4_train_step_640x512_v3_d192():
     # forward: as close to the float64 depth as the reference's train() forward is (max and rms)
     assert d["hip_vs_f64_mm"] <= 1.25 * d["ref_vs_f64_mm"], d
     assert d["hip_vs_f64_rms"] <= 1.1 * d["ref_vs_f64_rms"], d
-    assert d["maxabs_mm"] <= d["hip_vs_f64_mm"] + d["ref_vs_f64_mm"], d
+    # against the reference's own train-mode depth: a FIXED bound (the sum of the two distances to float64 is the
+    # triangle inequality and cannot fail).  Measured 0.218 mm, with the reference itself 0.234 mm from the float64 step (batch-
+    # statistics BatchNorm and a x30 sharper softmax amplify float32 rounding ~300x over the eval forward's 7e-4 mm)
+    assert d["maxabs_mm"] <= 0.30, d
     # loss
     assert abs(r["loss"] - r["loss64"]) <= 2.0 * abs(r["loss_ref"] - r["loss64"]) + 1e-6 * abs(r["loss64"]), r
     assert abs(r["loss"] - r["loss_ref"]) <= 1e-5 * abs(r["loss_ref"]), r

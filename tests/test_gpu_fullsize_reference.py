@@ -15,6 +15,7 @@ import pytest
 import torch
 
 from fullsize_cases import run_cas, run_cvp, run_mvsnet
+from mvs_amd import ops
 
 pytestmark = pytest.mark.gpu
 GATE_MM = 1e-3
@@ -77,7 +78,10 @@ def test_cvp_config4_matches_reference_forward(scene):
         r = run_cvp(scene)
     for k, v in r.items():
         if k.startswith("level"):
-            assert v["hip_vs_f64_mm"] < GATE_MM and v["hip_vs_f64_mm"] <= 1.2 * v["ref_vs_f64_mm"] and v["hip_vs_f64_rms"] <= v["ref_vs_f64_rms"], (k, v)
+            # default build: no farther from the float64 answer than the reference, maximum and rms, no allowance;
+            # the 1.2x on the maximum remains for the exact-operand switches only (1.15x at one level there)
+            slack = 1.0 if (ops.conv0_f16_enabled() and ops.split_f16_enabled()) else 1.2
+            assert v["hip_vs_f64_mm"] < GATE_MM and v["hip_vs_f64_mm"] <= slack * v["ref_vs_f64_mm"] and v["hip_vs_f64_rms"] <= v["ref_vs_f64_rms"], (k, v)
             assert v["p999_mm"] < GATE_MM, (k, v)
             gate = GATE_MM if v["ref_vs_f64_mm"] < 0.7 * GATE_MM else 1.3e-3
             assert v["maxabs_mm"] < gate, (k, v)

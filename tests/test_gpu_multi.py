@@ -30,6 +30,27 @@ def test_bench_two_gpus_shards_reference_views_without_a_collective():
     assert "no collective" in line["config"]["sharding"]
 
 
+def test_plain_python_bench_gpus_2_starts_two_ranks():
+    """VERDICT r04 item 1: `python bench.py --gpus 2` WITHOUT a launcher starts its own two ranks and forwards rank 0's line;
+    the training child of the line runs on two ranks as graph replays around the RCCL all-reduce."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2"], cwd=REPO, env=env,
+                       capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    tr = line["train"]
+    assert "error" not in tr, tr
+    assert tr["n_gpus"] == 2 and tr["launch"].startswith("two HIP graph replays") and tr["allreduce_us"] > 0
+
+
+def test_bench_train_graph_two_gpus():
+    out = _torchrun(["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "2", "--mode", "train", "--graph", "--no-cpu-baseline"], 29614)
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["launch"].startswith("two HIP graph replays")
+    assert line["allreduce_us"] is not None and line["allreduce_us"] > 0
+
+
 def test_bench_train_mode_two_gpus_allreduces_the_flat_gradient():
     out = _torchrun(["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "2", "--mode", "train"], 29612)
     line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])

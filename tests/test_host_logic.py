@@ -222,3 +222,65 @@ def test_derived_weight_cache_is_tied_to_the_tensor_object():
     del w, alias, a
     gc.collect()
     assert len(train_ops._derived) < n       # the weakref callbacks evicted the entries
+
+
+def test_derived_packs_die_with_the_packed_tensor():
+    """the split-operand companions and the lazy fp32 fill of a packed weight must not be owned by any
+    module-level table -- an id-keyed registry whose value closed over `packed` pinned every eager training step's packs
+    (~5 MB per step).  They are attributes of the tensor object: N pack / drop cycles leave nothing behind."""
+    import gc
+    import weakref
+    from mvs_amd import ops
+    assert not hasattr(ops, "_lazy_fill") and not hasattr(ops, "_split_registry")
+    refs, filled = [], []
+    for i in range(50):
+        packed = torch.empty(16)
+        comp, comp16 = torch.empty(8), torch.empty(4)
+        weight = torch.randn(4)
+        ops._register_split(packed, comp, comp16)
+        ops._register_lazy(packed, lambda dst, w=weight: filled.append(dst.data_ptr()))   # closes over the weight, not the pack
+        assert ops.split_companion(packed) is comp and ops.f16_companion(packed) is comp16
+        if i % 2:
+            assert ops.materialize_packed(packed) is packed and filled[-1] == packed.data_ptr()
+            n = len(filled)
+            ops.materialize_packed(packed)                 # a second call does not fill again
+            assert len(filled) == n
+        refs += [weakref.ref(packed), weakref.ref(comp), weakref.ref(comp16)]
+        del packed, comp, comp16, weight
+    gc.collect()
+    assert all(r() is None for r in refs)
+    assert ops.split_companion(None) is None and ops.f16_companion(torch.empty(1)) is None
+
+
+def test_bench_self_launch_command_and_environment(monkeypatch):
+    """plain `python bench.py --gpus N` must start N ranks (one process per GPU, CasMVSNet/train.py:365-393)
+    -- never relabel a one-rank run.  The command construction, the scrubbed environment and the refusal on a box with fewer
+    GPUs are host logic."""
+    import json
+    sys.path.insert(0, REPO)
+    import bench
+    cmd = bench.launch_command(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"], 29555)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert "--nproc-per-node=8" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29555"
+    i = cmd.index(os.path.join(REPO, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        monkeypatch.setenv(k, "7")
+    env = bench.clean_env({"MVS_X": "1"})
+    assert not any(k in env for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "TORCHELASTIC_RUN_ID"))
+    assert env["MVS_X"] == "1" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert 1024 < bench.free_port() < 65536
+    assert bench.last_json_line('noise\n{"n_gpus": 2}\ntrailing') == {"n_gpus": 2}
+    assert bench.last_json_line("no json here") is None
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit) as e:
+        bench.self_launch(2, ["--gpus", "2"])
+    assert "refusing" in str(e.value)
+    # a launcher that started another number of ranks than --gpus says: an error, not a relabelled line
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE=1" in str(e.value)
