@@ -76,6 +76,9 @@ def algorithmic_work(V, C, D, h, w):
                                    "conv11": (16, 8, 1)}.items():
         work["costreg." + name] = ("mfma", 2.0 * 27 * ci * co * n0 / (8 ** lvl_in))
     work["costreg.prob"] = ("mfma", 2.0 * 27 * 8 * 1 * n0)
+    # conv11 + prob in one launch (tail_fused.hip): HBM-bound -- conv11's 16-channel input at 1/8 of the voxels, the 8-channel
+    # skip volume, the cost volume out; the 8-channel volume between the two layers stays in LDS
+    work["costreg.tail"] = ("hbm", 4.0 * n0 * (16 / 8 + 8 + 1))
     # FeatureNet: V views, image 4h x 4w; (cin, cout, k, out-scale)
     for name, (ci, co, k, sc) in {"conv0": (3, 8, 3, 1), "conv1": (8, 8, 3, 1),
                                   "conv2": (8, 16, 5, 2), "conv3": (16, 16, 3, 2),

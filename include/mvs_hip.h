@@ -342,6 +342,39 @@ int mvs_costreg_fwd2_f32(const float *in, int in_layout, const mvs_conv_layer *l
                          int B, int Cin, int base, int D, int H, int W, int impl, void *workspace, size_t workspace_bytes,
                          const void *in_absmax, float *out_cost, void *stream);
 
+/* ---- the tail of CostRegNet as one kernel (mvs_amd/csrc/tail_fused.hip; MVSNet/models/mvsnet.py:79-81,89-93) -------
+ * x = conv0 + conv11(x) (ConvTranspose3d 16 -> 8, k3 s2 p1 op1, folded BatchNorm, ReLU, skip add after the ReLU) followed by
+ * prob (Conv3d 8 -> 1, k3 p1, bias): the full-resolution 8-channel volume between them never reaches HBM.  Two-piece fp16
+ * operands as mvs_conv3d_c8_f16x3_f32 (same bound per product; the intermediate volume is scaled by a power of two derived from
+ * a BOUND on its magnitude -- the two absmax blocks, the weights' largest magnitude, the affine -- so no pass over it is needed).
+ *   in [B, Di, Hi, Wi, 16] channels-last with its absmax block; skip [B, 2Di, 2Hi, 2Wi, 8] with its block;
+ *   packed_tail: mvs_costreg_tail_packed_bytes() bytes written by mvs_costreg_tail_pack_weights_f32 from conv11's weight
+ *   (16, 8, 3, 3, 3); scale / shift: conv11's 8 + 8 affine (NULL = 1 / 0); prob_weight (1, 8, 3, 3, 3) as PyTorch stores it,
+ *   prob_scale / prob_shift: 1 + 1 (NULL = 1 / 0; shift = the bias); out_cost [B, 2Di, 2Hi, 2Wi].
+ * RANGE GUARD: the verdict of mvs_conv3d_c8_f16x3_f32 on BOTH blocks, finite weights, a finite bound.  A launch that fails it
+ * computes nothing and writes 1 to *fallback_flag (a device word the caller zeroed); the caller then runs the unfused layers
+ * (mvs_deconv_split_f16_f32 + mvs_conv3d_f32), whose own guard reproduces the reference's Inf / NaN semantics.
+ * mvs_costreg_fwd3_f32 = mvs_costreg_fwd2_f32 with that arrangement inside: packed_tail non-NULL (and base = 8) routes conv11 + prob
+ * through the fused kernel and enqueues the unfused layers behind it so that they run only if the flag was set -- no host
+ * synchronisation.  mvs_costreg_workspace_bytes covers the flag. */
+size_t mvs_costreg_tail_packed_bytes(void);
+int mvs_costreg_tail_pack_weights_f32(const float *conv11_weight, void *packed, void *stream);
+int mvs_costreg_tail_supported(int B, int Di, int Hi, int Wi);
+int mvs_costreg_tail_f16_f32(const float *in, const void *in_absmax, const float *skip, const void *skip_absmax,
+                             const void *packed_tail, const float *scale, const float *shift, const float *prob_weight,
+                             const float *prob_scale, const float *prob_shift, int B, int Di, int Hi, int Wi,
+                             float *out_cost, void *fallback_flag, void *stream);
+/* The fused kernel with the unfused layers enqueued behind it under its flag (what mvs_costreg_fwd3_f32 does for conv11 + prob):
+ * conv11 / prob = the layers' descriptors (weight, packed, scale, shift), conv11_f16 = conv11's mvs_deconv_split_f16 pack,
+ * d11_scratch = [B, 2Di, 2Hi, 2Wi, 8] floats the unfused path writes conv11's output to, *flag = 0 on entry. */
+int mvs_costreg_tail_guarded_f16_f32(const float *in, const void *in_absmax, const float *skip, const void *skip_absmax,
+                                     const void *packed_tail, const mvs_conv_layer *conv11, const void *conv11_f16,
+                                     const mvs_conv_layer *prob, int B, int Di, int Hi, int Wi, float *d11_scratch,
+                                     float *out_cost, void *flag, void *stream);
+int mvs_costreg_fwd3_f32(const float *in, int in_layout, const mvs_conv_layer *layers, const void *const *packed_f16,
+                         const void *packed_tail, int B, int Cin, int base, int D, int H, int W, int impl, void *workspace,
+                         size_t workspace_bytes, const void *in_absmax, float *out_cost, void *stream);
+
 /* Weight gradient of one 3x3x3 layer (training, BASELINE config 5; the reference gets it from
  * autograd through nn.Conv3d / nn.ConvTranspose3d, module.py:26-33, mvsnet.py:66-79):
  *   grad_weight[co][ci][kz][ky][kx] += sum_o grad_out[o][co] * in[o*stride + k - 1][ci]

@@ -46,6 +46,12 @@ _SIGS = {
     "mvs_costreg_workspace_bytes": (ctypes.c_size_t, [_c_i] * 5),
     "mvs_costreg_fwd_f32": (_c_i, [_c_f, _c_i, _c_f] + [_c_i] * 7 + [_c_f, ctypes.c_size_t, _c_f, _c_f]),
     "mvs_costreg_fwd2_f32": (_c_i, [_c_f, _c_i, _c_f, _c_f] + [_c_i] * 7 + [_c_f, ctypes.c_size_t, _c_f, _c_f, _c_f]),
+    "mvs_costreg_fwd3_f32": (_c_i, [_c_f, _c_i, _c_f, _c_f, _c_f] + [_c_i] * 7 + [_c_f, ctypes.c_size_t, _c_f, _c_f, _c_f]),
+    "mvs_costreg_tail_packed_bytes": (ctypes.c_size_t, []),
+    "mvs_costreg_tail_pack_weights_f32": (_c_i, [_c_f, _c_f, _c_f]),
+    "mvs_costreg_tail_supported": (_c_i, [_c_i] * 4),
+    "mvs_costreg_tail_f16_f32": (_c_i, [_c_f] * 10 + [_c_i] * 4 + [_c_f, _c_f, _c_f]),
+    "mvs_costreg_tail_guarded_f16_f32": (_c_i, [_c_f] * 8 + [_c_i] * 4 + [_c_f] * 4),
     "mvs_conv3d_packed_weight_floats": (_c_l, [_c_i] * 4),
     "mvs_conv3d_pack_weights_f32": (_c_i, [_c_f] + [_c_i] * 4 + [_c_f, _c_f]),
     "mvs_conv3d_mfma_supported": (_c_i, [_c_i] * 4),

@@ -16,6 +16,11 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+const unsigned *&conv_run_flag() {
+    static thread_local const unsigned *flag = nullptr;
+    return flag;
+}
+
 // launches that took the range guard's fallback (conv_guard.h), per device
 __device__ unsigned long long g_guard_fallbacks;
 unsigned long long *guard_counter() {

@@ -520,6 +520,7 @@ __global__ __launch_bounds__(NWV * 64) void conv3d_cout1_kernel(ConvArgs a, cons
     constexpr int PLANE = round_up_c(NVOX, 64);            // whole 64-lane DMA instructions
     __shared__ __attribute__((aligned(16))) float lds[CQ * PLANE * 4];
     __shared__ __attribute__((aligned(16))) float wl[27 * CIN];
+    if (a.run_flag && *a.run_flag == 0u) return;
     const int tid = threadIdx.x, lx = tid & 31, ly = (tid >> 5) & 7, zh = (tid >> 8) * TZL;
     const TileIdx tile = decode_tile(a, blockIdx.x, gridDim.x);
     const int tx = tile.tx, ty = tile.ty, tz = tile.tz, b = tile.b;
@@ -645,6 +646,7 @@ __global__ __launch_bounds__(768) void conv3d_cout1_march_kernel(MarchArgs m, co
     using namespace march;
     constexpr int CIN = 8;
     const ConvArgs &a = m.c;
+    if (a.run_flag && *a.run_flag == 0u) return;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     float *wl = lds + RING * SLOT_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1012,6 +1014,7 @@ int conv3d_mfma_launch(const float *in, const float *packed, const float *scale,
         return MVS_EUNSUPPORTED;
     }
     if (is_cout1(transposed, Cin, Cout, stride)) {
+        a.run_flag = conv_run_flag();
         a.Do = D; a.Ho = H; a.Wo = W;
         a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 7) / 8; a.tiles_z = (D + 3) / 4;
         const int64_t nblk = (int64_t)B * a.tiles_x * a.tiles_y * a.tiles_z;

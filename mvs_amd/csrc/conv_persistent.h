@@ -27,6 +27,7 @@ struct ConvArgs {
     int res_up2; // residual is [B,Do,Ho/2,Wo/2,C]: added through a nearest x2 upsample in y and x (FPN top-down path)
     int out_c4 = 0;   // 2D layers: write [image,C/4,Ho,Wo,4] (4-channel blocked, the sweep kernel's fastest input) instead of [image,Ho,Wo,C]
     unsigned *out_absmax = nullptr;   // the absmax block (mvs_common.h) the largest magnitude stored is max-ed into, or NULL
+    const unsigned *run_flag = nullptr;   // Cout = 1 kernels: a device word; the launch returns at once when it is 0 (mvs_common.h: conv_run_flag)
 };
 
 // XCD-aware bijective remap: consecutive tiles land on the same XCD (same L2)

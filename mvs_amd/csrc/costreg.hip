@@ -6,6 +6,8 @@
 namespace mvs {
 
 // activation sizes (floats) of the four resolutions for batch B and `base` channels
+constexpr int kFlagWords = 64;
+
 struct CostRegPlan {
     int64_t n[4];          // voxels per batch item at levels 0..3
     size_t off[10];        // workspace offsets (floats): c0 t1 c2 t3 c4 t5 t6 d7 d9 d11
@@ -23,7 +25,9 @@ static bool costreg_plan(int B, int base, int D, int H, int W, CostRegPlan &p) {
         p.off[i] = o;
         o += ((size_t)sz[i] + 63) & ~(size_t)63;   // 256-byte aligned slices
     }
-    p.total = o + 10 * kAbsmaxWords;   // + the absmax blocks of mvs_costreg_fwd2_f32: the input's (when the caller has none), nine activations'
+    // + the absmax blocks of mvs_costreg_fwd2_f32: the input's (when the caller has none), nine activations'; + the flag words of
+    // mvs_costreg_fwd3_f32 (the fused tail kernel's "I declined")
+    p.total = o + 10 * kAbsmaxWords + kFlagWords;
     return true;
 }
 
@@ -36,8 +40,34 @@ extern "C" size_t mvs_costreg_workspace_bytes(int B, int base, int D, int H, int
     return costreg_plan(B, base, D, H, W, p) ? p.total * sizeof(float) : 0;
 }
 
+// conv11 + prob: the fused kernel (tail_fused.hip), then the two unfused layers enqueued behind it with the "run only if" word
+// (mvs_common.h: conv_run_flag) = the flag the fused kernel's range guard sets when it declines -- they return at once otherwise.
+// No host synchronisation.  *flag must be 0 on entry (a device word; the caller clears it).
+extern "C" int mvs_costreg_tail_guarded_f16_f32(const float *in, const void *in_absmax, const float *skip, const void *skip_absmax,
+                                                const void *packed_tail, const mvs_conv_layer *conv11, const void *conv11_f16,
+                                                const mvs_conv_layer *prob, int B, int Di, int Hi, int Wi, float *d11_scratch,
+                                                float *out_cost, void *flag, void *stream) {
+    if (!conv11 || !conv11_f16 || !prob || !prob->weight || !d11_scratch || !flag) {
+        set_error("mvs_costreg_tail_guarded_f16_f32: needs conv11's layer and two-piece pack, prob's layer, a [B, 2Di, 2Hi, 2Wi, 8] scratch "
+                  "volume for the unfused path and a zeroed flag word");
+        return MVS_EINVAL;
+    }
+    int rc = mvs_costreg_tail_f16_f32(in, in_absmax, skip, skip_absmax, packed_tail, conv11->scale, conv11->shift, prob->weight,
+                                      prob->scale, prob->shift, B, Di, Hi, Wi, out_cost, flag, stream);
+    if (rc != MVS_OK) return rc;
+    struct FlagScope {
+        explicit FlagScope(const void *f) { conv_run_flag() = static_cast<const unsigned *>(f); }
+        ~FlagScope() { conv_run_flag() = nullptr; }
+    } scope(flag);
+    rc = mvs_deconv_split_f16_f32(in, in_absmax, conv11_f16, conv11->scale, conv11->shift, skip, 1, B, 16, 8, Di, Hi, Wi, d11_scratch,
+                                  nullptr, stream);
+    if (rc != MVS_OK) return rc;
+    return mvs_conv3d_absmax_f32(d11_scratch, prob->weight, prob->packed, prob->scale, prob->shift, nullptr, 0, 0, B, 8, 1, 2 * Di,
+                                 2 * Hi, 2 * Wi, 1, MVS_LAYOUT_NHWC, 0, out_cost, nullptr, stream);
+}
+
 // layers: the eleven layers; f16 = their two-piece fp16 packs or NULL (the entry of before those existed)
-static int costreg_impl(const float *in, int in_layout, const mvs_conv_layer *layers, const void *const *f16, int B,
+static int costreg_impl(const float *in, int in_layout, const mvs_conv_layer *layers, const void *const *f16, const void *tail_pack, int B,
                         int Cin, int base, int D, int H, int W, int impl, void *workspace,
                         size_t workspace_bytes, const void *in_absmax, float *out_cost, void *stream, const char *who) {
     if (!in || !layers || !out_cost || (in_layout != MVS_LAYOUT_NHWC && in_layout != MVS_LAYOUT_C8)) {
@@ -65,10 +95,11 @@ static int costreg_impl(const float *in, int in_layout, const mvs_conv_layer *la
           *d9 = ws + p.off[8], *d11 = ws + p.off[9];
     // absmax blocks (mvs_common.h): [0] the input's when the caller has none, [1 + i] activation i's -- what a layer on the
     // two-piece fp16 kernels scales its input by, collected in the epilogue of the layer that wrote it
-    unsigned *const amax = reinterpret_cast<unsigned *>(ws + p.total - 10 * kAbsmaxWords);
+    unsigned *const amax = reinterpret_cast<unsigned *>(ws + p.total - 10 * kAbsmaxWords - kFlagWords);
+    unsigned *const flags = amax + 10 * kAbsmaxWords;
     auto block = [&](int i) { return static_cast<void *>(amax + (size_t)i * kAbsmaxWords); };
     const bool two_piece = f16 && impl != 1;
-    if (two_piece && hipMemsetAsync(amax, 0, 10 * kAbsmaxWords * sizeof(unsigned), as_stream(stream)) != hipSuccess)
+    if (two_piece && hipMemsetAsync(amax, 0, (10 * kAbsmaxWords + kFlagWords) * sizeof(unsigned), as_stream(stream)) != hipSuccess)
         return bare_error(MVS_ELAUNCH, __func__, __LINE__);
     const int b = base;
     struct Step {
@@ -100,9 +131,17 @@ static int costreg_impl(const float *in, int in_layout, const mvs_conv_layer *la
     bool wanted[10] = {false};     // activation i's absmax block has a reader
     for (const Step &s : steps)
         if (s.src_act >= 0 && two_piece_layer(s)) wanted[s.src_act] = true;
+    // conv11 -> prob as ONE kernel (tail_fused.hip) when both run on the two-piece path of a base-8 net: it needs the blocks of
+    // conv11's input (activation 8) and of the skip volume (activation 0), both collected anyway.  The unfused layers stay enqueued
+    // behind it with the "run only if" word: they return at once unless the fused kernel's range guard declined.
+    const bool fuse_tail = tail_pack && b == 8 && two_piece_layer(steps[9]) && wanted[0] && wanted[8] &&
+                           mvs_costreg_tail_supported(B, D >> 1, H >> 1, W >> 1);
     for (const Step &s : steps) {
         const mvs_conv_layer &L = layers[s.layer];
         const int d = D >> s.lvl, h = H >> s.lvl, w = W >> s.lvl;
+        if (fuse_tail && s.layer == 9)      // conv11 + prob: the fused kernel, the two layers behind it under its flag
+            return mvs_costreg_tail_guarded_f16_f32(s.src, block(1 + 8), s.skip, block(1 + 0), tail_pack, &L, f16[9], &layers[10],
+                                                    B, d, h, w, s.dst, out_cost, flags, stream);
         void *const out_mx = (s.dst_act >= 0 && wanted[s.dst_act]) ? block(1 + s.dst_act) : nullptr;
         bool collected = false;     // did the kernel collect out_mx in its epilogue?
         int rc;
@@ -151,7 +190,7 @@ static int costreg_impl(const float *in, int in_layout, const mvs_conv_layer *la
 extern "C" int mvs_costreg_fwd_f32(const float *in, int in_layout, const mvs_conv_layer *layers, int B,
                                    int Cin, int base, int D, int H, int W, int impl, void *workspace,
                                    size_t workspace_bytes, float *out_cost, void *stream) {
-    return costreg_impl(in, in_layout, layers, nullptr, B, Cin, base, D, H, W, impl, workspace, workspace_bytes, nullptr, out_cost,
+    return costreg_impl(in, in_layout, layers, nullptr, nullptr, B, Cin, base, D, H, W, impl, workspace, workspace_bytes, nullptr, out_cost,
                         stream, "mvs_costreg_fwd_f32");
 }
 
@@ -162,6 +201,18 @@ extern "C" int mvs_costreg_fwd2_f32(const float *in, int in_layout, const mvs_co
         set_error("mvs_costreg_fwd2_f32: packed_f16 = the eleven layers' two-piece packs (NULL entries allowed)");
         return MVS_EINVAL;
     }
-    return costreg_impl(in, in_layout, layers, packed_f16, B, Cin, base, D, H, W, impl, workspace, workspace_bytes, in_absmax,
+    return costreg_impl(in, in_layout, layers, packed_f16, nullptr, B, Cin, base, D, H, W, impl, workspace, workspace_bytes, in_absmax,
                         out_cost, stream, "mvs_costreg_fwd2_f32");
+}
+
+// fwd2 + packed_tail (mvs_costreg_tail_pack_weights_f32 of conv11's weight, or NULL = fwd2): conv11 and prob as one kernel
+extern "C" int mvs_costreg_fwd3_f32(const float *in, int in_layout, const mvs_conv_layer *layers, const void *const *packed_f16,
+                                    const void *packed_tail, int B, int Cin, int base, int D, int H, int W, int impl, void *workspace,
+                                    size_t workspace_bytes, const void *in_absmax, float *out_cost, void *stream) {
+    if (!packed_f16) {
+        set_error("mvs_costreg_fwd3_f32: packed_f16 = the eleven layers' two-piece packs (NULL entries allowed)");
+        return MVS_EINVAL;
+    }
+    return costreg_impl(in, in_layout, layers, packed_f16, packed_tail, B, Cin, base, D, H, W, impl, workspace, workspace_bytes,
+                        in_absmax, out_cost, stream, "mvs_costreg_fwd3_f32");
 }

@@ -36,6 +36,7 @@ struct DeconvArgs {
     const float *w_f32;
     int co0;
     unsigned long long *guard_cnt;
+    const unsigned *run_flag;   // NULL, or a device word: the launch returns at once when it is 0 (mvs_common.h: conv_run_flag)
 };
 
 // per-dimension tap t of parity p -> (kernel index, input offset)
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(kDeconvThreads) void deconv_split_kernel(DeconvArgs
     constexpr int NWC = (WBYTES / 1024 + NC - 1) / NC;
     __shared__ __attribute__((aligned(16))) unsigned char lds[C::LDS_BYTES];
 
+    if (a.run_flag && *a.run_flag == 0u) return;      // (uniform: the fused tail kernel in front of this launch did the work)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kq = lane >> 4;
@@ -575,6 +577,7 @@ static int deconv_split_impl(const float *in, const void *in_absmax, const void 
         a.out_absmax = static_cast<unsigned *>(out_absmax);
         a.w_f32 = a.w_iscale + 4; a.co0 = co0;
         a.guard_cnt = np == 2 ? guard_counter() : nullptr;
+        a.run_flag = conv_run_flag();
         a.in = in; a.wpk = static_cast<const unsigned char *>(packed) + (co0 / step) * per_launch;
         a.scale = scale ? scale + co0 : nullptr; a.shift = shift ? shift + co0 : nullptr;
         a.residual = residual ? residual + co0 : nullptr; a.out = out + co0;

@@ -31,6 +31,11 @@ inline int check_launch(const char *what) {
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// "Run only if this device word is non-zero": while set (per host thread), the launchers of deconv_split.hip and of the Cout = 1
+// kernels of conv3d_mfma.hip hand the word to their kernels, which return at once when it is 0.  mvs_costreg_fwd3_f32 enqueues
+// the unfused conv11 / prob layers that way behind the fused tail kernel (tail_fused.hip), whose range guard sets the word.
+const unsigned *&conv_run_flag();
+
 // Compute units of the current device (grid size of the persistent kernels); 256 if the
 // runtime cannot tell.  Queried per call: cheap, and correct when a process drives several GPUs.
 inline int device_cu_count() {

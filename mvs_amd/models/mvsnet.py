@@ -291,6 +291,14 @@ class CostRegNet(nn.Module):
         t = run("conv6", t5, x_abs=blk(3), out_abs=blk(4))
         t = run("conv7", t, c4, x_abs=blk(4), out_abs=blk(5))
         t = run("conv9", t, c2, x_abs=blk(5), out_abs=blk(6))
+        # conv11 + prob: one kernel, as inside mvs_costreg_fwd3_f32 (the two layers enqueued behind it run only if its range guard
+        # declined: no host synchronisation)
+        p11 = P["conv11"]
+        if f16 and ops.tail_fused_enabled() and ops.f16_companion(p11["packed"]) is not None and tuple(p11["weight"].shape[:2]) == (16, 8):
+            if p11.get("packed_tail") is None:
+                p11["packed_tail"] = ops.pack_costreg_tail(p11["weight"])
+            with ops.stage("costreg.tail"):
+                return ops.costreg_tail_guarded(t, blk(6), c0, blk(0), p11, P["prob"])
         t = run("conv11", t, c0, x_abs=blk(6))
         cost = run("prob", t, None, relu=False)     # [B,D,H,W,1]
         return cost.squeeze(-1)

@@ -1137,6 +1137,64 @@ def conv0_f16_enabled():
     return conv_split_enabled() and os.environ.get("MVS_CONV0_F16", "1") != "0"
 
 
+def tail_fused_enabled():
+    """False when MVS_TAIL_FUSED=0 keeps conv11 and prob as two launches (A/B switch).  Default: the fused kernel
+    (mvs_costreg_tail_f16_f32) inside mvs_costreg_fwd3_f32."""
+    import os
+    return split_f16_enabled() and os.environ.get("MVS_TAIL_FUSED", "1") != "0"
+
+
+def pack_costreg_tail(conv11_weight):
+    """conv11's (16, 8, 3, 3, 3) ConvTranspose3d weight -> the fragments of the fused conv11 + prob kernel."""
+    w = _f32c(conv11_weight)
+    lib = _lib.load()
+    out = torch.empty(lib.mvs_costreg_tail_packed_bytes(), device=w.device, dtype=torch.uint8)
+    check(lib.mvs_costreg_tail_pack_weights_f32(ptr(w), ctypes.c_void_p(out.data_ptr()), stream()), "mvs_costreg_tail_pack_weights_f32")
+    return out
+
+
+def costreg_tail(x, x_absmax, skip, skip_absmax, packed_tail, scale, shift, prob_weight, prob_scale, prob_shift):
+    """conv11 + prob as one kernel: x [B,Di,Hi,Wi,16], skip [B,2Di,2Hi,2Wi,8] -> (cost [B,2Di,2Hi,2Wi], flag); flag[0] = 1 when
+    the launch declined (range guard): the cost is then NOT written and the caller runs the unfused layers."""
+    x, skip = _f32c(x), _f32c(skip)
+    B, Di, Hi, Wi, _ = x.shape
+    out = torch.empty((B, 2 * Di, 2 * Hi, 2 * Wi), device=x.device, dtype=torch.float32)
+    flag = torch.zeros(1, device=x.device, dtype=torch.int32)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
+    check(_lib.load().mvs_costreg_tail_f16_f32(ptr(x), vp(x_absmax), ptr(skip), vp(skip_absmax), vp(packed_tail),
+                                               ptr(scale) if scale is not None else None, ptr(shift) if shift is not None else None,
+                                               ptr(_f32c(prob_weight)), ptr(prob_scale) if prob_scale is not None else None,
+                                               ptr(prob_shift) if prob_shift is not None else None, B, Di, Hi, Wi, ptr(out), vp(flag),
+                                               stream()), "mvs_costreg_tail_f16_f32")
+    return out, flag
+
+
+def costreg_tail_guarded(x, x_absmax, skip, skip_absmax, p11, pprob):
+    """conv11 + prob: the fused kernel with the two unfused layers enqueued behind it under its flag (no host synchronisation):
+    whatever the range guard decides, the cost comes back.  p11 / pprob: the layers' parameter dicts (weight, packed, scale,
+    shift; p11 with its two-piece companion and 'packed_tail')."""
+    x, skip = _f32c(x), _f32c(skip)
+    B, Di, Hi, Wi, _ = x.shape
+    out = torch.empty((B, 2 * Di, 2 * Hi, 2 * Wi), device=x.device, dtype=torch.float32)
+    d11 = torch.empty((B, 2 * Di, 2 * Hi, 2 * Wi, 8), device=x.device, dtype=torch.float32)     # touched only if the guard declines
+    flag = torch.zeros(1, device=x.device, dtype=torch.int32)
+    layers = (_lib.ConvLayer * 2)()
+    keep = []
+    for i, p in enumerate((p11, pprob)):
+        for field in ("weight", "packed", "scale", "shift"):
+            t = p.get(field)
+            if t is not None:
+                t = _f32c(t)
+                keep.append(t)
+                setattr(layers[i], field, t.data_ptr())
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    check(_lib.load().mvs_costreg_tail_guarded_f16_f32(
+        ptr(x), vp(x_absmax), ptr(skip), vp(skip_absmax), vp(p11["packed_tail"]), ctypes.cast(ctypes.byref(layers[0]), ctypes.c_void_p),
+        vp(f16_companion(p11["packed"])), ctypes.cast(ctypes.byref(layers[1]), ctypes.c_void_p), B, Di, Hi, Wi, ptr(d11), ptr(out),
+        vp(flag), stream()), "mvs_costreg_tail_guarded_f16_f32")
+    return out
+
+
 def costreg_forward(x, params, in_c8=False, impl=IMPL_AUTO, x_absmax=None):
     """The whole 3D U-Net in one C call (mvs_costreg_fwd_f32; mvsnet.py:83-93).  x: variance
     volume [B,D,H,W,Cin] or (in_c8) [B,D,H,Cin/8,W,8]; params: name -> dict(weight, packed, scale,
@@ -1184,11 +1242,20 @@ def costreg_forward(x, params, in_c8=False, impl=IMPL_AUTO, x_absmax=None):
             f16[i] = t.data_ptr()
             any_f16 = True
     if any_f16:
-        check(lib.mvs_costreg_fwd2_f32(ptr(x), MVS_LAYOUT_C8 if in_c8 else MVS_LAYOUT_NHWC,
+        # conv11 -> prob as one kernel (tail_fused.hip) where both run two-piece on a base-8 net; its pack is made once per
+        # params dict (the dict is rebuilt with the weights)
+        tail = None
+        if tail_fused_enabled() and base == 8 and f16[9] and params["conv11"]["weight"].shape[:2] == (16, 8):
+            tail = params["conv11"].get("packed_tail")
+            if tail is None:
+                tail = params["conv11"]["packed_tail"] = pack_costreg_tail(params["conv11"]["weight"])
+            keep.append(tail)
+        check(lib.mvs_costreg_fwd3_f32(ptr(x), MVS_LAYOUT_C8 if in_c8 else MVS_LAYOUT_NHWC,
                                        ctypes.cast(layers, ctypes.c_void_p), ctypes.cast(f16, ctypes.c_void_p),
+                                       ctypes.c_void_p(tail.data_ptr()) if tail is not None else None,
                                        B, cin, base, D, H, W, impl, ctypes.c_void_p(ws.data_ptr()), ws.numel(),
                                        ctypes.c_void_p(x_absmax.data_ptr()) if x_absmax is not None else None,
-                                       ptr(out), stream()), "mvs_costreg_fwd2_f32")
+                                       ptr(out), stream()), "mvs_costreg_fwd3_f32")
     else:
         check(lib.mvs_costreg_fwd_f32(ptr(x), MVS_LAYOUT_C8 if in_c8 else MVS_LAYOUT_NHWC,
                                       ctypes.cast(layers, ctypes.c_void_p), B, cin, base, D, H, W, impl,
