@@ -13,7 +13,10 @@ from mvs_amd import ops  # noqa: E402
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    argv = list(sys.argv[1:])
+    if "--reps" in argv:
+        del argv[argv.index("--reps") + 1]
+    args = [a for a in argv if not a.startswith("--")]
     D, H, W = (int(v) for v in (args[:3] or (192, 296, 400)))
     reps = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 20
     dev = torch.device("cuda:0")
