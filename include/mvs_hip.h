@@ -136,6 +136,11 @@ int mvs_costvol_variance_fwd_f32(const float *ref_fea, const float *src_feas,
  * (module.py:78-79 + grid_sample) folded into one FMA, Q += w*w as an FMA, multiplication by
  * 1/V -- sampling positions within ~1e-4 texel of the reference's. */
 #define MVS_SWEEP_FAST 1
+/* mvs_costvol_variance_fwd_ws*_f32, device-selected kernel: launch the per-tile CANDIDATE as one block per tile (fastest when the
+ * chooser picks it: wide footprints) instead of the looping form (cheapest when it does not: the usual case).  A speed hint only:
+ * the result is the same.  The word the chooser writes -- workspace word 1: 16 / 8 = the persistent kernel's tile depth, 0 = the
+ * per-tile kernel -- tells a caller which way its geometry falls. */
+#define MVS_SWEEP_TILE_CANDIDATE_PER_TILE 2
 size_t mvs_costvol_variance_workspace_bytes(int depth_mode, int B, int V, int C, int D, int H, int W,
                                             int fea_layout);   /* = ..._bytes2(..., alias_quirk 0) */
 size_t mvs_costvol_variance_workspace_bytes2(int depth_mode, int B, int V, int C, int D, int H, int W,

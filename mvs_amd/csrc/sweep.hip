@@ -1206,7 +1206,7 @@ extern "C" int mvs_warp_bwd_f32(const float *grad_out, const float *rot_trans,
 // LDS-staged per-tile kernel: features [B,C/16,H,W,16].  sel: see variance_fwd_dma_kernel.
 static int launch_variance_tile_c16(const float *ref_fea, const float *src_feas, const float *rot_trans,
                                     const float *depth_values, const SweepParams &p, float *out_var, int out_c8,
-                                    hipStream_t st, const unsigned *sel, unsigned *absmax) {
+                                    hipStream_t st, const unsigned *sel, unsigned *absmax, bool candidate_per_tile = false) {
     const int B = p.B, C = p.C, D = p.D, H = p.H, W = p.W, NV = p.V - 1, depth_mode = p.depth_mode;
     if (C % 16 || C > 64) {
         set_error("mvs_costvol_variance_fwd_f32: C16 features need C in {16,32,48,64}, got %d", C);
@@ -1223,9 +1223,15 @@ static int launch_variance_tile_c16(const float *ref_fea, const float *src_feas,
 #else
     const int lds_ablate = 0;
 #endif
-    // MVS_SWEEP_TILE_LOOP=1 (A/B): behind the chooser, a fixed grid of three workgroups per CU loops over the tiles
-    static const int tile_loop = [] { const char *e = getenv("MVS_SWEEP_TILE_LOOP"); return e ? atoi(e) : 0; }();   // workgroups per CU (0: one block per tile)
-    const bool loop = sel && tile_loop > 0;
+    // Behind the chooser this kernel is a CANDIDATE that usually returns at once (the persistent kernel took the call): as one
+    // block per tile its 44,000 early exits cost more than they look -- at config 2 the whole sweep takes 1.27 ms with them
+    // and 1.16 ms with a fixed grid of four workgroups per CU looping over the tiles (scripts/exp_sweep_select.py, round 5),
+    // which in turn is ~25 % slower where this kernel IS the one chosen (0.77 -> 0.92 ms at 48 planes x4 on the wide rig).
+    // So: the looping form by default; a caller that knows the geometry picks this kernel asks for one block per tile
+    // (MVS_SWEEP_TILE_CANDIDATE_PER_TILE: the Python mirror reads the chooser's verdict back asynchronously and sets it).
+    // MVS_SWEEP_TILE_LOOP = <workgroups per CU> overrides (0: one block per tile always).
+    static const int tile_loop = [] { const char *e = getenv("MVS_SWEEP_TILE_LOOP"); return e ? atoi(e) : 4; }();
+    const bool loop = sel && tile_loop > 0 && !candidate_per_tile;
     const int loop_wgs = (tile_loop == 1 ? 3 : tile_loop) * device_cu_count();
     // (behind the chooser, sel != NULL, the chooser has cleared the word)
     if (!sel && absmax && hipMemsetAsync(absmax, 0, 4 * kAbsmaxWords, st) != hipSuccess) return check_launch("variance absmax memset");
@@ -1477,7 +1483,8 @@ extern "C" int mvs_costvol_variance_fwd_ws2_f32(const float *ref_fea, const floa
                                            nmaps * (V - 1), plane, sel);
                         r16 = scratch; s16 = scratch + (size_t)B * C * plane;
                     }
-                    rc = launch_variance_tile_c16(r16, s16, rot_trans, depth_values, p, out_var, out_c8, st, sel, absmax);
+                    rc = launch_variance_tile_c16(r16, s16, rot_trans, depth_values, p, out_var, out_c8, st, sel, absmax,
+                                                  (flags & MVS_SWEEP_TILE_CANDIDATE_PER_TILE) != 0);
                     if (rc != MVS_OK) return rc;
                 }
                 return check_launch("mvs_costvol_variance_fwd_ws_f32(device-selected)");

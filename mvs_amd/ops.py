@@ -512,14 +512,60 @@ def costvol_variance_c16(ref16, srcs16, rts, depth_values, align_corners=False, 
     mode = _depth_mode(depth_values)
     need = lib.mvs_costvol_variance_workspace_bytes2(mode, B, V, C, D, H, W, layout, int(alias_quirk))
     ws = _variance_workspace(ref16.device, need) if need else None
+    import os
+    # (a forced kernel, MVS_SWEEP_PERSIST, runs no chooser: nothing to read back)
+    hint = _SweepVerdict.get(ref16.device, (mode, B, V, C, D, H, W, layout)) if ws is not None and "MVS_SWEEP_PERSIST" not in os.environ else None
+    flags = (1 if fast else 0) | (2 if hint is not None and hint.per_tile() else 0)      # MVS_SWEEP_FAST | MVS_SWEEP_TILE_CANDIDATE_PER_TILE
     check(lib.mvs_costvol_variance_fwd_ws2_f32(
         ptr(ref16), ptr(srcs16), ptr(rts), ptr(depth_values), mode, B, V, C,
         D, H, W, int(align_corners), int(alias_quirk), layout,
-        MVS_LAYOUT_C8 if out_c8 else MVS_LAYOUT_NHWC, 1 if fast else 0, ptr(out),
+        MVS_LAYOUT_C8 if out_c8 else MVS_LAYOUT_NHWC, flags, ptr(out),
         ctypes.c_void_p(ws.data_ptr()) if ws is not None else None, ws.numel() if ws is not None else 0,
         ctypes.c_void_p(absmax_out.data_ptr()) if absmax_out is not None else None,
         stream()), "mvs_costvol_variance_fwd_ws2_f32")
+    if hint is not None:
+        hint.observe(ws)
     return out
+
+
+class _SweepVerdict:
+    """Which kernel the device-side chooser of the sweep picked for a shape, read back WITHOUT synchronising: now and then the
+    verdict word of the workspace is copied to pinned host memory behind the call, and looked at by a later call once its event
+    has completed.  Only a speed hint comes of it (how the per-tile candidate is launched: include/mvs_hip.h,
+    MVS_SWEEP_TILE_CANDIDATE_PER_TILE); a stale or missing verdict costs microseconds, never correctness.  Skipped while the
+    stream is capturing a HIP graph."""
+    _table = {}
+    PERIOD = 8           # calls between two read-backs once a verdict is known (4 bytes, asynchronous)
+
+    @classmethod
+    def get(cls, device, key):
+        k = (device.index, key)
+        v = cls._table.get(k)
+        if v is None:
+            v = cls._table[k] = cls()
+        return v
+
+    def __init__(self):
+        self.choice = None       # 16 / 8 / 0, or None: not known yet
+        self.pending = None      # (pinned word, event)
+        self.calls = 0
+
+    def per_tile(self):
+        if self.pending is not None and self.pending[1].query():
+            self.choice = int(self.pending[0].item())
+            self.pending = None
+        return self.choice == 0
+
+    def observe(self, ws):
+        self.calls += 1
+        due = self.choice is None or self.calls % self.PERIOD == 0
+        if not due or self.pending is not None or torch.cuda.is_current_stream_capturing():
+            return
+        word = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        word.copy_(ws[4:8].view(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending = (word, ev)
 
 
 def costvol_variance_nhwc_ws(ref_cl, srcs_cl, rts, depth_values, align_corners=False, out_c8=False, fast=False,

@@ -73,12 +73,15 @@ def test_split_graph_step_equals_single_graph_and_eager_steps():
     # (even the first loss moves in its last bit from run to run: train-mode BatchNorm reduces its batch statistics with atomics)
     def dist(a, b, k):
         return float((a[k].double() - b[k].double()).abs().max()) / (float(a[k].double().abs().max()) + 1e-3)
+    # a FIXED bound: two runs of the SAME form differ by up to ~6e-4 here (a BatchNorm bias starts at 0 -- after five steps it IS
+    # lr x the sum of its gradients, noise and all); a wrong step -- a gradient lost in the flat pack, the average applied twice,
+    # a stale pack in a replay -- moves parameters by O(1) of their change
     for k in p1:
-        noise = dist(p1, p1b, k)
-        assert noise < 1e-3, (k, noise)      # (a BatchNorm bias starts at 0: after five steps it IS lr x sum of gradients, noise and all)
-        tol = max(20 * noise, 1e-5)
-        assert dist(p1, p2, k) <= tol, (k, dist(p1, p2, k), tol)
-        assert dist(p1, p0, k) <= tol, (k, dist(p1, p0, k), tol)
+        assert dist(p1, p1b, k) <= 5e-3, (k, dist(p1, p1b, k))
+        assert dist(p1, p2, k) <= 5e-3, (k, dist(p1, p2, k))
+        assert dist(p1, p0, k) <= 5e-3, (k, dist(p1, p0, k))
+    # ... and the parameters did move
+    assert max(float((p1[k].double() - p0[k].double()).abs().max()) for k in p1) < 1.0
     assert torch.allclose(l1, l2, rtol=1e-5, atol=0) and torch.allclose(l1, l0, rtol=1e-5, atol=0), (l1, l2, l0)
 
 
