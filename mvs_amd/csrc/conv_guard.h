@@ -57,24 +57,32 @@ struct GuardConv {
     int kd, kh, stride, transposed, relu, in_c8, out_c4;
 };
 
-// Every thread of the launch (copy waves included) takes (voxel, 4-channel block) items in a grid-stride loop.
-__device__ __forceinline__ void guard_direct_conv(const GuardConv &g) {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && g.counter) atomicAdd(g.counter, 1ull);
-    const int nq = g.nco >> 2;
-    const int64_t total = (int64_t)g.B * g.Do * g.Ho * g.Wo * nq;
+// Every thread of the launch (copy waves included) takes output VOXELS in a grid-stride loop and computes all NCO output
+// channels of the launch for its voxel: the weight addresses are then the same for every lane (scalar loads, the weight rides
+// in an SGPR operand of the FMA) and the input comes in as one 16-byte load per four input channels -- per (tap, input channel)
+// a quarter of a vector load and NCO FMAs, where the first version (one 4-channel block per thread, scalar loads of everything)
+// issued five loads per four FMAs: one NaN pixel in a source image cost 178 ms per forward at config 2, now ~NN ms
+// (scripts/exp_guard_cost.py).  The accumulation order per output is unchanged: taps (z, y, x), then input channels.
+template <int NCO>
+__device__ __forceinline__ void guard_direct_conv_n(const GuardConv &g) {
+    const int64_t total = (int64_t)g.B * g.Do * g.Ho * g.Wo;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int ntap = g.kd * g.kh * g.kh, pz = g.kd / 2, ph = g.kh / 2;
     const int sz = g.kd == 1 ? 1 : g.stride;          // images are not strided in z
+    const int c0 = g.co0;                              // first output channel of the launch in the whole tensor
+    // weight of (output channel c0 + j, input channel ci, tap t): wbase + j * wj + ci * wci + t
+    const int64_t wj = g.transposed ? ntap : (int64_t)g.Cin * ntap, wci = g.transposed ? (int64_t)g.ldc * ntap : ntap;
+    const float *const wbase = g.w + (g.transposed ? (int64_t)c0 * ntap : (int64_t)c0 * g.Cin * ntap);
     unsigned vmax = 0;
     for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += stride) {
-        const int q = (int)(it % nq);
-        int64_t vox = it / nq;
+        int64_t vox = it;
         const int x = (int)(vox % g.Wo); vox /= g.Wo;
         const int y = (int)(vox % g.Ho); vox /= g.Ho;
         const int z = (int)(vox % g.Do);
         const int b = (int)(vox / g.Do);
-        const int c0 = g.co0 + 4 * q;                  // first output channel of the item in the whole tensor
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        float acc[NCO];
+#pragma unroll
+        for (int j = 0; j < NCO; ++j) acc[j] = 0.f;
         for (int tz = 0; tz < g.kd; ++tz) {
             int iz;
             if (g.transposed) { const int n = z + 1 - tz; if (n & 1) continue; iz = n >> 1; }
@@ -92,34 +100,55 @@ __device__ __forceinline__ void guard_direct_conv(const GuardConv &g) {
                     if ((unsigned)ix >= (unsigned)g.W) continue;
                     const int t = (tz * g.kh + ty) * g.kh + tx;
                     const int64_t row = ((int64_t)b * g.D + iz) * g.H + iy;
-                    for (int ci = 0; ci < g.Cin; ++ci) {
-                        const float xv = g.in_c8 ? g.in[((row * (g.Cin >> 3) + (ci >> 3)) * g.W + ix) * 8 + (ci & 7)]
-                                                 : g.in[(row * g.W + ix) * g.Cin + ci];
+                    const float *const wt = wbase + t;
+                    for (int ci = 0; ci < g.Cin; ci += 4) {
+                        const float4 xq = g.in_c8 ? *reinterpret_cast<const float4 *>(g.in + ((row * (g.Cin >> 3) + (ci >> 3)) * g.W + ix) * 8 + (ci & 7))
+                                                  : *reinterpret_cast<const float4 *>(g.in + (row * g.W + ix) * g.Cin + ci);
+                        const float xs[4] = {xq.x, xq.y, xq.z, xq.w};
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float wv = g.transposed ? g.w[((int64_t)ci * g.ldc + c0 + j) * ntap + t]
-                                                          : g.w[((int64_t)(c0 + j) * g.Cin + ci) * ntap + t];
-                            acc[j] = __fmaf_rn(wv, xv, acc[j]);
+                        for (int k = 0; k < 4; ++k) {
+                            const float *const wk = wt + (ci + k) * wci;
+#pragma unroll
+                            for (int j = 0; j < NCO; ++j) acc[j] = __fmaf_rn(wk[j * wj], xs[k], acc[j]);
                         }
                     }
                 }
             }
         }
         const int64_t ovox = (((int64_t)b * g.Do + z) * g.Ho + y) * g.Wo + x;
-        const int64_t o = g.out_c4 ? (((int64_t)b * g.Do + z) * (g.ldc >> 2) + (c0 >> 2)) * ((int64_t)g.Ho * g.Wo * 4) + ((int64_t)y * g.Wo + x) * 4
-                                   : ovox * g.ldc + 4 * q;
-        float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v[j] = acc[j] * (g.scale ? g.scale[4 * q + j] : 1.0f) + (g.shift ? g.shift[4 * q + j] : 0.0f);
-            if (g.relu == 1) v[j] = relu_nan(v[j]);
-            else if (g.relu == 2) v[j] = v[j] > 0.f ? v[j] : v[j] * 0.1f;
-            if (g.residual) v[j] += g.residual[ovox * g.ldc + 4 * q + j];
-            vmax = max(vmax, __float_as_uint(v[j]) & 0x7fffffffu);
+        for (int q = 0; q < NCO / 4; ++q) {
+            const int64_t o = g.out_c4 ? (((int64_t)b * g.Do + z) * (g.ldc >> 2) + ((c0 >> 2) + q)) * ((int64_t)g.Ho * g.Wo * 4) + ((int64_t)y * g.Wo + x) * 4
+                                       : ovox * g.ldc + 4 * q;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = acc[4 * q + j] * (g.scale ? g.scale[4 * q + j] : 1.0f) + (g.shift ? g.shift[4 * q + j] : 0.0f);
+                if (g.relu == 1) v[j] = relu_nan(v[j]);
+                else if (g.relu == 2) v[j] = v[j] > 0.f ? v[j] : v[j] * 0.1f;
+                if (g.residual) v[j] += g.residual[ovox * g.ldc + 4 * q + j];
+                vmax = max(vmax, __float_as_uint(v[j]) & 0x7fffffffu);
+            }
+            *reinterpret_cast<float4 *>(g.out + o) = make_float4(v[0], v[1], v[2], v[3]);
         }
-        *reinterpret_cast<float4 *>(g.out + o) = make_float4(v[0], v[1], v[2], v[3]);
     }
     if (g.out_absmax && vmax) atomicMax(g.out_absmax + (blockIdx.x & (kAbsmaxWords - 1)), vmax);
+}
+
+__device__ __forceinline__ void guard_direct_conv(const GuardConv &g) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && g.counter) atomicAdd(g.counter, 1ull);
+    if (g.nco == 8) guard_direct_conv_n<8>(g);
+    else if (g.nco == 16) guard_direct_conv_n<16>(g);
+    else if (g.nco == 32) guard_direct_conv_n<32>(g);
+    else {      // (no launcher passes another count; keep the data path defined: 4 channels at a time)
+        GuardConv h = g;
+        for (int q = 0; q < g.nco / 4; ++q) {
+            h.co0 = g.co0 + 4 * q; h.nco = 4;
+            h.scale = g.scale ? g.scale + 4 * q : nullptr; h.shift = g.shift ? g.shift + 4 * q : nullptr;
+            h.residual = g.residual ? g.residual + 4 * q : nullptr; h.out = g.out + (g.out_c4 ? 0 : 4 * q);
+            guard_direct_conv_n<4>(h);
+        }
+    }
 }
 
 }  // namespace mvs

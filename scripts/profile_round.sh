@@ -2,7 +2,7 @@
 # Round profile on the GPU box: rocprofv3 kernel trace + stats of the bench command,
 # then HBM-traffic counters in their own passes (no tracing mixed in).
 # Usage: bash scripts/profile_round.sh r01     (writes gpurun_out/prof_<tag>/...)
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd "$(dirname "$0")/.." ; mkdir -p gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 CMD="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras"
@@ -32,7 +32,7 @@ json.dump(out, open(f"{root}/summary.json", "w"), indent=1)
 names = {"costvol_variance": "variance_fwd_persist_kernel", "costreg.conv0": "conv3d_c8_f16x3_zs_kernel<32",
          "costreg.conv1": "SplitCfg<8, 16, 3, 2", "costreg.conv2": "SplitCfg<16, 16, 3",
          "costreg.conv4": "SplitCfg<32, 32, 3", "costreg.conv11": "DeconvSplitCfg<16, true",
-         "costreg.prob": "conv3d_cout1_march_kernel", "softmax_regress_conf": "softmax_regress_conf_kernel",
+         "costreg.prob": "conv3d_cout1_march_kernel", "costreg.tail": "costreg_tail_kernel", "softmax_regress_conf": "softmax_regress_conf_kernel",
          "feature.head": "feature_head_kernel", "feature.conv2": "SplitCfg<8, 16, 1, 2, 5"}
 F, W = out["FETCH_SIZE_per_launch_KB"], out["WRITE_SIZE_per_launch_KB"]
 def find(d, sub):
