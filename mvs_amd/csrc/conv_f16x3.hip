@@ -446,8 +446,7 @@ __global__ __launch_bounds__(256) void pack_f16x3_kernel(const float *__restrict
     const int e = absmax_exponent(*wmax);
     // what undoes the scale; NaN = "the weights are not finite", which sends every launch to the guard's fp32 path
     if (i == 0) *reinterpret_cast<float *>(out + (size_t)total * 2) = *wmax >= 0x7f800000u ? __builtin_nanf("") : pow2f(e - 14);
-    // the original fp32 weights behind the 16-byte trailer (conv_guard.h)
-    if (i < 8 * Cin * 27) reinterpret_cast<float *>(out + (size_t)total * 2)[4 + i] = w[i];
+    // (the fp32 weights behind the 16-byte trailer, conv_guard.h: launch_guard_weights from the host side of this pack)
     if (i >= total) return;
     const int j = i & 7, lane = (i >> 3) & 63, t = (i >> 9) % 9, ch = i / (9 * 512);
     const int m = lane & 15, kq = lane >> 4, co = m & 7, sft = m >> 3, kx = kq - sft;
@@ -473,6 +472,18 @@ extern "C" size_t mvs_conv3d_f16x3_packed_bytes(int Cin) {
 }
 
 namespace mvs {
+__global__ __launch_bounds__(256) void guard_weights_kernel(const float *__restrict__ w, int transposed, int Cin, int Cout, int ntap,
+                                                            float *__restrict__ dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Cin * Cout * ntap) return;
+    const int co = i % Cout, ci = (i / Cout) % Cin, t = i / (Cout * Cin);
+    dst[i] = transposed ? w[((int64_t)ci * Cout + co) * ntap + t] : w[((int64_t)co * Cin + ci) * ntap + t];
+}
+int launch_guard_weights(const float *w, int transposed, int Cin, int Cout, int ntap, float *dst, hipStream_t st) {
+    const int total = Cin * Cout * ntap;
+    hipLaunchKernelGGL(guard_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, transposed, Cin, Cout, ntap, dst);
+    return check_launch("guard_weights_kernel");
+}
 // (weights) one word; n below 2^31
 int launch_absmax_word(const float *x, int64_t n, unsigned *word, hipStream_t st) {
     hipLaunchKernelGGL(absmax_word_kernel, dim3(1), dim3(1024), 0, st, x, (int)n, word);
@@ -506,7 +517,10 @@ extern "C" int mvs_conv3d_pack_weights_f16x3_f32(const float *weight, int Cin, v
     const int total = (Cin / 8) * 9 * 512;
     hipLaunchKernelGGL(pack_f16x3_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), weight, Cin,
                        static_cast<unsigned short *>(packed), total, wmax);
-    return check_launch("mvs_conv3d_pack_weights_f16x3_f32");
+    const int rc2 = check_launch("mvs_conv3d_pack_weights_f16x3_f32");
+    if (rc2 != MVS_OK) return rc2;
+    return launch_guard_weights(weight, 0, Cin, 8, 27,
+                                reinterpret_cast<float *>(static_cast<unsigned char *>(packed) + (size_t)(Cin / 8) * kF16ChunkBytes + 16), as_stream(stream));
 }
 
 extern "C" int mvs_conv3d_c8_f16x3_f32(const float *in, const void *in_absmax, const void *packed, const float *scale,

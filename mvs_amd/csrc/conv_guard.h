@@ -21,6 +21,10 @@
 
 namespace mvs {
 
+// PyTorch-layout fp32 weights -- (Cout, Cin, taps), or transposed (Cin, Cout, taps) -- into the guard's layout [tap][Cin][Cout]
+// behind a two-piece pack (conv_f16x3.hip; called by every *_pack_weights_f16* entry)
+int launch_guard_weights(const float *w, int transposed, int Cin, int Cout, int ntap, float *dst, hipStream_t st);
+
 // the device counter of launches that took the fallback (capi.hip; one per device, the launchers pass its address)
 unsigned long long *guard_counter();
 
@@ -46,7 +50,7 @@ __device__ __forceinline__ AbsmaxVerdict absmax_verdict(const unsigned *absmax) 
 
 struct GuardConv {
     const float *in;      // channels-last [B, D, H, W, Cin], or (in_c8) 8-channel blocks [B, D, H, Cin/8, W, 8]
-    const float *w;       // PyTorch layout: (Cout_total, Cin, taps), transposed: (Cin, Cout_total, 27)
+    const float *w;       // the layer's fp32 weights as launch_guard_weights() lays them out: [tap][Cin][Cout_total]
     const float *scale, *shift, *residual;   // as the fast kernel's arguments (already offset to the launch's first channel)
     float *out;
     unsigned *out_absmax;
@@ -61,7 +65,7 @@ struct GuardConv {
 // channels of the launch for its voxel: the weight addresses are then the same for every lane (scalar loads, the weight rides
 // in an SGPR operand of the FMA) and the input comes in as one 16-byte load per four input channels -- per (tap, input channel)
 // a quarter of a vector load and NCO FMAs, where the first version (one 4-channel block per thread, scalar loads of everything)
-// issued five loads per four FMAs: one NaN pixel in a source image cost 178 ms per forward at config 2, now ~NN ms
+// issued five loads per four FMAs: one NaN pixel in a source image cost 178 ms per forward at config 2, now 43 ms
 // (scripts/exp_guard_cost.py).  The accumulation order per output is unchanged: taps (z, y, x), then input channels.
 template <int NCO>
 __device__ __forceinline__ void guard_direct_conv_n(const GuardConv &g) {
@@ -70,9 +74,8 @@ __device__ __forceinline__ void guard_direct_conv_n(const GuardConv &g) {
     const int ntap = g.kd * g.kh * g.kh, pz = g.kd / 2, ph = g.kh / 2;
     const int sz = g.kd == 1 ? 1 : g.stride;          // images are not strided in z
     const int c0 = g.co0;                              // first output channel of the launch in the whole tensor
-    // weight of (output channel c0 + j, input channel ci, tap t): wbase + j * wj + ci * wci + t
-    const int64_t wj = g.transposed ? ntap : (int64_t)g.Cin * ntap, wci = g.transposed ? (int64_t)g.ldc * ntap : ntap;
-    const float *const wbase = g.w + (g.transposed ? (int64_t)c0 * ntap : (int64_t)c0 * g.Cin * ntap);
+    // weight of (tap t, input channel ci, output channel c0 + j): g.w[(t * Cin + ci) * ldc + c0 + j] -- the NCO weights of one
+    // (tap, input channel) are contiguous: one wide scalar load
     unsigned vmax = 0;
     for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += stride) {
         int64_t vox = it;
@@ -100,16 +103,16 @@ __device__ __forceinline__ void guard_direct_conv_n(const GuardConv &g) {
                     if ((unsigned)ix >= (unsigned)g.W) continue;
                     const int t = (tz * g.kh + ty) * g.kh + tx;
                     const int64_t row = ((int64_t)b * g.D + iz) * g.H + iy;
-                    const float *const wt = wbase + t;
+                    const float *const wt = g.w + (int64_t)t * g.Cin * g.ldc + c0;
                     for (int ci = 0; ci < g.Cin; ci += 4) {
                         const float4 xq = g.in_c8 ? *reinterpret_cast<const float4 *>(g.in + ((row * (g.Cin >> 3) + (ci >> 3)) * g.W + ix) * 8 + (ci & 7))
                                                   : *reinterpret_cast<const float4 *>(g.in + (row * g.W + ix) * g.Cin + ci);
                         const float xs[4] = {xq.x, xq.y, xq.z, xq.w};
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            const float *const wk = wt + (ci + k) * wci;
+                            const float *const wk = wt + (ci + k) * g.ldc;
 #pragma unroll
-                            for (int j = 0; j < NCO; ++j) acc[j] = __fmaf_rn(wk[j * wj], xs[k], acc[j]);
+                            for (int j = 0; j < NCO; ++j) acc[j] = __fmaf_rn(wk[j], xs[k], acc[j]);
                         }
                     }
                 }

@@ -712,7 +712,7 @@ extern "C" int mvs_conv_split_pack_weights_f16_f32(const float *weight, int kd, 
                            co0, reinterpret_cast<unsigned short *>(pk + (co0 / step) * per_launch), total, wmax,
                            reinterpret_cast<float *>(pk + body));
     }
-    if (hipMemcpyAsync(pk + body + 16, weight, (size_t)Cout * Cin * ntap * 4, hipMemcpyDeviceToDevice, as_stream(stream)) != hipSuccess)
+    if (launch_guard_weights(weight, 0, Cin, Cout, ntap, reinterpret_cast<float *>(pk + body + 16), as_stream(stream)) != MVS_OK)
         return bare_error(MVS_ELAUNCH, __func__, __LINE__);
     return check_launch("mvs_conv_split_pack_weights_f16_f32");
 }

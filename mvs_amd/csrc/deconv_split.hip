@@ -534,7 +534,7 @@ extern "C" int mvs_deconv_split_pack_weights_f16_f32(const float *weight, int Ci
         else
             hipLaunchKernelGGL((pack_deconv_split_kernel<false, true>), dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), weight, Cin, Cout, co0, dst, total, wmax, iscale);
     }
-    if (hipMemcpyAsync(pk + body + 16, weight, (size_t)Cin * Cout * 27 * 4, hipMemcpyDeviceToDevice, as_stream(stream)) != hipSuccess)
+    if (launch_guard_weights(weight, 1, Cin, Cout, 27, reinterpret_cast<float *>(pk + body + 16), as_stream(stream)) != MVS_OK)
         return bare_error(MVS_ELAUNCH, __func__, __LINE__);
     return check_launch("mvs_deconv_split_pack_weights_f16_f32");
 }
