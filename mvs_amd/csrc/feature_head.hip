@@ -5,11 +5,16 @@
 // image in and 0.30 GB out.  Here a persistent workgroup (4 waves, two workgroups per CU) walks 32 x 16-pixel tiles:
 //   copy      the image halo of the NEXT tile, 3 planes x 20 rows x 40 columns, by LDS-DMA (double-buffered; zero
 //             fill outside the image by the buffer range check = conv0's zero padding)
-//   conv0     on the vector ALU (216 FMAs per pixel cannot fill a matrix tile): a thread owns three consecutive rows of
-//             one column of the 18 x 34 region conv1 needs, keeps its 5 x 3 x 3 inputs in registers, reads the 27 x 8
-//             weights as broadcast ds_read_b128, applies BN + ReLU, splits every result exactly into three bf16 numbers
-//             (conv_split_common.h) and writes them -- zeros outside the image: conv1 pads conv0's OUTPUT -- as the
-//             operand planes of conv1's matrix stream
+//   conv0     (round 5) on the BF16 matrix pipe too, exact three-piece operands: the image tile is split once into pixel-major
+//             planes [row][column][3 channels + a zero] of bf16 pieces, so that 8 consecutive K slots = two neighbouring
+//             columns x 4 channels are ONE ds_read_b128; MFMA rows = (x-shift, 8 output channels) against a 4-column window
+//             (the Cout = 8 shifted form), K = 3 kernel rows x 4 window columns x 4 channels = 48 of 64 slots in two K-steps,
+//             N = 16 column pairs of one row; 18 rows + 2 items for the 17th column pair (N = rows there) = 20 items of 12
+//             MFMAs per tile.  BN + ReLU, every result split exactly into three bf16 numbers (conv_split_common.h) and
+//             written -- zeros outside the image: conv1 pads conv0's OUTPUT -- as the operand planes of conv1's matrix
+//             stream.  (Rounds 2-4 ran conv0 on the vector ALU: 216 FMAs per pixel, ~1190 instructions per wave and tile,
+//             0.09-0.11 ms of the kernel's 0.21; now 0.06 of 0.185: items in pairs -- four accumulators in
+//             flight, one 8-value split for both -- with the next pair's MFMAs issued before a pair's epilogue.)
 //   conv1     on the BF16 matrix pipe at fp32 accuracy (six partial products per fp32 product): the Cout = 8 "shifted"
 //             form -- MFMA rows = channel x x-shift, 16 even-x pixels per column group -- with K = 4 x-taps x 8
 //             channels, i.e. one v_mfma_f32_16x16x32_bf16 per kernel row and product
@@ -29,17 +34,20 @@ constexpr int kTH = 16;                                  // tile rows (x: 32)
 constexpr int kHR = kTH + 2, kHT = 34, kHXH = 17;        // conv1's halo of a tile; half of its width (x de-interleaved)
 constexpr int kBPartBytes = kHR * kHT * 16;              // one bf16 part of the halo: 8 channels = 16 bytes per pixel
 constexpr int kIR = kTH + 4, kIP = 40;                   // image tile: rows y0-2 .. y0+17, columns x0-4 .. x0+35
-constexpr int kImgGran = 3 * kIR * kIP / 4;              // 16-byte pieces: 600
-constexpr int kImgDma = (kImgGran + 63) / 64;            // 10 wave instructions
-constexpr int kImgFloats = kImgDma * 256;
-constexpr int kW1Bytes = 3 * 3 * 1024;                   // conv1 A fragments: [kernel row][part][lane][8 bf16]
-constexpr int kW0Floats = 27 * 8 + 16;                   // conv0 [tap][cout], scale, shift
+constexpr int kNPos = kIR * (kIP / 4);                   // (row, 4-column group) positions of the image tile: 200
 constexpr int kHeadWaves = 4, kHeadThreads = 256, kRPW = kTH / kHeadWaves;
-constexpr int kRG = 3, kNRG = kHR / kRG;                 // conv0: rows per thread, row groups
+// a wave copies -- and later splits -- its OWN 64 positions, all three channels: [wave][channel][lane][4 floats]
+constexpr int kImgFloats = kHeadWaves * 3 * 256;
+static_assert(kHeadWaves * 64 >= kNPos, "positions per wave");
+constexpr int kPRowBytes = kIP * 8;                      // image pieces: [row][column][4 bf16] -- one row
+constexpr int kPPartBytes = (kIR + 1) * kPRowBytes;      // ... one piece plane (+ a zero row: kernel row 3 of the second K-step)
+constexpr int kW1Bytes = 3 * 3 * 1024;                   // conv1 A fragments: [kernel row][part][lane][8 bf16]
+constexpr int kW0Floats = 16;                            // conv0's scale, shift
+constexpr int kItems = kHR + 2, kIPW0 = kItems / kHeadWaves;   // conv0: 18 row items + 2 column items, five per wave
+static_assert(kItems % kHeadWaves == 0, "items per wave");
 constexpr int kW1Off = 0, kBOff = kW1Off + kW1Bytes / 4, kImgOff = kBOff + 3 * kBPartBytes / 4;
-constexpr int kW0Off = kImgOff + 2 * kImgFloats, kHeadLdsFloats = kW0Off + kW0Floats;
-static_assert(2 * (kHeadLdsFloats * 4 + 512) <= 160 * 1024 && kNRG * kHT <= kHeadThreads, "two workgroups per CU");
-constexpr int kIPW = (kImgDma + kHeadWaves - 1) / kHeadWaves;   // copies per wave
+constexpr int kPOff = kImgOff + kImgFloats, kW0Off = kPOff + 3 * kPPartBytes / 4, kHeadLdsFloats = kW0Off + kW0Floats;
+static_assert(2 * (kHeadLdsFloats * 4 + 512) <= 160 * 1024, "two workgroups per CU");
 }  // namespace
 
 struct HeadArgs {
@@ -71,26 +79,33 @@ __global__ __launch_bounds__(kHeadThreads) __attribute__((amdgpu_waves_per_eu(2,
             t_cur = blockIdx.x; t_end = ntiles; t_step = nb;
         }
     }
-    // once: conv1's A fragments, conv0's weights and affine
+    // once: conv1's A fragments, conv0's affine, zeros in the image pieces (their pad row stays zero)
     for (int i = tid; i < kW1Bytes / 16; i += kHeadThreads)
         reinterpret_cast<float4 *>(lds + kW1Off)[i] = reinterpret_cast<const float4 *>(a.wpk1)[i];
-    for (int i = tid; i < kW0Floats; i += kHeadThreads) {
-        float v;
-        if (i < 216) v = a.w0[(i & 7) * 27 + (i >> 3)];
-        else if (i < 224) v = a.scale0 ? a.scale0[i - 216] : 1.0f;
-        else v = a.shift0 ? a.shift0[i - 224] : 0.0f;
-        lds[kW0Off + i] = v;
+    if (tid < kW0Floats) lds[kW0Off + tid] = tid < 8 ? (a.scale0 ? a.scale0[tid] : 1.0f) : (a.shift0 ? a.shift0[tid - 8] : 0.0f);
+    for (int i = tid; i < 3 * kPPartBytes / 16; i += kHeadThreads) reinterpret_cast<float4 *>(lds + kPOff)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // conv0's A fragments in registers: lane (m, kq), K-step s, element i: K slot 8 s + 2 kq + (i >> 2) = (kernel row ky = slot >> 2,
+    // window column kxw = slot & 3), channel i & 3; MFMA row m = (x-shift m >> 3, output channel m & 7): w0[co][c][ky][kxw - shift]
+    bf16x8 A0[2][3];
+    {
+        const int m = lane & 15, co = m & 7, sft = m >> 3;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            f32x4 x0, x1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int slot = 8 * st + 2 * kq + (i >> 2), ky = slot >> 2, kx = (slot & 3) - sft, c = i & 3;
+                const float v = (c < 3 && ky < 3 && kx >= 0 && kx < 3) ? a.w0[((co * 3 + c) * 3 + ky) * 3 + kx] : 0.0f;
+                if (i < 4) x0[i] = v; else x1[i - 4] = v;
+            }
+            split3_block(x0, x1, A0[st][0], A0[st][1], A0[st][2]);
+        }
     }
 
-    // tile-independent coordinates of this wave's copies: piece q = (channel, row, 4-column group)
-    int loc[kIPW];
-#pragma unroll
-    for (int i = 0; i < kIPW; ++i) {
-        const int q = (i * kHeadWaves + wv) * 64 + lane;
-        const int qc = min(q, kImgGran - 1);
-        const int c = qc / (kIR * 10), r = (qc / 10) % kIR, g = qc % 10;
-        loc[i] = g | (r << 8) | (c << 16) | (q < kImgGran ? 0 : (int)0x80000000);
-    }
+    // tile-independent coordinates of this wave's copies: position p = 64 wv + lane = (row, 4-column group), channels 0..2
+    const int pos = wv * 64 + lane;
+    const bool pos_ok = pos < kNPos;
+    const int prow = pos_ok ? pos / (kIP / 4) : 0, pgrp = pos_ok ? pos % (kIP / 4) : 0;
     const int plane = a.H * a.W;
     struct Tile { int tx, ty, b; };
     auto decode = [&](int t) {
@@ -105,19 +120,32 @@ __global__ __launch_bounds__(kHeadThreads) __attribute__((amdgpu_waves_per_eu(2,
         return r;
     };
     Tile nxt = {0, 0, 0};
-    auto issue = [&](int t, int parity) {
+    auto issue = [&](int t) {
         nxt = decode(t);
+        if (a.abl & 8) return;
         const mvs_srd_t srd = make_srd(a.img + (int64_t)nxt.b * 3 * plane, (unsigned)(3 * plane) * 4u);
-        const int gx0 = nxt.tx * 32 - 4, gy0 = nxt.ty * kTH - 2;
-        const unsigned base = lds_base + (unsigned)(kImgOff + parity * kImgFloats) * 4u;
+        const int gx = nxt.tx * 32 - 4 + pgrp * 4, gy = nxt.ty * kTH - 2 + prow;
+        const bool ok = pos_ok && (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H;
+        const unsigned base = lds_base + (unsigned)(kImgOff * 4 + wv * 3 * 1024);
 #pragma unroll
-        for (int i = 0; i < kIPW; ++i) {
-            if (i * kHeadWaves + wv >= kImgDma) continue;   // wave-uniform
-            const int gx = gx0 + (loc[i] & 255) * 4, gy = gy0 + ((loc[i] >> 8) & 255), c = (loc[i] >> 16) & 3;
-            const bool ok = loc[i] >= 0 && (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H;
-            const unsigned voff = ok ? (unsigned)((c * plane + gy * a.W + gx) * 4) : 0xffffff00u;
-            glds16_buf(voff, srd, 0u, base + (unsigned)(i * kHeadWaves + wv) * 1024u);
-        }
+        for (int c = 0; c < 3; ++c)
+            glds16_buf(ok ? (unsigned)((c * plane + gy * a.W + gx) * 4) : 0xffffff00u, srd, 0u, base + (unsigned)c * 1024u);
+    };
+    // this wave's positions of the staged image -> the three piece planes: 4 pixels x (3 channels + 0) per lane
+    auto split_own = [&]() {
+        if (!pos_ok) return;
+        const float *im = lds + kImgOff + wv * 3 * 256 + lane * 4;
+        const float4 c0v = *reinterpret_cast<const float4 *>(im), c1v = *reinterpret_cast<const float4 *>(im + 256),
+                     c2v = *reinterpret_cast<const float4 *>(im + 512);
+        const unsigned dst = lds_base + (unsigned)(kPOff * 4 + prow * kPRowBytes + pgrp * 32);
+        f32x4 p0 = {c0v.x, c1v.x, c2v.x, 0.f}, p1 = {c0v.y, c1v.y, c2v.y, 0.f};
+        f32x4 p2 = {c0v.z, c1v.z, c2v.z, 0.f}, p3 = {c0v.w, c1v.w, c2v.w, 0.f};
+        bf16x8 h, m, l;
+        split3_block(p0, p1, h, m, l);
+        lds_write_b128<0>(dst, h); lds_write_b128<kPPartBytes>(dst, m); lds_write_b128<2 * kPPartBytes>(dst, l);
+        split3_block(p2, p3, h, m, l);
+        lds_write_b128<16>(dst, h); lds_write_b128<16 + kPPartBytes>(dst, m); lds_write_b128<16 + 2 * kPPartBytes>(dst, l);
+        lds_wait_n<0>();
     };
 
     // conv1's BN affine of this lane's four channels
@@ -128,98 +156,123 @@ __global__ __launch_bounds__(kHeadThreads) __attribute__((amdgpu_waves_per_eu(2,
     // wave's first row, every part; rows, kernel rows and parts are compile-time offsets
     const unsigned aA = lds_base + (unsigned)(kW1Off * 4 + lane * 16);
     const unsigned aB = lds_base + (unsigned)(kBOff * 4 + ((wv * kRPW) * kHT + (kq & 1) * kHXH + (kq >> 1) + n) * 16);
-    // conv0: this thread's column and first row of the 18 x 34 region
-    const int hcol = tid % kHT, hrow0 = (tid / kHT) * kRG;
-    const bool conv0_thread = tid < kNRG * kHT;
-    const int hxd = (hcol & 1) ? kHXH + (hcol >> 1) : (hcol >> 1);
 
-    int parity = 0;
-    bool full_stores = false;   // did this wave issue exactly kRPW stores after its last copies?
-    if (t_cur < t_end) issue(t_cur, 0);
+    if (t_cur < t_end) {
+        issue(t_cur);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();         // the zeroed piece planes, conv1's fragments, the affine
+    if (t_cur < t_end) split_own();
     float vmax = 0.0f;
     while (t_cur < t_end) {
         const Tile cur = nxt;
         const int t_next = t_cur + t_step;
-        // The image tile was requested before the previous tile's stores; vector memory retires in order, so with
-        // a full set of kRPW stores behind the copies a counted wait leaves the HBM write latency out of the tile.
-        if (full_stores) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();   // the image tile has landed; every wave is done with conv1 of the previous tile
-        if (t_next < t_end && !(a.abl & 8)) issue(t_next, parity ^ 1);
-        else if (t_next < t_end) nxt = decode(t_next);
+        __syncthreads();     // A: the image pieces of this tile are complete; every wave is done with conv1 of the previous tile
+        if (t_next < t_end) issue(t_next);       // (each wave's staging slots are its own: free since its split)
 
         // ---- conv0 + BN + ReLU -> conv1's operand planes
-        if (conv0_thread && !(a.abl & 1)) {
-            const float *im = lds + kImgOff + parity * kImgFloats + hrow0 * kIP + hcol + 2;
-            const float *wl = lds + kW0Off;
-            float acc[kRG][8];
+        if (!(a.abl & 1)) {
+            const float4 sc0 = *reinterpret_cast<const float4 *>(lds + kW0Off + c0), sh0 = *reinterpret_cast<const float4 *>(lds + kW0Off + 8 + c0);
+            const int sft = kq >> 1;
+            // items in pairs (four independent accumulators in flight; one 8-value split serves both); the reads of the next
+            // pair go out before the MFMAs of this one
+            int rowk[kIPW0 + 1], pairk[kIPW0 + 1];
+            unsigned adk[kIPW0 + 1];
 #pragma unroll
-            for (int r = 0; r < kRG; ++r)
-#pragma unroll
-                for (int c = 0; c < 8; ++c) acc[r][c] = 0.0f;
-            // weights of one (channel, kernel row) = 3 taps x 8 output channels, fetched one group ahead; the
-            // scheduler is fenced per group (left alone it hoists all 54 weight reads: 330 registers, one
-            // workgroup per CU)
-            float4 wq[2][6];
-            auto load_w = [&](int slot, int g) {
-#pragma unroll
-                for (int i = 0; i < 6; ++i) wq[slot][i] = *reinterpret_cast<const float4 *>(wl + g * 24 + i * 4);
-            };
-            load_w(0, 0);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float in[kRG + 2][3];
-#pragma unroll
-                for (int r = 0; r < kRG + 2; ++r)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) in[r][kx] = im[(c * kIR + r) * kIP + kx];
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int g = c * 3 + ky;
-                    if (g + 1 < 9) load_w((g + 1) & 1, g + 1);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const float4 wa = wq[g & 1][kx * 2], wb = wq[g & 1][kx * 2 + 1];
-                        const float w[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-#pragma unroll
-                        for (int r = 0; r < kRG; ++r)
-#pragma unroll
-                            for (int co = 0; co < 8; ++co) acc[r][co] = fmaf(in[r + ky][kx], w[co], acc[r][co]);
-                    }
-                    // (the FMAs have no side effects: without these pins instruction selection sinks all of them
-                    // below the last group's loads)
-#pragma unroll
-                    for (int r = 0; r < kRG; ++r)
-#pragma unroll
-                        for (int co = 0; co < 8; ++co) asm volatile("" : "+v"(acc[r][co]));
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+            for (int k = 0; k < kIPW0 + 1; ++k) {
+                const int it = wv + kHeadWaves * (k < kIPW0 ? k : kIPW0 - 1);   // wave-uniform (the odd item out is paired with itself)
+                // row items: row = it, column pair = n; column items (the 17th pair): rows 0..15 / 2..17, pair 16
+                rowk[k] = it < kHR ? it : (it - kHR) * 2 + n;
+                pairk[k] = it < kHR ? n : 16;
+                adk[k] = lds_base + (unsigned)(kPOff * 4 + (rowk[k] + (kq >> 1)) * kPRowBytes + (2 * pairk[k] + 2 + 2 * (kq & 1)) * 8);
             }
-            const float4 s0a = *reinterpret_cast<const float4 *>(wl + 216), s0b = *reinterpret_cast<const float4 *>(wl + 220);
-            const float4 h0a = *reinterpret_cast<const float4 *>(wl + 224), h0b = *reinterpret_cast<const float4 *>(wl + 228);
-            const int gx = cur.tx * 32 - 1 + hcol;
-            const bool xin = (unsigned)gx < (unsigned)a.W;
-            const unsigned bw = lds_base + (unsigned)(kBOff * 4 + (hrow0 * kHT + hxd) * 16);
-            static_for<0, kRG>([&](auto rc) {
-                constexpr int r = decltype(rc)::value;
-                const int gy = cur.ty * kTH - 1 + hrow0 + r;
-                const bool in_img = xin && (unsigned)gy < (unsigned)a.H;
-                f32x4 lo, hi;
-                lo[0] = relu_nan(fmaf(acc[r][0], s0a.x, h0a.x)); lo[1] = relu_nan(fmaf(acc[r][1], s0a.y, h0a.y));
-                lo[2] = relu_nan(fmaf(acc[r][2], s0a.z, h0a.z)); lo[3] = relu_nan(fmaf(acc[r][3], s0a.w, h0a.w));
-                hi[0] = relu_nan(fmaf(acc[r][4], s0b.x, h0b.x)); hi[1] = relu_nan(fmaf(acc[r][5], s0b.y, h0b.y));
-                hi[2] = relu_nan(fmaf(acc[r][6], s0b.z, h0b.z)); hi[3] = relu_nan(fmaf(acc[r][7], s0b.w, h0b.w));
-                if (!in_img) lo = hi = (f32x4){0.f, 0.f, 0.f, 0.f};
+            bf16x8 B0[2][2][2][3];      // [pair parity][item of the pair][K-step][part]
+            auto read_pair = [&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                static_for<0, 2>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value, k = 2 * q + i;
+                    if constexpr (k < kIPW0) {
+                        static_for<0, 2>([&](auto sc_) {
+                            constexpr int st = decltype(sc_)::value;
+                            static_for<0, 3>([&](auto pc) {
+                                constexpr int p = decltype(pc)::value;
+                                B0[q & 1][i][st][p] = __builtin_bit_cast(bf16x8, lds_read_b128<st * 2 * kPRowBytes + p * kPPartBytes>(adk[k]));
+                            });
+                        });
+                    }
+                });
+            };
+            constexpr int NPAIR = (kIPW0 + 1) / 2;
+            f32x4 acc[2][2][2];       // [pair parity][item][K-step]: per item two accumulators, six partial products each
+            auto mfma_pair = [&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                constexpr bool two = 2 * q + 1 < kIPW0;
+                lds_wait_n<0>();
+                static_for<0, 2>([&](auto sc_) {
+                    constexpr int st = decltype(sc_)::value;
+                    asm volatile("" : "+v"(B0[q & 1][0][st][0]), "+v"(B0[q & 1][0][st][1]), "+v"(B0[q & 1][0][st][2]));
+                    if constexpr (two) asm volatile("" : "+v"(B0[q & 1][1][st][0]), "+v"(B0[q & 1][1][st][1]), "+v"(B0[q & 1][1][st][2]));
+                });
+                if constexpr (q + 1 < NPAIR) read_pair(std::integral_constant<int, q + 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) acc[q & 1][i][st] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};      // small terms first
+                static_for<0, 6>([&](auto pc) {
+                    constexpr int pr = decltype(pc)::value;
+                    static_for<0, two ? 2 : 1>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        acc[q & 1][i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0[0][PA[pr]], B0[q & 1][i][0][PB[pr]], acc[q & 1][i][0], 0, 0, 0);
+                        acc[q & 1][i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0[1][PA[pr]], B0[q & 1][i][1][PB[pr]], acc[q & 1][i][1], 0, 0, 0);
+                    });
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            // this lane: 4 output channels of pixel (row, column 2 pair + shift) of the 18 x 34 region, per item
+            auto epilogue_pair = [&](auto qc) {
+                constexpr int q = decltype(qc)::value, k0 = 2 * q;
+                constexpr bool two = 2 * q + 1 < kIPW0;
+                f32x4 v[2];
+                unsigned bw[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int k = (i == 1 && !two) ? k0 : k0 + i;
+                    const int row = rowk[k], hcol = 2 * pairk[k] + sft;
+                    const int gx = cur.tx * 32 - 1 + hcol, gy = cur.ty * kTH - 1 + row;
+                    const bool in_img = (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H;
+                    const f32x4 e = acc[q & 1][i][0], o = acc[q & 1][i][1];
+                    v[i][0] = relu_nan(fmaf(e[0] + o[0], sc0.x, sh0.x)); v[i][1] = relu_nan(fmaf(e[1] + o[1], sc0.y, sh0.y));
+                    v[i][2] = relu_nan(fmaf(e[2] + o[2], sc0.z, sh0.z)); v[i][3] = relu_nan(fmaf(e[3] + o[3], sc0.w, sh0.w));
+                    if (!in_img || (i == 1 && !two)) v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    const int hxd = (hcol & 1) ? kHXH + (hcol >> 1) : (hcol >> 1);
+                    bw[i] = lds_base + (unsigned)(kBOff * 4 + (row * kHT + hxd) * 16 + (kq & 1) * 8);
+                }
                 bf16x8 ph, pm, pl;
-                split3_block(lo, hi, ph, pm, pl);
-                lds_write_b128<r * kHT * 16>(bw, ph);
-                lds_write_b128<r * kHT * 16 + kBPartBytes>(bw, pm);
-                lds_write_b128<r * kHT * 16 + 2 * kBPartBytes>(bw, pl);
+                split3_block(v[0], v[1], ph, pm, pl);
+                const u32x4 hu = __builtin_bit_cast(u32x4, ph), mu = __builtin_bit_cast(u32x4, pm), lu = __builtin_bit_cast(u32x4, pl);
+                lds_write_b64<0>(bw[0], hu[0], hu[1]);
+                lds_write_b64<kBPartBytes>(bw[0], mu[0], mu[1]);
+                lds_write_b64<2 * kBPartBytes>(bw[0], lu[0], lu[1]);
+                if constexpr (two) {
+                    lds_write_b64<0>(bw[1], hu[2], hu[3]);
+                    lds_write_b64<kBPartBytes>(bw[1], mu[2], mu[3]);
+                    lds_write_b64<2 * kBPartBytes>(bw[1], lu[2], lu[3]);
+                }
+            };
+            // the MFMAs of pair q + 1 are issued before the vector work of pair q's epilogue: it runs in their shadow
+            read_pair(std::integral_constant<int, 0>{});
+            mfma_pair(std::integral_constant<int, 0>{});
+            static_for<1, NPAIR>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                mfma_pair(std::integral_constant<int, q>{});
+                epilogue_pair(std::integral_constant<int, q - 1>{});
             });
+            epilogue_pair(std::integral_constant<int, NPAIR - 1>{});
             lds_wait_n<0>();
         }
-        __syncthreads();
+        __syncthreads();     // B: conv1's operand planes are complete; the image pieces are free
 
         // ---- conv1: items (kernel row ky, row r): three B reads (one per part) one item ahead of its six MFMAs; the A
         // fragments of a kernel row (three reads) go out with the last item of the row before
@@ -273,6 +326,11 @@ __global__ __launch_bounds__(kHeadThreads) __attribute__((amdgpu_waves_per_eu(2,
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
+        // ---- the next tile's image (this wave's own copies) has had conv0 and conv1 to land: split it into the piece planes
+        if (t_next < t_end) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(a.abl & 8)) split_own();
+        }
         // ---- epilogue: BN affine, ReLU, one 16-byte store per lane and row
         {
             const int ox = cur.tx * 32 + 2 * n + (kq >> 1);
@@ -288,8 +346,6 @@ __global__ __launch_bounds__(kHeadThreads) __attribute__((amdgpu_waves_per_eu(2,
                 vmax = max_nan(max_nan(max_nan(vmax, v[0]), v[1]), max_nan(v[2], v[3]));       // (after the ReLU: non-negative)
             }
         }
-        full_stores = !(a.abl & 4) && cur.ty * kTH + wv * kRPW + kRPW <= a.H;
-        parity ^= 1;
         t_cur = t_next;
     }
     publish_absmax(a.out_absmax, vmax);
