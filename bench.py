@@ -147,12 +147,16 @@ def last_json_line(text):
     return None
 
 
+def one_device_rehearsal():
+    return os.environ.get("MVS_BENCH_ONE_DEVICE") == "1"
+
+
 def self_launch(n_gpus, script_args, timeout=None):
     """Run N ranks of this script and forward rank 0's JSON line.  Never falls back to fewer ranks: a box with fewer GPUs than
     asked for is an error (a one-rank run labelled as the N-GPU line is worse than no line)."""
     import subprocess
     have = torch.cuda.device_count()
-    if have < n_gpus:
+    if have < n_gpus and not one_device_rehearsal():
         raise SystemExit(f"bench.py: --gpus {n_gpus} but this box has {have} GPU(s); refusing to run fewer ranks than asked")
     cmd = launch_command(n_gpus, script_args, free_port())
     try:
@@ -378,7 +382,8 @@ def train_main(args, rank, world, dev, dist):
                 "config": {"workload": f"MVSNet DTU training {W}x{H}, N={V} views, D={D} (BASELINE configs[4]); "
                                        f"global batch {world} reference views, 1 per GPU; Adam 1e-3",
                            "sharding": f"data parallel x{world}, one flat {reduce_grads.numel * 4 / 1e6:.2f} MB "
-                                       "gradient all-reduce per step (RCCL)", "grad_floats": reduce_grads.numel},
+                                       "gradient all-reduce per step (RCCL)" + (" [ONE-DEVICE REHEARSAL: all ranks on cuda:0 over gloo -- not a measurement]" if one_device_rehearsal() else ""),
+                           "grad_floats": reduce_grads.numel},
                 "allreduce_us": (round(1e3 * sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events), 1)
                                  if ar_events else None),
                 "launch": graph.launch_note if graph is not None else "eager (~300 launches per step)",
@@ -466,13 +471,21 @@ def main():
     # the reference's drivers set this (MVSNet/eval.py:23, train.py:25); on ROCm it lets
     # MIOpen pick its fastest FeatureNet convolution kernels during warm-up
     torch.backends.cudnn.benchmark = True
+    # MVS_BENCH_ONE_DEVICE=1: a REHEARSAL of the N-rank control flow on a one-GPU box -- every rank on cuda:0, gloo instead of
+    # RCCL (two ranks cannot share a device under RCCL).  Its numbers mean nothing; the line says so (tests/test_gpu_multi.py).
+    rehearsal = one_device_rehearsal()
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)   # RCCL over xGMI
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)   # RCCL over xGMI
 
     if args.mode == "train":
         return train_main(args, rank, world, dev, dist)
@@ -570,7 +583,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"MVSNet DTU {W}x{H}, N={V} views, D={D} inference (BASELINE "
                                "configs[1]); 1 reference view per step per GPU",
-                   "feature_res": [h, w], "sharding": f"ref-views x{world}, no collective",
+                   "feature_res": [h, w], "sharding": f"ref-views x{world}, no collective" + (" [ONE-DEVICE REHEARSAL: all ranks on cuda:0 over gloo -- not a measurement]" if one_device_rehearsal() else ""),
                    "conv_impl": args.conv_impl, "proj_inverse": model.proj_where,
                    "arithmetic": arithmetic_note()},
         "roofline": roof,
@@ -630,6 +643,23 @@ def main():
             "max_abs_depth_diff_vs_gpu_mm": err, **extra,
         }
     line["guard_fallbacks"] = ops.guard_fallback_count()   # launches whose two-piece layer fell back to fp32 (conv_guard.h): 0 on a sane volume
+    if world == 1 and not args.no_extras:
+        # the same K forwards with reference views ALTERNATED over two HIP streams (what an evaluation loop over a scan would do):
+        # the tail of one view's kernels overlaps the head of the next view's.  Reported beside the headline, which stays one
+        # stream so that a step is one forward and the rounds stay comparable.
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for i in range(4):
+            with torch.cuda.stream(streams[i % 2]):
+                step()
+        torch.cuda.synchronize()
+        t0s = time.perf_counter()
+        for i in range(args.steps):
+            with torch.cuda.stream(streams[i % 2]):
+                step()
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t0s
+        line["two_streams"] = {"value": round(args.steps / el2, 4), "unit": "depth-maps/s", "ms_per_step": round(el2 / args.steps * 1e3, 4),
+                               "steps": args.steps, "note": "reference views alternated over two HIP streams; not the headline"}
     if dist is not None:
         dist.destroy_process_group()      # the extras below are rank 0's alone (the other ranks have left)
         dist = None

@@ -64,3 +64,10 @@ def test_rccl_gradient_average_equals_mean_of_shard_gradients():
     out = _torchrun([os.path.join("tests", "rccl_grad_worker.py")], 29613)
     res = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     assert res["ranks_agree"] and res["max_rel_err_vs_mean_of_shards"] < 1e-5, res
+
+
+def test_two_graph_step_averages_the_gradient_over_two_gpus():
+    """The same check as tests/test_gpu_rehearsal.py::test_two_graph_step_averages_the_gradient_over_the_ranks over RCCL on two devices."""
+    out = _torchrun([os.path.join("tests", "graph_grad_worker.py")], 29618)
+    res = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert res["graphs"] == 2 and res["ranks_agree"] and res["max_rel_err_vs_mean_of_shards"] < 1e-4, res
