@@ -305,6 +305,26 @@ int mvs_conv_split_pack_weights_f16_f32(const float *weight, int kd, int Cin, in
 int mvs_conv_split_f16_f32(const float *in, const void *in_absmax, const void *packed, const float *scale,
                            const float *shift, const float *residual, int relu, int kd, int stride, int B, int Cin,
                            int Cout, int D, int H, int W, int out_c4, float *out, void *out_absmax, void *stream);
+/* ---- two consecutive 3x3 stride-1 C -> C layers of a 2D net as one kernel (mvs_amd/csrc/conv2d_pair.hip; C = 16: conv3 + conv4 of
+ * FeatureNet, MVSNet/models/mvsnet.py:15-16,37-38) -- the map between them stays in LDS.  Two-piece fp16 operands; the
+ * intermediate map is scaled by a power of two from a BOUND on its magnitude (the input's absmax block, the first layer's largest
+ * weight and affine).  in [N, H, W, C] channels-last with its absmax block; packed_pair: mvs_conv2d_pair_packed_bytes(C) bytes from
+ * mvs_conv2d_pair_pack_weights_f32(w1, w2: (C, C, 3, 3) as PyTorch stores them); scale / shift per layer (NULL = 1 / 0); the first
+ * layer ends in a ReLU, the second in one if relu2; out [N, H, W, C] or (out_c4) [N, C/4, H, W, 4]; out_absmax: NULL or a zeroed block.
+ * RANGE GUARD as mvs_costreg_tail_f16_f32: a launch that fails it writes 1 to *fallback_flag and computes nothing.
+ * mvs_conv2d_pair_guarded_f16_f32 = that launch with the two layers of mvs_conv_split_f16_f32 (packed1_f16 / packed2_f16: their own
+ * packs) enqueued behind it so that they run only if the flag was set; flag: MVS_ABSMAX_WORDS + 64 zeroed words (the flag, then the
+ * block of the unfused path's intermediate map); mid_scratch: [N, H, W, C] floats that only the unfused path touches. */
+size_t mvs_conv2d_pair_packed_bytes(int C);
+int mvs_conv2d_pair_supported(int C, int N, int H, int W);
+int mvs_conv2d_pair_pack_weights_f32(const float *w1, const float *w2, int C, void *packed, void *stream);
+int mvs_conv2d_pair_f16_f32(const float *in, const void *in_absmax, const void *packed_pair, const float *scale1,
+                            const float *shift1, const float *scale2, const float *shift2, int relu2, int N, int C,
+                            int H, int W, int out_c4, float *out, void *out_absmax, void *fallback_flag, void *stream);
+int mvs_conv2d_pair_guarded_f16_f32(const float *in, const void *in_absmax, const void *packed_pair, const void *packed1_f16,
+                                    const void *packed2_f16, const float *scale1, const float *shift1, const float *scale2,
+                                    const float *shift2, int relu2, int N, int C, int H, int W, int out_c4, float *mid_scratch,
+                                    float *out, void *out_absmax, void *flag, void *stream);
 size_t mvs_deconv_split_f16_packed_bytes(int Cin, int Cout);
 int mvs_deconv_split_pack_weights_f16_f32(const float *weight, int Cin, int Cout, void *packed, void *stream);
 int mvs_deconv_split_f16_f32(const float *in, const void *in_absmax, const void *packed, const float *scale,

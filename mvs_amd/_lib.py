@@ -72,6 +72,11 @@ _SIGS = {
     "mvs_conv_split_f16_packed_bytes": (ctypes.c_size_t, [_c_i] * 4),
     "mvs_conv_split_pack_weights_f16_f32": (_c_i, [_c_f] + [_c_i] * 4 + [_c_f, _c_f]),
     "mvs_conv_split_f16_f32": (_c_i, [_c_f] * 6 + [_c_i] * 10 + [_c_f, _c_f, _c_f]),
+    "mvs_conv2d_pair_packed_bytes": (ctypes.c_size_t, [_c_i]),
+    "mvs_conv2d_pair_supported": (_c_i, [_c_i] * 4),
+    "mvs_conv2d_pair_pack_weights_f32": (_c_i, [_c_f, _c_f, _c_i, _c_f, _c_f]),
+    "mvs_conv2d_pair_f16_f32": (_c_i, [_c_f] * 7 + [_c_i] * 6 + [_c_f] * 4),
+    "mvs_conv2d_pair_guarded_f16_f32": (_c_i, [_c_f] * 9 + [_c_i] * 6 + [_c_f] * 5),
     "mvs_deconv_split_supported": (_c_i, [_c_i] * 2),
     "mvs_deconv_split_packed_bytes": (ctypes.c_size_t, [_c_i] * 2),
     "mvs_deconv_split_pack_weights_f32": (_c_i, [_c_f] + [_c_i] * 2 + [_c_f, _c_f]),

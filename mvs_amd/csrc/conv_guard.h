@@ -71,7 +71,7 @@ template <int NCO>
 __device__ __forceinline__ void guard_direct_conv_n(const GuardConv &g) {
     const int64_t total = (int64_t)g.B * g.Do * g.Ho * g.Wo;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int ntap = g.kd * g.kh * g.kh, pz = g.kd / 2, ph = g.kh / 2;
+    const int pz = g.kd / 2, ph = g.kh / 2;
     const int sz = g.kd == 1 ? 1 : g.stride;          // images are not strided in z
     const int c0 = g.co0;                              // first output channel of the launch in the whole tensor
     // weight of (tap t, input channel ci, output channel c0 + j): g.w[(t * Cin + ci) * ldc + c0 + j] -- the NCO weights of one

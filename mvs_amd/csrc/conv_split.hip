@@ -42,6 +42,7 @@ struct SplitArgs {
     // packed weights) and the device counter of launches that fell back to them
     const float *w_f32;
     unsigned long long *guard_cnt;
+    const unsigned *run_flag;   // NULL, or a device word: the launch returns at once when it is 0 (mvs_common.h: conv_run_flag)
 };
 
 // NP: operand pieces -- 3 = bf16 hi/mid/lo, six products (exact split); 2 = scaled fp16 hi/lo, three products (conv_f16x3.hip
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_split_kernel(SplitArgs a, in
     constexpr int NWC = (WBYTES / 1024 + NC - 1) / NC;            // weight copies per copy wave
     __shared__ __attribute__((aligned(16))) unsigned char lds[C::LDS_BYTES];
 
+    if (a.run_flag && *a.run_flag == 0u) return;      // (uniform: a fused kernel in front of this launch did the work)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kq = lane >> 4;
@@ -756,6 +758,7 @@ static int conv_split_impl(const float *in, const void *in_absmax, const void *p
         a.out_absmax = static_cast<unsigned *>(out_absmax);
         a.w_f32 = a.w_iscale + 4;
         a.guard_cnt = np == 2 ? guard_counter() : nullptr;
+        a.run_flag = conv_run_flag();
         a.in = in; a.wpk = static_cast<const unsigned char *>(packed) + (co0 / step) * per_launch;
         a.scale = scale ? scale + co0 : nullptr; a.shift = shift ? shift + co0 : nullptr;
         a.residual = residual ? residual + co0 : nullptr; a.out = out + co0;

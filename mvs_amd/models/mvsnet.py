@@ -70,7 +70,7 @@ class FeatureNet(nn.Module):
                 shift = (m.bn.bias - m.bn.running_mean * scale).float().contiguous()
                 P.append(dict(name=name, cin=w.shape[1], cout=w.shape[0], k=w.shape[2],
                               stride=stride, packed=ops.pack_conv2d_weight(w, stride, split=True), scale=scale,
-                              shift=shift, relu=True, weight=w if name == "conv0" else None,
+                              shift=shift, relu=True, weight=w,
                               head=ops.pack_feature_head_weight(w) if name == "conv1" else None))
             w = self.feature.weight.detach().float().contiguous()
             P.append(dict(name="feature", cin=w.shape[1], cout=w.shape[0], k=w.shape[2], stride=1,
@@ -123,10 +123,25 @@ class FeatureNet(nn.Module):
                 x = ops.feature_head(x, P[0]["weight"], P[0]["scale"], P[0]["shift"], P[1]["head"], P[1]["scale"],
                                      P[1]["shift"], out_absmax=blocks[1] if blocks is not None else None)
             first = 2
+        skip = -1
         for i, p in enumerate(P):
-            if i < first:
+            if i < first or i == skip:
                 continue
             last = i == len(P) - 1
+            # two consecutive 3x3 stride-1 16 -> 16 layers (conv3 + conv4): one kernel, the map between them stays in LDS
+            nx = P[i + 1] if i + 1 < len(P) else None
+            if (blocks is not None and nx is not None and ops.conv2d_pair_enabled() and p["k"] == 3 and nx["k"] == 3 and
+                    p["stride"] == 1 and nx["stride"] == 1 and p["cin"] == p["cout"] == nx["cin"] == nx["cout"] == 16 and
+                    p["relu"] is True and ops.f16_companion(p["packed"]) is not None and ops.f16_companion(nx["packed"]) is not None):
+                if p.get("pair") is None:
+                    p["pair"] = ops.pack_conv2d_pair(p["weight"], nx["weight"])
+                if p["pair"] is not None:
+                    nlast = i + 1 == len(P) - 1
+                    with ops.stage("feature." + p["name"] + "+" + nx["name"]):
+                        x = ops.conv2d_pair(x, blocks[i - 1], p["pair"], p, nx, out_c4=(out_c4 and nlast),
+                                            out_absmax=blocks[i + 1] if not nlast else None)
+                    skip = i + 1
+                    continue
             with ops.stage("feature." + p["name"]):
                 x = ops.conv2d(x, p["packed"], p["cin"], p["cout"], p["k"], p["stride"], p["scale"],
                                p["shift"], p["relu"], planar=(i == 0), out_c4=(out_c4 and last),

@@ -1684,6 +1684,46 @@ def conv2d(x, packed, cin, cout, ksize, stride, scale=None, shift=None, relu=Fal
     return out
 
 
+def conv2d_pair_enabled():
+    """False when MVS_CONV2D_PAIR=0 keeps FeatureNet's conv3 / conv4 as two launches (A/B).  Default: one kernel
+    (mvs_conv2d_pair_guarded_f16_f32)."""
+    import os
+    return split_f16_enabled() and os.environ.get("MVS_CONV2D_PAIR", "1") != "0"
+
+
+def pack_conv2d_pair(w1, w2):
+    """Two (C, C, 3, 3) weights -> the fragments of the fused pair kernel, or None when the shape has none (C = 16 only)."""
+    w1, w2 = _f32c(w1), _f32c(w2)
+    C = w1.shape[0]
+    lib = _lib.load()
+    if tuple(w1.shape) != (C, C, 3, 3) or tuple(w2.shape) != (C, C, 3, 3):
+        return None
+    n = lib.mvs_conv2d_pair_packed_bytes(C)
+    if n == 0:
+        return None
+    out = torch.empty(n, device=w1.device, dtype=torch.uint8)
+    check(lib.mvs_conv2d_pair_pack_weights_f32(ptr(w1), ptr(w2), C, ctypes.c_void_p(out.data_ptr()), stream()),
+          "mvs_conv2d_pair_pack_weights_f32")
+    return out
+
+
+def conv2d_pair(x, x_absmax, packed_pair, p1, p2, out_c4=False, out_absmax=None):
+    """Two consecutive 3x3 stride-1 layers (parameter dicts p1, p2 with 'packed' -- whose two-piece companions serve the unfused
+    path --, 'scale', 'shift', 'relu') as one kernel; the two layers of conv_split are enqueued behind it and run only if its range
+    guard declined (no host synchronisation).  x [N,H,W,C] -> [N,H,W,C] (or out_c4 [N,C/4,H,W,4])."""
+    x = _f32c(x)
+    N, H, W, C = x.shape
+    out = torch.empty((N, C // 4, H, W, 4) if out_c4 else (N, H, W, C), device=x.device, dtype=torch.float32)
+    mid = torch.empty((N, H, W, C), device=x.device, dtype=torch.float32)       # touched only if the guard declines
+    flag = torch.zeros(ABSMAX_WORDS + 64, device=x.device, dtype=torch.int32)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
+    check(_lib.load().mvs_conv2d_pair_guarded_f16_f32(
+        ptr(x), vp(x_absmax), vp(packed_pair), vp(f16_companion(p1["packed"])), vp(f16_companion(p2["packed"])),
+        ptr(p1["scale"]), ptr(p1["shift"]), ptr(p2["scale"]), ptr(p2["shift"]), int(bool(p2["relu"])), N, C, H, W, int(bool(out_c4)),
+        ptr(mid), ptr(out), vp(out_absmax), vp(flag), stream()), "mvs_conv2d_pair_guarded_f16_f32")
+    return out
+
+
 # ------------------------------------------------------------- K4+K5 regress
 class _SoftmaxRegress(torch.autograd.Function):
     @staticmethod
