@@ -117,7 +117,8 @@ class FeatureNet(nn.Module):
         # a layer on a two-piece fp16 kernel scales its input by the absmax block the layer in front of it collected in its
         # epilogue (ops.conv2d: x_absmax / out_absmax); the chain starts at the fused head
         head = ops.feature_head_enabled() and ops.feature_head_supported(x.shape[2], x.shape[3])
-        blocks = ops.absmax_block(x.device, zero=True, n=len(P)) if (head and ops.split_f16_enabled()) else None
+        # (+ two rows: the flag words and the spare block of the fused conv3 + conv4 kernel -- zeroed by the same fill)
+        blocks = ops.absmax_block(x.device, zero=True, n=len(P) + 2) if (head and ops.split_f16_enabled()) else None
         if head:
             with ops.stage("feature.head"):   # conv0 + conv1 in one kernel
                 x = ops.feature_head(x, P[0]["weight"], P[0]["scale"], P[0]["shift"], P[1]["head"], P[1]["scale"],
@@ -139,7 +140,7 @@ class FeatureNet(nn.Module):
                     nlast = i + 1 == len(P) - 1
                     with ops.stage("feature." + p["name"] + "+" + nx["name"]):
                         x = ops.conv2d_pair(x, blocks[i - 1], p["pair"], p, nx, out_c4=(out_c4 and nlast),
-                                            out_absmax=blocks[i + 1] if not nlast else None)
+                                            out_absmax=blocks[i + 1] if not nlast else None, flag=blocks[len(P):].reshape(-1))
                     skip = i + 1
                     continue
             with ops.stage("feature." + p["name"]):
@@ -279,7 +280,7 @@ class CostRegNet(nn.Module):
         # the per-layer chain of mvs_costreg_fwd2_f32: a layer on a two-piece fp16 kernel scales its input by the absmax block the
         # layer in front of it collected (blocks of activations nobody reads that way stay None)
         f16 = ops.split_f16_enabled() and self.conv_impl == ops.IMPL_AUTO
-        blocks = ops.absmax_block(x_cl.device, zero=True, n=9) if f16 else None
+        blocks = ops.absmax_block(x_cl.device, zero=True, n=10) if f16 else None      # (row 9: the fused tail's flag word)
         blk = (lambda i: blocks[i]) if f16 else (lambda i: None)
 
         def run(name, t, skip=None, relu=True, x_abs=None, out_abs=None):
@@ -313,7 +314,7 @@ class CostRegNet(nn.Module):
             if p11.get("packed_tail") is None:
                 p11["packed_tail"] = ops.pack_costreg_tail(p11["weight"])
             with ops.stage("costreg.tail"):
-                return ops.costreg_tail_guarded(t, blk(6), c0, blk(0), p11, P["prob"])
+                return ops.costreg_tail_guarded(t, blk(6), c0, blk(0), p11, P["prob"], flag=blocks[9])
         t = run("conv11", t, c0, x_abs=blk(6))
         cost = run("prob", t, None, relu=False)     # [B,D,H,W,1]
         return cost.squeeze(-1)

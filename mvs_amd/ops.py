@@ -1215,7 +1215,7 @@ def costreg_tail(x, x_absmax, skip, skip_absmax, packed_tail, scale, shift, prob
     return out, flag
 
 
-def costreg_tail_guarded(x, x_absmax, skip, skip_absmax, p11, pprob):
+def costreg_tail_guarded(x, x_absmax, skip, skip_absmax, p11, pprob, flag=None):
     """conv11 + prob: the fused kernel with the two unfused layers enqueued behind it under its flag (no host synchronisation):
     whatever the range guard decides, the cost comes back.  p11 / pprob: the layers' parameter dicts (weight, packed, scale,
     shift; p11 with its two-piece companion and 'packed_tail')."""
@@ -1223,7 +1223,8 @@ def costreg_tail_guarded(x, x_absmax, skip, skip_absmax, p11, pprob):
     B, Di, Hi, Wi, _ = x.shape
     out = torch.empty((B, 2 * Di, 2 * Hi, 2 * Wi), device=x.device, dtype=torch.float32)
     d11 = torch.empty((B, 2 * Di, 2 * Hi, 2 * Wi, 8), device=x.device, dtype=torch.float32)     # touched only if the guard declines
-    flag = torch.zeros(1, device=x.device, dtype=torch.int32)
+    if flag is None:        # (or a zeroed word of the caller's: one fill for a whole network's blocks and flags)
+        flag = torch.zeros(1, device=x.device, dtype=torch.int32)
     layers = (_lib.ConvLayer * 2)()
     keep = []
     for i, p in enumerate((p11, pprob)):
@@ -1707,7 +1708,7 @@ def pack_conv2d_pair(w1, w2):
     return out
 
 
-def conv2d_pair(x, x_absmax, packed_pair, p1, p2, out_c4=False, out_absmax=None):
+def conv2d_pair(x, x_absmax, packed_pair, p1, p2, out_c4=False, out_absmax=None, flag=None):
     """Two consecutive 3x3 stride-1 layers (parameter dicts p1, p2 with 'packed' -- whose two-piece companions serve the unfused
     path --, 'scale', 'shift', 'relu') as one kernel; the two layers of conv_split are enqueued behind it and run only if its range
     guard declined (no host synchronisation).  x [N,H,W,C] -> [N,H,W,C] (or out_c4 [N,C/4,H,W,4])."""
@@ -1715,7 +1716,10 @@ def conv2d_pair(x, x_absmax, packed_pair, p1, p2, out_c4=False, out_absmax=None)
     N, H, W, C = x.shape
     out = torch.empty((N, C // 4, H, W, 4) if out_c4 else (N, H, W, C), device=x.device, dtype=torch.float32)
     mid = torch.empty((N, H, W, C), device=x.device, dtype=torch.float32)       # touched only if the guard declines
-    flag = torch.zeros(ABSMAX_WORDS + 64, device=x.device, dtype=torch.int32)
+    if flag is None:        # (a caller that zeroes its absmax blocks in one fill hands over ABSMAX_WORDS + 64 of those words)
+        flag = torch.zeros(ABSMAX_WORDS + 64, device=x.device, dtype=torch.int32)
+    elif flag.numel() < ABSMAX_WORDS + 64 or not flag.is_contiguous():
+        raise MvsHipError("conv2d_pair: flag = ABSMAX_WORDS + 64 zeroed contiguous int32 words")
     vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
     check(_lib.load().mvs_conv2d_pair_guarded_f16_f32(
         ptr(x), vp(x_absmax), vp(packed_pair), vp(f16_companion(p1["packed"])), vp(f16_companion(p2["packed"])),
