@@ -739,6 +739,12 @@ extern "C" int mvs_conv_split_pack_weights_f32(const float *weight, int kd, int 
 
 // np = 3: the bf16 form; np = 2: the fp16 form (in_absmax required).  out_absmax: NULL, or the absmax block the largest
 // magnitude of `out` is atomically max-ed INTO (the caller clears it: one memset serves the blocks of a whole network)
+namespace mvs {
+int launch_conv_s2_march(const float *in, const void *in_absmax, const void *packed, const float *w_iscale, const float *scale,
+                         const float *shift, int relu, int B, int D, int H, int W, float *out, void *out_absmax,
+                         unsigned long long *guard_cnt, const unsigned *run_flag, hipStream_t st);     // conv_s2_march.hip
+}
+
 static int conv_split_impl(const float *in, const void *in_absmax, const void *packed, const float *scale, const float *shift,
                            const float *residual, int relu, int kd, int stride, int B, int Cin, int Cout, int D, int H,
                            int W, int out_c4, float *out, void *out_absmax, int np, void *stream) {
@@ -748,6 +754,15 @@ static int conv_split_impl(const float *in, const void *in_absmax, const void *p
         return MVS_EINVAL;
     }
     if ((int64_t)(kd + 3) * H * W * Cin * 4 >= 0xffffff00LL) return bare_error(MVS_EUNSUPPORTED, __func__, __LINE__);   // 32-bit halo offsets: callers fall back to the fp32 kernels
+    // conv1 of the 3D U-Net (8 -> 16, stride 2) in the two-piece form: the z-marching kernel of conv_s2_march.hip on the SAME
+    // packed fragments (1.10 instead of 1.45 input voxels copied per voxel used); MVS_CONV1_MARCH=0: the per-tile kernel below
+    static const bool s2_march = !(getenv("MVS_CONV1_MARCH") && atoi(getenv("MVS_CONV1_MARCH")) == 0);
+    if (s2_march && np == 2 && kd == 3 && stride == 2 && Cin == 8 && Cout == 16 && !residual && !out_c4 && split_cout_step(kd, Cout, stride, np) == 16) {
+        const float *w_iscale = reinterpret_cast<const float *>(static_cast<const unsigned char *>(packed) + split_packed_bytes(kd, Cin, Cout, stride, 2));
+        const int rc = launch_conv_s2_march(in, in_absmax, packed, w_iscale, scale, shift, relu, B, D, H, W, out, out_absmax, guard_counter(),
+                                            conv_run_flag(), as_stream(stream));
+        if (rc != MVS_EUNSUPPORTED) return rc;
+    }
     const int step = split_cout_step(kd, Cout, stride, np), cps = split_cps(kd, Cin, stride), G = (split_ntap(kd, stride) * cps + 3) / 4;
     const size_t per_launch = (size_t)(Cin / (8 * cps)) * G * (step / 16) * np * 1024;
     hipStream_t st = as_stream(stream);
