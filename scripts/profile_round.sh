@@ -30,7 +30,7 @@ for name in ("fetch", "write"):
 json.dump(out, open(f"{root}/summary.json", "w"), indent=1)
 # per-stage HBM-side traffic for bench.py's roofline.traffic (2*FETCH + WRITE, bytes)
 names = {"costvol_variance": "variance_fwd_persist_kernel", "costreg.conv0": "conv3d_c8_f16x3_zs_kernel<32",
-         "costreg.conv1": "SplitCfg<8, 16, 3, 2", "costreg.conv2": "SplitCfg<16, 16, 3",
+         "costreg.conv1": "conv_s2_march_kernel", "feature.conv3+conv4": "conv2d_pair_kernel", "costreg.conv2": "SplitCfg<16, 16, 3",
          "costreg.conv4": "SplitCfg<32, 32, 3", "costreg.conv11": "DeconvSplitCfg<16, true",
          "costreg.prob": "conv3d_cout1_march_kernel", "costreg.tail": "costreg_tail_kernel", "softmax_regress_conf": "softmax_regress_conf_kernel",
          "feature.head": "feature_head_kernel", "feature.conv2": "SplitCfg<8, 16, 1, 2, 5"}
