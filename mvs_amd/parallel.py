@@ -119,7 +119,9 @@ class GraphedTrainStep:
             # back into the tensors backward wrote (one multi-tensor copy): the optimizer then runs the very kernels of the
             # one-graph step on the very same operands -- with the gradients as VIEWS of the flat buffer torch's multi-tensor
             # Adam took another code path (unaligned views) and the parameters drifted from the one-graph step's in the last bit
-            torch._foreach_copy_([p.grad for p in self.params], self.views)
+            pairs = [(p.grad, v) for p, v in zip(self.params, self.views) if p.grad is not None]     # (a parameter the loss does not reach has none)
+            if pairs:
+                torch._foreach_copy_([g for g, _ in pairs], [v for _, v in pairs])
         self.opt.step()
 
     def _reduce(self):
