@@ -30,6 +30,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 
+# sources compiled WITH the SLP vectoriser (v_pk_fma_f32 / v_pk_mul_f32 pairs); MVS_BUILD_SLP="a,b" overrides for experiments
+SLP_SOURCES = tuple(x for x in os.environ.get("MVS_BUILD_SLP", "").split(",") if x)
+
+
 def hipcc():
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -59,7 +63,8 @@ def build(force=False, verbose=False, tuning=False):
         src = os.path.join(CSRC, name + ".hip")
         obj = os.path.join(obj_dir, name + ".o")
         if force or _stale(obj, (src,) + HEADERS):
-            jobs.append([cc] + FLAGS + (["-DMVS_TUNING"] if tuning else []) + ["-c", src, "-o", obj])
+            flags = [f for f in FLAGS if not (f == "-fno-slp-vectorize" and name in SLP_SOURCES)]
+            jobs.append([cc] + flags + (["-DMVS_TUNING"] if tuning else []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
