@@ -593,7 +593,7 @@ int mvs_softmax_regress_bwd_f32(const float *cost, const float *depth_values, in
 
 /* ---- FeatureNet under autograd (training path, BASELINE configs[4]; MVSNet/models/mvsnet.py:8-45, train.py:222-226) ----
  * Weight gradient of a k x k, stride-s 2D convolution (3x3 stride 1 or 5x5 stride 2, up to 32 channels either side):
- * x [N,H,W,Cin] channels-last (planar: [N,Cin,H,W], the RGB layer), grad_out [N,Ho,Wo,Cout] -> grad_weight
+ * x [N,H,W,Cin] channels-last (planar: [N,Cin,H,W], the RGB layer, Cin <= 4), grad_out [N,Ho,Wo,Cout] -> grad_weight
  * (Cout,Cin,k,k).  The workspace holds one partial gradient per workgroup. */
 size_t mvs_conv2d_wgrad_workspace_bytes(int N, int Cin, int Cout, int H, int W, int ksize, int stride);
 int mvs_conv2d_wgrad_f32(const float *x, const float *grad_out, int N, int Cin, int Cout, int H, int W, int ksize,

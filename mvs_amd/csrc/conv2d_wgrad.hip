@@ -33,7 +33,7 @@ constexpr int kW2TY = 8;    // output rows per tile (16 columns)
 
 // K = kernel size, S = stride, MT / NT = 16-channel tiles of Cout / Cin (channels beyond the real count are zeros)
 template <int K, int S, int MT, int NT>
-__global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(Wgrad2dArgs a, int ntiles) {
+__global__ __launch_bounds__(256, (K == 5 && NT == 2) ? 1 : 2) void conv2d_wgrad_kernel(Wgrad2dArgs a, int ntiles) {
     constexpr int TY = kW2TY, PAD = K / 2;
     constexpr int YT = (TY - 1) * S + K, XT = 15 * S + K;
     constexpr int GP = MT * 16 + (MT == 2 ? 16 : 0);    // floats per output pixel in LDS (bank spread, see conv3d_wgrad.hip)
@@ -55,43 +55,79 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(Wgrad2dArgs a, int
             for (int n = 0; n < NT; ++n) acc[t][m][n] = (w2_f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int64_t gimg = (int64_t)a.Ho * a.Wo * a.Cout, ximg = (int64_t)a.H * a.W * a.Cin;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // The next tile's global loads are issued before this tile's K loop and wait in registers (gr / xr / xs1) while the matrix
+    // pipe works; they go to LDS between the two barriers of the next round (as conv3d_wgrad.hip).
+    constexpr int GI = (TY * 16 * MT * 4 + 255) / 256, XI = (YT * XT * NT * 4 + 255) / 256;
+    constexpr int PI = (YT * XT * 4 + 255) / 256;   // planar input (the image: Cin <= 4): one float per item, channels 0..3
+    float4 gr[GI], xr[XI];
+    float xs1[PI];
+    auto fetch = [&](int t) {
         int bid = t;
         const int tx = bid % a.tiles_x; bid /= a.tiles_x;
         const int ty = bid % a.tiles_y;
         const int n = bid / a.tiles_y;
         const int ox0 = tx * 16, oy0 = ty * TY, ix0 = ox0 * S - PAD, iy0 = oy0 * S - PAD;
-        __syncthreads();   // every wave is done with the previous tile
-        // output-gradient tile -> gl[pixel][co], zeros beyond Cout and the image (16-byte pieces: Cout % 4 == 0)
-        for (int e = tid; e < TY * 16 * MT * 4; e += 256) {
+        // output-gradient tile, zeros beyond Cout and the image (16-byte pieces: Cout % 4 == 0)
+#pragma unroll
+        for (int i = 0; i < GI; ++i) {
+            const int e = tid + i * 256;
             const int q = e % (MT * 4), v = e / (MT * 4);
             const int ox = ox0 + (v & 15), oy = oy0 + (v >> 4);
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q * 4 < a.Cout && ox < a.Wo && oy < a.Ho)
-                val = *reinterpret_cast<const float4 *>(a.g + (int64_t)n * gimg + ((int64_t)oy * a.Wo + ox) * a.Cout + q * 4);
-            *reinterpret_cast<float4 *>(gl + v * GP + q * 4) = val;
+            gr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < TY * 16 * MT * 4 && q * 4 < a.Cout && ox < a.Wo && oy < a.Ho)
+                gr[i] = *reinterpret_cast<const float4 *>(a.g + (int64_t)n * gimg + ((int64_t)oy * a.Wo + ox) * a.Cout + q * 4);
         }
-        // input halo -> xl[pixel][ci], zeros beyond Cin and the image (= the convolution's padding)
+        // input halo, zeros beyond Cin and the image (= the convolution's padding)
         if (a.planar) {
-            for (int e = tid; e < YT * XT * NT * 16; e += 256) {
+#pragma unroll
+            for (int i = 0; i < PI; ++i) {
+                const int e = tid + i * 256;
                 const int v = e % (YT * XT), ci = e / (YT * XT);      // pixel fastest: planar rows are contiguous in x
                 const int gx = ix0 + v % XT, gy = iy0 + v / XT;
-                float val = 0.f;
-                if (ci < a.Cin && (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H)
-                    val = a.x[((int64_t)n * a.Cin + ci) * a.H * a.W + (int64_t)gy * a.W + gx];
-                xl[v * XP + ci] = val;
+                xs1[i] = 0.f;
+                if (ci < 4 && ci < a.Cin && (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H)
+                    xs1[i] = a.x[((int64_t)n * a.Cin + ci) * a.H * a.W + (int64_t)gy * a.W + gx];
             }
         } else {
-            for (int e = tid; e < YT * XT * NT * 4; e += 256) {
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const int e = tid + i * 256;
                 const int q = e % (NT * 4), v = e / (NT * 4);
                 const int gx = ix0 + v % XT, gy = iy0 + v / XT;
-                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (q * 4 < a.Cin && (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H)
-                    val = *reinterpret_cast<const float4 *>(a.x + (int64_t)n * ximg + ((int64_t)gy * a.W + gx) * a.Cin + q * 4);
-                *reinterpret_cast<float4 *>(xl + v * XP + q * 4) = val;
+                xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < YT * XT * NT * 4 && q * 4 < a.Cin && (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H)
+                    xr[i] = *reinterpret_cast<const float4 *>(a.x + (int64_t)n * ximg + ((int64_t)gy * a.W + gx) * a.Cin + q * 4);
             }
         }
+    };
+    auto stash = [&]() {   // registers -> gl[pixel][co], xl[pixel][ci]
+#pragma unroll
+        for (int i = 0; i < GI; ++i) {
+            const int e = tid + i * 256;
+            if (e < TY * 16 * MT * 4) *reinterpret_cast<float4 *>(gl + (e / (MT * 4)) * GP + (e % (MT * 4)) * 4) = gr[i];
+        }
+        if (a.planar) {
+#pragma unroll
+            for (int i = 0; i < PI; ++i) {
+                const int e = tid + i * 256;
+                if (e < YT * XT * 4) xl[(e % (YT * XT)) * XP + e / (YT * XT)] = xs1[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const int e = tid + i * 256;
+                if (e < YT * XT * NT * 4) *reinterpret_cast<float4 *>(xl + (e / (NT * 4)) * XP + (e % (NT * 4)) * 4) = xr[i];
+            }
+        }
+    };
+    if (a.planar)      // columns 4 .. of a planar input are zeros for the whole kernel
+        for (int e = tid; e < YT * XT * XP; e += 256) xl[e] = 0.f;
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        __syncthreads();   // every wave is done with the previous tile
+        stash();
         __syncthreads();
+        if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
 #pragma unroll 1
         for (int row = 0; row < TY; ++row) {
 #pragma unroll
@@ -101,8 +137,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(Wgrad2dArgs a, int
                 for (int m = 0; m < MT; ++m) af[m] = gl[(row * 16 + xs * 4 + kv) * GP + m * 16 + c];
 #pragma unroll
                 for (int tt = 0; tt < TPW; ++tt) {
-                    const int tap = wv + tt * 4;          // wave-uniform
-                    if (tap >= NTAP) continue;
+                    // wave-uniform; a slot past the last tap repeats it (computed, never stored): a branch around the
+                    // MFMA made every LDS read wait for its own round trip (96 x ~130 cycles per tile instead of 96 x 32)
+                    const int tap = min(wv + tt * 4, NTAP - 1);
                     const int ky = tap / K, kx = tap % K;
                     const float *xb = xl + ((row * S + ky) * XT + (xs * 4 + kv) * S + kx) * XP + c;
 #pragma unroll
@@ -212,6 +249,10 @@ extern "C" int mvs_conv2d_wgrad_f32(const float *x, const float *grad_out, int N
     if (!x || !grad_out || !grad_weight || N <= 0 || H <= 0 || W <= 0) {
         set_error("mvs_conv2d_wgrad_f32: invalid argument");
         return MVS_EINVAL;
+    }
+    if (planar && Cin > 4) {
+        set_error("mvs_conv2d_wgrad_f32: a planar input is the image (Cin <= 4), got Cin=%d", Cin);
+        return MVS_EUNSUPPORTED;
     }
     if (!wgrad2d_shape(Cin, Cout, ksize, stride, &mt, &nt)) {
         set_error("mvs_conv2d_wgrad_f32: 3x3 stride 1 or 5x5 stride 2 with up to 32 channels, got k=%d stride=%d Cin=%d Cout=%d",

@@ -78,7 +78,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(WgradArgs a, int n
 
     if (t0 < ntiles && blockIdx.x < tstep * ncc) {
         const int64_t gplane = (int64_t)a.Ho * a.Wo * a.Cout, xplane = (int64_t)a.H * a.W * a.Cin;
-        for (int t = t0; t < ntiles; t += tstep) {
+        // A tile's global loads are issued BEFORE the previous tile's K loop and land in registers (gr / xr) while the matrix
+        // pipe works; they go to LDS between the two barriers at the top of the next round.  (Loading, waiting and computing
+        // in turn left a workgroup idle for one memory round trip per tile: 30 tiles x ~5 us of the stride-2 layers' 190 us.)
+        constexpr int QG = COUT_T / 4;      // float4 pieces per g voxel
+        constexpr int GI = (C::NOUT * QG + 255) / 256, XI = (C::NVOX * 4 + 255) / 256;
+        float4 gr[GI], xr[XI];
+        auto fetch = [&](int t) {
             int bid = t;
             const int tx = bid % a.tiles_x; bid /= a.tiles_x;
             const int ty = bid % a.tiles_y; bid /= a.tiles_y;
@@ -86,51 +92,67 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(WgradArgs a, int n
             const int b = bid / a.tiles_z;
             const int ox0 = tx * 16, oy0 = ty * C::TY, oz0 = tz * C::TZ;
             const int ix0 = ox0 * S - 1, iy0 = oy0 * S - 1, iz0 = oz0 * S - 1;
-            __syncthreads();   // every wave is done with the previous tile
-            {   // g tile: [row][x][Cout] -> gl[voxel * GP + co]; zero beyond Cout and the volume
+            {   // g tile: [row][x][Cout]; zero beyond Cout and the volume
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<float *>(a.g + ((int64_t)b * a.Do + oz0) * gplane), 0,
                     (int)(unsigned)min((int64_t)C::TZ * gplane * 4, (int64_t)0xffffff00u), 0x00020000);
-                constexpr int Q = COUT_T / 4;   // float4 pieces per voxel
-                for (int e = tid; e < C::NOUT * Q; e += 256) {
-                    const int q = e % Q, v = e / Q;
+#pragma unroll
+                for (int i = 0; i < GI; ++i) {
+                    const int e = tid + i * 256;
+                    const int q = e % QG, v = e / QG;
                     const int x = v & 15, row = v >> 4;
                     const int oz = row / C::TY, oy = oy0 + row % C::TY, ox = ox0 + x;
-                    const bool ok = oz0 + oz < a.Do && oy < a.Ho && ox < a.Wo && q * 4 < a.Cout;
+                    const bool ok = e < C::NOUT * QG && oz0 + oz < a.Do && oy < a.Ho && ox < a.Wo && q * 4 < a.Cout;
                     const unsigned off = ok ? (unsigned)(((int64_t)oz * gplane + ((int64_t)oy * a.Wo + ox) * a.Cout + q * 4) * 4)
                                             : 0xffffff00u;
-                    float4 val4;
                     if (a.Cout == 1) {   // the `prob` layer: one channel per voxel, no 16-byte pieces
-                        val4 = make_float4(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0)), 0.f, 0.f, 0.f);
+                        gr[i] = make_float4(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0)), 0.f, 0.f, 0.f);
                     } else {
                         const auto val = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
-                        val4 = make_float4(__uint_as_float(val[0]), __uint_as_float(val[1]), __uint_as_float(val[2]),
-                                           __uint_as_float(val[3]));
+                        gr[i] = make_float4(__uint_as_float(val[0]), __uint_as_float(val[1]), __uint_as_float(val[2]),
+                                            __uint_as_float(val[3]));
                     }
-                    *reinterpret_cast<float4 *>(gl + v * GP + q * 4) = val4;
                 }
             }
-            {   // x halo: channels cc*CK .. +CK of every halo voxel -> xl[voxel * XP + ci]
+            {   // x halo: channels cc*CK .. +CK of every halo voxel (16 columns per voxel, the upper ones zero if CK = 8)
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<float *>(a.x + ((int64_t)b * a.D + iz0) * xplane), 0,
                     (int)(unsigned)min((int64_t)C::ZT * xplane * 4, (int64_t)0xffffff00u), 0x00020000);
-                constexpr int Q = 4;            // 16 columns per voxel, the upper ones zero if CK = 8
-                for (int e = tid; e < C::NVOX * Q; e += 256) {
-                    const int q = e % Q, v = e / Q;
+#pragma unroll
+                for (int i = 0; i < XI; ++i) {
+                    const int e = tid + i * 256;
+                    const int q = e & 3, v = e >> 2;
                     const int lx = v % XT, t2 = v / XT, ly = t2 % YT, lz = t2 / YT;
                     const int gx = ix0 + lx, gy = iy0 + ly, gz = iz0 + lz;
-                    const bool ok = (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H &&
+                    const bool ok = e < C::NVOX * 4 && (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H &&
                                     (unsigned)gz < (unsigned)a.D && q * 4 < CK;
                     const unsigned off = ok ? (unsigned)(((int64_t)lz * xplane + ((int64_t)gy * a.W + gx) * a.Cin +
                                                           cc * CK + q * 4) * 4)
                                             : 0xffffff00u;
                     const auto val = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
-                    *reinterpret_cast<float4 *>(xl + v * XP + q * 4) =
-                        make_float4(__uint_as_float(val[0]), __uint_as_float(val[1]), __uint_as_float(val[2]),
-                                    __uint_as_float(val[3]));
+                    xr[i] = make_float4(__uint_as_float(val[0]), __uint_as_float(val[1]), __uint_as_float(val[2]),
+                                        __uint_as_float(val[3]));
                 }
             }
+        };
+        auto stash = [&]() {   // registers -> gl[voxel * GP + co], xl[voxel * XP + ci]
+#pragma unroll
+            for (int i = 0; i < GI; ++i) {
+                const int e = tid + i * 256;
+                if (e < C::NOUT * QG) *reinterpret_cast<float4 *>(gl + (e / QG) * GP + (e % QG) * 4) = gr[i];
+            }
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const int e = tid + i * 256;
+                if (e < C::NVOX * 4) *reinterpret_cast<float4 *>(xl + (e >> 2) * XP + (e & 3) * 4) = xr[i];
+            }
+        };
+        fetch(t0);
+        for (int t = t0; t < ntiles; t += tstep) {
+            __syncthreads();   // every wave is done with the previous tile
+            stash();
             __syncthreads();
+            if (t + tstep < ntiles) fetch(t + tstep);
             // ---- K loop: 4 output voxels along x per MFMA
 #pragma unroll 1
             for (int row = 0; row < C::ROWS; ++row) {
@@ -142,14 +164,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(WgradArgs a, int n
                     for (int m = 0; m < MT; ++m) af[m] = gl[(row * 16 + xs * 4 + kv) * GP + m * 16 + c];
                     const float *xb = xl + (((rz * S) * YT + ry * S) * XT + (xs * 4 + kv) * S) * XP + c;
 #pragma unroll
-                    for (int t = 0; t < TPW; ++t) {
-                        if (t >= ntap) break;                       // wave-uniform
-                        const int tap = tap0 + t;
+                    for (int t2 = 0; t2 < TPW; ++t2) {
+                        const int tap = min(tap0 + t2, 26);          // wave-uniform; the 28th slot repeats tap 26 (never stored)
                         const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
                         const float bf = xb[((kz * YT + ky) * XT + kx) * XP];
 #pragma unroll
                         for (int m = 0; m < MT; ++m)
-                            acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf, acc[t][m], 0, 0, 0);
+                            acc[t2][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf, acc[t2][m], 0, 0, 0);
                     }
                 }
             }
@@ -219,7 +240,8 @@ static int launch_wgrad(WgradArgs a, int ntiles, void *workspace, size_t workspa
     hipLaunchKernelGGL((conv3d_wgrad_kernel<COUT_T, CK, S>), dim3((unsigned)(streams * ncc)), dim3(256), 0, st,
                        a, ntiles, ncc);
     if (two_stage) {
-        const int split = streams >= 64 ? 4 : 1;
+        // thread groups per slot: 16 fill the chip (28 MT ncc blocks each) and keep a thread's chain of loads short
+        const int split = streams >= 256 ? 16 : (streams >= 64 ? 4 : 1);
         hipLaunchKernelGGL((wgrad_reduce_kernel<MT, CK>), dim3((unsigned)((ncc * PB + 255) / 256), (unsigned)split),
                            dim3(256), 0, st, a.partial, streams, ncc, a.Cin, a.Cout, a.gw);
     }
@@ -390,7 +412,7 @@ static int launch_wgrad_xanchor(WgradArgs a, int ntiles, void *workspace, hipStr
     const int nblocks = wgrad_xanchor_blocks(ntiles);
     a.partial = static_cast<float *>(workspace);
     hipLaunchKernelGGL((conv3d_wgrad_xanchor_kernel<CIN, COUT>), dim3((unsigned)nblocks), dim3(256), 0, st, a, ntiles);
-    hipLaunchKernelGGL((wgrad_xanchor_reduce_kernel<CIN, COUT>), dim3((unsigned)((C::PB + 255) / 256), 8u), dim3(256),
+    hipLaunchKernelGGL((wgrad_xanchor_reduce_kernel<CIN, COUT>), dim3((unsigned)((C::PB + 255) / 256), 32u), dim3(256),
                        0, st, a.partial, nblocks, a.gw);
     return check_launch("mvs_conv3d_wgrad_f32(x-anchored)");
 }
