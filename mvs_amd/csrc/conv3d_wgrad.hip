@@ -29,6 +29,9 @@ namespace mvs {
 
 typedef float wg_f32x4 __attribute__((ext_vector_type(4)));
 
+// num_records of a buffer resource: the bytes of the window, capped below 4 GB (the out-of-range offset the loaders use)
+__device__ __forceinline__ int rsrc_bytes(int64_t n) { return (int)(unsigned)(n < 0xffffff00LL ? n : 0xffffff00LL); }
+
 struct WgradArgs {
     const float *x, *g;
     float *gw;
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(WgradArgs a, int n
             {   // g tile: [row][x][Cout]; zero beyond Cout and the volume
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<float *>(a.g + ((int64_t)b * a.Do + oz0) * gplane), 0,
-                    (int)(unsigned)min((int64_t)C::TZ * gplane * 4, (int64_t)0xffffff00u), 0x00020000);
+                    rsrc_bytes((int64_t)C::TZ * gplane * 4), 0x00020000);
 #pragma unroll
                 for (int i = 0; i < GI; ++i) {
                     const int e = tid + i * 256;
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(WgradArgs a, int n
             {   // x halo: channels cc*CK .. +CK of every halo voxel (16 columns per voxel, the upper ones zero if CK = 8)
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<float *>(a.x + ((int64_t)b * a.D + iz0) * xplane), 0,
-                    (int)(unsigned)min((int64_t)C::ZT * xplane * 4, (int64_t)0xffffff00u), 0x00020000);
+                    rsrc_bytes((int64_t)C::ZT * xplane * 4), 0x00020000);
 #pragma unroll
                 for (int i = 0; i < XI; ++i) {
                     const int e = tid + i * 256;
@@ -218,15 +221,27 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     if (c >= CK || ci >= Cin || co >= Cout || tap >= 27) return;
     const int s0 = blockIdx.y, sstep = gridDim.y;
     const float *p = partial + (size_t)cc * PB + r;
-    float sum = 0.f;
-    for (int s = s0; s < streams; s += sstep) sum += p[(size_t)s * ncc * PB];
+    const size_t ps = (size_t)ncc * PB;
+    float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;      // four loads in flight (one chain of `streams` loads was 40 us for 60 streams)
+    int s = s0;
+    for (; s + 3 * sstep < streams; s += 4 * sstep) {
+        u0 += p[(size_t)s * ps]; u1 += p[(size_t)(s + sstep) * ps];
+        u2 += p[(size_t)(s + 2 * sstep) * ps]; u3 += p[(size_t)(s + 3 * sstep) * ps];
+    }
+    for (; s < streams; s += sstep) u0 += p[(size_t)s * ps];
+    const float sum = (u0 + u1) + (u2 + u3);
     float *dst = gw + ((int64_t)co * Cin + ci) * 27 + tap;
     if (sstep == 1) *dst += sum; else unsafeAtomicAdd(dst, sum);
 }
 
-static int wgrad_streams(int ntiles, int ncc) {
+// A stream = one workgroup's run of tiles; it ends in a partial dW of 28 MT KB that the reduce kernel reads back.  The small
+// layers have fewer tiles than the chip has workgroup slots: one tile per workgroup made the partials (55 MB for 32 -> 64
+// stride 2) cost more than the tiles, so a stream takes at least 4 stride-2 / 2 stride-1 tiles.
+static int wgrad_streams(int ntiles, int ncc, int stride) {
     int streams = (2 * device_cu_count()) / ncc;   // tile streams per ci slice
-    if (streams > ntiles) streams = ntiles;
+    const int per = stride == 2 ? 4 : 2;
+    const int few = (ntiles + per - 1) / per;
+    if (streams > few) streams = few;
     return streams < 1 ? 1 : streams;
 }
 
@@ -234,14 +249,14 @@ template <int COUT_T, int CK, int S>
 static int launch_wgrad(WgradArgs a, int ntiles, void *workspace, size_t workspace_bytes, hipStream_t st) {
     constexpr int MT = COUT_T / 16, PB = 4 * 7 * MT * 256;
     const int ncc = (a.Cin + CK - 1) / CK;
-    const int streams = wgrad_streams(ntiles, ncc);
+    const int streams = wgrad_streams(ntiles, ncc, S);
     const bool two_stage = workspace && workspace_bytes >= (size_t)streams * ncc * PB * sizeof(float);
     a.partial = two_stage ? static_cast<float *>(workspace) : nullptr;
     hipLaunchKernelGGL((conv3d_wgrad_kernel<COUT_T, CK, S>), dim3((unsigned)(streams * ncc)), dim3(256), 0, st,
                        a, ntiles, ncc);
     if (two_stage) {
         // thread groups per slot: 16 fill the chip (28 MT ncc blocks each) and keep a thread's chain of loads short
-        const int split = streams >= 256 ? 16 : (streams >= 64 ? 4 : 1);
+        const int split = streams >= 256 ? 16 : (streams >= 32 ? 8 : (streams >= 8 ? 4 : 1));
         hipLaunchKernelGGL((wgrad_reduce_kernel<MT, CK>), dim3((unsigned)((ncc * PB + 255) / 256), (unsigned)split),
                            dim3(256), 0, st, a.partial, streams, ncc, a.Cin, a.Cout, a.gw);
     }
@@ -281,9 +296,10 @@ template <int CIN, int COUT>
 __global__ __launch_bounds__(256, 2) void conv3d_wgrad_xanchor_kernel(WgradArgs a, int ntiles) {
     using C = WgradXCfg<CIN, COUT>;
     constexpr int NU = C::NU, Q = C::Q, GYT = C::GYT, GXT = C::GXT;
-    __shared__ __attribute__((aligned(16))) float lds[C::X_FLOATS + C::G_FLOATS];
-    float *xl = lds, *gl = lds + C::X_FLOATS;
-    const unsigned lds_base = (unsigned)(uintptr_t)lds;
+    // two tile buffers: the LDS-DMA of tile t + 1 runs under the K loop of tile t (one barrier per tile; loading, waiting
+    // and computing in turn left the matrix pipe idle for a memory round trip per 128-voxel tile)
+    constexpr int BUF = C::X_FLOATS + C::G_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -309,19 +325,27 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_xanchor_kernel(WgradArgs 
     for (int i = 0; i < NU; ++i) acc[i] = (wg_f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int64_t plane = (int64_t)a.H * a.W;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // Tile t + 1 is loaded into registers (xr / gr / g1) before the K loop of tile t and written to the other LDS buffer
+    // after it: one barrier per tile.  (As LDS-DMA the 8 copies per wave and tile cost ~250 cycles of issue each, a quarter
+    // of the tile's 7168 MFMA cycles; loading, waiting and computing in turn cost a memory round trip per tile on top.)
+    constexpr int XI = C::NOUT * Q / 256;       // 16-byte granules of the x tile per thread
+    constexpr int G1 = (C::GVOX + 255) / 256;   // Cout = 1: one float per halo voxel
+    constexpr int GI = COUT == 1 ? 1 : C::G_INSTR;
+    float4 xr[XI], gr[GI];
+    float g1[G1];
+    auto fetch = [&](int t) {
         int bid = t;
         const int tx = bid % a.tiles_x; bid /= a.tiles_x;
         const int ty = bid % a.tiles_y; bid /= a.tiles_y;
         const int tz = bid % a.tiles_z;
         const int b = bid / a.tiles_z;
         const int x0 = tx * 16, y0 = ty * C::TY, z0 = tz * C::TZ;
-        __syncthreads();   // every wave is done with the previous tile
         {   // x tile, no halo: slot s <- granule (v = s / Q, q = (s % Q) ^ swz(v))
-            const mvs_srd_t srd = make_srd(a.x + ((int64_t)b * a.D + z0) * plane * CIN,
-                                           (unsigned)min((int64_t)C::TZ * plane * CIN * 4, (int64_t)0xffffff00u));
+            const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float *>(a.x + ((int64_t)b * a.D + z0) * plane * CIN), 0,
+                rsrc_bytes((int64_t)C::TZ * plane * CIN * 4), 0x00020000);
 #pragma unroll
-            for (int it = 0; it < C::NOUT * Q / 256; ++it) {
+            for (int it = 0; it < XI; ++it) {
                 const int s = (it * 4 + wv) * 64 + lane;
                 const int v = s / Q, q = (s % Q) ^ (CIN == 32 ? ((v >> 1) & 1) * 4 : 0);
                 const int x = v & 15, row = v >> 4, rz = row / C::TY, ry = row % C::TY;
@@ -329,26 +353,32 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_xanchor_kernel(WgradArgs 
                 const unsigned off = !ok ? 0xffffff00u
                     : a.x_c8 ? (unsigned)(((((int64_t)rz * a.H + (y0 + ry)) * (CIN / 8) + (q >> 1)) * a.W + x0 + x) * 32 + (q & 1) * 16)
                              : (unsigned)(((rz * plane + (int64_t)(y0 + ry) * a.W + x0 + x) * CIN + q * 4) * 4);
-                glds16_buf(off, srd, 0u, lds_base + (unsigned)((it * 4 + wv) * 1024));
+                const auto val = __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0);
+                xr[it] = make_float4(__uint_as_float(val[0]), __uint_as_float(val[1]), __uint_as_float(val[2]),
+                                     __uint_as_float(val[3]));
             }
         }
         if (COUT == 1) {   // g halo, one float per voxel
             const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float *>(a.g + ((int64_t)b * a.D + z0 - 1) * plane), 0,
-                (int)(unsigned)min((int64_t)C::GZT * plane * 4, (int64_t)0xffffff00u), 0x00020000);
-            for (int e = tid; e < C::GVOX; e += 256) {
+                rsrc_bytes((int64_t)C::GZT * plane * 4), 0x00020000);
+#pragma unroll
+            for (int i = 0; i < G1; ++i) {
+                const int e = tid + i * 256;
                 const int lx = e % GXT, t2 = e / GXT, ly = t2 % GYT, lz = t2 / GYT;
                 const int gx = x0 - 1 + lx, gy = y0 - 1 + ly, gz = z0 - 1 + lz;
-                const bool ok = (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H && (unsigned)gz < (unsigned)a.D;
+                const bool ok = e < C::GVOX && (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H &&
+                                (unsigned)gz < (unsigned)a.D;
                 const unsigned off = ok ? (unsigned)((lz * plane + (int64_t)gy * a.W + gx) * 4) : 0xffffff00u;
-                gl[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsg, off, 0, 0));
+                g1[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsg, off, 0, 0));
             }
-        } else {           // g halo: [halo voxel][Cout], 16-byte granules by DMA
+        } else {           // g halo: [halo voxel][Cout], 16-byte granules
             constexpr int GQ = COUT / 4;
-            const mvs_srd_t srd = make_srd(a.g + ((int64_t)b * a.D + z0 - 1) * plane * COUT,
-                                           (unsigned)min((int64_t)C::GZT * plane * COUT * 4, (int64_t)0xffffff00u));
+            const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float *>(a.g + ((int64_t)b * a.D + z0 - 1) * plane * COUT), 0,
+                rsrc_bytes((int64_t)C::GZT * plane * COUT * 4), 0x00020000);
 #pragma unroll
-            for (int it = 0; it < C::G_INSTR; ++it) {
+            for (int it = 0; it < GI; ++it) {
                 const int s = (it * 4 + wv) * 64 + lane;
                 const int hv = s / GQ, q = s % GQ;
                 const int lx = hv % GXT, t2 = hv / GXT, ly = t2 % GYT, lz = t2 / GYT;
@@ -356,11 +386,35 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_xanchor_kernel(WgradArgs 
                 const bool ok = hv < C::GVOX && (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H &&
                                 (unsigned)gz < (unsigned)a.D;
                 const unsigned off = ok ? (unsigned)(((lz * plane + (int64_t)gy * a.W + gx) * COUT + q * 4) * 4) : 0xffffff00u;
-                glds16_buf(off, srd, 0u, lds_base + (unsigned)(C::X_FLOATS * 4 + (it * 4 + wv) * 1024));
+                const auto val = __builtin_amdgcn_raw_buffer_load_b128(rsg, off, 0, 0);
+                gr[it] = make_float4(__uint_as_float(val[0]), __uint_as_float(val[1]), __uint_as_float(val[2]),
+                                     __uint_as_float(val[3]));
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+    };
+    auto stash = [&](int buf) {   // registers -> LDS, slot order (the layouts the LDS-DMA form wrote)
+        float *xb = lds + buf * BUF, *gb = xb + C::X_FLOATS;
+#pragma unroll
+        for (int it = 0; it < XI; ++it) *reinterpret_cast<float4 *>(xb + ((it * 4 + wv) * 64 + lane) * 4) = xr[it];
+        if (COUT == 1) {
+#pragma unroll
+            for (int i = 0; i < G1; ++i)
+                if (tid + i * 256 < C::GVOX) gb[tid + i * 256] = g1[i];
+        } else {
+#pragma unroll
+            for (int it = 0; it < GI; ++it) *reinterpret_cast<float4 *>(gb + ((it * 4 + wv) * 64 + lane) * 4) = gr[it];
+        }
+    };
+    if ((int)blockIdx.x < ntiles) {
+        fetch(blockIdx.x);
+        stash(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x, buf ^= 1) {
+        const float *xl = lds + buf * BUF, *gl = xl + C::X_FLOATS;
+        const bool more = t + (int)gridDim.x < ntiles;
+        if (more) fetch(t + gridDim.x);
         // ---- K loop over this wave's rows: 4 input voxels along x per MFMA
         constexpr int RPW = C::ROWS / C::NRS;
 #pragma unroll 1
@@ -375,6 +429,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_xanchor_kernel(WgradArgs 
                     acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(gb[aoff[i]], bf, acc[i], 0, 0, 0);
             }
         }
+        if (more) stash(buf ^ 1);   // the other buffer was last read in round t - 1: every wave passed that round's barrier
+        __syncthreads();
     }
     float *dst = a.partial + ((size_t)blockIdx.x * 4 + wv) * (NU * 256) + lane;
 #pragma unroll
@@ -394,7 +450,15 @@ __global__ __launch_bounds__(256) void wgrad_xanchor_reduce_kernel(const float *
     const int m = (lane >> 4) * 4 + j, tap = p * C::TPM + m / COUT, co = m % COUT, ci = nt * 16 + (lane & 15);
     if (tap >= 27 || ci >= CIN) return;
     float sum = 0.f;
-    for (int s = blockIdx.y; s < nblocks; s += gridDim.y) sum += partial[(size_t)s * C::PB + r];
+    float u1 = 0.f, u2 = 0.f, u3 = 0.f;
+    int s = blockIdx.y;
+    const int ss = gridDim.y;
+    for (; s + 3 * ss < nblocks; s += 4 * ss) {
+        sum += partial[(size_t)s * C::PB + r]; u1 += partial[(size_t)(s + ss) * C::PB + r];
+        u2 += partial[(size_t)(s + 2 * ss) * C::PB + r]; u3 += partial[(size_t)(s + 3 * ss) * C::PB + r];
+    }
+    for (; s < nblocks; s += ss) sum += partial[(size_t)s * C::PB + r];
+    sum = (sum + u1) + (u2 + u3);
     unsafeAtomicAdd(gw + ((int64_t)co * CIN + ci) * 27 + tap, sum);
 }
 
@@ -445,7 +509,7 @@ extern "C" size_t mvs_conv3d_wgrad_workspace_bytes(int B, int Cin, int Cout, int
     if (wgrad_xanchor_shape(Cin, Cout, stride)) return wgrad_xanchor_bytes(Cout, (int)nt);
     const int ck = Cin >= 16 ? 16 : 8, ncc = (Cin + ck - 1) / ck;
     const int mt = Cout <= 16 ? 1 : (Cout <= 32 ? 2 : 4);
-    return (size_t)wgrad_streams((int)nt, ncc) * ncc * (4 * 7 * mt * 256) * sizeof(float);
+    return (size_t)wgrad_streams((int)nt, ncc, stride) * ncc * (4 * 7 * mt * 256) * sizeof(float);
 }
 
 static int conv3d_wgrad_impl(const float *in, const float *grad_out, int B, int Cin, int Cout, int D, int H, int W, int stride,

@@ -203,6 +203,58 @@ extern "C" int mvs_softmax_regress_conf_f32(const float *cost, const float *dept
     return check_launch("mvs_softmax_regress_conf_f32");
 }
 
+// The same gradient with the depth axis split over the block: 64 pixels x 4 depth slices (d = s, s + 4, ...) per block, the
+// slice's costs held in registers (one pass over the volume instead of four), maximum / sum / expected depth joined through
+// LDS.  One thread per pixel was 20480 threads walking 4 x 192 dependent loads for the training step's 128 x 160 map: 0.15 ms
+// for 32 MB of traffic.  D <= 4 * kBwdRegs; the sums differ from the one-thread form's in summation order only.
+constexpr int kBwdRegs = 64;
+__global__ __launch_bounds__(256) void softmax_regress_bwd_sliced_kernel(
+    const float *__restrict__ cost, const float *__restrict__ depth, int depth_mode,
+    const float *__restrict__ gdepth, int B, int D, int64_t plane, float *__restrict__ gcost) {
+    __shared__ float red[3][4][64];
+    const int px = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + px;
+    const bool live = i < (int64_t)B * plane;
+    const int b = live ? (int)(i / plane) : 0;
+    const int64_t pix = live ? i % plane : 0;
+    const float *c = cost + (int64_t)b * D * plane + pix;
+    const float *dv = depth_mode == 0 ? depth + (int64_t)b * D : depth + (int64_t)b * D * plane + pix;
+    const int64_t dstride = depth_mode == 0 ? 1 : plane;
+    float v[kBwdRegs];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < kBwdRegs; ++k) {
+        const int d = sl + 4 * k;
+        v[k] = (live && d < D) ? c[(int64_t)d * plane] : -INFINITY;
+        m = fmaxf(m, v[k]);
+    }
+    red[0][sl][px] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0][0][px], red[0][1][px]), fmaxf(red[0][2][px], red[0][3][px]));
+    float sum = 0.0f, wd = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kBwdRegs; ++k) {
+        const int d = sl + 4 * k;
+        if (live && d < D) {
+            v[k] = expf(v[k] - m);
+            sum += v[k];
+            wd += v[k] * dv[(int64_t)d * dstride];
+        }
+    }
+    red[1][sl][px] = sum; red[2][sl][px] = wd;
+    __syncthreads();
+    sum = (red[1][0][px] + red[1][1][px]) + (red[1][2][px] + red[1][3][px]);
+    wd = (red[2][0][px] + red[2][1][px]) + (red[2][2][px] + red[2][3][px]);
+    if (!live) return;
+    const float dep = wd / sum, g = gdepth[i];
+    float *gc = gcost + (int64_t)b * D * plane + pix;
+#pragma unroll
+    for (int k = 0; k < kBwdRegs; ++k) {
+        const int d = sl + 4 * k;
+        if (d < D) gc[(int64_t)d * plane] = g * (v[k] / sum) * (dv[(int64_t)d * dstride] - dep);
+    }
+}
+
 extern "C" int mvs_softmax_regress_bwd_f32(const float *cost, const float *depth_values,
                                            int depth_mode, const float *grad_depth, int B, int D,
                                            int H, int W, float *grad_cost, void *stream) {
@@ -213,6 +265,11 @@ extern "C" int mvs_softmax_regress_bwd_f32(const float *cost, const float *depth
     }
     const int64_t plane = (int64_t)H * W;
     const int64_t n = (int64_t)B * plane;
+    if (D <= 4 * kBwdRegs) {
+        hipLaunchKernelGGL(softmax_regress_bwd_sliced_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, as_stream(stream),
+                           cost, depth_values, depth_mode, grad_depth, B, D, plane, grad_cost);
+        return check_launch("mvs_softmax_regress_bwd_f32");
+    }
     unsigned grid = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(softmax_regress_bwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream),
                        cost, depth_values, depth_mode, grad_depth, B, D, plane, grad_cost);

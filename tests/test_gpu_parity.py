@@ -844,20 +844,28 @@ def test_regress_per_pixel_and_clamp_golden(dev):
     np.testing.assert_allclose(depth.cpu().numpy(), g["regressed"], atol=2e-4)
 
 
-def test_regress_backward_vs_torch(dev):
+@pytest.mark.parametrize("D,shape,per_pixel", [(16, (6, 10), False), (37, (9, 15), False), (192, (16, 20), False),
+                                               (48, (7, 13), True), (300, (3, 5), False)])
+def test_regress_backward_vs_torch(dev, D, shape, per_pixel):
+    """grad_cost of the soft-argmin against torch autograd: the depth-sliced kernel (D <= 256; ragged pixel blocks, depth
+    counts that are no multiple of the 4 slices, per-pixel hypotheses) and the one-thread-per-pixel form beyond it."""
     from mvs_amd import ops
-    rng = np.random.default_rng(3)
-    cost = rng.standard_normal((2, 16, 6, 10)).astype(np.float32) * 2
+    rng = np.random.default_rng(3 + D)
+    H, W = shape
+    cost = rng.standard_normal((2, D, H, W)).astype(np.float32) * 2
     from mvs_amd import synth
-    dv = synth.depth_values(16, batch=2, interval=synth.sweep_interval(16))
+    dv = synth.depth_values(D, batch=2, interval=synth.sweep_interval(D))
+    if per_pixel:
+        dv = (dv[:, :, None, None] + rng.uniform(-1, 1, (2, D, H, W))).astype(np.float32)
     c = G(cost, dev).requires_grad_(True)
     depth, _, _ = ops.softmax_regress_conf(c, G(dv, dev))
-    gd = rng.standard_normal((2, 6, 10)).astype(np.float32)
+    gd = rng.standard_normal((2, H, W)).astype(np.float32)
     depth.backward(G(gd, dev))
     ct = torch.from_numpy(cost).requires_grad_(True)
-    want = (torch.softmax(ct, 1) * torch.from_numpy(dv).view(2, 16, 1, 1)).sum(1)
+    dvt = torch.from_numpy(dv) if per_pixel else torch.from_numpy(dv).view(2, D, 1, 1)
+    want = (torch.softmax(ct, 1) * dvt).sum(1)
     want.backward(torch.from_numpy(gd))
-    np.testing.assert_allclose(c.grad.cpu().numpy(), ct.grad.numpy(), atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(c.grad.cpu().numpy(), ct.grad.numpy(), atol=2e-4 * max(1.0, float(ct.grad.abs().max())), rtol=1e-4)
 
 
 # ----------------------------------------------------------- end to end
