@@ -45,7 +45,9 @@ struct WgradArgs {
 
 template <int COUT_T, int CK, int S>
 struct WgradCfg {
-    static constexpr int TZ = (S == 1) ? 2 : 1, TY = (S == 1) ? 4 : 2;
+    // (8-channel slices at stride 2 -- conv1 and the last decoder layer, full-resolution inputs -- take 4 rows: their x halo is
+    // 32 bytes a voxel, and 32-voxel tiles were mostly per-tile overhead)
+    static constexpr int TZ = (S == 1) ? 2 : 1, TY = (S == 1 || CK == 8) ? 4 : 2;
     static constexpr int ROWS = TZ * TY, NOUT = ROWS * 16;
     static constexpr int XT = 15 * S + 3, YT = (TY - 1) * S + 3, ZT = (TZ - 1) * S + 3;
     static constexpr int NVOX = ZT * YT * XT;
@@ -53,8 +55,11 @@ struct WgradCfg {
     // voxel strides (floats) chosen so the two 16-lane runs of a ds_read_b32 half-wave land
     // on different banks: consecutive voxels of a fragment are GP apart in g, S*XP in x
     static constexpr int GP = (COUT_T % 32 == 0) ? COUT_T + 16 : COUT_T;
-    static constexpr int XP = (S == 1) ? 16 : 24;
-    static constexpr int LDS_FLOATS = NOUT * GP + NVOX * XP;
+    // CK = 8: 8 floats per voxel, lanes 8..15 of a B fragment read the next voxel's channels -- columns of the product nothing
+    // stores (a 4-voxel fragment is then 64 consecutive floats at stride 2)
+    static constexpr int QX = CK / 4;                     // 16-byte pieces per x voxel
+    static constexpr int XP = CK == 8 ? 8 : ((S == 1) ? 16 : 24);
+    static constexpr int LDS_FLOATS = NOUT * GP + NVOX * XP + 8;   // (+8: the last voxel's lanes 8..15 at CK = 8)
     static constexpr int TAPS_PER_WAVE = 7;
 };
 
@@ -85,7 +90,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(WgradArgs a, int n
         // pipe works; they go to LDS between the two barriers at the top of the next round.  (Loading, waiting and computing
         // in turn left a workgroup idle for one memory round trip per tile: 30 tiles x ~5 us of the stride-2 layers' 190 us.)
         constexpr int QG = COUT_T / 4;      // float4 pieces per g voxel
-        constexpr int GI = (C::NOUT * QG + 255) / 256, XI = (C::NVOX * 4 + 255) / 256;
+        constexpr int QX = C::QX;
+        constexpr int GI = (C::NOUT * QG + 255) / 256, XI = (C::NVOX * QX + 255) / 256;
         float4 gr[GI], xr[XI];
         auto fetch = [&](int t) {
             int bid = t;
@@ -117,18 +123,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(WgradArgs a, int n
                     }
                 }
             }
-            {   // x halo: channels cc*CK .. +CK of every halo voxel (16 columns per voxel, the upper ones zero if CK = 8)
+            {   // x halo: channels cc*CK .. +CK of every halo voxel
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<float *>(a.x + ((int64_t)b * a.D + iz0) * xplane), 0,
                     rsrc_bytes((int64_t)C::ZT * xplane * 4), 0x00020000);
 #pragma unroll
                 for (int i = 0; i < XI; ++i) {
                     const int e = tid + i * 256;
-                    const int q = e & 3, v = e >> 2;
+                    const int q = e % QX, v = e / QX;
                     const int lx = v % XT, t2 = v / XT, ly = t2 % YT, lz = t2 / YT;
                     const int gx = ix0 + lx, gy = iy0 + ly, gz = iz0 + lz;
-                    const bool ok = e < C::NVOX * 4 && (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H &&
-                                    (unsigned)gz < (unsigned)a.D && q * 4 < CK;
+                    const bool ok = e < C::NVOX * QX && (unsigned)gx < (unsigned)a.W && (unsigned)gy < (unsigned)a.H &&
+                                    (unsigned)gz < (unsigned)a.D;
                     const unsigned off = ok ? (unsigned)(((int64_t)lz * xplane + ((int64_t)gy * a.W + gx) * a.Cin +
                                                           cc * CK + q * 4) * 4)
                                             : 0xffffff00u;
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(WgradArgs a, int n
 #pragma unroll
             for (int i = 0; i < XI; ++i) {
                 const int e = tid + i * 256;
-                if (e < C::NVOX * 4) *reinterpret_cast<float4 *>(xl + (e >> 2) * XP + (e & 3) * 4) = xr[i];
+                if (e < C::NVOX * QX) *reinterpret_cast<float4 *>(xl + (e / QX) * XP + (e % QX) * 4) = xr[i];
             }
         };
         fetch(t0);
@@ -494,7 +500,7 @@ extern "C" int mvs_conv3d_wgrad_supported(int Cin, int Cout, int stride) {
 static bool wgrad_geometry(int B, int Cin, int Cout, int D, int H, int W, int stride, WgradArgs &a, int64_t &nt) {
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
     a.Do = (D - 1) / stride + 1; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;
-    const int tz = stride == 1 ? 2 : 1, ty = stride == 1 ? 4 : 2;
+    const int tz = stride == 1 ? 2 : 1, ty = (stride == 1 || Cin < 16) ? 4 : 2;     // WgradCfg::TZ, TY (CK = 8 for Cin < 16)
     a.tiles_x = (a.Wo + 15) / 16; a.tiles_y = (a.Ho + ty - 1) / ty; a.tiles_z = (a.Do + tz - 1) / tz;
     nt = (int64_t)B * a.tiles_x * a.tiles_y * a.tiles_z;
     return nt > 0 && nt <= 0x7fffffffLL && (int64_t)9 * H * W * Cin * 4 < 0xffffff00LL;
