@@ -421,6 +421,17 @@ int mvs_conv3d_wgrad_f32(const float *in, const float *grad_out, int B, int Cin,
  * split-operand bf16 kernel and takes its weight gradient from the same tensor. */
 int mvs_conv3d_wgrad_c8_f32(const float *in_c8, const float *grad_out, int B, int Cin, int D, int H, int W,
                             float *grad_weight, void *workspace, size_t workspace_bytes, void *stream);
+/* conv0's weight gradient (Cin = 32, Cout = 8, 3x3x3, stride 1) on the 16-bit matrix pipe with two-piece fp16 operands
+ * (mvs_amd/csrc/conv3d_wgrad_f16.hip; MVSNet/models/mvsnet.py:52 under autograd, train.py:222-226): the same sum as
+ * mvs_conv3d_wgrad_c8_f32, products within 2^-22 relative of the fp32 products for operands within 2^-18 of their tensor's largest
+ * magnitude.  in_absmax / grad_absmax: the MVS_ABSMAX_WORDS-word absmax blocks of in_c8 and grad_out (the sweep kernel's and
+ * mvs_absmax_f32's outputs).  grad_weight (8,32,3,3,3) is ACCUMULATED into.  workspace: mvs_conv3d_wgrad_c8_f16_workspace_bytes.
+ * mvs_conv3d_wgrad_c8_f16_supported: 1 if the shape has this kernel (Cin = 32, volume below 4 GB). */
+int mvs_conv3d_wgrad_c8_f16_supported(int B, int Cin, int D, int H, int W);
+size_t mvs_conv3d_wgrad_c8_f16_workspace_bytes(int B, int Cin, int D, int H, int W);
+int mvs_conv3d_wgrad_c8_f16_f32(const float *in_c8, const unsigned *in_absmax, const float *grad_out, const unsigned *grad_absmax,
+                                int B, int Cin, int D, int H, int W, float *grad_weight, void *workspace, size_t workspace_bytes,
+                                void *stream);
 size_t mvs_conv3d_wgrad_workspace_bytes(int B, int Cin, int Cout, int D, int H, int W, int stride);
 int mvs_conv3d_wgrad_supported(int Cin, int Cout, int stride);
 

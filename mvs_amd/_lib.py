@@ -87,6 +87,9 @@ _SIGS = {
     "mvs_conv3d_wgrad_f32": (_c_i, [_c_f, _c_f] + [_c_i] * 7 + [_c_f, _c_f, ctypes.c_size_t, _c_f]),
     "mvs_conv3d_wgrad_workspace_bytes": (ctypes.c_size_t, [_c_i] * 7),
     "mvs_conv3d_wgrad_c8_f32": (_c_i, [_c_f, _c_f] + [_c_i] * 5 + [_c_f, _c_f, ctypes.c_size_t, _c_f]),
+    "mvs_conv3d_wgrad_c8_f16_supported": (_c_i, [_c_i] * 5),
+    "mvs_conv3d_wgrad_c8_f16_workspace_bytes": (ctypes.c_size_t, [_c_i] * 5),
+    "mvs_conv3d_wgrad_c8_f16_f32": (_c_i, [_c_f] * 4 + [_c_i] * 5 + [_c_f, _c_f, ctypes.c_size_t, _c_f]),
     "mvs_conv2d_wgrad_f32": (_c_i, [_c_f, _c_f] + [_c_i] * 8 + [_c_f, _c_f, ctypes.c_size_t, _c_f]),
     "mvs_conv2d_wgrad_workspace_bytes": (ctypes.c_size_t, [_c_i] * 7),
     "mvs_interleave2x2_f32": (_c_i, [_c_f] + [_c_i] * 4 + [_c_f, _c_f]),

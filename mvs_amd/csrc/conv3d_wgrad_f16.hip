@@ -1,0 +1,277 @@
+// Weight gradient of conv0 (32 -> 8, 3x3x3, stride 1; MVSNet/models/mvsnet.py:52 under autograd, train.py:222-226) on the
+// 16-bit matrix pipe with the two-piece fp16 operands of the forward kernels (conv_f16x3.hip has the arithmetic and its
+// error bound):
+//
+//   dW[co][ci][kz,ky,kx] = sum over input voxels v of  g[v - (k - 1)][co] * x[v][ci]
+//
+// x = the variance volume, 8-channel blocked [B,D,H,Cin/8,W,8] as conv0's forward reads it, g = the gradient of conv0's raw
+// output [B,D,H,W,8].  On the fp32 matrix pipe (conv3d_wgrad_xanchor_kernel) this layer is 27.5 M v_mfma_f32_16x16x4_f32 per
+// step = 0.36 ms at the pipe's peak and 0.52-0.56 ms measured, the largest weight gradient of a training step by 3x.
+// v_mfma_f32_16x16x32_f16 carries 8x the voxels per instruction at half the cycles; with three products per fp32 product
+// (hi*hi + hi*lo + lo*hi of x * 2^(14-ex) = hi + lo, g likewise) that is 5.3x the rate.
+//
+// The reduction dimension of the MFMA is 32 consecutive voxels along x, and BOTH operands want 8 consecutive voxels of one
+// channel per lane -- the transpose of how either tensor lies in memory.  No LDS: a lane loads its 8 voxels as 8 dwords, 32
+// bytes apart, straight from HBM/L2 (the 8 loads of a lane walk the same cache lines, the 16 lanes of a row cover the 32-byte
+// channel groups), splits them in registers and feeds the pipe:
+//   A (M = 16 input channels, two tiles): x[z][y][x0 + 8 kq + i][ci],            i = 0..7
+//   B (N = 2 tap rows x 8 output channels): g[z - dz_h][y - dy_h][x0 + 8 kq + i - dx][co]
+// The nine (dz, dy) rows of the 27 taps pair up into five N tiles; the three x shifts of a row pair come from ONE set of ten
+// loads per lane (elements -1..8): dx = 0 packs the pairs (0,1)(2,3)(4,5)(6,7), dx = +1 the pairs (-1,0)(1,2)(3,4)(5,6) and
+// dx = -1 (1,2)(3,4)(5,6)(7,8), so a chunk of 32 voxels costs 66 dword loads and 53 pair splits for its 90 MFMAs.  A wave
+// owns all 2 x 15 accumulator tiles (120 registers = the whole weight gradient) and a stream of (row, 32-voxel segment)
+// chunks; it stores them once, the reduce kernel sums the waves and undoes the two scales.
+//
+// Arithmetic: products are within 2^-22 relative of the fp32 products for operands within 2^-18 of their tensor's largest
+// magnitude and within 2^-40 of (max |x| max |g|) absolute below that (an element far below its tensor's maximum loses
+// relative precision, as in the forward layers); accumulation is fp32 as before.  Non-finite inputs give non-finite
+// gradients, as the fp32 kernel does.  There is no range guard on this path: it is taken by the training node only
+// (ops._VarianceConv0), MVS_WGRAD_F16=0 keeps the fp32 kernel.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mvs_common.h"
+#include "conv_split_common.h"
+
+namespace mvs {
+
+struct WgradF16Args {
+    const float *x, *g;
+    const unsigned *x_absmax, *g_absmax;
+    float *partial;          // [wave][mt][tile][j][lane]
+    float *gw;
+    int B, D, H, W;
+    int nseg;                // 32-voxel segments per row
+    int nchunks;             // B * D * H * nseg
+    int nwaves;
+};
+
+constexpr int kWFTiles = 15;                       // 5 row pairs x 3 x-shifts
+constexpr int kWFSlots = 2 * kWFTiles * 256;       // floats of one wave's partial
+
+// (a * s, b * s) -> hi = fp16 pair (round to nearest even), lo = fp16 pair of the residuals
+__device__ __forceinline__ void split_pair(float a, float b, float s, unsigned &h, unsigned &l) {
+    asm volatile(
+        "v_fma_mixlo_f16 %2, %0, %4, 0\n\t"
+        "v_fma_mixhi_f16 %2, %1, %4, 0\n\t"
+        "v_fma_mix_f32 %0, %0, %4, -%2 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %1, %1, %4, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_cvt_pk_f16_f32 %3, %0, %1"
+        : "+v"(a), "+v"(b), "=&v"(h), "=&v"(l)
+        : "s"(s));
+}
+
+__device__ __forceinline__ f16x8 frag(unsigned a, unsigned b, unsigned c, unsigned d) {
+    return __builtin_bit_cast(f16x8, (u32x4){a, b, c, d});
+}
+
+__device__ __forceinline__ int wf_rsrc_bytes(int64_t n) { return (int)(unsigned)(n < 0xffffff00LL ? n : 0xffffff00LL); }
+
+// FULLW: W is a multiple of 32 (no element of a segment lies beyond the row)
+template <bool FULLW>
+__global__ __launch_bounds__(256, 2) void conv3d_wgrad_c8_f16_kernel(WgradF16Args a) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 15, kq = lane >> 4;
+    const int h = n >> 3, co = n & 7;
+    const float sx = pow2f(14 - absmax_exponent(load_absmax(a.x_absmax)));
+    const float sg = pow2f(14 - absmax_exponent(load_absmax(a.g_absmax)));
+
+    f32x4 acc[2][kWFTiles];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int t = 0; t < kWFTiles; ++t) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int64_t vox = (int64_t)a.B * a.D * a.H * a.W;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, wf_rsrc_bytes(vox * 128), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.g), 0, wf_rsrc_bytes(vox * 32), 0x00020000);
+    constexpr unsigned OOB = 0xffffff00u;
+    const int gwave = blockIdx.x * 4 + wv;
+
+    // chunk c = ((b D + z) H + y) nseg + seg, c = gwave, gwave + nwaves, ...: the four coordinates advance by the digits of
+    // nwaves with carries (four integer divisions per chunk were a third of the loop's vector instructions)
+    int seg, y, z, b;
+    {
+        int r = gwave;
+        seg = r % a.nseg; r /= a.nseg;
+        y = r % a.H; r /= a.H;
+        z = r % a.D;
+        b = r / a.D;
+    }
+    int sseg, sy, sz, sb;
+    {
+        int r = a.nwaves;
+        sseg = r % a.nseg; r /= a.nseg;
+        sy = r % a.H; r /= a.H;
+        sz = r % a.D;
+        sb = r / a.D;
+    }
+    const int niter = gwave < a.nchunks ? (a.nchunks - gwave + a.nwaves - 1) / a.nwaves : 0;
+#pragma unroll 1
+    for (int it = 0; it < niter; ++it) {
+        if (it) {
+            seg += sseg; int cy = 0;
+            if (seg >= a.nseg) { seg -= a.nseg; cy = 1; }
+            y += sy + cy; cy = 0;
+            if (y >= a.H) { y -= a.H; cy = 1; }
+            z += sz + cy; cy = 0;
+            if (z >= a.D) { z -= a.D; cy = 1; }
+            b += sb + cy;
+        }
+        const int xb = seg * 32 + kq * 8;          // this lane's first voxel
+        const int lim = a.W - xb;                  // elements e < lim are inside the row
+
+        // ---- x: 2 tiles x 8 voxels of channel mt * 16 + n; blocked layout [row][Cin/8][W][8]
+        float xv[2][8];
+        {
+            const int64_t row = ((int64_t)b * a.D + z) * a.H + y;
+            const unsigned base = (unsigned)((((row * 4 + (n >> 3)) * a.W + xb) * 8 + (n & 7)) * 4);
+            const unsigned off = lim > 0 ? base : OOB;
+            const int tile = a.W * 64;             // bytes from channel group g to g + 2
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    xv[mt][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, off + i * 32, mt * tile, 0));
+                    if (!FULLW && i >= lim) xv[mt][i] = 0.f;
+                }
+        }
+        // ---- g: per row pair, elements -1 .. 8 of output channel co in tap row 2 p + h
+        auto load_pair = [&](int p, float (&gv)[10]) {
+            const int rr = 2 * p + h;              // tap row (kz, ky); the tenth does not exist
+            const int kz = rr / 3, ky = rr - 3 * kz;
+            const int gz = z - (kz - 1), gy = y - (ky - 1);
+            const bool rowok = rr < 9 && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && lim > 0;
+            const int64_t row = ((int64_t)b * a.D + gz) * a.H + gy;
+            const unsigned base = (unsigned)(((row * a.W + xb) * 8 + co) * 4);
+            const unsigned off = rowok ? base : OOB;
+            gv[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, (rowok && xb > 0) ? base - 32u : OOB, 0, 0));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                gv[1 + i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, off + i * 32, 0, 0));
+                if (!FULLW && i >= lim) gv[1 + i] = 0.f;
+            }
+            gv[9] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, (rowok && 8 < lim) ? base + 256u : OOB, 0, 0));
+        };
+        float gcur[10], gnext[10];
+        load_pair(0, gcur);
+
+        f16x8 Ah[2], Al[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            unsigned hh[4], ll[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split_pair(xv[mt][2 * j], xv[mt][2 * j + 1], sx, hh[j], ll[j]);
+            Ah[mt] = frag(hh[0], hh[1], hh[2], hh[3]);
+            Al[mt] = frag(ll[0], ll[1], ll[2], ll[3]);
+        }
+#pragma unroll
+        for (int p = 0; p < 5; ++p) {
+            if (p < 4) load_pair(p + 1, gnext);
+            // even pairs (0,1)(2,3)(4,5)(6,7) of elements 0..7 = gcur[1..8]; odd pairs (-1,0)(1,2)(3,4)(5,6)(7,8)
+            unsigned eh[4], el[4], oh[5], ol[5];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split_pair(gcur[1 + 2 * j], gcur[2 + 2 * j], sg, eh[j], el[j]);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) split_pair(gcur[2 * j], gcur[2 * j + 1], sg, oh[j], ol[j]);
+            // x-shift index 0: kx = 0, g at x + 1 (elements 1..8); 1: kx = 1 (0..7); 2: kx = 2, g at x - 1 (-1..6)
+            const f16x8 Bh[3] = {frag(oh[1], oh[2], oh[3], oh[4]), frag(eh[0], eh[1], eh[2], eh[3]), frag(oh[0], oh[1], oh[2], oh[3])};
+            const f16x8 Bl[3] = {frag(ol[1], ol[2], ol[3], ol[4]), frag(el[0], el[1], el[2], el[3]), frag(ol[0], ol[1], ol[2], ol[3])};
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    f32x4 cc = acc[mt][p * 3 + s];
+                    cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[mt], Bl[s], cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[mt], Bh[s], cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[mt], Bh[s], cc, 0, 0, 0);
+                    acc[mt][p * 3 + s] = cc;
+                }
+            if (p < 4) {
+#pragma unroll
+                for (int i = 0; i < 10; ++i) gcur[i] = gnext[i];
+            }
+        }
+    }
+    // ---- this wave's partial, accumulator order (coalesced): [wave][mt][tile][j][lane]
+    float *dst = a.partial + (size_t)gwave * kWFSlots + lane;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int t = 0; t < kWFTiles; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[((mt * kWFTiles + t) * 4 + j) * 64] = acc[mt][t][j];
+}
+
+// grad_weight += 2^(ex - 14) 2^(eg - 14) * sum over the waves.  blockIdx.y slices the waves; a slot's slices meet in
+// grad_weight through one atomic each.  D layout: lane (n = (h, co), q), register j -> ci = 16 mt + 4 q + j.
+__global__ __launch_bounds__(256) void conv3d_wgrad_c8_f16_reduce_kernel(WgradF16Args a) {
+    const int slot = blockIdx.x * 256 + threadIdx.x;   // < kWFSlots (a multiple of 256)
+    const unsigned bx = load_absmax(a.x_absmax), bg = load_absmax(a.g_absmax);
+    const int lane = slot & 63, j = (slot >> 6) & 3, t = (slot >> 8) % kWFTiles, mt = slot / (256 * kWFTiles);
+    const int n = lane & 15, q = lane >> 4, h = n >> 3, co = n & 7;
+    const int rr = 2 * (t / 3) + h, kx = t % 3;
+    if (rr >= 9) return;
+    const int ci = mt * 16 + 4 * q + j;
+    float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
+    int w = blockIdx.y;
+    const int ws = gridDim.y;
+    for (; w + 3 * ws < a.nwaves; w += 4 * ws) {
+        u0 += a.partial[(size_t)w * kWFSlots + slot]; u1 += a.partial[(size_t)(w + ws) * kWFSlots + slot];
+        u2 += a.partial[(size_t)(w + 2 * ws) * kWFSlots + slot]; u3 += a.partial[(size_t)(w + 3 * ws) * kWFSlots + slot];
+    }
+    for (; w < a.nwaves; w += ws) u0 += a.partial[(size_t)w * kWFSlots + slot];
+    const float unscale = pow2f(absmax_exponent(bx) - 14) * pow2f(absmax_exponent(bg) - 14);
+    unsafeAtomicAdd(a.gw + ((int64_t)co * 32 + ci) * 27 + rr * 3 + kx, ((u0 + u1) + (u2 + u3)) * unscale);
+}
+
+static int wgrad_f16_waves() { return 2 * device_cu_count() * 4; }
+
+}  // namespace mvs
+
+using namespace mvs;
+
+extern "C" int mvs_conv3d_wgrad_c8_f16_supported(int B, int Cin, int D, int H, int W) {
+    if (Cin != 32 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    const int64_t vox = (int64_t)B * D * H * W;
+    return vox * 128 < 0xffffff00LL && vox * (int64_t)((W + 31) / 32) / W < 0x7fffffffLL ? 1 : 0;
+}
+
+extern "C" size_t mvs_conv3d_wgrad_c8_f16_workspace_bytes(int B, int Cin, int D, int H, int W) {
+    if (!mvs_conv3d_wgrad_c8_f16_supported(B, Cin, D, H, W)) return 0;
+    return (size_t)wgrad_f16_waves() * kWFSlots * sizeof(float);
+}
+
+extern "C" int mvs_conv3d_wgrad_c8_f16_f32(const float *in_c8, const unsigned *in_absmax, const float *grad_out,
+                                           const unsigned *grad_absmax, int B, int Cin, int D, int H, int W, float *grad_weight,
+                                           void *workspace, size_t workspace_bytes, void *stream) {
+    if (!in_c8 || !in_absmax || !grad_out || !grad_absmax || !grad_weight || !workspace) {
+        set_error("mvs_conv3d_wgrad_c8_f16_f32: null argument (both absmax blocks and the workspace are required)");
+        return MVS_EINVAL;
+    }
+    if (!mvs_conv3d_wgrad_c8_f16_supported(B, Cin, D, H, W)) {
+        set_error("mvs_conv3d_wgrad_c8_f16_f32: Cin = 32 (Cout = 8, 3x3x3, stride 1) and a volume below 4 GB, got Cin=%d %dx%dx%dx%d",
+                  Cin, B, D, H, W);
+        return MVS_EUNSUPPORTED;
+    }
+    const size_t need = mvs_conv3d_wgrad_c8_f16_workspace_bytes(B, Cin, D, H, W);
+    if (workspace_bytes < need) {
+        set_error("mvs_conv3d_wgrad_c8_f16_f32: workspace of %zu bytes, need %zu", workspace_bytes, need);
+        return MVS_EWORKSPACE;
+    }
+    WgradF16Args a;
+    a.x = in_c8; a.g = grad_out; a.x_absmax = in_absmax; a.g_absmax = grad_absmax;
+    a.partial = static_cast<float *>(workspace); a.gw = grad_weight;
+    a.B = B; a.D = D; a.H = H; a.W = W;
+    a.nseg = (W + 31) / 32;
+    a.nchunks = (int)((int64_t)B * D * H * a.nseg);
+    a.nwaves = wgrad_f16_waves();
+    hipStream_t st = as_stream(stream);
+    if (W % 32 == 0)
+        hipLaunchKernelGGL((conv3d_wgrad_c8_f16_kernel<true>), dim3((unsigned)(a.nwaves / 4)), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv3d_wgrad_c8_f16_kernel<false>), dim3((unsigned)(a.nwaves / 4)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(conv3d_wgrad_c8_f16_reduce_kernel, dim3(kWFSlots / 256, 32), dim3(256), 0, st, a);
+    return check_launch("mvs_conv3d_wgrad_c8_f16_f32");
+}

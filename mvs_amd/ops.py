@@ -1379,6 +1379,33 @@ def conv3d_wgrad_c8(x_c8, g_cl):
     return gw
 
 
+def wgrad_f16_enabled():
+    """False when MVS_WGRAD_F16=0 keeps conv0's weight gradient on the fp32 matrix pipe (A/B switch; default: the two-piece
+    fp16 kernel, mvs_conv3d_wgrad_c8_f16_f32, wherever the training node has both operands' absmax blocks)."""
+    import os
+    return os.environ.get("MVS_WGRAD_F16", "1") != "0"
+
+
+def conv3d_wgrad_c8_f16(x_c8, x_absmax, g_cl, g_absmax):
+    """conv0's weight gradient on the 16-bit matrix pipe (mvs_conv3d_wgrad_c8_f16_f32): x_c8 [B,D,H,4,W,8] with its absmax
+    block, g_cl [B,D,H,W,8] with its absmax block -> (8,32,3,3,3); None if the shape has no such kernel."""
+    x_c8, g_cl = _f32c(x_c8), _f32c(g_cl)
+    B, D, H, G, W, _ = x_c8.shape
+    cin = G * 8
+    lib = _lib.load()
+    if not lib.mvs_conv3d_wgrad_c8_f16_supported(B, cin, D, H, W):
+        return None
+    if tuple(g_cl.shape) != (B, D, H, W, 8):
+        raise MvsHipError(f"conv3d_wgrad_c8_f16: grad_out {tuple(g_cl.shape)} does not match the volume {tuple(x_c8.shape)}")
+    gw = torch.zeros((8, cin, 3, 3, 3), device=x_c8.device, dtype=torch.float32)   # (the reduction adds into it)
+    nbytes = int(lib.mvs_conv3d_wgrad_c8_f16_workspace_bytes(B, cin, D, H, W))
+    ws = torch.empty((nbytes // 4,), device=x_c8.device, dtype=torch.float32)     # one partial per wave
+    check(lib.mvs_conv3d_wgrad_c8_f16_f32(ptr(x_c8), ctypes.c_void_p(x_absmax.data_ptr()), ptr(g_cl),
+                                          ctypes.c_void_p(g_absmax.data_ptr()), B, cin, D, H, W, ptr(gw), ptr(ws), nbytes,
+                                          stream()), "mvs_conv3d_wgrad_c8_f16_f32")
+    return gw
+
+
 class _VarianceConv0(torch.autograd.Function):
     """Training path: fused warp + variance -> conv0 (raw output, before BatchNorm) as ONE autograd node, so that the
     variance volume can live in the 8-channel-blocked layout conv0's split-operand bf16 kernel reads (0.87 -> 0.4 ms at
@@ -1404,6 +1431,7 @@ class _VarianceConv0(torch.autograd.Function):
             out = conv3d_c8_f16x3(var, pks, amax) if f16 else conv3d_c8_split(var, pks, None, None, None, False)
         ctx.save_for_backward(ref16, srcs16, rts, depth_values, var, weight)
         ctx.ac = int(align_corners)
+        ctx.var_absmax = amax          # (None on the bf16 path)
         return out
 
     @staticmethod
@@ -1412,14 +1440,21 @@ class _VarianceConv0(torch.autograd.Function):
         g = _f32c(g)
         w = weight.detach()
         gw = g_ref = g_src = None
+        g_absmax = None                # max |g|: the operand scale of both two-piece kernels below, one pass
         if ctx.needs_input_grad[4]:
             with stage("train.conv0.wgrad"):
-                gw = conv3d_wgrad_c8(var, g)
+                if ctx.var_absmax is not None and wgrad_f16_enabled():
+                    g_absmax = absmax(g)
+                    gw = conv3d_wgrad_c8_f16(var, ctx.var_absmax, g, g_absmax)
+                if gw is None:
+                    gw = conv3d_wgrad_c8(var, g)
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             wt = w.flip(2, 3, 4).permute(1, 0, 2, 3, 4).contiguous()      # (32, 8, k) as a conv weight
             pk = pack_conv3d_weight(wt, False, 1, split=True)
+            if g_absmax is None and f16_companion(pk) is not None:
+                g_absmax = absmax(g)
             with stage("train.conv0.dgrad"):     # (8 -> 32 on the split-operand kernel: two pieces when the pack has them, scale = max |g|)
-                gvar = conv3d(g, wt, channels_last=True, packed=pk, x_absmax=absmax(g) if f16_companion(pk) is not None else None)   # [B,D,H,W,32]
+                gvar = conv3d(g, wt, channels_last=True, packed=pk, x_absmax=g_absmax if f16_companion(pk) is not None else None)   # [B,D,H,W,32]
             if split_companion(pk) is not None:
                 split_stage_names.add("train.conv0.dgrad")
             B, G, H, W, _ = ref16.shape

@@ -1804,6 +1804,32 @@ def test_conv0_weight_gradient_from_blocked_volume(dev):
         assert (a - b).abs().max().item() < 1e-5 * scale and (b - w.grad).abs().max().item() < 2e-5 * scale
 
 
+@pytest.mark.parametrize("shape", [(1, 4, 8, 32), (2, 5, 7, 64), (1, 6, 9, 21), (1, 3, 5, 45), (1, 2, 3, 160)])
+@pytest.mark.parametrize("spread", [1.0, 1e-6, 3e4])
+def test_conv0_weight_gradient_two_piece_fp16(dev, shape, spread):
+    """mvs_conv3d_wgrad_c8_f16_f32 (conv0's weight gradient on the 16-bit matrix pipe, two fp16 pieces per operand, three
+    products) against a float64 autograd convolution and the fp32-pipe kernel: rows that are / are not a multiple of the
+    32-voxel segment, batch 2, every volume edge inside one segment, operands far from 1 (the scales come from the absmax
+    blocks), accumulation into a non-zero grad_weight left to the caller's zeros."""
+    import torch.nn.functional as F
+    from mvs_amd import ops
+    B, D, H, W = shape
+    g = torch.Generator().manual_seed(D * 100 + W)
+    x = torch.randn(B, 32, D, H, W, generator=g) * spread
+    go = torch.randn(B, D, H, W, 8, generator=g) / spread
+    w = torch.zeros(8, 32, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv3d(x.double(), w, padding=1).backward(go.permute(0, 4, 1, 2, 3).double())
+    xc8, gd = ops.nchw_to_c8(x.to(dev)), go.to(dev)
+    got = ops.conv3d_wgrad_c8_f16(xc8, ops.absmax(xc8), gd, ops.absmax(gd))
+    assert got is not None
+    ref32 = ops.conv3d_wgrad_c8(xc8, gd).cpu().double()
+    scale = w.grad.abs().max().item()
+    err = (got.cpu().double() - w.grad).abs().max().item()
+    err32 = (ref32 - w.grad).abs().max().item()
+    assert err < 2e-5 * scale, (err / scale, err32 / scale)
+    assert err < 4 * err32 + 2e-6 * scale, (err / scale, err32 / scale)      # no farther from float64 than the fp32 pipe, to a small factor
+
+
 def test_fused_variance_conv0_node_matches_separate_ops(dev):
     """ops.variance_conv0_autograd (warp + variance -> conv0 as one autograd node on the bf16 kernel) against the two separate
     autograd ops of the unfused training path: conv0's raw output, the gradients of all feature maps and of the weight."""
