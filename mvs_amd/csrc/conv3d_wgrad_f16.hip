@@ -22,6 +22,13 @@
 // owns all 2 x 15 accumulator tiles (120 registers = the whole weight gradient) and a stream of (row, 32-voxel segment)
 // chunks; it stores them once, the reduce kernel sums the waves and undoes the two scales.
 //
+// Measured (640x512 training step, 3.9 M voxels): 0.25 ms + 0.02 ms reduce against 0.54 + 0.02 on the fp32 pipe.  What bounds
+// it is the vector memory pipe, not the matrix pipe: a chunk is 90 MFMAs (1440 cycles of one SIMD) and ~500 vector ALU
+// instructions, but its 66 dword loads touch 8 separate 32-byte pieces each and retire at ~16 cycles per instruction through
+// the CU's one texture path -- ~1050 cycles per chunk and CU, 0.21 ms for the 122,880 chunks; running the loads a chunk ahead
+// changed nothing.  Next step: 16-byte loads (4 channels of one voxel per lane) and a 4 x 4 transpose inside each lane quad
+// (DPP), which quarters the load instructions.
+//
 // Arithmetic: products are within 2^-22 relative of the fp32 products for operands within 2^-18 of their tensor's largest
 // magnitude and within 2^-40 of (max |x| max |g|) absolute below that (an element far below its tensor's maximum loses
 // relative precision, as in the forward layers); accumulation is fp32 as before.  Non-finite inputs give non-finite
@@ -91,13 +98,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_c8_f16_kernel(WgradF16Arg
 
     // chunk c = ((b D + z) H + y) nseg + seg, c = gwave, gwave + nwaves, ...: the four coordinates advance by the digits of
     // nwaves with carries (four integer divisions per chunk were a third of the loop's vector instructions)
-    int seg, y, z, b;
+    struct Pos { int seg, y, z, b; };
+    Pos cur, nxt;
     {
         int r = gwave;
-        seg = r % a.nseg; r /= a.nseg;
-        y = r % a.H; r /= a.H;
-        z = r % a.D;
-        b = r / a.D;
+        nxt.seg = r % a.nseg; r /= a.nseg;
+        nxt.y = r % a.H; r /= a.H;
+        nxt.z = r % a.D;
+        nxt.b = r / a.D;
     }
     int sseg, sy, sz, sb;
     {
@@ -108,55 +116,61 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_c8_f16_kernel(WgradF16Arg
         sb = r / a.D;
     }
     const int niter = gwave < a.nchunks ? (a.nchunks - gwave + a.nwaves - 1) / a.nwaves : 0;
-#pragma unroll 1
-    for (int it = 0; it < niter; ++it) {
-        if (it) {
-            seg += sseg; int cy = 0;
-            if (seg >= a.nseg) { seg -= a.nseg; cy = 1; }
-            y += sy + cy; cy = 0;
-            if (y >= a.H) { y -= a.H; cy = 1; }
-            z += sz + cy; cy = 0;
-            if (z >= a.D) { z -= a.D; cy = 1; }
-            b += sb + cy;
-        }
-        const int xb = seg * 32 + kq * 8;          // this lane's first voxel
-        const int lim = a.W - xb;                  // elements e < lim are inside the row
-
-        // ---- x: 2 tiles x 8 voxels of channel mt * 16 + n; blocked layout [row][Cin/8][W][8]
-        float xv[2][8];
-        {
-            const int64_t row = ((int64_t)b * a.D + z) * a.H + y;
-            const unsigned base = (unsigned)((((row * 4 + (n >> 3)) * a.W + xb) * 8 + (n & 7)) * 4);
-            const unsigned off = lim > 0 ? base : OOB;
-            const int tile = a.W * 64;             // bytes from channel group g to g + 2
+    auto advance = [&](Pos q) {
+        q.seg += sseg; int cy = 0;
+        if (q.seg >= a.nseg) { q.seg -= a.nseg; cy = 1; }
+        q.y += sy + cy; cy = 0;
+        if (q.y >= a.H) { q.y -= a.H; cy = 1; }
+        q.z += sz + cy; cy = 0;
+        if (q.z >= a.D) { q.z -= a.D; cy = 1; }
+        q.b += sb + cy;
+        return q;
+    };
+    // ---- x: 2 tiles x 8 voxels of channel mt * 16 + n of the chunk at (b, z, y, seg); blocked layout [row][Cin/8][W][8]
+    float xv[2][8];
+    auto load_x = [&](const Pos &q) {
+        const int seg = q.seg, y = q.y, z = q.z, b = q.b;
+        const int xb = seg * 32 + kq * 8, lim = a.W - xb;      // this lane's first voxel; elements e < lim are inside the row
+        const int64_t row = ((int64_t)b * a.D + z) * a.H + y;
+        const unsigned base = (unsigned)((((row * 4 + (n >> 3)) * a.W + xb) * 8 + (n & 7)) * 4);
+        const unsigned off = lim > 0 ? base : OOB;
+        const int tile = a.W * 64;                             // bytes from channel group g to g + 2
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    xv[mt][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, off + i * 32, mt * tile, 0));
-                    if (!FULLW && i >= lim) xv[mt][i] = 0.f;
-                }
-        }
-        // ---- g: per row pair, elements -1 .. 8 of output channel co in tap row 2 p + h
-        auto load_pair = [&](int p, float (&gv)[10]) {
-            const int rr = 2 * p + h;              // tap row (kz, ky); the tenth does not exist
-            const int kz = rr / 3, ky = rr - 3 * kz;
-            const int gz = z - (kz - 1), gy = y - (ky - 1);
-            const bool rowok = rr < 9 && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && lim > 0;
-            const int64_t row = ((int64_t)b * a.D + gz) * a.H + gy;
-            const unsigned base = (unsigned)(((row * a.W + xb) * 8 + co) * 4);
-            const unsigned off = rowok ? base : OOB;
-            gv[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, (rowok && xb > 0) ? base - 32u : OOB, 0, 0));
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                gv[1 + i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, off + i * 32, 0, 0));
-                if (!FULLW && i >= lim) gv[1 + i] = 0.f;
+                xv[mt][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, off + i * 32, mt * tile, 0));
+                if (!FULLW && i >= lim) xv[mt][i] = 0.f;
             }
-            gv[9] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, (rowok && 8 < lim) ? base + 256u : OOB, 0, 0));
-        };
-        float gcur[10], gnext[10];
-        load_pair(0, gcur);
-
+    };
+    // ---- g: per row pair, elements -1 .. 8 of output channel co in tap row 2 p + h of the chunk at (b, z, y, seg)
+    auto load_pair = [&](const Pos &q, int p, float (&gv)[10]) {
+        const int seg = q.seg, y = q.y, z = q.z, b = q.b;
+        const int xb = seg * 32 + kq * 8, lim = a.W - xb;
+        const int rr = 2 * p + h;              // tap row (kz, ky); the tenth does not exist
+        const int kz = rr / 3, ky = rr - 3 * kz;
+        const int gz = z - (kz - 1), gy = y - (ky - 1);
+        const bool rowok = rr < 9 && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && lim > 0;
+        const int64_t row = ((int64_t)b * a.D + gz) * a.H + gy;
+        const unsigned base = (unsigned)(((row * a.W + xb) * 8 + co) * 4);
+        const unsigned off = rowok ? base : OOB;
+        gv[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, (rowok && xb > 0) ? base - 32u : OOB, 0, 0));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            gv[1 + i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, off + i * 32, 0, 0));
+            if (!FULLW && i >= lim) gv[1 + i] = 0.f;
+        }
+        gv[9] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, (rowok && 8 < lim) ? base + 256u : OOB, 0, 0));
+    };
+    // Loads run ahead of their use: a chunk's x one whole chunk (HBM: the volume is read once), a row pair's g one pair
+    // (mostly L2: a g row serves nine tap rows) -- the first pair of the next chunk behind the fourth pair of this one.
+    float gcur[10], gnext[10];
+    if (niter > 0) {
+        load_x(nxt);
+        load_pair(nxt, 0, gcur);
+    }
+#pragma unroll 1
+    for (int it = 0; it < niter; ++it) {
         f16x8 Ah[2], Al[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -166,9 +180,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_c8_f16_kernel(WgradF16Arg
             Ah[mt] = frag(hh[0], hh[1], hh[2], hh[3]);
             Al[mt] = frag(ll[0], ll[1], ll[2], ll[3]);
         }
+        const bool more = it + 1 < niter;
+        cur = nxt;
+        nxt = advance(cur);
+        if (more) load_x(nxt);       // (xv is free: its pieces are in Ah / Al)
 #pragma unroll
         for (int p = 0; p < 5; ++p) {
-            if (p < 4) load_pair(p + 1, gnext);
+            if (p < 4) load_pair(cur, p + 1, gnext);
+            else if (more) load_pair(nxt, 0, gnext);
             // even pairs (0,1)(2,3)(4,5)(6,7) of elements 0..7 = gcur[1..8]; odd pairs (-1,0)(1,2)(3,4)(5,6)(7,8)
             unsigned eh[4], el[4], oh[5], ol[5];
 #pragma unroll
@@ -178,20 +197,24 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_c8_f16_kernel(WgradF16Arg
             // x-shift index 0: kx = 0, g at x + 1 (elements 1..8); 1: kx = 1 (0..7); 2: kx = 2, g at x - 1 (-1..6)
             const f16x8 Bh[3] = {frag(oh[1], oh[2], oh[3], oh[4]), frag(eh[0], eh[1], eh[2], eh[3]), frag(oh[0], oh[1], oh[2], oh[3])};
             const f16x8 Bl[3] = {frag(ol[1], ol[2], ol[3], ol[4]), frag(el[0], el[1], el[2], el[3]), frag(ol[0], ol[1], ol[2], ol[3])};
+            // product by product over the six accumulators of the pair: no MFMA waits for the one before it
 #pragma unroll
             for (int s = 0; s < 3; ++s)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    f32x4 cc = acc[mt][p * 3 + s];
-                    cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[mt], Bl[s], cc, 0, 0, 0);
-                    cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[mt], Bh[s], cc, 0, 0, 0);
-                    cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[mt], Bh[s], cc, 0, 0, 0);
-                    acc[mt][p * 3 + s] = cc;
-                }
-            if (p < 4) {
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[mt][p * 3 + s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[mt], Bl[s], acc[mt][p * 3 + s], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < 10; ++i) gcur[i] = gnext[i];
-            }
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[mt][p * 3 + s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[mt], Bh[s], acc[mt][p * 3 + s], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[mt][p * 3 + s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[mt], Bh[s], acc[mt][p * 3 + s], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) gcur[i] = gnext[i];
         }
     }
     // ---- this wave's partial, accumulator order (coalesced): [wave][mt][tile][j][lane]
