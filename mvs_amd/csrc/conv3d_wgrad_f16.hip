@@ -124,59 +124,74 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_c8_f16_kernel(WgradF16Arg
         q.b += sb + cy;
         return q;
     };
-    // ---- x: 2 tiles x 8 voxels of channel mt * 16 + n of the chunk at (b, z, y, seg); blocked layout [row][Cin/8][W][8]
-    float xv[2][8];
+    // ---- x: 2 tiles x elements -1 .. 8 of channel mt * 16 + n of the chunk at q; blocked layout [row][Cin/8][W][8].
+    // The x shift of a tap rides on THIS operand (sum_v g[v - dx] x[v] = sum_u g[u] x[u + dx]): it is loaded once per chunk,
+    // g five times, so the odd-pair splits and the two halo loads are paid per chunk instead of per row pair.
+    float xv[2][10];
     auto load_x = [&](const Pos &q) {
-        const int seg = q.seg, y = q.y, z = q.z, b = q.b;
-        const int xb = seg * 32 + kq * 8, lim = a.W - xb;      // this lane's first voxel; elements e < lim are inside the row
-        const int64_t row = ((int64_t)b * a.D + z) * a.H + y;
+        const int xb = q.seg * 32 + kq * 8, lim = a.W - xb;    // this lane's first voxel; elements e < lim are inside the row
+        const int64_t row = ((int64_t)q.b * a.D + q.z) * a.H + q.y;
         const unsigned base = (unsigned)((((row * 4 + (n >> 3)) * a.W + xb) * 8 + (n & 7)) * 4);
         const unsigned off = lim > 0 ? base : OOB;
+        const unsigned offl = (lim > 0 && xb > 0) ? base - 32u : OOB, offr = 8 < lim ? base + 256u : OOB;
         const int tile = a.W * 64;                             // bytes from channel group g to g + 2
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt) {
+            xv[mt][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, offl, mt * tile, 0));
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                xv[mt][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, off + i * 32, mt * tile, 0));
-                if (!FULLW && i >= lim) xv[mt][i] = 0.f;
+                xv[mt][1 + i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, off + i * 32, mt * tile, 0));
+                if (!FULLW && i >= lim) xv[mt][1 + i] = 0.f;
             }
+            xv[mt][9] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, offr, mt * tile, 0));
+        }
     };
-    // ---- g: per row pair, elements -1 .. 8 of output channel co in tap row 2 p + h of the chunk at (b, z, y, seg)
-    auto load_pair = [&](const Pos &q, int p, float (&gv)[10]) {
-        const int seg = q.seg, y = q.y, z = q.z, b = q.b;
-        const int xb = seg * 32 + kq * 8, lim = a.W - xb;
+    // ---- g: per row pair, elements 0 .. 7 of output channel co in tap row 2 p + h of the chunk at q
+    auto load_pair = [&](const Pos &q, int p, float (&gv)[8]) {
+        const int xb = q.seg * 32 + kq * 8, lim = a.W - xb;
         const int rr = 2 * p + h;              // tap row (kz, ky); the tenth does not exist
         const int kz = rr / 3, ky = rr - 3 * kz;
-        const int gz = z - (kz - 1), gy = y - (ky - 1);
+        const int gz = q.z - (kz - 1), gy = q.y - (ky - 1);
         const bool rowok = rr < 9 && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && lim > 0;
-        const int64_t row = ((int64_t)b * a.D + gz) * a.H + gy;
-        const unsigned base = (unsigned)(((row * a.W + xb) * 8 + co) * 4);
-        const unsigned off = rowok ? base : OOB;
-        gv[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, (rowok && xb > 0) ? base - 32u : OOB, 0, 0));
+        const int64_t row = ((int64_t)q.b * a.D + gz) * a.H + gy;
+        const unsigned off = rowok ? (unsigned)(((row * a.W + xb) * 8 + co) * 4) : OOB;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            gv[1 + i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, off + i * 32, 0, 0));
-            if (!FULLW && i >= lim) gv[1 + i] = 0.f;
+            gv[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, off + i * 32, 0, 0));
+            if (!FULLW && i >= lim) gv[i] = 0.f;
         }
-        gv[9] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, (rowok && 8 < lim) ? base + 256u : OOB, 0, 0));
     };
-    // Loads run ahead of their use: a chunk's x one whole chunk (HBM: the volume is read once), a row pair's g one pair
-    // (mostly L2: a g row serves nine tap rows) -- the first pair of the next chunk behind the fourth pair of this one.
-    float gcur[10], gnext[10];
+    // Software pipeline over the row pairs (and across chunks): while the 18 MFMAs of pair p run, the four splits of pair
+    // p + 1 sit between their three groups and the loads of pair p + 2 are in flight -- issued in source order, a wave's
+    // splits, loads and MFMAs took turns (ablation: MFMAs 0.10 ms, splits 0.085, loads 0.125 of 0.28, adding up).  x is
+    // loaded a whole chunk ahead (HBM: the volume is read once); g mostly hits L2 (a g row serves nine tap rows).
+    float g1[8], g2[8];                 // raw g of the next pair (landed) and of the one after (in flight)
+    f16x8 Bh, Bl;
     if (niter > 0) {
         load_x(nxt);
-        load_pair(nxt, 0, gcur);
+        float g0[8];
+        load_pair(nxt, 0, g0);
+        load_pair(nxt, 1, g1);
+        unsigned bh[4], bl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split_pair(g0[2 * j], g0[2 * j + 1], sg, bh[j], bl[j]);
+        Bh = frag(bh[0], bh[1], bh[2], bh[3]); Bl = frag(bl[0], bl[1], bl[2], bl[3]);
     }
 #pragma unroll 1
     for (int it = 0; it < niter; ++it) {
-        f16x8 Ah[2], Al[2];
+        // A fragments: x-shift index 0: kx = 0, x at u - 1 (elements -1..6 = odd pairs 0..3); 1: kx = 1 (even pairs);
+        // 2: kx = 2, x at u + 1 (elements 1..8 = odd pairs 1..4)
+        f16x8 Ah[2][3], Al[2][3];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            unsigned hh[4], ll[4];
+            unsigned eh[4], el[4], oh[5], ol[5];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) split_pair(xv[mt][2 * j], xv[mt][2 * j + 1], sx, hh[j], ll[j]);
-            Ah[mt] = frag(hh[0], hh[1], hh[2], hh[3]);
-            Al[mt] = frag(ll[0], ll[1], ll[2], ll[3]);
+            for (int j = 0; j < 4; ++j) split_pair(xv[mt][1 + 2 * j], xv[mt][2 + 2 * j], sx, eh[j], el[j]);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) split_pair(xv[mt][2 * j], xv[mt][2 * j + 1], sx, oh[j], ol[j]);
+            Ah[mt][0] = frag(oh[0], oh[1], oh[2], oh[3]); Al[mt][0] = frag(ol[0], ol[1], ol[2], ol[3]);
+            Ah[mt][1] = frag(eh[0], eh[1], eh[2], eh[3]); Al[mt][1] = frag(el[0], el[1], el[2], el[3]);
+            Ah[mt][2] = frag(oh[1], oh[2], oh[3], oh[4]); Al[mt][2] = frag(ol[1], ol[2], ol[3], ol[4]);
         }
         const bool more = it + 1 < niter;
         cur = nxt;
@@ -184,35 +199,32 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_c8_f16_kernel(WgradF16Arg
         if (more) load_x(nxt);       // (xv is free: its pieces are in Ah / Al)
 #pragma unroll
         for (int p = 0; p < 5; ++p) {
-            if (p < 4) load_pair(cur, p + 1, gnext);
-            else if (more) load_pair(nxt, 0, gnext);
-            // even pairs (0,1)(2,3)(4,5)(6,7) of elements 0..7 = gcur[1..8]; odd pairs (-1,0)(1,2)(3,4)(5,6)(7,8)
-            unsigned eh[4], el[4], oh[5], ol[5];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) split_pair(gcur[1 + 2 * j], gcur[2 + 2 * j], sg, eh[j], el[j]);
-#pragma unroll
-            for (int j = 0; j < 5; ++j) split_pair(gcur[2 * j], gcur[2 * j + 1], sg, oh[j], ol[j]);
-            // x-shift index 0: kx = 0, g at x + 1 (elements 1..8); 1: kx = 1 (0..7); 2: kx = 2, g at x - 1 (-1..6)
-            const f16x8 Bh[3] = {frag(oh[1], oh[2], oh[3], oh[4]), frag(eh[0], eh[1], eh[2], eh[3]), frag(oh[0], oh[1], oh[2], oh[3])};
-            const f16x8 Bl[3] = {frag(ol[1], ol[2], ol[3], ol[4]), frag(el[0], el[1], el[2], el[3]), frag(ol[0], ol[1], ol[2], ol[3])};
-            // product by product over the six accumulators of the pair: no MFMA waits for the one before it
+            // pair p + 2 of this chunk, or pair p - 3 of the next one
+            if (p < 3) load_pair(cur, p + 2, g2);
+            else if (more) load_pair(nxt, p - 3, g2);
+            unsigned nh[4], nl[4];
 #pragma unroll
             for (int s = 0; s < 3; ++s)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
-                    acc[mt][p * 3 + s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[mt], Bl[s], acc[mt][p * 3 + s], 0, 0, 0);
+                    acc[mt][p * 3 + s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[mt][s], Bl, acc[mt][p * 3 + s], 0, 0, 0);
+            split_pair(g1[0], g1[1], sg, nh[0], nl[0]);
+            split_pair(g1[2], g1[3], sg, nh[1], nl[1]);
 #pragma unroll
             for (int s = 0; s < 3; ++s)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
-                    acc[mt][p * 3 + s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[mt], Bh[s], acc[mt][p * 3 + s], 0, 0, 0);
+                    acc[mt][p * 3 + s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[mt][s], Bh, acc[mt][p * 3 + s], 0, 0, 0);
+            split_pair(g1[4], g1[5], sg, nh[2], nl[2]);
+            split_pair(g1[6], g1[7], sg, nh[3], nl[3]);
 #pragma unroll
             for (int s = 0; s < 3; ++s)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
-                    acc[mt][p * 3 + s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[mt], Bh[s], acc[mt][p * 3 + s], 0, 0, 0);
+                    acc[mt][p * 3 + s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[mt][s], Bh, acc[mt][p * 3 + s], 0, 0, 0);
+            Bh = frag(nh[0], nh[1], nh[2], nh[3]); Bl = frag(nl[0], nl[1], nl[2], nl[3]);
 #pragma unroll
-            for (int i = 0; i < 10; ++i) gcur[i] = gnext[i];
+            for (int i = 0; i < 8; ++i) g1[i] = g2[i];
         }
     }
     // ---- this wave's partial, accumulator order (coalesced): [wave][mt][tile][j][lane]
