@@ -14,24 +14,31 @@
 // channel per lane -- the transpose of how either tensor lies in memory.  No LDS: a lane loads its 8 voxels as 8 dwords, 32
 // bytes apart, straight from HBM/L2 (the 8 loads of a lane walk the same cache lines, the 16 lanes of a row cover the 32-byte
 // channel groups), splits them in registers and feeds the pipe:
-//   A (M = 16 input channels, two tiles): x[z][y][x0 + 8 kq + i][ci],            i = 0..7
-//   B (N = 2 tap rows x 8 output channels): g[z - dz_h][y - dy_h][x0 + 8 kq + i - dx][co]
-// The nine (dz, dy) rows of the 27 taps pair up into five N tiles; the three x shifts of a row pair come from ONE set of ten
-// loads per lane (elements -1..8): dx = 0 packs the pairs (0,1)(2,3)(4,5)(6,7), dx = +1 the pairs (-1,0)(1,2)(3,4)(5,6) and
-// dx = -1 (1,2)(3,4)(5,6)(7,8), so a chunk of 32 voxels costs 66 dword loads and 53 pair splits for its 90 MFMAs.  A wave
-// owns all 2 x 15 accumulator tiles (120 registers = the whole weight gradient) and a stream of (row, 32-voxel segment)
-// chunks; it stores them once, the reduce kernel sums the waves and undoes the two scales.
+//   A (M = 16 input channels, two tiles, three x shifts): x[z][y][x0 + 8 kq + i + dx][ci],   i = 0..7, dx = kx - 1
+//   B (N = 2 tap rows x 8 output channels):               g[z - dz_h][y - dy_h][x0 + 8 kq + i][co]
+// The x shift of a tap rides on the x operand (sum_v g[v - dx] x[v] = sum_u g[u] x[u + dx]), which is loaded once per chunk
+// while g is loaded for each of the five row pairs the nine (dz, dy) tap rows make: ten loads per lane and tile (elements
+// -1..8) give all three shifts -- dx = 0 packs the pairs (0,1)(2,3)(4,5)(6,7), dx = -1 the pairs (-1,0)(1,2)(3,4)(5,6), dx = +1
+// (1,2)(3,4)(5,6)(7,8) -- so a chunk of 32 voxels costs 60 dword loads and 38 pair splits for its 90 MFMAs.  A wave owns all
+// 2 x 15 accumulator tiles (120 registers = the whole weight gradient) and a stream of (row, 32-voxel segment) chunks; it
+// stores them once, the reduce kernel sums the waves and undoes the two scales.
 //
-// Measured (640x512 training step, 3.9 M voxels): 0.25 ms + 0.02 ms reduce against 0.54 + 0.02 on the fp32 pipe.  What bounds
-// it is the vector memory path, not the matrix pipe: a chunk is 90 MFMAs (~1500 cycles of one SIMD, 380 per CU) and ~500
-// vector ALU instructions, but its 66 dword loads move 16.9 KB through the CU's one texture path at ~16 bytes per cycle
-// (8 separate 32-byte pieces per instruction; MI355X_MICROARCH.md: ~22 cycles per L2-hit load drained) -- ~1050 cycles per
-// chunk and CU, 0.21 ms for the 122,880 chunks.  Tried: g two row pairs ahead instead of one, x a whole chunk ahead -- 0.25 ms
-// either way (not latency); 16-byte loads (4 channels of one voxel per lane) with a 4 x 4 DPP transpose inside each lane quad
-// -- 24 load instructions instead of 66 but the same bytes at ~10 B/cycle plus 224 selects and moves: 0.30 ms, not kept.
-// The bytes are the lever: every g row is fetched by the nine tap rows of every wave that needs it (10.9 KB per chunk for
-// 1.1 KB of new data).  Next: the four waves of a workgroup on four adjacent rows with ONE g halo tile in LDS (voxel stride
-// 36 bytes: the four 8-voxel groups of a fragment land on different banks), which leaves 9 KB per chunk on the texture path.
+// Measured (640x512 training step, 3.9 M voxels): 0.23 ms + 0.02 ms reduce against 0.54 + 0.02 on the fp32 pipe.  Ablation
+// of the first version (0.28 ms in isolation, shifts on g: 66 loads, 53 splits; scripts/exp_wgrad_f16_abl.py times the op):
+// without the MFMAs -0.10 ms (19 cycles each: the pipe's own time), without the g splits -0.085, without the loads -0.125 --
+// the three add up: a wave takes them in turn and two waves per SIMD (230 registers) overlap little.  Tried on top of it:
+// loads two pairs / a whole chunk ahead (no change: not latency); 16-byte loads with a 4 x 4 DPP transpose per lane quad (24
+// load instructions instead of 66, +224 selects and moves: 0.30 ms); the four waves of a workgroup on adjacent rows sharing
+// one g halo tile in LDS (19.6 KB instead of 4 x 10.9 KB through the texture path: 0.27 ms); the next pair's splits placed
+// between this pair's three MFMA groups (kept, no measurable change).  Moving the shifts to x (this version) took 0.02 ms.
+// The split asm must stay `volatile`: without it the compiler mis-handles the half-register writes of v_fma_mixlo / mixhi
+// (wrong gradients).
+//
+// Arithmetic: products are within 2^-22 relative of the fp32 products for operands within 2^-18 of their tensor's largest
+// magnitude and within 2^-40 of (max |x| max |g|) absolute below that (an element far below its tensor's maximum loses
+// relative precision, as in the forward layers); accumulation is fp32 as before.  Non-finite inputs give non-finite
+// gradients, as the fp32 kernel does.  There is no range guard on this path: it is taken by the training node only
+// (ops._VarianceConv0), MVS_WGRAD_F16=0 keeps the fp32 kernel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
