@@ -22,7 +22,7 @@ def step():
 for _ in range(3): step()
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     step(); torch.cuda.synchronize()
 groups = collections.Counter()
 for e in prof.events():
@@ -30,7 +30,7 @@ for e in prof.events():
         continue
     if e.name in ("aten::copy_", "aten::fill_", "aten::zero_", "hipMemcpyAsync", "hipMemsetAsync", "aten::cat", "aten::stack"):
         frame = next((f for f in e.stack if "mvs_amd" in f or "bench" in f), e.stack[0] if e.stack else "?")
-        groups[(e.name, frame.strip()[-110:])] += 1
+        groups[(e.name, str(e.input_shapes)[:80] + ' ' + frame.strip()[-60:])] += 1
 for (name, frame), n in sorted(groups.items(), key=lambda kv: -kv[1]):
     print(f"{n:3d} {name:18s} {frame}")
 print("device kernels:")

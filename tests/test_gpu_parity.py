@@ -1432,6 +1432,12 @@ def test_training_ops_reject_unsupported_shapes(dev):
     assert ops.conv3d_wgrad(torch.randn(1, 4, 4, 8, 12, device=dev), torch.randn(1, 4, 4, 8, 8, device=dev), 1) is None
     with pytest.raises(ops.MvsHipError):
         ops.cas_depth_hypotheses(torch.rand(1, 4, 4, device=dev), 1, 2.0, (8, 8), (8, 8))   # D < 2
+    # a planar input of the 2D weight gradient is the image: more than 4 channels has no kernel
+    with pytest.raises(ops.MvsHipError):
+        ops.conv2d_wgrad(torch.randn(1, 8, 16, 16, device=dev), torch.randn(1, 16, 16, 8, device=dev), 3, 1, planar=True)
+    # conv0's two-piece weight gradient: 32 input channels only (None = no such kernel; the caller takes the fp32 one)
+    x16 = torch.randn(1, 4, 8, 2, 32, 8, device=dev)
+    assert ops.conv3d_wgrad_c8_f16(x16, ops.absmax(x16), torch.randn(1, 4, 8, 32, 8, device=dev), ops.absmax(x16)) is None
 
 
 def test_geo_consistency_kernel_vs_numpy_restatement(dev):
