@@ -48,22 +48,37 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(BnArgs a) {
     }
     double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
     const int64_t step = (int64_t)gridDim.x * 256;
-    for (int64_t el = (int64_t)blockIdx.x * 256 + tid; el < a.nq; el += step) {
-        const int64_t e = g0 + el;
-        const float4 xv = ld4(a.x, e);
-        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-        if (MODE == 0) {
+    // Four elements of the thread's stride per round, their loads issued together: with two blocks per CU and one 16-byte
+    // load in flight per thread the pass ran at 2.5 TB/s (8 KB in flight per CU against ~1 us of latency).  The sums take
+    // the elements in the same order as before.
+    constexpr int U = 4;
+    for (int64_t el = (int64_t)blockIdx.x * 256 + tid; el < a.nq; el += step * U) {
+        float4 xv[U], gv[U];
+        bool ok[U];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { s0[j] += (double)xs[j]; s1[j] += (double)xs[j] * (double)xs[j]; }
-        } else {
-            const float4 gv = ld4(a.dy, e);
-            const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
+        for (int u = 0; u < U; ++u) {
+            const int64_t eu = el + u * step;
+            ok[u] = eu < a.nq;
+            const int64_t e = g0 + (ok[u] ? eu : el);
+            xv[u] = ld4(a.x, e);
+            if (MODE == 1) gv[u] = ld4(a.dy, e);
+        }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float xm = xs[j] - mean[j];
-                const float z = xm * istd[j] * w[j] + b[j];
-                const float dz = (a.relu && !(z > 0.0f)) ? 0.0f : gs[j];
-                s0[j] += (double)dz; s1[j] += (double)dz * (double)xm;
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+            const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+            if (MODE == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s0[j] += (double)xs[j]; s1[j] += (double)xs[j] * (double)xs[j]; }
+            } else {
+                const float gs[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xm = xs[j] - mean[j];
+                    const float z = xm * istd[j] * w[j] + b[j];
+                    const float dz = (a.relu && !(z > 0.0f)) ? 0.0f : gs[j];
+                    s0[j] += (double)dz; s1[j] += (double)dz * (double)xm;
+                }
             }
         }
     }
