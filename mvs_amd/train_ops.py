@@ -74,6 +74,35 @@ def invalidate_derived():
     _derived_capture.clear()
 
 
+def _pk3(weight, transposed, stride):
+    """Forward pack of a 3D layer (split-operand bf16 kernels where the shape has one)."""
+    return _cached(weight, ("pk3", transposed, stride),
+                   lambda: ops.pack_conv3d_weight(weight.detach().contiguous(), transposed, stride, split=True, f16=False, lazy=True))
+
+
+def _dgrad3(weight, transposed, stride):
+    """What the input gradient of a 3D layer runs on: (conv weight, pack) of the flipped / transposed weights for a stride-1
+    convolution, the pack of the weight read as a transposed convolution for a stride-2 one, as a convolution for a
+    transposed layer."""
+    w = weight.detach()
+    if not transposed and stride == 1:
+        return _cached(weight, "dgrad3_s1", lambda: (lambda t: (t, ops.pack_conv3d_weight(t, False, 1, split=True, f16=False, lazy=True)))(
+            w.flip(2, 3, 4).permute(1, 0, 2, 3, 4).contiguous()))        # (Ci,Co,k) as a conv weight
+    if not transposed:
+        return _cached(weight, "dgrad3_s2", lambda: ops.pack_conv3d_weight(w.contiguous(), True, 2, split=True, f16=False, lazy=True))
+    return _cached(weight, ("dgrad3_t", stride), lambda: ops.pack_conv3d_weight(w.contiguous(), False, stride))
+
+
+def _dgrad2_s1(weight):
+    w = weight.detach()
+    return _cached(weight, "dgrad2_s1", lambda: ops.pack_conv2d_weight(
+        w.flip(2, 3).permute(1, 0, 2, 3).contiguous(), 1, split=True, f16=False, lazy=True))
+
+
+def _dgrad2_parity(weight):
+    return _cached(weight, "dgrad2_parity", lambda: [ops.pack_conv2d_weight(wc, 1) for wc in _parity_weights(weight.detach())])
+
+
 class _Conv3dCL(torch.autograd.Function):
     """x [B,D,H,W,Ci] -> raw convolution output [B,Do,Ho,Wo,Co] (no bias, no affine)."""
 
@@ -82,7 +111,7 @@ class _Conv3dCL(torch.autograd.Function):
         x = x.contiguous()
         w = weight.detach().contiguous()
         # (split-operand bf16 kernels where the shape has one)
-        packed = _cached(weight, ("pk3", transposed, stride), lambda: ops.pack_conv3d_weight(w, transposed, stride, split=True, f16=False, lazy=True))
+        packed = _pk3(weight, transposed, stride)
         if ops.split_companion(packed) is not None:
             ops.split_stage_names.add(f"train.{tag}.fwd")
         with ops.stage(f"train.{tag}.fwd"):
@@ -101,8 +130,7 @@ class _Conv3dCL(torch.autograd.Function):
         gx = gw = None
         if ctx.needs_input_grad[0]:
             if not transposed and stride == 1:
-                wt, pk = _cached(weight, "dgrad3_s1", lambda: (lambda t: (t, ops.pack_conv3d_weight(t, False, 1, split=True, f16=False, lazy=True)))(
-                    w.flip(2, 3, 4).permute(1, 0, 2, 3, 4).contiguous()))        # (Ci,Co,k) as a conv weight
+                wt, pk = _dgrad3(weight, False, 1)
                 if ops.split_companion(pk) is not None:
                     ops.split_stage_names.add(f"train.{tag}.dgrad")
                 with ops.stage(f"train.{tag}.dgrad"):
@@ -111,14 +139,14 @@ class _Conv3dCL(torch.autograd.Function):
                 if any(s % 2 for s in x.shape[1:4]):
                     raise ops.MvsHipError("stride-2 conv backward needs even D, H, W")
                 wc = w.contiguous()                                            # (Co,Ci,k) as a deconv weight
-                pk = _cached(weight, "dgrad3_s2", lambda: ops.pack_conv3d_weight(wc, True, 2, split=True, f16=False, lazy=True))
+                pk = _dgrad3(weight, False, 2)
                 if ops.split_companion(pk) is not None:
                     ops.split_stage_names.add(f"train.{tag}.dgrad")
                 with ops.stage(f"train.{tag}.dgrad"):
                     gx = ops.conv3d(g, wc, transposed=True, stride=2, channels_last=True, packed=pk)
             else:
                 wc = w.contiguous()                                            # (Ci,Co,k) as a conv weight
-                pk = _cached(weight, ("dgrad3_t", stride), lambda: ops.pack_conv3d_weight(wc, False, stride))
+                pk = _dgrad3(weight, True, stride)
                 with ops.stage(f"train.{tag}.dgrad"):
                     gx = ops.conv3d(g, wc, stride=stride, channels_last=True, packed=pk)
         if ctx.needs_input_grad[1]:
@@ -252,14 +280,13 @@ class _Conv2dCL(torch.autograd.Function):
             H, W = (x.shape[2], x.shape[3]) if planar else (x.shape[1], x.shape[2])
             with ops.stage("train.feature.dgrad"):
                 if stride == 1 and ops.conv2d_supported(cout, cin, k, 1) and not planar:
-                    pk = _cached(weight, "dgrad2_s1", lambda: ops.pack_conv2d_weight(
-                        w.flip(2, 3).permute(1, 0, 2, 3).contiguous(), 1, split=True, f16=False, lazy=True))
+                    pk = _dgrad2_s1(weight)
                     gx = ops.conv2d(g, pk, cout, cin, k, 1)
                 elif stride == 2 and k == 5 and not planar and H % 2 == 0 and W % 2 == 0 and \
                         ops.conv2d_supported(cout, cin, 3, 1):
                     N, Ho, Wo, _ = g.shape
                     cls = torch.empty(4, N, Ho, Wo, cin, device=g.device, dtype=torch.float32)
-                    pks = _cached(weight, "dgrad2_parity", lambda: [ops.pack_conv2d_weight(wc, 1) for wc in _parity_weights(w)])
+                    pks = _dgrad2_parity(weight)
                     for i, pk in enumerate(pks):
                         ops.conv2d(g, pk, cout, cin, 3, 1, out=cls[i])
                     gx = ops.interleave2x2(cls)
