@@ -66,7 +66,9 @@ extern "C" {
 #define MVS_LAYOUT_C8H 5 /* fp16 pairs of an 8-channel-blocked volume: tuning builds only, include/mvs_hip_tuning.h */
 
 /* Library version: major*10000 + minor*100 + patch.  101 (0.1.1): every *_f16*_packed_bytes size grew -- the fp32 weights
- * ride behind the packed fragments for the range guard -- so buffers sized by 100 are too small: re-query the sizes. */
+ * ride behind the packed fragments for the range guard -- so buffers sized by 100 are too small: re-query the sizes.
+ * 102 (0.1.2): mvs_conv3d_wgrad_c8_f16_* added; a planar input of mvs_conv2d_wgrad_f32 is the image (Cin <= 4, else
+ * MVS_EUNSUPPORTED); nothing a 101 caller sized or packed changes. */
 int mvs_version(void);
 /* Text of the last error on the calling thread ("" if none). */
 const char *mvs_last_error_string(void);

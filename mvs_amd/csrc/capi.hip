@@ -126,7 +126,7 @@ using namespace mvs;
 
 // 0.1.1: the *_f16*_packed_bytes sizes grew (the fp32 weights ride behind the packed fragments for the range guard) and the
 // c8h entry points left the release library -- a client sized by 0.1.0 must re-query
-extern "C" int mvs_version(void) { return 101; /* 0.1.1 */ }
+extern "C" int mvs_version(void) { return 102; /* 0.1.2 */ }
 extern "C" const char *mvs_last_error_string(void) { return g_err; }
 extern "C" const char *mvs_arch(void) { return "gfx950"; }
 

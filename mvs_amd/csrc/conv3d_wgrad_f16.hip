@@ -274,8 +274,8 @@ using namespace mvs;
 
 extern "C" int mvs_conv3d_wgrad_c8_f16_supported(int B, int Cin, int D, int H, int W) {
     if (Cin != 32 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
-    const int64_t vox = (int64_t)B * D * H * W;
-    return vox * 128 < 0xffffff00LL && vox * (int64_t)((W + 31) / 32) / W < 0x7fffffffLL ? 1 : 0;
+    const int64_t vox = (int64_t)B * D * H * W, chunks = (int64_t)B * D * H * ((W + 31) / 32);
+    return vox * 128 < 0xffffff00LL && chunks < 0x7fffffffLL ? 1 : 0;      // one buffer resource per tensor; chunk index in an int
 }
 
 extern "C" size_t mvs_conv3d_wgrad_c8_f16_workspace_bytes(int B, int Cin, int D, int H, int W) {
