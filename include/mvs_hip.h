@@ -67,7 +67,7 @@ extern "C" {
 
 /* Library version: major*10000 + minor*100 + patch.  101 (0.1.1): every *_f16*_packed_bytes size grew -- the fp32 weights
  * ride behind the packed fragments for the range guard -- so buffers sized by 100 are too small: re-query the sizes.
- * 102 (0.1.2): mvs_conv3d_wgrad_c8_f16_* added; a planar input of mvs_conv2d_wgrad_f32 is the image (Cin <= 4, else
+ * 102 (0.1.2): mvs_conv3d_wgrad_c8_f16_* and mvs_pack_batch_begin / _end added; a planar input of mvs_conv2d_wgrad_f32 is the image (Cin <= 4, else
  * MVS_EUNSUPPORTED); nothing a 101 caller sized or packed changes. */
 int mvs_version(void);
 /* Text of the last error on the calling thread ("" if none). */
@@ -283,6 +283,12 @@ int mvs_conv3d_c8_f16x3_f32(const float *in, const void *in_absmax, const void *
 int mvs_conv_split_supported(int kd, int Cin, int Cout, int stride);
 size_t mvs_conv_split_packed_bytes(int kd, int Cin, int Cout, int stride);
 int mvs_conv_split_pack_weights_f32(const float *weight, int kd, int Cin, int Cout, int stride, void *packed, void *stream);
+/* Several packs as ONE launch: between mvs_pack_batch_begin() and mvs_pack_batch_end(stream) on a thread, every
+ * mvs_conv_split_pack_weights_f32 call records its job (weight and packed pointers must stay valid) instead of launching;
+ * _end launches them together on `stream` (a training step re-packs every layer: 26 launches of microseconds of work).
+ * Other entry points are unaffected.  Errors: a second _begin, an _end without _begin (MVS_EINVAL). */
+int mvs_pack_batch_begin(void);
+int mvs_pack_batch_end(void *stream);
 int mvs_conv_split_f32(const float *in, const void *packed, const float *scale, const float *shift,
                        const float *residual, int relu, int kd, int stride, int B, int Cin, int Cout, int D, int H, int W,
                        int out_c4, float *out, void *stream);

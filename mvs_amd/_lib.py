@@ -68,6 +68,8 @@ _SIGS = {
     "mvs_conv_split_supported": (_c_i, [_c_i] * 4),
     "mvs_conv_split_packed_bytes": (ctypes.c_size_t, [_c_i] * 4),
     "mvs_conv_split_pack_weights_f32": (_c_i, [_c_f] + [_c_i] * 4 + [_c_f, _c_f]),
+    "mvs_pack_batch_begin": (_c_i, []),
+    "mvs_pack_batch_end": (_c_i, [_c_f]),
     "mvs_conv_split_f32": (_c_i, [_c_f] * 5 + [_c_i] * 10 + [_c_f, _c_f]),
     "mvs_conv_split_f16_packed_bytes": (ctypes.c_size_t, [_c_i] * 4),
     "mvs_conv_split_pack_weights_f16_f32": (_c_i, [_c_f] + [_c_i] * 4 + [_c_f, _c_f]),

@@ -15,6 +15,9 @@
 //                along x; per (row block, tap group) the B fragment is three ds_read_b128 (one per part), per
 //                (tap group, 16 output channels) the A fragment three more; six MFMAs per pair
 // Tiles of a group share the chunk's weights in LDS and keep their accumulators in registers over the chunk loop.
+#include <algorithm>
+#include <vector>
+
 #include "conv_split_common.h"
 #include "conv_guard.h"
 
@@ -587,10 +590,9 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_split_kernel(SplitArgs a, in
 // PyTorch-layout weight (Cout_total, Cin, [kd,] 3, 3), output channels [co0, co0 + COUT) ->
 // [step][group][m-tile][part][lane][8 bf16]; lane (mrow, kq): output channel co0 + m*16 + mrow, slot 4 g + kq = (tap,
 // chunk c of the step) (zero past the kernel), channel (step*cps + c)*8 + j
-__global__ __launch_bounds__(256) void pack_split_kernel(const float *__restrict__ w, int Cin, int Cout, int ntap, int cps, int G, int MT,
-                                                         int co0, unsigned short *__restrict__ out, int total) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
+// one element of a packed bf16 hi / mid / lo fragment buffer: i = ((step * G + g) * MT + m) * 512 + lane * 8 + j
+__device__ __forceinline__ void pack_split_element(const float *__restrict__ w, int Cin, int Cout, int ntap, int cps, int G, int MT, int co0,
+                                                   unsigned short *__restrict__ out, int i) {
     const int j = i & 7, lane = (i >> 3) & 63;
     int rest = i >> 9;
     const int m = rest % MT; rest /= MT;
@@ -607,6 +609,59 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const float *__restrict
     o[0] = __builtin_bit_cast(unsigned short, h);
     o[512] = __builtin_bit_cast(unsigned short, mm);
     o[1024] = __builtin_bit_cast(unsigned short, l);
+}
+
+__global__ __launch_bounds__(256) void pack_split_kernel(const float *__restrict__ w, int Cin, int Cout, int ntap, int cps, int G, int MT,
+                                                         int co0, unsigned short *__restrict__ out, int total) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    pack_split_element(w, Cin, Cout, ntap, cps, G, MT, co0, out, i);
+}
+
+// Several packs in one launch (mvs_pack_batch_begin / _end): a training step packs every layer's weights again, 26 launches
+// of a few microseconds of work each behind ~4 us of launch; recorded between begin and end they are ONE launch whose blocks
+// look their job up in the kernel arguments.
+struct PackSplitJob {
+    const float *w;
+    unsigned short *out;
+    int Cin, Cout, ntap, cps, G, MT, co0, total, block0;
+};
+constexpr int kPackBatch = 24;
+struct PackSplitBatch {
+    PackSplitJob job[kPackBatch];
+    int n;
+};
+__global__ __launch_bounds__(256) void pack_split_batch_kernel(PackSplitBatch b) {
+    PackSplitJob q = b.job[0];
+#pragma unroll
+    for (int k = 1; k < kPackBatch; ++k)
+        if (k < b.n && (int)blockIdx.x >= b.job[k].block0) q = b.job[k];     // (wave-uniform selects: no indexed copy of the table)
+    const int i = ((int)blockIdx.x - q.block0) * 256 + threadIdx.x;
+    if (i >= q.total) return;
+    pack_split_element(q.w, q.Cin, q.Cout, q.ntap, q.cps, q.G, q.MT, q.co0, q.out, i);
+}
+
+struct PackRecorder {
+    bool active = false;
+    std::vector<PackSplitJob> jobs;
+};
+static PackRecorder &pack_recorder() {
+    static thread_local PackRecorder r;
+    return r;
+}
+static int flush_pack_jobs(PackRecorder &r, hipStream_t st) {
+    for (size_t first = 0; first < r.jobs.size(); first += kPackBatch) {
+        PackSplitBatch b;
+        b.n = (int)std::min<size_t>(kPackBatch, r.jobs.size() - first);
+        int blocks = 0;
+        for (int k = 0; k < kPackBatch; ++k) {
+            b.job[k] = r.jobs[first + (k < b.n ? k : 0)];
+            if (k < b.n) { b.job[k].block0 = blocks; blocks += (b.job[k].total + 255) / 256; }
+        }
+        hipLaunchKernelGGL(pack_split_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, st, b);
+    }
+    r.jobs.clear();
+    return check_launch("mvs_pack_batch_end");
 }
 
 // the two-piece fp16 form of the same fragments: [step][group][m-tile][hi,lo][lane][8 fp16] of w * 2^(14 - exponent(max |w|))
@@ -731,10 +786,38 @@ extern "C" int mvs_conv_split_pack_weights_f32(const float *weight, int kd, int 
     const size_t per_launch = (size_t)(Cin / (8 * cps)) * G * MT * 3 * 1024;
     for (int co0 = 0; co0 < Cout; co0 += step) {
         const int total = (Cin / (8 * cps)) * G * MT * 512;
+        unsigned short *dst = reinterpret_cast<unsigned short *>(static_cast<unsigned char *>(packed) + (co0 / step) * per_launch);
+        PackRecorder &rec = pack_recorder();
+        if (rec.active) {     // between mvs_pack_batch_begin and _end: one launch for all of them at _end
+            PackSplitJob q = {weight, dst, Cin, Cout, ntap, cps, G, MT, co0, total, 0};
+            rec.jobs.push_back(q);
+            continue;
+        }
         hipLaunchKernelGGL(pack_split_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), weight, Cin, Cout, ntap, cps, G, MT,
-                           co0, reinterpret_cast<unsigned short *>(static_cast<unsigned char *>(packed) + (co0 / step) * per_launch), total);
+                           co0, dst, total);
     }
     return check_launch("mvs_conv_split_pack_weights_f32");
+}
+
+extern "C" int mvs_pack_batch_begin(void) {
+    PackRecorder &rec = pack_recorder();
+    if (rec.active) {
+        set_error("mvs_pack_batch_begin: a batch is already open on this thread");
+        return MVS_EINVAL;
+    }
+    rec.active = true;
+    rec.jobs.clear();
+    return MVS_OK;
+}
+
+extern "C" int mvs_pack_batch_end(void *stream) {
+    PackRecorder &rec = pack_recorder();
+    if (!rec.active) {
+        set_error("mvs_pack_batch_end: no batch is open on this thread");
+        return MVS_EINVAL;
+    }
+    rec.active = false;
+    return flush_pack_jobs(rec, as_stream(stream));
 }
 
 // np = 3: the bf16 form; np = 2: the fp16 form (in_absmax required).  out_absmax: NULL, or the absmax block the largest

@@ -398,6 +398,9 @@ class MVSNet(nn.Module):
                 # reference (mvsnet.py:146)
                 feats_cl = feats_stacked = None
                 if self.train_feature_impl == "hip" and self.feature.hip_supported():
+                    if self.train_impl == "hip":
+                        from .. import train_ops
+                        train_ops.prepare_step(self.feature, self.cost_regularization)   # the step's packs up front, the bf16 ones as one launch
                     if self.train_feature_batched:
                         # the V per-view calls as one batch of V groups (view-major): per-view BatchNorm statistics, one launch per layer
                         Bn = imgs.shape[0]

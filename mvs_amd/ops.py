@@ -4,6 +4,7 @@ Tensors in, tensors out; device memory and streams come from PyTorch-ROCm,
 every FLOP of the cost-volume path runs in the hand-written HIP kernels.
 There is no fallback: CPU tensors or a missing library raise MvsHipError.
 """
+import contextlib
 import ctypes
 import threading
 
@@ -862,6 +863,36 @@ def conv3d_c8h_f16x3(x_pairs, shape, packed, x_absmax, scale=None, shift=None, r
     return out
 
 
+_pack_batch_tls = threading.local()
+
+
+def _pack_batch_state():
+    st = getattr(_pack_batch_tls, "st", None)
+    if st is None:
+        st = _pack_batch_tls.st = {"open": False, "keep": []}
+    return st
+
+
+@contextlib.contextmanager
+def pack_batch():
+    """Within the block every bf16 split pack (pack_conv_weight_split) is recorded and all of them run as ONE launch at the
+    end (mvs_pack_batch_begin / _end): the training step's prepare pass.  Source weights -- temporaries such as the flipped
+    weights of an input-gradient layer included -- are kept alive until then.  Not re-entrant."""
+    st = _pack_batch_state()
+    if st["open"]:
+        yield
+        return
+    check(_lib.load().mvs_pack_batch_begin(), "mvs_pack_batch_begin")
+    st["open"] = True
+    try:
+        yield
+    finally:
+        st["open"] = False
+        rc = _lib.load().mvs_pack_batch_end(stream())
+        st["keep"].clear()
+        check(rc, "mvs_pack_batch_end")
+
+
 def pack_conv_weight_split(weight, stride=1):
     """(Cout, Cin, [3,] 3, 3) weight -> the bf16 hi/mid/lo A fragments of conv_split (None if the shape has no
     such kernel: stride 1 with Cin, Cout in {16, 32, 64}; 3D stride 2 with Cin in {8, 16, 32}; 2D stride 2 = the
@@ -875,6 +906,9 @@ def pack_conv_weight_split(weight, stride=1):
     if n == 0:
         return None
     packed = torch.empty(n // 4, device=weight.device, dtype=torch.float32)   # opaque bytes
+    st = _pack_batch_state()
+    if st["open"]:
+        st["keep"].append((weight, packed))
     check(_lib.load().mvs_conv_split_pack_weights_f32(ptr(weight), kd, int(weight.shape[1]), int(weight.shape[0]), stride,
                                                       ptr(packed), stream()), "mvs_conv_split_pack_weights_f32")
     return packed

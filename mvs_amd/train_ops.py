@@ -103,6 +103,48 @@ def _dgrad2_parity(weight):
     return _cached(weight, "dgrad2_parity", lambda: [ops.pack_conv2d_weight(wc, 1) for wc in _parity_weights(weight.detach())])
 
 
+def _pk2(weight, stride):
+    """Forward pack of a 2D layer."""
+    return _cached(weight, ("pk2", stride),
+                   lambda: ops.pack_conv2d_weight(weight.detach().contiguous(), stride, split=True, f16=False, lazy=True))
+
+
+def prepare_step(feature, costreg):
+    """Every weight-derived tensor a training step will ask for -- FeatureNet's and CostRegNet's forward packs, every
+    layer's input-gradient weights and packs -- made up front with the bf16 split packs recorded and run as ONE launch
+    (ops.pack_batch: 26 launches of a few microseconds of work otherwise).  Entries land in the same cache the layers look
+    in, so a layer this pass does not know simply makes its own on first use.  MVS_TRAIN_PREPARE=0 switches it off."""
+    import os
+    if os.environ.get("MVS_TRAIN_PREPARE", "1") == "0":
+        return
+    with ops.pack_batch():
+        for name, stride in feature._PLAN:
+            w = getattr(feature, name).conv.weight
+            cout, cin, k, _ = w.shape
+            _pk2(w, stride)
+            if name == feature._PLAN[0][0]:
+                continue                       # the image needs no gradient
+            if stride == 1 and ops.conv2d_supported(cout, cin, k, 1):
+                _dgrad2_s1(w)
+            elif stride == 2 and k == 5 and ops.conv2d_supported(cout, cin, 3, 1):
+                _dgrad2_parity(w)
+        w = feature.feature.weight
+        _pk2(w, 1)
+        if ops.conv2d_supported(w.shape[0], w.shape[1], w.shape[2], 1):
+            _dgrad2_s1(w)
+        for name in ("conv1", "conv2", "conv3", "conv4", "conv5", "conv6"):
+            m = getattr(costreg, name)
+            stride = m.conv.stride[0]
+            _pk3(m.conv.weight, False, stride)
+            _dgrad3(m.conv.weight, False, stride)
+        for name in ("conv7", "conv9", "conv11"):
+            w = getattr(costreg, name)[0].weight
+            _pk3(w, True, 2)
+            _dgrad3(w, True, 2)
+        _pk3(costreg.prob.weight, False, 1)
+        _dgrad3(costreg.prob.weight, False, 1)
+
+
 class _Conv3dCL(torch.autograd.Function):
     """x [B,D,H,W,Ci] -> raw convolution output [B,Do,Ho,Wo,Co] (no bias, no affine)."""
 
@@ -261,7 +303,7 @@ class _Conv2dCL(torch.autograd.Function):
         x = x.contiguous()
         w = weight.detach().contiguous()
         cout, cin, k, _ = w.shape
-        pk = _cached(weight, ("pk2", stride), lambda: ops.pack_conv2d_weight(w, stride, split=True, f16=False, lazy=True))
+        pk = _pk2(weight, stride)
         with ops.stage("train.feature.fwd"):
             out = ops.conv2d(x, pk, cin, cout, k, stride, None, None, False, planar=planar)
         ctx.save_for_backward(x, weight)

@@ -1422,6 +1422,30 @@ def test_cas_hypotheses_kernel_vs_torch_ops(dev, case):
     np.testing.assert_allclose(got.numpy(), want.numpy(), atol=3e-4, rtol=0)
 
 
+def test_pack_batch_equals_single_launches(dev):
+    """ops.pack_batch (mvs_pack_batch_begin / _end): the bf16 split packs recorded inside the block and run as one launch are
+    bit-identical to the same packs launched one by one -- 3D and 2D layers, a layer with several cout blocks, more jobs than
+    one batch holds, temporaries as sources -- and the batch calls reject misuse."""
+    from mvs_amd import ops, _lib
+    g = torch.Generator(device=dev).manual_seed(11)
+    shapes = [(16, 16, 3, 3, 3), (32, 32, 3, 3, 3), (64, 64, 3, 3, 3), (32, 16, 3, 3, 3), (16, 16, 3, 3), (32, 32, 3, 3),
+              (16, 8, 5, 5), (32, 16, 5, 5)] * 4            # 32 layers, > 24 jobs
+    ws = [torch.randn(*sh, device=dev, generator=g) for sh in shapes]
+    stride = lambda w: 2 if (w.shape[-1] == 5 or (w.dim() == 5 and w.shape[0] == 2 * w.shape[1])) else 1
+    single = [ops.pack_conv_weight_split(w, stride(w)) for w in ws]
+    with ops.pack_batch():
+        batched = [ops.pack_conv_weight_split(w.clone() * 1.0, stride(w)) for w in ws]      # (sources are temporaries)
+    torch.cuda.synchronize()
+    assert all(p is not None for p in single)
+    for a, b in zip(single, batched):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    lib = _lib.load()
+    assert lib.mvs_pack_batch_end(None) != 0            # no batch open
+    assert lib.mvs_pack_batch_begin() == 0
+    assert lib.mvs_pack_batch_begin() != 0              # already open
+    assert lib.mvs_pack_batch_end(None) == 0            # (an empty batch launches nothing)
+
+
 def test_training_ops_reject_unsupported_shapes(dev):
     """The fused BatchNorm op and the weight-gradient kernel fail loudly (no silent torch
     fallback inside ops) on shapes they have no kernel for."""
