@@ -276,6 +276,7 @@ __global__ __launch_bounds__(1024) void variance_choose_kernel(PersistArgs a, in
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid < 2) { s_max[tid] = 0; s_sum[tid] = 0; s_cnt[tid] = 0; }
     if (tid < kAbsmaxWords && a.absmax) a.absmax[tid] = 0u;
+    if (tid < kQueueHdr) hdr[tid] = 0u;      // the candidates' queue header (was a memset node in front of this kernel)
     __syncthreads();
     const int tiles_x = (p.W + kPW - 1) / kPW, tiles_y = (p.H + kPH - 1) / kPH;
     for (int t = wv; t < 54 * p.B; t += 16) {
@@ -781,7 +782,6 @@ int launch_variance_choose(const float *rt, const float *depth, const SweepParam
         a.sy = (float)((double)p.H / (double)(p.H - 1)); a.oy = -0.5f;
     }
     const int NV = p.V - 1;
-    if (hipMemsetAsync(workspace, 0, 4 * kQueueHdr, st) != hipSuccess) return check_launch("variance workspace memset");
     hipLaunchKernelGGL(variance_choose_kernel, dim3(1), dim3(1024), 0, st, a, NV, persist_cap(NV, 2), allow_tile,
                        static_cast<unsigned *>(workspace));
     return check_launch("variance_choose_kernel");
