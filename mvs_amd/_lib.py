@@ -135,6 +135,9 @@ _TUNING_SIGS = {
     "mvs_c8h_bytes": (ctypes.c_size_t, [_c_i] * 5),
     "mvs_c8_to_c8h_f32": (_c_i, [_c_f, _c_f] + [_c_i] * 5 + [_c_f, _c_f]),
     "mvs_conv3d_c8h_f16x3_f32": (_c_i, [_c_f] * 6 + [_c_i] * 6 + [_c_f, _c_f, _c_f]),
+    "mvs_c8p_bytes": (ctypes.c_size_t, [_c_i] * 6),
+    "mvs_c8_to_c8p_f32": (_c_i, [_c_f, _c_f] + [_c_i] * 6 + [_c_f, _c_f]),
+    "mvs_conv3d_c8p_f16x3_f32": (_c_i, [_c_f] * 6 + [_c_i] * 8 + [_c_f, _c_f, _c_f]),
 }
 
 

@@ -462,6 +462,11 @@ __global__ __launch_bounds__(256) void pack_f16x3_kernel(const float *__restrict
 
 }  // namespace mvs
 
+namespace mvs {
+int launch_conv3d_c8_f16x3_y8(ConvArgs a, int Cin, int variant, const unsigned *in_absmax, unsigned *out_absmax,
+                              unsigned long long *guard_cnt, hipStream_t st);   // conv_f16x3_y8.hip
+}
+
 using namespace mvs;
 
 static bool f16x3_shape_ok(int Cin) { return Cin == 8 || Cin == 16 || Cin == 32; }
@@ -547,6 +552,9 @@ extern "C" int mvs_conv3d_c8_f16x3_f32(const float *in, const void *in_absmax, c
     const unsigned *mx = static_cast<const unsigned *>(in_absmax);
     unsigned *omx = static_cast<unsigned *>(out_absmax);
     unsigned long long *const gc = guard_counter();
+    // eight-row tiles (conv_f16x3_y8.hip; bit-identical results): MVS_CONV0_Y8 = 2 (two barriers per step), 1 (one), 0 = this file's kernel
+    static const int y8 = [] { const char *e = getenv("MVS_CONV0_Y8"); return e ? atoi(e) : 0; }();
+    if (y8 == 1 || y8 == 2) return launch_conv3d_c8_f16x3_y8(a, Cin, y8, mx, omx, gc, st);
 #ifdef MVS_TUNING   // phase-stamp build: cycle counters written through `residual` (scripts/exp_conv0_f16.py)
     static const int abl = [] { const char *e = getenv("MVS_CONV_SPLIT_ABL"); return e ? atoi(e) : 0; }();
     if ((abl & 128) && Cin == 32) {

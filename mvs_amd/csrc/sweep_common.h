@@ -102,6 +102,44 @@ inline bool grid_for(int64_t total, int per_block, unsigned &grid) {
 }
 
 
+// ---- hand-over of the variance volume as two fp16 pieces per value (round 6; conv_f16x3_y8p.hip has the kernel that reads it and
+// the layouts): byte strides of a pairs volume
+struct PairsGeom {
+    int64_t plane;          // between depth planes
+    int64_t chunk;          // between 8-channel chunks of a plane
+    int64_t xtile;          // C8PT: between 32-voxel x tiles (0 for C8P)
+    int64_t region;         // between (part, parity) blocks: H * rowpitch
+    int rowpitch;           // between rows of a block
+    int tiled;              // 1 = C8PT
+};
+constexpr int kPairsLayoutRows = 6, kPairsLayoutTiled = 7;   // = MVS_LAYOUT_C8P / MVS_LAYOUT_C8PT (include/mvs_hip.h)
+__host__ __device__ inline PairsGeom pairs_geom(int C, int H, int W, int layout) {
+    PairsGeom g;
+    g.tiled = layout == kPairsLayoutTiled;
+    g.rowpitch = g.tiled ? 17 * 16 : ((W + 1) / 2) * 16;
+    g.region = (int64_t)H * g.rowpitch;
+    g.xtile = g.tiled ? 4 * g.region : 0;
+    g.chunk = g.tiled ? (int64_t)((W + 31) / 32) * g.xtile : 4 * g.region;
+    g.plane = (int64_t)(C / 8) * g.chunk;
+    return g;
+}
+// What the sweep kernels need to hand the volume over (all device pointers; hand == NULL: the fp32 volume as ever).
+//   fea_absmax  in: absmax block of ALL feature maps (reference + sources).  var = E[x^2] - E[x]^2 <= max |f|^2: the scale of
+//               the pieces comes from that BOUND, known before the sweep runs (the volume's true maximum is not).
+//   hand        the chooser kernel fills its 256 words with the bits of the bound when the volume is to be written as pairs
+//               (a persistent candidate was chosen and the bound is finite), else with a NaN pattern = "fp32 MVS_LAYOUT_C8";
+//               every later kernel decides on word 0 / the block's maximum.
+//   redo        one word: zeroed by the chooser; set by the conv0 kernel that takes the pairs when it cannot (no pairs, or the
+//               volume's true absmax block fails the range rule against the bound); the fp32 kernels behind it run only then.
+struct SweepHandover {
+    const unsigned *fea_absmax = nullptr;
+    unsigned *hand = nullptr;
+    unsigned *redo = nullptr;
+    int layout = 0;           // kPairsLayoutRows / kPairsLayoutTiled
+    int redo_all = 0;         // cold kernel only: serve EVERY (tile, wave) in fp32, provided *redo != 0 and hand holds a bound
+};
+__device__ __forceinline__ bool hand_is_pairs(unsigned bits) { return bits < 0x7f800000u; }
+
 // sweep_persist.hip: the persistent kernel for shared depth planes and 16-channel-blocked
 // features (+ its cold-path kernel); MVS_EUNSUPPORTED (nothing launched) when the shape is not
 // its own.  The workspace holds the cold path's queue.
@@ -110,11 +148,16 @@ bool variance_persist_shape_ok(const SweepParams &p);     // the ONE predicate o
 int launch_variance_persist(const float *ref16, const float *srcs16, const float *rt,
                             const float *depth, const SweepParams &p, float *out, int out_c8,
                             int fea_c4, int fast, int nw, int nq, int flags, void *workspace,
-                            size_t workspace_bytes, hipStream_t st, int autosel = 0, unsigned *absmax = nullptr);
+                            size_t workspace_bytes, hipStream_t st, int autosel = 0, unsigned *absmax = nullptr,
+                            const SweepHandover *ho = nullptr);
 // device-side choice between 16-plane tiles, 8-plane tiles and (allow_tile) the per-tile kernel of sweep.hip from the
 // footprints of sample tiles; clears the workspace header (and the absmax block the candidates collect the largest
 // |variance| in, if given) and writes the choice into word 1 of the header
 int launch_variance_choose(const float *rt, const float *depth, const SweepParams &p, int allow_tile, unsigned *absmax,
-                           void *workspace, hipStream_t st);
+                           void *workspace, hipStream_t st, const SweepHandover *ho = nullptr);
+// the cold kernel alone over every (tile, wave) of the 16-plane tiling, fp32 MVS_LAYOUT_C8 output, gated by ho->redo (the
+// never-taken path behind a declined hand-over: global gathers, ~10x the persistent kernel's time)
+int launch_variance_redo_all(const float *ref16, const float *srcs16, const float *rt, const float *depth, const SweepParams &p,
+                             float *out, int fea_c4, int fast, void *workspace, hipStream_t st, const SweepHandover &ho);
 
 }  // namespace mvs

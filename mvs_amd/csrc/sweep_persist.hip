@@ -39,6 +39,7 @@
 // 1614 VALU instructions per wave-tile-plane FAST (2216 EXACT; per-tile kernel 2103), LDS
 // array busy 46 % of the kernel, 17 % of its cycles conflicted (per-tile kernel: 54 %).
 #include "sweep_common.h"
+#include "split2.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -70,7 +71,22 @@ struct PersistArgs {
     int autosel;            // 1: run only if queue[kSelWord] names this kernel's tile depth (variance_choose_kernel)
     unsigned *absmax;       // NULL, or the absmax block (mvs_common.h) that collects the largest |variance| written
                             // (atomic max; the operand scale of mvs_conv3d_c8_f16x3_f32)
+    SweepHandover ho;       // ho.hand != NULL: the volume may leave as two fp16 pieces per value (sweep_common.h)
+    PairsGeom pg;           // ... in this layout; `out` then holds max(fp32, pairs) bytes
 };
+// Byte offset of a voxel's hi piece inside its (plane, chunk) block of a pairs volume (the lo piece: + 2 * pg.region), and -- x-tiled
+// layout -- of its second copy as a halo voxel of the neighbouring 32-voxel tile (0xffffffff: none).
+__device__ __forceinline__ void pairs_offsets(const PairsGeom &pg, int x, int y, int W, unsigned &main, unsigned &dup) {
+    dup = 0xffffffffu;
+    if (!pg.tiled) {
+        main = (unsigned)((x & 1) * pg.region + (int64_t)y * pg.rowpitch + (x >> 1) * 16);
+        return;
+    }
+    const int tx = x >> 5, xl = (x & 31) + 1;     // local x' = 1 .. 32 of the tile's 0 .. 33
+    main = (unsigned)(tx * pg.xtile + (xl & 1) * pg.region + (int64_t)y * pg.rowpitch + (xl >> 1) * 16);
+    if (xl == 32 && (tx + 1) * 32 < W) dup = (unsigned)((tx + 1) * pg.xtile + (int64_t)y * pg.rowpitch);                      // x' = 0 of tile tx + 1
+    else if (xl == 1 && tx > 0) dup = (unsigned)((tx - 1) * pg.xtile + pg.region + (int64_t)y * pg.rowpitch + 16 * 16);      // x' = 33 of tile tx - 1
+}
 // workspace header (32-bit words): [0] cold-path records, [1] the chosen tile depth (16, 8, or 0 = the per-tile
 // kernel), [2..7] what the choice was made from (largest / mean footprint box of 16- and 8-plane tiles, texels; box
 // samples), records from word 8
@@ -81,6 +97,7 @@ constexpr int kPFlagNoBlend = 4;       // tuning
 constexpr int kPFlagNoDma = 8;         // tuning (results are garbage)
 constexpr int kPFlagNoTaps = 32;       // tuning: constant tap set (garbage)
 constexpr int kPFlagContiguous = 64;   // tuning: one contiguous, pixel-tile-major unit range per CU (round 2's first schedule)
+constexpr int kPFlagNoDup = 128;       // tuning: x-tiled pairs without the halo copies (wrong results at tile borders)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int OFF>
@@ -165,12 +182,17 @@ template <int NV, bool FAST>
 __global__ __launch_bounds__(256) void variance_fwd_cold_kernel(PersistArgs a, int nw) {
     const SweepParams &p = a.p;
     int nchunks = a.nchunks;
-    if (a.autosel) {   // one launch behind both candidates: the records are the chosen kernel's
+    const unsigned hb = a.ho.hand ? a.ho.hand[0] : 0xffffffffu;
+    if (a.ho.redo_all) {   // behind a declined hand-over: every (tile, wave) of the 16-plane tiling, fp32 output
+        if (*a.ho.redo == 0u || !hand_is_pairs(hb)) return;
+    } else if (a.autosel) {   // one launch behind both candidates: the records are the chosen kernel's
         nw = (int)a.queue[kSelWord];
         if (nw == 0) return;
         nchunks = (p.D + nw - 1) / nw;
     }
-    const unsigned count = a.queue[0];
+    const bool pairs = !a.ho.redo_all && hand_is_pairs(hb);
+    const float ps = pow2f(14 - absmax_exponent(hb));
+    const unsigned count = a.ho.redo_all ? (unsigned)a.total_tiles * (unsigned)nw : a.queue[0];
     const int lane = threadIdx.x & 63;
     const int plane = p.H * p.W, ngroups = p.C >> 4;
     const size_t grp_floats = (size_t)plane * 16, map_floats = (size_t)plane * p.C;
@@ -178,7 +200,7 @@ __global__ __launch_bounds__(256) void variance_fwd_cold_kernel(PersistArgs a, i
     const float rV = 1.0f / p.fV;
     float vmax = 0.0f;
     for (unsigned rec = blockIdx.x * 4 + (threadIdx.x >> 6); rec < count; rec += gridDim.x * 4) {
-        const unsigned q = a.queue[kQueueHdr + rec];
+        const unsigned q = a.ho.redo_all ? ((rec / (unsigned)nw) << 4 | (rec % (unsigned)nw)) : a.queue[kQueueHdr + rec];
         int t = (int)(q >> 4);
         const int wv = (int)(q & 15u);
         const int dc = t % nchunks; t /= nchunks;
@@ -204,6 +226,10 @@ __global__ __launch_bounds__(256) void variance_fwd_cold_kernel(PersistArgs a, i
             o10[v] = (unsigned)(y1c * p.W + x0c) * tex; o11[v] = (unsigned)(y1c * p.W + x1c) * tex;
         }
         float *pl = a.out + ((size_t)b * p.D + d) * ((size_t)plane * p.C);
+        unsigned char *const plp = reinterpret_cast<unsigned char *>(a.out) + ((size_t)b * p.D + d) * a.pg.plane;
+        unsigned pmain = 0, pdup = 0xffffffffu;
+        if (pairs) pairs_offsets(a.pg, cx, cy, p.W, pmain, pdup);
+        float keep[4] = {0.f, 0.f, 0.f, 0.f};      // pairs: the even quad of an 8-channel chunk waits for the odd one
 #pragma unroll 1
         for (int gk = 0; gk < ngroups * 4; ++gk) {
             const int g = gk >> 2, k = gk & 3;
@@ -246,7 +272,24 @@ __global__ __launch_bounds__(256) void variance_fwd_cold_kernel(PersistArgs a, i
                     var[c] = Q[c] / p.fV - m * m;
                 }
             }
-            if (live && !(a.flags & kPFlagNoStore)) {
+            if (pairs) {
+                if (!(gk & 1)) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) keep[c] = var[c];
+                } else if (live && !(a.flags & kPFlagNoStore)) {
+                    f32x4 v0 = {keep[0], keep[1], keep[2], keep[3]}, v1 = {var[0], var[1], var[2], var[3]};
+                    vmax = amax4_nan(amax4_nan(vmax, keep[0], keep[1], keep[2], keep[3]), var[0], var[1], var[2], var[3]);
+                    u32x4 h, l;
+                    split2_block(v0, v1, ps, h, l);
+                    unsigned char *const ch = plp + (size_t)(gk >> 1) * a.pg.chunk;
+                    *reinterpret_cast<u32x4 *>(ch + pmain) = h;
+                    *reinterpret_cast<u32x4 *>(ch + pmain + 2 * a.pg.region) = l;
+                    if (pdup != 0xffffffffu && !(a.flags & kPFlagNoDup)) {
+                        *reinterpret_cast<u32x4 *>(ch + pdup) = h;
+                        *reinterpret_cast<u32x4 *>(ch + pdup + 2 * a.pg.region) = l;
+                    }
+                }
+            } else if (live && !(a.flags & kPFlagNoStore)) {
                 float *o = a.out_c8
                     ? pl + ((unsigned)(py * (p.C >> 3) + (g * 2 + (k >> 1))) * (unsigned)p.W + (unsigned)px) * 8u + (k & 1) * 4
                     : pl + (unsigned)pix * (unsigned)p.C + (unsigned)(g * 16 + k * 4);
@@ -274,7 +317,9 @@ __global__ __launch_bounds__(1024) void variance_choose_kernel(PersistArgs a, in
     __shared__ int s_max[2], s_sum[2], s_cnt[2];
     const SweepParams &p = a.p;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ unsigned s_fmax, s_choice;
     if (tid < 2) { s_max[tid] = 0; s_sum[tid] = 0; s_cnt[tid] = 0; }
+    if (tid == 0) { s_fmax = 0u; if (a.ho.redo) *a.ho.redo = 0u; }
     if (tid < kAbsmaxWords && a.absmax) a.absmax[tid] = 0u;
     if (tid < kQueueHdr) hdr[tid] = 0u;      // the candidates' queue header (was a memset node in front of this kernel)
     __syncthreads();
@@ -325,8 +370,19 @@ __global__ __launch_bounds__(1024) void variance_choose_kernel(PersistArgs a, in
         else if (m8 <= 0.52f * (float)cap || !allow_tile) choice = 8;
         else choice = 0;
         hdr[kSelWord] = choice;
+        s_choice = choice;
         hdr[2] = (unsigned)s_max[0]; hdr[3] = (unsigned)(m16 + 0.5f); hdr[4] = (unsigned)s_max[1]; hdr[5] = (unsigned)(m8 + 0.5f);
         hdr[6] = (unsigned)s_cnt[0]; hdr[7] = (unsigned)cap;
+    }
+    // the hand-over block (sweep_common.h): the bound max |f|^2 of the variance when a persistent candidate runs and the bound is
+    // finite, else a NaN pattern = "the volume leaves as fp32"
+    if (a.ho.hand) {
+        if (tid < kAbsmaxWords) atomicMax(&s_fmax, a.ho.fea_absmax[tid]);
+        __syncthreads();
+        const float f = __uint_as_float(s_fmax), bound = f * f;
+        const unsigned bb = __float_as_uint(bound);
+        const bool ok = s_choice != 0u && s_fmax < 0x7f800000u && bb < 0x7f800000u;
+        if (tid < kAbsmaxWords) a.ho.hand[tid] = ok ? bb : 0x7fc00000u;
     }
 }
 
@@ -390,6 +446,10 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
         }
     }
     if (u >= u_end) return;
+    // hand-over (sweep_common.h): the chooser has left the bound in a.ho.hand, or a NaN pattern = store fp32 as ever
+    const unsigned hb = a.ho.hand ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.ho.hand[0]) : 0xffffffffu;
+    const bool pairs = hand_is_pairs(hb);
+    const float ps = pow2f(14 - absmax_exponent(hb));
 
     // camera rows and depth planes into LDS: inside the loop nothing but the copies and the
     // stores touches vector memory, so a counted vmcnt can tell them apart
@@ -535,7 +595,7 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
     issue_dma(0, 0u);
     unsigned buf_off = 0;
     const float rV = 1.0f / p.fV;
-    bool stored = false;   // did this wave issue its NST stores after the last copy it issued?
+    int stored = 0;        // store instructions this wave has issued after the last copy it issued (0: wait for everything)
     float vmax = 0.0f;     // largest |variance| this lane has stored
 
 #pragma unroll 1
@@ -584,11 +644,16 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
         if (!hot && wave_live && lane == 0) {
             const unsigned slot = atomicAdd(a.queue, 1u);
             a.queue[kQueueHdr + slot] = ((unsigned)T << 4) | (unsigned)wv;
-            stored = false;   // more vector-memory traffic behind the last copy: wait for all of it
+            stored = 0;   // more vector-memory traffic behind the last copy: wait for all of it
         }
         const bool has_next = pdc + 1 < seg_end || u + u_step < u_end;
         const bool any_live = __ballot(live) != 0ull;
         float *const pl = a.out + ((size_t)cb * p.D + cd) * ((size_t)plane * p.C);   // wave-uniform plane base
+        unsigned char *const plp = reinterpret_cast<unsigned char *>(a.out) + ((size_t)cb * p.D + cd) * a.pg.plane;   // ... of a pairs volume
+        unsigned pmain = 0, pdup = 0xffffffffu;
+        if (pairs) pairs_offsets(a.pg, cx, cy, p.W, pmain, pdup);
+        if (!live || (a.flags & kPFlagNoDup)) pdup = 0xffffffffu;
+        const bool any_dup = pairs && __ballot(pdup != 0xffffffffu) != 0ull;
 
 #pragma unroll 1
         for (int st = 0; st < nstage; ++st) {
@@ -613,13 +678,14 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
             // stores issued behind them are still in flight -- waiting for those too would put a
             // full HBM write latency into every stage), for every wave, and nobody still reads
             // the other buffer.
-            if (stored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+            if (stored == NST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+            else if (stored == 2 * NST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NST) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (!last) issue_dma(st + 1, buf_off ^ kBufBytes);
             else if (has_next) issue_dma(0, buf_off ^ kBufBytes);
-            stored = false;
+            stored = 0;
 
             if (wave_live && hot && !(a.flags & kPFlagNoBlend)) {
                 // Taps by hand-issued ds_read_b128, one (view, channel quad) batch of four ahead of
@@ -706,7 +772,32 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
                 }
 #pragma unroll
                 for (int c = 0; c < GC; ++c) asm volatile("" : "+v"(var[c]));   // formed here, not inside the `if`
-                if (any_live && !(a.flags & kPFlagNoStore)) {
+                if (any_live && !(a.flags & kPFlagNoStore) && pairs) {
+                    // hand-over: scale by the power of two of the bound, split into two fp16 pieces (split2.h), one 16-byte store per
+                    // piece -- the same NST = 2 store instructions as the fp32 form; x-tiled layout: the tile's border column once more
+                    // into the neighbouring tile's block (2 more instructions, four lanes each)
+                    static_assert(GC == 8, "a stage = one 8-channel chunk");
+                    f32x4 v0 = {var[0], var[1], var[2], var[3]}, v1 = {var[4], var[5], var[6], var[7]};
+                    if (live) {
+#pragma unroll
+                        for (int c = 0; c < GC; c += 2) vmax = max_nan(max_nan(vmax, __builtin_fabsf(var[c])), __builtin_fabsf(var[c + 1]));
+                    }
+                    u32x4 hp, lp;
+                    split2_block(v0, v1, ps, hp, lp);
+                    unsigned char *const ch = plp + (size_t)st * a.pg.chunk;
+                    if (live) {
+                        *reinterpret_cast<u32x4 *>(ch + pmain) = hp;
+                        *reinterpret_cast<u32x4 *>(ch + pmain + 2 * a.pg.region) = lp;
+                    }
+                    stored = NST;
+                    if (any_dup) {
+                        if (pdup != 0xffffffffu) {
+                            *reinterpret_cast<u32x4 *>(ch + pdup) = hp;
+                            *reinterpret_cast<u32x4 *>(ch + pdup + 2 * a.pg.region) = lp;
+                        }
+                        stored = 2 * NST;
+                    }
+                } else if (any_live && !(a.flags & kPFlagNoStore)) {
                     // exactly NST store instructions per wave (lanes outside the volume masked off)
                     float *o = a.out_c8
                         ? pl + ((unsigned)(cy * (p.C >> 3) + st * (NQ / 2)) * (unsigned)p.W + (unsigned)cx) * 8u   // [B,D,H,C/8,W,8]
@@ -721,7 +812,7 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
 #pragma unroll
                         for (int c = 0; c < GC; c += 2) vmax = max_nan(max_nan(vmax, __builtin_fabsf(var[c])), __builtin_fabsf(var[c + 1]));
                     }
-                    stored = true;
+                    stored = NST;
                 }
             }
             buf_off ^= kBufBytes;
@@ -773,9 +864,10 @@ bool variance_persist_shape_ok(const SweepParams &p) { return persist_shape_ok(p
 
 // the chooser in front of the candidate kernels (all of them launched with autosel)
 int launch_variance_choose(const float *rt, const float *depth, const SweepParams &p, int allow_tile, unsigned *absmax, void *workspace,
-                           hipStream_t st) {
+                           hipStream_t st, const SweepHandover *ho) {
     PersistArgs a{};
     a.rt = rt; a.depth = depth; a.p = p; a.absmax = absmax;
+    if (ho) a.ho = *ho;
     if (p.align_corners) { a.sx = 1.0f; a.ox = 0.0f; a.sy = 1.0f; a.oy = 0.0f; }
     else {
         a.sx = (float)((double)p.W / (double)(p.W - 1)); a.ox = -0.5f;
@@ -790,7 +882,7 @@ int launch_variance_choose(const float *rt, const float *depth, const SweepParam
 int launch_variance_persist(const float *ref16, const float *srcs16, const float *rt,
                             const float *depth, const SweepParams &p, float *out, int out_c8,
                             int fea_c4, int fast, int nw, int nq, int flags, void *workspace,
-                            size_t workspace_bytes, hipStream_t st, int autosel, unsigned *absmax) {
+                            size_t workspace_bytes, hipStream_t st, int autosel, unsigned *absmax, const SweepHandover *ho) {
     if ((nw != 8 && nw != 16) || nq != 2) return MVS_EUNSUPPORTED;
     const size_t need = variance_persist_workspace_bytes(p, nw);
     if (need == 0) return MVS_EUNSUPPORTED;
@@ -798,8 +890,14 @@ int launch_variance_persist(const float *ref16, const float *srcs16, const float
         set_error("mvs_costvol_variance_fwd_ws_f32: workspace of %zu bytes, need %zu", workspace_bytes, need);
         return MVS_EWORKSPACE;
     }
-    PersistArgs a;
+    PersistArgs a{};
     a.ref16 = ref16; a.srcs16 = srcs16; a.rt = rt; a.depth = depth; a.out = out; a.p = p;
+    if (ho) {
+        if (!autosel || !out_c8 || p.C % 8) return bare_error(MVS_EINVAL, __func__, __LINE__);   // the chooser writes ho->hand
+        a.ho = *ho;
+        a.pg = pairs_geom(p.C, p.H, p.W, ho->layout);
+        if (a.pg.plane >= 0xffffffffLL) return bare_error(MVS_EINVAL, __func__, __LINE__);       // 32-bit per-lane offsets
+    }
     a.queue = static_cast<unsigned *>(workspace);
     a.tiles_x = (p.W + kPW - 1) / kPW;
     a.tiles_y = (p.H + kPH - 1) / kPH;
@@ -836,6 +934,39 @@ int launch_variance_persist(const float *ref16, const float *srcs16, const float
     MVS_PERSIST_PICK(16, 2) MVS_PERSIST_PICK(8, 2)
 #undef MVS_PERSIST_PICK
     return MVS_EUNSUPPORTED;
+}
+
+int launch_variance_redo_all(const float *ref16, const float *srcs16, const float *rt, const float *depth, const SweepParams &p,
+                             float *out, int fea_c4, int fast, void *workspace, hipStream_t st, const SweepHandover &ho) {
+    if (!persist_shape_ok(p) || !ho.redo || !ho.hand) return bare_error(MVS_EINVAL, __func__, __LINE__);
+    const int nw = 16, NV = p.V - 1;
+    PersistArgs a{};
+    a.ref16 = ref16; a.srcs16 = srcs16; a.rt = rt; a.depth = depth; a.out = out; a.p = p;
+    a.queue = static_cast<unsigned *>(workspace);
+    a.tiles_x = (p.W + kPW - 1) / kPW;
+    a.tiles_y = (p.H + kPH - 1) / kPH;
+    a.nchunks = (p.D + nw - 1) / nw;
+    a.total_tiles = (int)persist_tiles(p, nw);
+    a.out_c8 = 1; a.fea_c4 = fea_c4;
+    a.ho = ho; a.ho.redo_all = 1;
+    if (p.align_corners) { a.sx = 1.0f; a.ox = 0.0f; a.sy = 1.0f; a.oy = 0.0f; }
+    else {
+        a.sx = (float)((double)p.W / (double)(p.W - 1)); a.ox = -0.5f;
+        a.sy = (float)((double)p.H / (double)(p.H - 1)); a.oy = -0.5f;
+    }
+    const int grid = 8 * device_cu_count();
+#define MVS_REDO_CASE(n)                                                                                                      \
+    case n:                                                                                                                   \
+        if (fast) hipLaunchKernelGGL((variance_fwd_cold_kernel<n, true>), dim3(grid), dim3(256), 0, st, a, nw);               \
+        else hipLaunchKernelGGL((variance_fwd_cold_kernel<n, false>), dim3(grid), dim3(256), 0, st, a, nw);                   \
+        break;
+    switch (NV) {
+        MVS_REDO_CASE(1) MVS_REDO_CASE(2) MVS_REDO_CASE(3) MVS_REDO_CASE(4)
+        MVS_REDO_CASE(5) MVS_REDO_CASE(6) MVS_REDO_CASE(7) MVS_REDO_CASE(8)
+        default: return MVS_EUNSUPPORTED;
+    }
+#undef MVS_REDO_CASE
+    return check_launch("variance_fwd_cold_kernel (redo)");
 }
 
 }  // namespace mvs
