@@ -698,7 +698,28 @@ def main():
                             "steps": 5, "roofline": cvp.get("roofline"), "peak_mem_GB": cvp.get("peak_mem_gb"),
                             "depth_maxabs_vs_reference_mm": cvp.get("depth_maxabs_vs_reference_mm_per_level"),
                             "checker": cvp.get("golden")} if "error" not in cvp else cvp)
+    line["summary"] = compact_summary(line)     # LAST key: the driver keeps the final 2,000 characters of the line
     print(json.dumps(line), flush=True)
+
+
+def compact_summary(line):
+    """The numbers a reader of a truncated line needs, in <= 600 characters: headline, dominant kernel, the training step of
+    configs[4], the exact-operand and two-stream figures, configs[2] / configs[3], guard fall-backs."""
+    def g(d, *ks):
+        for k in ks:
+            d = d.get(k) if isinstance(d, dict) else None
+        return d
+    rf = line.get("roofline") or {}
+    s = {"value": line.get("value"), "ms": line.get("ms_per_step"), "n_gpus": line.get("n_gpus"),
+         "dom": str(rf.get("kernel", ""))[:28], "dom_ms": rf.get("ms"), "frac": rf.get("frac"),
+         "train_ms": g(line, "train", "ms_per_step"), "train_frac": g(line, "train", "roofline", "frac"),
+         "exact_value": line.get("value_exact_operands"), "two_streams": g(line, "two_streams", "value"),
+         "cascade_ms": g(line, "cascade", "ms_per_step"), "cvp_ms": g(line, "cvp", "ms_per_step"),
+         "cpu_s": g(line, "cpu_baseline", "seconds"), "cpu_diff_mm": g(line, "cpu_baseline", "max_abs_depth_diff_vs_gpu_mm"),
+         "guard_fallbacks": line.get("guard_fallbacks")}
+    s = {k: (round(v, 5) if isinstance(v, float) else v) for k, v in s.items() if v is not None}
+    assert len(json.dumps(s)) <= 600, len(json.dumps(s))
+    return s
 
 
 if __name__ == "__main__":

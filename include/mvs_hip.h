@@ -64,11 +64,24 @@ extern "C" {
 #define MVS_LAYOUT_C16 3
 #define MVS_LAYOUT_C4 4
 #define MVS_LAYOUT_C8H 5 /* fp16 pairs of an 8-channel-blocked volume: tuning builds only, include/mvs_hip_tuning.h */
+/* An 8-channel-blocked VOLUME as two fp16 pieces per value, hi = fp16(x s), lo = fp16(x s - hi), s a power of two taken from an
+ * absmax block (4 bytes per element like fp32; mvs_amd/csrc/conv_f16x3_y8p.hip has the byte layouts).  16-byte piece = the 8
+ * channels of one voxel and part; parity = of the voxel's x.
+ *   MVS_LAYOUT_C8P  (6): [B, D, C/8, part (hi, lo), parity, H, ceil(W/2)] pieces
+ *   MVS_LAYOUT_C8PT (7): [B, D, C/8, ceil(W/32), part, local parity, H, 17] pieces -- x-tiled, each 32-voxel tile with its two halo
+ *                        columns (+6 % bytes): what a hand-over sweep writes and conv0 reads ten rows at a time as one run */
+#define MVS_LAYOUT_C8P 6
+#define MVS_LAYOUT_C8PT 7
 
 /* Library version: major*10000 + minor*100 + patch.  101 (0.1.1): every *_f16*_packed_bytes size grew -- the fp32 weights
  * ride behind the packed fragments for the range guard -- so buffers sized by 100 are too small: re-query the sizes.
  * 102 (0.1.2): mvs_conv3d_wgrad_c8_f16_* and mvs_pack_batch_begin / _end added; a planar input of mvs_conv2d_wgrad_f32 is the image (Cin <= 4, else
- * MVS_EUNSUPPORTED); nothing a 101 caller sized or packed changes. */
+ * MVS_EUNSUPPORTED); mvs_costreg_fwd3_f32, the fused tail entry points and mvs_conv2d_pair_* added; mvs_costreg_workspace_bytes grew
+ * by 64 flag words (re-query it).
+ * 103 (0.1.3): the hand-over of the variance volume as fp16 pieces -- mvs_costvol_variance_fwd_ws3_f32 / _handover_bytes,
+ * mvs_conv3d_c8p_f16x3_f32, mvs_conv3d_c8_handed_f16x3_f32, mvs_c8p_bytes, mvs_c8_to_c8p_f32, mvs_conv3d_f16x3_pack_veto_word, mvs_costreg_fwd4_f32; a launch
+ * under a run-only-if word that has no kernel honouring it now fails with MVS_EUNSUPPORTED instead of running unconditionally;
+ * mvs_costreg_tail_guarded_f16_f32 needs prob's packed weights.  Nothing a 102 caller sized or packed changes. */
 int mvs_version(void);
 /* Text of the last error on the calling thread ("" if none). */
 const char *mvs_last_error_string(void);
@@ -407,6 +420,47 @@ int mvs_costreg_tail_guarded_f16_f32(const float *in, const void *in_absmax, con
 int mvs_costreg_fwd3_f32(const float *in, int in_layout, const mvs_conv_layer *layers, const void *const *packed_f16,
                          const void *packed_tail, int B, int Cin, int base, int D, int H, int W, int impl, void *workspace,
                          size_t workspace_bytes, const void *in_absmax, float *out_cost, void *stream);
+
+/* ---- hand-over of the variance volume as fp16 pieces (round 6) ------------------------------------------------------------
+ * conv0 on the two-piece fp16 kernel spent a third of its time turning fp32 planes into pieces between two barriers.  The sweep
+ * holds every variance in a register anyway: it can store the pieces, under a scale known BEFORE it runs -- var = E[x^2] - E[x]^2
+ * <= max|f|^2 over all feature maps, whose absmax block FeatureNet's last layer collects.  No host synchronisation anywhere:
+ *
+ *   mvs_costvol_variance_fwd_ws3_f32   = ..._ws2_f32 for shared depth planes on the device-selected persistent kernels (else
+ *       MVS_EUNSUPPORTED, nothing launched), fea_layout C16 / C4 / NHWC.  out_volume (mvs_costvol_variance_handover_bytes) receives
+ *       MVS_LAYOUT_C8PT pieces scaled by 2^(14 - exponent(bound)), hand (MVS_ABSMAX_WORDS words) the bits of the bound, var_absmax the
+ *       volume's TRUE largest magnitude, *redo = 0 -- or, *redo = 1, the plain fp32 MVS_LAYOUT_C8 volume: when the chooser took the
+ *       per-tile kernel, when the bound is not finite, when *reader_veto (optional: one float of the reader, e.g.
+ *       mvs_conv3d_f16x3_pack_veto_word) is NaN, or when the pieces do not hold (true maximum not finite or outlier-dominated --
+ *       conv_guard.h's rule -- or more than 8 binary orders below the bound): in that last case a referee launch behind the sweep
+ *       computes the volume again in fp32 (slow; the path of broken inputs).
+ *   mvs_conv3d_c8p_f16x3_f32   conv0 (3x3x3, Cout 8, stride 1) on such pieces, eight-row tiles, copies straight into the plane ring:
+ *       returns at once if redo != NULL and *redo != 0.  in_absmax = the block the pieces were scaled by (`hand`).  Same results bit
+ *       for bit as mvs_conv3d_c8_f16x3_f32 on the fp32 volume with that block.  npair = 4.
+ *   mvs_costreg_fwd4_f32   = fwd3 on the sweep's output: conv0 on the pieces, then mvs_conv3d_c8_f16x3_f32 on the fp32 volume under
+ *       *redo as its run-only-if word -- exactly one of the two runs.
+ *   mvs_c8_to_c8p_f32 / mvs_c8p_bytes   an fp32 MVS_LAYOUT_C8 volume into pieces (tests, other producers). */
+size_t mvs_costvol_variance_handover_bytes(int B, int C, int D, int H, int W);
+int mvs_costvol_variance_fwd_ws3_f32(const float *ref_fea, const float *src_feas, const float *rot_trans,
+                                     const float *depth_values, int B, int V, int C, int D, int H, int W,
+                                     int align_corners, int fea_layout, int flags, const void *fea_absmax,
+                                     const void *reader_veto, void *out_volume, void *workspace, size_t workspace_bytes,
+                                     void *var_absmax, void *hand, void *redo, void *stream);
+size_t mvs_c8p_bytes(int B, int C, int D, int H, int W, int layout);
+int mvs_c8_to_c8p_f32(const float *in_c8, const void *absmax, int B, int C, int D, int H, int W, int layout, void *out_pairs, void *stream);
+int mvs_conv3d_c8p_f16x3_f32(const void *in_pairs, const void *in_absmax, const void *redo, const void *packed, const float *scale,
+                             const float *shift, const float *residual, int relu, int B, int Cin, int D, int H, int W,
+                             int layout, int npair, float *out, void *out_absmax, void *stream);
+/* conv0 on whatever the sweep left: the kernel on the pieces, then mvs_conv3d_c8_f16x3_f32 on the fp32 volume under *redo as its
+ * run-only-if word -- exactly one of the two writes out (and maxes into out_absmax) */
+int mvs_conv3d_c8_handed_f16x3_f32(const void *volume, const void *hand, const void *redo, const void *var_absmax,
+                                   const void *packed, const float *scale, const float *shift, const float *residual, int relu,
+                                   int B, int Cin, int D, int H, int W, float *out, void *out_absmax, void *stream);
+const void *mvs_conv3d_f16x3_pack_veto_word(const void *packed, int Cin);
+int mvs_costreg_fwd4_f32(const void *in_volume, const void *hand, const void *redo, const void *var_absmax,
+                         const mvs_conv_layer *layers, const void *const *packed_f16, const void *packed_tail, int B, int Cin,
+                         int base, int D, int H, int W, int impl, void *workspace, size_t workspace_bytes, float *out_cost,
+                         void *stream);
 
 /* Weight gradient of one 3x3x3 layer (training, BASELINE config 5; the reference gets it from
  * autograd through nn.Conv3d / nn.ConvTranspose3d, module.py:26-33, mvsnet.py:66-79):

@@ -24,15 +24,9 @@ int mvs_conv3d_c8h_f16x3_f32(const void *in_pairs, const void *in_absmax, const 
                              const float *shift, const float *residual, int relu, int B, int Cin, int D, int H, int W,
                              float *out, void *out_absmax, void *stream);
 
-/* Round 6: the same hand-over with eight-row tiles (mvs_amd/csrc/conv_f16x3_y8p.hip has the layouts and the kernel).
- * layout = MVS_LAYOUT_C8P (6) or MVS_LAYOUT_C8PT (7); npair = 4 (copies two steps ahead) or 5 (three). */
-#define MVS_LAYOUT_C8P 6
-#define MVS_LAYOUT_C8PT 7
-size_t mvs_c8p_bytes(int B, int C, int D, int H, int W, int layout);
-int mvs_c8_to_c8p_f32(const float *in_c8, const void *absmax, int B, int C, int D, int H, int W, int layout, void *out_pairs, void *stream);
-int mvs_conv3d_c8p_f16x3_f32(const void *in_pairs, const void *in_absmax, const void *packed, const float *scale,
-                             const float *shift, const float *residual, int relu, int B, int Cin, int D, int H, int W,
-                             int layout, int npair, float *out, void *out_absmax, void *stream);
+/* (round 6: the hand-over with eight-row tiles is in the release library -- include/mvs_hip.h, mvs_conv3d_c8p_f16x3_f32; the tuning
+ * build also takes npair = 5 there and MVS_CONV0_Y8 = 1 | 2 selects the eight-row kernels that keep the staging buffer,
+ * mvs_amd/csrc/conv_f16x3_y8.hip) */
 
 #ifdef __cplusplus
 }

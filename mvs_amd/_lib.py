@@ -19,6 +19,8 @@ MVS_LAYOUT_C8 = 2
 MVS_LAYOUT_C16 = 3
 MVS_LAYOUT_C4 = 4
 MVS_LAYOUT_C8H = 5
+MVS_LAYOUT_C8P = 6
+MVS_LAYOUT_C8PT = 7
 
 _c_f = ctypes.c_void_p   # device pointers travel as integers
 _c_i = ctypes.c_int
@@ -38,6 +40,14 @@ _SIGS = {
     "mvs_costvol_variance_workspace_bytes": (ctypes.c_size_t, [_c_i] * 8),
     "mvs_costvol_variance_workspace_bytes2": (ctypes.c_size_t, [_c_i] * 9),
     "mvs_costvol_variance_fwd_ws_f32": (_c_i, [_c_f] * 4 + [_c_i] * 12 + [_c_f, _c_f, ctypes.c_size_t, _c_f]),
+    "mvs_costvol_variance_handover_bytes": (ctypes.c_size_t, [_c_i] * 5),
+    "mvs_costvol_variance_fwd_ws3_f32": (_c_i, [_c_f] * 4 + [_c_i] * 9 + [_c_f, _c_f, _c_f, _c_f, ctypes.c_size_t, _c_f, _c_f, _c_f, _c_f]),
+    "mvs_c8p_bytes": (ctypes.c_size_t, [_c_i] * 6),
+    "mvs_c8_to_c8p_f32": (_c_i, [_c_f, _c_f] + [_c_i] * 6 + [_c_f, _c_f]),
+    "mvs_conv3d_c8p_f16x3_f32": (_c_i, [_c_f] * 7 + [_c_i] * 8 + [_c_f, _c_f, _c_f]),
+    "mvs_conv3d_c8_handed_f16x3_f32": (_c_i, [_c_f] * 8 + [_c_i] * 6 + [_c_f, _c_f, _c_f]),
+    "mvs_conv3d_f16x3_pack_veto_word": (ctypes.c_void_p, [_c_f, _c_i]),
+    "mvs_costreg_fwd4_f32": (_c_i, [_c_f] * 7 + [_c_i] * 7 + [_c_f, ctypes.c_size_t, _c_f, _c_f]),
     "mvs_costvol_variance_fwd_ws2_f32": (_c_i, [_c_f] * 4 + [_c_i] * 12 + [_c_f, _c_f, ctypes.c_size_t, _c_f, _c_f]),
     "mvs_selftest_div_by_views_f32": (_c_i, [_c_i, _c_f, _c_f]),
     "mvs_costvol_variance_bwd_f32": (_c_i, [_c_f] * 5 + [_c_i] * 10 + [_c_f, _c_f, _c_f]),
@@ -135,9 +145,6 @@ _TUNING_SIGS = {
     "mvs_c8h_bytes": (ctypes.c_size_t, [_c_i] * 5),
     "mvs_c8_to_c8h_f32": (_c_i, [_c_f, _c_f] + [_c_i] * 5 + [_c_f, _c_f]),
     "mvs_conv3d_c8h_f16x3_f32": (_c_i, [_c_f] * 6 + [_c_i] * 6 + [_c_f, _c_f, _c_f]),
-    "mvs_c8p_bytes": (ctypes.c_size_t, [_c_i] * 6),
-    "mvs_c8_to_c8p_f32": (_c_i, [_c_f, _c_f] + [_c_i] * 6 + [_c_f, _c_f]),
-    "mvs_conv3d_c8p_f16x3_f32": (_c_i, [_c_f] * 6 + [_c_i] * 8 + [_c_f, _c_f, _c_f]),
 }
 
 

@@ -16,9 +16,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(CSRC, "libmvs_hip.so")
-SOURCES = ("capi", "sweep", "sweep_persist", "regress", "conv3d_direct", "conv3d_mfma", "costreg", "conv_bf16x6", "conv_f16x3", "conv_f16x3_y8", "conv_split", "conv_s2_march", "deconv_split", "tail_fused", "conv2d_pair", "conv2d_mfma", "feature_head", "fpn_tail", "conv3d_wgrad", "conv3d_wgrad_f16", "conv2d_wgrad", "bnorm", "cas_hypo", "geo_filter", "cvp_hypo", "cvp_glue", "imgprep", "fusibile", "camera")
+SOURCES = ("capi", "sweep", "sweep_persist", "regress", "conv3d_direct", "conv3d_mfma", "costreg", "conv_bf16x6", "conv_f16x3", "conv_f16x3_y8p", "conv_split", "conv_s2_march", "deconv_split", "tail_fused", "conv2d_pair", "conv2d_mfma", "feature_head", "fpn_tail", "conv3d_wgrad", "conv3d_wgrad_f16", "conv2d_wgrad", "bnorm", "cas_hypo", "geo_filter", "cvp_hypo", "cvp_glue", "imgprep", "fusibile", "camera")
 # experiments kept with their tests, compiled into the tuning build only (dead weight in the release .so)
-TUNING_SOURCES = ("conv_f16x3_pairs", "conv_f16x3_y8p")
+TUNING_SOURCES = ("conv_f16x3_pairs", "conv_f16x3_y8")
 HEADERS = (os.path.join(CSRC, "mvs_common.h"), os.path.join(CSRC, "sweep_common.h"), os.path.join(CSRC, "conv_persistent.h"), os.path.join(CSRC, "conv_split_common.h"), os.path.join(CSRC, "conv_guard.h"), os.path.join(CSRC, "split2.h"),
            os.path.join(os.path.dirname(HERE), "include", "mvs_hip_tuning.h"), os.path.join(os.path.dirname(HERE), "include", "mvs_hip.h"))
 # -ffp-contract=off: the plane-sweep coordinate arithmetic places its FMAs by

@@ -124,9 +124,9 @@ static int launch_transpose(const float *in, float *out, int B, int R, int64_t S
 
 using namespace mvs;
 
-// 0.1.1: the *_f16*_packed_bytes sizes grew (the fp32 weights ride behind the packed fragments for the range guard) and the
-// c8h entry points left the release library -- a client sized by 0.1.0 must re-query
-extern "C" int mvs_version(void) { return 102; /* 0.1.2 */ }
+// the changelog is in include/mvs_hip.h above mvs_version(): 0.1.1 re-query the *_f16*_packed_bytes sizes, 0.1.2 re-query
+// mvs_costreg_workspace_bytes, 0.1.3 the hand-over entry points
+extern "C" int mvs_version(void) { return 103; /* 0.1.3 */ }
 extern "C" const char *mvs_last_error_string(void) { return g_err; }
 extern "C" const char *mvs_arch(void) { return "gfx950"; }
 
@@ -239,6 +239,14 @@ extern "C" int mvs_conv3d_absmax_f32(const float *in, const float *weight, const
     // out_absmax: the MFMA convolutions collect it in their epilogue; behind every other kernel, one more pass over `out`
     const int64_t nout = transposed ? (int64_t)B * Cout * (2 * D) * (2 * H) * (2 * W)
                                     : (int64_t)B * Cout * ((D - 1) / stride + 1) * ((H - 1) / stride + 1) * ((W - 1) / stride + 1);
+    // a "run only if" word is in scope (mvs_common.h: conv_run_flag): only the Cout = 1 MFMA kernels read it -- any other kernel would
+    // run unconditionally on a scratch volume nobody wrote, so refuse instead
+    if (conv_run_flag() && !((impl == 2 || (impl == 0 && mfma_ok)) && !transposed && Cout == 1 && stride == 1)) {
+        set_error("mvs_conv3d_f32: a run-only-if flag is in scope and this shape (%s Cin=%d Cout=%d stride=%d, packed %s, plane window %s) "
+                  "has no kernel that honours it", transposed ? "deconv" : "conv", Cin, Cout, stride, packed_weight ? "yes" : "no",
+                  window_ok ? "ok" : "too large");
+        return MVS_EUNSUPPORTED;
+    }
     if (impl == 2 || (impl == 0 && mfma_ok)) {
         bool collected = false;
         const int rc = conv3d_mfma_launch(in, packed_weight, scale, shift, residual, relu, transposed, B,

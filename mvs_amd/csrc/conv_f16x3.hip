@@ -56,6 +56,7 @@ __global__ __launch_bounds__(kFThreads) void conv3d_c8_f16x3_zs_kernel(ConvArgs 
     const bool copier = wv >= 8;
     const int cw = wv - 8;       // copy wave index
 
+    if (a.run_flag && *a.run_flag == 0u) return;      // (uniform: a launch in front of this one did the work -- conv_f16x3_y8p.hip on a handed-over volume)
     // operand scale of the input and what undoes it and the weights' scale (the trailer of the packed weights)
     const AbsmaxVerdict verdict = absmax_verdict(in_absmax);
     const int xe = absmax_exponent(verdict.bits);
@@ -544,6 +545,7 @@ extern "C" int mvs_conv3d_c8_f16x3_f32(const float *in, const void *in_absmax, c
     a.Do = D; a.Ho = H; a.Wo = W;
     a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 3) / 4; a.tiles_z = (D + 3) / 4;
     a.relu = relu; a.in_c8 = 1; a.ystrip = 8; a.res_up2 = 0;
+    a.run_flag = conv_run_flag();
     const int64_t ng = (int64_t)B * a.tiles_x * a.tiles_y * ((a.tiles_z + kFGroup - 1) / kFGroup);
     if (ng <= 0 || ng > 0x7fffffffLL) return bare_error(MVS_EINVAL, __func__, __LINE__);
     const int n_cu = device_cu_count();
@@ -552,10 +554,12 @@ extern "C" int mvs_conv3d_c8_f16x3_f32(const float *in, const void *in_absmax, c
     const unsigned *mx = static_cast<const unsigned *>(in_absmax);
     unsigned *omx = static_cast<unsigned *>(out_absmax);
     unsigned long long *const gc = guard_counter();
-    // eight-row tiles (conv_f16x3_y8.hip; bit-identical results): MVS_CONV0_Y8 = 2 (two barriers per step), 1 (one), 0 = this file's kernel
+#ifdef MVS_TUNING
+    // eight-row tiles with the staging buffer kept (conv_f16x3_y8.hip; bit-identical results, no faster: profiles/r06_conv0_y8.json):
+    // MVS_CONV0_Y8 = 2 (two barriers per step), 1 (one), 0 = this file's kernel
     static const int y8 = [] { const char *e = getenv("MVS_CONV0_Y8"); return e ? atoi(e) : 0; }();
     if (y8 == 1 || y8 == 2) return launch_conv3d_c8_f16x3_y8(a, Cin, y8, mx, omx, gc, st);
-#ifdef MVS_TUNING   // phase-stamp build: cycle counters written through `residual` (scripts/exp_conv0_f16.py)
+    // phase-stamp build: cycle counters written through `residual` (scripts/exp_conv0_f16.py)
     static const int abl = [] { const char *e = getenv("MVS_CONV_SPLIT_ABL"); return e ? atoi(e) : 0; }();
     if ((abl & 128) && Cin == 32) {
         if (!residual) return bare_error(MVS_EINVAL, __func__, __LINE__);

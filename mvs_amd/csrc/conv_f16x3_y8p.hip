@@ -62,7 +62,11 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {   // wave-uniform n: at 
 template <int CIN, int NPAIR, int ABL = 0>
 __global__ __launch_bounds__(kYPThreads) void conv3d_c8p_f16x3_kernel(ConvArgs a, PairsGeom pg, int ngroups,
                                                                       const unsigned *__restrict__ in_absmax,
+                                                                      const unsigned *__restrict__ redo,
                                                                       unsigned *__restrict__ out_absmax) {
+    // hand-over protocol (sweep_common.h): *redo != 0 = the volume is fp32 after all; the fp32 kernel enqueued behind this launch
+    // (mvs_conv3d_c8_f16x3_f32 under that word as its run-only-if flag) serves it
+    if (redo && *redo != 0u) return;
     constexpr int NCHUNK = CIN / 8, YT = kYPRows, T = kYPT, AHEAD = NPAIR - 2;
     constexpr int NSLOT = 2 * NPAIR;
     constexpr int WBYTES = kYPChunkBytes, WCOPIES = WBYTES / 1024;
@@ -86,6 +90,8 @@ __global__ __launch_bounds__(kYPThreads) void conv3d_c8p_f16x3_kernel(ConvArgs a
     // the producer scaled by 2^(14 - exponent(block)); the weights' scale is the trailer of their pack
     const int xe = absmax_exponent(load_absmax(in_absmax));
     const float isx = pow2f(xe - 14);
+    // (non-finite weights leave a NaN here: every output becomes NaN.  A hand-over sweep that was given this word as its veto,
+    // mvs_costvol_variance_fwd_ws3_f32, never lets it come to that: the volume is then fp32 and conv_f16x3.hip's guard serves it)
     const float isw = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(
         __builtin_bit_cast(int, a.wpk[(size_t)NCHUNK * (WBYTES / 4)])));
 
@@ -408,8 +414,14 @@ using namespace mvs;
 
 extern "C" size_t mvs_conv3d_f16x3_packed_bytes(int Cin);
 
+// the word of a conv0 pack that is NaN when the layer's weights are not finite -- what a hand-over sweep takes as its veto
+extern "C" const void *mvs_conv3d_f16x3_pack_veto_word(const void *packed, int Cin) {
+    if (!packed || mvs_conv3d_f16x3_packed_bytes(Cin) == 0) return nullptr;
+    return static_cast<const unsigned char *>(packed) + (size_t)(Cin / 8) * kYPChunkBytes;
+}
+
 extern "C" size_t mvs_c8p_bytes(int B, int C, int D, int H, int W, int layout) {
-    if (B <= 0 || C <= 0 || C % 8 || D <= 0 || H <= 0 || W <= 0 || (layout != MVS_LAYOUT_C8P && layout != MVS_LAYOUT_C8PT)) return 0;
+    if (B <= 0 || C <= 0 || C % 8 || D <= 0 || H <= 0 || W <= 0 || (layout != kPairsLayoutRows && layout != kPairsLayoutTiled)) return 0;
     return (size_t)B * D * pairs_geom(C, H, W, layout).plane;
 }
 
@@ -425,13 +437,18 @@ extern "C" int mvs_c8_to_c8p_f32(const float *in, const void *absmax, int B, int
     return check_launch("mvs_c8_to_c8p_f32");
 }
 
-extern "C" int mvs_conv3d_c8p_f16x3_f32(const void *in_pairs, const void *in_absmax, const void *packed, const float *scale,
+extern "C" int mvs_conv3d_c8p_f16x3_f32(const void *in_pairs, const void *in_absmax, const void *redo, const void *packed, const float *scale,
                                         const float *shift, const float *residual, int relu, int B, int Cin,
                                         int D, int H, int W, int layout, int npair, float *out, void *out_absmax, void *stream) {
+#ifdef MVS_TUNING
+    const bool npair_ok = npair == 4 || npair == 5;
+#else
+    const bool npair_ok = npair == 4;        // (copies three steps ahead, npair 5, measured no faster: tuning build only)
+#endif
     if (!in_pairs || !in_absmax || !packed || !out || mvs_c8p_bytes(B, Cin, D, H, W, layout) == 0 || mvs_conv3d_f16x3_packed_bytes(Cin) == 0 ||
-        (npair != 4 && npair != 5)) {
+        !npair_ok) {
         set_error("mvs_conv3d_c8p_f16x3_f32: invalid argument (Cin in {8, 16, 32}, Cout = 8, stride 1; in_pairs = MVS_LAYOUT_C8P / C8PT volume, "
-                  "in_absmax = the block it was scaled by, packed = mvs_conv3d_pack_weights_f16x3_f32, npair 4 or 5)");
+                  "in_absmax = the block it was scaled by, packed = mvs_conv3d_pack_weights_f16x3_f32, npair 4)");
         return MVS_EINVAL;
     }
     const PairsGeom pg = pairs_geom(Cin, H, W, layout);
@@ -450,7 +467,8 @@ extern "C" int mvs_conv3d_c8p_f16x3_f32(const void *in_pairs, const void *in_abs
     const dim3 grid((unsigned)(ng < n_cu ? ng : n_cu)), blk(kYPThreads);
     const unsigned *mx = static_cast<const unsigned *>(in_absmax);
     unsigned *omx = static_cast<unsigned *>(out_absmax);
-#define MVS_YP_LAUNCH(C, NP, AB) hipLaunchKernelGGL((conv3d_c8p_f16x3_kernel<C, NP, AB>), grid, blk, 0, st, a, pg, (int)ng, mx, omx)
+    const unsigned *rd = static_cast<const unsigned *>(redo);
+#define MVS_YP_LAUNCH(C, NP, AB) hipLaunchKernelGGL((conv3d_c8p_f16x3_kernel<C, NP, AB>), grid, blk, 0, st, a, pg, (int)ng, mx, rd, omx)
 #ifdef MVS_TUNING
     static const int abl = [] { const char *e = getenv("MVS_CONV_SPLIT_ABL"); return e ? atoi(e) : 0; }();
     if ((abl & 128) && Cin == 32) {
@@ -465,9 +483,34 @@ extern "C" int mvs_conv3d_c8p_f16x3_f32(const void *in_pairs, const void *in_abs
 #endif
     if (npair == 4) {
         if (Cin == 32) MVS_YP_LAUNCH(32, 4, 0); else if (Cin == 16) MVS_YP_LAUNCH(16, 4, 0); else MVS_YP_LAUNCH(8, 4, 0);
-    } else {
+    }
+#ifdef MVS_TUNING
+    else {
         if (Cin == 32) MVS_YP_LAUNCH(32, 5, 0); else if (Cin == 16) MVS_YP_LAUNCH(16, 5, 0); else MVS_YP_LAUNCH(8, 5, 0);
     }
+#endif
 #undef MVS_YP_LAUNCH
     return check_launch("mvs_conv3d_c8p_f16x3_f32");
+}
+
+// conv0 on the volume of a hand-over sweep (include/mvs_hip.h): the kernel above on the pieces (returns at once if *redo != 0), then
+// mvs_conv3d_c8_f16x3_f32 on the fp32 volume under *redo as its run-only-if word (returns at once if *redo == 0) -- exactly one of
+// the two writes `out` and maxes into out_absmax.  No host synchronisation.
+extern "C" int mvs_conv3d_c8_handed_f16x3_f32(const void *volume, const void *hand, const void *redo, const void *var_absmax,
+                                              const void *packed, const float *scale, const float *shift, const float *residual, int relu,
+                                              int B, int Cin, int D, int H, int W, float *out, void *out_absmax, void *stream) {
+    if (!hand || !redo || !var_absmax) {
+        set_error("mvs_conv3d_c8_handed_f16x3_f32: needs the hand-over block, the redo word and the volume's absmax block of "
+                  "mvs_costvol_variance_fwd_ws3_f32");
+        return MVS_EINVAL;
+    }
+    int rc = mvs_conv3d_c8p_f16x3_f32(volume, hand, redo, packed, scale, shift, residual, relu, B, Cin, D, H, W, kPairsLayoutTiled, 4, out,
+                                      out_absmax, stream);
+    if (rc != MVS_OK) return rc;
+    struct FlagScope {
+        explicit FlagScope(const void *f) { conv_run_flag() = static_cast<const unsigned *>(f); }
+        ~FlagScope() { conv_run_flag() = nullptr; }
+    } scope(redo);
+    return mvs_conv3d_c8_f16x3_f32(static_cast<const float *>(volume), var_absmax, packed, scale, shift, residual, relu, B, Cin, D, H, W, out,
+                                   out_absmax, stream);
 }

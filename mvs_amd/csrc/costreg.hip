@@ -52,6 +52,13 @@ extern "C" int mvs_costreg_tail_guarded_f16_f32(const float *in, const void *in_
                   "volume for the unfused path and a zeroed flag word");
         return MVS_EINVAL;
     }
+    // the unfused `prob` behind the flag must be the Cout = 1 MFMA kernel (the only one that reads the word): it needs the packed
+    // weights and nine output-resolution planes inside 32-bit offsets (capi.hip: window_ok) -- checked BEFORE anything is enqueued
+    if (!prob->packed || (int64_t)9 * (2 * Hi) * (2 * Wi) * 8 * 4 >= 0xffffff00LL) {
+        set_error("mvs_costreg_tail_guarded_f16_f32: the guarded fall-back needs prob's packed weights and an output plane of fewer than "
+                  "%lld voxels (2Hi x 2Wi = %d x %d)", (long long)(0xffffff00LL / (9 * 8 * 4)), 2 * Hi, 2 * Wi);
+        return MVS_EUNSUPPORTED;
+    }
     int rc = mvs_costreg_tail_f16_f32(in, in_absmax, skip, skip_absmax, packed_tail, conv11->scale, conv11->shift, prob->weight,
                                       prob->scale, prob->shift, B, Di, Hi, Wi, out_cost, flag, stream);
     if (rc != MVS_OK) return rc;
@@ -67,13 +74,21 @@ extern "C" int mvs_costreg_tail_guarded_f16_f32(const float *in, const void *in_
 }
 
 // layers: the eleven layers; f16 = their two-piece fp16 packs or NULL (the entry of before those existed)
+// hand / redo: non-NULL with in_layout = MVS_LAYOUT_C8PT -- the volume of a hand-over sweep (mvs_costvol_variance_fwd_ws3_f32): two
+// fp16 pieces per value scaled by the bound in `hand` if *redo == 0, an fp32 MVS_LAYOUT_C8 volume if *redo == 1; in_absmax = the
+// block the sweep collected the volume's true maximum in
 static int costreg_impl(const float *in, int in_layout, const mvs_conv_layer *layers, const void *const *f16, const void *tail_pack, int B,
                         int Cin, int base, int D, int H, int W, int impl, void *workspace,
-                        size_t workspace_bytes, const void *in_absmax, float *out_cost, void *stream, const char *who) {
-    if (!in || !layers || !out_cost || (in_layout != MVS_LAYOUT_NHWC && in_layout != MVS_LAYOUT_C8)) {
-        set_error("%s: invalid argument", who);
+                        size_t workspace_bytes, const void *in_absmax, float *out_cost, void *stream, const char *who,
+                        const void *hand = nullptr, const void *redo = nullptr) {
+    const bool handed = in_layout == MVS_LAYOUT_C8PT;
+    if (!in || !layers || !out_cost || (in_layout != MVS_LAYOUT_NHWC && in_layout != MVS_LAYOUT_C8 && !handed) ||
+        (handed && (!hand || !redo || !in_absmax || !f16 || !f16[0] || impl == 1 || base != 8 || mvs_conv3d_f16x3_packed_bytes(Cin) == 0))) {
+        set_error("%s: invalid argument%s", who, handed ? " (a handed-over volume needs the hand-over block, the redo word, the volume's absmax "
+                                                          "block, conv0's two-piece pack, base 8, Cin in {8, 16, 32}, impl 0 or 2)" : "");
         return MVS_EINVAL;
     }
+    if (handed) in_layout = MVS_LAYOUT_C8;      // what the volume is when it is not pieces; the layer table below is written for that
     CostRegPlan p;
     if (!costreg_plan(B, base, D, H, W, p)) {
         set_error("%s: D, H, W = %d, %d, %d must be positive multiples of 8 (three "
@@ -135,7 +150,8 @@ static int costreg_impl(const float *in, int in_layout, const mvs_conv_layer *la
     // conv11's input (activation 8) and of the skip volume (activation 0), both collected anyway.  The unfused layers stay enqueued
     // behind it with the "run only if" word: they return at once unless the fused kernel's range guard declined.
     const bool fuse_tail = tail_pack && b == 8 && two_piece_layer(steps[9]) && wanted[0] && wanted[8] &&
-                           mvs_costreg_tail_supported(B, D >> 1, H >> 1, W >> 1);
+                           mvs_costreg_tail_supported(B, D >> 1, H >> 1, W >> 1) && layers[10].packed &&
+                           (int64_t)9 * H * W * 8 * 4 < 0xffffff00LL;   // what mvs_costreg_tail_guarded_f16_f32's fall-back needs
     for (const Step &s : steps) {
         const mvs_conv_layer &L = layers[s.layer];
         const int d = D >> s.lvl, h = H >> s.lvl, w = W >> s.lvl;
@@ -152,7 +168,11 @@ static int costreg_impl(const float *in, int in_layout, const mvs_conv_layer *la
                 if (rc != MVS_OK) return rc;
                 mx = block(0);
             }
-            if (s.layer == 0)            // conv0 on the fp16 matrix pipe with two-piece operands (conv_f16x3.hip)
+            if (s.layer == 0 && handed) {
+                // conv0 on the pieces, then conv0 on the fp32 volume under *redo: exactly one of the two writes c0 and its absmax block
+                rc = mvs_conv3d_c8_handed_f16x3_f32(s.src, hand, redo, mx, f16[0], L.scale, L.shift, nullptr, s.relu, B, Cin, D, H, W, s.dst,
+                                                    out_mx, stream);
+            } else if (s.layer == 0)     // conv0 on the fp16 matrix pipe with two-piece operands (conv_f16x3.hip)
                 rc = mvs_conv3d_c8_f16x3_f32(s.src, mx, f16[0], L.scale, L.shift, nullptr, s.relu, B, Cin, D, H, W, s.dst, out_mx, stream);
             else if (s.transposed)       // conv7 / conv9 / conv11 (deconv_split.hip); s.lvl is the INPUT level
                 rc = mvs_deconv_split_f16_f32(s.src, mx, f16[s.layer], L.scale, L.shift, s.skip, s.relu, B, s.cin, s.cout, d, h, w,
@@ -215,4 +235,13 @@ extern "C" int mvs_costreg_fwd3_f32(const float *in, int in_layout, const mvs_co
     }
     return costreg_impl(in, in_layout, layers, packed_f16, packed_tail, B, Cin, base, D, H, W, impl, workspace, workspace_bytes,
                         in_absmax, out_cost, stream, "mvs_costreg_fwd3_f32");
+}
+
+// fwd3 on the volume of a hand-over sweep (mvs_costvol_variance_fwd_ws3_f32): in = its out_volume, hand / redo / var_absmax = its blocks
+extern "C" int mvs_costreg_fwd4_f32(const void *in_volume, const void *hand, const void *redo, const void *var_absmax,
+                                    const mvs_conv_layer *layers, const void *const *packed_f16, const void *packed_tail, int B, int Cin,
+                                    int base, int D, int H, int W, int impl, void *workspace, size_t workspace_bytes, float *out_cost,
+                                    void *stream) {
+    return costreg_impl(static_cast<const float *>(in_volume), MVS_LAYOUT_C8PT, layers, packed_f16, packed_tail, B, Cin, base, D, H, W, impl,
+                        workspace, workspace_bytes, var_absmax, out_cost, stream, "mvs_costreg_fwd4_f32", hand, redo);
 }

@@ -1433,13 +1433,11 @@ extern "C" size_t mvs_costvol_variance_workspace_bytes(int depth_mode, int B, in
     return mvs_costvol_variance_workspace_bytes2(depth_mode, B, V, C, D, H, W, fea_layout, 0);
 }
 
-extern "C" int mvs_costvol_variance_fwd_ws2_f32(const float *ref_fea, const float *src_feas,
-                                                const float *rot_trans, const float *depth_values,
-                                                int depth_mode, int B, int V, int C, int D, int H,
-                                                int W, int align_corners, int alias_quirk,
-                                                int fea_layout, int out_layout, int flags,
-                                                float *out_var, void *workspace,
-                                                size_t workspace_bytes, void *absmax_bits, void *stream) {
+// ho: NULL, or the hand-over of the volume as two fp16 pieces per value (sweep_common.h) -- only the device-selected route takes it
+static int variance_ws_impl(const float *ref_fea, const float *src_feas, const float *rot_trans, const float *depth_values,
+                            int depth_mode, int B, int V, int C, int D, int H, int W, int align_corners, int alias_quirk,
+                            int fea_layout, int out_layout, int flags, float *out_var, void *workspace,
+                            size_t workspace_bytes, void *absmax_bits, void *stream, const SweepHandover *ho) {
     const bool c4 = fea_layout == MVS_LAYOUT_C4;
     unsigned *const absmax = static_cast<unsigned *>(absmax_bits);
     hipStream_t st = as_stream(stream);
@@ -1448,6 +1446,11 @@ extern "C" int mvs_costvol_variance_fwd_ws2_f32(const float *ref_fea, const floa
         const SweepParams p = make_params(B, V, C, D, H, W, depth_mode, align_corners, alias_quirk);
         int tune, quads;
         const int forced = persist_forced(&tune, &quads);
+        if (ho && !(persist_takes(p, fea_layout) && forced < 0 && out_layout == MVS_LAYOUT_C8 && absmax)) {
+            set_error("mvs_costvol_variance_fwd_ws3_f32: the hand-over rides on the device-selected persistent sweep (shared depth planes, "
+                      "no alias quirk, mvs_costvol_variance_workspace_bytes2 > 0, no forced kernel), an MVS_LAYOUT_C8 volume and its absmax block");
+            return MVS_EUNSUPPORTED;
+        }
         if (persist_takes(p, fea_layout) && forced != 0) {
             const int out_c8 = out_layout == MVS_LAYOUT_C8, lay = c4 ? 1 : (fea_layout == MVS_LAYOUT_NHWC ? 2 : 0);
             if (forced > 0) {
@@ -1464,11 +1467,16 @@ extern "C" int mvs_costvol_variance_fwd_ws2_f32(const float *ref_fea, const floa
                 // the per-tile kernel reads 16-channel blocks: directly (C16), or from a copy made only if it is chosen (C4);
                 // channels-last maps choose between the two tile depths of the persistent kernel only
                 const int allow_tile = fea_layout != MVS_LAYOUT_NHWC && B <= 65535;
-                int rc = launch_variance_choose(rot_trans, depth_values, p, allow_tile, absmax, workspace, st);
+                int rc = launch_variance_choose(rot_trans, depth_values, p, allow_tile, absmax, workspace, st, ho);
                 if (rc != MVS_OK) return rc;
+#ifdef MVS_TUNING
+                static const int tflags = [] { const char *e = getenv("MVS_HANDOVER_FLAGS"); return e ? atoi(e) : 0; }();
+#else
+                constexpr int tflags = 0;
+#endif
                 for (int nw = 16; nw >= 8; nw -= 8) {   // (autosel 2: no cold-path launch behind the first candidate)
                     rc = launch_variance_persist(ref_fea, src_feas, rot_trans, depth_values, p, out_var, out_c8, lay,
-                                                 flags & MVS_SWEEP_FAST, nw, 2, 0, workspace, workspace_bytes, st, nw == 16 ? 2 : 1, absmax);
+                                                 flags & MVS_SWEEP_FAST, nw, 2, ho ? tflags : 0, workspace, workspace_bytes, st, nw == 16 ? 2 : 1, absmax, ho);
                     if (rc != MVS_OK) return rc == MVS_EUNSUPPORTED ? bare_error(MVS_ELAUNCH, __func__, __LINE__) : rc;
                 }
                 if (allow_tile) {
@@ -1487,9 +1495,18 @@ extern "C" int mvs_costvol_variance_fwd_ws2_f32(const float *ref_fea, const floa
                                                   (flags & MVS_SWEEP_TILE_CANDIDATE_PER_TILE) != 0);
                     if (rc != MVS_OK) return rc;
                 }
+                if (ho) {   // the referee (sweep_common.h): writes *redo; returns at once unless the pieces do not hold
+                    rc = launch_variance_redo_all(ref_fea, src_feas, rot_trans, depth_values, p, out_var, lay, flags & MVS_SWEEP_FAST,
+                                                  workspace, st, *ho, absmax);
+                    if (rc != MVS_OK) return rc;
+                }
                 return check_launch("mvs_costvol_variance_fwd_ws_f32(device-selected)");
             }
         }
+    }
+    if (ho) {
+        set_error("mvs_costvol_variance_fwd_ws3_f32: invalid argument");
+        return MVS_EINVAL;
     }
     if (c4) {
         set_error("mvs_costvol_variance_fwd_ws_f32: C4 features are the persistent kernel's layout "
@@ -1499,6 +1516,47 @@ extern "C" int mvs_costvol_variance_fwd_ws2_f32(const float *ref_fea, const floa
     return variance_fwd_impl(ref_fea, src_feas, rot_trans, depth_values, depth_mode, B, V, C,
                              D, H, W, align_corners, alias_quirk, fea_layout, out_layout,
                              out_var, absmax, stream);
+}
+
+extern "C" int mvs_costvol_variance_fwd_ws2_f32(const float *ref_fea, const float *src_feas,
+                                                const float *rot_trans, const float *depth_values,
+                                                int depth_mode, int B, int V, int C, int D, int H,
+                                                int W, int align_corners, int alias_quirk,
+                                                int fea_layout, int out_layout, int flags,
+                                                float *out_var, void *workspace,
+                                                size_t workspace_bytes, void *absmax_bits, void *stream) {
+    return variance_ws_impl(ref_fea, src_feas, rot_trans, depth_values, depth_mode, B, V, C, D, H, W, align_corners, alias_quirk,
+                            fea_layout, out_layout, flags, out_var, workspace, workspace_bytes, absmax_bits, stream, nullptr);
+}
+
+extern "C" size_t mvs_costvol_variance_handover_bytes(int B, int C, int D, int H, int W) {
+    if (B <= 0 || C <= 0 || C % 8 || D <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t pairs = (size_t)B * D * pairs_geom(C, H, W, kPairsLayoutTiled).plane, f32 = (size_t)B * D * H * W * C * 4;
+    return pairs > f32 ? pairs : f32;
+}
+
+extern "C" int mvs_costvol_variance_fwd_ws3_f32(const float *ref_fea, const float *src_feas, const float *rot_trans,
+                                                const float *depth_values, int B, int V, int C, int D, int H, int W,
+                                                int align_corners, int fea_layout, int flags, const void *fea_absmax,
+                                                const void *reader_veto, void *out_volume, void *workspace, size_t workspace_bytes, void *var_absmax,
+                                                void *hand, void *redo, void *stream) {
+    if (!fea_absmax || !hand || !redo || !var_absmax || !out_volume) {
+        set_error("mvs_costvol_variance_fwd_ws3_f32: needs the feature maps' absmax block, the volume (mvs_costvol_variance_handover_bytes), "
+                  "its absmax block, the hand-over block and the redo word");
+        return MVS_EINVAL;
+    }
+    SweepHandover ho;
+    ho.fea_absmax = static_cast<const unsigned *>(fea_absmax);
+    ho.hand = static_cast<unsigned *>(hand);
+    ho.redo = static_cast<unsigned *>(redo);
+    ho.veto = static_cast<const float *>(reader_veto);
+    ho.layout = kPairsLayoutTiled;
+#ifdef MVS_TUNING   // scripts/exp_handover.py: the row layout (no halo copies; conv0 on it is not wired), ablation flags of the persistent kernel
+    static const int lay = [] { const char *e = getenv("MVS_HANDOVER_LAYOUT"); return e ? atoi(e) : 0; }();
+    if (lay == kPairsLayoutRows) ho.layout = lay;
+#endif
+    return variance_ws_impl(ref_fea, src_feas, rot_trans, depth_values, 0, B, V, C, D, H, W, align_corners, 0, fea_layout,
+                            MVS_LAYOUT_C8, flags, static_cast<float *>(out_volume), workspace, workspace_bytes, var_absmax, stream, &ho);
 }
 
 extern "C" int mvs_costvol_variance_fwd_ws_f32(const float *ref_fea, const float *src_feas,

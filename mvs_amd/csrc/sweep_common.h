@@ -129,16 +129,26 @@ __host__ __device__ inline PairsGeom pairs_geom(int C, int H, int W, int layout)
 //   hand        the chooser kernel fills its 256 words with the bits of the bound when the volume is to be written as pairs
 //               (a persistent candidate was chosen and the bound is finite), else with a NaN pattern = "fp32 MVS_LAYOUT_C8";
 //               every later kernel decides on word 0 / the block's maximum.
-//   redo        one word: zeroed by the chooser; set by the conv0 kernel that takes the pairs when it cannot (no pairs, or the
-//               volume's true absmax block fails the range rule against the bound); the fp32 kernels behind it run only then.
+//   redo        one word, written by the launch that follows the candidates (launch_variance_redo_all: the cold kernel, which
+//               returns at once on a sane volume): 0 = the volume is pairs, 1 = it is fp32 MVS_LAYOUT_C8 -- because the chooser
+//               took the per-tile kernel, or because the pieces do not hold (the volume's TRUE absmax block is not finite or
+//               outlier-dominated, or the bound lies more than kHandoverLooseBits above it) and that launch has computed the
+//               volume again in fp32.  conv0 on the pairs runs only if it is 0, the fp32 conv0 behind it only if it is 1.
 struct SweepHandover {
     const unsigned *fea_absmax = nullptr;
     unsigned *hand = nullptr;
     unsigned *redo = nullptr;
+    const float *veto = nullptr;   // NULL, or one float of the volume's reader: NaN there = "I cannot take pieces" (conv0's pack leaves a
+                                   // NaN in its scale word when the layer's weights are not finite) -- the volume then leaves as fp32
     int layout = 0;           // kPairsLayoutRows / kPairsLayoutTiled
-    int redo_all = 0;         // cold kernel only: serve EVERY (tile, wave) in fp32, provided *redo != 0 and hand holds a bound
+    int redo_all = 0;         // cold kernel only: decide *redo and, if the pieces do not hold, serve EVERY (tile, wave) in fp32
 };
 __device__ __forceinline__ bool hand_is_pairs(unsigned bits) { return bits < 0x7f800000u; }
+// how many binary orders the a-priori bound may lie above the volume's true maximum before the pieces are declined: the pieces
+// carry 2^-22 relative for values within 2^-18 of the SCALE's maximum and 2^-40 of it absolute below, so k loose bits move
+// both marks by k -- at 8 a value within 2^-10 of the true maximum still has its 22 bits, and the absolute floor, 2^-32 of the
+// true maximum, stays far below the 2^-22 relative error of the products that dominate a sum
+constexpr int kHandoverLooseBits = 8;
 
 // sweep_persist.hip: the persistent kernel for shared depth planes and 16-channel-blocked
 // features (+ its cold-path kernel); MVS_EUNSUPPORTED (nothing launched) when the shape is not
@@ -155,9 +165,9 @@ int launch_variance_persist(const float *ref16, const float *srcs16, const float
 // |variance| in, if given) and writes the choice into word 1 of the header
 int launch_variance_choose(const float *rt, const float *depth, const SweepParams &p, int allow_tile, unsigned *absmax,
                            void *workspace, hipStream_t st, const SweepHandover *ho = nullptr);
-// the cold kernel alone over every (tile, wave) of the 16-plane tiling, fp32 MVS_LAYOUT_C8 output, gated by ho->redo (the
+// the cold kernel as the hand-over's referee: writes *ho.redo; if the pieces do not hold, every (tile, wave) of the 16-plane tiling again as fp32 MVS_LAYOUT_C8 (the
 // never-taken path behind a declined hand-over: global gathers, ~10x the persistent kernel's time)
 int launch_variance_redo_all(const float *ref16, const float *srcs16, const float *rt, const float *depth, const SweepParams &p,
-                             float *out, int fea_c4, int fast, void *workspace, hipStream_t st, const SweepHandover &ho);
+                             float *out, int fea_c4, int fast, void *workspace, hipStream_t st, const SweepHandover &ho, unsigned *absmax);
 
 }  // namespace mvs

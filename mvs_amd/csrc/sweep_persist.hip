@@ -40,6 +40,7 @@
 // array busy 46 % of the kernel, 17 % of its cycles conflicted (per-tile kernel: 54 %).
 #include "sweep_common.h"
 #include "split2.h"
+#include "conv_guard.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -183,8 +184,20 @@ __global__ __launch_bounds__(256) void variance_fwd_cold_kernel(PersistArgs a, i
     const SweepParams &p = a.p;
     int nchunks = a.nchunks;
     const unsigned hb = a.ho.hand ? a.ho.hand[0] : 0xffffffffu;
-    if (a.ho.redo_all) {   // behind a declined hand-over: every (tile, wave) of the 16-plane tiling, fp32 output
-        if (*a.ho.redo == 0u || !hand_is_pairs(hb)) return;
+    if (a.ho.redo_all) {
+        // The launch behind the candidates of a hand-over sweep: it DECIDES (every workgroup alike, from the two blocks) what the volume
+        // is for its readers and tells them through *redo -- 0: two fp16 pieces per value; 1: fp32 MVS_LAYOUT_C8.
+        //   the chooser picked the per-tile kernel or had no finite bound (hand = NaN pattern): the volume IS fp32 already;
+        //   the pieces were written but do not hold (conv_guard.h's verdict on the volume's TRUE maximum, which the candidates
+        //   collected as they stored: a NaN / Inf voxel, an outlier-dominated volume; or the bound max|f|^2 lies more than
+        //   kHandoverLooseBits above that maximum): this launch computes the whole volume again, in fp32 -- every (tile, wave) of
+        //   the 16-plane tiling by global gathers, ~10x the persistent kernel's time, the path of broken inputs.
+        const AbsmaxVerdict tv = absmax_verdict(a.absmax);
+        const bool was_pairs = hand_is_pairs(hb);
+        const bool bad = was_pairs && tv.bits != 0u &&
+                         (tv.code != 0 || absmax_exponent(hb) - absmax_exponent(tv.bits) > kHandoverLooseBits);
+        if (blockIdx.x == 0 && threadIdx.x == 0) *a.ho.redo = (!was_pairs || bad) ? 1u : 0u;
+        if (!bad) return;
     } else if (a.autosel) {   // one launch behind both candidates: the records are the chosen kernel's
         nw = (int)a.queue[kSelWord];
         if (nw == 0) return;
@@ -381,7 +394,8 @@ __global__ __launch_bounds__(1024) void variance_choose_kernel(PersistArgs a, in
         __syncthreads();
         const float f = __uint_as_float(s_fmax), bound = f * f;
         const unsigned bb = __float_as_uint(bound);
-        const bool ok = s_choice != 0u && s_fmax < 0x7f800000u && bb < 0x7f800000u;
+        const float vt = a.ho.veto ? *a.ho.veto : 0.0f;
+        const bool ok = s_choice != 0u && s_fmax < 0x7f800000u && bb < 0x7f800000u && vt == vt;
         if (tid < kAbsmaxWords) a.ho.hand[tid] = ok ? bb : 0x7fc00000u;
     }
 }
@@ -937,8 +951,8 @@ int launch_variance_persist(const float *ref16, const float *srcs16, const float
 }
 
 int launch_variance_redo_all(const float *ref16, const float *srcs16, const float *rt, const float *depth, const SweepParams &p,
-                             float *out, int fea_c4, int fast, void *workspace, hipStream_t st, const SweepHandover &ho) {
-    if (!persist_shape_ok(p) || !ho.redo || !ho.hand) return bare_error(MVS_EINVAL, __func__, __LINE__);
+                             float *out, int fea_c4, int fast, void *workspace, hipStream_t st, const SweepHandover &ho, unsigned *absmax) {
+    if (!persist_shape_ok(p) || !ho.redo || !ho.hand || !absmax) return bare_error(MVS_EINVAL, __func__, __LINE__);
     const int nw = 16, NV = p.V - 1;
     PersistArgs a{};
     a.ref16 = ref16; a.srcs16 = srcs16; a.rt = rt; a.depth = depth; a.out = out; a.p = p;
@@ -947,7 +961,7 @@ int launch_variance_redo_all(const float *ref16, const float *srcs16, const floa
     a.tiles_y = (p.H + kPH - 1) / kPH;
     a.nchunks = (p.D + nw - 1) / nw;
     a.total_tiles = (int)persist_tiles(p, nw);
-    a.out_c8 = 1; a.fea_c4 = fea_c4;
+    a.out_c8 = 1; a.fea_c4 = fea_c4; a.absmax = absmax;
     a.ho = ho; a.ho.redo_all = 1;
     if (p.align_corners) { a.sx = 1.0f; a.ox = 0.0f; a.sy = 1.0f; a.oy = 0.0f; }
     else {

@@ -108,9 +108,10 @@ class FeatureNet(nn.Module):
         y = F.conv2d(x, self.feature.weight, self.feature.bias, 1, 1)
         return y.permute(0, 2, 3, 1).contiguous()
 
-    def forward_hip(self, imgs_nchw, out_c4=False):
+    def forward_hip(self, imgs_nchw, out_c4=False, out_absmax=None):
         """[N,3,H,W] image batch (the reference's layout) -> [N,H/4,W/4,32] channels-last, or with
-        out_c4 the last layer's epilogue writes 4-channel blocks [N,8,H/4,W/4,4] (MVS_LAYOUT_C4)."""
+        out_c4 the last layer's epilogue writes 4-channel blocks [N,8,H/4,W/4,4] (MVS_LAYOUT_C4).  out_absmax: a ZEROED absmax
+        block the last layer's epilogue collects the maps' largest magnitude in (the bound a hand-over sweep scales its pieces by)."""
         x = imgs_nchw
         P = self._hip_params()
         first = 0
@@ -140,14 +141,14 @@ class FeatureNet(nn.Module):
                     nlast = i + 1 == len(P) - 1
                     with ops.stage("feature." + p["name"] + "+" + nx["name"]):
                         x = ops.conv2d_pair(x, blocks[i - 1], p["pair"], p, nx, out_c4=(out_c4 and nlast),
-                                            out_absmax=blocks[i + 1] if not nlast else None, flag=blocks[len(P):].reshape(-1))
+                                            out_absmax=blocks[i + 1] if not nlast else out_absmax, flag=blocks[len(P):].reshape(-1))
                     skip = i + 1
                     continue
             with ops.stage("feature." + p["name"]):
                 x = ops.conv2d(x, p["packed"], p["cin"], p["cout"], p["k"], p["stride"], p["scale"],
                                p["shift"], p["relu"], planar=(i == 0), out_c4=(out_c4 and last),
                                x_absmax=blocks[i - 1] if blocks is not None else None,
-                               out_absmax=blocks[i] if (blocks is not None and not last) else None)
+                               out_absmax=out_absmax if last else (blocks[i] if blocks is not None else None))
         return x
 
 
@@ -271,7 +272,8 @@ class CostRegNet(nn.Module):
         [B,D,H,4,W,8] with in_c8) -> cost [B,D,H,W].  x_absmax: the word the variance op filled with the volume's
         largest magnitude (conv0's operand scale on the fp16 kernel; None: collected by one more pass)."""
         P = self._hip_params()
-        D, H, W = (x_cl.shape[1], x_cl.shape[2], x_cl.shape[4 if in_c8 else 3])
+        handed = isinstance(x_cl, ops.HandedVolume)       # the sweep's hand-over: pieces or fp32, decided on the device
+        D, H, W = x_cl.shape[2:] if handed else (x_cl.shape[1], x_cl.shape[2], x_cl.shape[4 if in_c8 else 3])
         if not ops.timing_enabled() and D % 8 == 0 and H % 8 == 0 and W % 8 == 0:
             # one C call for the eleven layers (mvs_costreg_fwd_f32); the per-layer calls below
             # remain for stage timing and for sizes the whole-net entry does not take
@@ -280,6 +282,8 @@ class CostRegNet(nn.Module):
         # the per-layer chain of mvs_costreg_fwd2_f32: a layer on a two-piece fp16 kernel scales its input by the absmax block the
         # layer in front of it collected (blocks of activations nobody reads that way stay None)
         f16 = ops.split_f16_enabled() and self.conv_impl == ops.IMPL_AUTO
+        if handed and not f16:
+            raise ops.MvsHipError("CostRegNet.forward_hip: a handed-over volume needs the two-piece layers (MVS_SPLIT_F16, conv_impl auto)")
         blocks = ops.absmax_block(x_cl.device, zero=True, n=10) if f16 else None      # (row 9: the fused tail's flag word)
         blk = (lambda i: blocks[i]) if f16 else (lambda i: None)
 
@@ -292,7 +296,9 @@ class CostRegNet(nn.Module):
 
         p0 = P["conv0"]
         with ops.stage("costreg.conv0"):
-            if in_c8 and p0.get("packed_f16x3") is not None and self.conv_impl != ops.IMPL_DIRECT:
+            if handed:
+                c0 = ops.conv3d_c8_handed(x_cl, p0["packed_f16x3"], p0["scale"], p0["shift"], True, out_absmax=blk(0))
+            elif in_c8 and p0.get("packed_f16x3") is not None and self.conv_impl != ops.IMPL_DIRECT:
                 c0 = ops.conv3d_c8_f16x3(x_cl, p0["packed_f16x3"], x_absmax, p0["scale"], p0["shift"], None, True, out_absmax=blk(0))
             elif in_c8 and p0.get("packed_split") is not None and self.conv_impl != ops.IMPL_DIRECT:
                 c0 = ops._with_absmax(ops.conv3d_c8_split(x_cl, p0["packed_split"], p0["scale"], p0["shift"], None, True), blk(0))
@@ -464,6 +470,11 @@ class MVSNet(nn.Module):
             # FeatureNet's last layer writes them directly (a lane of its MFMA epilogue holds 4 channels)
             c4 = use_lds and ops.variance_persistent_supported(depth_values, B, V, C, h, w)
             f4 = None
+            # the variance volume leaves the sweep as two fp16 pieces per value where conv0 reads them
+            p0 = self.cost_regularization._hip_params()["conv0"] if c4 else None
+            hand_over = (c4 and ops.handover_enabled() and self.cost_regularization.wants_c8_input() and
+                         self.cost_regularization.conv_impl != ops.IMPL_DIRECT and p0.get("packed_f16x3") is not None)
+            fea_amax = None
             if features is not None:
                 if tuple(features.shape) != (B, V, C // 4, h, w, 4):
                     raise ops.MvsHipError(f"forward: features {tuple(features.shape)} do not fit this sample "
@@ -474,7 +485,9 @@ class MVSNet(nn.Module):
                     f = features.permute(0, 1, 3, 4, 2, 5).reshape(B * V, h, w, C)
             elif self.feature_impl == "hip" and self.feature.hip_supported():
                 if c4 and ops.conv2d_persistent_enabled():
-                    f4 = self.feature.forward_hip(flat, out_c4=True)     # [B*V,8,h,w,4]
+                    # (the last layer collects the maps' largest magnitude: the bound a hand-over sweep scales its pieces by)
+                    fea_amax = ops.absmax_block(flat.device, zero=True) if hand_over else None
+                    f4 = self.feature.forward_hip(flat, out_c4=True, out_absmax=fea_amax)     # [B*V,8,h,w,4]
                 else:
                     f = self.feature.forward_hip(flat)                   # [B*V,h,w,32]: HIP 2D MFMA kernels
             else:
@@ -504,7 +517,15 @@ class MVSNet(nn.Module):
                     fcl = f.reshape(B, V, h, w, C).transpose(0, 1).contiguous()   # [V,B,h,w,C]
             amax = None
             with ops.stage("costvol_variance"):
-                if use_lds:
+                var = None
+                if use_lds and hand_over and c8:
+                    if fea_amax is None:         # maps that came without their block (features=, stage timing): one pass over them
+                        fea_amax = ops.absmax(f16)
+                    var = ops.costvol_variance_handover(f16[0], f16[1:], rts, depth_values, fea_amax, self.align_corners,
+                                                        fast=self.variance_fast, veto=ops.conv0_veto_word(p0["packed_f16x3"], C))
+                if var is not None:
+                    pass
+                elif use_lds:
                     if c8 and ops.conv0_f16_enabled():   # the sweep kernels collect conv0's operand scale as they store
                         amax = ops.absmax_block(f16.device)
                     var = ops.costvol_variance_c16(f16[0], f16[1:], rts, depth_values,

@@ -529,6 +529,95 @@ def costvol_variance_c16(ref16, srcs16, rts, depth_values, align_corners=False, 
     return out
 
 
+def handover_enabled():
+    """False when MVS_HANDOVER=0 keeps the variance volume fp32 between the sweep and conv0 (A/B).  Default: the sweep hands it
+    over as two fp16 pieces per value (mvs_costvol_variance_fwd_ws3_f32) wherever conv0 runs on the two-piece kernel."""
+    import os
+    return conv0_f16_enabled() and os.environ.get("MVS_HANDOVER", "1") != "0"
+
+
+class HandedVolume:
+    """What mvs_costvol_variance_fwd_ws3_f32 left on the device: `buf` = the volume -- MVS_LAYOUT_C8PT pieces scaled by the bound
+    in `hand` if redo[0] == 0, plain fp32 MVS_LAYOUT_C8 if redo[0] == 1 (nobody on the host needs to know which) --, `absmax` =
+    the block of its true largest magnitude, shape = (B, C, D, H, W)."""
+    __slots__ = ("buf", "hand", "absmax", "redo", "shape")
+
+    def __init__(self, buf, hand, absmax, redo, shape):
+        self.buf, self.hand, self.absmax, self.redo, self.shape = buf, hand, absmax, redo, shape
+
+    @property
+    def device(self):
+        return self.buf.device
+
+    def to_c8(self):
+        """The volume as fp32 [B,D,H,C/8,W,8] (tests, diagnostics: synchronises the device)."""
+        B, C, D, H, W = self.shape
+        if int(self.redo[0].item()) != 0:
+            return self.buf[:B * D * H * W * C * 4].view(torch.float32).view(B, D, H, C // 8, W, 8).clone()
+        e = (int(self.hand.max().item()) >> 23 & 255) - 127
+        e = max(-100, min(127, e))
+        tiles = (W + 31) // 32
+        pc = self.buf[:B * D * (C // 8) * tiles * 4 * H * 17 * 16].view(torch.float16).view(B, D, C // 8, tiles, 2, 2, H, 17, 8)
+        v = pc[:, :, :, :, 0].double() + pc[:, :, :, :, 1].double()            # [B,D,G,tiles,parity,H,17,8]
+        # local x' = 2 i + parity; own voxels x' = 1 .. 32
+        v = v.permute(0, 1, 2, 3, 5, 6, 4, 7).reshape(B, D, C // 8, tiles, H, 34, 8)[:, :, :, :, :, 1:33]
+        v = v.permute(0, 1, 4, 2, 3, 5, 6).reshape(B, D, H, C // 8, tiles * 32, 8)[:, :, :, :, :W]
+        return (v * 2.0 ** (e - 14)).float().contiguous()
+
+
+def costvol_variance_handover(ref16, srcs16, rts, depth_values, fea_absmax, align_corners=False, fast=False, veto=None):
+    """The fused warp + variance sweep with the volume handed to conv0 as two fp16 pieces per value (include/mvs_hip.h:
+    mvs_costvol_variance_fwd_ws3_f32).  ref16 / srcs16 as costvol_variance_c16; fea_absmax: the absmax block of ALL the feature
+    maps (the pieces' scale comes from the bound var <= max|f|^2); veto: None, or a device address (int) of one float of the
+    reader -- NaN there keeps the volume fp32.  -> HandedVolume, or None when this shape / environment has no hand-over
+    (per-pixel hypotheses, a forced kernel, MVS_HANDOVER=0): call costvol_variance_c16 then."""
+    import os
+    ref16, srcs16, depth_values = _f32c(ref16), _f32c(srcs16), _f32c(depth_values)
+    B, G, H, W, blk = ref16.shape
+    if blk not in (4, 16) or not handover_enabled() or "MVS_SWEEP_PERSIST" in os.environ or _depth_mode(depth_values) != 0:
+        return None
+    layout = MVS_LAYOUT_C16 if blk == 16 else MVS_LAYOUT_C4
+    C, V, D = G * blk, srcs16.shape[0] + 1, depth_values.shape[1]
+    lib = _lib.load()
+    need = lib.mvs_costvol_variance_workspace_bytes2(0, B, V, C, D, H, W, layout, 0)
+    nbytes = lib.mvs_costvol_variance_handover_bytes(B, C, D, H, W)
+    if need == 0 or nbytes == 0 or nbytes // (B * D) >= 0xffffffff:
+        return None
+    ws = _variance_workspace(ref16.device, need)
+    buf = torch.empty(nbytes, device=ref16.device, dtype=torch.uint8)
+    words = torch.empty(2 * ABSMAX_WORDS + 4, device=ref16.device, dtype=torch.int32)      # hand, absmax, redo: all written by the kernels
+    hv = HandedVolume(buf, words[:ABSMAX_WORDS], words[ABSMAX_WORDS:2 * ABSMAX_WORDS], words[2 * ABSMAX_WORDS:], (B, C, D, H, W))
+    hint = _SweepVerdict.get(ref16.device, (0, B, V, C, D, H, W, layout))
+    flags = (1 if fast else 0) | (2 if hint.per_tile() else 0)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    check(lib.mvs_costvol_variance_fwd_ws3_f32(
+        ptr(ref16), ptr(srcs16), ptr(rts), ptr(depth_values), B, V, C, D, H, W, int(align_corners), layout, flags,
+        vp(fea_absmax), ctypes.c_void_p(veto) if veto else None, vp(buf), vp(ws), ws.numel(), vp(hv.absmax), vp(hv.hand), vp(hv.redo),
+        stream()), "mvs_costvol_variance_fwd_ws3_f32")
+    hint.observe(ws)
+    return hv
+
+
+def conv0_veto_word(packed_f16x3, cin):
+    """Device address of the word of a conv0 two-piece pack that is NaN when the layer's weights are not finite (what
+    costvol_variance_handover takes as `veto`)."""
+    return _lib.load().mvs_conv3d_f16x3_pack_veto_word(ctypes.c_void_p(packed_f16x3.data_ptr()), cin)
+
+
+def conv3d_c8_handed(hv, packed, scale=None, shift=None, relu=False, out_absmax=None):
+    """conv0 on whatever the hand-over sweep left (mvs_conv3d_c8_handed_f16x3_f32): the kernel on the pieces, then the fp32 kernel
+    under the redo word -- exactly one of the two runs.  -> [B,D,H,W,8]."""
+    B, C, D, H, W = hv.shape
+    out = torch.empty(B, D, H, W, 8, device=hv.device, dtype=torch.float32)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
+    with stage("conv3d_split"):
+        check(_lib.load().mvs_conv3d_c8_handed_f16x3_f32(
+            vp(hv.buf), vp(hv.hand), vp(hv.redo), vp(hv.absmax), ptr(packed), ptr(_f32c(scale)) if scale is not None else None,
+            ptr(_f32c(shift)) if shift is not None else None, None, int(bool(relu)), B, C, D, H, W, ptr(out), vp(out_absmax), stream()),
+            "mvs_conv3d_c8_handed_f16x3_f32")
+    return out
+
+
 class _SweepVerdict:
     """Which kernel the device-side chooser of the sweep picked for a shape, read back WITHOUT synchronising: now and then the
     verdict word of the workspace is copied to pinned host memory behind the call, and looked at by a later call once its event
@@ -552,7 +641,8 @@ class _SweepVerdict:
         self.calls = 0
 
     def per_tile(self):
-        if self.pending is not None and self.pending[1].query():
+        # (an event query is not a legal call while a stream captures in the default 'global' mode: keep the last known choice)
+        if self.pending is not None and not torch.cuda.is_current_stream_capturing() and self.pending[1].query():
             self.choice = int(self.pending[0].item())
             self.pending = None
         return self.choice == 0
@@ -1249,14 +1339,15 @@ def costreg_tail(x, x_absmax, skip, skip_absmax, packed_tail, scale, shift, prob
     return out, flag
 
 
-def costreg_tail_guarded(x, x_absmax, skip, skip_absmax, p11, pprob, flag=None):
+def costreg_tail_guarded(x, x_absmax, skip, skip_absmax, p11, pprob, flag=None, d11=None):
     """conv11 + prob: the fused kernel with the two unfused layers enqueued behind it under its flag (no host synchronisation):
     whatever the range guard decides, the cost comes back.  p11 / pprob: the layers' parameter dicts (weight, packed, scale,
     shift; p11 with its two-piece companion and 'packed_tail')."""
     x, skip = _f32c(x), _f32c(skip)
     B, Di, Hi, Wi, _ = x.shape
     out = torch.empty((B, 2 * Di, 2 * Hi, 2 * Wi), device=x.device, dtype=torch.float32)
-    d11 = torch.empty((B, 2 * Di, 2 * Hi, 2 * Wi, 8), device=x.device, dtype=torch.float32)     # touched only if the guard declines
+    if d11 is None:         # conv11's output for the unfused path: touched only if the guard declines
+        d11 = torch.empty((B, 2 * Di, 2 * Hi, 2 * Wi, 8), device=x.device, dtype=torch.float32)
     if flag is None:        # (or a zeroed word of the caller's: one fill for a whole network's blocks and flags)
         flag = torch.zeros(1, device=x.device, dtype=torch.int32)
     layers = (_lib.ConvLayer * 2)()
@@ -1281,12 +1372,18 @@ def costreg_forward(x, params, in_c8=False, impl=IMPL_AUTO, x_absmax=None):
     volume [B,D,H,W,Cin] or (in_c8) [B,D,H,Cin/8,W,8]; params: name -> dict(weight, packed, scale,
     shift) for the eleven layers of COSTREG_ORDER.  -> cost [B,D,H,W].  The activations live in a
     per-(device, stream) workspace that the next call on the same stream reuses."""
-    x = _f32c(x)
-    if in_c8:
-        B, D, H, G, W, _ = x.shape
-        cin = G * 8
+    handed = isinstance(x, HandedVolume)
+    if handed:
+        hv, x = x, x.buf
+        B, cin, D, H, W = hv.shape
+        in_c8 = True
     else:
-        B, D, H, W, cin = x.shape
+        x = _f32c(x)
+        if in_c8:
+            B, D, H, G, W, _ = x.shape
+            cin = G * 8
+        else:
+            B, D, H, W, cin = x.shape
     base = params["conv0"]["weight"].shape[0]
     lib = _lib.load()
     need = lib.mvs_costreg_workspace_bytes(B, base, D, H, W)
@@ -1331,12 +1428,22 @@ def costreg_forward(x, params, in_c8=False, impl=IMPL_AUTO, x_absmax=None):
             if tail is None:
                 tail = params["conv11"]["packed_tail"] = pack_costreg_tail(params["conv11"]["weight"])
             keep.append(tail)
+        if handed:
+            if not f16[0]:
+                raise MvsHipError("costreg_forward: a handed-over volume needs conv0's two-piece pack (packed_f16x3) and MVS_CONV0_F16 != 0")
+            vp = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+            check(lib.mvs_costreg_fwd4_f32(vp(hv.buf), vp(hv.hand), vp(hv.redo), vp(hv.absmax), ctypes.cast(layers, ctypes.c_void_p),
+                                           ctypes.cast(f16, ctypes.c_void_p), vp(tail) if tail is not None else None,
+                                           B, cin, base, D, H, W, impl, vp(ws), ws.numel(), ptr(out), stream()), "mvs_costreg_fwd4_f32")
+            return out
         check(lib.mvs_costreg_fwd3_f32(ptr(x), MVS_LAYOUT_C8 if in_c8 else MVS_LAYOUT_NHWC,
                                        ctypes.cast(layers, ctypes.c_void_p), ctypes.cast(f16, ctypes.c_void_p),
                                        ctypes.c_void_p(tail.data_ptr()) if tail is not None else None,
                                        B, cin, base, D, H, W, impl, ctypes.c_void_p(ws.data_ptr()), ws.numel(),
                                        ctypes.c_void_p(x_absmax.data_ptr()) if x_absmax is not None else None,
                                        ptr(out), stream()), "mvs_costreg_fwd3_f32")
+    elif handed:
+        raise MvsHipError("costreg_forward: a handed-over volume needs the two-piece packs")
     else:
         check(lib.mvs_costreg_fwd_f32(ptr(x), MVS_LAYOUT_C8 if in_c8 else MVS_LAYOUT_NHWC,
                                       ctypes.cast(layers, ctypes.c_void_p), B, cin, base, D, H, W, impl,

@@ -97,6 +97,68 @@ def test_fused_tail_declines_what_the_guard_declines(dev, poison):
     assert flag == 1
 
 
+def _guarded_params(dev, case):
+    from mvs_amd import ops
+    x, skip, w11, sc, sh, pw, pb = (t.to(dev) for t in case)
+    pk11 = ops.pack_conv3d_weight(w11, True, 2, split=True)
+    p11 = dict(weight=w11, packed=pk11, scale=sc, shift=sh, packed_tail=ops.pack_costreg_tail(w11))
+    assert ops.f16_companion(pk11) is not None
+    pprob = dict(weight=pw, packed=ops.pack_conv3d_weight(pw, False, 1), shift=pb)
+    return x, skip, p11, pprob
+
+
+def test_guarded_tail_leaves_the_cost_alone_when_the_fused_kernel_ran(dev):
+    """the two unfused layers enqueued behind the fused kernel must return at once when its flag stays 0 -- with the
+    scratch volume poisoned, the cost is the fused kernel's bit for bit and the scratch is untouched."""
+    from mvs_amd import ops
+    case = _case(11, 1, 6, 12, 24)
+    x, skip, p11, pprob = _guarded_params(dev, case)
+    xa, sa = ops.absmax(x), ops.absmax(skip)
+    alone, flag = ops.costreg_tail(x, xa, skip, sa, p11["packed_tail"], p11["scale"], p11["shift"], pprob["weight"], None, pprob["shift"])
+    d11 = torch.full((1, 12, 24, 48, 8), float("nan"), device=dev)
+    flag2 = torch.zeros(1, device=dev, dtype=torch.int32)
+    cost = ops.costreg_tail_guarded(x, xa, skip, sa, p11, pprob, flag=flag2, d11=d11)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0 and int(flag2.item()) == 0
+    assert torch.equal(cost, alone) and torch.isfinite(cost).all()
+    assert torch.isnan(d11).all()
+
+
+def test_guarded_tail_refuses_a_fallback_that_would_ignore_the_flag(dev):
+    """Without prob's packed weights the unfused `prob` would take the direct kernel, which does not read the run-only-if word:
+    the call must fail before anything is enqueued (MVS_EUNSUPPORTED), and so must any non-flag-aware launch under a flag."""
+    from mvs_amd import ops
+    case = _case(12, 1, 4, 8, 16)
+    x, skip, p11, pprob = _guarded_params(dev, case)
+    xa, sa = ops.absmax(x), ops.absmax(skip)
+    bad = dict(pprob)
+    bad.pop("packed")
+    with pytest.raises(ops.MvsHipError, match="packed"):
+        ops.costreg_tail_guarded(x, xa, skip, sa, p11, bad)
+
+
+def test_guarded_tail_falls_back_when_the_fused_kernel_declines(dev):
+    """A NaN voxel in conv11's input: the fused kernel declines, the unfused layers run behind the flag and the cost carries the
+    reference's NaN pattern (ATen float32 on the CPU is the checker, as in tests/test_gpu_range_guard.py)."""
+    from mvs_amd import ops
+    case = list(_case(13, 1, 4, 8, 16))
+    case[0][0, 1, 2, 3, 4] = float("nan")
+    x, skip, p11, pprob = _guarded_params(dev, case)
+    xa, sa = ops.absmax(x), ops.absmax(skip)
+    flag = torch.zeros(1, device=dev, dtype=torch.int32)
+    cost = ops.costreg_tail_guarded(x, xa, skip, sa, p11, pprob, flag=flag)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1
+    xc, sk, w11, sc, sh, pw, pb = case
+    y = F.conv_transpose3d(xc.permute(0, 4, 1, 2, 3), w11, stride=2, padding=1, output_padding=1)
+    y = torch.relu(y * sc.view(1, 8, 1, 1, 1) + sh.view(1, 8, 1, 1, 1)) + sk.permute(0, 4, 1, 2, 3)
+    ref = F.conv3d(y, pw, pb, padding=1)[:, 0]
+    got = cost.cpu()
+    assert torch.equal(torch.isnan(got), torch.isnan(ref)) and torch.isnan(ref).any()
+    ok = ~torch.isnan(ref)
+    assert float((got[ok] - ref[ok]).abs().max()) <= 5e-6 * float(ref[ok].abs().max())
+
+
 def test_costregnet_through_the_fused_tail_equals_the_unfused_net(dev, weights, monkeypatch):
     """mvs_costreg_fwd3_f32 with and without the fused tail (MVS_TAIL_FUSED) on a variance-like volume: same regularised cost to
     float32 rounding, and the fused call launches neither conv11's nor prob's full kernel (their run flag stays 0)."""
