@@ -69,9 +69,15 @@ extern "C" {
  * channels of one voxel and part; parity = of the voxel's x.
  *   MVS_LAYOUT_C8P  (6): [B, D, C/8, part (hi, lo), parity, H, ceil(W/2)] pieces
  *   MVS_LAYOUT_C8PT (7): [B, D, C/8, ceil(W/32), part, local parity, H, 17] pieces -- x-tiled, each 32-voxel tile with its two halo
- *                        columns (+6 % bytes): what a hand-over sweep writes and conv0 reads ten rows at a time as one run */
+ *                        columns (+6 % bytes): conv0 reads ten rows at a time as one run, but a sweep tile's stores straddle cache
+ *                        lines (rows of 272 bytes): the sweep is 0.5 ms slower at configs[1] (profiles/r06_handover_sweep.json)
+ *   MVS_LAYOUT_C8PH (8): MVS_LAYOUT_C8P per 8-channel chunk, followed by that chunk's halo strips [part, ceil(W/32), side, H] pieces:
+ *                        the columns x = 32 t - 1 (side 0) and x = 32 t + 32 (side 1) of every 32-voxel tile t once more, H pieces in
+ *                        a row (+6 % bytes; the chunk's block padded to 256 bytes).  What a hand-over sweep writes -- whole aligned
+ *                        cache lines per store -- and conv0 reads: a tile's halo column costs it two cache lines per plane, not ten */
 #define MVS_LAYOUT_C8P 6
 #define MVS_LAYOUT_C8PT 7
+#define MVS_LAYOUT_C8PH 8
 
 /* Library version: major*10000 + minor*100 + patch.  101 (0.1.1): every *_f16*_packed_bytes size grew -- the fp32 weights
  * ride behind the packed fragments for the range guard -- so buffers sized by 100 are too small: re-query the sizes.
@@ -428,7 +434,7 @@ int mvs_costreg_fwd3_f32(const float *in, int in_layout, const mvs_conv_layer *l
  *
  *   mvs_costvol_variance_fwd_ws3_f32   = ..._ws2_f32 for shared depth planes on the device-selected persistent kernels (else
  *       MVS_EUNSUPPORTED, nothing launched), fea_layout C16 / C4 / NHWC.  out_volume (mvs_costvol_variance_handover_bytes) receives
- *       MVS_LAYOUT_C8PT pieces scaled by 2^(14 - exponent(bound)), hand (MVS_ABSMAX_WORDS words) the bits of the bound, var_absmax the
+ *       MVS_LAYOUT_C8PH pieces scaled by 2^(14 - exponent(bound)), hand (MVS_ABSMAX_WORDS words) the bits of the bound, var_absmax the
  *       volume's TRUE largest magnitude, *redo = 0 -- or, *redo = 1, the plain fp32 MVS_LAYOUT_C8 volume: when the chooser took the
  *       per-tile kernel, when the bound is not finite, when *reader_veto (optional: one float of the reader, e.g.
  *       mvs_conv3d_f16x3_pack_veto_word) is NaN, or when the pieces do not hold (true maximum not finite or outlier-dominated --

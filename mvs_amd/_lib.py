@@ -21,6 +21,7 @@ MVS_LAYOUT_C4 = 4
 MVS_LAYOUT_C8H = 5
 MVS_LAYOUT_C8P = 6
 MVS_LAYOUT_C8PT = 7
+MVS_LAYOUT_C8PH = 8
 
 _c_f = ctypes.c_void_p   # device pointers travel as integers
 _c_i = ctypes.c_int

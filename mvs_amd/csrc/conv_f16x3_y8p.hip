@@ -139,13 +139,18 @@ __global__ __launch_bounds__(kYPThreads) void conv3d_c8p_f16x3_kernel(ConvArgs a
             const int iy0 = cg.ty * 8 - 1;
             // local x' = 2 i + lpar counts from the tile's halo origin 32 tx - 1
             tile_off = (unsigned)(pg.tiled ? cg.tx * pg.xtile + (part * 2 + lpar) * pg.region
-                                           : (part * 2 + (1 - lpar)) * pg.region);          // C8P: global parity = 1 - local parity
+                                           : (part * 2 + (1 - lpar)) * pg.region);          // C8P / C8PH: global parity = 1 - local parity
 #pragma unroll
             for (int i = 0; i < IPR; ++i) {
                 const int gy = iy0 + qrow[i], gx = cg.tx * 32 - 1 + 2 * qidx[i] + lpar;
                 const bool ok = qpl[i] < 2 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
                 const int col = pg.tiled ? qidx[i] : (gx >> 1);
-                voff[i] = ok ? (unsigned)(qpl[i] * pg.plane + (int64_t)gy * pg.rowpitch + col * 16) : 0xffffff00u;
+                unsigned o = (unsigned)(qpl[i] * pg.plane + (int64_t)gy * pg.rowpitch + col * 16);
+                // C8PH: the tile's two halo columns (x' = 0: first piece of local parity 0; x' = 33: last piece of local parity 1) come
+                // from its halo strips -- H pieces in a row, so the ten rows of a plane share two cache lines instead of taking one each
+                const bool halo = pg.strips && (lpar == 0 ? qidx[i] == 0 : qidx[i] == kYPRowVox - 1);
+                if (halo) o = (unsigned)(qpl[i] * pg.plane + pg.halo + part * pg.halo_part + (int64_t)(cg.tx * 2 + lpar) * pg.strip + gy * 16) - tile_off;
+                voff[i] = ok ? o : 0xffffff00u;
             }
         };
         auto issue_halo = [&](int p, int ch, int pair) {              // planes 2p, 2p + 1 of the column (global z = 16 zg - 1 + ...)
@@ -388,6 +393,17 @@ __global__ __launch_bounds__(256) void c8_to_c8p_kernel(const float *__restrict_
             unsigned char *o = pl + (x & 1) * pg.region + (int64_t)y * pg.rowpitch + (x >> 1) * 16;
             *reinterpret_cast<u32x4 *>(o) = h;
             *reinterpret_cast<u32x4 *>(o + 2 * pg.region) = l;
+            if (pg.strips) {      // a tile-border column once more, into the neighbouring tile's halo strip
+                const int tx = x >> 5, xm = x & 31;
+                int64_t so = -1;
+                if (xm == 31 && x + 1 < W) so = (int64_t)((tx + 1) * 2) * pg.strip;
+                else if (xm == 0 && x > 0) so = (int64_t)((tx - 1) * 2 + 1) * pg.strip;
+                if (so >= 0) {
+                    unsigned char *d = pl + pg.halo + so + y * 16;
+                    *reinterpret_cast<u32x4 *>(d) = h;
+                    *reinterpret_cast<u32x4 *>(d + pg.halo_part) = l;
+                }
+            }
         } else {
             // own tile, and as a halo voxel of the neighbour: x' = 32 of tile tx is x' = 0 of tile tx + 1; x' = 1 is x' = 33 of tx - 1
             const int tx = x >> 5, xl = (x & 31) + 1;
@@ -421,7 +437,7 @@ extern "C" const void *mvs_conv3d_f16x3_pack_veto_word(const void *packed, int C
 }
 
 extern "C" size_t mvs_c8p_bytes(int B, int C, int D, int H, int W, int layout) {
-    if (B <= 0 || C <= 0 || C % 8 || D <= 0 || H <= 0 || W <= 0 || (layout != kPairsLayoutRows && layout != kPairsLayoutTiled)) return 0;
+    if (B <= 0 || C <= 0 || C % 8 || D <= 0 || H <= 0 || W <= 0 || !pairs_layout_ok(layout)) return 0;
     return (size_t)B * D * pairs_geom(C, H, W, layout).plane;
 }
 
@@ -504,7 +520,7 @@ extern "C" int mvs_conv3d_c8_handed_f16x3_f32(const void *volume, const void *ha
                   "mvs_costvol_variance_fwd_ws3_f32");
         return MVS_EINVAL;
     }
-    int rc = mvs_conv3d_c8p_f16x3_f32(volume, hand, redo, packed, scale, shift, residual, relu, B, Cin, D, H, W, kPairsLayoutTiled, 4, out,
+    int rc = mvs_conv3d_c8p_f16x3_f32(volume, hand, redo, packed, scale, shift, residual, relu, B, Cin, D, H, W, kPairsLayoutStrips, 4, out,
                                       out_absmax, stream);
     if (rc != MVS_OK) return rc;
     struct FlagScope {

@@ -74,14 +74,14 @@ extern "C" int mvs_costreg_tail_guarded_f16_f32(const float *in, const void *in_
 }
 
 // layers: the eleven layers; f16 = their two-piece fp16 packs or NULL (the entry of before those existed)
-// hand / redo: non-NULL with in_layout = MVS_LAYOUT_C8PT -- the volume of a hand-over sweep (mvs_costvol_variance_fwd_ws3_f32): two
+// hand / redo: non-NULL with in_layout = MVS_LAYOUT_C8PH -- the volume of a hand-over sweep (mvs_costvol_variance_fwd_ws3_f32): two
 // fp16 pieces per value scaled by the bound in `hand` if *redo == 0, an fp32 MVS_LAYOUT_C8 volume if *redo == 1; in_absmax = the
 // block the sweep collected the volume's true maximum in
 static int costreg_impl(const float *in, int in_layout, const mvs_conv_layer *layers, const void *const *f16, const void *tail_pack, int B,
                         int Cin, int base, int D, int H, int W, int impl, void *workspace,
                         size_t workspace_bytes, const void *in_absmax, float *out_cost, void *stream, const char *who,
                         const void *hand = nullptr, const void *redo = nullptr) {
-    const bool handed = in_layout == MVS_LAYOUT_C8PT;
+    const bool handed = in_layout == MVS_LAYOUT_C8PH;
     if (!in || !layers || !out_cost || (in_layout != MVS_LAYOUT_NHWC && in_layout != MVS_LAYOUT_C8 && !handed) ||
         (handed && (!hand || !redo || !in_absmax || !f16 || !f16[0] || impl == 1 || base != 8 || mvs_conv3d_f16x3_packed_bytes(Cin) == 0))) {
         set_error("%s: invalid argument%s", who, handed ? " (a handed-over volume needs the hand-over block, the redo word, the volume's absmax "
@@ -242,6 +242,6 @@ extern "C" int mvs_costreg_fwd4_f32(const void *in_volume, const void *hand, con
                                     const mvs_conv_layer *layers, const void *const *packed_f16, const void *packed_tail, int B, int Cin,
                                     int base, int D, int H, int W, int impl, void *workspace, size_t workspace_bytes, float *out_cost,
                                     void *stream) {
-    return costreg_impl(static_cast<const float *>(in_volume), MVS_LAYOUT_C8PT, layers, packed_f16, packed_tail, B, Cin, base, D, H, W, impl,
+    return costreg_impl(static_cast<const float *>(in_volume), MVS_LAYOUT_C8PH, layers, packed_f16, packed_tail, B, Cin, base, D, H, W, impl,
                         workspace, workspace_bytes, var_absmax, out_cost, stream, "mvs_costreg_fwd4_f32", hand, redo);
 }

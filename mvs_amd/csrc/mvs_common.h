@@ -87,6 +87,41 @@ __device__ __forceinline__ void sweep_coord(const float *__restrict__ r, float r
     }
 }
 
+// ---- the same coordinates, bit for bit, with cheaper divisions (round 6: the persistent sweep's FAST mode) -----------------
+// IEEE-correct a / b from a reciprocal of b refined by one Newton step: the quotient and two residual corrections -- the
+// compiler's own fp32 division sequence without its range scaling (v_div_scale / v_div_fixup), so exact for operands whose
+// quotient and residuals stay far from overflow and the subnormals: sweep_coord_safe() below decides, per wave.
+__device__ __forceinline__ float refined_rcp(float b) {
+    const float y = __builtin_amdgcn_rcpf(b);
+    return __fmaf_rn(__fmaf_rn(-b, y, 1.0f), y, y);
+}
+__device__ __forceinline__ float div_with_rcp(float a, float b, float y) {
+    float q = a * y;
+    q = __fmaf_rn(__fmaf_rn(-b, q, a), y, q);
+    return __fmaf_rn(__fmaf_rn(-b, q, a), y, q);
+}
+__device__ __forceinline__ bool sweep_coord_safe(float X, float Y, float Z) {
+    const float ax = fabsf(X), ay = fabsf(Y), az = fabsf(Z);
+    return (az >= 1e-10f) & (az <= 1e10f) & ((ax >= 1e-10f) | (ax == 0.0f)) & (ax <= 1e10f) & ((ay >= 1e-10f) | (ay == 0.0f)) & (ay <= 1e10f);
+}
+// sweep_coord with X/Z and Y/Z sharing one refined reciprocal and the divisions by (W-1)/2, (H-1)/2 through their refined
+// reciprocals rhw / rhh (wave-uniform): 23 vector instructions where four compiler divisions take 44.  The caller has checked
+// sweep_coord_safe(X, Y, Z) for the whole wave (else: sweep_coord).
+__device__ __forceinline__ void sweep_coord_shared(float X, float Y, float Z, float half_w, float half_h, float rhw, float rhh,
+                                                   float unn_w, float unn_h, int align_corners, float &ix, float &iy) {
+    const float y = refined_rcp(Z);
+    const float px = div_with_rcp(X, Z, y), py = div_with_rcp(Y, Z, y);
+    const float gx = div_with_rcp(px, half_w, rhw) - 1.0f;
+    const float gy = div_with_rcp(py, half_h, rhh) - 1.0f;
+    if (align_corners) {
+        ix = (gx + 1.0f) * unn_w;
+        iy = (gy + 1.0f) * unn_h;
+    } else {
+        ix = __fmaf_rn(gx + 1.0f, unn_w, -0.5f);
+        iy = __fmaf_rn(gy + 1.0f, unn_h, -0.5f);
+    }
+}
+
 // Bilinear taps with zeros padding (ATen grid_sampler_2d bilinear/zeros).
 struct Taps {
     float nw, ne, sw, se;  // weights of (y0,x0) (y0,x1) (y1,x0) (y1,x1)

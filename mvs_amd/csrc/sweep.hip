@@ -1531,7 +1531,7 @@ extern "C" int mvs_costvol_variance_fwd_ws2_f32(const float *ref_fea, const floa
 
 extern "C" size_t mvs_costvol_variance_handover_bytes(int B, int C, int D, int H, int W) {
     if (B <= 0 || C <= 0 || C % 8 || D <= 0 || H <= 0 || W <= 0) return 0;
-    const size_t pairs = (size_t)B * D * pairs_geom(C, H, W, kPairsLayoutTiled).plane, f32 = (size_t)B * D * H * W * C * 4;
+    const size_t pairs = (size_t)B * D * pairs_geom(C, H, W, kPairsLayoutStrips).plane, f32 = (size_t)B * D * H * W * C * 4;
     return pairs > f32 ? pairs : f32;
 }
 
@@ -1550,10 +1550,10 @@ extern "C" int mvs_costvol_variance_fwd_ws3_f32(const float *ref_fea, const floa
     ho.hand = static_cast<unsigned *>(hand);
     ho.redo = static_cast<unsigned *>(redo);
     ho.veto = static_cast<const float *>(reader_veto);
-    ho.layout = kPairsLayoutTiled;
-#ifdef MVS_TUNING   // scripts/exp_handover.py: the row layout (no halo copies; conv0 on it is not wired), ablation flags of the persistent kernel
+    ho.layout = kPairsLayoutStrips;
+#ifdef MVS_TUNING   // scripts/exp_handover.py: the other layouts (conv0 on them is not wired), ablation flags of the persistent kernel
     static const int lay = [] { const char *e = getenv("MVS_HANDOVER_LAYOUT"); return e ? atoi(e) : 0; }();
-    if (lay == kPairsLayoutRows) ho.layout = lay;
+    if (pairs_layout_ok(lay)) ho.layout = lay;
 #endif
     return variance_ws_impl(ref_fea, src_feas, rot_trans, depth_values, 0, B, V, C, D, H, W, align_corners, 0, fea_layout,
                             MVS_LAYOUT_C8, flags, static_cast<float *>(out_volume), workspace, workspace_bytes, var_absmax, stream, &ho);

@@ -107,19 +107,31 @@ inline bool grid_for(int64_t total, int per_block, unsigned &grid) {
 struct PairsGeom {
     int64_t plane;          // between depth planes
     int64_t chunk;          // between 8-channel chunks of a plane
-    int64_t xtile;          // C8PT: between 32-voxel x tiles (0 for C8P)
+    int64_t xtile;          // C8PT: between 32-voxel x tiles (0 otherwise)
     int64_t region;         // between (part, parity) blocks: H * rowpitch
+    int64_t halo;           // C8PH: offset of the halo strips inside a chunk's block (behind its four regions)
+    int64_t halo_part;      // C8PH: between the hi and the lo strips
+    int64_t dup_lo;         // from the hi piece of a halo COPY to its lo piece (C8PT: 2 * region, C8PH: halo_part)
     int rowpitch;           // between rows of a block
+    int strip;              // C8PH: bytes of one strip = H pieces
     int tiled;              // 1 = C8PT
+    int strips;             // 1 = C8PH
 };
-constexpr int kPairsLayoutRows = 6, kPairsLayoutTiled = 7;   // = MVS_LAYOUT_C8P / MVS_LAYOUT_C8PT (include/mvs_hip.h)
+// = MVS_LAYOUT_C8P / MVS_LAYOUT_C8PT / MVS_LAYOUT_C8PH (include/mvs_hip.h)
+constexpr int kPairsLayoutRows = 6, kPairsLayoutTiled = 7, kPairsLayoutStrips = 8;
+__host__ __device__ inline bool pairs_layout_ok(int layout) { return layout >= kPairsLayoutRows && layout <= kPairsLayoutStrips; }
 __host__ __device__ inline PairsGeom pairs_geom(int C, int H, int W, int layout) {
     PairsGeom g;
     g.tiled = layout == kPairsLayoutTiled;
+    g.strips = layout == kPairsLayoutStrips;
     g.rowpitch = g.tiled ? 17 * 16 : ((W + 1) / 2) * 16;
     g.region = (int64_t)H * g.rowpitch;
     g.xtile = g.tiled ? 4 * g.region : 0;
-    g.chunk = g.tiled ? (int64_t)((W + 31) / 32) * g.xtile : 4 * g.region;
+    g.strip = H * 16;
+    g.halo = 4 * g.region;
+    g.halo_part = g.strips ? (int64_t)((W + 31) / 32) * 2 * g.strip : 0;
+    g.dup_lo = g.tiled ? 2 * g.region : g.halo_part;
+    g.chunk = g.tiled ? (int64_t)((W + 31) / 32) * g.xtile : ((4 * g.region + 2 * g.halo_part + 255) & ~(int64_t)255);
     g.plane = (int64_t)(C / 8) * g.chunk;
     return g;
 }
@@ -140,7 +152,7 @@ struct SweepHandover {
     unsigned *redo = nullptr;
     const float *veto = nullptr;   // NULL, or one float of the volume's reader: NaN there = "I cannot take pieces" (conv0's pack leaves a
                                    // NaN in its scale word when the layer's weights are not finite) -- the volume then leaves as fp32
-    int layout = 0;           // kPairsLayoutRows / kPairsLayoutTiled
+    int layout = 0;           // kPairsLayoutRows / kPairsLayoutTiled / kPairsLayoutStrips
     int redo_all = 0;         // cold kernel only: decide *redo and, if the pieces do not hold, serve EVERY (tile, wave) in fp32
 };
 __device__ __forceinline__ bool hand_is_pairs(unsigned bits) { return bits < 0x7f800000u; }

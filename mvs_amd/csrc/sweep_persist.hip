@@ -31,8 +31,11 @@
 //
 // EXACT = the reference's coordinate arithmetic op for op (mvs_common.h) and its
 // E[x^2] - E[x]^2 with IEEE divisions: bit-identical to the other variance kernels.
-// FAST  = one reciprocal (+1 Newton step) shared by X/Z and Y/Z, normalise/un-normalise
-// folded into one FMA, Q accumulated with an FMA, multiplication by 1/V.
+// FAST  = (round 6) the SAME sampling coordinates bit for bit -- the four divisions through shared / precomputed
+// refined reciprocals instead of four compiler sequences --, Q accumulated with an FMA, multiplication by 1/V
+// (until round 5: one reciprocal for X/Z and Y/Z and the normalise / un-normalise pair folded into one FMA; on a
+// TRAINED network those ~3e-5 texel coordinate differences moved the depth by up to 7e-3 mm against the reference,
+// profiles/r06_trained_budget_switches.json).
 //
 // Measured at BASELINE configs[1] (22.7 M voxels x 32 channels x 4 source views): 1.46-1.56 ms
 // EXACT, 1.21-1.25 ms FAST against 1.85 ms for the per-tile kernel.  SQ counters (profiles/):
@@ -68,19 +71,26 @@ struct PersistArgs {
     int nseg, cps;          // a pixel tile's depth chunks are walked in nseg segments of cps chunks (the work units)
     int out_c8, flags;
     int fea_c4;             // features: 0 = [B,C/16,H,W,16], 1 = [B,C/4,H,W,4], 2 = [B,H,W,C]
-    float sx, ox, sy, oy;   // FAST: ix = (X/Z) * sx + ox
+    float sx, ox, sy, oy;   // footprint planning (chooser, DMA boxes): ix ~ (X/Z) * sx + ox
+    float rhw, rhh;         // FAST: correctly rounded 1 / ((W-1)/2), 1 / ((H-1)/2) (mvs_common.h: sweep_coord_shared)
     int autosel;            // 1: run only if queue[kSelWord] names this kernel's tile depth (variance_choose_kernel)
     unsigned *absmax;       // NULL, or the absmax block (mvs_common.h) that collects the largest |variance| written
                             // (atomic max; the operand scale of mvs_conv3d_c8_f16x3_f32)
     SweepHandover ho;       // ho.hand != NULL: the volume may leave as two fp16 pieces per value (sweep_common.h)
     PairsGeom pg;           // ... in this layout; `out` then holds max(fp32, pairs) bytes
 };
-// Byte offset of a voxel's hi piece inside its (plane, chunk) block of a pairs volume (the lo piece: + 2 * pg.region), and -- x-tiled
-// layout -- of its second copy as a halo voxel of the neighbouring 32-voxel tile (0xffffffff: none).
+// Byte offset of a voxel's hi piece inside its (plane, chunk) block of a pairs volume (the lo piece: + 2 * pg.region), and of its
+// second copy as a halo voxel of the neighbouring 32-voxel tile (0xffffffff: none; its lo piece: + pg.dup_lo) -- inside that tile's
+// block (x-tiled layout) or in its halo strip (strips layout).
 __device__ __forceinline__ void pairs_offsets(const PairsGeom &pg, int x, int y, int W, unsigned &main, unsigned &dup) {
     dup = 0xffffffffu;
     if (!pg.tiled) {
         main = (unsigned)((x & 1) * pg.region + (int64_t)y * pg.rowpitch + (x >> 1) * 16);
+        if (pg.strips) {
+            const int tx = x >> 5, xm = x & 31;
+            if (xm == 31 && x + 1 < W) dup = (unsigned)(pg.halo + (int64_t)((tx + 1) * 2) * pg.strip + y * 16);        // left halo of tile tx + 1
+            else if (xm == 0 && x > 0) dup = (unsigned)(pg.halo + (int64_t)((tx - 1) * 2 + 1) * pg.strip + y * 16);    // right halo of tile tx - 1
+        }
         return;
     }
     const int tx = x >> 5, xl = (x & 31) + 1;     // local x' = 1 .. 32 of the tile's 0 .. 33
@@ -138,16 +148,14 @@ __device__ __forceinline__ void tap_setup(const float *__restrict__ r, int cx, i
     // index outside the image, so a non-finite coordinate ends up with no tap in the image and NaN weights exactly as with the
     // earlier `fin ? ... : -4` select -- whose exec-mask branch per view cost ~20 scalar instructions on every voxel.
     if constexpr (FAST) {
-        const float fx = (float)cx, fy = (float)cy;
-        const float rx = __fmaf_rn(r[0], fx, __fmaf_rn(r[1], fy, r[2]));
-        const float ry = __fmaf_rn(r[4], fx, __fmaf_rn(r[5], fy, r[6]));
-        const float rz = __fmaf_rn(r[8], fx, __fmaf_rn(r[9], fy, r[10]));
-        const float X = __fmaf_rn(rx, dv, r[3]), Y = __fmaf_rn(ry, dv, r[7]);
-        const float Z = __fmaf_rn(rz, dv, r[11]);
-        float inv = __builtin_amdgcn_rcpf(Z);
-        inv = __fmaf_rn(__fmaf_rn(-Z, inv, 1.0f), inv, inv);
-        ix = __fmaf_rn(X * inv, sx, ox);
-        iy = __fmaf_rn(Y * inv, sy, oy);
+        // (round 6) the reference's coordinate arithmetic op for op -- so the taps ARE the reference's -- with its four divisions
+        // done through shared / precomputed reciprocals (mvs_common.h: sweep_coord_shared; sx / sy here = the correctly rounded
+        // reciprocals of (W-1)/2, (H-1)/2: PersistArgs.rhw / rhh); a wave with an operand outside the safe range takes the compiler's divisions
+        float rx, ry, rz;
+        sweep_ray(r, (float)cx, (float)cy, rx, ry, rz);
+        const float X = rx * dv + r[3], Y = ry * dv + r[7], Z = rz * dv + r[11];
+        if (__any(!sweep_coord_safe(X, Y, Z))) sweep_coord(r, rx, ry, rz, dv, p.half_w, p.half_h, p.unn_w, p.unn_h, p.align_corners, ix, iy);
+        else sweep_coord_shared(X, Y, Z, p.half_w, p.half_h, sx, sy, p.unn_w, p.unn_h, p.align_corners, ix, iy);
         fin = (int)(fabsf(ix) <= 3.0e38f) & (int)(fabsf(iy) <= 3.0e38f);   // (bitwise on purpose: no branch)
         const float x0f = floorf(ix), y0f = floorf(iy);
         const float wx = ix - x0f, wy = iy - y0f, ex = 1.0f - wx, ey = 1.0f - wy;
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(256) void variance_fwd_cold_kernel(PersistArgs a, i
         for (int v = 0; v < NV; ++v) {
             int tx0, ty0;
             bool has;
-            tap_setup<FAST>(a.rt + ((int64_t)v * p.B + b) * 12, cx, cy, dv, p, a.sx, a.ox, a.sy, a.oy,
+            tap_setup<FAST>(a.rt + ((int64_t)v * p.B + b) * 12, cx, cy, dv, p, a.rhw, 0.0f, a.rhh, 0.0f,
                             wnw[v], wne[v], wsw[v], wse[v], tx0, ty0, has);
             const int x0c = min(max(tx0, 0), p.W - 1), x1c = min(max(tx0 + 1, 0), p.W - 1);
             const int y0c = min(max(ty0, 0), p.H - 1), y1c = min(max(ty0 + 1, 0), p.H - 1);
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(256) void variance_fwd_cold_kernel(PersistArgs a, i
                     *reinterpret_cast<u32x4 *>(ch + pmain + 2 * a.pg.region) = l;
                     if (pdup != 0xffffffffu && !(a.flags & kPFlagNoDup)) {
                         *reinterpret_cast<u32x4 *>(ch + pdup) = h;
-                        *reinterpret_cast<u32x4 *>(ch + pdup + 2 * a.pg.region) = l;
+                        *reinterpret_cast<u32x4 *>(ch + pdup + a.pg.dup_lo) = l;
                     }
                 }
             } else if (live && !(a.flags & kPFlagNoStore)) {
@@ -641,7 +649,7 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
             for (int v = 0; v < NV; ++v) {
                 int tx0, ty0;
                 bool has;
-                tap_setup<FAST>(s_cam + (v * p.B + cb) * 12, cx, cy, dv, p, a.sx, a.ox, a.sy, a.oy,
+                tap_setup<FAST>(s_cam + (v * p.B + cb) * 12, cx, cy, dv, p, a.rhw, 0.0f, a.rhh, 0.0f,
                                 wnw[v], wne[v], wsw[v], wse[v], tx0, ty0, has);
                 const int bx0 = pbx0[v], by0 = pby0[v], bw = pbw[v], bh = pbh[v];
                 const bool inbox = !has | ((tx0 >= bx0) & (tx0 + 1 < bx0 + bw) & (ty0 >= by0) & (ty0 + 1 < by0 + bh));
@@ -807,7 +815,7 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
                     if (any_dup) {
                         if (pdup != 0xffffffffu) {
                             *reinterpret_cast<u32x4 *>(ch + pdup) = hp;
-                            *reinterpret_cast<u32x4 *>(ch + pdup + 2 * a.pg.region) = lp;
+                            *reinterpret_cast<u32x4 *>(ch + pdup + a.pg.dup_lo) = lp;
                         }
                         stored = 2 * NST;
                     }
@@ -882,6 +890,7 @@ int launch_variance_choose(const float *rt, const float *depth, const SweepParam
     PersistArgs a{};
     a.rt = rt; a.depth = depth; a.p = p; a.absmax = absmax;
     if (ho) a.ho = *ho;
+    a.rhw = (float)(1.0 / (double)p.half_w); a.rhh = (float)(1.0 / (double)p.half_h);
     if (p.align_corners) { a.sx = 1.0f; a.ox = 0.0f; a.sy = 1.0f; a.oy = 0.0f; }
     else {
         a.sx = (float)((double)p.W / (double)(p.W - 1)); a.ox = -0.5f;
@@ -931,6 +940,7 @@ int launch_variance_persist(const float *ref16, const float *srcs16, const float
     a.fea_c4 = fea_c4;
     a.autosel = autosel;
     a.absmax = absmax;
+    a.rhw = (float)(1.0 / (double)p.half_w); a.rhh = (float)(1.0 / (double)p.half_h);
     if (p.align_corners) { a.sx = 1.0f; a.ox = 0.0f; a.sy = 1.0f; a.oy = 0.0f; }
     else {
         a.sx = (float)((double)p.W / (double)(p.W - 1)); a.ox = -0.5f;
@@ -963,6 +973,7 @@ int launch_variance_redo_all(const float *ref16, const float *srcs16, const floa
     a.total_tiles = (int)persist_tiles(p, nw);
     a.out_c8 = 1; a.fea_c4 = fea_c4; a.absmax = absmax;
     a.ho = ho; a.ho.redo_all = 1;
+    a.rhw = (float)(1.0 / (double)p.half_w); a.rhh = (float)(1.0 / (double)p.half_h);
     if (p.align_corners) { a.sx = 1.0f; a.ox = 0.0f; a.sy = 1.0f; a.oy = 0.0f; }
     else {
         a.sx = (float)((double)p.W / (double)(p.W - 1)); a.ox = -0.5f;

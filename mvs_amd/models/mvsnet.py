@@ -108,10 +108,11 @@ class FeatureNet(nn.Module):
         y = F.conv2d(x, self.feature.weight, self.feature.bias, 1, 1)
         return y.permute(0, 2, 3, 1).contiguous()
 
-    def forward_hip(self, imgs_nchw, out_c4=False, out_absmax=None):
+    def forward_hip(self, imgs_nchw, out_c4=False, collect_absmax=False):
         """[N,3,H,W] image batch (the reference's layout) -> [N,H/4,W/4,32] channels-last, or with
-        out_c4 the last layer's epilogue writes 4-channel blocks [N,8,H/4,W/4,4] (MVS_LAYOUT_C4).  out_absmax: a ZEROED absmax
-        block the last layer's epilogue collects the maps' largest magnitude in (the bound a hand-over sweep scales its pieces by)."""
+        out_c4 the last layer's epilogue writes 4-channel blocks [N,8,H/4,W/4,4] (MVS_LAYOUT_C4).  collect_absmax: returns
+        (maps, block) -- the last layer's epilogue collects the maps' largest magnitude in an absmax block (the bound a hand-over
+        sweep scales its pieces by; a row of the layers' own blocks: one fill zeroes them all)."""
         x = imgs_nchw
         P = self._hip_params()
         first = 0
@@ -119,7 +120,10 @@ class FeatureNet(nn.Module):
         # epilogue (ops.conv2d: x_absmax / out_absmax); the chain starts at the fused head
         head = ops.feature_head_enabled() and ops.feature_head_supported(x.shape[2], x.shape[3])
         # (+ two rows: the flag words and the spare block of the fused conv3 + conv4 kernel -- zeroed by the same fill)
-        blocks = ops.absmax_block(x.device, zero=True, n=len(P) + 2) if (head and ops.split_f16_enabled()) else None
+        blocks = ops.absmax_block(x.device, zero=True, n=len(P) + 3) if (head and ops.split_f16_enabled()) else None
+        out_absmax = None
+        if collect_absmax:      # (row len(P) + 2; without the layers' blocks: one of its own)
+            out_absmax = blocks[len(P) + 2] if blocks is not None else ops.absmax_block(x.device, zero=True)
         if head:
             with ops.stage("feature.head"):   # conv0 + conv1 in one kernel
                 x = ops.feature_head(x, P[0]["weight"], P[0]["scale"], P[0]["shift"], P[1]["head"], P[1]["scale"],
@@ -141,7 +145,7 @@ class FeatureNet(nn.Module):
                     nlast = i + 1 == len(P) - 1
                     with ops.stage("feature." + p["name"] + "+" + nx["name"]):
                         x = ops.conv2d_pair(x, blocks[i - 1], p["pair"], p, nx, out_c4=(out_c4 and nlast),
-                                            out_absmax=blocks[i + 1] if not nlast else out_absmax, flag=blocks[len(P):].reshape(-1))
+                                            out_absmax=blocks[i + 1] if not nlast else out_absmax, flag=blocks[len(P):len(P) + 2].reshape(-1))
                     skip = i + 1
                     continue
             with ops.stage("feature." + p["name"]):
@@ -149,7 +153,8 @@ class FeatureNet(nn.Module):
                                p["shift"], p["relu"], planar=(i == 0), out_c4=(out_c4 and last),
                                x_absmax=blocks[i - 1] if blocks is not None else None,
                                out_absmax=out_absmax if last else (blocks[i] if blocks is not None else None))
-        return x
+        self._last_blocks = blocks        # (diagnostics, as CostRegNet's)
+        return (x, out_absmax) if collect_absmax else x
 
 
 def _deconv_block(cin, cout):
@@ -286,6 +291,7 @@ class CostRegNet(nn.Module):
             raise ops.MvsHipError("CostRegNet.forward_hip: a handed-over volume needs the two-piece layers (MVS_SPLIT_F16, conv_impl auto)")
         blocks = ops.absmax_block(x_cl.device, zero=True, n=10) if f16 else None      # (row 9: the fused tail's flag word)
         blk = (lambda i: blocks[i]) if f16 else (lambda i: None)
+        self._last_blocks = blocks        # (diagnostics: scripts/trained_guard_stats.py reads what the range guard judged)
 
         def run(name, t, skip=None, relu=True, x_abs=None, out_abs=None):
             p = P[name]
@@ -486,8 +492,10 @@ class MVSNet(nn.Module):
             elif self.feature_impl == "hip" and self.feature.hip_supported():
                 if c4 and ops.conv2d_persistent_enabled():
                     # (the last layer collects the maps' largest magnitude: the bound a hand-over sweep scales its pieces by)
-                    fea_amax = ops.absmax_block(flat.device, zero=True) if hand_over else None
-                    f4 = self.feature.forward_hip(flat, out_c4=True, out_absmax=fea_amax)     # [B*V,8,h,w,4]
+                    if hand_over:
+                        f4, fea_amax = self.feature.forward_hip(flat, out_c4=True, collect_absmax=True)     # [B*V,8,h,w,4]
+                    else:
+                        f4 = self.feature.forward_hip(flat, out_c4=True)
                 else:
                     f = self.feature.forward_hip(flat)                   # [B*V,h,w,32]: HIP 2D MFMA kernels
             else:
@@ -524,7 +532,7 @@ class MVSNet(nn.Module):
                     var = ops.costvol_variance_handover(f16[0], f16[1:], rts, depth_values, fea_amax, self.align_corners,
                                                         fast=self.variance_fast, veto=ops.conv0_veto_word(p0["packed_f16x3"], C))
                 if var is not None:
-                    pass
+                    self._last_handover_words = (var.hand, var.absmax, var.redo)      # (diagnostics: three small device tensors)
                 elif use_lds:
                     if c8 and ops.conv0_f16_enabled():   # the sweep kernels collect conv0's operand scale as they store
                         amax = ops.absmax_block(f16.device)

@@ -537,7 +537,7 @@ def handover_enabled():
 
 
 class HandedVolume:
-    """What mvs_costvol_variance_fwd_ws3_f32 left on the device: `buf` = the volume -- MVS_LAYOUT_C8PT pieces scaled by the bound
+    """What mvs_costvol_variance_fwd_ws3_f32 left on the device: `buf` = the volume -- MVS_LAYOUT_C8PH pieces scaled by the bound
     in `hand` if redo[0] == 0, plain fp32 MVS_LAYOUT_C8 if redo[0] == 1 (nobody on the host needs to know which) --, `absmax` =
     the block of its true largest magnitude, shape = (B, C, D, H, W)."""
     __slots__ = ("buf", "hand", "absmax", "redo", "shape")
@@ -556,13 +556,21 @@ class HandedVolume:
             return self.buf[:B * D * H * W * C * 4].view(torch.float32).view(B, D, H, C // 8, W, 8).clone()
         e = (int(self.hand.max().item()) >> 23 & 255) - 127
         e = max(-100, min(127, e))
-        tiles = (W + 31) // 32
-        pc = self.buf[:B * D * (C // 8) * tiles * 4 * H * 17 * 16].view(torch.float16).view(B, D, C // 8, tiles, 2, 2, H, 17, 8)
-        v = pc[:, :, :, :, 0].double() + pc[:, :, :, :, 1].double()            # [B,D,G,tiles,parity,H,17,8]
-        # local x' = 2 i + parity; own voxels x' = 1 .. 32
-        v = v.permute(0, 1, 2, 3, 5, 6, 4, 7).reshape(B, D, C // 8, tiles, H, 34, 8)[:, :, :, :, :, 1:33]
-        v = v.permute(0, 1, 4, 2, 3, 5, 6).reshape(B, D, H, C // 8, tiles * 32, 8)[:, :, :, :, :W]
+        main, _ = self.pieces()
+        v = main[:, :, :, 0].double() + main[:, :, :, 1].double()               # hi + lo: [B,D,G,parity,H,W2,8]
+        v = v.permute(0, 1, 4, 2, 5, 3, 6).reshape(B, D, H, C // 8, -1, 8)[:, :, :, :, :W]      # x = 2 i + parity
         return (v * 2.0 ** (e - 14)).float().contiguous()
+
+    def pieces(self):
+        """Views of the MVS_LAYOUT_C8PH buffer as fp16: main [B,D,C/8,part,parity,H,ceil(W/2),8], halo strips [B,D,C/8,part,tile,side,H,8]."""
+        B, C, D, H, W = self.shape
+        w2, tiles = (W + 1) // 2, (W + 31) // 32
+        region, strip = H * w2 * 16, H * 16
+        chunk = (4 * region + 4 * tiles * strip + 255) // 256 * 256
+        blk = self.buf[:B * D * (C // 8) * chunk].view(B, D, C // 8, chunk)
+        main = blk[..., :4 * region].view(torch.float16).view(B, D, C // 8, 2, 2, H, w2, 8)
+        halo = blk[..., 4 * region:4 * region + 4 * tiles * strip].view(torch.float16).view(B, D, C // 8, 2, tiles, 2, H, 8)
+        return main, halo
 
 
 def costvol_variance_handover(ref16, srcs16, rts, depth_values, fea_absmax, align_corners=False, fast=False, veto=None):

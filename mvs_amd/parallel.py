@@ -114,7 +114,7 @@ class GraphedTrainStep:
 
     def _average_and_step(self):
         if self.split:
-            if self.world > 1:
+            if self.world > 1 and self.allreduce:      # (allreduce=False is a timing aid: nothing was summed, nothing to average)
                 self.flat.mul_(1.0 / self.world)
             # back into the tensors backward wrote (one multi-tensor copy): the optimizer then runs the very kernels of the
             # one-graph step on the very same operands -- with the gradients as VIEWS of the flat buffer torch's multi-tensor

@@ -1,7 +1,7 @@
 """The sweep with its volume handed over as fp16 pieces (mvs_costvol_variance_fwd_ws3_f32) against the fp32 sweep, at BASELINE
 configs[1]'s shape (V = 5, 32 channels, 296 x 400, 192 planes): what the pieces cost the producer.
 
-    python scripts/exp_handover.py            # children: fp32, pieces (x-tiled), and with the tuning build: row layout, no halo copies, no stores
+    python scripts/exp_handover.py            # children: fp32, pieces (rows + halo strips), and with the tuning build: the other layouts, no halo copies, no stores
 
 Each variant in its own process (the switches are read once)."""
 import json
@@ -55,14 +55,15 @@ def run(env_extra):
 
 
 def main():
-    out = {"fp32": run({"EXP_MODE": "fp32"}), "pieces_xtiled": run({"EXP_MODE": "hand"})}
+    out = {"fp32": run({"EXP_MODE": "fp32"}), "pieces_strips": run({"EXP_MODE": "hand"})}
     if os.path.exists(os.path.join(ROOT, "mvs_amd", "csrc", "libmvs_hip_tuning.so")):
         t = {"MVS_HIP_TUNING": "1", "EXP_MODE": "hand"}
         out["tuning_fp32"] = run({"MVS_HIP_TUNING": "1", "EXP_MODE": "fp32"})
-        out["tuning_pieces_xtiled"] = run(t)
+        out["tuning_pieces_strips"] = run(t)
         out["tuning_pieces_rows"] = run(dict(t, MVS_HANDOVER_LAYOUT="6"))
-        out["tuning_pieces_xtiled_no_halo_copies"] = run(dict(t, MVS_HANDOVER_FLAGS="128"))
-        out["tuning_pieces_xtiled_no_stores"] = run(dict(t, MVS_HANDOVER_FLAGS="2"))
+        out["tuning_pieces_xtiled"] = run(dict(t, MVS_HANDOVER_LAYOUT="7"))
+        out["tuning_pieces_strips_no_halo_copies"] = run(dict(t, MVS_HANDOVER_FLAGS="128"))
+        out["tuning_pieces_strips_no_stores"] = run(dict(t, MVS_HANDOVER_FLAGS="2"))
     for k, v in out.items():
         print(k, json.dumps(v), flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

@@ -2,7 +2,7 @@
 # Round profile on the GPU box: rocprofv3 kernel trace + stats of the bench command,
 # then HBM-traffic counters in their own passes (no tracing mixed in).
 # Usage: bash scripts/profile_round.sh r01     (writes gpurun_out/prof_<tag>/...)
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd "$(dirname "$0")/.." ; mkdir -p gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 CMD="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras"
@@ -29,7 +29,7 @@ for name in ("fetch", "write"):
                                                  sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]}
 json.dump(out, open(f"{root}/summary.json", "w"), indent=1)
 # per-stage HBM-side traffic for bench.py's roofline.traffic (2*FETCH + WRITE, bytes)
-names = {"costvol_variance": "variance_fwd_persist_kernel", "costreg.conv0": "conv3d_c8_f16x3_zs_kernel<32",
+names = {"costvol_variance": "variance_fwd_persist_kernel", "costreg.conv0": "conv3d_c8p_f16x3_kernel<32",
          "costreg.conv1": "conv_s2_march_kernel", "feature.conv3+conv4": "conv2d_pair_kernel", "costreg.conv2": "SplitCfg<16, 16, 3",
          "costreg.conv4": "SplitCfg<32, 32, 3", "costreg.conv11": "DeconvSplitCfg<16, true",
          "costreg.prob": "conv3d_cout1_march_kernel", "costreg.tail": "costreg_tail_kernel", "softmax_regress_conf": "softmax_regress_conf_kernel",

@@ -101,6 +101,57 @@ def g17():
                      "cost_regularization.conv0.bn.running_var", "cost_regularization.conv11.1.running_mean")})
 
 
+G27_PARAMS = ("feature.conv0.conv.weight", "cost_regularization.conv6.conv.weight", "cost_regularization.prob.weight")
+G27_STATS = ("feature.conv0.bn.running_mean", "feature.conv6.bn.running_var", "cost_regularization.conv0.bn.running_var",
+             "cost_regularization.conv11.1.running_mean")
+
+
+def g27():
+    """SURVEY 8(c)'s last row: THREE consecutive steps of the reference's train_sample composition (MVSNet/train.py:98,204-248:
+    zero_grad -> forward(train) -> mvsnet_loss -> backward -> Adam(lr 1e-3, betas 0.9 / 0.999, wd 0).step()) on ONE fixed batch
+    (configs[4]'s per-GPU workload, tests/config_cases.py::train_case): the three losses, three named parameters and four
+    BatchNorm running statistics after step 3 -- and the same trajectory in float64 (oracle/torch_ref.py) beside them."""
+    c = cc.train_case()
+    net, ref_loss = _mvsnet_ref(c["sd"], train=True)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.0)
+    losses = []
+    t0 = time.time()
+    for step in range(3):
+        opt.zero_grad()
+        out = net(T(c["imgs"]), T(c["proj"]), T(c["depth_values"]))
+        loss = ref_loss(out["depth"], T(c["gt"]), T(c["mask"]))
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+        print("g27 reference step", step, "loss", float(loss), round(time.time() - t0, 1), "s", flush=True)
+    sd3 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    del net, out, opt
+    gc.collect()
+    sd64 = {k: (v.double().requires_grad_(True) if (v.is_floating_point() and "running" not in k) else
+                (v.double() if v.is_floating_point() else v.clone())) for k, v in c["sd"].items()}
+    params = [v for v in sd64.values() if v.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.0)
+    losses64 = []
+    for step in range(3):
+        opt.zero_grad()
+        o64 = torch_ref.mvsnet_forward(T(c["imgs"]).double(), T(c["proj"]).double(), T(c["depth_values"]).double(), sd64, train=True)
+        l64 = torch_ref.masked_smooth_l1(o64["depth"], T(c["gt"]).double(), T(c["mask"]))
+        l64.backward()
+        opt.step()
+        losses64.append(float(l64))
+        print("g27 float64 step", step, "loss", float(l64), round(time.time() - t0, 1), "s", flush=True)
+        del o64, l64
+        gc.collect()
+    print("  losses32", losses, "losses64", losses64)
+    for k in G27_PARAMS:
+        print("  ", k, "max |p32 - p64| after step 3:", float((sd3[k].double() - sd64[k].detach()).abs().max()),
+              " max |p3 - p0|:", float((sd3[k] - c["sd"][k]).abs().max()))
+    save("g27_train_3steps", losses=np.array(losses, dtype=np.float64), losses64=np.array(losses64, dtype=np.float64),
+         **{"param__" + k: sd3[k] for k in G27_PARAMS}, **{"param64__" + k: sd64[k].detach() for k in G27_PARAMS},
+         **{"stat__" + k: sd3[k] for k in G27_STATS},
+         **{"stat64__" + k: sd64[k] for k in G27_STATS if k in sd64})
+
+
 def _eval_case(name, c, tag):
     net, _ = _mvsnet_ref(c["sd"])
     t0 = time.time()

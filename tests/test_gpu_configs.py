@@ -57,3 +57,57 @@ def test_mvsnet_config4_train_step_640x512_v3_d192():
     # BatchNorm running statistics after the step (momentum 0.1, unbiased variance)
     for k, v in r["stats"].items():
         assert v < 5e-6, (k, v)
+
+
+def test_three_training_steps_follow_the_reference_trajectory():
+    """SURVEY 8(c)'s last row: THREE consecutive steps of the reference's train_sample composition (MVSNet/train.py:98,204-248:
+    zero_grad -> forward(train) -> mvsnet_loss -> backward -> Adam(1e-3, 0.9 / 0.999, wd 0).step()) on one fixed batch -- g27 holds
+    the reference's own three losses, three named parameters and four BatchNorm running statistics after step 3, and the float64
+    trajectory of the same composition.
+
+    What can be asserted: step 1 starts from the same weights -- its loss is the reference's to 1e-5 (as g17).  From then on the
+    trajectory is ILL-CONDITIONED in float32 and the fixture shows it: Adam divides every gradient element by its own running
+    magnitude, so an element whose float32 gradient is off by a few per cent of the tensor's largest (g17) moves by a different
+    +-1e-3 -- the reference's own float32 parameters end 9e-4 rms from the float64 ones after three steps, of a 2e-3 rms total
+    movement, and its losses 4.5e-4 relative.  So: losses 2 and 3 within 2e-3 relative of the reference's and no farther from the
+    float64 ones than 2x the reference; per parameter tensor the rms distance to the reference's AND to the float64 parameters no
+    larger than 1.5x the reference's own distance to float64; running statistics within 5 % of their largest entry of the
+    reference's (they average three batches of activations that already differ)."""
+    import numpy as np
+    import config_cases as cc
+    from fullsize_cases import GOLDEN, _dev
+    from mvs_amd.models import MVSNet, mvsnet_loss
+    import os
+    dev = torch.device("cuda:0")
+    c = cc.train_case()
+    g = dict(np.load(os.path.join(GOLDEN, "g27_train_3steps.npz")))
+    model = MVSNet(refine=False)
+    model.load_state_dict(c["sd"])
+    model = model.to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.0)
+    imgs, proj, dv, gt, mask = (_dev(c[k], dev) for k in ("imgs", "proj", "depth_values", "gt", "mask"))
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        out = model(imgs, proj, dv)
+        loss = mvsnet_loss(out["depth"], gt, mask)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    ref, l64 = g["losses"], g["losses64"]
+    assert abs(losses[0] - ref[0]) <= 1e-5 * ref[0], (losses, ref)
+    for i in (1, 2):
+        assert abs(losses[i] - ref[i]) <= 2e-3 * ref[i], (losses, ref)
+        assert abs(losses[i] - l64[i]) <= 2.0 * abs(ref[i] - l64[i]) + 1e-4 * l64[i], (losses, ref, l64)
+    assert losses[2] < losses[1] < losses[0]
+    sd = {k: v.detach().double().cpu().numpy() for k, v in model.state_dict().items()}
+    rms = lambda a: float(np.sqrt((a ** 2).mean()))   # noqa: E731
+    report = {}
+    for k in (x[7:] for x in g if x.startswith("param__")):
+        p32, p64 = g["param__" + k].astype(np.float64), g["param64__" + k]
+        own = rms(p32 - p64)
+        report[k] = (rms(sd[k] - p32), rms(sd[k] - p64), own)
+        assert rms(sd[k] - p32) <= 1.5 * own and rms(sd[k] - p64) <= 1.5 * own, (k, report[k])
+    for k in (x[6:] for x in g if x.startswith("stat__")):
+        s32 = g["stat__" + k].astype(np.float64)
+        assert np.abs(sd[k] - s32).max() <= 5e-2 * np.abs(s32).max(), (k, float(np.abs(sd[k] - s32).max()), float(np.abs(s32).max()))

@@ -44,11 +44,11 @@ def _conv_pairs(xp, blk, redo, pf, sc, sh, r, relu, shape, layout, om=None):
 
 @pytest.mark.parametrize("shape,cin", [((1, 12, 20, 70), 32), ((2, 7, 9, 37), 16), ((1, 5, 30, 33), 8), ((1, 33, 17, 64), 32), ((1, 2, 8, 32), 32),
                                        ((1, 1, 3, 5), 8), ((2, 19, 41, 100), 32)])
-@pytest.mark.parametrize("layout", [6, 7], ids=["rows", "xtiled"])
+@pytest.mark.parametrize("layout", [6, 7, 8], ids=["rows", "xtiled", "strips"])
 def test_conv0_on_pieces_is_bit_identical(dev, shape, cin, layout):
     """mvs_conv3d_c8p_f16x3_f32 (eight-row tiles, copies straight into the plane ring: no staging buffer, no split pass, one barrier
     per step) returns the bits of mvs_conv3d_c8_f16x3_f32 on the fp32 volume under the same absmax block: ragged sizes in every
-    dimension, one-plane and one-tile volumes, batch 2, all channel counts, affine + ReLU + skip add, both piece layouts; and does
+    dimension, one-plane and one-tile volumes, batch 2, all channel counts, affine + ReLU + skip add, all three piece layouts; and does
     nothing when its redo word is set."""
     from mvs_amd import ops
     B, D, H, W = shape
@@ -111,6 +111,13 @@ def test_sweep_hands_the_volume_over_as_pieces(dev, case, fast):
     assert ops.absmax_value(hv.hand) == float(bound)
     assert ops.absmax_value(hv.absmax) == ops.absmax_value(blk) == float(ref.abs().max())
     _decode_check(hv, ref, float(bound))
+    # the halo strips repeat the tile-border columns: x = 32 t - 1 (side 0) and x = 32 t + 32 (side 1), the same piece bits
+    main, halo = hv.pieces()
+    W = ref.shape[4]
+    for t in range((W + 31) // 32):
+        for side, x in ((0, 32 * t - 1), (1, 32 * t + 32)):
+            if 0 <= x < W:
+                assert torch.equal(halo[:, :, :, :, t, side], main[:, :, :, :, x & 1, :, x >> 1]), (t, side)
     # conv0
     g = torch.Generator().manual_seed(5)
     w = (torch.randn(8, 32, 3, 3, 3, generator=g) / (27 * 32) ** 0.5).to(dev)
@@ -253,3 +260,38 @@ def test_entry_points_reject_what_they_cannot_take(dev):
                                               vp(buf), None, 0, vp(words[:256]), vp(words[256:512]), vp(words[512:]),
                                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == -1 and b"absmax" in lib.mvs_last_error_string()
+
+
+@pytest.mark.parametrize("geom", [dict(h=40, w=64, D=24, rig=0), dict(h=74, w=100, D=48, rig=1), dict(h=128, w=160, D=192, rig=2)],
+                         ids=["small", "rig1", "rig2_d192"])
+def test_fast_mode_samples_at_the_reference_coordinates(dev, geom):
+    """(round 6) The persistent sweep's FAST mode keeps the reference's sampling coordinates bit for bit (module.py:66-84: its four
+    divisions through shared / precomputed refined reciprocals); only the variance arithmetic differs (FMA accumulation of the
+    squares, multiplication by 1/V).  With two views and a zero reference map the variance is w^2 / 4 in both arithmetics
+    EXACTLY (halving and quartering are exact), so the two modes must agree to the bit -- which they do iff every warped value
+    w, i.e. every tap and weight, is the same.  Until round 5 FAST had its own coordinate arithmetic (~3e-5 texel away) and a
+    trained network turned that into 7e-3 mm of depth (profiles/r06_trained_budget_switches.json)."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, torch
+from mvs_amd import ops, synth
+dev = torch.device("cuda:0")
+h, w, D, rig = %(h)d, %(w)d, %(D)d, %(rig)d
+g = torch.Generator().manual_seed(7)
+f = (torch.randn(2, 1, 8, h, w, 4, generator=g) * 3).to(dev)
+f[0] = 0
+rts = ops.rot_trans_all(torch.from_numpy(synth.proj_matrices(3, h, w, rig=rig)[:, [0, 2]]).to(dev), "device")
+dv = torch.from_numpy(synth.depth_values(D)).to(dev)
+a = ops.costvol_variance_c16(f[0], f[1:], rts, dv, out_c8=True, fast=True)
+b = ops.costvol_variance_c16(f[0], f[1:], rts, dv, out_c8=True, fast=False)
+assert float(a.abs().max()) > 0 and bool((a == 0).any())        # in-image and out-of-image samples both occur
+assert torch.equal(a, b), float((a - b).abs().max())
+print("OK")
+''' % geom
+    # (own process with the persistent kernel forced: the comparison must not depend on which kernel the chooser takes)
+    env = dict(os.environ, MVS_SWEEP_PERSIST="16")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

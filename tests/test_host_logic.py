@@ -284,3 +284,34 @@ def test_bench_self_launch_command_and_environment(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert "WORLD_SIZE=1" in str(e.value)
+
+
+def test_depth_metrics_are_per_image_then_batch_means():
+    """mvs_amd.tools.metrics against hand-computed cases of MVSNet/utils.py:129-158 (which cannot be imported: torchvision):
+    per-image masked means averaged over the batch -- NOT pooled --, the threshold strict, an empty mask NaN."""
+    import torch
+    from mvs_amd.tools import metrics
+    est = torch.tensor([[[1.0, 2.0], [3.0, 4.0]], [[10.0, 10.0], [10.0, 10.0]]])
+    gt = torch.tensor([[[1.5, 2.0], [7.0, 0.0]], [[12.0, 10.0], [2.0, 10.0]]])
+    mask = torch.tensor([[[True, True], [True, False]], [[True, False], [False, False]]])
+    # image 0: |err| over 3 pixels = 0.5, 0, 4 -> 1.5; image 1: one pixel, 2 -> 2; batch mean 1.75 (pooled would be 6.5 / 4 = 1.625)
+    assert metrics.abs_depth_error(est, gt, mask).item() == 1.75
+    # > 2 strictly: image 0: one of three (4 > 2); image 1: 2 > 2 is false -> 0; mean 1/6
+    assert abs(metrics.thres_error(est, gt, mask, 2).item() - (1.0 / 3.0) / 2) < 1e-7
+    assert abs(metrics.thres_error(est, gt, mask, 0.4).item() - (2.0 / 3.0 + 1.0) / 2) < 1e-7
+    assert metrics.thres_error(est, gt, mask, 8).item() == 0.0
+    # against the reference's own formulation (boolean indexing per image)
+    g = torch.Generator().manual_seed(0)
+    e, t = torch.rand(3, 16, 20, generator=g) * 50, torch.rand(3, 16, 20, generator=g) * 50
+    m = torch.rand(3, 16, 20, generator=g) > 0.3
+    want_abs = torch.stack([(e[i][m[i]] - t[i][m[i]]).abs().mean() for i in range(3)]).mean()
+    want_thr = torch.stack([((e[i][m[i]] - t[i][m[i]]).abs() > 8).float().mean() for i in range(3)]).mean()
+    assert abs(metrics.abs_depth_error(e, t, m).item() - want_abs.item()) < 1e-5
+    assert abs(metrics.thres_error(e, t, m, 8).item() - want_thr.item()) < 1e-6
+    out = metrics.scalar_outputs(e, t, m.float(), loss=torch.tensor(1.0))
+    assert sorted(out) == ["abs_depth_error", "loss", "thres2mm_error", "thres4mm_error", "thres8mm_error"]
+    empty = torch.zeros(1, 4, 4, dtype=torch.bool)
+    assert torch.isnan(metrics.abs_depth_error(e[:1, :4, :4], t[:1, :4, :4], empty))
+    import pytest
+    with pytest.raises(AssertionError):
+        metrics.thres_error(e, t, m, torch.tensor(2.0))
