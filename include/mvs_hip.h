@@ -51,6 +51,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: what is declared between this push and its pop is the exported C ABI, nothing else */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define MVS_OK 0
 #define MVS_EINVAL (-1)      /* bad argument (null pointer, non-positive size, unsupported shape) */
@@ -688,6 +692,9 @@ int mvs_interleave2x2_f32(const float *classes, int N, int H, int W, int C, floa
  * call on the host, stream-ordered.) */
 int mvs_rot_trans_f32(const float *proj_matrices, int B, int V, float *rot_trans, void *stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: what is declared between this push and its pop is the exported C ABI, nothing else */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 /* conv0 on a volume that ARRIVES as fp16 pairs (round 3: built, bit-identical to mvs_conv3d_c8_f16x3_f32, worth 0.06 ms, not wired:
  * DESIGN.md section 6; mvs_amd/csrc/conv_f16x3_pairs.hip). */
@@ -28,6 +32,9 @@ int mvs_conv3d_c8h_f16x3_f32(const void *in_pairs, const void *in_absmax, const 
  * build also takes npair = 5 there and MVS_CONV0_Y8 = 1 | 2 selects the eight-row kernels that keep the staging buffer,
  * mvs_amd/csrc/conv_f16x3_y8.hip) */
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -26,7 +26,9 @@ HEADERS = (os.path.join(CSRC, "mvs_common.h"), os.path.join(CSRC, "sweep_common.
 # -fno-slp-vectorize: v_pk_fma_f32 retires two results in 5-7 cycles (scripts/micro/pk_fma.hip), no
 # faster than two v_fma_f32, and the vectoriser pays for its pairs with register moves (85 per tap
 # iteration of the prob kernel): prob 0.36 -> 0.33 ms, conv9 0.145 -> 0.134 ms without it.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+# -fvisibility=hidden: only what include/mvs_hip.h (and, tuning build, mvs_hip_tuning.h) declares leaves the library (the
+# mvs:: launchers leaked as 64 extra text symbols)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off",
          "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 

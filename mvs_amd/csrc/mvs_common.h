@@ -90,7 +90,7 @@ __device__ __forceinline__ void sweep_coord(const float *__restrict__ r, float r
 // ---- the same coordinates, bit for bit, with cheaper divisions (round 6: the persistent sweep's FAST mode) -----------------
 // IEEE-correct a / b from a reciprocal of b refined by one Newton step: the quotient and two residual corrections -- the
 // compiler's own fp32 division sequence without its range scaling (v_div_scale / v_div_fixup), so exact for operands whose
-// quotient and residuals stay far from overflow and the subnormals: sweep_coord_safe() below decides, per wave.
+// quotient and residuals neither overflow nor underflow; sweep_coord_safe() below has what happens otherwise.
 __device__ __forceinline__ float refined_rcp(float b) {
     const float y = __builtin_amdgcn_rcpf(b);
     return __fmaf_rn(__fmaf_rn(-b, y, 1.0f), y, y);
@@ -100,13 +100,18 @@ __device__ __forceinline__ float div_with_rcp(float a, float b, float y) {
     q = __fmaf_rn(__fmaf_rn(-b, q, a), y, q);
     return __fmaf_rn(__fmaf_rn(-b, q, a), y, q);
 }
-__device__ __forceinline__ bool sweep_coord_safe(float X, float Y, float Z) {
-    const float ax = fabsf(X), ay = fabsf(Y), az = fabsf(Z);
-    return (az >= 1e-10f) & (az <= 1e10f) & ((ax >= 1e-10f) | (ax == 0.0f)) & (ax <= 1e10f) & ((ay >= 1e-10f) | (ay == 0.0f)) & (ay <= 1e10f);
+// When is that sequence's result the compiler's?  Whenever no intermediate over- or underflows -- and when one does, the FINAL
+// sampling coordinate still agrees in everything the kernels use: a quotient that overflows is Inf for the compiler and Inf or NaN
+// here, both "not finite" for the tap logic (NaN weights, as the reference's 0 * NaN); one in the subnormals vanishes in the
+// `- 1.0f` that follows it.  The one case that would differ is a SUBNORMAL or zero divisor Z (a point on the camera plane to within
+// 1e-38): v_rcp flushes it to Inf where the true quotient may be a huge finite number (taps outside the image: zero, not NaN).
+// So: safe = Z is a normal number (one v_cmp_class); a wave with any other Z takes the compiler's divisions.
+__device__ __forceinline__ bool sweep_coord_safe(float Z) {
+    return __builtin_amdgcn_class(Z, 0x108);      // negative normal | positive normal
 }
 // sweep_coord with X/Z and Y/Z sharing one refined reciprocal and the divisions by (W-1)/2, (H-1)/2 through their refined
 // reciprocals rhw / rhh (wave-uniform): 23 vector instructions where four compiler divisions take 44.  The caller has checked
-// sweep_coord_safe(X, Y, Z) for the whole wave (else: sweep_coord).
+// sweep_coord_safe(Z) for the whole wave (else: sweep_coord).
 __device__ __forceinline__ void sweep_coord_shared(float X, float Y, float Z, float half_w, float half_h, float rhw, float rhh,
                                                    float unn_w, float unn_h, int align_corners, float &ix, float &iy) {
     const float y = refined_rcp(Z);

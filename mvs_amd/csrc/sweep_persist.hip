@@ -154,7 +154,7 @@ __device__ __forceinline__ void tap_setup(const float *__restrict__ r, int cx, i
         float rx, ry, rz;
         sweep_ray(r, (float)cx, (float)cy, rx, ry, rz);
         const float X = rx * dv + r[3], Y = ry * dv + r[7], Z = rz * dv + r[11];
-        if (__any(!sweep_coord_safe(X, Y, Z))) sweep_coord(r, rx, ry, rz, dv, p.half_w, p.half_h, p.unn_w, p.unn_h, p.align_corners, ix, iy);
+        if (__any(!sweep_coord_safe(Z))) sweep_coord(r, rx, ry, rz, dv, p.half_w, p.half_h, p.unn_w, p.unn_h, p.align_corners, ix, iy);
         else sweep_coord_shared(X, Y, Z, p.half_w, p.half_h, sx, sy, p.unn_w, p.unn_h, p.align_corners, ix, iy);
         fin = (int)(fabsf(ix) <= 3.0e38f) & (int)(fabsf(iy) <= 3.0e38f);   // (bitwise on purpose: no branch)
         const float x0f = floorf(ix), y0f = floorf(iy);
@@ -675,6 +675,12 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
         unsigned pmain = 0, pdup = 0xffffffffu;
         if (pairs) pairs_offsets(a.pg, cx, cy, p.W, pmain, pdup);
         if (!live || (a.flags & kPFlagNoDup)) pdup = 0xffffffffu;
+        // Both pieces of a border column's halo copy leave in ONE store instruction: the border lane stores its hi piece, the lane
+        // beside it in the quad (x ^ 1: never a border lane itself) its lo piece, handed over by DPP.  (Two instructions of four
+        // lanes each cost the sweep 0.05-0.08 ms at configs[1]: profiles/r06_handover_sweep.json.)
+        const unsigned pdup_nb = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)pdup, 0xB1, 0xf, 0xf, false);      // quad_perm [1, 0, 3, 2]
+        const bool carries = pdup == 0xffffffffu && pdup_nb != 0xffffffffu;
+        if (carries) pdup = pdup_nb + (unsigned)a.pg.dup_lo;
         const bool any_dup = pairs && __ballot(pdup != 0xffffffffu) != 0ull;
 
 #pragma unroll 1
@@ -701,7 +707,7 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
             // full HBM write latency into every stage), for every wave, and nobody still reads
             // the other buffer.
             if (stored == NST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
-            else if (stored == 2 * NST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NST) : "memory");
+            else if (stored == NST + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST + 1) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -796,8 +802,8 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
                 for (int c = 0; c < GC; ++c) asm volatile("" : "+v"(var[c]));   // formed here, not inside the `if`
                 if (any_live && !(a.flags & kPFlagNoStore) && pairs) {
                     // hand-over: scale by the power of two of the bound, split into two fp16 pieces (split2.h), one 16-byte store per
-                    // piece -- the same NST = 2 store instructions as the fp32 form; x-tiled layout: the tile's border column once more
-                    // into the neighbouring tile's block (2 more instructions, four lanes each)
+                    // piece -- the same NST = 2 store instructions as the fp32 form; a tile-border column once more into the neighbouring
+                    // tile's halo strip / block (one more instruction, eight lanes)
                     static_assert(GC == 8, "a stage = one 8-channel chunk");
                     f32x4 v0 = {var[0], var[1], var[2], var[3]}, v1 = {var[4], var[5], var[6], var[7]};
                     if (live) {
@@ -813,11 +819,14 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
                     }
                     stored = NST;
                     if (any_dup) {
-                        if (pdup != 0xffffffffu) {
-                            *reinterpret_cast<u32x4 *>(ch + pdup) = hp;
-                            *reinterpret_cast<u32x4 *>(ch + pdup + a.pg.dup_lo) = lp;
+                        u32x4 dd;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lp[i], 0xB1, 0xf, 0xf, false);
+                            dd[i] = carries ? nb : hp[i];
                         }
-                        stored = 2 * NST;
+                        if (pdup != 0xffffffffu) *reinterpret_cast<u32x4 *>(ch + pdup) = dd;
+                        stored = NST + 1;
                     }
                 } else if (any_live && !(a.flags & kPFlagNoStore)) {
                     // exactly NST store instructions per wave (lanes outside the volume masked off)

@@ -12,15 +12,19 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))
 from fullsize_cases import run_cas, run_cvp, run_eval_small, run_mvsnet, run_train_step  # noqa: E402
+from trained_cases import run_trained  # noqa: E402
 
 
 def main():
     res = {}
     which = sys.argv[1:] or ["mvsnet", "mvsnet_fast", "mvsnet_s1", "mvsnet_fast_s1", "eval_small", "eval_small_fast",
-                             "cas", "cas_s1", "cvp", "cvp_s1", "cvp_s2", "train"]
+                             "cas", "cas_s1", "cvp", "cvp_s1", "cvp_s2", "train", "trained_small", "trained_small_exact", "trained_full",
+                             "trained_full_exact"]
     table = {"mvsnet": lambda: run_mvsnet(False), "mvsnet_fast": lambda: run_mvsnet(True),
              "mvsnet_s1": lambda: run_mvsnet(False, 1), "mvsnet_fast_s1": lambda: run_mvsnet(True, 1),
              "eval_small": lambda: run_eval_small(False), "eval_small_fast": lambda: run_eval_small(True),
+             "trained_small": lambda: run_trained("small", True), "trained_small_exact": lambda: run_trained("small", False),
+             "trained_full": lambda: run_trained("full", True), "trained_full_exact": lambda: run_trained("full", False),
              "cas": run_cas, "cvp": run_cvp, "cas_s1": lambda: run_cas(1), "cvp_s1": lambda: run_cvp(1), "cvp_s2": lambda: run_cvp(2)}
     for w in which:
         if w == "train":

@@ -63,3 +63,20 @@ def test_two_graph_step_averages_the_gradient_over_the_ranks():
     assert res["graphs"] == 2 and res["ranks_agree"], res
     assert res["shards_differ"] > 1e-2, res                 # the two ranks did see different data
     assert res["max_rel_err_vs_mean_of_shards"] < 1e-4, res
+
+
+def test_plain_bench_gpus_8_runs_eight_ranks():
+    """ The N the driver's node will use: plain `python bench.py --gpus 8 --no-extras` starts EIGHT ranks (all on
+    this one device here), scrubs the rendezvous environment, picks its port, and rank 0 prints ONE line with n_gpus = 8 whose
+    value is the MAX-over-ranks time turned into an aggregate -- eight times what one rank did."""
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--no-extras", "--steps", "2", "--warmup", "1",
+                        "--height", "128", "--width", "160", "--views", "3", "--ndepth", "16"], cwd=REPO, env=_env(),
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["steps"] == 2
+    assert "REHEARSAL" in line["config"]["sharding"] and "x8" in line["config"]["sharding"]
+    assert abs(line["value"] - 8 * 1e3 / line["ms_per_step"]) <= 1e-3 * line["value"]       # aggregate = ranks x steps / max time
+    assert "train" not in line and line["summary"]["n_gpus"] == 8

@@ -137,6 +137,7 @@ def test_guarded_tail_refuses_a_fallback_that_would_ignore_the_flag(dev):
         ops.costreg_tail_guarded(x, xa, skip, sa, p11, bad)
 
 
+@pytest.mark.poisoned_inputs
 def test_guarded_tail_falls_back_when_the_fused_kernel_declines(dev):
     """A NaN voxel in conv11's input: the fused kernel declines, the unfused layers run behind the flag and the cost carries the
     reference's NaN pattern (ATen float32 on the CPU is the checker, as in tests/test_gpu_range_guard.py)."""
