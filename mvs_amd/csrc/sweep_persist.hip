@@ -137,11 +137,14 @@ __device__ __forceinline__ void static_for(F &&f) {
 // a voxel gets the same taps whichever of them serves it.  Tap weights come pre-masked: 0 for a
 // tap outside the image, NaN for a non-finite coordinate (the reference's 0 * NaN); tx0, ty0 =
 // floor of the sampling coordinate clamped to [-4, size + 4]; has = some tap lies in the image.
-template <bool FAST>
+// SLOW_OK = false (the persistent kernel): a FAST wave whose Z is not a normal number does NOT take the compiler's divisions
+// here -- it reports `unsafe` and is handed to the cold kernel like a wave whose footprint does not fit (which calls this
+// function with SLOW_OK = true): the never-taken branch with its four division sequences stays out of the hot kernel's code.
+template <bool FAST, bool SLOW_OK = true>
 __device__ __forceinline__ void tap_setup(const float *__restrict__ r, int cx, int cy, float dv,
                                           const SweepParams &p, float sx, float ox, float sy,
                                           float oy, float &wnw, float &wne, float &wsw, float &wse,
-                                          int &tx0, int &ty0, bool &has) {
+                                          int &tx0, int &ty0, bool &has, bool *unsafe = nullptr) {
     float ix, iy, nw, ne, sw, se;
     bool x0ok, x1ok, y0ok, y1ok, fin;
     // Branch-free on purpose (round 4): the clamp alone decides tx0 / ty0.  fmaxf drops a NaN (-> -4) and clamps +-Inf to an
@@ -154,8 +157,13 @@ __device__ __forceinline__ void tap_setup(const float *__restrict__ r, int cx, i
         float rx, ry, rz;
         sweep_ray(r, (float)cx, (float)cy, rx, ry, rz);
         const float X = rx * dv + r[3], Y = ry * dv + r[7], Z = rz * dv + r[11];
-        if (__any(!sweep_coord_safe(Z))) sweep_coord(r, rx, ry, rz, dv, p.half_w, p.half_h, p.unn_w, p.unn_h, p.align_corners, ix, iy);
-        else sweep_coord_shared(X, Y, Z, p.half_w, p.half_h, sx, sy, p.unn_w, p.unn_h, p.align_corners, ix, iy);
+        if constexpr (SLOW_OK) {
+            if (__any(!sweep_coord_safe(Z))) sweep_coord(r, rx, ry, rz, dv, p.half_w, p.half_h, p.unn_w, p.unn_h, p.align_corners, ix, iy);
+            else sweep_coord_shared(X, Y, Z, p.half_w, p.half_h, sx, sy, p.unn_w, p.unn_h, p.align_corners, ix, iy);
+        } else {
+            *unsafe = *unsafe | !sweep_coord_safe(Z);
+            sweep_coord_shared(X, Y, Z, p.half_w, p.half_h, sx, sy, p.unn_w, p.unn_h, p.align_corners, ix, iy);
+        }
         fin = (int)(fabsf(ix) <= 3.0e38f) & (int)(fabsf(iy) <= 3.0e38f);   // (bitwise on purpose: no branch)
         const float x0f = floorf(ix), y0f = floorf(iy);
         const float wx = ix - x0f, wy = iy - y0f, ex = 1.0f - wx, ey = 1.0f - wy;
@@ -645,12 +653,13 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
             win = (1u << NV) - 1u;
         } else {
             const float dv = s_depth[cb * p.D + cd];
+            bool unsafe = false;
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 int tx0, ty0;
                 bool has;
-                tap_setup<FAST>(s_cam + (v * p.B + cb) * 12, cx, cy, dv, p, a.rhw, 0.0f, a.rhh, 0.0f,
-                                wnw[v], wne[v], wsw[v], wse[v], tx0, ty0, has);
+                tap_setup<FAST, false>(s_cam + (v * p.B + cb) * 12, cx, cy, dv, p, a.rhw, 0.0f, a.rhh, 0.0f,
+                                       wnw[v], wne[v], wsw[v], wse[v], tx0, ty0, has, &unsafe);
                 const int bx0 = pbx0[v], by0 = pby0[v], bw = pbw[v], bh = pbh[v];
                 const bool inbox = !has | ((tx0 >= bx0) & (tx0 + 1 < bx0 + bw) & (ty0 >= by0) & (ty0 + 1 < by0 + bh));
                 if (__all(inbox)) win |= 1u << v;
@@ -660,6 +669,7 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
                 cbw16[v] = bw * 16;
                 __builtin_amdgcn_sched_barrier(0);   // one view at a time
             }
+            if (__any(unsafe)) win = 0u;             // (FAST: a Z outside the shared-reciprocal division's range -> the cold kernel)
         }
         // a wave that cannot serve this tile from LDS hands its plane to the cold kernel
         const bool hot = (cstaged & win) == (1u << NV) - 1u;

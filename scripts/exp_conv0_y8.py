@@ -102,14 +102,14 @@ def pairs_child():
 
     def to_pairs(x, mx):
         B, D, H, G, W, _ = x.shape
-        out = torch.zeros(lib.mvs_c8p_bytes(B, G * 8, D, H, W, layout) // 2, device=x.device, dtype=torch.int16)
+        out = torch.zeros((lib.mvs_c8p_bytes(B, G * 8, D, H, W, layout) + 1) // 2, device=x.device, dtype=torch.int16)
         _lib.check(lib.mvs_c8_to_c8p_f32(vp(x), vp(mx), B, G * 8, D, H, W, layout, vp(out), st()), "mvs_c8_to_c8p_f32")
         return out
 
     def conv(xp, mx, pk, sc, sh, resid, relu, shape, omx=None):
         B, D, H, G, W, _ = shape
         out = torch.empty(B, D, H, W, 8, device=xp.device, dtype=torch.float32)
-        _lib.check(lib.mvs_conv3d_c8p_f16x3_f32(vp(xp), vp(mx), vp(pk), vp(sc), vp(sh), vp(resid), int(relu), B, G * 8, D, H, W, layout, npair,
+        _lib.check(lib.mvs_conv3d_c8p_f16x3_f32(vp(xp), vp(mx), None, vp(pk), vp(sc), vp(sh), vp(resid), int(relu), B, G * 8, D, H, W, layout, npair,
                                                 vp(out), vp(omx), st()), "mvs_conv3d_c8p_f16x3_f32")
         return out
 
@@ -194,7 +194,7 @@ def main():
                 print(k, out[k], flush=True)
             out["laps_y8=" + y8] = run({"MVS_CONV0_Y8": y8, "MVS_HIP_TUNING": "1", "MVS_CONV_SPLIT_ABL": "128"}, "laps")
             print("laps y8=" + y8, json.dumps(out["laps_y8=" + y8]), flush=True)
-        for layout in ("6", "7"):
+        for layout in ("6", "7", "8"):
             for npair in ("4", "5"):
                 env = {"MVS_HIP_TUNING": "1", "MVS_EXP_LAYOUT": layout, "MVS_EXP_NPAIR": npair}
                 k = f"pairs_layout{layout}_npair{npair}"
