@@ -16,6 +16,18 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+namespace {
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned *__restrict__ p, int n) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = 0u;
+}
+}  // namespace
+int launch_zero_words(void *p, int n, hipStream_t st) {
+    if (!p || n <= 0) return MVS_OK;
+    const int blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(zero_words_kernel, dim3(blocks < 64 ? blocks : 64), dim3(256), 0, st, static_cast<unsigned *>(p), n);
+    return check_launch("launch_zero_words");
+}
+
 const unsigned *&conv_run_flag() {
     static thread_local const unsigned *flag = nullptr;
     return flag;

@@ -504,7 +504,7 @@ extern "C" int mvs_absmax_f32(const float *x, int64_t n, void *absmax, void *str
         return MVS_EINVAL;
     }
     hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(absmax_bits, 0, 4 * kAbsmaxWords, st) != hipSuccess) return bare_error(MVS_ELAUNCH, __func__, __LINE__);
+    if (launch_zero_words(absmax_bits, kAbsmaxWords, st) != MVS_OK) return MVS_ELAUNCH;
     const int64_t blocks = (n / 4 + 255) / 256;
     const int nb = (int)(blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks));
     hipLaunchKernelGGL(absmax_kernel, dim3(nb), dim3(256), 0, st, x, n, static_cast<unsigned *>(absmax_bits));

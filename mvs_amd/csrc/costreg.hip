@@ -114,8 +114,10 @@ static int costreg_impl(const float *in, int in_layout, const mvs_conv_layer *la
     unsigned *const flags = amax + 10 * kAbsmaxWords;
     auto block = [&](int i) { return static_cast<void *>(amax + (size_t)i * kAbsmaxWords); };
     const bool two_piece = f16 && impl != 1;
-    if (two_piece && hipMemsetAsync(amax, 0, (10 * kAbsmaxWords + kFlagWords) * sizeof(unsigned), as_stream(stream)) != hipSuccess)
-        return bare_error(MVS_ELAUNCH, __func__, __LINE__);
+    if (two_piece) {
+        const int rc = launch_zero_words(amax, 10 * kAbsmaxWords + kFlagWords, as_stream(stream));      // (mvs_common.h: not a memset node)
+        if (rc != MVS_OK) return rc;
+    }
     const int b = base;
     struct Step {
         int layer; const float *src; const float *skip; float *dst; int cin, cout, lvl, stride, transposed, relu, layout;

@@ -78,7 +78,7 @@ extern "C" int mvs_cvp_interval_sum_f64(const float *depth, const double *mats, 
         return MVS_EINVAL;
     }
     hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(sum_abs, 0, sizeof(double), st) != hipSuccess) return check_launch("mvs_cvp_interval_sum_f64 memset");
+    if (launch_zero_words(sum_abs, 2, st) != MVS_OK) return MVS_ELAUNCH;
     CvpArgs a{depth, mats, sum_abs, H, W, pixel_interval};
     const int64_t n = (int64_t)H * W;
     const int64_t blocks = (n + 255) / 256;

@@ -35,6 +35,11 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 // kernels of conv3d_mfma.hip hand the word to their kernels, which return at once when it is 0.  mvs_costreg_fwd3_f32 enqueues
 // the unfused conv11 / prob layers that way behind the fused tail kernel (tail_fused.hip), whose range guard sets the word.
 const unsigned *&conv_run_flag();
+// Clears n 32-bit words with a KERNEL.  The library's small clears (absmax blocks, flag words, queue headers, counters) do not use
+// hipMemsetAsync: captured into a HIP graph, the memset node of mvs_costreg_fwd2_f32's 10 KiB of blocks took effect on the first
+// replay only (round 6, ROCm 7.2 -- every two-piece layer of a replayed forward then judged stale blocks and fell back to fp32;
+// tests/test_gpu_handover.py captures the eval forward and replays it on new pixels).
+int launch_zero_words(void *p, int n, hipStream_t st);
 
 // Compute units of the current device (grid size of the persistent kernels); 256 if the
 // runtime cannot tell.  Queried per call: cheap, and correct when a process drives several GPUs.

@@ -1234,7 +1234,7 @@ static int launch_variance_tile_c16(const float *ref_fea, const float *src_feas,
     const bool loop = sel && tile_loop > 0 && !candidate_per_tile;
     const int loop_wgs = (tile_loop == 1 ? 3 : tile_loop) * device_cu_count();
     // (behind the chooser, sel != NULL, the chooser has cleared the word)
-    if (!sel && absmax && hipMemsetAsync(absmax, 0, 4 * kAbsmaxWords, st) != hipSuccess) return check_launch("variance absmax memset");
+    if (!sel && absmax && launch_zero_words(absmax, kAbsmaxWords, st) != MVS_OK) return MVS_ELAUNCH;
     const dim3 g(loop ? (unsigned)(nblk < loop_wgs ? nblk : loop_wgs) : (unsigned)nblk, (unsigned)B);
 #define MVS_LDS_CASE(n)                                                                                      \
     case n: {                                                                                                \
@@ -1336,7 +1336,7 @@ static int variance_fwd_impl(const float *ref_fea, const float *src_feas,
         const int dchunks = (D + kTileD - 1) / kTileD;
         const int64_t nblk = (int64_t)tiles_x * tiles_y * dchunks;
         if (nblk > 0x7fffffffLL) return bare_error(MVS_EINVAL, __func__, __LINE__);
-        if (absmax && hipMemsetAsync(absmax, 0, 4 * kAbsmaxWords, st) != hipSuccess) return check_launch("variance absmax memset");
+        if (absmax && launch_zero_words(absmax, kAbsmaxWords, st) != MVS_OK) return MVS_ELAUNCH;
         const dim3 g((unsigned)nblk, (unsigned)B);
 #define MVS_LDS8_CASE(n)                                                                          \
     case n: {                                                                                     \
@@ -1531,6 +1531,9 @@ extern "C" int mvs_costvol_variance_fwd_ws2_f32(const float *ref_fea, const floa
 
 extern "C" size_t mvs_costvol_variance_handover_bytes(int B, int C, int D, int H, int W) {
     if (B <= 0 || C <= 0 || C % 8 || D <= 0 || H <= 0 || W <= 0) return 0;
+    // 0 = no hand-over for this shape: conv0 on the pieces addresses three planes of a window with 32-bit offsets
+    // (mvs_conv3d_c8p_f16x3_f32), the sweep one plane
+    if (3 * pairs_geom(C, H, W, kPairsLayoutStrips).plane >= 0xffffff00LL) return 0;
     const size_t pairs = (size_t)B * D * pairs_geom(C, H, W, kPairsLayoutStrips).plane, f32 = (size_t)B * D * H * W * C * 4;
     return pairs > f32 ? pairs : f32;
 }
@@ -1540,6 +1543,10 @@ extern "C" int mvs_costvol_variance_fwd_ws3_f32(const float *ref_fea, const floa
                                                 int align_corners, int fea_layout, int flags, const void *fea_absmax,
                                                 const void *reader_veto, void *out_volume, void *workspace, size_t workspace_bytes, void *var_absmax,
                                                 void *hand, void *redo, void *stream) {
+    if (mvs_costvol_variance_handover_bytes(B, C, D, H, W) == 0) {
+        set_error("mvs_costvol_variance_fwd_ws3_f32: no hand-over for this shape (mvs_costvol_variance_handover_bytes = 0)");
+        return MVS_EUNSUPPORTED;
+    }
     if (!fea_absmax || !hand || !redo || !var_absmax || !out_volume) {
         set_error("mvs_costvol_variance_fwd_ws3_f32: needs the feature maps' absmax block, the volume (mvs_costvol_variance_handover_bytes), "
                   "its absmax block, the hand-over block and the redo word");

@@ -966,8 +966,8 @@ int launch_variance_persist(const float *ref16, const float *srcs16, const float
         a.sy = (float)((double)p.H / (double)(p.H - 1)); a.oy = -0.5f;
     }
     // (with autosel the chooser has cleared the header)
-    if (!autosel && hipMemsetAsync(workspace, 0, 4 * kQueueHdr, st) != hipSuccess) return check_launch("variance workspace memset");
-    if (!autosel && absmax && hipMemsetAsync(absmax, 0, 4 * kAbsmaxWords, st) != hipSuccess) return check_launch("variance absmax memset");
+    if (!autosel && launch_zero_words(workspace, kQueueHdr, st) != MVS_OK) return MVS_ELAUNCH;
+    if (!autosel && absmax && launch_zero_words(absmax, kAbsmaxWords, st) != MVS_OK) return MVS_ELAUNCH;
     const int grid = device_cu_count();
     const int NV = p.V - 1;
 #define MVS_PERSIST_PICK(W_, Q_)                                                             \

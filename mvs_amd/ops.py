@@ -589,7 +589,7 @@ def costvol_variance_handover(ref16, srcs16, rts, depth_values, fea_absmax, alig
     lib = _lib.load()
     need = lib.mvs_costvol_variance_workspace_bytes2(0, B, V, C, D, H, W, layout, 0)
     nbytes = lib.mvs_costvol_variance_handover_bytes(B, C, D, H, W)
-    if need == 0 or nbytes == 0 or nbytes // (B * D) >= 0xffffffff:
+    if need == 0 or nbytes == 0:      # (0 bytes: a plane beyond the 32-bit offsets of conv0's copies)
         return None
     ws = _variance_workspace(ref16.device, need)
     buf = torch.empty(nbytes, device=ref16.device, dtype=torch.uint8)

@@ -295,3 +295,42 @@ print("OK")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_eval_forward_captures_into_a_hip_graph_in_the_default_capture_mode(dev):
+    """A user's `torch.cuda.graph(g)` around the eval forward (capture_error_mode='global', torch's default): nothing in the path --
+    the hand-over's blocks, the sweep chooser's asynchronous verdict read-back (an event query during capture), the
+    workspaces -- makes an illegal call while capturing, and a replay returns the eager forward's bits.  `proj_where="device"`:
+    the reference's float32 LAPACK inverse is a host hop, which no graph can hold."""
+    from mvs_amd import synth
+    from mvs_amd.models import MVSNet
+    model = MVSNet(refine=False)
+    model.load_state_dict(synth.random_state_dict(5), strict=False)
+    model = model.to(dev).eval()
+    model.proj_where = "device"
+    V, H, W, D = 3, 256, 320, 192
+    g = torch.Generator(device=dev).manual_seed(4)
+    imgs = torch.rand(1, V, 3, H, W, device=dev, generator=g)
+    proj = torch.from_numpy(synth.proj_matrices(V, H // 4, W // 4)).to(dev)
+    dv = torch.from_numpy(synth.depth_values(D)).to(dev)
+    with torch.no_grad():
+        for _ in range(9):                 # (past the first read-back of the chooser's verdict: one is pending or done)
+            eager = model(imgs, proj, dv)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            model(imgs, proj, dv)          # the side stream's workspaces exist before the capture
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = model(imgs, proj, dv)
+        graph.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(out["depth"], eager["depth"]) and torch.equal(out["photometric_confidence"], eager["photometric_confidence"])
+    imgs.copy_(torch.rand(1, V, 3, H, W, device=dev, generator=g))      # new pixels in the static input: the replay follows them
+    with torch.no_grad():
+        graph.replay()
+        torch.cuda.synchronize()
+        again = model(imgs, proj, dv)
+    assert torch.equal(out["depth"], again["depth"])
