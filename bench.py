@@ -107,7 +107,10 @@ def arithmetic_note():
         body = three
     else:
         body = f"conv0: {'two-piece fp16' if c0 else 'three-piece bf16'}, the other split-operand layers: {'two-piece fp16' if rest else 'three-piece bf16'} ({two}; {three})"
-    return "fp32 data in HBM, fp32 accumulation; convolution products on the 16-bit matrix pipe: " + body
+    vol = ("; the variance volume travels from the sweep to conv0 as those two fp16 pieces (scale from the bound max|f|^2, device-side "
+           "referee: include/mvs_hip.h, mvs_costvol_variance_fwd_ws3_f32)" if ops.handover_enabled() else "")
+    return ("fp32 data in HBM, fp32 accumulation; plane-sweep sampling coordinates = the reference's, bit for bit; convolution products on "
+            "the 16-bit matrix pipe: " + body + vol)
 
 
 # what torch.distributed.run exports into its workers: a child launch must not inherit its parent's rendezvous
