@@ -112,7 +112,7 @@ __device__ __forceinline__ float div_with_rcp(float a, float b, float y) {
 // 1e-38): v_rcp flushes it to Inf where the true quotient may be a huge finite number (taps outside the image: zero, not NaN).
 // So: safe = Z is a normal number (one v_cmp_class); a wave with any other Z takes the compiler's divisions.
 __device__ __forceinline__ bool sweep_coord_safe(float Z) {
-    return __builtin_amdgcn_class(Z, 0x108);      // negative normal | positive normal
+    return __builtin_amdgcn_classf(Z, 0x108);     // negative normal | positive normal (the f32 test: `class` promotes to f64)
 }
 // sweep_coord with X/Z and Y/Z sharing one refined reciprocal and the divisions by (W-1)/2, (H-1)/2 through their refined
 // reciprocals rhw / rhh (wave-uniform): 23 vector instructions where four compiler divisions take 44.  The caller has checked
@@ -123,13 +123,11 @@ __device__ __forceinline__ void sweep_coord_shared(float X, float Y, float Z, fl
     const float px = div_with_rcp(X, Z, y), py = div_with_rcp(Y, Z, y);
     const float gx = div_with_rcp(px, half_w, rhw) - 1.0f;
     const float gy = div_with_rcp(py, half_h, rhh) - 1.0f;
-    if (align_corners) {
-        ix = (gx + 1.0f) * unn_w;
-        iy = (gy + 1.0f) * unn_h;
-    } else {
-        ix = __fmaf_rn(gx + 1.0f, unn_w, -0.5f);
-        iy = __fmaf_rn(gy + 1.0f, unn_h, -0.5f);
-    }
+    // one FMA for both conventions: fma(a, b, +0) is the rounded product a b (align_corners: the reference's plain multiplication;
+    // a product of -0 comes out +0, which floor and the tap weights do not distinguish), fma(a, b, -0.5) the other
+    const float off = align_corners ? 0.0f : -0.5f;
+    ix = __fmaf_rn(gx + 1.0f, unn_w, off);
+    iy = __fmaf_rn(gy + 1.0f, unn_h, off);
 }
 
 // Bilinear taps with zeros padding (ATen grid_sampler_2d bilinear/zeros).

@@ -167,11 +167,16 @@ __device__ __forceinline__ void tap_setup(const float *__restrict__ r, int cx, i
         fin = (int)(fabsf(ix) <= 3.0e38f) & (int)(fabsf(iy) <= 3.0e38f);   // (bitwise on purpose: no branch)
         const float x0f = floorf(ix), y0f = floorf(iy);
         const float wx = ix - x0f, wy = iy - y0f, ex = 1.0f - wx, ey = 1.0f - wy;
-        nw = ey * ex; ne = ey * wx; sw = wy * ex; se = wy * wx;
         tx0 = (int)fminf(fmaxf(x0f, -4.0f), (float)p.W + 4.0f);
         ty0 = (int)fminf(fmaxf(y0f, -4.0f), (float)p.H + 4.0f);
         x0ok = (unsigned)tx0 < (unsigned)p.W; x1ok = (unsigned)(tx0 + 1) < (unsigned)p.W;
         y0ok = (unsigned)ty0 < (unsigned)p.H; y1ok = (unsigned)(ty0 + 1) < (unsigned)p.H;
+        // the four masked weights as products of masked one-dimensional factors (the factors lie in [0, 1], so a masked-out tap's
+        // weight is +0 like the select's, a non-finite coordinate's NaN): four selects and four products where masking the four
+        // products took four ANDs, four compares and four selects more
+        const float dead = fin ? 0.0f : __int_as_float(0x7fc00000);
+        const float mx0 = x0ok ? ex : dead, mx1 = x1ok ? wx : dead, my0 = y0ok ? ey : dead, my1 = y1ok ? wy : dead;
+        wnw = my0 * mx0; wne = my0 * mx1; wsw = my1 * mx0; wse = my1 * mx1;
     } else {
         float rx, ry, rz;
         sweep_ray(r, (float)cx, (float)cy, rx, ry, rz);
@@ -183,9 +188,11 @@ __device__ __forceinline__ void tap_setup(const float *__restrict__ r, int cx, i
         tx0 = (int)fminf(fmaxf(floorf(ix), -4.0f), (float)p.W + 4.0f);
         ty0 = (int)fminf(fmaxf(floorf(iy), -4.0f), (float)p.H + 4.0f);
     }
-    const float dead = fin ? 0.0f : __int_as_float(0x7fc00000);
-    wnw = (x0ok & y0ok) ? nw : dead; wne = (x1ok & y0ok) ? ne : dead;
-    wsw = (x0ok & y1ok) ? sw : dead; wse = (x1ok & y1ok) ? se : dead;
+    if constexpr (!FAST) {
+        const float dead = fin ? 0.0f : __int_as_float(0x7fc00000);
+        wnw = (x0ok & y0ok) ? nw : dead; wne = (x1ok & y0ok) ? ne : dead;
+        wsw = (x0ok & y1ok) ? sw : dead; wse = (x1ok & y1ok) ? se : dead;
+    }
     has = (x0ok | x1ok) & (y0ok | y1ok);
 }
 

@@ -262,8 +262,9 @@ def test_entry_points_reject_what_they_cannot_take(dev):
     assert rc == -1 and b"absmax" in lib.mvs_last_error_string()
 
 
-@pytest.mark.parametrize("geom", [dict(h=40, w=64, D=24, rig=0), dict(h=74, w=100, D=48, rig=1), dict(h=128, w=160, D=192, rig=2)],
-                         ids=["small", "rig1", "rig2_d192"])
+@pytest.mark.parametrize("geom", [dict(h=40, w=64, D=24, rig=0, ac=0), dict(h=74, w=100, D=48, rig=1, ac=0), dict(h=128, w=160, D=192, rig=2, ac=0),
+                                  dict(h=74, w=100, D=48, rig=1, ac=1)],
+                         ids=["small", "rig1", "rig2_d192", "rig1_align_corners"])
 def test_fast_mode_samples_at_the_reference_coordinates(dev, geom):
     """(round 6) The persistent sweep's FAST mode keeps the reference's sampling coordinates bit for bit (module.py:66-84: its four
     divisions through shared / precomputed refined reciprocals); only the variance arithmetic differs (FMA accumulation of the
@@ -284,8 +285,8 @@ f = (torch.randn(2, 1, 8, h, w, 4, generator=g) * 3).to(dev)
 f[0] = 0
 rts = ops.rot_trans_all(torch.from_numpy(synth.proj_matrices(3, h, w, rig=rig)[:, [0, 2]]).to(dev), "device")
 dv = torch.from_numpy(synth.depth_values(D)).to(dev)
-a = ops.costvol_variance_c16(f[0], f[1:], rts, dv, out_c8=True, fast=True)
-b = ops.costvol_variance_c16(f[0], f[1:], rts, dv, out_c8=True, fast=False)
+a = ops.costvol_variance_c16(f[0], f[1:], rts, dv, align_corners=bool(%(ac)d), out_c8=True, fast=True)
+b = ops.costvol_variance_c16(f[0], f[1:], rts, dv, align_corners=bool(%(ac)d), out_c8=True, fast=False)
 assert float(a.abs().max()) > 0 and bool((a == 0).any())        # in-image and out-of-image samples both occur
 assert torch.equal(a, b), float((a - b).abs().max())
 print("OK")
