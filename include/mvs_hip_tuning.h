@@ -32,6 +32,10 @@ int mvs_conv3d_c8h_f16x3_f32(const void *in_pairs, const void *in_absmax, const 
  * build also takes npair = 5 there and MVS_CONV0_Y8 = 1 | 2 selects the eight-row kernels that keep the staging buffer,
  * mvs_amd/csrc/conv_f16x3_y8.hip) */
 
+/* Cycles of wave 0 of every block of the training path's variance backward (mvs_costvol_variance_bwd_f32, C16 form), summed since the
+ * last reset: [0] set-up, [1] clear + staging, [2] bound, [3] accumulate, [4] flush, [5] passes counted (scripts/exp_varbwd_laps.py). */
+int mvs_tuning_varbwd_laps(unsigned long long *out8, int reset);
+
 #if defined(__GNUC__) || defined(__clang__)
 #pragma GCC visibility pop
 #endif

@@ -8,6 +8,9 @@
 //
 // Compiled with -ffp-contract=off: the coordinate arithmetic mirrors the
 // reference op for op (see mvs_common.h) and is bit-exact with it.
+#ifdef MVS_TUNING
+#include "../../include/mvs_hip_tuning.h"
+#endif
 #include "sweep_common.h"
 
 #include <cstdlib>
@@ -717,6 +720,15 @@ __device__ __forceinline__ float wave_max(float x) {
     return x;
 }
 
+#ifdef MVS_TUNING
+// tuning build: cycles of wave 0 per phase, summed over blocks and passes (mvs_tuning_varbwd_laps, scripts/exp_varbwd_laps.py):
+// [0] set-up, [1] clear + staging, [2] bound, [3] accumulate, [4] flush, [5] passes counted
+__device__ unsigned long long g_varbwd_laps[8];
+#define MVS_BWD_LAP(i) do { if (tid == 0) { const long long t_ = __builtin_readcyclecounter(); atomicAdd(&g_varbwd_laps[i], (unsigned long long)(t_ - lap_t)); lap_t = t_; } } while (0)
+#else
+#define MVS_BWD_LAP(i) do { } while (0)
+#endif
+
 template <int NV>
 __global__ __launch_bounds__(256, bwd_blocks_per_cu(NV)) void variance_bwd_dma_kernel(
     const float *__restrict__ gvar, const float *__restrict__ ref16, const float *__restrict__ srcs16,
@@ -734,6 +746,9 @@ __global__ __launch_bounds__(256, bwd_blocks_per_cu(NV)) void variance_bwd_dma_k
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef MVS_TUNING
+    long long lap_t = __builtin_readcyclecounter();
+#endif
     int tx, ty, dc;
     {
         const int nwg = gridDim.x;
@@ -848,6 +863,7 @@ __global__ __launch_bounds__(256, bwd_blocks_per_cu(NV)) void variance_bwd_dma_k
     for (int pass = 0; pass < ngroups * NPASS; ++pass) {
         const int g = pass / NPASS, q0 = (pass % NPASS) * NQ;   // group, first quad of the pass
         __syncthreads();   // previous pass's flush is complete
+        MVS_BWD_LAP(pass == 0 ? 0 : 4);
         for (int i = tid; i < NZ; i += 256)
             reinterpret_cast<uint4 *>(grd)[i] = make_uint4(0u, 0u, 0u, 0u);
         if (tid < 2) bound[tid] = 0u;
@@ -879,6 +895,7 @@ __global__ __launch_bounds__(256, bwd_blocks_per_cu(NV)) void variance_bwd_dma_k
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        MVS_BWD_LAP(1);
 
         // the four taps of view v, channel quad k, as float4
         auto taps = [&](int v, int k, float4 &a, float4 &bq, float4 &c, float4 &e) {
@@ -941,6 +958,7 @@ __global__ __launch_bounds__(256, bwd_blocks_per_cu(NV)) void variance_bwd_dma_k
             if (lane == 0) { atomicMax(bound, gm); atomicMax(bound + 1, fm); }
         }
         __syncthreads();
+        MVS_BWD_LAP(2);
         float scale, inv_scale;
         bool poison;
         {
@@ -1017,6 +1035,7 @@ __global__ __launch_bounds__(256, bwd_blocks_per_cu(NV)) void variance_bwd_dma_k
             }
         }
         __syncthreads();
+        MVS_BWD_LAP(3);
         // ---- flush: every staged texel once, every reference pixel once
         const double inv_scale_d = (double)inv_scale;
         const float qnan = __uint_as_float(0x7fc00000u);
@@ -1045,8 +1064,23 @@ __global__ __launch_bounds__(256, bwd_blocks_per_cu(NV)) void variance_bwd_dma_k
                 unsafeAtomicAdd(gref16 + ((size_t)b * ngroups + g) * grp_floats + ((size_t)qy * p.W + qx) * 16 + q0 * 4 + ch, val);
             }
         }
+#ifdef MVS_TUNING
+        if (tid == 0) atomicAdd(&g_varbwd_laps[5], 1ull);
+#endif
     }
+    MVS_BWD_LAP(4);
 }
+
+#ifdef MVS_TUNING
+extern "C" int mvs_tuning_varbwd_laps(unsigned long long *out8, int reset) {
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_varbwd_laps), 8 * sizeof(unsigned long long)) != hipSuccess) return MVS_ELAUNCH;
+    if (reset) {
+        const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_varbwd_laps), z, sizeof(z)) != hipSuccess) return MVS_ELAUNCH;
+    }
+    return MVS_OK;
+}
+#endif
 
 // Exhaustive check of div_views against IEEE division: every float bit pattern.
 __global__ __launch_bounds__(256) void div_selftest_kernel(float fV, unsigned long long *mismatch) {

@@ -440,6 +440,12 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
     __shared__ float s_depth[kPMaxDepthFloats];  // depth_values [B][D]
 
     const SweepParams &p = a.p;
+    // The arguments are ~70 words; held in scalar registers for the whole kernel they push the allocator 140 registers over its
+    // budget, and every spilled scalar comes back as a v_readlane -- a VECTOR instruction, in a kernel bound by vector issue
+    // (round 6: ~350 of a wave-plane's ~1980 vector instructions were such reloads).  What the planning, scheduling and per-tile code
+    // needs is therefore read from the kernel-argument segment WHERE IT IS USED (`ka->`: volatile scalar loads, scalar-memory pipe).
+    typedef const volatile PersistArgs __attribute__((address_space(4))) *KernArgPtr;
+    const KernArgPtr ka = (KernArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
     if (a.autosel && a.queue[kSelWord] != (unsigned)NW) return;   // the geometry asked for another kernel
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -498,12 +504,14 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
     int pdc, ptx, pty, pb, seg_end;
     struct TileIt { int u, dc, seg_end, tx, ty, b; };
     auto it_open = [&](TileIt &t) {   // unit t.u -> its pixel tile and first chunk
-        const int sg = contiguous ? t.u % a.nseg : t.u / ptiles;
-        int qq = contiguous ? t.u / a.nseg : t.u - sg * ptiles;
-        t.tx = qq % a.tiles_x; qq /= a.tiles_x;
-        t.ty = qq % a.tiles_y; t.b = qq / a.tiles_y;
-        t.dc = sg * a.cps;
-        t.seg_end = min(t.dc + a.cps, a.nchunks);
+        const int k_tx = ka->tiles_x, k_ty = ka->tiles_y, k_nseg = ka->nseg, k_cps = ka->cps, k_nch = ka->nchunks;
+        const int k_ptiles = k_tx * k_ty * ka->p.B;
+        const int sg = contiguous ? t.u % k_nseg : t.u / k_ptiles;
+        int qq = contiguous ? t.u / k_nseg : t.u - sg * k_ptiles;
+        t.tx = qq % k_tx; qq /= k_tx;
+        t.ty = qq % k_ty; t.b = qq / k_ty;
+        t.dc = sg * k_cps;
+        t.seg_end = min(t.dc + k_cps, k_nch);
     };
     auto it_advance = [&](TileIt &t) {   // -> false behind this workgroup's last tile
         if (++t.dc < t.seg_end) return true;
@@ -534,12 +542,14 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
         for (int i = 0; i < wv && ok; ++i) ok = it_advance(t);
         if (!ok) return;
         const int v0 = min(lane >> 3, NV - 1), k = lane & 7;
-        const int xlo = t.tx * kPW, xhi = min(xlo + kPW - 1, p.W - 1);
-        const int ylo = t.ty * kPH, yhi = min(ylo + kPH - 1, p.H - 1);
-        const int dlo = t.dc * NW, dhi = min(dlo + NW - 1, p.D - 1);
-        const float *r = s_cam + (v0 * p.B + t.b) * 12;
+        const int kW = ka->p.W, kH = ka->p.H, kD = ka->p.D, kB = ka->p.B;
+        const float k_sx = ka->sx, k_ox = ka->ox, k_sy = ka->sy, k_oy = ka->oy;
+        const int xlo = t.tx * kPW, xhi = min(xlo + kPW - 1, kW - 1);
+        const int ylo = t.ty * kPH, yhi = min(ylo + kPH - 1, kH - 1);
+        const int dlo = t.dc * NW, dhi = min(dlo + NW - 1, kD - 1);
+        const float *r = s_cam + (v0 * kB + t.b) * 12;
         const float cxk = (float)((k & 1) ? xhi : xlo), cyk = (float)((k & 2) ? yhi : ylo);
-        const float dk = s_depth[t.b * p.D + ((k & 4) ? dhi : dlo)];
+        const float dk = s_depth[t.b * kD + ((k & 4) ? dhi : dlo)];
         // Per depth plane pixel -> source is a homography, so (all Z > 0) the tile's image is
         // the convex hull of its corner images; along depth each coordinate is a Moebius
         // function of d, monotone between the extreme planes.  Approximate arithmetic is
@@ -549,7 +559,7 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
         const float rz = __fmaf_rn(r[8], cxk, __fmaf_rn(r[9], cyk, r[10]));
         const float X = __fmaf_rn(rx, dk, r[3]), Y = __fmaf_rn(ry, dk, r[7]), Z = __fmaf_rn(rz, dk, r[11]);
         const float inv = __builtin_amdgcn_rcpf(Z);
-        const float ix = __fmaf_rn(X * inv, a.sx, a.ox), iy = __fmaf_rn(Y * inv, a.sy, a.oy);
+        const float ix = __fmaf_rn(X * inv, k_sx, k_ox), iy = __fmaf_rn(Y * inv, k_sy, k_oy);
         const bool zok = Z > 1e-6f && fabsf(ix) < 1.0e9f && fabsf(iy) < 1.0e9f;
         const int fxi = zok ? (int)floorf(ix) : 0, fyi = zok ? (int)floorf(iy) : 0;
         int lo_x = fxi - 1, hi_x = fxi + 2, lo_y = fyi - 1, hi_y = fyi + 2;
@@ -562,7 +572,7 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
         }
         // one texel beyond the image on every side stays in the box, so a tap pair that
         // straddles the border is addressed like any other
-        int x0 = max(lo_x, -1), x1 = min(hi_x, p.W), y0 = max(lo_y, -1), y1 = min(hi_y, p.H);
+        int x0 = max(lo_x, -1), x1 = min(hi_x, kW), y0 = max(lo_y, -1), y1 = min(hi_y, kH);
         if (x1 <= x0 || y1 <= y0) { x0 = 0; y0 = 0; x1 = 1; y1 = 1; }   // nothing of this view in sight
         const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
         const int staged = (!bad && bw * bh <= cap) ? 1 : 0;
@@ -572,6 +582,7 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
     // the planned tile's entry -> the box scalars, the staged-view mask and this wave's per-lane source offsets
     auto load_plan = [&]() {
         pstaged = 0;
+        const int kW = ka->p.W, kH = ka->p.H;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int4 e = *reinterpret_cast<const int4 *>(&s_plan[tcount & (2 * NW - 1)][v][0]);
@@ -585,32 +596,34 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
                 const int t = (mj + i * WQ) * 64 + lane;
                 const int tyy = (int)(((float)t + 0.5f) * rb);      // t / bw (t < 2^10: exact)
                 const int txx = t - __mul24(tyy, bw);
-                const int sxx = min(max(x0 + txx, 0), p.W - 1), syy = min(max(y0 + tyy, 0), p.H - 1);
-                soff[v][i] = (unsigned)(__mul24(syy, p.W) + sxx) * tstride;
+                const int sxx = min(max(x0 + txx, 0), kW - 1), syy = min(max(y0 + tyy, 0), kH - 1);
+                soff[v][i] = (unsigned)(__mul24(syy, kW) + sxx) * tstride;
             }
         }
-        roff = (unsigned)(__mul24(min(pty * kPH + ly, p.H - 1), p.W) + min(ptx * kPW + lx, p.W - 1)) * tstride;
+        roff = (unsigned)(__mul24(min(pty * kPH + ly, kH - 1), kW) + min(ptx * kPW + lx, kW - 1)) * tstride;
     };
 
     // Stage st of the planned tile = channel quads [st * NQ, st * NQ + NQ); this wave copies quad
     // st * NQ + kq.  ONE buffer descriptor per tensor for the whole kernel; view, batch item and
     // quad travel in the 32-bit scalar offset of the instruction, so a copy costs a handful of
     // scalar instructions (the CU has one scalar unit for its 16 waves).
-    const unsigned map_bytes = (unsigned)plane * (unsigned)p.C * 4u;
-    const mvs_srd_t srd_src = make_srd(a.srcs16, map_bytes * (unsigned)(NV * p.B));
-    const mvs_srd_t srd_ref = make_srd(a.ref16, map_bytes * (unsigned)p.B);
     auto issue_dma = [&](int st, unsigned buf_off) {
         if (a.flags & kPFlagNoDma) return;
+        const int kB = ka->p.B, k_c4 = ka->fea_c4;
+        const unsigned k_plane = (unsigned)(ka->p.H * ka->p.W);
+        const unsigned map_bytes = k_plane * (unsigned)ka->p.C * 4u;
+        const mvs_srd_t srd_src = make_srd(ka->srcs16, map_bytes * (unsigned)(NV * kB));
+        const mvs_srd_t srd_ref = make_srd(ka->ref16, map_bytes * (unsigned)kB);
         const int q = st * NQ + kq;
-        const unsigned qoff = a.fea_c4 == 1 ? (unsigned)q * (unsigned)plane * 16u
-                            : a.fea_c4 == 2 ? (unsigned)q * 16u
-                                            : (unsigned)(q >> 2) * (unsigned)plane * 64u + (unsigned)(q & 3) * 16u;
+        const unsigned qoff = k_c4 == 1 ? (unsigned)q * k_plane * 16u
+                            : k_c4 == 2 ? (unsigned)q * 16u
+                                        : (unsigned)(q >> 2) * k_plane * 64u + (unsigned)(q & 3) * 16u;
         const unsigned boff = (unsigned)pb * map_bytes + qoff;
         const unsigned ldst = lds_base + buf_off + (unsigned)kq * cap * 16u;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             if (!((pstaged >> v) & 1u)) continue;
-            const unsigned so = (unsigned)(v * p.B) * map_bytes + boff;
+            const unsigned so = (unsigned)(v * kB) * map_bytes + boff;
             const int n = pbw[v] * pbh[v];
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
@@ -637,14 +650,19 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
 
 #pragma unroll 1
     for (;;) {
-        const int T = ((pb * a.tiles_y + pty) * a.tiles_x + ptx) * a.nchunks + pdc;   // tile id (cold-path records)
+        const int T = ((pb * ka->tiles_y + pty) * ka->tiles_x + ptx) * ka->nchunks + pdc;   // tile id (cold-path records)
         // ---- adopt the planned tile; per-voxel homography + tap set of every source view
+        SweepParams pl;     // the parameters, read here for this tile's set-up (see `ka` above)
+        pl.B = ka->p.B; pl.C = ka->p.C; pl.D = ka->p.D; pl.H = ka->p.H; pl.W = ka->p.W; pl.V = NV + 1;
+        pl.depth_mode = 0; pl.align_corners = ka->p.align_corners; pl.alias_quirk = 0;
+        pl.half_w = ka->p.half_w; pl.half_h = ka->p.half_h; pl.unn_w = ka->p.unn_w; pl.unn_h = ka->p.unn_h; pl.fV = (float)(NV + 1);
+        const float k_rhw = ka->rhw, k_rhh = ka->rhh;
         const int cb = pb;
         const int px = ptx * kPW + lx, py = pty * kPH + ly, d = pdc * NW + wv;
-        const bool live = px < p.W && py < p.H && d < p.D;
-        const bool wave_live = d < p.D;
-        const int cx = min(px, p.W - 1), cy = min(py, p.H - 1), cd = min(d, p.D - 1);
-        const int pix = cy * p.W + cx;
+        const bool live = px < pl.W && py < pl.H && d < pl.D;
+        const bool wave_live = d < pl.D;
+        const int cx = min(px, pl.W - 1), cy = min(py, pl.H - 1), cd = min(d, pl.D - 1);
+        const int pix = cy * pl.W + cx;
         const unsigned cstaged = pstaged;
         int cbw16[NV];
         float wnw[NV], wne[NV], wsw[NV], wse[NV];
@@ -659,13 +677,13 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
             }
             win = (1u << NV) - 1u;
         } else {
-            const float dv = s_depth[cb * p.D + cd];
+            const float dv = s_depth[cb * pl.D + cd];
             bool unsafe = false;
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 int tx0, ty0;
                 bool has;
-                tap_setup<FAST, false>(s_cam + (v * p.B + cb) * 12, cx, cy, dv, p, a.rhw, 0.0f, a.rhh, 0.0f,
+                tap_setup<FAST, false>(s_cam + (v * pl.B + cb) * 12, cx, cy, dv, pl, k_rhw, 0.0f, k_rhh, 0.0f,
                                        wnw[v], wne[v], wsw[v], wse[v], tx0, ty0, has, &unsafe);
                 const int bx0 = pbx0[v], by0 = pby0[v], bw = pbw[v], bh = pbh[v];
                 const bool inbox = !has | ((tx0 >= bx0) & (tx0 + 1 < bx0 + bw) & (ty0 >= by0) & (ty0 + 1 < by0 + bh));
@@ -687,17 +705,23 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
         }
         const bool has_next = pdc + 1 < seg_end || u + u_step < u_end;
         const bool any_live = __ballot(live) != 0ull;
-        float *const pl = a.out + ((size_t)cb * p.D + cd) * ((size_t)plane * p.C);   // wave-uniform plane base
-        unsigned char *const plp = reinterpret_cast<unsigned char *>(a.out) + ((size_t)cb * p.D + cd) * a.pg.plane;   // ... of a pairs volume
+        float *const k_out = ka->out;
+        float *const plf = k_out + ((size_t)cb * pl.D + cd) * ((size_t)(pl.H * pl.W) * pl.C);   // wave-uniform plane base
+        unsigned char *const plp = reinterpret_cast<unsigned char *>(k_out) + ((size_t)cb * pl.D + cd) * ka->pg.plane;   // ... of a pairs volume
         unsigned pmain = 0, pdup = 0xffffffffu;
-        if (pairs) pairs_offsets(a.pg, cx, cy, p.W, pmain, pdup);
+        if (pairs) {
+            PairsGeom pgl;
+            pgl.plane = 0; pgl.chunk = 0; pgl.xtile = ka->pg.xtile; pgl.region = ka->pg.region; pgl.halo = ka->pg.halo; pgl.halo_part = 0;
+            pgl.dup_lo = 0; pgl.rowpitch = ka->pg.rowpitch; pgl.strip = ka->pg.strip; pgl.tiled = ka->pg.tiled; pgl.strips = ka->pg.strips;
+            pairs_offsets(pgl, cx, cy, pl.W, pmain, pdup);
+        }
         if (!live || (a.flags & kPFlagNoDup)) pdup = 0xffffffffu;
         // Both pieces of a border column's halo copy leave in ONE store instruction: the border lane stores its hi piece, the lane
         // beside it in the quad (x ^ 1: never a border lane itself) its lo piece, handed over by DPP.  (Two instructions of four
         // lanes each cost the sweep 0.05-0.08 ms at configs[1]: profiles/r06_handover_sweep.json.)
         const unsigned pdup_nb = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)pdup, 0xB1, 0xf, 0xf, false);      // quad_perm [1, 0, 3, 2]
         const bool carries = pdup == 0xffffffffu && pdup_nb != 0xffffffffu;
-        if (carries) pdup = pdup_nb + (unsigned)a.pg.dup_lo;
+        if (carries) pdup = pdup_nb + (unsigned)ka->pg.dup_lo;
         const bool any_dup = pairs && __ballot(pdup != 0xffffffffu) != 0ull;
 
 #pragma unroll 1
@@ -829,10 +853,10 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
                     }
                     u32x4 hp, lp;
                     split2_block(v0, v1, ps, hp, lp);
-                    unsigned char *const ch = plp + (size_t)st * a.pg.chunk;
+                    unsigned char *const ch = plp + (size_t)st * ka->pg.chunk;
                     if (live) {
                         *reinterpret_cast<u32x4 *>(ch + pmain) = hp;
-                        *reinterpret_cast<u32x4 *>(ch + pmain + 2 * a.pg.region) = lp;
+                        *reinterpret_cast<u32x4 *>(ch + pmain + 2 * ka->pg.region) = lp;
                     }
                     stored = NST;
                     if (any_dup) {
@@ -847,10 +871,11 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
                     }
                 } else if (any_live && !(a.flags & kPFlagNoStore)) {
                     // exactly NST store instructions per wave (lanes outside the volume masked off)
-                    float *o = a.out_c8
-                        ? pl + ((unsigned)(cy * (p.C >> 3) + st * (NQ / 2)) * (unsigned)p.W + (unsigned)cx) * 8u   // [B,D,H,C/8,W,8]
-                        : pl + (unsigned)pix * (unsigned)p.C + (unsigned)(st * GC);
-                    const unsigned step = a.out_c8 ? (unsigned)p.W * 8u : 8u;   // floats between 8-channel blocks
+                    const int k_c8 = ka->out_c8, kC = ka->p.C, kW = ka->p.W;
+                    float *o = k_c8
+                        ? plf + ((unsigned)(cy * (kC >> 3) + st * (NQ / 2)) * (unsigned)kW + (unsigned)cx) * 8u   // [B,D,H,C/8,W,8]
+                        : plf + (unsigned)pix * (unsigned)kC + (unsigned)(st * GC);
+                    const unsigned step = k_c8 ? (unsigned)kW * 8u : 8u;   // floats between 8-channel blocks
                     if (live) {
 #pragma unroll
                         for (int h = 0; h < NQ / 2; ++h) {
