@@ -1030,7 +1030,9 @@ int launch_variance_redo_all(const float *ref16, const float *srcs16, const floa
         a.sx = (float)((double)p.W / (double)(p.W - 1)); a.ox = -0.5f;
         a.sy = (float)((double)p.H / (double)(p.H - 1)); a.oy = -0.5f;
     }
-    const int grid = 8 * device_cu_count();
+    // one workgroup per CU: the launch is in every forward and normally only DECIDES (every workgroup reads the two blocks and
+    // returns: 2048 of them took ~19 us, 256 take a third of that); when it does have to recompute the volume its loops stride the grid
+    const int grid = device_cu_count();
 #define MVS_REDO_CASE(n)                                                                                                      \
     case n:                                                                                                                   \
         if (fast) hipLaunchKernelGGL((variance_fwd_cold_kernel<n, true>), dim3(grid), dim3(256), 0, st, a, nw);               \
