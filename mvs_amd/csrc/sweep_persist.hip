@@ -41,6 +41,8 @@
 // EXACT, 1.21-1.25 ms FAST against 1.85 ms for the per-tile kernel.  SQ counters (profiles/):
 // 1614 VALU instructions per wave-tile-plane FAST (2216 EXACT; per-tile kernel 2103), LDS
 // array busy 46 % of the kernel, 17 % of its cycles conflicted (per-tile kernel: 54 %).
+// Round 6 (reference coordinates in FAST mode, fp16 pieces + halo strips, arguments read from the kernel-argument segment): 1.42 ms,
+// 1658 VALU / 677 scalar / 66 scalar-memory instructions per wave-plane (profiles/r06_sq_counters_sweep_handover.json).
 #include "sweep_common.h"
 #include "split2.h"
 #include "conv_guard.h"

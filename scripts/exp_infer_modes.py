@@ -53,4 +53,14 @@ def two_g(i):
     with torch.cuda.stream(streams[i % 2]): graphs[i % 2].replay()
 out["graph_two_streams"] = timed(two_g)
 out["eager_one_stream_again"] = timed(lambda i: step())
+# bench.py's timed region: the same loop with HIP events around the dominant stage of every step
+from mvs_amd import ops
+for rep in range(2):
+    live = ops.StageTimer(only={"costvol_variance"})
+    ops.set_timer(live)
+    out["eager_one_stream_bench_events_%d" % rep] = timed(lambda i: step())
+    torch.cuda.synchronize()
+    out["eager_one_stream_bench_events_%d" % rep]["costvol_variance_ms"] = round(live.summary_ms()["costvol_variance"][1], 4)
+    ops.set_timer(None)
+    out["eager_one_stream_no_events_%d" % rep] = timed(lambda i: step())
 print(json.dumps(out, indent=1))
