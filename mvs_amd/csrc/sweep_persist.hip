@@ -453,7 +453,6 @@ __global__ __launch_bounds__(NW * 64) void variance_fwd_persist_kernel(PersistAr
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kq = wv % NQ, mj = wv / NQ;
     const unsigned lds_base = (unsigned)(uintptr_t)lds_raw;
-    const int plane = p.H * p.W;
     const int nstage = p.C / GC;                 // stages per tile
     const unsigned tstride = a.fea_c4 == 1 ? 16u : a.fea_c4 == 2 ? (unsigned)p.C * 4u : 64u;   // bytes between neighbouring texels of one quad
 
