@@ -11,19 +11,19 @@ import collections, os, re, subprocess, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mvs_amd import build as B
 
-def main():
-    name, pat = sys.argv[1], sys.argv[2]
+def analyze(name, pat, rev=None):
+    """-> ({kernel: Counter of instruction classes}, {kernel: resource metadata}) for the kernels of mvs_amd/csrc/<name>.hip whose
+    mangled name contains `pat`; rev: the file as of that git revision."""
     src = os.path.join(B.CSRC, name + ".hip")
-    if "--git" in sys.argv:
-        rev = sys.argv[sys.argv.index("--git") + 1]
+    if rev:
         txt = subprocess.check_output(["git", "show", "%s:mvs_amd/csrc/%s.hip" % (rev, name)], cwd=os.path.dirname(B.HERE))
         src = os.path.join(B.CSRC, "_isa_tmp_%s.hip" % name)
         open(src, "wb").write(txt)
     out = tempfile.mktemp(suffix=".s")
     try:
-        subprocess.check_call([B.hipcc()] + B.FLAGS + ["--cuda-device-only", "-S", src, "-o", out])
+        subprocess.check_call([B.hipcc()] + B.FLAGS + ["--cuda-device-only", "-S", src, "-o", out], stderr=subprocess.DEVNULL)
     finally:
-        if "--git" in sys.argv:
+        if rev:
             os.remove(src)
     cur, stats, meta = None, collections.OrderedDict(), {}
     for line in open(out):
@@ -66,6 +66,13 @@ def main():
             if op.startswith("s_waitcnt"): c["waitcnt"] += 1
             if op.startswith("s_barrier"): c["barrier"] += 1
     os.remove(out)
+    meta.pop("_k", None)
+    return stats, meta
+
+
+def main():
+    rev = sys.argv[sys.argv.index("--git") + 1] if "--git" in sys.argv else None
+    stats, meta = analyze(sys.argv[1], sys.argv[2], rev)
     for k, c in stats.items():
         print(k)
         print("   ", dict(c))
