@@ -349,8 +349,11 @@ __global__ __launch_bounds__(256) void variance_fwd_cold_kernel(PersistArgs a, i
 // Rule, from the times of the three kernels over interval scales x1 ... x4, 192 / 96 / 48 planes and two camera rigs
 // (scripts/exp_sweep_select.py, profiles/r03_sweep_select.json): 16-plane tiles while the sampled boxes average at most
 // 0.31 of a view's LDS share (160 of 512 texels; beyond that the copies grow faster than the blends they feed and the
-// near chunks start to go cold), else 8-plane tiles up to 0.52 (266 texels), else the per-tile kernel of sweep.hip.  The
+// near chunks start to go cold), else 8-plane tiles up to 0.36 (184 texels), else the per-tile kernel of sweep.hip.  The
 // MEAN decides: the largest box sits at the nearest planes of the image corners and says little about the volume.
+// (Round 6: 0.52 -> 0.36.  With the reference's coordinate arithmetic in FAST mode and the cold kernel's share of an 8-plane
+// sweep the per-tile kernel now wins wherever the 8-plane boxes average more than ~0.37 of the share -- all four such cases
+// of the sweep above, by 5-17 %, CasMVSNet's first stage among them: profiles/r06_sweep_select.json.)
 __global__ __launch_bounds__(1024) void variance_choose_kernel(PersistArgs a, int NV, int cap, int allow_tile, unsigned *hdr) {
     __shared__ int s_max[2], s_sum[2], s_cnt[2];
     const SweepParams &p = a.p;
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(1024) void variance_choose_kernel(PersistArgs a, in
         const float m16 = (float)s_sum[0] / (float)max(s_cnt[0], 1), m8 = (float)s_sum[1] / (float)max(s_cnt[1], 1);
         unsigned choice;
         if (m16 <= 0.31f * (float)cap) choice = 16;
-        else if (m8 <= 0.52f * (float)cap || !allow_tile) choice = 8;
+        else if (m8 <= 0.36f * (float)cap || !allow_tile) choice = 8;
         else choice = 0;
         hdr[kSelWord] = choice;
         s_choice = choice;
