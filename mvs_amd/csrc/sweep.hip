@@ -503,12 +503,21 @@ __global__ __launch_bounds__(256, 2) void variance_fwd_dma_kernel(
     bool wave_in[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) wave_in[v] = true;
+    // (round 6) the reference's coordinates through shared / precomputed refined reciprocals -- the compiler's own division
+    // sequence without its range scaling, bit for bit the same quotients (mvs_common.h: sweep_coord_shared; a wave with a Z that is
+    // not a normal number takes the compiler's divisions): 23 vector instructions per view where four divisions take 44, in a
+    // kernel whose tap set-up outweighs its blends at 8 or 16 channels (CasMVSNet's second and third stage)
+    const float rhw = refined_rcp(p.half_w), rhh = refined_rcp(p.half_h);
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const float *r = rt + ((int64_t)v * p.B + b) * 12;
         float rx, ry, rz, ix, iy;
         sweep_ray(r, (float)cx, (float)cy, rx, ry, rz);
-        sweep_coord(r, rx, ry, rz, dv, p.half_w, p.half_h, p.unn_w, p.unn_h, p.align_corners, ix, iy);
+        {
+            const float X = rx * dv + r[3], Y = ry * dv + r[7], Z = rz * dv + r[11];
+            if (__any(!sweep_coord_safe(Z))) sweep_coord(r, rx, ry, rz, dv, p.half_w, p.half_h, p.unn_w, p.unn_h, p.align_corners, ix, iy);
+            else sweep_coord_shared(X, Y, Z, p.half_w, p.half_h, rhw, rhh, p.unn_w, p.unn_h, p.align_corners, ix, iy);
+        }
         Taps t = make_taps(ix, iy, p.H, p.W);
         const bool fin = (fabsf(ix) <= 3.0e38f) && (fabsf(iy) <= 3.0e38f);
         const float dead = fin ? 0.0f : __int_as_float(0x7fc00000);
