@@ -981,11 +981,13 @@ int launch_variance_persist(const float *ref16, const float *srcs16, const float
     a.tiles_y = (p.H + kPH - 1) / kPH;
     a.nchunks = (p.D + nw - 1) / nw;
     a.total_tiles = (int)persist_tiles(p, nw);
-    {   // segments: enough work units for ~16 per CU (balance), each as long as that allows (a CU that stays
-        // on a pixel tile re-reads its sliding footprints out of L2)
+    {   // segments: enough work units for ~32 per CU (balance), each as long as that allows (a CU that stays
+        // on a pixel tile re-reads its sliding footprints out of L2).  (Round 6: 16 -> 32 per CU.  At configs[1] that is 7400 units
+        // of three depth chunks instead of 5550 of four: a CU's share is 28.9 +- 0.1 units instead of 21.7 +- 0.3 and the last
+        // round of units is shorter -- the op's median 1.50-1.53 -> 1.42-1.44 ms on one box, alternating; 48 and 128: no better.)
         const int64_t ptiles = (int64_t)a.tiles_x * a.tiles_y * p.B;
         const int ncu = device_cu_count();
-        int nseg = (int)((16ll * ncu + ptiles - 1) / ptiles);
+        int nseg = (int)((32ll * ncu + ptiles - 1) / ptiles);
         nseg = nseg < 1 ? 1 : (nseg > a.nchunks ? a.nchunks : nseg);
         a.cps = (a.nchunks + nseg - 1) / nseg;
         a.nseg = (a.nchunks + a.cps - 1) / a.cps;
